@@ -1,0 +1,219 @@
+/*
+ * aircompressor_hip.h -- C ABI of libaircompressor_hip.so
+ *
+ * The MI355X (gfx950) batched block-codec backend for airlift/aircompressor's
+ * LZ4 / Snappy / Zstd block API.  Every entry point is `extern "C"`, takes plain
+ * pointers and integer sizes, and depends on nothing but libamdhip64.  This is
+ * the boundary a Java `java.lang.foreign` (FFM) binding attaches to, exactly the
+ * way the reference binds liblz4/libsnappy/libzstd:
+ *
+ *   reference binding mechanism ....... M/internal/NativeLoader.java:66-117
+ *   reference LZ4 symbol record ....... M/lz4/Lz4Native.java:30-40
+ *   reference Snappy symbol record .... M/snappy/SnappyNative.java:63-75
+ *   reference Zstd symbol record ...... M/zstd/ZstdNative.java:27-41
+ *   (M/ = src/main/java/io/airlift/compress/v3/ of airlift/aircompressor)
+ *
+ * FFM type map (NativeLoader.java:138-153): int8/int32/int64/pointer only --
+ * every signature below uses only those.
+ *
+ * Return convention: >= 0 is "bytes written" (or a size); < 0 is an ACHIP status
+ * (see achip_status_class / achip_status_detail).  Batched calls never abort a
+ * batch: they fill status[i] / errOffset[i] per block.
+ */
+#ifndef AIRCOMPRESSOR_HIP_H
+#define AIRCOMPRESSOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Status codes                                                              */
+/* ------------------------------------------------------------------------- */
+/* status = -(class + 16 * detail); class in 1..15, detail in 0..(2^26)       */
+#define ACHIP_OK 0
+#define ACHIP_CLASS_MALFORMED 1        /* -> MalformedInputException(offset, reason)  M/MalformedInputException.java:16-36 */
+#define ACHIP_CLASS_OUTPUT_TOO_SMALL 2 /* -> IllegalArgumentException (buffer sizing) e.g. M/lz4/Lz4RawCompressor.java:87-89 */
+#define ACHIP_CLASS_INVALID_ARGUMENT 3 /* -> IllegalArgumentException (bad args)      */
+#define ACHIP_CLASS_DEVICE 4           /* HIP runtime / device failure                */
+
+#define ACHIP_STATUS(cls, detail) (-((cls) + 16 * (detail)))
+
+/* detail ids: one per distinct message of the reference's Java codecs. */
+enum achip_detail {
+    ACHIP_D_GENERIC = 0,
+    /* LZ4 decode -- M/lz4/Lz4RawDecompressor.java */
+    ACHIP_D_LZ4_INPUT_EMPTY = 1,          /* :48-50  "input is empty"                                  */
+    ACHIP_D_LZ4_MALFORMED = 2,            /* :66,76,125,138 "Malformed input"                          */
+    ACHIP_D_LZ4_LAST_LITERAL_OUTSIDE = 3, /* :85   "attempt to write last literal outside of destination buffer" */
+    ACHIP_D_LZ4_INPUT_NOT_CONSUMED = 4,   /* :89   "all input must be consumed"                        */
+    ACHIP_D_LZ4_OFFSET_OUTSIDE = 5,       /* :118  "offset outside destination buffer"                 */
+    ACHIP_D_LZ4_LAST_5_LITERALS = 6,      /* :170  "last 5 bytes must be literals"                     */
+    ACHIP_D_LZ4_EMPTY_OUTPUT = 7,         /* :52-57 the reference *returns -1* here (no exception)     */
+    /* LZ4 encode -- M/lz4/Lz4RawCompressor.java */
+    ACHIP_D_LZ4_MAX_INPUT = 8,            /* :83-85 "Max input length exceeded"                        */
+    ACHIP_D_LZ4_MAX_OUTPUT = 9,           /* :87-89 "Max output length must be larger than N"          */
+    /* Snappy decode -- M/snappy/SnappyRawDecompressor.java */
+    ACHIP_D_SNAPPY_MALFORMED = 16,        /* :92,108,119,128,155,160,164 "Malformed input"             */
+    ACHIP_D_SNAPPY_TRUNCATED = 17,        /* :316-318 "Input is truncated"                             */
+    ACHIP_D_SNAPPY_LEN_HIGH_BIT = 18,     /* :300   "last byte of compressed length int has high bit set" */
+    ACHIP_D_SNAPPY_INVALID_LENGTH = 19,   /* :308   "invalid compressed length"                        */
+    ACHIP_D_SNAPPY_LENGTH_MISMATCH = 20,  /* :61-65 "Recorded length is N bytes but actual length ..." */
+    ACHIP_D_SNAPPY_OUTPUT_TOO_SMALL = 21, /* :49-50 "Uncompressed length N must be less than M"        */
+    /* Snappy encode -- M/snappy/SnappyRawCompressor.java */
+    ACHIP_D_SNAPPY_MAX_OUTPUT = 22,       /* :85-88 "Output buffer must be at least N bytes"           */
+    /* Zstd decode -- M/zstd/ZstdFrameDecompressor.java and friends */
+    ACHIP_D_ZSTD_NOT_ENOUGH_INPUT = 32,   /* "Not enough input bytes"                                  */
+    ACHIP_D_ZSTD_OUTPUT_TOO_SMALL = 33,   /* "Output buffer too small" (verify => MalformedInputException) */
+    ACHIP_D_ZSTD_CORRUPTED = 34,          /* "Input is corrupted"                                      */
+    ACHIP_D_ZSTD_BAD_MAGIC = 35,          /* :949-959 "Invalid magic prefix: <hex>"                    */
+    ACHIP_D_ZSTD_V07_MAGIC = 36,          /* :955   "Data encoded in unsupported ZSTD v0.7 format"     */
+    ACHIP_D_ZSTD_BAD_CHECKSUM = 37,       /* :199-201 "Bad checksum. Expected: .., actual: .."         */
+    ACHIP_D_ZSTD_DICTIONARY = 38,         /* :905   "Custom dictionaries not supported"                */
+    ACHIP_D_ZSTD_INVALID_BLOCK_TYPE = 39, /* :186   "Invalid block type"                               */
+    ACHIP_D_ZSTD_BLOCK_TOO_LARGE = 40,    /* :278   (blockSize > 128 KiB)                              */
+    ACHIP_D_ZSTD_BLOCK_TOO_SMALL = 41,    /* :279   "Compressed block size too small"                  */
+    ACHIP_D_ZSTD_WINDOW_TOO_LARGE = 42,   /* :303   "Window size too large (not yet supported)"        */
+    ACHIP_D_ZSTD_DICT_CORRUPTED = 43,     /* :294   treeless literals without a table                  */
+    ACHIP_D_ZSTD_LITERALS_TOO_LARGE = 44, /* :752,795 "Block exceeds maximum size"                     */
+    ACHIP_D_ZSTD_FSE_TABLE_LOG = 45,      /* FseTableReader.java:46 "FSE table size exceeds maximum allowed size" */
+    ACHIP_D_ZSTD_FSE_SYMBOL = 46,         /* FseTableReader.java:74,127 symbol too large               */
+    ACHIP_D_ZSTD_TABLE_MISSING = 47,      /* :622,645,668 repeat mode without a previous table         */
+    ACHIP_D_ZSTD_VALUE_TOO_LARGE = 48,    /* :616,639,662 "Value exceeds expected maximum value"       */
+    ACHIP_D_ZSTD_BITSTREAM_EMPTY = 49,    /* BitInputStream.java:112 "Bitstream is empty"              */
+    ACHIP_D_ZSTD_BITSTREAM_NO_MARK = 50,  /* BitInputStream.java:115 "Bitstream end mark not present"  */
+    ACHIP_D_ZSTD_BITSTREAM_NOT_CONSUMED = 51, /* Huffman.java:316 "Bit stream is not fully consumed"   */
+    ACHIP_D_ZSTD_SEQUENCES_NOT_CONSUMED = 52, /* :396 "Not all sequences were consumed"                */
+    ACHIP_D_ZSTD_FSE_OUTPUT_SMALL = 53,   /* FiniteStateEntropy.java:114,131 "Output buffer is too small" */
+    /* Zstd encode */
+    ACHIP_D_ZSTD_MAX_OUTPUT = 60,         /* Util.checkArgument "Output buffer too small"              */
+    /* runtime */
+    ACHIP_D_NO_DEVICE = 100,
+    ACHIP_D_HIP_ERROR = 101,
+    ACHIP_D_BAD_ARGUMENT = 102,
+    ACHIP_D_UNSUPPORTED = 103
+};
+
+int32_t achip_status_class(int32_t status);  /* 0 for status >= 0 */
+int32_t achip_status_detail(int32_t status);
+/* English reason string for a detail id, matching the reference's exception text
+ * up to the ": offset=N" suffix that MalformedInputException appends itself. */
+const char* achip_detail_message(int32_t detail);
+
+/* ------------------------------------------------------------------------- */
+/* Library / device                                                          */
+/* ------------------------------------------------------------------------- */
+const char* achip_version(void);
+int32_t achip_device_count(void); /* 0 when no HIP device is usable; isEnabled() keys off this, cf. M/lz4/Lz4Native.java:75-85 */
+const char* achip_last_error(void); /* thread-local text of the last ACHIP_CLASS_DEVICE failure */
+
+/* ------------------------------------------------------------------------- */
+/* Size helpers (host only, no device)                                        */
+/* ------------------------------------------------------------------------- */
+/* replaces Lz4RawCompressor.maxCompressedLength      M/lz4/Lz4RawCompressor.java:64-67 (bound as LZ4_compressBound in M/lz4/Lz4Native.java:31) */
+int32_t achip_lz4_max_compressed_length(int32_t uncompressedSize);
+/* replaces SnappyRawCompressor.maxCompressedLength   M/snappy/SnappyRawCompressor.java:47-70 (snappy_max_compressed_length, M/snappy/SnappyNative.java:68) */
+int32_t achip_snappy_max_compressed_length(int32_t uncompressedSize);
+/* replaces ZstdJavaCompressor.maxCompressedLength    M/zstd/ZstdJavaCompressor.java:31-40 (ZSTD_compressBound, M/zstd/ZstdNative.java:28) */
+int32_t achip_zstd_max_compressed_length(int32_t uncompressedSize);
+/* replaces SnappyRawDecompressor.getUncompressedLength  M/snappy/SnappyRawDecompressor.java:30-33,277-321; negative = status, *errOffset set */
+int64_t achip_snappy_uncompressed_length(const void* src, int64_t srcLen, int64_t* errOffset);
+/* replaces ZstdFrameDecompressor.getDecompressedSize    M/zstd/ZstdFrameDecompressor.java:942-947; -1 = unknown, < -1 = status */
+int64_t achip_zstd_decompressed_size(const void* src, int64_t srcLen, int64_t* errOffset);
+
+/* ------------------------------------------------------------------------- */
+/* Context: one HIP stream + device scratch on one GPU.                       */
+/* Not thread-safe (like one codec instance, M/lz4/Lz4JavaCompressor.java:27-29);*/
+/* distinct contexts may be used concurrently from distinct threads.           */
+/* ------------------------------------------------------------------------- */
+typedef struct achip_ctx achip_ctx;
+
+achip_ctx* achip_ctx_create(int32_t device);      /* NULL on failure; see achip_last_error */
+void achip_ctx_destroy(achip_ctx* ctx);
+int32_t achip_ctx_device(achip_ctx* ctx);
+void* achip_ctx_stream(achip_ctx* ctx);           /* the hipStream_t the batched calls launch on */
+int32_t achip_ctx_synchronize(achip_ctx* ctx);    /* hipStreamSynchronize */
+/* tuning knobs (kernel variant selection); name/value pairs documented in DESIGN.md. returns 0 or status */
+int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value);
+
+/* device / pinned memory helpers; addresses are usable as MemorySegment.ofAddress */
+void* achip_device_alloc(achip_ctx* ctx, int64_t bytes);
+int32_t achip_device_free(achip_ctx* ctx, void* p);
+void* achip_host_alloc_pinned(int64_t bytes);
+int32_t achip_host_free_pinned(void* p);
+int32_t achip_memcpy_h2d(achip_ctx* ctx, void* dst, const void* src, int64_t bytes); /* async on the ctx stream */
+int32_t achip_memcpy_d2h(achip_ctx* ctx, void* dst, const void* src, int64_t bytes); /* async on the ctx stream */
+int32_t achip_memset_d(achip_ctx* ctx, void* dst, int32_t value, int64_t bytes);     /* async on the ctx stream */
+
+/* HIP events on the ctx stream, for timing from a host language */
+void* achip_event_create(void);
+int32_t achip_event_destroy(void* ev);
+int32_t achip_event_record(achip_ctx* ctx, void* ev);
+float achip_event_elapsed_ms(void* evStart, void* evStop); /* synchronizes on evStop; <0 on failure */
+
+/* ------------------------------------------------------------------------- */
+/* Batched, device-resident block API (the hot path).                         */
+/*                                                                           */
+/* Every pointer is a DEVICE-accessible address (device memory, or pinned     */
+/* host memory).  Block i reads srcBase[srcOff[i] .. +srcLen[i]) and writes   */
+/* dstBase[dstOff[i] .. +dstCap[i]); on return (after achip_ctx_synchronize)  */
+/* outLen[i] = bytes written, status[i] = 0 or an ACHIP status,               */
+/* errOffset[i] = the offset the reference's exception would carry.           */
+/* The call itself is asynchronous on the ctx stream; its return value only   */
+/* reports launch failures.  Regions of distinct blocks must not overlap.     */
+/* ------------------------------------------------------------------------- */
+#define ACHIP_BATCH_ARGS                                                            \
+    achip_ctx *ctx, const void *srcBase, const int64_t *srcOff, const int32_t *srcLen, \
+        void *dstBase, const int64_t *dstOff, const int32_t *dstCap, int32_t *outLen, \
+        int32_t *status, int64_t *errOffset, int32_t nBlocks
+
+/* replaces Lz4RawDecompressor.decompress    M/lz4/Lz4RawDecompressor.java:35-198   (a1) */
+int32_t achip_lz4_decompress_batch(ACHIP_BATCH_ARGS);
+/* replaces Lz4RawCompressor.compress        M/lz4/Lz4RawCompressor.java:69-192     (a2) */
+int32_t achip_lz4_compress_batch(ACHIP_BATCH_ARGS);
+/* replaces SnappyRawDecompressor.decompress M/snappy/SnappyRawDecompressor.java:35-220 (a3) */
+int32_t achip_snappy_decompress_batch(ACHIP_BATCH_ARGS);
+/* replaces SnappyRawCompressor.compress     M/snappy/SnappyRawCompressor.java:74-233   (a4) */
+int32_t achip_snappy_compress_batch(ACHIP_BATCH_ARGS);
+/* replaces ZstdFrameDecompressor.decompress M/zstd/ZstdFrameDecompressor.java:135-210  (a5-a10) */
+int32_t achip_zstd_decompress_batch(ACHIP_BATCH_ARGS);
+/* replaces ZstdFrameCompressor.compress(level 3) M/zstd/ZstdFrameCompressor.java:136-150 (a11-a14) */
+int32_t achip_zstd_compress_batch(ACHIP_BATCH_ARGS);
+
+/* ------------------------------------------------------------------------- */
+/* Single-block host-pointer API: what Compressor.compress(MemorySegment,     */
+/* MemorySegment) / Decompressor.decompress(...) bind to (M/Compressor.java:  */
+/* 20-35, M/Decompressor.java:23-30).  src/dst are HOST pointers; the call    */
+/* stages through the context's pinned buffers, runs a 1-block batch and      */
+/* synchronizes.  Argument order follows LZ4_compress_fast /                  */
+/* LZ4_decompress_safe as bound in M/lz4/Lz4Native.java:33,37.                */
+/* ------------------------------------------------------------------------- */
+int32_t achip_lz4_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+int32_t achip_lz4_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+int32_t achip_snappy_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+int32_t achip_snappy_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+int32_t achip_zstd_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+int32_t achip_zstd_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+
+/* Host-pointer batch: nBlocks independent blocks described by HOST arrays of HOST
+ * pointers' offsets relative to srcBase/dstBase (host).  Stages in, launches the
+ * device batch for `codecOp`, stages out, synchronizes.  codecOp: see below. */
+#define ACHIP_OP_LZ4_DECOMPRESS 0
+#define ACHIP_OP_LZ4_COMPRESS 1
+#define ACHIP_OP_SNAPPY_DECOMPRESS 2
+#define ACHIP_OP_SNAPPY_COMPRESS 3
+#define ACHIP_OP_ZSTD_DECOMPRESS 4
+#define ACHIP_OP_ZSTD_COMPRESS 5
+int32_t achip_batch_host(int32_t codecOp, ACHIP_BATCH_ARGS);
+
+/* Balanced contiguous partition of a batch over nParts GPUs: fills
+ * starts[0..nParts] with block indices so that each part's sum of weight[i] is
+ * as equal as a contiguous split allows.  Pure host arithmetic. */
+int32_t achip_partition_blocks(const int64_t* weight, int32_t nBlocks, int32_t nParts, int32_t* starts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIRCOMPRESSOR_HIP_H */

@@ -1,0 +1,57 @@
+/*
+ * oracle.h -- CPU restatement of aircompressor's *Java* block codecs.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is linked, imported or
+ * executed by the product (libaircompressor_hip.so, aircompressor_amd/).  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it,
+ * and only as the checker / the CPU baseline.
+ *
+ * Each function follows one reference routine (M/ = src/main/java/io/airlift/
+ * compress/v3/ of airlift/aircompressor 3.8-SNAPSHOT), cited at its definition.
+ * Pinning: see oracle/README.md (golden vectors of the reference's own tests).
+ *
+ * Result convention: >= 0 bytes written, < 0 an ACHIP status from
+ * include/aircompressor_hip.h (class + 16*detail, negated); *err_off receives
+ * the offset the Java MalformedInputException would carry.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* LZ4 -- M/lz4/Lz4RawCompressor.java, M/lz4/Lz4RawDecompressor.java */
+int64_t orc_lz4_max_compressed_length(int64_t n);
+int64_t orc_lz4_compress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap);
+int64_t orc_lz4_decompress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap, int64_t* err_off);
+
+/* Snappy -- M/snappy/SnappyRawCompressor.java, M/snappy/SnappyRawDecompressor.java */
+int64_t orc_snappy_max_compressed_length(int64_t n);
+int64_t orc_snappy_compress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap);
+int64_t orc_snappy_decompress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap, int64_t* err_off);
+int64_t orc_snappy_uncompressed_length(const uint8_t* in, int64_t in_len, int64_t* err_off);
+
+/* Zstd -- M/zstd/ZstdFrameDecompressor.java (+Huffman, FseTableReader, FiniteStateEntropy, BitInputStream, XxHash64) */
+int64_t orc_zstd_max_compressed_length(int64_t n);
+int64_t orc_zstd_decompress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap, int64_t* err_off);
+int64_t orc_zstd_decompressed_size(const uint8_t* in, int64_t in_len, int64_t* err_off);
+/* Zstd level-3 encoder -- M/zstd/ZstdFrameCompressor.java and friends */
+int64_t orc_zstd_compress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap);
+
+/* XXH64 -- M/zstd/XxHash64.java:182-291 */
+uint64_t orc_xxh64(const uint8_t* in, int64_t len, uint64_t seed);
+
+/* Synthetic data: the reference's test generator -- T/snappy/RandomGenerator.java:25-74 on java.util.Random(301) */
+void orc_random_generator(double compression_ratio, uint8_t* out, int64_t len);
+
+/* batch drivers used by bench.py's cpu_baseline leg (plain loops, one thread) */
+int64_t orc_batch(int32_t op, const uint8_t* src_base, const int64_t* src_off, const int32_t* src_len,
+                  uint8_t* dst_base, const int64_t* dst_off, const int32_t* dst_cap,
+                  int32_t* out_len, int32_t* status, int64_t* err_off, int32_t n_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
