@@ -1,0 +1,26 @@
+"""aircompressor_amd -- MI355X (gfx950) batched block-codec backend for airlift/aircompressor.
+
+Host-side mirror of the reference's `io.airlift.compress.v3` block API over the C ABI of
+libaircompressor_hip.so (include/aircompressor_hip.h).  The product path is HIP only: if
+the shared library (or a GPU) is missing every codec fails loudly -- there is no CPU fallback.
+"""
+from .errors import IllegalArgumentException, MalformedInputException, HipUnavailableError
+from .native import HipNative, load_library
+from .codecs import (
+    Compressor,
+    Decompressor,
+    Lz4HipCompressor,
+    Lz4HipDecompressor,
+    SnappyHipCompressor,
+    SnappyHipDecompressor,
+    ZstdHipCompressor,
+    ZstdHipDecompressor,
+)
+from .batch import HipBatchCodec, OP_LZ4_DECOMPRESS, OP_LZ4_COMPRESS, OP_SNAPPY_DECOMPRESS, OP_SNAPPY_COMPRESS, OP_ZSTD_DECOMPRESS, OP_ZSTD_COMPRESS, partition_blocks
+
+__all__ = [
+    "IllegalArgumentException", "MalformedInputException", "HipUnavailableError", "HipNative", "load_library",
+    "Compressor", "Decompressor", "Lz4HipCompressor", "Lz4HipDecompressor", "SnappyHipCompressor", "SnappyHipDecompressor",
+    "ZstdHipCompressor", "ZstdHipDecompressor", "HipBatchCodec", "partition_blocks",
+    "OP_LZ4_DECOMPRESS", "OP_LZ4_COMPRESS", "OP_SNAPPY_DECOMPRESS", "OP_SNAPPY_COMPRESS", "OP_ZSTD_DECOMPRESS", "OP_ZSTD_COMPRESS",
+]

@@ -1,0 +1,86 @@
+"""Batched, device-resident entry points (the hot path): thin wrapper over achip_*_batch.
+
+Buffers are anything exposing `data_ptr()` (torch tensors on the HIP device) or raw integer
+device addresses; no torch import here -- PyTorch is only the callers' allocator.
+Work is sharded over GPUs one process per GPU by `partition_blocks` (contiguous, balanced
+by bytes): blocks are independent, so there is no collective on the data path.
+"""
+import ctypes
+
+import numpy as np
+
+from . import native
+from .native import HipNative
+
+OP_LZ4_DECOMPRESS, OP_LZ4_COMPRESS, OP_SNAPPY_DECOMPRESS, OP_SNAPPY_COMPRESS, OP_ZSTD_DECOMPRESS, OP_ZSTD_COMPRESS = range(6)
+_FN = {
+    OP_LZ4_DECOMPRESS: "achip_lz4_decompress_batch",
+    OP_LZ4_COMPRESS: "achip_lz4_compress_batch",
+    OP_SNAPPY_DECOMPRESS: "achip_snappy_decompress_batch",
+    OP_SNAPPY_COMPRESS: "achip_snappy_compress_batch",
+    OP_ZSTD_DECOMPRESS: "achip_zstd_decompress_batch",
+    OP_ZSTD_COMPRESS: "achip_zstd_compress_batch",
+}
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return int(x)
+
+
+def partition_blocks(weights, n_parts):
+    """Contiguous split of block indices balanced by `weights` (achip_partition_blocks)."""
+    lib = native.load_library()
+    w = np.ascontiguousarray(np.asarray(weights, dtype=np.int64))
+    starts = np.zeros(n_parts + 1, dtype=np.int32)
+    r = lib.achip_partition_blocks(w.ctypes.data, len(w), n_parts, starts.ctypes.data)
+    if r < 0:
+        native.raise_for_status(r)
+    return starts
+
+
+class HipBatchCodec:
+    def __init__(self, device=0, native_ctx=None):
+        self.native = native_ctx if native_ctx is not None else HipNative(device)
+        self.lib = self.native.lib
+
+    def launch(self, op, src, src_off, src_len, dst, dst_off, dst_cap, out_len, status, err_off, n_blocks):
+        """Asynchronous on the context stream; all arguments device-accessible."""
+        fn = getattr(self.lib, _FN[op])
+        r = fn(self.native.ctx, _ptr(src), _ptr(src_off), _ptr(src_len), _ptr(dst), _ptr(dst_off), _ptr(dst_cap),
+               _ptr(out_len), _ptr(status), _ptr(err_off), int(n_blocks))
+        if r < 0:
+            native.raise_for_status(r)
+
+    def synchronize(self):
+        self.native.synchronize()
+
+    def run_host(self, op, src, src_off, src_len, dst, dst_off, dst_cap):
+        """Host numpy arrays in/out through achip_batch_host (stages through pinned memory)."""
+        n = len(src_off)
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        src_off = np.ascontiguousarray(src_off, dtype=np.int64)
+        src_len = np.ascontiguousarray(src_len, dtype=np.int32)
+        dst_off = np.ascontiguousarray(dst_off, dtype=np.int64)
+        dst_cap = np.ascontiguousarray(dst_cap, dtype=np.int32)
+        out_len = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        err_off = np.zeros(n, dtype=np.int64)
+        r = self.lib.achip_batch_host(op, self.native.ctx, src.ctypes.data, src_off.ctypes.data, src_len.ctypes.data, dst.ctypes.data,
+                                      dst_off.ctypes.data, dst_cap.ctypes.data, out_len.ctypes.data, status.ctypes.data, err_off.ctypes.data, n)
+        if r < 0:
+            native.raise_for_status(r)
+        return out_len, status, err_off
+
+    # timing helpers on the context stream
+    def event(self):
+        return self.lib.achip_event_create()
+
+    def record(self, ev):
+        self.lib.achip_event_record(self.native.ctx, ev)
+
+    def elapsed_ms(self, ev0, ev1):
+        return float(self.lib.achip_event_elapsed_ms(ev0, ev1))

@@ -1,0 +1,178 @@
+"""Python mirror of the reference's block codec interfaces for the HIP backend.
+
+    Compressor   -- M/Compressor.java:18-36
+    Decompressor -- M/Decompressor.java:18-31
+
+`Lz4HipCompressor` etc. are what `java/io/airlift/compress/v3/{lz4,snappy,zstd}/*Hip*.java`
+are in Java: same method names (snake_case), same argument meaning, same exceptions.  The
+byte[] overloads take (buffer, offset, length, ...) exactly like the Java ones; the
+MemorySegment overloads take two buffer-protocol objects (`memoryview` = MemorySegment).
+"""
+import ctypes
+
+import numpy as np
+
+from . import native
+from .errors import IllegalArgumentException
+from .native import HipNative
+
+
+def _verify_range(data, offset, length):
+    # M/lz4/Lz4JavaCompressor.java:78-84
+    if data is None:
+        raise TypeError("data is null")
+    n = len(data)
+    if offset < 0 or length < 0 or offset + length > n:
+        raise IllegalArgumentException("Invalid offset or length (%s, %s) in array of length %s" % (offset, length, n))
+
+
+def _ro_view(buf):
+    a = np.frombuffer(buf, dtype=np.uint8)
+    return a
+
+
+def _rw_view(buf):
+    mv = memoryview(buf)
+    if mv.readonly:
+        raise IllegalArgumentException("MemorySegment is read-only")  # M/lz4/UnsafeUtil.java:53-55
+    return np.frombuffer(mv, dtype=np.uint8)
+
+
+class Compressor:
+    def max_compressed_length(self, uncompressed_size):
+        raise NotImplementedError
+
+    def compress(self, input, input_offset, input_length, output, output_offset, max_output_length):
+        raise NotImplementedError
+
+    def compress_segment(self, input, output):
+        raise NotImplementedError
+
+    def get_retained_size_in_bytes(self, input_length):
+        return 0
+
+
+class Decompressor:
+    def decompress(self, input, input_offset, input_length, output, output_offset, max_output_length):
+        raise NotImplementedError
+
+    def decompress_segment(self, input, output):
+        raise NotImplementedError
+
+
+class _HipCodecBase:
+    _codec = None
+
+    def __init__(self, device=0, native_ctx=None):
+        self._native = native_ctx if native_ctx is not None else HipNative(device)
+        self._lib = self._native.lib
+
+    @staticmethod
+    def is_enabled():
+        return HipNative.is_enabled()
+
+    def _call(self, fn_name, src, dst):
+        fn = getattr(self._lib, fn_name)
+        eo = ctypes.c_int64(0)
+        sp = src.ctypes.data if src.size else None
+        dp = dst.ctypes.data if dst.size else None
+        r = fn(self._native.ctx, sp, dp, int(src.size), int(dst.size), ctypes.byref(eo))
+        return r, eo.value
+
+
+class _HipCompressor(_HipCodecBase, Compressor):
+    def max_compressed_length(self, uncompressed_size):
+        return getattr(self._lib, "achip_%s_max_compressed_length" % self._codec)(uncompressed_size)
+
+    def compress(self, input, input_offset, input_length, output, output_offset, max_output_length):
+        _verify_range(input, input_offset, input_length)
+        _verify_range(output, output_offset, max_output_length)
+        src = _ro_view(input)[input_offset:input_offset + input_length]
+        dst = _rw_view(output)[output_offset:output_offset + max_output_length]
+        return self._compress(src, dst)
+
+    def compress_segment(self, input, output):
+        return self._compress(_ro_view(input), _rw_view(output))
+
+    def _compress(self, src, dst):
+        r, eo = self._call("achip_%s_compress" % self._codec, src, dst)
+        if r < 0:
+            native.raise_for_status(r, eo)
+        return r
+
+
+class _HipDecompressor(_HipCodecBase, Decompressor):
+    def decompress(self, input, input_offset, input_length, output, output_offset, max_output_length):
+        _verify_range(input, input_offset, input_length)
+        _verify_range(output, output_offset, max_output_length)
+        src = _ro_view(input)[input_offset:input_offset + input_length]
+        dst = _rw_view(output)[output_offset:output_offset + max_output_length]
+        return self._decompress(src, dst)
+
+    def decompress_segment(self, input, output):
+        return self._decompress(_ro_view(input), _rw_view(output))
+
+    def _decompress(self, src, dst):
+        r, eo = self._call("achip_%s_decompress" % self._codec, src, dst)
+        if r < 0:
+            native.raise_for_status(r, eo)
+        return r
+
+
+class Lz4HipCompressor(_HipCompressor):
+    """Drop-in for Lz4JavaCompressor (M/lz4/Lz4JavaCompressor.java:29-85)."""
+    _codec = "lz4"
+
+    def get_retained_size_in_bytes(self, input_length):
+        # Lz4RawCompressor.computeTableSize  M/lz4/Lz4RawCompressor.java:304-311
+        target = 0 if input_length <= 1 else (1 << ((input_length - 1).bit_length() - 1)) << 1
+        return max(16, min(4096, target))
+
+
+class Lz4HipDecompressor(_HipDecompressor):
+    """Drop-in for Lz4JavaDecompressor (M/lz4/Lz4JavaDecompressor.java:28-78)."""
+    _codec = "lz4"
+
+    def _decompress(self, src, dst):
+        r, eo = self._call("achip_lz4_decompress", src, dst)
+        if r < 0:
+            if native.status_detail(r) == native.DETAIL_LZ4_EMPTY_OUTPUT:
+                return -1  # the Java method returns -1 here (M/lz4/Lz4RawDecompressor.java:52-57)
+            native.raise_for_status(r, eo)
+        return r
+
+
+class SnappyHipCompressor(_HipCompressor):
+    """Drop-in for SnappyJavaCompressor (M/snappy/SnappyJavaCompressor.java:26-91)."""
+    _codec = "snappy"
+
+
+class SnappyHipDecompressor(_HipDecompressor):
+    """Drop-in for SnappyJavaDecompressor (M/snappy/SnappyJavaDecompressor.java:28-89)."""
+    _codec = "snappy"
+
+    def get_uncompressed_length(self, compressed, compressed_offset):
+        src = _ro_view(compressed)[compressed_offset:]
+        eo = ctypes.c_int64(0)
+        r = self._lib.achip_snappy_uncompressed_length(src.ctypes.data if src.size else None, int(src.size), ctypes.byref(eo))
+        if r < 0:
+            native.raise_for_status(int(r), eo.value)
+        return int(r)
+
+
+class ZstdHipCompressor(_HipCompressor):
+    """Drop-in for ZstdJavaCompressor (always level 3; M/zstd/ZstdJavaCompressor.java:28-90)."""
+    _codec = "zstd"
+
+
+class ZstdHipDecompressor(_HipDecompressor):
+    """Drop-in for ZstdJavaDecompressor (M/zstd/ZstdJavaDecompressor.java:29-90)."""
+    _codec = "zstd"
+
+    def get_decompressed_size(self, input, offset, length):
+        src = _ro_view(input)[offset:offset + length]
+        eo = ctypes.c_int64(0)
+        r = self._lib.achip_zstd_decompressed_size(src.ctypes.data if src.size else None, int(src.size), ctypes.byref(eo))
+        if r < -1:
+            native.raise_for_status(int(r), eo.value)
+        return int(r)

@@ -1,0 +1,634 @@
+// achip_abi.cpp -- host side of libaircompressor_hip.so: the C ABI of include/aircompressor_hip.h.
+//
+// Mirrors what the reference's FFM layer expects from a native codec library
+// (M/internal/NativeLoader.java:66-117; M/lz4/Lz4Native.java:30-40): plain C symbols,
+// int/long/pointer arguments, integer results.  Depends only on libamdhip64.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "achip_device.h"
+
+namespace achip {
+hipError_t launch_lz4_decompress(const BatchArgs& a, hipStream_t stream, int groupSize);
+hipError_t launch_snappy_decompress(const BatchArgs& a, hipStream_t stream, int groupSize);
+hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
+hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant);
+hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
+hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
+int64_t zstd_decompress_scratch_bytes(int32_t nBlocks);
+int64_t zstd_compress_scratch_bytes(int32_t nBlocks);
+}  // namespace achip
+
+struct achip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // options
+    int lz4dGroup = 8;
+    int snappydGroup = 8;
+    int lz4cVariant = 0;
+    int snappycVariant = 0;
+    int zstddVariant = 0;
+    int zstdcVariant = 0;
+    int maxSrcLenHint = 0;
+    // scratch for the zstd pipeline (grown on demand)
+    void* scratch = nullptr;
+    int64_t scratchBytes = 0;
+    // staging for the host-pointer entry points (grown on demand)
+    uint8_t* hostStage = nullptr;  // pinned
+    uint8_t* devStage = nullptr;
+    int64_t stageBytes = 0;
+};
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int32_t device_failure(const char* what, hipError_t e)
+{
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    g_lastError = buf;
+    return ACHIP_STATUS(ACHIP_CLASS_DEVICE, ACHIP_D_HIP_ERROR);
+}
+
+#define HIP_TRY(expr)                             \
+    do {                                          \
+        hipError_t e_ = (expr);                   \
+        if (e_ != hipSuccess) {                   \
+            return device_failure(#expr, e_);     \
+        }                                         \
+    } while (0)
+
+int32_t bad_argument(const char* what)
+{
+    g_lastError = what;
+    return ACHIP_STATUS(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_BAD_ARGUMENT);
+}
+
+achip::BatchArgs make_args(const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, void* dstBase, const int64_t* dstOff,
+                           const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t nBlocks)
+{
+    achip::BatchArgs a;
+    a.srcBase = (const uint8_t*)srcBase;
+    a.srcOff = srcOff;
+    a.srcLen = srcLen;
+    a.dstBase = (uint8_t*)dstBase;
+    a.dstOff = dstOff;
+    a.dstCap = dstCap;
+    a.outLen = outLen;
+    a.status = status;
+    a.errOffset = errOffset;
+    a.nBlocks = nBlocks;
+    return a;
+}
+
+int32_t ensure_scratch(achip_ctx* ctx, int64_t bytes)
+{
+    if (bytes <= ctx->scratchBytes) {
+        return 0;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->scratch) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratchBytes = 0;
+    }
+    HIP_TRY(hipMalloc(&ctx->scratch, (size_t)bytes));
+    ctx->scratchBytes = bytes;
+    return 0;
+}
+
+int32_t ensure_stage(achip_ctx* ctx, int64_t bytes)
+{
+    if (bytes <= ctx->stageBytes) {
+        return 0;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->hostStage) {
+        HIP_TRY(hipHostFree(ctx->hostStage));
+        ctx->hostStage = nullptr;
+    }
+    if (ctx->devStage) {
+        HIP_TRY(hipFree(ctx->devStage));
+        ctx->devStage = nullptr;
+    }
+    ctx->stageBytes = 0;
+    int64_t want = std::max<int64_t>(bytes, 1 << 20);
+    HIP_TRY(hipHostMalloc((void**)&ctx->hostStage, (size_t)want, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&ctx->devStage, (size_t)want));
+    ctx->stageBytes = want;
+    return 0;
+}
+
+int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& a)
+{
+    if (!ctx) {
+        return bad_argument("ctx is null");
+    }
+    if (a.nBlocks < 0) {
+        return bad_argument("nBlocks < 0");
+    }
+    if (a.nBlocks == 0) {
+        return 0;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = hipSuccess;
+    switch (op) {
+        case ACHIP_OP_LZ4_DECOMPRESS: e = achip::launch_lz4_decompress(a, ctx->stream, ctx->lz4dGroup); break;
+        case ACHIP_OP_LZ4_COMPRESS: e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint); break;
+        case ACHIP_OP_SNAPPY_DECOMPRESS: e = achip::launch_snappy_decompress(a, ctx->stream, ctx->snappydGroup); break;
+        case ACHIP_OP_SNAPPY_COMPRESS: e = achip::launch_snappy_compress(a, ctx->stream, ctx->snappycVariant); break;
+        case ACHIP_OP_ZSTD_DECOMPRESS: {
+            int32_t r = ensure_scratch(ctx, achip::zstd_decompress_scratch_bytes(a.nBlocks));
+            if (r < 0) return r;
+            e = achip::launch_zstd_decompress(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->zstddVariant);
+            break;
+        }
+        case ACHIP_OP_ZSTD_COMPRESS: {
+            int32_t r = ensure_scratch(ctx, achip::zstd_compress_scratch_bytes(a.nBlocks));
+            if (r < 0) return r;
+            e = achip::launch_zstd_compress(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->zstdcVariant);
+            break;
+        }
+        default: return bad_argument("unknown codecOp");
+    }
+    if (e != hipSuccess) {
+        return device_failure("kernel launch", e);
+    }
+    return 0;
+}
+
+struct DetailText {
+    int32_t detail;
+    const char* text;
+};
+const DetailText kDetailText[] = {
+    {ACHIP_D_GENERIC, "Unknown error"},
+    {ACHIP_D_LZ4_INPUT_EMPTY, "input is empty"},
+    {ACHIP_D_LZ4_MALFORMED, "Malformed input"},
+    {ACHIP_D_LZ4_LAST_LITERAL_OUTSIDE, "attempt to write last literal outside of destination buffer"},
+    {ACHIP_D_LZ4_INPUT_NOT_CONSUMED, "all input must be consumed"},
+    {ACHIP_D_LZ4_OFFSET_OUTSIDE, "offset outside destination buffer"},
+    {ACHIP_D_LZ4_LAST_5_LITERALS, "last 5 bytes must be literals"},
+    {ACHIP_D_LZ4_EMPTY_OUTPUT, "Output buffer too small"},
+    {ACHIP_D_LZ4_MAX_INPUT, "Max input length exceeded"},
+    {ACHIP_D_LZ4_MAX_OUTPUT, "Max output length must be larger than the LZ4 bound"},
+    {ACHIP_D_SNAPPY_MALFORMED, "Malformed input"},
+    {ACHIP_D_SNAPPY_TRUNCATED, "Input is truncated"},
+    {ACHIP_D_SNAPPY_LEN_HIGH_BIT, "last byte of compressed length int has high bit set"},
+    {ACHIP_D_SNAPPY_INVALID_LENGTH, "invalid compressed length"},
+    {ACHIP_D_SNAPPY_LENGTH_MISMATCH, "Recorded length differs from actual length after decompression"},
+    {ACHIP_D_SNAPPY_OUTPUT_TOO_SMALL, "Uncompressed length must be less than the output buffer size"},
+    {ACHIP_D_SNAPPY_MAX_OUTPUT, "Output buffer must be at least the Snappy bound"},
+    {ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, "Not enough input bytes"},
+    {ACHIP_D_ZSTD_OUTPUT_TOO_SMALL, "Output buffer too small"},
+    {ACHIP_D_ZSTD_CORRUPTED, "Input is corrupted"},
+    {ACHIP_D_ZSTD_BAD_MAGIC, "Invalid magic prefix"},
+    {ACHIP_D_ZSTD_V07_MAGIC, "Data encoded in unsupported ZSTD v0.7 format"},
+    {ACHIP_D_ZSTD_BAD_CHECKSUM, "Bad checksum"},
+    {ACHIP_D_ZSTD_DICTIONARY, "Custom dictionaries not supported"},
+    {ACHIP_D_ZSTD_INVALID_BLOCK_TYPE, "Invalid block type"},
+    {ACHIP_D_ZSTD_BLOCK_TOO_LARGE, "Expected match length table to be present"},
+    {ACHIP_D_ZSTD_BLOCK_TOO_SMALL, "Compressed block size too small"},
+    {ACHIP_D_ZSTD_WINDOW_TOO_LARGE, "Window size too large (not yet supported)"},
+    {ACHIP_D_ZSTD_DICT_CORRUPTED, "Dictionary is corrupted"},
+    {ACHIP_D_ZSTD_LITERALS_TOO_LARGE, "Block exceeds maximum size"},
+    {ACHIP_D_ZSTD_FSE_TABLE_LOG, "FSE table size exceeds maximum allowed size"},
+    {ACHIP_D_ZSTD_FSE_SYMBOL, "Symbol larger than max value"},
+    {ACHIP_D_ZSTD_TABLE_MISSING, "Expected match length table to be present"},
+    {ACHIP_D_ZSTD_VALUE_TOO_LARGE, "Value exceeds expected maximum value"},
+    {ACHIP_D_ZSTD_BITSTREAM_EMPTY, "Bitstream is empty"},
+    {ACHIP_D_ZSTD_BITSTREAM_NO_MARK, "Bitstream end mark not present"},
+    {ACHIP_D_ZSTD_BITSTREAM_NOT_CONSUMED, "Bit stream is not fully consumed"},
+    {ACHIP_D_ZSTD_SEQUENCES_NOT_CONSUMED, "Not all sequences were consumed"},
+    {ACHIP_D_ZSTD_FSE_OUTPUT_SMALL, "Output buffer is too small"},
+    {ACHIP_D_ZSTD_MAX_OUTPUT, "Output buffer too small"},
+    {ACHIP_D_NO_DEVICE, "No HIP device available"},
+    {ACHIP_D_HIP_ERROR, "HIP runtime error"},
+    {ACHIP_D_BAD_ARGUMENT, "Invalid argument"},
+    {ACHIP_D_UNSUPPORTED, "Operation not supported by this build"},
+};
+
+}  // namespace
+
+extern "C" {
+
+int32_t achip_status_class(int32_t status) { return status < 0 ? ((-status) & 15) : 0; }
+int32_t achip_status_detail(int32_t status) { return status < 0 ? ((-status) >> 4) : 0; }
+
+const char* achip_detail_message(int32_t detail)
+{
+    for (const DetailText& d : kDetailText) {
+        if (d.detail == detail) {
+            return d.text;
+        }
+    }
+    return "Unknown error";
+}
+
+const char* achip_version(void) { return "aircompressor-hip 0.1 (gfx950)"; }
+
+int32_t achip_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char* achip_last_error(void) { return g_lastError.c_str(); }
+
+// ---- size helpers -------------------------------------------------------
+int32_t achip_lz4_max_compressed_length(int32_t n) { return n + n / 255 + 16; }
+int32_t achip_snappy_max_compressed_length(int32_t n) { return 32 + n + n / 6; }
+int32_t achip_zstd_max_compressed_length(int32_t n)
+{
+    int32_t result = n + (int32_t)((uint32_t)n >> 8);
+    if (n < 128 * 1024) {
+        result += (int32_t)((uint32_t)(128 * 1024 - n) >> 11);
+    }
+    return result;
+}
+
+int64_t achip_snappy_uncompressed_length(const void* src, int64_t srcLen, int64_t* errOffset)
+{
+    // SnappyRawDecompressor.readUncompressedLength  M/snappy/SnappyRawDecompressor.java:277-321
+    const uint8_t* in = (const uint8_t*)src;
+    uint32_t result = 0;
+    int64_t n = 0;
+    for (int i = 0; i < 5; i++) {
+        if (n >= srcLen) {
+            if (errOffset) *errOffset = srcLen - n;
+            return ACHIP_STATUS(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_TRUNCATED);
+        }
+        uint32_t b = in[n++];
+        result |= (b & 0x7f) << (7 * i);
+        if ((b & 0x80) == 0) {
+            break;
+        }
+        if (i == 4) {
+            if (errOffset) *errOffset = n;
+            return ACHIP_STATUS(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_LEN_HIGH_BIT);
+        }
+    }
+    if ((int32_t)result < 0) {
+        if (errOffset) *errOffset = 0;
+        return ACHIP_STATUS(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_INVALID_LENGTH);
+    }
+    return (int64_t)result;
+}
+
+int64_t achip_zstd_decompressed_size(const void* src, int64_t srcLen, int64_t* errOffset)
+{
+    // ZstdFrameDecompressor.getDecompressedSize = verifyMagic + readFrameHeader
+    // M/zstd/ZstdFrameDecompressor.java:860-962
+    const uint8_t* in = (const uint8_t*)src;
+    auto fail = [&](int detail, int64_t off) -> int64_t {
+        if (errOffset) *errOffset = off;
+        return ACHIP_STATUS(ACHIP_CLASS_MALFORMED, detail);
+    };
+    auto rd = [&](int64_t pos, int n) -> uint64_t {
+        uint64_t v = 0;
+        for (int i = 0; i < n; i++) {
+            if (pos + i < srcLen) v |= (uint64_t)in[pos + i] << (8 * i);
+        }
+        return v;
+    };
+    if (srcLen < 4) return fail(ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, 0);
+    uint32_t magic = (uint32_t)rd(0, 4);
+    if (magic != 0xFD2FB528u) {
+        return fail(magic == 0xFD2FB527u ? ACHIP_D_ZSTD_V07_MAGIC : ACHIP_D_ZSTD_BAD_MAGIC, 0);
+    }
+    int64_t input = 4;
+    if (!(input < srcLen)) return fail(ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, input);
+    int32_t fhd = (int32_t)rd(input++, 1);
+    bool singleSegment = (fhd & 0x20) != 0;
+    int32_t dictDesc = fhd & 3;
+    int32_t csDesc = fhd >> 6;
+    int32_t headerSize = 1 + (singleSegment ? 0 : 1) + (dictDesc == 0 ? 0 : (1 << (dictDesc - 1))) +
+                         (csDesc == 0 ? (singleSegment ? 1 : 0) : (1 << csDesc));
+    if (headerSize > srcLen - 4) return fail(ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, input);
+    if (!singleSegment) input++;
+    if (dictDesc != 0) return fail(ACHIP_D_ZSTD_DICTIONARY, input + (1 << (dictDesc - 1)));
+    switch (csDesc) {
+        case 0: return singleSegment ? (int64_t)rd(input, 1) : -1;
+        case 1: return (int64_t)rd(input, 2) + 256;
+        case 2: return (int64_t)rd(input, 4);
+        default: return (int64_t)rd(input, 8);
+    }
+}
+
+// ---- context -----------------------------------------------------------
+achip_ctx* achip_ctx_create(int32_t device)
+{
+    int n = achip_device_count();
+    if (n <= 0 || device < 0 || device >= n) {
+        g_lastError = n <= 0 ? "no HIP device" : "device ordinal out of range";
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        g_lastError = "hipSetDevice failed";
+        return nullptr;
+    }
+    achip_ctx* ctx = new achip_ctx();
+    ctx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        device_failure("hipStreamCreate", e);
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+void achip_ctx_destroy(achip_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->hostStage) (void)hipHostFree(ctx->hostStage);
+    if (ctx->devStage) (void)hipFree(ctx->devStage);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int32_t achip_ctx_device(achip_ctx* ctx) { return ctx ? ctx->device : -1; }
+void* achip_ctx_stream(achip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int32_t achip_ctx_synchronize(achip_ctx* ctx)
+{
+    if (!ctx) return bad_argument("ctx is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
+{
+    if (!ctx || !name) return bad_argument("ctx/name is null");
+    std::string k(name);
+    auto pow2 = [](int64_t v) { return v >= 1 && v <= 64 && (v & (v - 1)) == 0; };
+    if (k == "lz4.decompress.group") {
+        if (!pow2(value)) return bad_argument("group size must be a power of two in 1..64");
+        ctx->lz4dGroup = (int)value;
+    }
+    else if (k == "snappy.decompress.group") {
+        if (!pow2(value)) return bad_argument("group size must be a power of two in 1..64");
+        ctx->snappydGroup = (int)value;
+    }
+    else if (k == "lz4.compress.variant") ctx->lz4cVariant = (int)value;
+    else if (k == "snappy.compress.variant") ctx->snappycVariant = (int)value;
+    else if (k == "zstd.decompress.variant") ctx->zstddVariant = (int)value;
+    else if (k == "zstd.compress.variant") ctx->zstdcVariant = (int)value;
+    else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;
+    else return bad_argument("unknown option");
+    return 0;
+}
+
+// ---- memory helpers ----------------------------------------------------
+void* achip_device_alloc(achip_ctx* ctx, int64_t bytes)
+{
+    if (!ctx || bytes < 0) return nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, (size_t)std::max<int64_t>(bytes, 1));
+    if (e != hipSuccess) {
+        device_failure("hipMalloc", e);
+        return nullptr;
+    }
+    return p;
+}
+
+int32_t achip_device_free(achip_ctx* ctx, void* p)
+{
+    if (!ctx) return bad_argument("ctx is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipFree(p));
+    return 0;
+}
+
+void* achip_host_alloc_pinned(int64_t bytes)
+{
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, (size_t)std::max<int64_t>(bytes, 1), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        device_failure("hipHostMalloc", e);
+        return nullptr;
+    }
+    return p;
+}
+
+int32_t achip_host_free_pinned(void* p)
+{
+    HIP_TRY(hipHostFree(p));
+    return 0;
+}
+
+int32_t achip_memcpy_h2d(achip_ctx* ctx, void* dst, const void* src, int64_t bytes)
+{
+    if (!ctx) return bad_argument("ctx is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+int32_t achip_memcpy_d2h(achip_ctx* ctx, void* dst, const void* src, int64_t bytes)
+{
+    if (!ctx) return bad_argument("ctx is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+int32_t achip_memset_d(achip_ctx* ctx, void* dst, int32_t value, int64_t bytes)
+{
+    if (!ctx) return bad_argument("ctx is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(dst, value, (size_t)bytes, ctx->stream));
+    return 0;
+}
+
+// ---- events ------------------------------------------------------------
+void* achip_event_create(void)
+{
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return (void*)ev;
+}
+int32_t achip_event_destroy(void* ev)
+{
+    HIP_TRY(hipEventDestroy((hipEvent_t)ev));
+    return 0;
+}
+int32_t achip_event_record(achip_ctx* ctx, void* ev)
+{
+    if (!ctx) return bad_argument("ctx is null");
+    HIP_TRY(hipEventRecord((hipEvent_t)ev, ctx->stream));
+    return 0;
+}
+float achip_event_elapsed_ms(void* evStart, void* evStop)
+{
+    if (hipEventSynchronize((hipEvent_t)evStop) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)evStart, (hipEvent_t)evStop) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+// ---- batched device-resident API ----------------------------------------
+#define ACHIP_DEFINE_BATCH(fn, op)                                                                                      \
+    int32_t fn(ACHIP_BATCH_ARGS)                                                                                        \
+    {                                                                                                                   \
+        return launch_op(op, ctx, make_args(srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, nBlocks)); \
+    }
+ACHIP_DEFINE_BATCH(achip_lz4_decompress_batch, ACHIP_OP_LZ4_DECOMPRESS)
+ACHIP_DEFINE_BATCH(achip_lz4_compress_batch, ACHIP_OP_LZ4_COMPRESS)
+ACHIP_DEFINE_BATCH(achip_snappy_decompress_batch, ACHIP_OP_SNAPPY_DECOMPRESS)
+ACHIP_DEFINE_BATCH(achip_snappy_compress_batch, ACHIP_OP_SNAPPY_COMPRESS)
+ACHIP_DEFINE_BATCH(achip_zstd_decompress_batch, ACHIP_OP_ZSTD_DECOMPRESS)
+ACHIP_DEFINE_BATCH(achip_zstd_compress_batch, ACHIP_OP_ZSTD_COMPRESS)
+
+// ---- host-pointer batch: stage in, run, stage out ------------------------
+int32_t achip_batch_host(int32_t codecOp, ACHIP_BATCH_ARGS)
+{
+    if (!ctx) return bad_argument("ctx is null");
+    if (nBlocks < 0) return bad_argument("nBlocks < 0");
+    if (nBlocks == 0) return 0;
+    if (!srcOff || !srcLen || !dstOff || !dstCap || !outLen || !status) return bad_argument("null metadata array");
+    // device layout: [src blocks packed, 16-aligned][dst blocks packed, 16-aligned][metadata]
+    const int64_t n = nBlocks;
+    std::vector<int64_t> dSrcOff(n), dDstOff(n);
+    int64_t srcBytes = 0, dstBytes = 0;
+    int32_t maxLen = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (srcLen[i] < 0 || dstCap[i] < 0) return bad_argument("negative length");
+        dSrcOff[i] = srcBytes;
+        srcBytes += ((int64_t)srcLen[i] + 15) & ~15LL;
+        dDstOff[i] = dstBytes;
+        dstBytes += ((int64_t)dstCap[i] + 15) & ~15LL;
+        maxLen = std::max(maxLen, srcLen[i]);
+    }
+    const int64_t metaOff = ((srcBytes + dstBytes) + 63) & ~63LL;
+    const int64_t metaBytes = n * (8 + 4 + 8 + 4 + 4 + 4 + 8) + 64;
+    int32_t r = ensure_stage(ctx, metaOff + metaBytes);
+    if (r < 0) return r;
+
+    uint8_t* h = ctx->hostStage;
+    uint8_t* d = ctx->devStage;
+    for (int64_t i = 0; i < n; i++) {
+        if (srcLen[i] > 0) memcpy(h + dSrcOff[i], (const uint8_t*)srcBase + srcOff[i], (size_t)srcLen[i]);
+    }
+    // metadata block
+    int64_t m = metaOff;
+    int64_t oSrcOff = m; m += n * 8;
+    int64_t oDstOff = m; m += n * 8;
+    int64_t oErr = m; m += n * 8;
+    int64_t oSrcLen = m; m += n * 4;
+    int64_t oDstCap = m; m += n * 4;
+    int64_t oOutLen = m; m += n * 4;
+    int64_t oStatus = m; m += n * 4;
+    for (int64_t i = 0; i < n; i++) {
+        ((int64_t*)(h + oSrcOff))[i] = dSrcOff[i];
+        ((int64_t*)(h + oDstOff))[i] = srcBytes + dDstOff[i];
+        ((int32_t*)(h + oSrcLen))[i] = srcLen[i];
+        ((int32_t*)(h + oDstCap))[i] = dstCap[i];
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(d, h, (size_t)srcBytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d + metaOff, h + metaOff, (size_t)(m - metaOff), hipMemcpyHostToDevice, ctx->stream));
+    achip::BatchArgs a = make_args(d, (const int64_t*)(d + oSrcOff), (const int32_t*)(d + oSrcLen), d, (const int64_t*)(d + oDstOff),
+                                   (const int32_t*)(d + oDstCap), (int32_t*)(d + oOutLen), (int32_t*)(d + oStatus), (int64_t*)(d + oErr), nBlocks);
+    const int savedHint = ctx->maxSrcLenHint;
+    ctx->maxSrcLenHint = std::max(maxLen, 1);
+    r = launch_op(codecOp, ctx, a);
+    ctx->maxSrcLenHint = savedHint;
+    if (r < 0) return r;
+    HIP_TRY(hipMemcpyAsync(h + srcBytes, d + srcBytes, (size_t)dstBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(h + oErr, d + oErr, (size_t)(m - oErr), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t len = ((int32_t*)(h + oOutLen))[i];
+        outLen[i] = len;
+        status[i] = ((int32_t*)(h + oStatus))[i];
+        if (errOffset) errOffset[i] = ((int64_t*)(h + oErr))[i];
+        if (status[i] == 0 && len > 0) {
+            memcpy((uint8_t*)dstBase + dstOff[i], h + srcBytes + dDstOff[i], (size_t)len);
+        }
+    }
+    return 0;
+}
+
+// ---- single block, host pointers -----------------------------------------
+static int32_t single_block(int32_t op, achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    if (!ctx) return bad_argument("ctx is null");
+    if (srcLen < 0 || dstCap < 0) return bad_argument("negative length");
+    int64_t so = 0, dofs = 0, eo = 0;
+    int32_t outLen = 0, status = 0;
+    int32_t r = achip_batch_host(op, ctx, src, &so, &srcLen, dst, &dofs, &dstCap, &outLen, &status, &eo, 1);
+    if (r < 0) return r;
+    if (errOffset) *errOffset = eo;
+    return status < 0 ? status : outLen;
+}
+
+int32_t achip_lz4_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_LZ4_COMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
+int32_t achip_lz4_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_LZ4_DECOMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
+int32_t achip_snappy_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_SNAPPY_COMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
+int32_t achip_snappy_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_SNAPPY_DECOMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
+int32_t achip_zstd_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_ZSTD_COMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
+int32_t achip_zstd_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_ZSTD_DECOMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
+
+// ---- multi-GPU partition (host arithmetic) --------------------------------
+int32_t achip_partition_blocks(const int64_t* weight, int32_t nBlocks, int32_t nParts, int32_t* starts)
+{
+    if (nBlocks < 0 || nParts <= 0 || !starts) return bad_argument("bad partition arguments");
+    int64_t total = 0;
+    for (int32_t i = 0; i < nBlocks; i++) {
+        total += weight ? std::max<int64_t>(weight[i], 0) : 1;
+    }
+    starts[0] = 0;
+    int64_t acc = 0;
+    int32_t idx = 0;
+    for (int32_t p = 1; p < nParts; p++) {
+        // smallest idx whose prefix weight reaches p/nParts of the total
+        const __int128 target = (__int128)total * p;
+        while (idx < nBlocks && (__int128)acc * nParts < target) {
+            acc += weight ? std::max<int64_t>(weight[idx], 0) : 1;
+            idx++;
+        }
+        starts[p] = idx;
+    }
+    starts[nParts] = nBlocks;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,198 @@
+// achip_device.h -- device-side building blocks shared by the gfx950 codec kernels.
+//
+// Execution shape used by the LZ77 decoders: a wavefront (64 lanes) is split into
+// 64/GS "groups" of GS consecutive lanes; each group owns one block of the batch.
+// Everything that is serial in the format (token grammar) is computed redundantly
+// by all GS lanes of the group (same addresses => one memory transaction), and
+// everything that moves bytes is spread over the GS lanes 16 bytes per lane, so a
+// group step touches GS*16 contiguous bytes of HBM.  Groups of one wave diverge only
+// on rare paths (length escapes, tails, overlapping matches).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/aircompressor_hip.h"
+
+namespace achip {
+
+struct BatchArgs {
+    const uint8_t* __restrict__ srcBase;
+    const int64_t* __restrict__ srcOff;
+    const int32_t* __restrict__ srcLen;
+    uint8_t* __restrict__ dstBase;
+    const int64_t* __restrict__ dstOff;
+    const int32_t* __restrict__ dstCap;
+    int32_t* __restrict__ outLen;
+    int32_t* __restrict__ status;
+    int64_t* __restrict__ errOffset;
+    int32_t nBlocks;
+};
+
+__device__ __forceinline__ constexpr int32_t mk_status(int cls, int detail) { return -(cls + 16 * detail); }
+
+// ---- unaligned little-endian accessors (global memory; gfx950 runs in unaligned-access mode) ----
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32x4 ld16(const uint8_t* p)
+{
+    u32x4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ void st16(uint8_t* p, u32x4 v) { __builtin_memcpy(p, &v, 16); }
+__device__ __forceinline__ uint64_t ld8(const uint8_t* p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ void st8(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+__device__ __forceinline__ uint32_t ld4(const uint8_t* p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ void st4(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+__device__ __forceinline__ uint32_t ld2(const uint8_t* p)
+{
+    uint16_t v;
+    __builtin_memcpy(&v, p, 2);
+    return v;
+}
+__device__ __forceinline__ void st2(uint8_t* p, uint32_t v)
+{
+    uint16_t w = (uint16_t)v;
+    __builtin_memcpy(p, &w, 2);
+}
+
+// Compiler-level ordering point between a store phase and a load phase whose addresses
+// may be produced by OTHER lanes of the same wave.  The hardware issues a wave's vector
+// memory instructions to the CU's L1/TA in program order, so keeping the compiler from
+// reordering across this point is sufficient inside one wave.
+__device__ __forceinline__ void wave_mem_order() { asm volatile("" ::: "memory"); }
+
+// ---- group copy: n bytes, src and dst ranges do not overlap (or src+n <= dst) ----
+// Lane g of a GS-lane group moves bytes [16g,16g+16) of every GS*16-byte step; the
+// ragged tail (n mod 16) is moved one byte per lane.  Exact: never reads or writes
+// outside [src,src+n) / [dst,dst+n).
+template <int GS>
+__device__ __forceinline__ void group_copy(uint8_t* dst, const uint8_t* src, int32_t n, int g)
+{
+    const int32_t full = n & ~15;
+    for (int32_t base = g * 16; base < full; base += GS * 16) {
+        st16(dst + base, ld16(src + base));
+    }
+    if constexpr (GS >= 4) {
+        for (int32_t k = full + g; k < n; k += GS) {
+            dst[k] = src[k];
+        }
+    }
+    else {
+        const int32_t r = n & 15;
+        if (r != 0 && g == ((n >> 4) % GS)) {
+            int32_t k = full;
+            if (r & 8) {
+                st8(dst + k, ld8(src + k));
+                k += 8;
+            }
+            if (r & 4) {
+                st4(dst + k, ld4(src + k));
+                k += 4;
+            }
+            if (r & 2) {
+                st2(dst + k, ld2(src + k));
+                k += 2;
+            }
+            if (r & 1) {
+                dst[k] = src[k];
+            }
+        }
+    }
+}
+
+// ---- group match copy: LZ77 back-reference inside the output buffer ----
+// out[pos+k] = out[pos-offset+k] for k in [0,len), byte-sequential semantics (the
+// source may overlap the destination when offset < len).  Overlap is resolved without
+// serialising on bytes: a prefix of the match that lies within one period is a plain
+// non-overlapping copy, and once 2^r periods exist the next 2^r periods can be copied
+// from them at distance offset*2^r.  For offset < 16 the first 256 bytes are produced
+// byte-per-lane from the period (source index = k mod offset), all reading data that
+// existed before the match started.
+template <int GS>
+__device__ __forceinline__ void group_match_copy(uint8_t* out, int32_t pos, int32_t offset, int32_t len, int g)
+{
+    wave_mem_order();
+    uint8_t* dst = out + pos;
+    int32_t copied = 0;
+    int32_t d = offset;
+    if (offset < 16 && len > offset) {
+        const int32_t head = len < 256 ? len : 256;
+        const uint8_t* period = dst - offset;
+        const uint32_t inv = (65536u + (uint32_t)offset - 1u) / (uint32_t)offset;  // exact k/offset for k < 4096
+        for (int32_t k = g; k < head; k += GS) {
+            const uint32_t q = ((uint32_t)k * inv) >> 16;
+            dst[k] = period[k - (int32_t)q * offset];
+        }
+        copied = head;
+        d = (256 / offset) * offset;
+        wave_mem_order();
+    }
+    while (copied < len) {
+        const int32_t rem = len - copied;
+        const int32_t n = rem < d ? rem : d;
+        group_copy<GS>(dst + copied, dst + copied - d, n, g);
+        copied += n;
+        if (copied < len) {
+            if (d < (1 << 20)) {
+                d += d;
+            }
+            wave_mem_order();
+        }
+    }
+}
+
+// ---- wave-wide match-length count (one wavefront per block) ----
+// Number of equal bytes of in[a..] vs in[b..] with a < limit, b < a: the `count` routines of the Java
+// encoders (M/lz4/Lz4RawCompressor.java:240-267, M/snappy/SnappyRawCompressor.java:235-266) both return
+// the exact common-prefix length capped at the limit.  64 lanes x 8 bytes per step; wave-uniform result.
+__device__ __forceinline__ int32_t wave_count(const uint8_t* __restrict__ in, int32_t a, int32_t b, int32_t limit, int lane)
+{
+    int32_t total = 0;
+    for (;;) {
+        const int32_t remaining = limit - a;  // bytes still comparable
+        const int32_t o = lane * 8;
+        int32_t chunk = remaining - o;
+        chunk = chunk > 8 ? 8 : chunk;
+        int32_t eq = 0;
+        if (chunk == 8) {
+            const uint64_t diff = ld8(in + a + o) ^ ld8(in + b + o);
+            eq = diff == 0 ? 8 : (__builtin_ctzll(diff) >> 3);
+        }
+        else if (chunk > 0) {
+            while (eq < chunk && in[a + o + eq] == in[b + o + eq]) {
+                eq++;
+            }
+        }
+        const bool stop = chunk < 8 || eq < 8;
+        const unsigned long long m = __ballot(stop);
+        if (m != 0) {
+            const int first = __builtin_ctzll(m);
+            const int32_t e = __shfl(eq, first);
+            return total + first * 8 + e;
+        }
+        total += 512;
+        a += 512;
+        b += 512;
+    }
+}
+
+// first lane index of this lane's group, lane index inside the group
+template <int GS>
+__device__ __forceinline__ int group_lane()
+{
+    return (int)(threadIdx.x & (GS - 1));
+}
+
+}  // namespace achip

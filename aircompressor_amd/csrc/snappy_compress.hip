@@ -1,0 +1,197 @@
+// snappy_compress.hip -- batched Snappy raw-format encode for gfx950, bit-exact with the Java encoder.
+//
+// Replaces SnappyRawCompressor.compress + count/emitLiteralLength/fastCopy/emitCopy/
+// getHashTableSize/hashBytes/writeUncompressedLength (M/snappy/SnappyRawCompressor.java:47-411).
+//
+// One wavefront per input buffer; the buffer's independent 64 KiB sub-blocks (:93-99) are
+// walked in order because their outputs are concatenated.  The u16 hash table (<= 16384
+// entries = 32 KiB) lives in LDS (5 waves / CU).  The greedy parse state is wave-uniform;
+// the lanes help with the match-length count (64 x 8 bytes per step, ballot for the first
+// mismatch) and the literal copies (64 x 16 bytes per step).
+#include "achip_device.h"
+
+namespace achip {
+
+namespace snc {
+constexpr int BLOCK_SIZE = 1 << 16;
+constexpr int INPUT_MARGIN_BYTES = 15;
+constexpr int MAX_HASH_TABLE_SIZE = 1 << 14;
+}  // namespace snc
+
+__device__ __forceinline__ int32_t snappy_hash(uint32_t v, int32_t shift) { return (int32_t)((v * 0x1e35a7bdu) >> shift); }  // :368-371
+
+// emitLiteralLength :268-298 -- returns the number of header bytes; lane 0 writes them
+__device__ __forceinline__ int32_t snappy_literal_header(uint8_t* out, int32_t o, int32_t literalLength, int lane)
+{
+    const int32_t n = literalLength - 1;
+    int32_t bytes = 0;
+    if (n >= 60) {
+        bytes = n < (1 << 8) ? 1 : (n < (1 << 16) ? 2 : (n < (1 << 24) ? 3 : 4));
+    }
+    if (lane == 0) {
+        if (n < 60) {
+            out[o] = (uint8_t)(n << 2);
+        }
+        else {
+            out[o] = (uint8_t)((59 + bytes) << 2);
+            for (int i = 0; i < bytes; i++) {
+                out[o + 1 + i] = (uint8_t)((uint32_t)n >> (8 * i));
+            }
+        }
+    }
+    return 1 + bytes;
+}
+
+// emitCopy :312-345 -- lane 0 writes; every lane returns the new output offset
+__device__ __forceinline__ int32_t snappy_emit_copy(uint8_t* out, int32_t o, int32_t offset, int32_t matchLength, int lane)
+{
+    while (matchLength >= 68) {
+        if (lane == 0) {
+            out[o] = (uint8_t)(2 + ((64 - 1) << 2));
+            out[o + 1] = (uint8_t)offset;
+            out[o + 2] = (uint8_t)(offset >> 8);
+        }
+        o += 3;
+        matchLength -= 64;
+    }
+    if (matchLength > 64) {
+        if (lane == 0) {
+            out[o] = (uint8_t)(2 + ((60 - 1) << 2));
+            out[o + 1] = (uint8_t)offset;
+            out[o + 2] = (uint8_t)(offset >> 8);
+        }
+        o += 3;
+        matchLength -= 60;
+    }
+    if (matchLength < 12 && offset < 2048) {
+        if (lane == 0) {
+            out[o] = (uint8_t)(1 + ((matchLength - 4) << 2) + ((offset >> 8) << 5));
+            out[o + 1] = (uint8_t)offset;
+        }
+        o += 2;
+    }
+    else {
+        if (lane == 0) {
+            out[o] = (uint8_t)(2 + ((matchLength - 1) << 2));
+            out[o + 1] = (uint8_t)offset;
+            out[o + 2] = (uint8_t)(offset >> 8);
+        }
+        o += 3;
+    }
+    return o;
+}
+
+__global__ __launch_bounds__(64) void snappy_compress_kernel(BatchArgs a)
+{
+    using namespace snc;
+    __shared__ uint16_t table[MAX_HASH_TABLE_SIZE];
+    const int lane = threadIdx.x;
+    const int64_t block = blockIdx.x;
+    const uint8_t* __restrict__ in0 = a.srcBase + a.srcOff[block];
+    uint8_t* __restrict__ out = a.dstBase + a.dstOff[block];
+    const int32_t inLen = a.srcLen[block];
+    const int32_t outCap = a.dstCap[block];
+
+    int32_t st = 0;
+    int32_t output = 0;
+    const int64_t bound = 32 + (int64_t)inLen + inLen / 6;  // :69
+    if ((int64_t)outCap < bound) {                          // :85-88
+        st = mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_SNAPPY_MAX_OUTPUT);
+    }
+    else {
+        // writeUncompressedLength :383-411
+        {
+            uint32_t n = (uint32_t)inLen;
+            int32_t nb = n < (1u << 7) ? 1 : (n < (1u << 14) ? 2 : (n < (1u << 21) ? 3 : (n < (1u << 28) ? 4 : 5)));
+            if (lane == 0) {
+                for (int i = 0; i < nb; i++) {
+                    out[i] = (uint8_t)((n >> (7 * i)) | (i + 1 < nb ? 0x80u : 0u));
+                }
+            }
+            output = nb;
+        }
+
+        for (int64_t blockAddress = 0; blockAddress < inLen; blockAddress += BLOCK_SIZE) {
+            const uint8_t* __restrict__ in = in0 + blockAddress;  // positions below are relative to the sub-block
+            const int32_t blockLimit = (int32_t)((inLen - blockAddress) < BLOCK_SIZE ? (inLen - blockAddress) : BLOCK_SIZE);
+            int32_t input = 0;
+
+            // getHashTableSize :348-361
+            int32_t tableSize = blockLimit <= 1 ? 0 : (int32_t)((0x80000000u >> __builtin_clz((uint32_t)(blockLimit - 1))) << 1);
+            tableSize = tableSize < 256 ? 256 : (tableSize > MAX_HASH_TABLE_SIZE ? MAX_HASH_TABLE_SIZE : tableSize);
+            __syncthreads();
+            for (int i = lane; i < tableSize; i += 64) {
+                table[i] = 0;
+            }
+            __syncthreads();
+            const int32_t shift = 32 - (31 - __builtin_clz((uint32_t)tableSize));
+
+            int32_t nextEmit = input;
+            const int32_t fastInputLimit = blockLimit - INPUT_MARGIN_BYTES;
+            while (input <= fastInputLimit) {
+                int32_t skip = 32;
+                int32_t candidate = 0;
+                for (input += 1; input + (int32_t)((uint32_t)skip >> 5) <= fastInputLimit; input += (int32_t)((uint32_t)(skip++) >> 5)) {  // :141-159
+                    const uint32_t currentInt = ld4(in + input);
+                    const int32_t hash = snappy_hash(currentInt, shift);
+                    candidate = table[hash];
+                    table[hash] = (uint16_t)input;  // every lane stores the same value
+                    if (currentInt == ld4(in + candidate)) {
+                        break;
+                    }
+                }
+                if (input + (int32_t)((uint32_t)skip >> 5) > fastInputLimit) {
+                    break;
+                }
+
+                const int32_t literalLength = input - nextEmit;  // :169-175
+                output += snappy_literal_header(out, output, literalLength, lane);
+                group_copy<64>(out + output, in + nextEmit, literalLength, lane);
+                output += literalLength;
+
+                uint32_t inputBytes;
+                do {  // :186-219
+                    int32_t matched = 4 + wave_count(in, input + 4, candidate + 4, blockLimit, lane);
+                    output = snappy_emit_copy(out, output, input - candidate, matched, lane);
+                    input += matched;
+                    if (input >= fastInputLimit) {
+                        break;
+                    }
+                    const uint64_t longValue = ld8(in + input - 1);
+                    const uint32_t prevInt = (uint32_t)longValue;
+                    inputBytes = (uint32_t)(longValue >> 8);
+                    table[snappy_hash(prevInt, shift)] = (uint16_t)(input - 1);
+                    const int32_t curHash = snappy_hash(inputBytes, shift);
+                    candidate = table[curHash];
+                    table[curHash] = (uint16_t)input;
+                } while (inputBytes == ld4(in + candidate));
+                nextEmit = input;
+            }
+
+            if (nextEmit < blockLimit) {  // :224-229
+                const int32_t literalLength = blockLimit - nextEmit;
+                output += snappy_literal_header(out, output, literalLength, lane);
+                group_copy<64>(out + output, in + nextEmit, literalLength, lane);
+                output += literalLength;
+            }
+        }
+    }
+
+    if (lane == 0) {
+        a.outLen[block] = st == 0 ? output : 0;
+        a.status[block] = st;
+        a.errOffset[block] = 0;
+    }
+}
+
+hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant)
+{
+    (void)variant;
+    if (a.nBlocks <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(snappy_compress_kernel, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace achip

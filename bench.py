@@ -1,0 +1,381 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement: batched LZ4 block decompress on MI355X through the C ABI.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path (achip_lz4_decompress_batch) over this rank's batch of
+synthetic blocks (BASELINE.json configs[1]: 262144 x 64 KiB per GPU).  Blocks are independent, so ranks
+own contiguous slices of the global batch (achip_partition_blocks) and there is NO data-path
+collective; torch.distributed (RCCL) only provides the barrier and the max-over-ranks of the time.
+Inputs (compressed blocks, offsets) and outputs are resident in HBM before the timed region.
+
+Synthetic data: the reference's test generator shape (T/snappy/RandomGenerator.java:25-74): 100-byte
+fragments made of max(1, 100*ratio) random bytes repeated; compressed ON THE GPU by the product's own
+bit-exact LZ4 encoder (the oracle is never used to make inputs).  The oracle (oracle/liboracle.so, the C
+restatement of the Java codec) is only timed as the `cpu_baseline` leg on rank 0 at N=1.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--blocks", type=int, default=262144, help="blocks per GPU (BASELINE configs[1]: 262144)")
+    p.add_argument("--block-size", type=int, default=65536)
+    p.add_argument("--pool", type=int, default=4096, help="distinct blocks generated; the batch tiles them at distinct addresses")
+    p.add_argument("--ratio", type=float, default=0.5, help="RandomGenerator compressibility (0.5 => LZ4 ratio ~1.9)")
+    p.add_argument("--workload", default="lz4_decompress", choices=["lz4_decompress", "snappy_decompress", "lz4_compress", "snappy_compress"])
+    p.add_argument("--data", default="fragments", choices=["fragments", "wordmix"])
+    p.add_argument("--group", type=int, default=0, help="decoder lanes per block (0 = library default)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extra", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    return p.parse_args()
+
+
+def gen_fragments(torch, dev, n_blocks, block_size, ratio, seed):
+    """RandomGenerator.compressibleData for every 100-byte fragment, generated on the device."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    raw = max(1, int(100 * ratio))
+    total = n_blocks * block_size
+    n_frag = (total + 99) // 100
+    frags = torch.randint(0, 256, (n_frag, raw), dtype=torch.uint8, device=dev, generator=g)
+    reps = (100 + raw - 1) // raw
+    data = frags.repeat(1, reps)[:, :100].reshape(-1)[:total].contiguous()
+    return data
+
+
+def gen_wordmix(torch, dev, n_blocks, block_size, seed):
+    """Text-like data: Zipf-distributed words from a 4096-word vocabulary separated by spaces (short LZ4 sequences)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    vocab = 4096
+    wl = torch.randint(2, 11, (vocab,), device=dev, generator=g)
+    letters = torch.randint(97, 123, (vocab, 12), dtype=torch.uint8, device=dev, generator=g)
+    pos = torch.arange(12, device=dev).unsqueeze(0)
+    letters = torch.where(pos < wl.unsqueeze(1), letters, torch.where(pos == wl.unsqueeze(1), torch.full_like(letters, 32), torch.full_like(letters, 255)))
+    total = n_blocks * block_size
+    need = int(total / 6.0) + 4096
+    out = []
+    produced = 0
+    while produced < total:
+        u = torch.rand((need,), device=dev, generator=g)
+        ids = (vocab ** u - 1).long().clamp_(0, vocab - 1)  # log-uniform ~ Zipf(1)
+        w = letters[ids].reshape(-1)
+        w = w[w != 255]
+        out.append(w)
+        produced += w.numel()
+    return torch.cat(out)[:total].contiguous()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import aircompressor_amd as A
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    bs = args.block_size
+    n_local_target = args.blocks
+    n_global = n_local_target * world
+    # contiguous, byte-balanced shard of the global block index (no collective on the data path)
+    starts = A.partition_blocks(np.full(n_global, bs, dtype=np.int64), world)
+    lo, hi = int(starts[rank]), int(starts[rank + 1])
+    n_local = hi - lo
+
+    codec = A.HipBatchCodec(local_rank)
+    lib = codec.lib
+    if args.group:
+        codec.native.set_option("lz4.decompress.group", args.group)
+        codec.native.set_option("snappy.decompress.group", args.group)
+    codec.native.set_option("max_src_len_hint", bs)
+
+    wl = args.workload
+    name = "lz4" if wl.startswith("lz4") else "snappy"
+    compress_op = A.OP_LZ4_COMPRESS if name == "lz4" else A.OP_SNAPPY_COMPRESS
+    decompress_op = A.OP_LZ4_DECOMPRESS if name == "lz4" else A.OP_SNAPPY_DECOMPRESS
+    max_c = getattr(lib, "achip_%s_max_compressed_length" % name)(bs)
+
+    # ---- untimed setup: pool of distinct blocks, compressed by the product's GPU encoder ----
+    pool_n = min(args.pool, n_local)
+    while n_local % pool_n:
+        pool_n -= 1
+    reps = n_local // pool_n
+    seed = 301 + 7919 * (lo // max(pool_n, 1))
+    if args.data == "fragments":
+        pool_plain = gen_fragments(torch, dev, pool_n, bs, args.ratio, seed)
+    else:
+        pool_plain = gen_wordmix(torch, dev, pool_n, bs, seed)
+    cstride = (max_c + 15) // 16 * 16
+    i64 = dict(dtype=torch.int64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    pool_src_off = torch.arange(pool_n, **i64) * bs
+    pool_src_len = torch.full((pool_n,), bs, **i32)
+    pool_dst_off = torch.arange(pool_n, **i64) * cstride
+    pool_dst_cap = torch.full((pool_n,), max_c, **i32)
+    pool_comp_wide = torch.zeros(pool_n * cstride, dtype=torch.uint8, device=dev)
+    pool_clen = torch.zeros(pool_n, **i32)
+    pool_st = torch.zeros(pool_n, **i32)
+    pool_eo = torch.zeros(pool_n, **i64)
+    torch.cuda.synchronize()
+    codec.launch(compress_op, pool_plain, pool_src_off, pool_src_len, pool_comp_wide, pool_dst_off, pool_dst_cap, pool_clen, pool_st, pool_eo, pool_n)
+    codec.synchronize()
+    assert int((pool_st != 0).sum()) == 0, "GPU compressor reported errors while preparing the workload"
+    # pack the compressed pool tightly (16-byte aligned starts) and tile it to the batch, each copy at its own address
+    clen = pool_clen.to(torch.int64)
+    cpad = (clen + 15) // 16 * 16
+    pool_pack_off = torch.cumsum(cpad, 0) - cpad
+    pool_pack_bytes = int(cpad.sum())
+    idx_block = torch.repeat_interleave(torch.arange(pool_n, device=dev), cpad)
+    within = torch.arange(pool_pack_bytes, device=dev) - pool_pack_off[idx_block]
+    pool_pack = pool_comp_wide[pool_dst_off[idx_block] + within]
+    del idx_block, within, pool_comp_wide
+    comp_bytes_pool = int(clen.sum())
+    plain_bytes_local = n_local * bs
+    comp_bytes_local = comp_bytes_pool * reps
+
+    rep_idx = torch.arange(reps, **i64).repeat_interleave(pool_n)
+    if wl.endswith("decompress"):
+        src = pool_pack.repeat(reps)
+        src_off = pool_pack_off.repeat(reps) + rep_idx * pool_pack_bytes
+        src_len = pool_clen.repeat(reps)
+        dst = torch.empty(n_local * bs + 64, dtype=torch.uint8, device=dev)
+        dst_off = torch.arange(n_local, **i64) * bs
+        dst_cap = torch.full((n_local,), bs, **i32)
+        op = decompress_op
+    else:
+        src = pool_plain.repeat(reps)
+        src_off = torch.arange(n_local, **i64) * bs
+        src_len = torch.full((n_local,), bs, **i32)
+        dst = torch.empty(n_local * cstride + 64, dtype=torch.uint8, device=dev)
+        dst_off = torch.arange(n_local, **i64) * cstride
+        dst_cap = torch.full((n_local,), max_c, **i32)
+        op = compress_op
+    out_len = torch.zeros(n_local, **i32)
+    status = torch.zeros(n_local, **i32)
+    err_off = torch.zeros(n_local, **i64)
+    torch.cuda.synchronize()
+
+    def step():
+        codec.launch(op, src, src_off, src_len, dst, dst_off, dst_cap, out_len, status, err_off, n_local)
+
+    def barrier():
+        torch.cuda.synchronize()
+        codec.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(codec.event(), codec.event()) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        codec.record(ev[k][0])
+        step()
+        codec.record(ev[k][1])
+    codec.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = [codec.elapsed_ms(a, b) for a, b in ev]
+
+    # ---- untimed verification: every block ok and bit-exact ----
+    assert int((status != 0).sum()) == 0, "a block failed"
+    if wl.endswith("decompress"):
+        assert int((out_len != bs).sum()) == 0
+        ok = bool((dst[:n_local * bs].view(reps, pool_n * bs) == pool_plain.unsqueeze(0)).all())
+        assert ok, "decompressed output differs from the plaintext"
+    else:
+        assert bool((out_len == pool_clen.repeat(reps)).all())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    total_plain = plain_bytes_local * world  # weak scaling: every rank owns n_local blocks
+    value = total_plain * args.steps / elapsed / 2**30
+    kavg = float(np.mean(kernel_ms)) * 1e-3
+    alg_bytes = plain_bytes_local + comp_bytes_local + n_local * 20  # U_i + C_i + 20 B metadata per block
+    achieved = alg_bytes / kavg / 1e9
+    result = {
+        "metric": "GiB/s decompressed throughput (Zstd+LZ4) at 1/2/4/8 GPUs; % of HBM3E roofline",
+        "value": round(value, 2),
+        "unit": "GiB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s, %d x %d B %s blocks per GPU (BASELINE configs[1]), %s data%s, LZ4 ratio %.3f, batched C-ABI launch, HBM-resident" % (
+                wl, n_local, bs, name.upper(), args.data, (" ratio=%.2f" % args.ratio) if args.data == "fragments" else "", plain_bytes_local / comp_bytes_local),
+            "blocks_per_gpu": n_local, "block_bytes": bs, "distinct_blocks": pool_n, "compression_ratio": round(plain_bytes_local / comp_bytes_local, 4),
+            "parallelism": "block-sharded x%d, no collective" % world,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None, "kernel": "%s_kernel" % wl, "kernel_ms_avg": round(kavg * 1e3, 4), "algorithmic_bytes_per_launch": alg_bytes,
+            "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
+        },
+    }
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            t = json.load(open(tpath)).get(wl)
+            if t and t.get("blocks") == n_local:
+                result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = t.get("source")
+        except Exception:
+            pass
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        result["extra"] = extras(torch, A, codec, dev, args)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(torch, pool_pack, pool_pack_off, pool_clen, pool_plain, bs, op, wl, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def extras(torch, A, codec, dev, args):
+    """Secondary numbers in the same run (smaller batches, same measurement): other codecs/directions and text-like data."""
+    out = {}
+    lib = codec.lib
+    bs = args.block_size
+    n = 16384
+    for data_kind in ("fragments", "wordmix"):
+        plain = gen_fragments(torch, dev, n, bs, args.ratio, 977) if data_kind == "fragments" else gen_wordmix(torch, dev, n, bs, 977)
+        for name, cop, dop in (("lz4", A.OP_LZ4_COMPRESS, A.OP_LZ4_DECOMPRESS), ("snappy", A.OP_SNAPPY_COMPRESS, A.OP_SNAPPY_DECOMPRESS)):
+            max_c = getattr(lib, "achip_%s_max_compressed_length" % name)(bs)
+            cstride = (max_c + 15) // 16 * 16
+            i64 = dict(dtype=torch.int64, device=dev)
+            i32 = dict(dtype=torch.int32, device=dev)
+            p_off = torch.arange(n, **i64) * bs
+            p_len = torch.full((n,), bs, **i32)
+            c_off = torch.arange(n, **i64) * cstride
+            c_cap = torch.full((n,), max_c, **i32)
+            comp = torch.empty(n * cstride + 64, dtype=torch.uint8, device=dev)
+            clen = torch.zeros(n, **i32)
+            st = torch.zeros(n, **i32)
+            eo = torch.zeros(n, **i64)
+            back = torch.empty(n * bs + 64, dtype=torch.uint8, device=dev)
+            blen = torch.zeros(n, **i32)
+            torch.cuda.synchronize()
+
+            def timed(fn, iters=3):
+                fn()
+                codec.synchronize()
+                e0, e1 = codec.event(), codec.event()
+                codec.record(e0)
+                for _ in range(iters):
+                    fn()
+                codec.record(e1)
+                return codec.elapsed_ms(e0, e1) / iters * 1e-3
+
+            tc = timed(lambda: codec.launch(cop, plain, p_off, p_len, comp, c_off, c_cap, clen, st, eo, n), iters=2)
+            assert int((st != 0).sum()) == 0
+            cbytes = int(clen.to(torch.int64).sum())
+            td = timed(lambda: codec.launch(dop, comp, c_off, clen, back, p_off, p_len, blen, st, eo, n))
+            assert int((st != 0).sum()) == 0 and bool((back[:n * bs] == plain).all())
+            key = "%s_%s" % (name, data_kind)
+            out[key] = {
+                "ratio": round(n * bs / cbytes, 3),
+                "compress_GiBps": round(n * bs / tc / 2**30, 2), "compress_hbm_frac": round((n * bs + cbytes) / tc / 1e9 / HBM_PEAK_GBS, 4),
+                "decompress_GiBps": round(n * bs / td / 2**30, 2), "decompress_hbm_frac": round((n * bs + cbytes) / td / 1e9 / HBM_PEAK_GBS, 4),
+                "blocks": n,
+            }
+            del comp, back
+    return out
+
+
+def cpu_baseline(torch, pool_pack, pool_pack_off, pool_clen, pool_plain, bs, op, wl, seconds):
+    """The oracle (C restatement of the Java codec -- no JVM on this box) on the host cores, same blocks, bounded sample."""
+    from concurrent.futures import ThreadPoolExecutor
+    from tests import oracle_lib
+    o = oracle_lib.load()
+    n = int(pool_clen.numel())
+    sample = min(n, 2048)
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    if wl.endswith("decompress"):
+        end = int(pool_pack_off[sample - 1].item()) + int(pool_clen[sample - 1].item())
+        src = pool_pack[:end].cpu().numpy()
+        src_off = pool_pack_off[:sample].cpu().numpy().astype(np.int64)
+        src_len = pool_clen[:sample].cpu().numpy().astype(np.int32)
+        cap = bs
+    else:
+        src = pool_plain[:sample * bs].cpu().numpy()
+        src_off = (np.arange(sample, dtype=np.int64) * bs)
+        src_len = np.full(sample, bs, dtype=np.int32)
+        cap = int(o.max_compressed_length("lz4" if wl.startswith("lz4") else "snappy", bs))
+    dst_off = np.arange(sample, dtype=np.int64) * ((cap + 15) // 16 * 16)
+    dst_cap = np.full(sample, cap, dtype=np.int32)
+    dst = np.zeros(int(dst_off[-1]) + cap + 64, dtype=np.uint8)
+    per = (sample + threads - 1) // threads
+    slices = [(i, min(sample, i + per)) for i in range(0, sample, per)]
+
+    def work(sl):
+        a, b = sl
+        return o.batch(op, src, src_off[a:b], src_len[a:b], dst, dst_off[a:b], dst_cap[a:b])[3]
+
+    def one_pass(pool):
+        return sum(pool.map(work, slices)) if pool else work((0, sample))
+
+    # single thread
+    t0 = time.perf_counter()
+    passes1 = 0
+    while time.perf_counter() - t0 < seconds * 0.35 or passes1 == 0:
+        one_pass(None)
+        passes1 += 1
+    t1 = (time.perf_counter() - t0) / passes1
+    with ThreadPoolExecutor(threads) as pool:
+        one_pass(pool)  # warm
+        t0 = time.perf_counter()
+        passes = 0
+        while time.perf_counter() - t0 < seconds * 0.65 or passes == 0:
+            one_pass(pool)
+            passes += 1
+        tN = (time.perf_counter() - t0) / passes
+    plain = sample * bs
+    return {
+        "value": round(plain / tN / 2**30, 3), "unit": "GiB/s", "cores": threads, "kind": "port",
+        "value_1_thread": round(plain / t1 / 2**30, 3),
+        "sample": "%d of the same %d-byte blocks (%s), oracle/liboracle.so = C restatement of the Java codec (no JVM on the box); %d passes x %d threads, %d passes x 1 thread" % (
+            sample, bs, wl, passes, threads, passes1),
+    }
+
+
+if __name__ == "__main__":
+    main()

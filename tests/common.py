@@ -1,0 +1,68 @@
+"""Shared test inputs: the reference harness' hand cases, the committed corpus sample, synthetic blocks."""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+# T/AbstractTestCompression.java:47-56
+HAND_CASES = [
+    ("nothing", b""),
+    ("short literal", b"hello world!"),
+    ("small copy", b"XXXXabcdabcdABCDABCDwxyzwzyz123"),
+    ("long copy", b"XXXXabcdefgh abcdefgh abcdefgh abcdefgh abcdefgh abcdefgh ABC"),
+    ("long literal", bytes(range(256))),
+]
+
+
+def corpus_sample():
+    """[(name, bytes, index_entry)] -- 64 KiB slices of the reference's corpora (tools/make_golden.py)."""
+    blob = open(os.path.join(GOLDEN, "corpus_sample.bin"), "rb").read()
+    index = json.load(open(os.path.join(GOLDEN, "corpus_sample.json")))
+    return [("%s@%d" % (e["file"], e["offset"]), blob[e["blob_offset"]:e["blob_offset"] + e["length"]], e) for e in index]
+
+
+def golden_zstd(name):
+    return open(os.path.join(GOLDEN, "zstd", name), "rb").read()
+
+
+def synthetic_blocks(seed, n_blocks, block_size=65536):
+    """Mixed-statistics blocks: random-fragment data at several compressibilities (the shape of
+    T/snappy/RandomGenerator.java), word-soup text, long runs, pure noise; ragged sizes at the end."""
+    rng = np.random.default_rng(seed)
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(2000)]
+    out = []
+    for b in range(n_blocks):
+        kind = b % 6
+        if kind == 0:  # fragments: raw bytes repeated to 100
+            ratio = [0.1, 0.25, 0.5, 0.75, 1.0][(b // 6) % 5]
+            raw = max(1, int(100 * ratio))
+            frags = rng.integers(0, 256, size=(block_size // 100 + 1, raw), dtype=np.uint8)
+            data = np.tile(frags, (1, 100 // raw + 1))[:, :100].reshape(-1)[:block_size].tobytes()
+        elif kind == 1:  # zipf word soup
+            ids = np.minimum(rng.zipf(1.3, size=block_size // 3), len(words)) - 1
+            data = b" ".join(words[i] for i in ids)[:block_size]
+        elif kind == 2:  # runs of a single byte with noise
+            data = bytearray()
+            while len(data) < block_size:
+                data += bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 600))
+                data += rng.integers(0, 256, size=int(rng.integers(0, 20)), dtype=np.uint8).tobytes()
+            data = bytes(data[:block_size])
+        elif kind == 3:  # noise
+            data = rng.integers(0, 256, size=block_size, dtype=np.uint8).tobytes()
+        elif kind == 4:  # short-period repeats (overlapping matches, offsets 1..40)
+            data = bytearray()
+            while len(data) < block_size:
+                p = rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8).tobytes()
+                data += p * int(rng.integers(2, 60))
+            data = bytes(data[:block_size])
+        else:  # low-entropy bytes (few symbols)
+            data = rng.integers(0, 4, size=block_size, dtype=np.uint8).tobytes()
+        out.append(data)
+    # ragged tail sizes
+    for n in (0, 1, 2, 12, 13, 14, 64, 255, 4097, 65535):
+        if n <= block_size:
+            out.append(out[len(out) % max(1, n_blocks)][:n] if n_blocks else b"")
+    return out

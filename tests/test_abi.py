@@ -1,0 +1,126 @@
+"""The C-ABI shared library: loads, exports every symbol include/*.h declares, host-only helpers
+agree with the oracle, and the codecs fail loudly without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import common, oracle_lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build_library()
+    import aircompressor_amd as A
+    return A.load_library()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "aircompressor_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(achip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 40
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "aircompressor_amd", "libaircompressor_hip.so")],
+                         check=True, capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\bT (achip_[a-z0-9_]+)", out))
+    missing = [n for n in names if n not in exported]
+    assert not missing, missing
+    from aircompressor_amd import native
+    assert sorted(native.SIGNATURES) == names  # the Python binding types exactly the declared surface
+
+
+def test_no_torch_or_oracle_in_product():
+    # the product library depends on libamdhip64 only; the package never touches oracle/
+    out = subprocess.run(["ldd", os.path.join(ROOT, "aircompressor_amd", "libaircompressor_hip.so")], capture_output=True, text=True).stdout
+    assert "torch" not in out and "oracle" not in out
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "aircompressor_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower() or f == "errors.py", (dirpath, f)
+                assert "import torch" not in text, (dirpath, f)
+
+
+def test_size_helpers_match_reference_kats(lib):
+    # T/zstd/AbstractTestZstd.java:140-147 + SURVEY Appendix B
+    assert lib.achip_zstd_max_compressed_length(0) == 64
+    assert lib.achip_zstd_max_compressed_length(64 * 1024) == 65_824
+    assert lib.achip_zstd_max_compressed_length(128 * 1024) == 131_584
+    assert lib.achip_zstd_max_compressed_length(128 * 1024 + 1) == 131_585
+    assert lib.achip_lz4_max_compressed_length(65536) == 65_809
+    assert lib.achip_snappy_max_compressed_length(65536) == 76_490
+    o = oracle_lib.load()
+    for n in (0, 1, 5, 254, 255, 256, 65535, 65536, 131072, 1 << 20, 0x7E000000):
+        for codec in ("lz4", "snappy", "zstd"):
+            got = getattr(lib, "achip_%s_max_compressed_length" % codec)(n)
+            assert got == ctypes.c_int32(o.max_compressed_length(codec, n)).value
+
+
+def test_status_helpers(lib):
+    st = -(1 + 16 * 5)
+    assert lib.achip_status_class(st) == 1 and lib.achip_status_detail(st) == 5
+    assert lib.achip_detail_message(5) == b"offset outside destination buffer"
+    assert lib.achip_status_class(12) == 0
+    assert lib.achip_version().startswith(b"aircompressor-hip")
+
+
+def test_snappy_uncompressed_length(lib):
+    o = oracle_lib.load()
+    for data in (b"", b"x", b"hello" * 1000, bytes(70000)):
+        c = np.frombuffer(o.compress("snappy", data), dtype=np.uint8)
+        eo = ctypes.c_int64()
+        assert lib.achip_snappy_uncompressed_length(c.ctypes.data, len(c), ctypes.byref(eo)) == len(data)
+    bad = np.frombuffer(bytes([0xFF] * 5), dtype=np.uint8)
+    eo = ctypes.c_int64()
+    r = lib.achip_snappy_uncompressed_length(bad.ctypes.data, 5, ctypes.byref(eo))
+    assert lib.achip_status_detail(r) == 18
+    r = lib.achip_snappy_uncompressed_length(bad.ctypes.data, 1, ctypes.byref(eo))
+    assert lib.achip_status_detail(r) == 17
+
+
+def test_zstd_decompressed_size(lib):
+    o = oracle_lib.load()
+    for name in ("with-checksum.zst", "multiple-frames.zst", "offset-before-start.zst"):
+        z = np.frombuffer(common.golden_zstd(name), dtype=np.uint8)
+        eo = ctypes.c_int64()
+        eo2 = ctypes.c_int64()
+        assert lib.achip_zstd_decompressed_size(z.ctypes.data, len(z), ctypes.byref(eo)) == \
+            o.lib.orc_zstd_decompressed_size(z.ctypes.data, len(z), ctypes.byref(eo2))
+    junk = np.frombuffer(b"\x00\x01\x02\x03\x04\x05", dtype=np.uint8)
+    eo = ctypes.c_int64()
+    r = lib.achip_zstd_decompressed_size(junk.ctypes.data, 6, ctypes.byref(eo))
+    assert lib.achip_status_detail(r) == 35
+
+
+def test_partition_blocks():
+    import aircompressor_amd as A
+    w = np.full(1000, 65536 + 30000, dtype=np.int64)
+    for parts in (1, 2, 4, 8):
+        s = A.partition_blocks(w, parts)
+        assert s[0] == 0 and s[-1] == 1000 and all(s[i] <= s[i + 1] for i in range(parts))
+        sizes = np.diff(s)
+        assert sizes.max() - sizes.min() <= 1
+    s = A.partition_blocks([1, 1, 1, 1, 10, 1, 1, 1], 2)
+    assert list(s) == [0, 5, 8]
+    assert list(A.partition_blocks([], 4)) == [0, 0, 0, 0, 0]
+
+
+def test_codecs_fail_loudly_without_gpu(lib):
+    import aircompressor_amd as A
+    if lib.achip_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    assert not A.Lz4HipCompressor.is_enabled()
+    with pytest.raises(A.HipUnavailableError):
+        A.Lz4HipCompressor()
+    with pytest.raises(A.HipUnavailableError):
+        A.HipBatchCodec()

