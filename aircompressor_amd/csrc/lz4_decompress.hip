@@ -31,14 +31,14 @@ __global__ __launch_bounds__(256) void lz4_decompress_kernel(BatchArgs a)
     const int32_t outLimit = a.dstCap[block];
 
     int32_t st = 0;
-    int64_t eo = 0;
+    int32_t eo = 0;  // 32-bit on purpose: hipcc (ROCm 7.2) mis-merged a 64-bit error offset across the divergent breaks for GS=8/64
     int32_t ip = 0;
     int32_t op = 0;
 
 #define LZ4_FAIL(detail, off)                          \
     {                                                  \
         st = mk_status(ACHIP_CLASS_MALFORMED, detail); \
-        eo = (off);                                    \
+        eo = (int32_t)(off);                                  \
         break;                                         \
     }
 
@@ -115,12 +115,12 @@ __global__ __launch_bounds__(256) void lz4_decompress_kernel(BatchArgs a)
     if (g == 0) {
         a.outLen[block] = st == 0 ? op : 0;
         a.status[block] = st;
-        a.errOffset[block] = eo;
+        a.errOffset[block] = (int64_t)eo;
     }
 }
 
 template <int GS>
-static hipError_t launch_gs(const BatchArgs& a, hipStream_t stream)
+static hipError_t lz4d_launch_gs(const BatchArgs& a, hipStream_t stream)
 {
     constexpr int GROUPS_PER_WG = 256 / GS;
     const unsigned grid = (unsigned)((a.nBlocks + GROUPS_PER_WG - 1) / GROUPS_PER_WG);
@@ -131,13 +131,13 @@ static hipError_t launch_gs(const BatchArgs& a, hipStream_t stream)
 hipError_t launch_lz4_decompress(const BatchArgs& a, hipStream_t stream, int groupSize)
 {
     switch (groupSize) {
-        case 1: return launch_gs<1>(a, stream);
-        case 2: return launch_gs<2>(a, stream);
-        case 4: return launch_gs<4>(a, stream);
-        case 16: return launch_gs<16>(a, stream);
-        case 32: return launch_gs<32>(a, stream);
-        case 64: return launch_gs<64>(a, stream);
-        default: return launch_gs<8>(a, stream);
+        case 1: return lz4d_launch_gs<1>(a, stream);
+        case 2: return lz4d_launch_gs<2>(a, stream);
+        case 4: return lz4d_launch_gs<4>(a, stream);
+        case 16: return lz4d_launch_gs<16>(a, stream);
+        case 32: return lz4d_launch_gs<32>(a, stream);
+        case 64: return lz4d_launch_gs<64>(a, stream);
+        default: return lz4d_launch_gs<8>(a, stream);
     }
 }
 

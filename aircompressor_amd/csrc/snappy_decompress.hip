@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void snappy_decompress_kernel(BatchArgs a)
     const int32_t outLimit = a.dstCap[block];
 
     int32_t st = 0;
-    int64_t eo = 0;
+    int32_t eo = 0;  // 32-bit on purpose: hipcc (ROCm 7.2) mis-merged a 64-bit error offset across the divergent breaks for GS=8/64
     int32_t op = 0;
 
     // readUncompressedLength :277-321
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void snappy_decompress_kernel(BatchArgs a)
     for (int i = 0; i < 5; i++) {
         if (nread >= inLen0) {
             st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_TRUNCATED);
-            eo = (int64_t)inLen0 - nread;
+            eo = inLen0 - nread;
             break;
         }
         const uint32_t b = in0[nread++];
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void snappy_decompress_kernel(BatchArgs a)
 #define SN_FAIL(off)                                                       \
     {                                                                      \
         st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_MALFORMED);   \
-        eo = (off);                                                        \
+        eo = (int32_t)(off);                                                      \
         break;                                                             \
     }
         while (ip < inLimit) {
@@ -137,12 +137,12 @@ __global__ __launch_bounds__(256) void snappy_decompress_kernel(BatchArgs a)
     if (g == 0) {
         a.outLen[block] = st == 0 ? op : 0;
         a.status[block] = st;
-        a.errOffset[block] = eo;
+        a.errOffset[block] = (int64_t)eo;
     }
 }
 
 template <int GS>
-static hipError_t launch_gs(const BatchArgs& a, hipStream_t stream)
+static hipError_t snd_launch_gs(const BatchArgs& a, hipStream_t stream)
 {
     constexpr int GROUPS_PER_WG = 256 / GS;
     const unsigned grid = (unsigned)((a.nBlocks + GROUPS_PER_WG - 1) / GROUPS_PER_WG);
@@ -153,13 +153,13 @@ static hipError_t launch_gs(const BatchArgs& a, hipStream_t stream)
 hipError_t launch_snappy_decompress(const BatchArgs& a, hipStream_t stream, int groupSize)
 {
     switch (groupSize) {
-        case 1: return launch_gs<1>(a, stream);
-        case 2: return launch_gs<2>(a, stream);
-        case 4: return launch_gs<4>(a, stream);
-        case 16: return launch_gs<16>(a, stream);
-        case 32: return launch_gs<32>(a, stream);
-        case 64: return launch_gs<64>(a, stream);
-        default: return launch_gs<8>(a, stream);
+        case 1: return snd_launch_gs<1>(a, stream);
+        case 2: return snd_launch_gs<2>(a, stream);
+        case 4: return snd_launch_gs<4>(a, stream);
+        case 16: return snd_launch_gs<16>(a, stream);
+        case 32: return snd_launch_gs<32>(a, stream);
+        case 64: return snd_launch_gs<64>(a, stream);
+        default: return snd_launch_gs<8>(a, stream);
     }
 }
 

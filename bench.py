@@ -73,10 +73,10 @@ def gen_wordmix(torch, dev, n_blocks, block_size, seed):
     pos = torch.arange(12, device=dev).unsqueeze(0)
     letters = torch.where(pos < wl.unsqueeze(1), letters, torch.where(pos == wl.unsqueeze(1), torch.full_like(letters, 32), torch.full_like(letters, 255)))
     total = n_blocks * block_size
-    need = int(total / 6.0) + 4096
     out = []
     produced = 0
     while produced < total:
+        need = min(int((total - produced) / 6.0) + 4096, 1 << 26)  # masked-select chunks stay far below 2^31 elements
         u = torch.rand((need,), device=dev, generator=g)
         ids = (vocab ** u - 1).long().clamp_(0, vocab - 1)  # log-uniform ~ Zipf(1)
         w = letters[ids].reshape(-1)

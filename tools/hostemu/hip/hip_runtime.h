@@ -1,0 +1,30 @@
+// Host shim used ONLY by tools/hostemu: lets the single-lane (GS=1) instantiations of the decoder
+// kernels be compiled with g++ and stepped through on the CPU while debugging.  Not part of the product.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+extern thread_local dim3 threadIdx, blockIdx, blockDim;
+typedef int hipError_t;
+typedef void* hipStream_t;
+#define hipSuccess 0
+inline hipError_t hipGetLastError() { return 0; }
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)              \
+    do {                                                                         \
+        blockDim = block;                                                        \
+        for (unsigned bx_ = 0; bx_ < dim3(grid).x; bx_++)                        \
+            for (unsigned tx_ = 0; tx_ < dim3(block).x; tx_++) {                 \
+                blockIdx = dim3(bx_);                                            \
+                threadIdx = dim3(tx_);                                           \
+                kernel(__VA_ARGS__);                                             \
+            }                                                                    \
+    } while (0)
+inline void __syncthreads() {}
+inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
+template <typename T> inline T __shfl(T v, int) { return v; }
