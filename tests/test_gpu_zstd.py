@@ -1,0 +1,144 @@
+"""GPU parity tests (through the C ABI) for the Zstd frame decoder against the CPU oracle and the reference's
+golden decoder fixtures (T/zstd/AbstractTestZstd.java:41-78,175-184).  Frames with diverse features come from
+libzstd via pyarrow (a third-party encoder, like zstd-jni in T/zstd/TestZstd.java:21-47)."""
+import numpy as np
+import pytest
+
+from tests import common, oracle_lib
+from tests.oracle_lib import OracleError
+
+pytestmark = pytest.mark.gpu
+OP_ZSTD_DECOMPRESS = 4
+
+
+@pytest.fixture(scope="module")
+def gb():
+    from tests.gpu_harness import GpuBatch
+    return GpuBatch(0)
+
+
+@pytest.fixture(scope="module")
+def o():
+    return oracle_lib.load()
+
+
+def zstd_frames(blocks, level):
+    import pyarrow as pa
+    codec = pa.Codec("zstd", compression_level=level)
+    return [codec.compress(b, asbytes=True) if len(b) else codec.compress(b"", asbytes=True) for b in blocks]
+
+
+def plain_blocks():
+    sample = [d for _, d, _ in common.corpus_sample()]
+    blocks = list(sample)
+    blocks += [sample[i] + sample[i + 1] for i in range(0, len(sample) - 1, 2)]  # 128 KiB: one full zstd block
+    blocks += common.synthetic_blocks(21, 18)
+    blocks += [d for _, d in common.HAND_CASES]
+    return blocks
+
+
+def test_golden_fixtures(gb, o):
+    z1, p1 = common.golden_zstd("with-checksum.zst"), common.golden_zstd("with-checksum")
+    z2, p2 = common.golden_zstd("multiple-frames.zst"), common.golden_zstd("multiple-frames")
+    outs, status, err = gb.run(OP_ZSTD_DECOMPRESS, [z1, z2, z1, z2], [len(p1), len(p2), len(p1) + 500, len(p2) + 1], unaligned=True)
+    assert status == [0, 0, 0, 0], (status, err)
+    assert outs[0] == p1 and outs[2] == p1 and outs[1] == p2 and outs[3] == p2
+
+
+def _expect(o, data, cap):
+    try:
+        return 0, 0, o.decompress("zstd", data, cap)
+    except OracleError as e:
+        return e.status, e.offset, None
+
+
+def test_error_fixtures_and_corruptions(gb, o):
+    rng = np.random.default_rng(5)
+    z1, p1 = common.golden_zstd("with-checksum.zst"), common.golden_zstd("with-checksum")
+    cases = [
+        (common.golden_zstd("offset-before-start.zst"), 1 << 20),  # "Input is corrupted"
+        (common.golden_zstd("bad-second-frame.zst"), 1 << 20),      # "Invalid magic prefix"
+        (z1, len(p1) - 1),                                          # "Output buffer too small"
+        (z1[:-1], len(p1)), (z1[:-4], len(p1)), (z1[:100], len(p1)), (z1[:3], 10), (b"", 10), (z1, 0),
+        (b"\x27\xb5\x2f\xfd" + z1[4:], len(p1)),                    # v0.7 magic
+        (z1[:4] + bytes([z1[4] | 1]) + z1[5:], len(p1)),            # dictionary id flag
+    ]
+    bad_sum = bytearray(z1)
+    bad_sum[-2] ^= 0x40
+    cases.append((bytes(bad_sum), len(p1)))
+    frames = zstd_frames([d for _, d, _ in common.corpus_sample()[:5]], 3)
+    plains = [d for _, d, _ in common.corpus_sample()[:5]]
+    for z, p in zip(frames, plains):
+        cases.append((z, len(p) - 7))
+        for cut in (len(z) // 3, len(z) - 2):
+            cases.append((z[:cut], len(p)))
+        for _ in range(10):
+            m = bytearray(z)
+            for _ in range(int(rng.integers(1, 3))):
+                m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+            cases.append((bytes(m), len(p)))
+    outs, status, err = gb.run(OP_ZSTD_DECOMPRESS, [c for c, _ in cases], [cap for _, cap in cases])
+    for i, (c, cap) in enumerate(cases):
+        est, eoff, eout = _expect(o, c, cap)
+        assert status[i] == est, "case %d: gpu status %d oracle %d (gpu offset %d, oracle %d)" % (i, status[i], est, err[i], eoff)
+        if est == 0:
+            assert outs[i] == eout, "case %d" % i
+        else:
+            assert err[i] == eoff, "case %d: gpu offset %d oracle %d" % (i, err[i], eoff)
+
+
+@pytest.mark.parametrize("level", [1, 3, 9])
+def test_libzstd_frames_decode_to_plaintext(gb, o, level):
+    blocks = plain_blocks()
+    frames = zstd_frames(blocks, level)
+    for pad in (0, 64):
+        outs, status, err = gb.run(OP_ZSTD_DECOMPRESS, frames, [len(b) + pad for b in blocks], unaligned=(pad == 0))
+        for i, (b, p, s) in enumerate(zip(blocks, outs, status)):
+            assert s == 0, (i, len(b), s, err[i])
+            assert p == b, "block %d (len %d)" % (i, len(b))
+    for b, z in list(zip(blocks, frames))[:8]:
+        assert o.decompress("zstd", z, len(b)) == b
+
+
+def test_multi_block_frames_and_concatenated_frames(gb, o):
+    whole = b"".join(d for _, d, _ in common.corpus_sample())  # ~1.2 MB: ten 128 KiB blocks with cross-block history
+    frames = zstd_frames([whole, whole[:300000], whole[100000:100000 + 131073]], 3)
+    cat = frames[1] + frames[2] + zstd_frames([b""], 3)[0] + frames[1]
+    plain_cat = whole[:300000] + whole[100000:100000 + 131073] + whole[:300000]
+    outs, status, err = gb.run(OP_ZSTD_DECOMPRESS, frames + [cat], [len(whole), 300000, 131073, len(plain_cat)])
+    assert status == [0, 0, 0, 0], (status, err)
+    assert outs[0] == whole and outs[1] == whole[:300000] and outs[2] == whole[100000:100000 + 131073] and outs[3] == plain_cat
+    assert o.decompress("zstd", cat, len(plain_cat)) == plain_cat
+
+
+def test_single_block_host_api(o):
+    import aircompressor_amd as A
+    z1, p1 = common.golden_zstd("with-checksum.zst"), common.golden_zstd("with-checksum")
+    d = A.ZstdHipDecompressor()
+    out = bytearray(len(p1) + 9)
+    n = d.decompress(z1, 0, len(z1), out, 9, len(p1))
+    assert n == len(p1) and bytes(out[9:]) == p1
+    assert d.get_decompressed_size(z1, 0, len(z1)) == -1
+    with pytest.raises(A.MalformedInputException) as e:
+        d.decompress(common.golden_zstd("offset-before-start.zst"), 0, 1559, bytearray(1 << 16), 0, 1 << 16)
+    assert str(e.value).startswith("Input is corrupted")
+    with pytest.raises(A.MalformedInputException) as e:
+        z = common.golden_zstd("bad-second-frame.zst")
+        d.decompress(z, 0, len(z), bytearray(1 << 16), 0, 1 << 16)
+    assert str(e.value).startswith("Invalid magic prefix")
+
+
+def test_many_frames_full_size_property(gb, o):
+    """1024 x 128 KiB frames (libzstd level 3) -> GPU decode must restore every block (checked by hash)."""
+    import hashlib
+    rng = np.random.default_rng(77)
+    sample = b"".join(d for _, d, _ in common.corpus_sample())
+    blocks = []
+    for i in range(256):
+        off = int(rng.integers(0, len(sample) - 131072))
+        blocks.append(sample[off:off + 131072])
+    frames = zstd_frames(blocks, 3)
+    outs, status, err = gb.run(OP_ZSTD_DECOMPRESS, frames * 4, [131072] * 1024)
+    assert all(s == 0 for s in status)
+    want = [hashlib.sha256(b).digest() for b in blocks] * 4
+    assert [hashlib.sha256(p).digest() for p in outs] == want
