@@ -17,6 +17,8 @@
 namespace achip {
 hipError_t launch_lz4_decompress(const BatchArgs& a, hipStream_t stream, int groupSize);
 hipError_t launch_snappy_decompress(const BatchArgs& a, hipStream_t stream, int groupSize);
+hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass);
+hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
 hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant);
 hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
@@ -29,8 +31,11 @@ struct achip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     // options
-    int lz4dGroup = 8;
-    int snappydGroup = 8;
+    int lz4dGroup = 16;
+    int snappydGroup = 16;
+    int lz4dVariant = 1;     // 0 = direct-to-HBM groups (lz4_decompress.hip), 1 = LDS rings (lz4_decompress_v2.hip)
+    int snappydVariant = 1;
+    int ringClass = 0;       // 0 = compact rings, 1 = large rings
     int lz4cVariant = 0;
     int snappycVariant = 0;
     int zstddVariant = 0;
@@ -142,9 +147,15 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& a)
     HIP_TRY(hipSetDevice(ctx->device));
     hipError_t e = hipSuccess;
     switch (op) {
-        case ACHIP_OP_LZ4_DECOMPRESS: e = achip::launch_lz4_decompress(a, ctx->stream, ctx->lz4dGroup); break;
+        case ACHIP_OP_LZ4_DECOMPRESS:
+            e = ctx->lz4dVariant == 0 ? achip::launch_lz4_decompress(a, ctx->stream, ctx->lz4dGroup)
+                                      : achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass);
+            break;
         case ACHIP_OP_LZ4_COMPRESS: e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint); break;
-        case ACHIP_OP_SNAPPY_DECOMPRESS: e = achip::launch_snappy_decompress(a, ctx->stream, ctx->snappydGroup); break;
+        case ACHIP_OP_SNAPPY_DECOMPRESS:
+            e = ctx->snappydVariant == 0 ? achip::launch_snappy_decompress(a, ctx->stream, ctx->snappydGroup)
+                                         : achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass);
+            break;
         case ACHIP_OP_SNAPPY_COMPRESS: e = achip::launch_snappy_compress(a, ctx->stream, ctx->snappycVariant); break;
         case ACHIP_OP_ZSTD_DECOMPRESS: {
             int32_t r = ensure_scratch(ctx, achip::zstd_decompress_scratch_bytes(a.nBlocks));
@@ -388,6 +399,9 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         if (!pow2(value)) return bad_argument("group size must be a power of two in 1..64");
         ctx->snappydGroup = (int)value;
     }
+    else if (k == "lz4.decompress.variant") ctx->lz4dVariant = (int)value;
+    else if (k == "snappy.decompress.variant") ctx->snappydVariant = (int)value;
+    else if (k == "decompress.ring_class") ctx->ringClass = (int)value;
     else if (k == "lz4.compress.variant") ctx->lz4cVariant = (int)value;
     else if (k == "snappy.compress.variant") ctx->snappycVariant = (int)value;
     else if (k == "zstd.decompress.variant") ctx->zstddVariant = (int)value;

@@ -1,0 +1,180 @@
+// achip_rings.h -- LDS ring buffers for the streaming LZ77 decoders (v2 kernels).
+//
+// Every block (one GS-lane group of a wavefront) owns two rings in LDS:
+//   * an INPUT ring: the compressed stream is pulled from HBM exactly once, in 16-byte aligned
+//     granules, GS granules (GS*16 contiguous bytes) per refill -- coalesced, no partial lines;
+//   * an OUTPUT ring: the sliding history window.  Literal and match bytes are produced into it
+//     one byte per lane per step; completed GS*16-byte aligned chunks are flushed to HBM with one
+//     16-byte store per lane -- every output line is written once, whole.
+// Back-references that reach at most LDS_REACH bytes back are served from the output ring (LDS
+// latency, no memory traffic); farther ones re-read the block's own flushed output through L2.
+// All positions are "virtual": absolute position + (buffer address & 15), so that virtual 0 is a
+// 16-byte aligned address; ring index = virtual position & (RING-1).
+#pragma once
+#include "achip_device.h"
+
+namespace achip {
+
+template <int GS, int IN_RING, int OUT_RING>
+struct Rings {
+    static constexpr int CHUNK = GS * 16;                      // bytes per refill / flush / copy step
+    static constexpr int LDS_REACH = OUT_RING - CHUNK - 16;    // farthest back-reference served from the ring
+    static_assert((IN_RING & (IN_RING - 1)) == 0 && (OUT_RING & (OUT_RING - 1)) == 0, "rings are powers of two");
+    static_assert(IN_RING >= 2 * CHUNK && OUT_RING >= 4 * CHUNK, "ring too small for the chunk size");
+
+    uint8_t* inRing;
+    uint8_t* outRing;
+    const uint8_t* inAligned;  // in - inBase
+    uint8_t* outAligned;       // out - outBase
+    int32_t inBase, outBase;
+    int32_t inEndV;            // virtual end of the input
+    int32_t inLoadedV;         // input ring holds virtual [inLoadedV - IN_RING, inLoadedV)
+    int32_t flushedV;          // output flushed to HBM up to this virtual position (multiple of 16, or the final end)
+    int g;
+
+    __device__ __forceinline__ void init(uint8_t* ldsIn, uint8_t* ldsOut, const uint8_t* in, int32_t inLimit, uint8_t* out, int lane)
+    {
+        inRing = ldsIn;
+        outRing = ldsOut;
+        inBase = (int32_t)((uintptr_t)in & 15);
+        outBase = (int32_t)((uintptr_t)out & 15);
+        inAligned = in - inBase;
+        outAligned = out - outBase;
+        inEndV = inLimit + inBase;
+        inLoadedV = 0;
+        flushedV = 0;
+        g = lane;
+    }
+
+    // ---- input side ----
+    __device__ __forceinline__ void refill()
+    {
+        const int32_t v = inLoadedV + 16 * g;
+        u32x4 d = {0, 0, 0, 0};
+        if (v >= inBase && v + 16 <= inEndV) {
+            d = *(const u32x4*)(inAligned + v);  // aligned 16-byte granule, fully inside the input
+        }
+        else if (v + 16 > inBase && v < inEndV) {
+            uint8_t b[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int32_t p = v + i;
+                b[i] = (p >= inBase && p < inEndV) ? inAligned[p] : (uint8_t)0;
+            }
+            __builtin_memcpy(&d, b, 16);
+        }
+        *(u32x4*)(inRing + (v & (IN_RING - 1))) = d;
+        inLoadedV += CHUNK;
+    }
+    // make input bytes [pos, pos+need) readable from the ring (need <= CHUNK); bytes past the input end read as 0
+    __device__ __forceinline__ void ensure_input(int32_t pos, int32_t need)
+    {
+        const int32_t want = pos + inBase + need;
+        while (want > inLoadedV && inLoadedV < inEndV) {
+            refill();
+        }
+        wave_mem_order();
+    }
+    __device__ __forceinline__ uint32_t in_u8(int32_t pos) const { return inRing[(pos + inBase) & (IN_RING - 1)]; }
+
+    // ---- output side ----
+    __device__ __forceinline__ void out_put(int32_t pos, uint32_t byte) { outRing[(pos + outBase) & (OUT_RING - 1)] = (uint8_t)byte; }
+    __device__ __forceinline__ uint32_t out_get(int32_t pos) const { return outRing[(pos + outBase) & (OUT_RING - 1)]; }
+
+    // flush every complete CHUNK below position `op` (absolute)
+    __device__ __forceinline__ void flush_complete(int32_t op)
+    {
+        const int32_t opV = op + outBase;
+        wave_mem_order();
+        while (flushedV + CHUNK <= opV) {
+            const int32_t v = flushedV + 16 * g;
+            if (v >= outBase) {
+                *(u32x4*)(outAligned + v) = *(const u32x4*)(outRing + (v & (OUT_RING - 1)));
+            }
+            else if (v + 16 > outBase) {  // the granule straddling the start of the output buffer
+                for (int32_t p = outBase; p < v + 16; p++) {
+                    outAligned[p] = outRing[p & (OUT_RING - 1)];
+                }
+            }
+            flushedV += CHUNK;
+        }
+        wave_mem_order();
+    }
+    // flush everything up to `op` (end of block)
+    __device__ __forceinline__ void flush_all(int32_t op)
+    {
+        flush_complete(op);
+        const int32_t opV = op + outBase;
+        const int32_t v = flushedV + 16 * g;
+        if (v < opV) {
+            if (v >= outBase && v + 16 <= opV) {
+                *(u32x4*)(outAligned + v) = *(const u32x4*)(outRing + (v & (OUT_RING - 1)));
+            }
+            else {
+                const int32_t lo = v > outBase ? v : outBase;
+                const int32_t hi = v + 16 < opV ? v + 16 : opV;
+                for (int32_t p = lo; p < hi; p++) {
+                    outAligned[p] = outRing[p & (OUT_RING - 1)];
+                }
+            }
+        }
+        flushedV = opV;
+        wave_mem_order();
+    }
+
+    // literals: n input bytes at ip -> output at op (n arbitrary; input ring refilled, output flushed as we go)
+    __device__ __forceinline__ void copy_literals(int32_t ip, int32_t op, int32_t n)
+    {
+        while (n > 0) {
+            const int32_t c = n < CHUNK ? n : CHUNK;
+            ensure_input(ip, c);
+            for (int32_t k = g; k < c; k += GS) {
+                out_put(op + k, in_u8(ip + k));
+            }
+            ip += c;
+            op += c;
+            n -= c;
+            flush_complete(op);
+        }
+    }
+
+    // back-reference: out[op+k] = out[op-offset+k], byte-sequential semantics, n arbitrary.
+    // Processed in chunks of <= CHUNK bytes.  Inside a chunk starting at c0 every byte j reads
+    // c0 - offset + (j mod offset): for offset >= chunk length that is the plain source, for shorter
+    // offsets the period is folded so all sources lie BEFORE the chunk (no intra-chunk dependency).
+    __device__ __forceinline__ void copy_match(int32_t op, int32_t offset, int32_t n)
+    {
+        int32_t c0 = op;
+        while (n > 0) {
+            const int32_t c = n < CHUNK ? n : CHUNK;
+            wave_mem_order();
+            if (offset <= LDS_REACH) {
+                if (offset >= c) {
+                    for (int32_t j = g; j < c; j += GS) {
+                        out_put(c0 + j, out_get(c0 - offset + j));
+                    }
+                }
+                else {
+                    // ceil(2^32 / offset): j / offset == umulhi(j, inv) exactly for j < CHUNK (offset == 1: quotient is j)
+                    const uint32_t inv = offset == 1 ? 0u : (0xFFFFFFFFu / (uint32_t)offset + 1u);
+                    for (int32_t j = g; j < c; j += GS) {
+                        const uint32_t q = offset == 1 ? (uint32_t)j : __umulhi((uint32_t)j, inv);
+                        out_put(c0 + j, out_get(c0 - offset + (j - (int32_t)q * offset)));
+                    }
+                }
+            }
+            else {
+                // far: offset > LDS_REACH >= 2*CHUNK, so the sources of this chunk were flushed to HBM at least CHUNK bytes ago
+                const uint8_t* src = outAligned + outBase + (c0 - offset);
+                for (int32_t j = g; j < c; j += GS) {
+                    out_put(c0 + j, src[j]);
+                }
+            }
+            c0 += c;
+            n -= c;
+            flush_complete(c0);
+        }
+    }
+};
+
+}  // namespace achip

@@ -44,6 +44,8 @@ def parse_args():
     p.add_argument("--workload", default="lz4_decompress", choices=["lz4_decompress", "snappy_decompress", "lz4_compress", "snappy_compress"])
     p.add_argument("--data", default="fragments", choices=["fragments", "wordmix"])
     p.add_argument("--group", type=int, default=0, help="decoder lanes per block (0 = library default)")
+    p.add_argument("--variant", type=int, default=-1, help="decoder variant: 1 = LDS rings (default), 0 = direct-to-HBM groups")
+    p.add_argument("--ring-class", type=int, default=-1, help="0 = compact LDS rings, 1 = large")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -114,6 +116,11 @@ def main():
     if args.group:
         codec.native.set_option("lz4.decompress.group", args.group)
         codec.native.set_option("snappy.decompress.group", args.group)
+    if args.variant >= 0:
+        codec.native.set_option("lz4.decompress.variant", args.variant)
+        codec.native.set_option("snappy.decompress.variant", args.variant)
+    if args.ring_class >= 0:
+        codec.native.set_option("decompress.ring_class", args.ring_class)
     codec.native.set_option("max_src_len_hint", bs)
 
     wl = args.workload

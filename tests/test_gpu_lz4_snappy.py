@@ -12,9 +12,18 @@ from tests.oracle_lib import OracleError
 pytestmark = pytest.mark.gpu
 
 CODECS = {
-    "lz4": dict(c=1, d=0, group_opt="lz4.decompress.group"),
-    "snappy": dict(c=3, d=2, group_opt="snappy.decompress.group"),
+    "lz4": dict(c=1, d=0, group_opt="lz4.decompress.group", variant_opt="lz4.decompress.variant"),
+    "snappy": dict(c=3, d=2, group_opt="snappy.decompress.group", variant_opt="snappy.decompress.variant"),
 }
+# decoder configurations: (variant, lanes per block, ring class); variant 1 = LDS rings (default), 0 = direct-to-HBM groups
+DECODERS = [(1, 16, 0), (1, 16, 1), (1, 8, 0), (1, 8, 1), (1, 32, 0), (1, 32, 1), (1, 64, 0), (1, 64, 1)] + [(0, g, 0) for g in (1, 2, 4, 8, 16, 32, 64)]
+
+
+def configure(gb, codec, cfg):
+    variant, group, ring = cfg
+    gb.set_option(CODECS[codec]["variant_opt"], variant)
+    gb.set_option(CODECS[codec]["group_opt"], group)
+    gb.set_option("decompress.ring_class", ring)
 
 
 @pytest.fixture(scope="module")
@@ -52,9 +61,9 @@ def test_compress_is_bit_exact_with_oracle(gb, o, codec):
 
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
-@pytest.mark.parametrize("group", [1, 2, 4, 8, 16, 32, 64])
-def test_decompress_matches_plaintext_all_group_sizes(gb, o, codec, group):
-    gb.set_option(CODECS[codec]["group_opt"], group)
+@pytest.mark.parametrize("cfg", DECODERS)
+def test_decompress_matches_plaintext_all_decoder_configs(gb, o, codec, cfg):
+    configure(gb, codec, cfg)
     blocks = [b for b in all_blocks() if not (codec == "lz4" and len(b) == 0)]
     comp = [o.compress(codec, b) for b in blocks]
     for pad in (0, 100):  # exact capacity and padded capacity (T/AbstractTestCompression.java:110-129)
@@ -63,7 +72,7 @@ def test_decompress_matches_plaintext_all_group_sizes(gb, o, codec, group):
         for i, (b, p, s) in enumerate(zip(blocks, outs, status)):
             assert s == 0, (i, len(b), s)
             assert p == b, "block %d (len %d)" % (i, len(b))
-    gb.set_option(CODECS[codec]["group_opt"], 8)
+    configure(gb, codec, DECODERS[0])
 
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
@@ -86,9 +95,11 @@ def _oracle_status(o, codec, data, cap):
 
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
-def test_malformed_inputs_report_the_reference_errors(gb, o, codec):
+@pytest.mark.parametrize("cfg", [(1, 16, 0), (1, 8, 1), (1, 64, 0), (0, 8, 0), (0, 64, 0)])
+def test_malformed_inputs_report_the_reference_errors(gb, o, codec, cfg):
     """Error KATs of the reference plus systematic corruption: status class/detail and offset must equal the oracle's
     (= what the Java decoder throws), and nothing is written outside the block's output."""
+    configure(gb, codec, cfg)
     rng = np.random.default_rng(99)
     cases = []
     if codec == "lz4":
@@ -127,6 +138,7 @@ def test_malformed_inputs_report_the_reference_errors(gb, o, codec):
             assert err[i] == eoff, "case %d: gpu offset %d oracle %d" % (i, err[i], eoff)
         else:
             assert outs[i] == eout, "case %d" % i
+    configure(gb, codec, DECODERS[0])
 
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Condenses a tools/profile.sh capture into the text summary committed under profiles/."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(root, pattern), recursive=True))
+
+
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for f in find("stats/**/*kernel_stats.csv"):
+    for row in csv.DictReader(open(f)):
+        print("%-70s calls=%s avg_ns=%s total_ns=%s pct=%s" % (row.get("Name", "")[:70], row.get("Calls"), row.get("AverageNs"), row.get("TotalDurationNs"), row.get("Percentage")))
+for line in open(os.path.join(root, "stats.log")).read().splitlines():
+    if line.startswith("{"):
+        r = json.loads(line)
+        print("bench under profiler: value=%s GiB/s kernel_ms_avg=%s" % (r["value"], r["roofline"]["kernel_ms_avg"]))
+
+print("== PMC counters per kernel (sum over dispatches / dispatches) ==")
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcp"):
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(int))
+    for f in find(d + "/**/*counter_collection.csv"):
+        for row in csv.DictReader(open(f)):
+            k = row.get("Kernel_Name", "")[:60]
+            acc[k][row.get("Counter_Name")] += float(row.get("Counter_Value", 0))
+            cnt[k][row.get("Counter_Name")] += 1
+    for k in acc:
+        if "decompress" not in k and "compress" not in k:
+            continue
+        for name, v in acc[k].items():
+            n = cnt[k][name]
+            print("%-12s %-60s %-32s per_dispatch=%.6g (n=%d)" % (d, k, name, v / max(n, 1), n))
+    log = os.path.join(root, d + ".log")
+    if os.path.exists(log):
+        tail = [l for l in open(log).read().splitlines() if "rror" in l][:3]
+        for l in tail:
+            print("   log:", l[:200])
