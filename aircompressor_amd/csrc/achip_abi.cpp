@@ -31,8 +31,8 @@ struct achip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     // options
-    int lz4dGroup = 16;
-    int snappydGroup = 16;
+    int lz4dGroup = 4;       // lanes per block: measured best on MI355X (profiles/r01_sweep_v2_rings.txt)
+    int snappydGroup = 4;
     int lz4dVariant = 1;     // 0 = direct-to-HBM groups (lz4_decompress.hip), 1 = LDS rings (lz4_decompress_v2.hip)
     int snappydVariant = 1;
     int ringClass = 0;       // 0 = compact rings, 1 = large rings

@@ -30,6 +30,7 @@ struct Rings {
     int32_t inEndV;            // virtual end of the input
     int32_t inLoadedV;         // input ring holds virtual [inLoadedV - IN_RING, inLoadedV)
     int32_t flushedV;          // output flushed to HBM up to this virtual position (multiple of 16, or the final end)
+    u32x4 pending;             // this lane's granule of the NEXT input chunk, requested one refill ahead (hides HBM latency)
     int g;
 
     __device__ __forceinline__ void init(uint8_t* ldsIn, uint8_t* ldsOut, const uint8_t* in, int32_t inLimit, uint8_t* out, int lane)
@@ -44,15 +45,15 @@ struct Rings {
         inLoadedV = 0;
         flushedV = 0;
         g = lane;
+        pending = fetch_granule(16 * g);
     }
 
-    // ---- input side ----
-    __device__ __forceinline__ void refill()
+    // this lane's 16-byte granule at virtual position v; bytes outside the input read as 0
+    __device__ __forceinline__ u32x4 fetch_granule(int32_t v) const
     {
-        const int32_t v = inLoadedV + 16 * g;
         u32x4 d = {0, 0, 0, 0};
         if (v >= inBase && v + 16 <= inEndV) {
-            d = *(const u32x4*)(inAligned + v);  // aligned 16-byte granule, fully inside the input
+            d = *(const u32x4*)(inAligned + v);  // aligned, fully inside the input: one coalesced CHUNK per group
         }
         else if (v + 16 > inBase && v < inEndV) {
             uint8_t b[16];
@@ -63,8 +64,16 @@ struct Rings {
             }
             __builtin_memcpy(&d, b, 16);
         }
-        *(u32x4*)(inRing + (v & (IN_RING - 1))) = d;
+        return d;
+    }
+
+    // ---- input side ----
+    __device__ __forceinline__ void refill()
+    {
+        const int32_t v = inLoadedV + 16 * g;
+        *(u32x4*)(inRing + (v & (IN_RING - 1))) = pending;  // requested during the previous refill
         inLoadedV += CHUNK;
+        pending = fetch_granule(v + CHUNK);
     }
     // make input bytes [pos, pos+need) readable from the ring (need <= CHUNK); bytes past the input end read as 0
     __device__ __forceinline__ void ensure_input(int32_t pos, int32_t need)
@@ -76,6 +85,16 @@ struct Rings {
         wave_mem_order();
     }
     __device__ __forceinline__ uint32_t in_u8(int32_t pos) const { return inRing[(pos + inBase) & (IN_RING - 1)]; }
+
+    // 4 bytes at an arbitrary virtual position of a ring: two aligned LDS dword reads + v_alignbyte
+    template <int RING>
+    static __device__ __forceinline__ uint32_t ring_ld4(const uint8_t* ring, int32_t pv)
+    {
+        const int32_t a = pv & ~3;
+        const uint32_t lo = *(const uint32_t*)(ring + (a & (RING - 1)));
+        const uint32_t hi = *(const uint32_t*)(ring + ((a + 4) & (RING - 1)));
+        return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(pv & 3));
+    }
 
     // ---- output side ----
     __device__ __forceinline__ void out_put(int32_t pos, uint32_t byte) { outRing[(pos + outBase) & (OUT_RING - 1)] = (uint8_t)byte; }
@@ -128,8 +147,25 @@ struct Rings {
         while (n > 0) {
             const int32_t c = n < CHUNK ? n : CHUNK;
             ensure_input(ip, c);
-            for (int32_t k = g; k < c; k += GS) {
-                out_put(op + k, in_u8(ip + k));
+            if (GS < 4 || c <= GS) {
+                for (int32_t k = g; k < c; k += GS) {
+                    out_put(op + k, in_u8(ip + k));
+                }
+            }
+            else {  // aligned destination dwords, funnel-shifted source; <= 3 head and <= 3 tail bytes one per lane
+                const int32_t dV = op + outBase, sV = ip + inBase;
+                const int32_t head = (4 - (dV & 3)) & 3;
+                const int32_t nd = (c - head) >> 2;
+                const int32_t t0 = head + 4 * nd;
+                if (g < head) {
+                    outRing[(dV + g) & (OUT_RING - 1)] = inRing[(sV + g) & (IN_RING - 1)];
+                }
+                for (int32_t j = g; j < nd; j += GS) {
+                    *(uint32_t*)(outRing + ((dV + head + 4 * j) & (OUT_RING - 1))) = ring_ld4<IN_RING>(inRing, sV + head + 4 * j);
+                }
+                if (g < c - t0) {
+                    outRing[(dV + t0 + g) & (OUT_RING - 1)] = inRing[(sV + t0 + g) & (IN_RING - 1)];
+                }
             }
             ip += c;
             op += c;
@@ -149,9 +185,24 @@ struct Rings {
             const int32_t c = n < CHUNK ? n : CHUNK;
             wave_mem_order();
             if (offset <= LDS_REACH) {
-                if (offset >= c) {
+                if (offset >= c && (GS < 4 || c <= GS)) {
                     for (int32_t j = g; j < c; j += GS) {
                         out_put(c0 + j, out_get(c0 - offset + j));
+                    }
+                }
+                else if (offset >= c) {
+                    const int32_t dV = c0 + outBase, sV = dV - offset;
+                    const int32_t head = (4 - (dV & 3)) & 3;
+                    const int32_t nd = (c - head) >> 2;
+                    const int32_t t0 = head + 4 * nd;
+                    if (g < head) {
+                        outRing[(dV + g) & (OUT_RING - 1)] = outRing[(sV + g) & (OUT_RING - 1)];
+                    }
+                    for (int32_t j = g; j < nd; j += GS) {
+                        *(uint32_t*)(outRing + ((dV + head + 4 * j) & (OUT_RING - 1))) = ring_ld4<OUT_RING>(outRing, sV + head + 4 * j);
+                    }
+                    if (g < c - t0) {
+                        outRing[(dV + t0 + g) & (OUT_RING - 1)] = outRing[(sV + t0 + g) & (OUT_RING - 1)];
                     }
                 }
                 else {
@@ -166,8 +217,25 @@ struct Rings {
             else {
                 // far: offset > LDS_REACH >= 2*CHUNK, so the sources of this chunk were flushed to HBM at least CHUNK bytes ago
                 const uint8_t* src = outAligned + outBase + (c0 - offset);
-                for (int32_t j = g; j < c; j += GS) {
-                    out_put(c0 + j, src[j]);
+                if (GS < 4 || c <= GS) {
+                    for (int32_t j = g; j < c; j += GS) {
+                        out_put(c0 + j, src[j]);
+                    }
+                }
+                else {
+                    const int32_t dV = c0 + outBase;
+                    const int32_t head = (4 - (dV & 3)) & 3;
+                    const int32_t nd = (c - head) >> 2;
+                    const int32_t t0 = head + 4 * nd;
+                    if (g < head) {
+                        outRing[(dV + g) & (OUT_RING - 1)] = src[g];
+                    }
+                    for (int32_t j = g; j < nd; j += GS) {
+                        *(uint32_t*)(outRing + ((dV + head + 4 * j) & (OUT_RING - 1))) = ld4(src + head + 4 * j);
+                    }
+                    if (g < c - t0) {
+                        outRing[(dV + t0 + g) & (OUT_RING - 1)] = src[t0 + g];
+                    }
                 }
             }
             c0 += c;

@@ -135,6 +135,7 @@ static hipError_t lz4d2_launch(const BatchArgs& a, hipStream_t stream)
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass)
 {
     switch (groupSize) {
+        case 4: return ringClass ? lz4d2_launch<4, 256, 512>(a, stream) : lz4d2_launch<4, 128, 256>(a, stream);
         case 8: return ringClass ? lz4d2_launch<8, 512, 1024>(a, stream) : lz4d2_launch<8, 256, 512>(a, stream);
         case 32: return ringClass ? lz4d2_launch<32, 2048, 4096>(a, stream) : lz4d2_launch<32, 1024, 2048>(a, stream);
         case 64: return ringClass ? lz4d2_launch<64, 4096, 8192>(a, stream) : lz4d2_launch<64, 2048, 4096>(a, stream);

@@ -151,6 +151,7 @@ static hipError_t snd2_launch(const BatchArgs& a, hipStream_t stream)
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass)
 {
     switch (groupSize) {
+        case 4: return ringClass ? snd2_launch<4, 256, 512>(a, stream) : snd2_launch<4, 128, 256>(a, stream);
         case 8: return ringClass ? snd2_launch<8, 512, 1024>(a, stream) : snd2_launch<8, 256, 512>(a, stream);
         case 32: return ringClass ? snd2_launch<32, 2048, 4096>(a, stream) : snd2_launch<32, 1024, 2048>(a, stream);
         case 64: return ringClass ? snd2_launch<64, 4096, 8192>(a, stream) : snd2_launch<64, 2048, 4096>(a, stream);
