@@ -1,0 +1,509 @@
+/*
+ * Licensed under the Apache License, Version 2.0 (the "License");
+ * you may not use this file except in compliance with the License.
+ * You may obtain a copy of the License at
+ *
+ *     http://www.apache.org/licenses/LICENSE-2.0
+ *
+ * Unless required by applicable law or agreed to in writing, software
+ * distributed under the License is distributed on an "AS IS" BASIS,
+ * WITHOUT WARRANTIES OR CONDITIONS OF ANY KIND, either express or implied.
+ * See the License for the specific language governing permissions and
+ * limitations under the License.
+ */
+package io.airlift.compress.v3.hip;
+
+import io.airlift.compress.v3.MalformedInputException;
+import io.airlift.compress.v3.internal.NativeLoader.Symbols;
+import io.airlift.compress.v3.internal.NativeSignature;
+
+import java.lang.foreign.Arena;
+import java.lang.foreign.MemorySegment;
+import java.lang.invoke.MethodHandle;
+import java.lang.ref.Cleaner;
+import java.util.Optional;
+
+import static io.airlift.compress.v3.internal.NativeLoader.loadSymbols;
+import static java.lang.foreign.ValueLayout.JAVA_LONG;
+import static java.lang.invoke.MethodHandles.lookup;
+
+/**
+ * FFM binding of {@code libaircompressor_hip.so} (C ABI: {@code include/aircompressor_hip.h}).
+ * <p>
+ * Built exactly like {@code Lz4Native}/{@code SnappyNative}/{@code ZstdNative}: a record of
+ * {@link NativeSignature}-annotated method handles resolved by {@code NativeLoader.loadSymbols},
+ * which extracts {@code /aircompressor/linux-amd64/libaircompressor_hip.so} from the class path.
+ * When the library or a HIP device is missing every handle throws {@link LinkageError} and
+ * {@link #isEnabled()} is false, so callers can fall back to the Java codecs the same way the
+ * {@code create()} factories do for the existing native codecs.
+ */
+public final class HipNative
+{
+    private HipNative() {}
+
+    // status = -(class + 16 * detail), see aircompressor_hip.h
+    public static final int CLASS_MALFORMED = 1;
+    public static final int CLASS_OUTPUT_TOO_SMALL = 2;
+    public static final int CLASS_INVALID_ARGUMENT = 3;
+    public static final int CLASS_DEVICE = 4;
+    public static final int DETAIL_LZ4_EMPTY_OUTPUT = 7;
+
+    public static final int OP_LZ4_DECOMPRESS = 0;
+    public static final int OP_LZ4_COMPRESS = 1;
+    public static final int OP_SNAPPY_DECOMPRESS = 2;
+    public static final int OP_SNAPPY_COMPRESS = 3;
+    public static final int OP_ZSTD_DECOMPRESS = 4;
+    public static final int OP_ZSTD_COMPRESS = 5;
+
+    private record MethodHandles(
+            @NativeSignature(name = "achip_device_count", returnType = int.class, argumentTypes = {})
+            MethodHandle deviceCount,
+            @NativeSignature(name = "achip_detail_message", returnType = MemorySegment.class, argumentTypes = int.class)
+            MethodHandle detailMessage,
+            @NativeSignature(name = "achip_last_error", returnType = MemorySegment.class, argumentTypes = {})
+            MethodHandle lastError,
+            @NativeSignature(name = "achip_lz4_max_compressed_length", returnType = int.class, argumentTypes = int.class)
+            MethodHandle lz4MaxCompressedLength,
+            @NativeSignature(name = "achip_snappy_max_compressed_length", returnType = int.class, argumentTypes = int.class)
+            MethodHandle snappyMaxCompressedLength,
+            @NativeSignature(name = "achip_zstd_max_compressed_length", returnType = int.class, argumentTypes = int.class)
+            MethodHandle zstdMaxCompressedLength,
+            @NativeSignature(name = "achip_snappy_uncompressed_length", returnType = long.class, argumentTypes = {MemorySegment.class, long.class, MemorySegment.class})
+            MethodHandle snappyUncompressedLength,
+            @NativeSignature(name = "achip_zstd_decompressed_size", returnType = long.class, argumentTypes = {MemorySegment.class, long.class, MemorySegment.class})
+            MethodHandle zstdDecompressedSize,
+            @NativeSignature(name = "achip_ctx_create", returnType = MemorySegment.class, argumentTypes = int.class)
+            MethodHandle ctxCreate,
+            @NativeSignature(name = "achip_ctx_destroy", returnType = void.class, argumentTypes = MemorySegment.class)
+            MethodHandle ctxDestroy,
+            @NativeSignature(name = "achip_ctx_synchronize", returnType = int.class, argumentTypes = MemorySegment.class)
+            MethodHandle ctxSynchronize,
+            @NativeSignature(name = "achip_device_alloc", returnType = MemorySegment.class, argumentTypes = {MemorySegment.class, long.class})
+            MethodHandle deviceAlloc,
+            @NativeSignature(name = "achip_device_free", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class})
+            MethodHandle deviceFree,
+            @NativeSignature(name = "achip_host_alloc_pinned", returnType = MemorySegment.class, argumentTypes = long.class)
+            MethodHandle hostAllocPinned,
+            @NativeSignature(name = "achip_host_free_pinned", returnType = int.class, argumentTypes = MemorySegment.class)
+            MethodHandle hostFreePinned,
+            @NativeSignature(name = "achip_memcpy_h2d", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, long.class})
+            MethodHandle memcpyHostToDevice,
+            @NativeSignature(name = "achip_memcpy_d2h", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, long.class})
+            MethodHandle memcpyDeviceToHost,
+            // single block, host pointers: (ctx, src, dst, srcLen, dstCap, errOffset*) -- argument order of LZ4_compress_fast / LZ4_decompress_safe
+            @NativeSignature(name = "achip_lz4_compress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle lz4Compress,
+            @NativeSignature(name = "achip_lz4_decompress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle lz4Decompress,
+            @NativeSignature(name = "achip_snappy_compress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle snappyCompress,
+            @NativeSignature(name = "achip_snappy_decompress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle snappyDecompress,
+            @NativeSignature(name = "achip_zstd_compress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle zstdCompress,
+            @NativeSignature(name = "achip_zstd_decompress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle zstdDecompress,
+            // batched, device-resident: (op, ctx, srcBase, srcOff*, srcLen*, dstBase, dstOff*, dstCap*, outLen*, status*, errOffset*, nBlocks)
+            @NativeSignature(name = "achip_batch_host", returnType = int.class, argumentTypes = {int.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle batchHost,
+            @NativeSignature(name = "achip_lz4_decompress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle lz4DecompressBatch,
+            @NativeSignature(name = "achip_lz4_compress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle lz4CompressBatch,
+            @NativeSignature(name = "achip_snappy_decompress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle snappyDecompressBatch,
+            @NativeSignature(name = "achip_snappy_compress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle snappyCompressBatch,
+            @NativeSignature(name = "achip_zstd_decompress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle zstdDecompressBatch,
+            @NativeSignature(name = "achip_zstd_compress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle zstdCompressBatch) {}
+
+    private static final Optional<LinkageError> LINKAGE_ERROR;
+    private static final MethodHandles HANDLES;
+    private static final int DEVICE_COUNT;
+    private static final Cleaner CLEANER = Cleaner.create();
+
+    static {
+        Symbols<MethodHandles> symbols;
+        if (System.getProperty("io.airlift.compress.v3.disable-hip") != null) {
+            // mirrors io.airlift.compress.v3.disable-native (NativeLoader.java:158)
+            symbols = new Symbols<>(Optional.of(new LinkageError("HIP backend is disabled")), null);
+        }
+        else {
+            symbols = loadSymbols("aircompressor_hip", MethodHandles.class, lookup());
+        }
+        LINKAGE_ERROR = symbols.linkageError();
+        HANDLES = symbols.symbols();
+        int devices = 0;
+        if (LINKAGE_ERROR.isEmpty()) {
+            try {
+                devices = (int) HANDLES.deviceCount().invokeExact();
+            }
+            catch (Throwable e) {
+                throw new ExceptionInInitializerError(e);
+            }
+        }
+        DEVICE_COUNT = devices;
+    }
+
+    /** true when the library loaded AND at least one HIP device is usable. */
+    public static boolean isEnabled()
+    {
+        return LINKAGE_ERROR.isEmpty() && DEVICE_COUNT > 0;
+    }
+
+    public static int deviceCount()
+    {
+        return DEVICE_COUNT;
+    }
+
+    public static void verifyEnabled()
+    {
+        if (LINKAGE_ERROR.isPresent()) {
+            throw new IllegalStateException("HIP native library is not enabled", LINKAGE_ERROR.get());
+        }
+        if (DEVICE_COUNT <= 0) {
+            throw new IllegalStateException("No HIP device available");
+        }
+    }
+
+    // ---- status translation -------------------------------------------------------------------
+
+    static int statusClass(int status)
+    {
+        return status < 0 ? ((-status) & 15) : 0;
+    }
+
+    static int statusDetail(int status)
+    {
+        return status < 0 ? ((-status) >> 4) : 0;
+    }
+
+    static String detailMessage(int detail)
+    {
+        try {
+            MemorySegment text = (MemorySegment) HANDLES.detailMessage().invokeExact(detail);
+            return text.reinterpret(256).getString(0);
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
+    /**
+     * Throws what the Java codec would throw for this status: MalformedInputException(offset, reason)
+     * for corrupt input, IllegalArgumentException for buffer sizing / arguments.
+     */
+    public static RuntimeException toException(int status, long errorOffset)
+    {
+        String reason = detailMessage(statusDetail(status));
+        return switch (statusClass(status)) {
+            case CLASS_MALFORMED -> new MalformedInputException(errorOffset, reason);
+            case CLASS_DEVICE -> new IllegalStateException(reason + ": " + lastError());
+            default -> new IllegalArgumentException(reason);
+        };
+    }
+
+    static String lastError()
+    {
+        try {
+            MemorySegment text = (MemorySegment) HANDLES.lastError().invokeExact();
+            return text.reinterpret(512).getString(0);
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
+    // ---- size helpers -------------------------------------------------------------------------
+
+    public static int lz4MaxCompressedLength(int n)
+    {
+        try {
+            return (int) HANDLES.lz4MaxCompressedLength().invokeExact(n);
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
+    public static int snappyMaxCompressedLength(int n)
+    {
+        try {
+            return (int) HANDLES.snappyMaxCompressedLength().invokeExact(n);
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
+    public static int zstdMaxCompressedLength(int n)
+    {
+        try {
+            return (int) HANDLES.zstdMaxCompressedLength().invokeExact(n);
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
+    public static long snappyUncompressedLength(MemorySegment compressed)
+    {
+        try (Arena arena = Arena.ofConfined()) {
+            MemorySegment errorOffset = arena.allocate(JAVA_LONG);
+            long result = (long) HANDLES.snappyUncompressedLength().invokeExact(compressed, compressed.byteSize(), errorOffset);
+            if (result < 0) {
+                throw toException((int) result, errorOffset.get(JAVA_LONG, 0));
+            }
+            return result;
+        }
+        catch (RuntimeException e) {
+            throw e;
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
+    public static long zstdDecompressedSize(MemorySegment compressed)
+    {
+        try (Arena arena = Arena.ofConfined()) {
+            MemorySegment errorOffset = arena.allocate(JAVA_LONG);
+            long result = (long) HANDLES.zstdDecompressedSize().invokeExact(compressed, compressed.byteSize(), errorOffset);
+            if (result < -1) {
+                throw toException((int) result, errorOffset.get(JAVA_LONG, 0));
+            }
+            return result;
+        }
+        catch (RuntimeException e) {
+            throw e;
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
+    // ---- context --------------------------------------------------------------------------------
+
+    /**
+     * One HIP stream + device scratch on one GPU.  Like a codec instance it is not thread-safe;
+     * distinct contexts may be used from distinct threads.  Freed by a Cleaner.
+     */
+    public static final class Context
+    {
+        private final MemorySegment handle;
+        private final MemorySegment errorOffset = Arena.ofAuto().allocate(JAVA_LONG);
+
+        public Context(int device)
+        {
+            verifyEnabled();
+            MemorySegment created;
+            try {
+                created = (MemorySegment) HANDLES.ctxCreate().invokeExact(device);
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+            if (created.address() == 0) {
+                throw new IllegalStateException("achip_ctx_create(" + device + ") failed: " + lastError());
+            }
+            handle = created;
+            MethodHandle destroy = HANDLES.ctxDestroy();
+            CLEANER.register(this, () -> {
+                try {
+                    destroy.invokeExact(created);
+                }
+                catch (Throwable ignored) {
+                }
+            });
+        }
+
+        MemorySegment handle()
+        {
+            return handle;
+        }
+
+        public void synchronize()
+        {
+            int status;
+            try {
+                status = (int) HANDLES.ctxSynchronize().invokeExact(handle);
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+            if (status < 0) {
+                throw toException(status, 0);
+            }
+        }
+
+        /** Single block through host memory: returns bytes written or throws the Java codec's exception. */
+        public int singleBlock(int op, MemorySegment input, int inputLength, MemorySegment output, int outputLength)
+        {
+            int result;
+            try {
+                MethodHandle method = switch (op) {
+                    case OP_LZ4_COMPRESS -> HANDLES.lz4Compress();
+                    case OP_LZ4_DECOMPRESS -> HANDLES.lz4Decompress();
+                    case OP_SNAPPY_COMPRESS -> HANDLES.snappyCompress();
+                    case OP_SNAPPY_DECOMPRESS -> HANDLES.snappyDecompress();
+                    case OP_ZSTD_COMPRESS -> HANDLES.zstdCompress();
+                    case OP_ZSTD_DECOMPRESS -> HANDLES.zstdDecompress();
+                    default -> throw new IllegalArgumentException("unknown op " + op);
+                };
+                result = (int) method.invokeExact(handle, input, output, inputLength, outputLength, errorOffset);
+            }
+            catch (RuntimeException e) {
+                throw e;
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+            if (result < 0) {
+                if (op == OP_LZ4_DECOMPRESS && statusDetail(result) == DETAIL_LZ4_EMPTY_OUTPUT) {
+                    return -1; // Lz4RawDecompressor.java:52-57 returns -1 here instead of throwing
+                }
+                throw toException(result, errorOffset.get(JAVA_LONG, 0));
+            }
+            return result;
+        }
+
+        /** Launches a device-resident batch (asynchronous on this context's stream). All segments are native (device or pinned). */
+        public void launchBatch(int op, MemorySegment srcBase, MemorySegment srcOff, MemorySegment srcLen, MemorySegment dstBase, MemorySegment dstOff,
+                MemorySegment dstCap, MemorySegment outLen, MemorySegment status, MemorySegment errOffset, int blocks)
+        {
+            int result;
+            try {
+                MethodHandle method = switch (op) {
+                    case OP_LZ4_COMPRESS -> HANDLES.lz4CompressBatch();
+                    case OP_LZ4_DECOMPRESS -> HANDLES.lz4DecompressBatch();
+                    case OP_SNAPPY_COMPRESS -> HANDLES.snappyCompressBatch();
+                    case OP_SNAPPY_DECOMPRESS -> HANDLES.snappyDecompressBatch();
+                    case OP_ZSTD_COMPRESS -> HANDLES.zstdCompressBatch();
+                    case OP_ZSTD_DECOMPRESS -> HANDLES.zstdDecompressBatch();
+                    default -> throw new IllegalArgumentException("unknown op " + op);
+                };
+                result = (int) method.invokeExact(handle, srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, blocks);
+            }
+            catch (RuntimeException e) {
+                throw e;
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+            if (result < 0) {
+                throw toException(result, 0);
+            }
+        }
+
+        /** Host-memory batch: stages in, runs, stages out, synchronizes. Arrays are native or heap segments. */
+        public void batchHost(int op, MemorySegment srcBase, MemorySegment srcOff, MemorySegment srcLen, MemorySegment dstBase, MemorySegment dstOff,
+                MemorySegment dstCap, MemorySegment outLen, MemorySegment status, MemorySegment errOffset, int blocks)
+        {
+            int result;
+            try {
+                result = (int) HANDLES.batchHost().invokeExact(op, handle, srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, blocks);
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+            if (result < 0) {
+                throw toException(result, 0);
+            }
+        }
+
+        public MemorySegment allocateDevice(long bytes)
+        {
+            try {
+                MemorySegment segment = (MemorySegment) HANDLES.deviceAlloc().invokeExact(handle, bytes);
+                if (segment.address() == 0) {
+                    throw new OutOfMemoryError("achip_device_alloc(" + bytes + ") failed: " + lastError());
+                }
+                return segment.reinterpret(bytes);
+            }
+            catch (Error | RuntimeException e) {
+                throw e;
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+        }
+
+        public void freeDevice(MemorySegment segment)
+        {
+            try {
+                int ignored = (int) HANDLES.deviceFree().invokeExact(handle, segment);
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+        }
+
+        public void copyToDevice(MemorySegment device, MemorySegment host, long bytes)
+        {
+            try {
+                int status = (int) HANDLES.memcpyHostToDevice().invokeExact(handle, device, host, bytes);
+                if (status < 0) {
+                    throw toException(status, 0);
+                }
+            }
+            catch (RuntimeException e) {
+                throw e;
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+        }
+
+        public void copyToHost(MemorySegment host, MemorySegment device, long bytes)
+        {
+            try {
+                int status = (int) HANDLES.memcpyDeviceToHost().invokeExact(handle, host, device, bytes);
+                if (status < 0) {
+                    throw toException(status, 0);
+                }
+            }
+            catch (RuntimeException e) {
+                throw e;
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+        }
+    }
+
+    public static MemorySegment allocatePinned(long bytes)
+    {
+        try {
+            MemorySegment segment = (MemorySegment) HANDLES.hostAllocPinned().invokeExact(bytes);
+            if (segment.address() == 0) {
+                throw new OutOfMemoryError("achip_host_alloc_pinned(" + bytes + ") failed");
+            }
+            return segment.reinterpret(bytes);
+        }
+        catch (Error | RuntimeException e) {
+            throw e;
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
+    public static void freePinned(MemorySegment segment)
+    {
+        try {
+            int ignored = (int) HANDLES.hostFreePinned().invokeExact(segment);
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+}
