@@ -107,8 +107,8 @@ def main():
     n_local_target = args.blocks
     n_global = n_local_target * world
     # contiguous, byte-balanced shard of the global block index (no collective on the data path)
-    starts = A.partition_blocks(np.full(n_global, bs, dtype=np.int64), world)
-    lo, hi = int(starts[rank]), int(starts[rank + 1])
+    from aircompressor_amd.sharding import shard_for_rank
+    lo, hi = shard_for_rank(np.full(n_global, bs, dtype=np.int64), world, rank)
     n_local = hi - lo
 
     codec = A.HipBatchCodec(local_rank)
@@ -268,6 +268,10 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extra:
         result["extra"] = extras(torch, A, codec, dev, args)
+        try:
+            result["extra"].update(zstd_extra(torch, A, codec, dev, args))
+        except ImportError:
+            pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(torch, pool_pack, pool_pack_off, pool_clen, pool_plain, bs, op, wl, args.cpu_seconds)
     if rank == 0:
@@ -282,7 +286,7 @@ def extras(torch, A, codec, dev, args):
     out = {}
     lib = codec.lib
     bs = args.block_size
-    n = 16384
+    n = 65536
     for data_kind in ("fragments", "wordmix"):
         plain = gen_fragments(torch, dev, n, bs, args.ratio, 977) if data_kind == "fragments" else gen_wordmix(torch, dev, n, bs, 977)
         for name, cop, dop in (("lz4", A.OP_LZ4_COMPRESS, A.OP_LZ4_DECOMPRESS), ("snappy", A.OP_SNAPPY_COMPRESS, A.OP_SNAPPY_DECOMPRESS)):
@@ -325,6 +329,60 @@ def extras(torch, A, codec, dev, args):
                 "blocks": n,
             }
             del comp, back
+    return out
+
+
+def zstd_extra(torch, A, codec, dev, args):
+    """Zstd level-3 frames of 128 KiB (BASELINE configs[3]); frames made on the host by libzstd via pyarrow
+    (a third-party encoder; no Zstd encoder in the product yet), decoded on the GPU, verified against the plaintext."""
+    import pyarrow as pa
+    out = {}
+    fs = 131072
+    pool_n, reps = 512, 16
+    zc = pa.Codec("zstd", compression_level=3)
+    for data_kind in ("fragments", "wordmix"):
+        plain = gen_fragments(torch, dev, pool_n, fs, args.ratio, 4242) if data_kind == "fragments" else gen_wordmix(torch, dev, pool_n, fs, 4242)
+        host = plain.cpu().numpy()
+        frames = [zc.compress(host[i * fs:(i + 1) * fs].tobytes(), asbytes=True) for i in range(pool_n)]
+        lens = np.array([len(f) for f in frames], dtype=np.int64)
+        pad = (lens + 15) // 16 * 16
+        offs = np.cumsum(pad) - pad
+        pack = np.zeros(int(pad.sum()), dtype=np.uint8)
+        for f, o in zip(frames, offs):
+            pack[o:o + len(f)] = np.frombuffer(f, dtype=np.uint8)
+        n = pool_n * reps
+        i64 = dict(dtype=torch.int64, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        d_pack = torch.from_numpy(pack).to(dev).repeat(reps)
+        rep_idx = torch.arange(reps, **i64).repeat_interleave(pool_n)
+        src_off = torch.from_numpy(offs).to(dev).repeat(reps) + rep_idx * int(pad.sum())
+        src_len = torch.from_numpy(lens.astype(np.int32)).to(dev).repeat(reps)
+        dst = torch.empty(n * fs + 64, dtype=torch.uint8, device=dev)
+        dst_off = torch.arange(n, **i64) * fs
+        dst_cap = torch.full((n,), fs, **i32)
+        olen = torch.zeros(n, **i32)
+        st = torch.zeros(n, **i32)
+        eo = torch.zeros(n, **i64)
+        torch.cuda.synchronize()
+        launch = lambda: codec.launch(A.OP_ZSTD_DECOMPRESS, d_pack, src_off, src_len, dst, dst_off, dst_cap, olen, st, eo, n)  # noqa: E731
+        launch()
+        codec.synchronize()
+        assert int((st != 0).sum()) == 0, "zstd decode failed"
+        assert bool((dst[:n * fs].view(reps, pool_n * fs) == plain.unsqueeze(0)).all()), "zstd plaintext mismatch"
+        e0, e1 = codec.event(), codec.event()
+        iters = 3
+        codec.record(e0)
+        for _ in range(iters):
+            launch()
+        codec.record(e1)
+        t = codec.elapsed_ms(e0, e1) / iters * 1e-3
+        cbytes = int(lens.sum()) * reps
+        out["zstd_%s" % data_kind] = {
+            "ratio": round(n * fs / cbytes, 3), "decompress_GiBps": round(n * fs / t / 2**30, 2),
+            "decompress_hbm_frac": round((n * fs + cbytes) / t / 1e9 / HBM_PEAK_GBS, 4), "frames": n, "frame_bytes": fs,
+            "encoder": "libzstd level 3 via pyarrow %s" % pa.__version__,
+        }
+        del d_pack, dst
     return out
 
 
