@@ -40,6 +40,10 @@ int64_t orc_zstd_decompressed_size(const uint8_t* in, int64_t in_len, int64_t* e
 /* Zstd level-3 encoder -- M/zstd/ZstdFrameCompressor.java and friends */
 int64_t orc_zstd_compress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap);
 
+/* test hooks for the frame-header KATs of T/zstd/TestCompressor.java:52-98 */
+int32_t orc_zstd_write_frame_header(uint8_t* out14, int32_t inputSize, int32_t windowSize);
+int32_t orc_zstd_read_frame_header(const uint8_t* in, int64_t in_len, int64_t* out4);
+
 /* XXH64 -- M/zstd/XxHash64.java:182-291 */
 uint64_t orc_xxh64(const uint8_t* in, int64_t len, uint64_t seed);
 

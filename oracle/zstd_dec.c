@@ -1102,6 +1102,27 @@ int64_t orc_zstd_decompressed_size(const uint8_t* in, int64_t in_len, int64_t* e
     return fh.content_size;
 }
 
+/* test hook: ZstdFrameDecompressor.readFrameHeader on a bare header (T/zstd/TestCompressor.java:100-110);
+ * out4 = {headerSize, windowSize, contentSize, hasChecksum} */
+int32_t orc_zstd_read_frame_header(const uint8_t* in, int64_t in_len, int64_t* out4)
+{
+    if (!g_ctx) {
+        g_ctx = (zctx*)calloc(1, sizeof(zctx));
+    }
+    zctx* c = g_ctx;
+    c->in = in;
+    c->in_len = in_len;
+    frame_header fh;
+    if (read_frame_header(c, 0, in_len, &fh) < 0) {
+        return ACHIP_STATUS(ACHIP_CLASS_MALFORMED, c->err_detail);
+    }
+    out4[0] = fh.header_size;
+    out4[1] = fh.window_size;
+    out4[2] = fh.content_size;
+    out4[3] = fh.has_checksum;
+    return 0;
+}
+
 /* ZstdJavaCompressor.maxCompressedLength  M/zstd/ZstdJavaCompressor.java:31-40 */
 int64_t orc_zstd_max_compressed_length(int64_t n)
 {

@@ -203,7 +203,7 @@ def test_round_trip_every_prefix(o, codec):
         assert o.decompress(codec, o.compress(codec, d), n) == d
 
 
-@pytest.mark.parametrize("codec", ["lz4", "snappy"])
+@pytest.mark.parametrize("codec", ["lz4", "snappy", "zstd"])
 def test_round_trip_corpus_sample_and_pinned_hashes(o, codec):
     import hashlib
     for name, data, entry in common.corpus_sample():
@@ -250,3 +250,48 @@ def test_random_generator_structure(o):
     assert list(g[:8]) == vals
     g1 = o.random_generator(0.1)
     assert bytes(g1[:10]) * 10 == bytes(g1[:100])
+
+
+# ---- Zstd encoder (level 3): frame-header KATs T/zstd/TestCompressor.java:52-98 ----
+def test_zstd_frame_header_kats(o):
+    import ctypes
+    o.lib.orc_zstd_write_frame_header.restype = ctypes.c_int32
+    o.lib.orc_zstd_write_frame_header.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
+    o.lib.orc_zstd_read_frame_header.restype = ctypes.c_int32
+    o.lib.orc_zstd_read_frame_header.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    big = 65536 + 256
+    kats = [(1, 1024, (2, -1, 1)), (256, 1024, (3, -1, 256)), (big, 2048, (6, 2048, big)), (2**31 - 1, 1024, (6, 1024, 2**31 - 1))]
+    kats += [(big, 1024 + 128 * k, (6, 1024 + 128 * k, big)) for k in range(1, 9)]
+    for input_size, window, (hsize, wsize, csize) in kats:
+        buf = np.zeros(14, dtype=np.uint8)
+        n = o.lib.orc_zstd_write_frame_header(buf.ctypes.data, input_size, window)
+        assert n == hsize, (input_size, window, n)
+        out4 = np.zeros(4, dtype=np.int64)
+        assert o.lib.orc_zstd_read_frame_header(buf.ctypes.data, 14, out4.ctypes.data) == 0
+        assert tuple(out4) == (hsize, wsize, csize, 1), (input_size, window, tuple(out4))
+    buf = np.zeros(14, dtype=np.uint8)
+    assert o.lib.orc_zstd_write_frame_header(buf.ctypes.data, 2000, 1023) == -1  # "Minimum window size is 1024"
+    assert o.lib.orc_zstd_write_frame_header(buf.ctypes.data, 2000, 1025) == -2  # "... must be multiple of 128"
+
+
+def test_zstd_encoder_round_trips_through_own_decoder(o):
+    blocks = [d for _, d in common.HAND_CASES] + [d for _, d, _ in common.corpus_sample()] + common.synthetic_blocks(17, 18)
+    blocks.append(b"".join(d for _, d, _ in common.corpus_sample()[:5]))  # multi-block frame (5 x 64 KiB)
+    blocks.append(common.golden_zstd("large-rle"))
+    blocks.append(common.golden_zstd("incompressible"))
+    for i, d in enumerate(blocks):
+        z = o.compress("zstd", d, o.max_compressed_length("zstd", len(d)))
+        assert len(z) <= o.max_compressed_length("zstd", len(d))
+        assert z[:4] == bytes([0x28, 0xB5, 0x2F, 0xFD])
+        assert o.decompress("zstd", z, len(d)) == d, i
+    with pytest.raises(OracleError) as e:  # T/zstd/TestCompressor.java:33-41
+        o.compress("zstd", b"x" * 100, cap=3)
+    assert e.value.cls == 2
+
+
+def test_zstd_encoder_cross_decodes_with_libzstd_when_available(o):
+    pa = pytest.importorskip("pyarrow")
+    codec = pa.Codec("zstd")
+    for _, d, _ in common.corpus_sample()[:8]:
+        z = o.compress("zstd", d, o.max_compressed_length("zstd", len(d)))
+        assert codec.decompress(z, decompressed_size=len(d)).to_pybytes() == d

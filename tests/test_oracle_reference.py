@@ -30,7 +30,7 @@ def test_manifest_is_current(o):
         rel = os.path.relpath(f, os.path.join(REF, "testdata"))
         d = open(f, "rb").read()
         assert manifest[rel]["sha256"] == hashlib.sha256(d).hexdigest()
-        for codec in ("lz4", "snappy"):
+        for codec in ("lz4", "snappy", "zstd"):
             c = o.compress(codec, d)
             assert manifest[rel][codec]["sha256"] == hashlib.sha256(c).hexdigest(), (rel, codec)
             assert o.decompress(codec, c, len(d)) == d
@@ -44,6 +44,10 @@ def test_cross_decode_with_bundled_native_codecs(o):
         assert o.decompress("lz4", nl.lz4_compress(d), len(d)) == d, f        # their stream, our decoder
         assert nl.snappy_decompress(o.compress("snappy", d), len(d)) == d, f
         assert o.decompress("snappy", nl.snappy_compress(d), len(d)) == d, f
+        assert nl.zstd_decompress(o.compress("zstd", d), len(d)) == d, f           # oracle's level-3 frames, libzstd 1.5.6 decoder
+        for i in range(0, min(len(d), 3 * 131072), 131072):
+            b = d[i:i + 131072]
+            assert nl.zstd_decompress(o.compress("zstd", b), len(b)) == b
 
 
 def test_zstd_decoder_on_libzstd_frames(o):

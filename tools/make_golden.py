@@ -8,7 +8,7 @@
     (the GPU box has no /root/reference);
   * writes tests/golden/manifest.json: SHA-256 of the oracle's compressed output for every
     corpus file (whole file, single block) and every sample slice, per codec.  A JDK >= 22 box can
-    diff these against the real Lz4JavaCompressor / SnappyJavaCompressor (tools/GoldenDump.java).
+    diff these against the real Lz4JavaCompressor / SnappyJavaCompressor / ZstdJavaCompressor (tools/GoldenDump.java).
 """
 import glob
 import hashlib
@@ -52,7 +52,7 @@ def main():
     for e in index:
         d = bytes(blob[e["blob_offset"]:e["blob_offset"] + e["length"]])
         e["sha256"] = sha(d)
-        for codec in ("lz4", "snappy"):
+        for codec in ("lz4", "snappy", "zstd"):
             c = o.compress(codec, d)
             e[codec] = {"compressed_length": len(c), "sha256": sha(c)}
     json.dump(index, open(os.path.join(GOLD, "corpus_sample.json"), "w"), indent=1)
@@ -63,7 +63,7 @@ def main():
         rel = os.path.relpath(f, os.path.join(REF, "testdata"))
         d = open(f, "rb").read()
         entry = {"length": len(d), "sha256": sha(d)}
-        for codec in ("lz4", "snappy"):
+        for codec in ("lz4", "snappy", "zstd"):
             c = o.compress(codec, d)
             entry[codec] = {"compressed_length": len(c), "sha256": sha(c)}
         manifest[rel] = entry
