@@ -188,6 +188,68 @@ __device__ __forceinline__ int32_t wave_count(const uint8_t* __restrict__ in, in
     }
 }
 
+// ---- wave-wide fill and XXH64 (one wavefront per item) ----
+__device__ __forceinline__ void wave_fill(uint8_t* dst, int32_t value, int32_t n, int lane)
+{
+    const uint32_t v4 = (uint32_t)value * 0x01010101u;
+    const int32_t full = n & ~15;
+    u32x4 v = {v4, v4, v4, v4};
+    for (int32_t base = lane * 16; base < full; base += 64 * 16) {
+        st16(dst + base, v);
+    }
+    for (int32_t k = full + lane; k < n; k += 64) {
+        dst[k] = (uint8_t)value;
+    }
+}
+
+// XXH64 (seed 0) of out[0..len) -- M/zstd/XxHash64.java:182-291.  Lanes 0-3 own the four accumulators.
+__device__ inline uint64_t wave_xxh64(const uint8_t* p, int32_t len, int lane)
+{
+    constexpr uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+    auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+    auto mix = [&](uint64_t cur, uint64_t v) { return rotl(cur + v * P2, 31) * P1; };
+    uint64_t hash;
+    if (len >= 32) {
+        uint64_t v = lane == 0 ? P1 + P2 : (lane == 1 ? P2 : (lane == 2 ? 0 : (0 - P1)));
+        const int32_t stripes = len >> 5;
+        if (lane < 4) {
+            const uint8_t* q = p + lane * 8;
+            for (int32_t s = 0; s < stripes; s++) {
+                v = mix(v, ld8(q + (int64_t)s * 32));
+            }
+        }
+        const uint64_t v1 = __shfl(v, 0), v2 = __shfl(v, 1), v3 = __shfl(v, 2), v4 = __shfl(v, 3);
+        hash = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+        hash = (hash ^ mix(0, v1)) * P1 + P4;
+        hash = (hash ^ mix(0, v2)) * P1 + P4;
+        hash = (hash ^ mix(0, v3)) * P1 + P4;
+        hash = (hash ^ mix(0, v4)) * P1 + P4;
+    }
+    else {
+        hash = P5;
+    }
+    hash += (uint64_t)len;
+    int32_t index = len & ~31;
+    while (index <= len - 8) {
+        hash = rotl(hash ^ mix(0, ld8(p + index)), 27) * P1 + P4;
+        index += 8;
+    }
+    if (index <= len - 4) {
+        hash = rotl(hash ^ ((uint64_t)ld4(p + index) * P1), 23) * P2 + P3;
+        index += 4;
+    }
+    while (index < len) {
+        hash = rotl(hash ^ ((uint64_t)p[index] * P5), 11) * P1;
+        index++;
+    }
+    hash ^= hash >> 33;
+    hash *= P2;
+    hash ^= hash >> 29;
+    hash *= P3;
+    hash ^= hash >> 32;
+    return hash;
+}
+
 // first lane index of this lane's group, lane index inside the group
 template <int GS>
 __device__ __forceinline__ int group_lane()

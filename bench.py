@@ -377,12 +377,45 @@ def zstd_extra(torch, A, codec, dev, args):
         codec.record(e1)
         t = codec.elapsed_ms(e0, e1) / iters * 1e-3
         cbytes = int(lens.sum()) * reps
-        out["zstd_%s" % data_kind] = {
+        entry = {
             "ratio": round(n * fs / cbytes, 3), "decompress_GiBps": round(n * fs / t / 2**30, 2),
             "decompress_hbm_frac": round((n * fs + cbytes) / t / 1e9 / HBM_PEAK_GBS, 4), "frames": n, "frame_bytes": fs,
             "encoder": "libzstd level 3 via pyarrow %s" % pa.__version__,
         }
         del d_pack, dst
+        # GPU level-3 encoder (bit-exact with the Java encoder) over the same plaintext, then GPU decode of its frames
+        max_c = lib_max = codec.lib.achip_zstd_max_compressed_length(fs)
+        cstride = (max_c + 15) // 16 * 16
+        nz = pool_n * 4
+        zplain = plain.repeat(4)
+        z_src_off = torch.arange(nz, **i64) * fs
+        z_src_len = torch.full((nz,), fs, **i32)
+        z_dst = torch.empty(nz * cstride + 64, dtype=torch.uint8, device=dev)
+        z_dst_off = torch.arange(nz, **i64) * cstride
+        z_dst_cap = torch.full((nz,), max_c, **i32)
+        z_len = torch.zeros(nz, **i32)
+        z_st = torch.zeros(nz, **i32)
+        z_eo = torch.zeros(nz, **i64)
+        torch.cuda.synchronize()
+        zl = lambda: codec.launch(A.OP_ZSTD_COMPRESS, zplain, z_src_off, z_src_len, z_dst, z_dst_off, z_dst_cap, z_len, z_st, z_eo, nz)  # noqa: E731
+        zl()
+        codec.synchronize()
+        assert int((z_st != 0).sum()) == 0, "zstd encode failed"
+        e0, e1 = codec.event(), codec.event()
+        codec.record(e0)
+        zl()
+        codec.record(e1)
+        tz = codec.elapsed_ms(e0, e1) * 1e-3
+        zbytes = int(z_len.to(torch.int64).sum())
+        back = torch.empty(nz * fs + 64, dtype=torch.uint8, device=dev)
+        b_len = torch.zeros(nz, **i32)
+        codec.launch(A.OP_ZSTD_DECOMPRESS, z_dst, z_dst_off, z_len, back, z_src_off, z_src_len, b_len, z_st, z_eo, nz)
+        codec.synchronize()
+        assert int((z_st != 0).sum()) == 0 and bool((back[:nz * fs] == zplain).all()), "zstd GPU encode -> GPU decode round trip failed"
+        entry.update({"gpu_encoder_ratio": round(nz * fs / zbytes, 3), "compress_GiBps": round(nz * fs / tz / 2**30, 2),
+                      "compress_hbm_frac": round((nz * fs + zbytes) / tz / 1e9 / HBM_PEAK_GBS, 5), "compress_frames": nz})
+        out["zstd_%s" % data_kind] = entry
+        del z_dst, back, zplain
     return out
 
 

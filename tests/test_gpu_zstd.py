@@ -142,3 +142,79 @@ def test_many_frames_full_size_property(gb, o):
     assert all(s == 0 for s in status)
     want = [hashlib.sha256(b).digest() for b in blocks] * 4
     assert [hashlib.sha256(p).digest() for p in outs] == want
+
+
+# ---- encoder (level 3), rows a11-a14 -------------------------------------------------------------------------
+OP_ZSTD_COMPRESS = 5
+
+
+def encoder_inputs():
+    sample = [d for _, d, _ in common.corpus_sample()]
+    blocks = [d for _, d in common.HAND_CASES]
+    blocks += sample
+    blocks += [sample[i] + sample[i + 1] for i in range(0, len(sample) - 1, 2)]   # 128 KiB: one full block
+    blocks += common.synthetic_blocks(31, 24)
+    blocks.append(b"".join(sample[:5]) + b"tail")                                  # 3 blocks sharing tables / repcodes / Huffman reuse
+    blocks.append(b"".join(sample[3:9]))                                           # > 256 KiB: default parameter row, 2^17 long table
+    blocks.append(common.golden_zstd("large-rle"))
+    blocks.append(common.golden_zstd("incompressible"))
+    base = sample[0]
+    blocks += [base[:n] for n in (1, 2, 6, 7, 8, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 16383, 16384, 16385)]
+    return blocks
+
+
+def test_zstd_compress_is_bit_exact_with_oracle(gb, o):
+    blocks = encoder_inputs()
+    caps = [o.max_compressed_length("zstd", len(b)) for b in blocks]
+    outs, status, _ = gb.run(OP_ZSTD_COMPRESS, blocks, caps)
+    assert all(s == 0 for s in status), status
+    for i, (b, z) in enumerate(zip(blocks, outs)):
+        assert z == o.compress("zstd", b, caps[i]), "block %d (len %d): gpu %d bytes" % (i, len(b), len(z))
+    # and the GPU decoder restores the plaintext from the GPU encoder's frames
+    plain, status, err = gb.run(OP_ZSTD_DECOMPRESS, outs, [max(len(b), 1) for b in blocks])
+    for i, (b, p, s) in enumerate(zip(blocks, plain, status)):
+        if len(b) == 0:
+            continue
+        assert s == 0 and p == b, (i, s, err[i])
+
+
+def test_zstd_compress_pinned_hashes_and_third_party_decoder(gb, o):
+    import hashlib
+    import pyarrow as pa
+    sample = common.corpus_sample()
+    blocks = [d for _, d, _ in sample]
+    outs, status, _ = gb.run(OP_ZSTD_COMPRESS, blocks, [o.max_compressed_length("zstd", len(b)) for b in blocks])
+    assert all(s == 0 for s in status)
+    codec = pa.Codec("zstd")
+    for (name, d, e), z in zip(sample, outs):
+        assert hashlib.sha256(z).hexdigest() == e["zstd"]["sha256"], name       # committed hash of the oracle's stream
+        assert codec.decompress(z, decompressed_size=len(d)).to_pybytes() == d  # libzstd accepts the frame
+
+
+def test_zstd_compress_output_too_small(gb, o):
+    b = common.corpus_sample()[0][1]
+    cap = o.max_compressed_length("zstd", len(b))
+    outs, status, _ = gb.run(OP_ZSTD_COMPRESS, [b, b, b], [10, cap, 20000])
+    assert status[1] == 0 and outs[1] == o.compress("zstd", b, cap)
+    for i, c in ((0, 10), (2, 20000)):
+        try:
+            expect = o.compress("zstd", b, c)
+            assert status[i] == 0 and outs[i] == expect
+        except OracleError as e:
+            assert status[i] == e.status
+
+
+def test_zstd_host_api_round_trip(o):
+    import aircompressor_amd as A
+    data = common.corpus_sample()[2][1]
+    comp, decomp = A.ZstdHipCompressor(), A.ZstdHipDecompressor()
+    cap = comp.max_compressed_length(len(data))
+    assert cap == o.max_compressed_length("zstd", len(data))
+    out = bytearray(cap)
+    n = comp.compress(data, 0, len(data), out, 0, cap)
+    assert bytes(out[:n]) == o.compress("zstd", data, cap)
+    assert decomp.get_decompressed_size(out, 0, n) == len(data)
+    back = bytearray(len(data))
+    assert decomp.decompress(out, 0, n, back, 0, len(data)) == len(data) and bytes(back) == data
+    with pytest.raises(A.IllegalArgumentException):
+        comp.compress(data, 0, len(data), bytearray(5), 0, 5)
