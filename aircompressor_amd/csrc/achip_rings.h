@@ -15,9 +15,9 @@
 
 namespace achip {
 
-template <int GS, int IN_RING, int OUT_RING>
+template <int GS, int IN_RING, int OUT_RING, int GPL = 1>
 struct Rings {
-    static constexpr int CHUNK = GS * 16;                      // bytes per refill / flush / copy step
+    static constexpr int CHUNK = GS * 16 * GPL;                // bytes per refill / flush / copy step (GPL 16-byte granules per lane)
     static constexpr int LDS_REACH = OUT_RING - CHUNK - 16;    // farthest back-reference served from the ring
     static_assert((IN_RING & (IN_RING - 1)) == 0 && (OUT_RING & (OUT_RING - 1)) == 0, "rings are powers of two");
     static_assert(IN_RING >= 2 * CHUNK && OUT_RING >= 4 * CHUNK, "ring too small for the chunk size");
@@ -30,7 +30,7 @@ struct Rings {
     int32_t inEndV;            // virtual end of the input
     int32_t inLoadedV;         // input ring holds virtual [inLoadedV - IN_RING, inLoadedV)
     int32_t flushedV;          // output flushed to HBM up to this virtual position (multiple of 16, or the final end)
-    u32x4 pending;             // this lane's granule of the NEXT input chunk, requested one refill ahead (hides HBM latency)
+    u32x4 pending[GPL];        // this lane's granules of the NEXT input chunk, requested one refill ahead (hides HBM latency)
     int g;
 
     __device__ __forceinline__ void init(uint8_t* ldsIn, uint8_t* ldsOut, const uint8_t* in, int32_t inLimit, uint8_t* out, int lane)
@@ -45,7 +45,24 @@ struct Rings {
         inLoadedV = 0;
         flushedV = 0;
         g = lane;
-        pending = fetch_granule(16 * g);
+#pragma unroll
+        for (int q = 0; q < GPL; q++) {
+            pending[q] = fetch_granule(16 * (g + GS * q));
+        }
+    }
+
+    // switch the input ring to a new source stream (Zstd: literals of the next block, a raw block, ...)
+    __device__ __forceinline__ void reset_input(const uint8_t* in, int32_t inLimit)
+    {
+        inBase = (int32_t)((uintptr_t)in & 15);
+        inAligned = in - inBase;
+        inEndV = inLimit + inBase;
+        inLoadedV = 0;
+        wave_mem_order();
+#pragma unroll
+        for (int q = 0; q < GPL; q++) {
+            pending[q] = fetch_granule(16 * (g + GS * q));
+        }
     }
 
     // this lane's 16-byte granule at virtual position v; bytes outside the input read as 0
@@ -55,14 +72,16 @@ struct Rings {
         if (v >= inBase && v + 16 <= inEndV) {
             d = *(const u32x4*)(inAligned + v);  // aligned, fully inside the input: one coalesced CHUNK per group
         }
-        else if (v + 16 > inBase && v < inEndV) {
-            uint8_t b[16];
-#pragma unroll
+        else if (v + 16 > inBase && v < inEndV) {  // first / last granule of the stream: byte-guarded, kept small (cold)
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll 1
             for (int i = 0; i < 16; i++) {
                 const int32_t p = v + i;
-                b[i] = (p >= inBase && p < inEndV) ? inAligned[p] : (uint8_t)0;
+                if (p >= inBase && p < inEndV) {
+                    w[i >> 2] |= (uint32_t)inAligned[p] << (8 * (i & 3));
+                }
             }
-            __builtin_memcpy(&d, b, 16);
+            d = u32x4{w[0], w[1], w[2], w[3]};
         }
         return d;
     }
@@ -70,10 +89,13 @@ struct Rings {
     // ---- input side ----
     __device__ __forceinline__ void refill()
     {
-        const int32_t v = inLoadedV + 16 * g;
-        *(u32x4*)(inRing + (v & (IN_RING - 1))) = pending;  // requested during the previous refill
+#pragma unroll
+        for (int q = 0; q < GPL; q++) {
+            const int32_t v = inLoadedV + 16 * (g + GS * q);
+            *(u32x4*)(inRing + (v & (IN_RING - 1))) = pending[q];  // requested during the previous refill
+            pending[q] = fetch_granule(v + CHUNK);
+        }
         inLoadedV += CHUNK;
-        pending = fetch_granule(v + CHUNK);
     }
     // make input bytes [pos, pos+need) readable from the ring (need <= CHUNK); bytes past the input end read as 0
     __device__ __forceinline__ void ensure_input(int32_t pos, int32_t need)
@@ -106,13 +128,16 @@ struct Rings {
         const int32_t opV = op + outBase;
         wave_mem_order();
         while (flushedV + CHUNK <= opV) {
-            const int32_t v = flushedV + 16 * g;
-            if (v >= outBase) {
-                *(u32x4*)(outAligned + v) = *(const u32x4*)(outRing + (v & (OUT_RING - 1)));
-            }
-            else if (v + 16 > outBase) {  // the granule straddling the start of the output buffer
-                for (int32_t p = outBase; p < v + 16; p++) {
-                    outAligned[p] = outRing[p & (OUT_RING - 1)];
+#pragma unroll
+            for (int q = 0; q < GPL; q++) {
+                const int32_t v = flushedV + 16 * (g + GS * q);
+                if (v >= outBase) {
+                    *(u32x4*)(outAligned + v) = *(const u32x4*)(outRing + (v & (OUT_RING - 1)));
+                }
+                else if (v + 16 > outBase) {  // the granule straddling the start of the output buffer
+                    for (int32_t p = outBase; p < v + 16; p++) {
+                        outAligned[p] = outRing[p & (OUT_RING - 1)];
+                    }
                 }
             }
             flushedV += CHUNK;
@@ -124,21 +149,38 @@ struct Rings {
     {
         flush_complete(op);
         const int32_t opV = op + outBase;
-        const int32_t v = flushedV + 16 * g;
-        if (v < opV) {
-            if (v >= outBase && v + 16 <= opV) {
-                *(u32x4*)(outAligned + v) = *(const u32x4*)(outRing + (v & (OUT_RING - 1)));
-            }
-            else {
-                const int32_t lo = v > outBase ? v : outBase;
-                const int32_t hi = v + 16 < opV ? v + 16 : opV;
-                for (int32_t p = lo; p < hi; p++) {
-                    outAligned[p] = outRing[p & (OUT_RING - 1)];
+#pragma unroll
+        for (int q = 0; q < GPL; q++) {
+            const int32_t v = flushedV + 16 * (g + GS * q);
+            if (v < opV) {
+                if (v >= outBase && v + 16 <= opV) {
+                    *(u32x4*)(outAligned + v) = *(const u32x4*)(outRing + (v & (OUT_RING - 1)));
+                }
+                else {
+                    const int32_t lo = v > outBase ? v : outBase;
+                    const int32_t hi = v + 16 < opV ? v + 16 : opV;
+                    for (int32_t p = lo; p < hi; p++) {
+                        outAligned[p] = outRing[p & (OUT_RING - 1)];
+                    }
                 }
             }
         }
-        flushedV = opV;
+        flushedV = opV & ~15;  // stays granule-aligned: a later flush re-stores the partial granule from the ring, whole
         wave_mem_order();
+    }
+
+    // n copies of one byte (Zstd RLE blocks)
+    __device__ __forceinline__ void fill(int32_t op, uint32_t value, int32_t n)
+    {
+        while (n > 0) {
+            const int32_t c = n < CHUNK ? n : CHUNK;
+            for (int32_t k = g; k < c; k += GS) {
+                out_put(op + k, value);
+            }
+            op += c;
+            n -= c;
+            flush_complete(op);
+        }
     }
 
     // literals: n input bytes at ip -> output at op (n arbitrary; input ring refilled, output flushed as we go)
@@ -147,7 +189,7 @@ struct Rings {
         while (n > 0) {
             const int32_t c = n < CHUNK ? n : CHUNK;
             ensure_input(ip, c);
-            if (GS < 4 || c <= GS) {
+            if (c <= (GS > 4 ? GS : 4)) {
                 for (int32_t k = g; k < c; k += GS) {
                     out_put(op + k, in_u8(ip + k));
                 }
@@ -157,14 +199,14 @@ struct Rings {
                 const int32_t head = (4 - (dV & 3)) & 3;
                 const int32_t nd = (c - head) >> 2;
                 const int32_t t0 = head + 4 * nd;
-                if (g < head) {
-                    outRing[(dV + g) & (OUT_RING - 1)] = inRing[(sV + g) & (IN_RING - 1)];
+                for (int32_t k = g; k < head; k += GS) {
+                    outRing[(dV + k) & (OUT_RING - 1)] = inRing[(sV + k) & (IN_RING - 1)];
                 }
                 for (int32_t j = g; j < nd; j += GS) {
                     *(uint32_t*)(outRing + ((dV + head + 4 * j) & (OUT_RING - 1))) = ring_ld4<IN_RING>(inRing, sV + head + 4 * j);
                 }
-                if (g < c - t0) {
-                    outRing[(dV + t0 + g) & (OUT_RING - 1)] = inRing[(sV + t0 + g) & (IN_RING - 1)];
+                for (int32_t k = t0 + g; k < c; k += GS) {
+                    outRing[(dV + k) & (OUT_RING - 1)] = inRing[(sV + k) & (IN_RING - 1)];
                 }
             }
             ip += c;
@@ -185,7 +227,7 @@ struct Rings {
             const int32_t c = n < CHUNK ? n : CHUNK;
             wave_mem_order();
             if (offset <= LDS_REACH) {
-                if (offset >= c && (GS < 4 || c <= GS)) {
+                if (offset >= c && c <= (GS > 4 ? GS : 4)) {
                     for (int32_t j = g; j < c; j += GS) {
                         out_put(c0 + j, out_get(c0 - offset + j));
                     }
@@ -195,14 +237,14 @@ struct Rings {
                     const int32_t head = (4 - (dV & 3)) & 3;
                     const int32_t nd = (c - head) >> 2;
                     const int32_t t0 = head + 4 * nd;
-                    if (g < head) {
-                        outRing[(dV + g) & (OUT_RING - 1)] = outRing[(sV + g) & (OUT_RING - 1)];
+                    for (int32_t k = g; k < head; k += GS) {
+                        outRing[(dV + k) & (OUT_RING - 1)] = outRing[(sV + k) & (OUT_RING - 1)];
                     }
                     for (int32_t j = g; j < nd; j += GS) {
                         *(uint32_t*)(outRing + ((dV + head + 4 * j) & (OUT_RING - 1))) = ring_ld4<OUT_RING>(outRing, sV + head + 4 * j);
                     }
-                    if (g < c - t0) {
-                        outRing[(dV + t0 + g) & (OUT_RING - 1)] = outRing[(sV + t0 + g) & (OUT_RING - 1)];
+                    for (int32_t k = t0 + g; k < c; k += GS) {
+                        outRing[(dV + k) & (OUT_RING - 1)] = outRing[(sV + k) & (OUT_RING - 1)];
                     }
                 }
                 else {
@@ -217,7 +259,7 @@ struct Rings {
             else {
                 // far: offset > LDS_REACH >= 2*CHUNK, so the sources of this chunk were flushed to HBM at least CHUNK bytes ago
                 const uint8_t* src = outAligned + outBase + (c0 - offset);
-                if (GS < 4 || c <= GS) {
+                if (c <= (GS > 4 ? GS : 4)) {
                     for (int32_t j = g; j < c; j += GS) {
                         out_put(c0 + j, src[j]);
                     }
@@ -227,14 +269,14 @@ struct Rings {
                     const int32_t head = (4 - (dV & 3)) & 3;
                     const int32_t nd = (c - head) >> 2;
                     const int32_t t0 = head + 4 * nd;
-                    if (g < head) {
-                        outRing[(dV + g) & (OUT_RING - 1)] = src[g];
+                    for (int32_t k = g; k < head; k += GS) {
+                        outRing[(dV + k) & (OUT_RING - 1)] = src[k];
                     }
                     for (int32_t j = g; j < nd; j += GS) {
                         *(uint32_t*)(outRing + ((dV + head + 4 * j) & (OUT_RING - 1))) = ld4(src + head + 4 * j);
                     }
-                    if (g < c - t0) {
-                        outRing[(dV + t0 + g) & (OUT_RING - 1)] = src[t0 + g];
+                    for (int32_t k = t0 + g; k < c; k += GS) {
+                        outRing[(dV + k) & (OUT_RING - 1)] = src[k];
                     }
                 }
             }

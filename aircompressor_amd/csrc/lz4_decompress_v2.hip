@@ -9,7 +9,7 @@
 
 namespace achip {
 
-template <int GS, int IN_RING, int OUT_RING>
+template <int GS, int IN_RING, int OUT_RING, int GPL>
 __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a)
     const int32_t inLimit = a.srcLen[block];
     const int32_t outLimit = a.dstCap[block];
 
-    Rings<GS, IN_RING, OUT_RING> R;
+    Rings<GS, IN_RING, OUT_RING, GPL> R;
     R.init(smem + grp * (IN_RING + OUT_RING), smem + grp * (IN_RING + OUT_RING) + IN_RING, in, inLimit, out, g);
 
     int32_t st = 0;
@@ -121,13 +121,13 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a)
     }
 }
 
-template <int GS, int IN_RING, int OUT_RING>
+template <int GS, int IN_RING, int OUT_RING, int GPL = 1>
 static hipError_t lz4d2_launch(const BatchArgs& a, hipStream_t stream)
 {
     constexpr int GROUPS_PER_WG = 256 / GS;
     const unsigned grid = (unsigned)((a.nBlocks + GROUPS_PER_WG - 1) / GROUPS_PER_WG);
     const size_t lds = (size_t)GROUPS_PER_WG * (IN_RING + OUT_RING);
-    hipLaunchKernelGGL((lz4_decompress_rings_kernel<GS, IN_RING, OUT_RING>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((lz4_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL>), dim3(grid), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -135,6 +135,8 @@ static hipError_t lz4d2_launch(const BatchArgs& a, hipStream_t stream)
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass)
 {
     switch (groupSize) {
+        case 1: return ringClass ? lz4d2_launch<1, 128, 256, 4>(a, stream) : lz4d2_launch<1, 64, 128, 2>(a, stream);
+        case 2: return ringClass ? lz4d2_launch<2, 128, 256, 2>(a, stream) : lz4d2_launch<2, 64, 128, 1>(a, stream);
         case 4: return ringClass ? lz4d2_launch<4, 256, 512>(a, stream) : lz4d2_launch<4, 128, 256>(a, stream);
         case 8: return ringClass ? lz4d2_launch<8, 512, 1024>(a, stream) : lz4d2_launch<8, 256, 512>(a, stream);
         case 32: return ringClass ? lz4d2_launch<32, 2048, 4096>(a, stream) : lz4d2_launch<32, 1024, 2048>(a, stream);

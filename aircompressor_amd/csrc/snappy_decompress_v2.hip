@@ -20,7 +20,7 @@ __device__ __forceinline__ int32_t snappy_op_entry2(int32_t op)  // opLookupTabl
     return ((kind == 2 ? 2 : 4) << 11) | (hi + 1);
 }
 
-template <int GS, int IN_RING, int OUT_RING>
+template <int GS, int IN_RING, int OUT_RING, int GPL>
 __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs 
         const int32_t inLimit = inLen0 - nread;
         const int32_t fastOutLimit = outLimit - 8;
         int32_t ip = 0;
-        Rings<GS, IN_RING, OUT_RING> R;
+        Rings<GS, IN_RING, OUT_RING, GPL> R;
         R.init(smem + grp * (IN_RING + OUT_RING), smem + grp * (IN_RING + OUT_RING) + IN_RING, in, inLimit, out, g);
 
 #define SN_FAIL(off)                                                     \
@@ -138,19 +138,21 @@ __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs 
     }
 }
 
-template <int GS, int IN_RING, int OUT_RING>
+template <int GS, int IN_RING, int OUT_RING, int GPL = 1>
 static hipError_t snd2_launch(const BatchArgs& a, hipStream_t stream)
 {
     constexpr int GROUPS_PER_WG = 256 / GS;
     const unsigned grid = (unsigned)((a.nBlocks + GROUPS_PER_WG - 1) / GROUPS_PER_WG);
     const size_t lds = (size_t)GROUPS_PER_WG * (IN_RING + OUT_RING);
-    hipLaunchKernelGGL((snappy_decompress_rings_kernel<GS, IN_RING, OUT_RING>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((snappy_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL>), dim3(grid), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass)
 {
     switch (groupSize) {
+        case 1: return ringClass ? snd2_launch<1, 128, 256, 4>(a, stream) : snd2_launch<1, 64, 128, 2>(a, stream);
+        case 2: return ringClass ? snd2_launch<2, 128, 256, 2>(a, stream) : snd2_launch<2, 64, 128, 1>(a, stream);
         case 4: return ringClass ? snd2_launch<4, 256, 512>(a, stream) : snd2_launch<4, 128, 256>(a, stream);
         case 8: return ringClass ? snd2_launch<8, 512, 1024>(a, stream) : snd2_launch<8, 256, 512>(a, stream);
         case 32: return ringClass ? snd2_launch<32, 2048, 4096>(a, stream) : snd2_launch<32, 1024, 2048>(a, stream);

@@ -17,11 +17,12 @@
 // Decoding tables live in LDS (Huffman 8 KiB, three FSE tables 6 KiB, a 1024-sequence ring 8 KiB);
 // the regenerated literals of the current block live in a per-wave scratch slab in HBM (128 KiB + 64).
 // Checks are made in the order the Java code makes them, so status + detail equal the Java exception.
-#include "achip_device.h"
+#include "achip_rings.h"
 
 namespace achip {
 
 namespace zd {
+using ZRings = Rings<64, 2048, 4096>;  // one wavefront per item: 1 KiB refill / flush chunks, back-references within 3056 bytes served from LDS
 constexpr int MAX_BLOCK_SIZE = 128 * 1024;
 constexpr int MAX_WINDOW_SIZE = 1 << 23;
 constexpr int HUF_MAX_TABLE_LOG = 12;
@@ -56,6 +57,11 @@ struct Shared {
     int16_t next[256 + 4];
     uint8_t hw[256 + 4];                    // Huffman weights
     int32_t ranks[16];
+    int32_t bS[65];                         // batch execution: exclusive prefix of (litLen + matchLen), bS[n..64] = span
+    int32_t bLL[64];                        // literal length per sequence
+    int32_t bLP[64];                        // exclusive prefix of literal lengths
+    int32_t bOF[64];                        // offset per sequence
+    __attribute__((aligned(16))) uint8_t rings[2048 + 4096];  // input ring (literal / raw-block stream) + output history ring
 };
 
 struct Ctx {
@@ -64,6 +70,7 @@ struct Ctx {
     uint8_t* out;
     int32_t outCap;
     uint8_t* lit;  // this wave's literal slab
+    ZRings* R;     // all output bytes go through this ring pair
     int lane;
     int32_t detail;  // 0 = ok
     int32_t errOff;
@@ -722,6 +729,130 @@ __device__ int32_t compute_table(Ctx& c, Shared& sh, FrameState& fs, int which, 
     return input;
 }
 
+
+// ---- byte-parallel execution of up to 64 decoded sequences (ZstdFrameDecompressor.java:488-509 per sequence) ----
+// Lane i first owns sequence i: two wave scans give every sequence its literal and output start, and the Java
+// validity checks (:491-496) are evaluated for all of them at once -- the lowest failing lane / first failing
+// check is what the sequential Java loop would have thrown.  Then the batch's output span is produced 64 bytes
+// per step, one byte per lane: a binary search over the scanned starts tells the lane which sequence its byte
+// belongs to and whether it is a literal (source = literal stream) or a match byte (source = output - offset).
+// Match bytes whose source lies inside the same 64-byte step are resolved by pointer jumping over the lanes
+// (<= 6 rounds, each round doubles the resolved distance) -- no byte waits for another byte.
+__device__ int32_t execute_batch(Ctx& c, Shared& sh, int32_t i0, int32_t n, int32_t& output, int32_t& literalsInput, int32_t litSize, int32_t input)
+{
+    ZRings& R = *c.R;
+    const int lane = c.lane;
+    const int32_t outputLimit = c.outCap;
+    int32_t ll = 0, ml = 0, of = 0;
+    if (lane < n) {
+        const uint64_t s = sh.seq[i0 + lane];
+        ll = (int32_t)(s & 0x3FFFF);
+        ml = (int32_t)((s >> 18) & 0x3FFFF);
+        of = (int32_t)(s >> 36);
+    }
+    // inclusive scans of litLen and litLen + matchLen
+    int32_t lsum = ll, osum = ll + ml;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t a = __shfl_up(lsum, d);
+        const int32_t b = __shfl_up(osum, d);
+        if (lane >= d) {
+            lsum += a;
+            osum += b;
+        }
+    }
+    const int32_t lp = lsum - ll;          // literals consumed before this sequence (within the batch)
+    const int32_t op = osum - (ll + ml);   // output produced before this sequence (within the batch)
+    // the three checks, in the Java order, for every sequence at once
+    int32_t err = 0;
+    if (lane < n) {
+        if ((int64_t)output + osum > outputLimit) {
+            err = 1;  // "Output buffer too small"
+        }
+        else if ((int64_t)literalsInput + lsum > litSize) {
+            err = 2;  // "Input is corrupted" (literals exhausted)
+        }
+        else if ((int64_t)output + op + ll - of < 0) {
+            err = 3;  // "Input is corrupted" (match before the start of the call's output)
+        }
+    }
+    const unsigned long long bad = __ballot(err != 0);
+    if (bad != 0) {
+        const int32_t e = __shfl(err, __builtin_ctzll(bad));
+        ZFAIL(c, e == 1 ? ACHIP_D_ZSTD_OUTPUT_TOO_SMALL : ACHIP_D_ZSTD_CORRUPTED, input);
+    }
+    const int32_t span = __shfl(osum, 63);
+    const int32_t litTotal = __shfl(lsum, 63);
+    __syncthreads();
+    sh.bS[lane] = lane < n ? op : span;
+    sh.bLL[lane] = ll;
+    sh.bLP[lane] = lp;
+    sh.bOF[lane] = of;
+    if (lane == 0) {
+        sh.bS[64] = span;
+    }
+    __syncthreads();
+
+    for (int32_t chunk = 0; chunk < span; chunk += 64) {
+        const int32_t p = chunk + lane;
+        const bool active = p < span;
+        // which sequence: largest k with bS[k] <= p
+        int32_t k = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            if (sh.bS[k + step] <= p) {
+                k += step;
+            }
+        }
+        const int32_t r = p - sh.bS[k];
+        const int32_t kll = sh.bLL[k];
+        const bool isLit = r < kll;
+        const int32_t litBefore = sh.bLP[k] + (isLit ? r : kll);  // literal bytes of the batch consumed before byte p
+        // source descriptor: literal -> position in the literal stream; match -> absolute output position
+        int32_t src = isLit ? literalsInput + litBefore : (output + p) - sh.bOF[k];
+        int32_t kind = isLit ? 0 : 1;
+        const int32_t chunkAbs = output + chunk;
+        // pointer jumping for match bytes whose source is inside this 64-byte step
+        for (;;) {
+            const bool pending = active && kind == 1 && src >= chunkAbs;
+            if (__ballot(pending) == 0) {
+                break;
+            }
+            const int from = pending ? (src - chunkAbs) : lane;
+            const int32_t nsrc = __shfl(src, from);
+            const int32_t nkind = __shfl(kind, from);
+            if (pending) {
+                src = nsrc;
+                kind = nkind;
+            }
+        }
+        // literal bytes come from the input ring: make the step's literal window resident (monotone cursor)
+        const int32_t litCursor = literalsInput + __shfl(litBefore, 0);
+        R.ensure_input(litCursor, 64);
+        uint32_t byte = 0;
+        if (active) {
+            if (kind == 0) {
+                byte = R.in_u8(src);
+            }
+            else if (chunkAbs - src <= ZRings::LDS_REACH) {
+                byte = R.out_get(src);
+            }
+            else {
+                byte = R.outAligned[R.outBase + src];  // far back-reference: flushed long ago
+            }
+        }
+        wave_mem_order();
+        if (active) {
+            R.out_put(output + p, byte);
+        }
+        const int32_t done = chunk + 64 < span ? chunk + 64 : span;
+        R.flush_complete(output + done);
+    }
+    output += span;
+    literalsInput += litTotal;
+    return 0;
+}
+
 // decompressSequences :312-516 ; returns decoded size or -1
 __device__ int32_t decompress_sequences(Ctx& c, Shared& sh, FrameState& fs, const FseTable* dflt, int32_t inputAddress, int32_t inputLimit, int32_t outputAddress,
                                         const uint8_t* litPtr, int32_t litSize)
@@ -733,6 +864,7 @@ __device__ int32_t decompress_sequences(Ctx& c, Shared& sh, FrameState& fs, cons
     const int32_t size = inputLimit - inputAddress;
     ZVERIFY(c, size >= 1, ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, input);
 
+    c.R->reset_input(litPtr, litSize);
     int32_t sequenceCount = (int32_t)rd_le(c, input++, 1);
     if (sequenceCount != 0) {
         if (sequenceCount == 255) {
@@ -852,23 +984,12 @@ __device__ int32_t decompress_sequences(Ctx& c, Shared& sh, FrameState& fs, cons
                 nDecoded++;
             }
             __syncthreads();
-            // ---- execute them in order (checks of :491-496 first, then copyLiterals / copyMatch) ----
-            for (int32_t i = 0; i < nDecoded; i++) {
-                const uint64_t s = sh.seq[i];
-                const int32_t literalsLength = (int32_t)(s & 0x3FFFF);
-                const int32_t matchLength = (int32_t)((s >> 18) & 0x3FFFF);
-                const int32_t offset = (int32_t)(s >> 36);
-                const int64_t literalOutputLimit = (int64_t)output + literalsLength;
-                const int64_t matchOutputLimit = literalOutputLimit + matchLength;
-                ZVERIFY(c, matchOutputLimit <= outputLimit, ACHIP_D_ZSTD_OUTPUT_TOO_SMALL, input);
-                const int32_t literalEnd = literalsInput + literalsLength;
-                ZVERIFY(c, literalEnd <= litSize, ACHIP_D_ZSTD_CORRUPTED, input);
-                const int64_t matchAddress = literalOutputLimit - offset;
-                ZVERIFY(c, matchAddress >= 0, ACHIP_D_ZSTD_CORRUPTED, input);  // >= start of the whole call's output :496
-                wave_copy(c.out + output, litPtr + literalsInput, literalsLength, c.lane);
-                group_match_copy<64>(c.out, (int32_t)literalOutputLimit, offset, matchLength, c.lane);
-                output = (int32_t)matchOutputLimit;
-                literalsInput = literalEnd;
+            // ---- execute them, 64 sequences per batch, one output byte per lane per step ----
+            for (int32_t i0 = 0; i0 < nDecoded; i0 += 64) {
+                const int32_t nb = nDecoded - i0 < 64 ? nDecoded - i0 : 64;
+                if (execute_batch(c, sh, i0, nb, output, literalsInput, litSize, input) < 0) {
+                    return -1;
+                }
             }
             if (notConsumed) {
                 ZFAIL(c, ACHIP_D_ZSTD_SEQUENCES_NOT_CONSUMED, input);
@@ -881,8 +1002,7 @@ __device__ int32_t decompress_sequences(Ctx& c, Shared& sh, FrameState& fs, cons
     // copyLastLiteral :518-525
     const int32_t last = litSize - literalsInput;
     ZVERIFY(c, (int64_t)output + last <= outputLimit, ACHIP_D_ZSTD_OUTPUT_TOO_SMALL, input);
-    wave_mem_order();
-    wave_copy(c.out + output, litPtr + literalsInput, last, c.lane);
+    c.R->copy_literals(literalsInput, output, last);
     output += last;
     return output - outputAddress;
 }
@@ -961,14 +1081,15 @@ __device__ int32_t zstd_decompress_item(Ctx& c, Shared& sh, const FseTable* dflt
             if (blockType == 0) {  // decodeRawBlock :223-229
                 ZVERIFY(c, (int64_t)input + blockSize <= inputLimit, ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, input);
                 ZVERIFY(c, (int64_t)output + blockSize <= c.outCap, ACHIP_D_ZSTD_OUTPUT_TOO_SMALL, input);
-                wave_copy(c.out + output, c.in + input, blockSize, c.lane);
+                c.R->reset_input(c.in + input, blockSize);
+                c.R->copy_literals(0, output, blockSize);
                 decodedSize = blockSize;
                 input += blockSize;
             }
             else if (blockType == 1) {  // decodeRleBlock :231-263
                 ZVERIFY(c, input + 1 <= inputLimit, ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, input);
                 ZVERIFY(c, (int64_t)output + blockSize <= c.outCap, ACHIP_D_ZSTD_OUTPUT_TOO_SMALL, input);
-                wave_fill(c.out + output, c.in[input], blockSize, c.lane);
+                c.R->fill(output, c.in[input], blockSize);
                 decodedSize = blockSize;
                 input += 1;
             }
@@ -986,7 +1107,8 @@ __device__ int32_t zstd_decompress_item(Ctx& c, Shared& sh, const FseTable* dflt
         } while (!lastBlock);
 
         if (hasChecksum) {
-            // all of this frame's stores must be visible to the hashing loads: same wave, program order
+            // flush the ring, then all of this frame's stores are visible to the hashing loads: same wave, program order
+            c.R->flush_all(output);
             const uint64_t hash = wave_xxh64(c.out + outputStart, output - outputStart, c.lane);
             ZVERIFY(c, input + 4 <= inputLimit, ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, input);
             const uint32_t checksum = (uint32_t)rd_le(c, input, 4);
@@ -996,6 +1118,7 @@ __device__ int32_t zstd_decompress_item(Ctx& c, Shared& sh, const FseTable* dflt
             input += 4;
         }
     }
+    c.R->flush_all(output);
     return output;
 }
 
@@ -1012,6 +1135,7 @@ __global__ __launch_bounds__(64) void zstd_default_tables_kernel(zd::FseTable* d
     c.out = nullptr;
     c.outCap = 0;
     c.lit = nullptr;
+    c.R = nullptr;
     c.lane = threadIdx.x;
     c.detail = 0;
     c.errOff = 0;
@@ -1057,6 +1181,9 @@ __global__ __launch_bounds__(64) void zstd_decompress_kernel(BatchArgs a, const 
         c.lane = lane;
         c.detail = 0;
         c.errOff = 0;
+        ZRings R;
+        R.init(sh.rings, sh.rings + 2048, c.in, 0, c.out, lane);
+        c.R = &R;
         const int32_t r = zstd_decompress_item(c, sh, dflt);
         if (lane == 0) {
             a.outLen[block] = r >= 0 ? r : 0;

@@ -16,7 +16,7 @@ CODECS = {
     "snappy": dict(c=3, d=2, group_opt="snappy.decompress.group", variant_opt="snappy.decompress.variant"),
 }
 # decoder configurations: (variant, lanes per block, ring class); variant 1 = LDS rings (default), 0 = direct-to-HBM groups
-DECODERS = [(1, 16, 0), (1, 16, 1), (1, 4, 0), (1, 4, 1), (1, 8, 0), (1, 8, 1), (1, 32, 0), (1, 32, 1), (1, 64, 0), (1, 64, 1)] + [(0, g, 0) for g in (1, 2, 4, 8, 16, 32, 64)]
+DECODERS = [(1, 16, 0), (1, 16, 1), (1, 4, 0), (1, 4, 1), (1, 2, 0), (1, 2, 1), (1, 1, 0), (1, 1, 1), (1, 8, 0), (1, 8, 1), (1, 32, 0), (1, 32, 1), (1, 64, 0), (1, 64, 1)] + [(0, g, 0) for g in (1, 2, 4, 8, 16, 32, 64)]
 
 
 def configure(gb, codec, cfg):
@@ -95,7 +95,7 @@ def _oracle_status(o, codec, data, cap):
 
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
-@pytest.mark.parametrize("cfg", [(1, 16, 0), (1, 4, 0), (1, 8, 1), (1, 64, 0), (0, 8, 0), (0, 64, 0)])
+@pytest.mark.parametrize("cfg", [(1, 16, 0), (1, 4, 0), (1, 2, 1), (1, 1, 0), (1, 8, 1), (1, 64, 0), (0, 8, 0), (0, 64, 0)])
 def test_malformed_inputs_report_the_reference_errors(gb, o, codec, cfg):
     """Error KATs of the reference plus systematic corruption: status class/detail and offset must equal the oracle's
     (= what the Java decoder throws), and nothing is written outside the block's output."""

@@ -9,7 +9,7 @@ wls = sys.argv[2].split(",") if len(sys.argv) > 2 else ["lz4_decompress"]
 rows = []
 for wl in wls:
     for data in ("fragments", "wordmix"):
-        for variant, group, ring in [(1, 4, 0), (1, 4, 1), (1, 8, 0), (1, 8, 1), (1, 16, 0), (1, 16, 1), (1, 32, 0)]:
+        for variant, group, ring in [(1, 1, 0), (1, 1, 1), (1, 2, 0), (1, 2, 1), (1, 4, 0), (1, 4, 1), (1, 8, 0)]:
             cmd = [sys.executable, "bench.py", "--blocks", blocks, "--pool", "2048", "--steps", "4", "--warmup", "1", "--workload", wl, "--data", data,
                    "--group", str(group), "--variant", str(variant), "--ring-class", str(ring), "--no-cpu-baseline", "--no-extra"]
             p = subprocess.run(cmd, capture_output=True, text=True)
