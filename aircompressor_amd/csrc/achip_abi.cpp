@@ -36,8 +36,8 @@ struct achip_ctx {
     int lz4dVariant = 1;     // 0 = direct-to-HBM groups (lz4_decompress.hip), 1 = LDS rings (lz4_decompress_v2.hip)
     int snappydVariant = 1;
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
-    int lz4cVariant = 0;
-    int snappycVariant = 0;
+    int lz4cVariant = 1;     // 0 = serial probes, 1 = 64 probes per step (batch)
+    int snappycVariant = 1;  // 0 = serial probes, 1 = 64 probes per step (batch)
     int zstddVariant = 0;
     int zstdcVariant = 0;
     int maxSrcLenHint = 0;

@@ -118,6 +118,50 @@ struct Rings {
         return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(pv & 3));
     }
 
+
+    // c bytes (GS < c <= CHUNK) from virtual position sV of ring `src` to virtual position dV of the output ring:
+    // aligned destination dwords (<= 4 per lane, reads issued back to back so one LDS latency covers them all),
+    // <= 3 head and <= 3 tail bytes.  The source must not overlap the c destination bytes.
+    template <int SRC_RING>
+    __device__ __forceinline__ void copy_dwords(const uint8_t* src, int32_t sV, int32_t dV, int32_t c)
+    {
+        const int32_t head = (4 - (dV & 3)) & 3;
+        const int32_t nd = (c - head) >> 2;
+        const int32_t t0 = head + 4 * nd;
+        constexpr int ITER = CHUNK / (4 * GS);  // = 4 * GPL
+        uint32_t w[ITER];
+#pragma unroll
+        for (int q = 0; q < ITER; q++) {
+            const int32_t j = g + GS * q;
+            w[q] = j < nd ? ring_ld4<SRC_RING>(src, sV + head + 4 * j) : 0u;
+        }
+        uint32_t hb = 0, tb = 0;
+        const bool hasHead = g < head, hasTail = t0 + g < c;
+        if (GS >= 4) {
+            if (hasHead) hb = src[(sV + g) & (SRC_RING - 1)];
+            if (hasTail) tb = src[(sV + t0 + g) & (SRC_RING - 1)];
+        }
+#pragma unroll
+        for (int q = 0; q < ITER; q++) {
+            const int32_t j = g + GS * q;
+            if (j < nd) {
+                *(uint32_t*)(outRing + ((dV + head + 4 * j) & (OUT_RING - 1))) = w[q];
+            }
+        }
+        if (GS >= 4) {
+            if (hasHead) outRing[(dV + g) & (OUT_RING - 1)] = (uint8_t)hb;
+            if (hasTail) outRing[(dV + t0 + g) & (OUT_RING - 1)] = (uint8_t)tb;
+        }
+        else {
+            for (int32_t k = g; k < head; k += GS) {
+                outRing[(dV + k) & (OUT_RING - 1)] = src[(sV + k) & (SRC_RING - 1)];
+            }
+            for (int32_t k = t0 + g; k < c; k += GS) {
+                outRing[(dV + k) & (OUT_RING - 1)] = src[(sV + k) & (SRC_RING - 1)];
+            }
+        }
+    }
+
     // ---- output side ----
     __device__ __forceinline__ void out_put(int32_t pos, uint32_t byte) { outRing[(pos + outBase) & (OUT_RING - 1)] = (uint8_t)byte; }
     __device__ __forceinline__ uint32_t out_get(int32_t pos) const { return outRing[(pos + outBase) & (OUT_RING - 1)]; }
@@ -194,20 +238,8 @@ struct Rings {
                     out_put(op + k, in_u8(ip + k));
                 }
             }
-            else {  // aligned destination dwords, funnel-shifted source; <= 3 head and <= 3 tail bytes one per lane
-                const int32_t dV = op + outBase, sV = ip + inBase;
-                const int32_t head = (4 - (dV & 3)) & 3;
-                const int32_t nd = (c - head) >> 2;
-                const int32_t t0 = head + 4 * nd;
-                for (int32_t k = g; k < head; k += GS) {
-                    outRing[(dV + k) & (OUT_RING - 1)] = inRing[(sV + k) & (IN_RING - 1)];
-                }
-                for (int32_t j = g; j < nd; j += GS) {
-                    *(uint32_t*)(outRing + ((dV + head + 4 * j) & (OUT_RING - 1))) = ring_ld4<IN_RING>(inRing, sV + head + 4 * j);
-                }
-                for (int32_t k = t0 + g; k < c; k += GS) {
-                    outRing[(dV + k) & (OUT_RING - 1)] = inRing[(sV + k) & (IN_RING - 1)];
-                }
+            else {
+                copy_dwords<IN_RING>(inRing, ip + inBase, op + outBase, c);
             }
             ip += c;
             op += c;
@@ -233,19 +265,7 @@ struct Rings {
                     }
                 }
                 else if (offset >= c) {
-                    const int32_t dV = c0 + outBase, sV = dV - offset;
-                    const int32_t head = (4 - (dV & 3)) & 3;
-                    const int32_t nd = (c - head) >> 2;
-                    const int32_t t0 = head + 4 * nd;
-                    for (int32_t k = g; k < head; k += GS) {
-                        outRing[(dV + k) & (OUT_RING - 1)] = outRing[(sV + k) & (OUT_RING - 1)];
-                    }
-                    for (int32_t j = g; j < nd; j += GS) {
-                        *(uint32_t*)(outRing + ((dV + head + 4 * j) & (OUT_RING - 1))) = ring_ld4<OUT_RING>(outRing, sV + head + 4 * j);
-                    }
-                    for (int32_t k = t0 + g; k < c; k += GS) {
-                        outRing[(dV + k) & (OUT_RING - 1)] = outRing[(sV + k) & (OUT_RING - 1)];
-                    }
+                    copy_dwords<OUT_RING>(outRing, c0 + outBase - offset, c0 + outBase, c);
                 }
                 else {
                     // ceil(2^32 / offset): j / offset == umulhi(j, inv) exactly for j < CHUNK (offset == 1: quotient is j)

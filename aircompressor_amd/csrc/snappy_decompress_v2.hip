@@ -91,10 +91,8 @@ __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs 
             if (!(ip + 4 < inLimit)) {  // :90-92
                 if (ip + trailerBytes > inLimit) SN_FAIL(ip);
             }
-            uint32_t t = 0;  // little-endian trailer; bytes past the input end are never selected
-            for (int k = trailerBytes - 1; k >= 0; k--) {
-                t = (t << 8) | R.in_u8(ip + k);
-            }
+            // little-endian trailer: one unaligned 4-byte ring read, masked to trailerBytes (bytes past the input end are never selected)
+            const uint32_t t = trailerBytes == 0 ? 0u : (R.template ring_ld4<IN_RING>(R.inRing, ip + R.inBase) & (0xFFFFFFFFu >> (32 - 8 * trailerBytes)));
             const int32_t trailer = (int32_t)t;
             if (trailer < 0) SN_FAIL(ip);
             ip += trailerBytes;

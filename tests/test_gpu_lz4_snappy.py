@@ -47,7 +47,9 @@ def all_blocks():
 
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
-def test_compress_is_bit_exact_with_oracle(gb, o, codec):
+@pytest.mark.parametrize("variant", [1, 0])
+def test_compress_is_bit_exact_with_oracle(gb, o, codec, variant):
+    gb.set_option("%s.compress.variant" % codec, variant)  # 1 = 64 probes per step (default), 0 = serial probes
     blocks = all_blocks()
     caps = [o.max_compressed_length(codec, len(b)) for b in blocks]
     outs, status, _ = gb.run(CODECS[codec]["c"], blocks, caps)
@@ -58,6 +60,7 @@ def test_compress_is_bit_exact_with_oracle(gb, o, codec):
     n_hand = len(common.HAND_CASES)
     for k, (_, _, e) in enumerate(common.corpus_sample()):
         assert hashlib.sha256(outs[n_hand + k]).hexdigest() == e[codec]["sha256"]
+    gb.set_option("%s.compress.variant" % codec, 1)
 
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
