@@ -38,8 +38,10 @@ struct achip_ctx {
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
     int lz4cVariant = 1;     // 0 = serial probes, 1 = 64 probes per step (batch)
     int snappycVariant = 1;  // 0 = serial probes, 1 = 64 probes per step (batch)
-    int zstddVariant = 0;
+    int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 0;
+    int32_t lastZstddBlocks = 0;  // achip_ctx_get_stat
+    int lastZstddVariant = 0;
     int maxSrcLenHint = 0;
     // scratch for the zstd pipeline (grown on demand)
     void* scratch = nullptr;
@@ -161,6 +163,8 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& a)
             int32_t r = ensure_scratch(ctx, achip::zstd_decompress_scratch_bytes(a.nBlocks));
             if (r < 0) return r;
             e = achip::launch_zstd_decompress(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->zstddVariant);
+            ctx->lastZstddBlocks = a.nBlocks;
+            ctx->lastZstddVariant = ctx->zstddVariant;
             break;
         }
         case ACHIP_OP_ZSTD_COMPRESS: {
@@ -409,6 +413,28 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;
     else return bad_argument("unknown option");
     return 0;
+}
+
+int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name)
+{
+    if (!ctx || !name) return -1;
+    std::string k(name);
+    const std::string prefix = "zstd.decompress.fallback_";
+    if (k.compare(0, prefix.size(), prefix) == 0) {
+        // "items": all items handed to the one-kernel decoder; "stage1".."stage5": by the stage that handed them over
+        const std::string what = k.substr(prefix.size());
+        int word = -1;
+        if (what == "items") word = 0;
+        else if (what.size() == 6 && what.compare(0, 5, "stage") == 0 && what[5] >= '1' && what[5] <= '5') word = 32 + (what[5] - '0');
+        if (word < 0) return -1;
+        if (ctx->lastZstddBlocks <= 0 || ctx->scratch == nullptr) return -1;
+        if (ctx->lastZstddVariant == 0) return word == 0 ? ctx->lastZstddBlocks : 0;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+        int32_t v = 0;
+        if (hipMemcpy(&v, (const int32_t*)ctx->scratch + word, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;  // the pipeline's counters lead its scratch
+        return v;
+    }
+    return -1;
 }
 
 // ---- memory helpers ----------------------------------------------------

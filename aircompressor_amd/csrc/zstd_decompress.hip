@@ -17,514 +17,11 @@
 // Decoding tables live in LDS (Huffman 8 KiB, three FSE tables 6 KiB, a 1024-sequence ring 8 KiB);
 // the regenerated literals of the current block live in a per-wave scratch slab in HBM (128 KiB + 64).
 // Checks are made in the order the Java code makes them, so status + detail equal the Java exception.
-#include "achip_rings.h"
+#include "zstd_dec_common.h"
 
 namespace achip {
 
 namespace zd {
-using ZRings = Rings<64, 2048, 4096>;  // one wavefront per item: 1 KiB refill / flush chunks, back-references within 3056 bytes served from LDS
-constexpr int MAX_BLOCK_SIZE = 128 * 1024;
-constexpr int MAX_WINDOW_SIZE = 1 << 23;
-constexpr int HUF_MAX_TABLE_LOG = 12;
-constexpr int SEQ_RING = 1024;
-constexpr int LIT_SLAB = MAX_BLOCK_SIZE + 64;
-
-__constant__ int32_t LL_BASE[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 0x80, 0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x4000, 0x8000, 0x10000};
-__constant__ int32_t ML_BASE[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34,
-                                    35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 0x83, 0x103, 0x203, 0x403, 0x803, 0x1003, 0x2003, 0x4003, 0x8003, 0x10003};
-__constant__ int32_t OF_BASE[29] = {0, 1, 1, 5, 0xD, 0x1D, 0x3D, 0x7D, 0xFD, 0x1FD, 0x3FD, 0x7FD, 0xFFD, 0x1FFD, 0x3FFD, 0x7FFD, 0xFFFD, 0x1FFFD, 0x3FFFD, 0x7FFFD,
-                                    0xFFFFD, 0x1FFFFD, 0x3FFFFD, 0x7FFFFD, 0xFFFFFD, 0x1FFFFFD, 0x3FFFFFD, 0x7FFFFFD, 0xFFFFFFD};
-__constant__ uint8_t LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-__constant__ uint8_t ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                                    1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-// predefined distributions, RFC 8878 3.1.1.3.2.2 (they rebuild ZstdFrameDecompressor.java:85-113 exactly; checked entry by entry against the Java source in the CPU test suite)
-__constant__ int16_t LL_DEFAULT_NORM[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
-__constant__ int16_t OF_DEFAULT_NORM[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
-__constant__ int16_t ML_DEFAULT_NORM[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
-                                            1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
-
-// FSE decoding table entry: newState (low 16, signed) | symbol << 16 | numberOfBits << 24
-struct FseTable {
-    uint32_t e[512];
-};
-
-struct Shared {
-    uint16_t huf[1 << HUF_MAX_TABLE_LOG];  // symbol | numberOfBits << 8
-    FseTable fse[3];                        // 0 = literal lengths, 1 = offsets, 2 = match lengths (own tables)
-    FseTable weights;                       // Huffman weight FSE table (log <= 6), reused as scratch
-    uint64_t seq[SEQ_RING];                 // litLen (18) | matchLen (18) << 18 | offset (24+) << 36
-    int16_t norm[256 + 4];
-    int16_t next[256 + 4];
-    uint8_t hw[256 + 4];                    // Huffman weights
-    int32_t ranks[16];
-    int32_t bS[65];                         // batch execution: exclusive prefix of (litLen + matchLen), bS[n..64] = span
-    int32_t bLL[64];                        // literal length per sequence
-    int32_t bLP[64];                        // exclusive prefix of literal lengths
-    int32_t bOF[64];                        // offset per sequence
-    __attribute__((aligned(16))) uint8_t rings[2048 + 4096];  // input ring (literal / raw-block stream) + output history ring
-};
-
-struct Ctx {
-    const uint8_t* __restrict__ in;
-    int32_t inLen;
-    uint8_t* out;
-    int32_t outCap;
-    uint8_t* lit;  // this wave's literal slab
-    ZRings* R;     // all output bytes go through this ring pair
-    int lane;
-    int32_t detail;  // 0 = ok
-    int32_t errOff;
-};
-
-__device__ __forceinline__ uint64_t rd_le(const Ctx& c, int32_t pos, int n)
-{
-    // bounds-guarded little-endian read of n <= 8 bytes; bytes outside the input read as 0
-    if (pos >= 0 && pos + 8 <= c.inLen) {
-        const uint64_t v = ld8(c.in + pos);
-        return n >= 8 ? v : (v & ((1ull << (8 * n)) - 1ull));
-    }
-    uint64_t v = 0;
-    for (int i = 0; i < n; i++) {
-        const int32_t p = pos + i;
-        if (p >= 0 && p < c.inLen) {
-            v |= (uint64_t)c.in[p] << (8 * i);
-        }
-    }
-    return v;
-}
-
-#define ZFAIL(c, d, off)         \
-    {                            \
-        (c).detail = (d);        \
-        (c).errOff = (int32_t)(off); \
-        return -1;               \
-    }
-#define ZVERIFY(c, cond, d, off) \
-    if (!(cond)) ZFAIL(c, d, off)
-
-__device__ __forceinline__ int32_t highest_bit(uint32_t v) { return 31 - __builtin_clz(v); }
-
-// ---- BitInputStream.java ----
-struct Bits {
-    int32_t start, current;
-    uint64_t bits;
-    int32_t consumed;
-    bool overflow;
-};
-__device__ __forceinline__ uint64_t peek_bits(int32_t consumed, uint64_t bits, int32_t n)  // :64-67
-{
-    return ((bits << (consumed & 63)) >> 1) >> ((63 - n) & 63);
-}
-__device__ __forceinline__ uint64_t peek_bits_fast(int32_t consumed, uint64_t bits, int32_t n)  // :74-77
-{
-    return (bits << (consumed & 63)) >> ((64 - n) & 63);
-}
-// Initializer.initialize :110-130 ; returns detail (0 = ok) and the offset through *eo
-__device__ __forceinline__ int32_t bit_init(const Ctx& c, Bits& b, int32_t start, int32_t end, int32_t* eo)
-{
-    if (end - start < 1) {
-        *eo = start;
-        return ACHIP_D_ZSTD_BITSTREAM_EMPTY;
-    }
-    const int32_t last = (int32_t)rd_le(c, end - 1, 1);
-    if (last == 0) {
-        *eo = end;
-        return ACHIP_D_ZSTD_BITSTREAM_NO_MARK;
-    }
-    b.start = start;
-    b.overflow = false;
-    b.consumed = 8 - highest_bit((uint32_t)last);
-    const int32_t size = end - start;
-    if (size >= 8) {
-        b.current = end - 8;
-        b.bits = rd_le(c, b.current, 8);
-    }
-    else {
-        b.current = start;
-        b.bits = rd_le(c, start, size);
-        b.consumed += (8 - size) * 8;
-    }
-    return 0;
-}
-// Loader.load :171-204 ; returns the Java boolean
-__device__ __forceinline__ bool bit_load(const Ctx& c, Bits& b)
-{
-    if (b.consumed > 64) {
-        b.overflow = true;
-        return true;
-    }
-    if (b.current == b.start) {
-        return true;
-    }
-    int32_t bytes = (int32_t)((uint32_t)b.consumed >> 3);
-    if (b.current >= b.start + 8) {
-        if (bytes > 0) {
-            b.current -= bytes;
-            b.bits = rd_le(c, b.current, 8);
-        }
-        b.consumed &= 7;
-    }
-    else if (b.current - bytes < b.start) {
-        bytes = b.current - b.start;
-        b.current = b.start;
-        b.consumed -= bytes * 8;
-        b.bits = rd_le(c, b.start, 8);
-        return true;
-    }
-    else {
-        b.current -= bytes;
-        b.consumed -= bytes * 8;
-        b.bits = rd_le(c, b.current, 8);
-    }
-    return false;
-}
-
-// ---- FSE decoding table from normalized counts: FseTableReader.java:127-159 + spreadSymbols ----
-// Wave-uniform serial code: every lane computes the same values; lane 0's LDS stores are the ones that count.
-__device__ int32_t fse_build(Ctx& c, Shared& sh, FseTable& t, int32_t maxSymbol, int32_t tableLog, int32_t off)
-{
-    const int32_t tableSize = 1 << tableLog;
-    int32_t high = tableSize - 1;
-    __syncthreads();
-    if (c.lane == 0) {
-        for (int32_t s = 0; s <= maxSymbol; s++) {
-            if (sh.norm[s] == -1) {
-                t.e[high--] = (uint32_t)s << 16;
-                sh.next[s] = 1;
-            }
-            else {
-                sh.next[s] = sh.norm[s];
-            }
-        }
-    }
-    else {
-        for (int32_t s = 0; s <= maxSymbol; s++) {
-            if (sh.norm[s] == -1) {
-                high--;
-            }
-        }
-    }
-    const int32_t mask = tableSize - 1;
-    const int32_t step = (tableSize >> 1) + (tableSize >> 3) + 3;
-    int32_t position = 0;
-    for (int32_t s = 0; s <= maxSymbol; s++) {
-        const int32_t n = sh.norm[s];
-        for (int32_t i = 0; i < n; i++) {
-            if (c.lane == 0) {
-                t.e[position] = (uint32_t)s << 16;
-            }
-            do {
-                position = (position + step) & mask;
-            } while (position > high);
-        }
-    }
-    ZVERIFY(c, position == 0, ACHIP_D_ZSTD_CORRUPTED, off);
-    __syncthreads();
-    if (c.lane == 0) {
-        for (int32_t i = 0; i < tableSize; i++) {
-            const uint32_t symbol = t.e[i] >> 16;
-            const int32_t nextState = (uint16_t)sh.next[symbol]++;
-            const int32_t nb = tableLog - highest_bit((uint32_t)nextState);
-            const int32_t newState = (int16_t)((nextState << nb) - tableSize);
-            t.e[i] = ((uint32_t)newState & 0xFFFFu) | (symbol << 16) | ((uint32_t)nb << 24);
-        }
-    }
-    __syncthreads();
-    return 0;
-}
-
-// FseTableReader.readFseTable :27-160 ; returns bytes consumed (>= 0) or -1; *logOut = table log
-__device__ int32_t read_fse_table(Ctx& c, Shared& sh, FseTable& t, int32_t inputAddress, int32_t inputLimit, int32_t maxSymbol, int32_t maxTableLog, int32_t* logOut)
-{
-    int32_t input = inputAddress;
-    ZVERIFY(c, inputLimit - inputAddress >= 4, ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, input);
-    int32_t symbolNumber = 0;
-    bool previousIsZero = false;
-    uint32_t bitStream = (uint32_t)rd_le(c, input, 4);
-    const int32_t tableLog = (int32_t)(bitStream & 0xF) + 5;
-    int32_t numberOfBits = tableLog + 1;
-    bitStream >>= 4;
-    int32_t bitCount = 4;
-    ZVERIFY(c, tableLog <= maxTableLog, ACHIP_D_ZSTD_FSE_TABLE_LOG, input);
-    int32_t remaining = (1 << tableLog) + 1;
-    int32_t threshold = 1 << tableLog;
-    __syncthreads();
-    while (remaining > 1 && symbolNumber <= maxSymbol) {
-        if (previousIsZero) {
-            int32_t n0 = symbolNumber;
-            while ((bitStream & 0xFFFF) == 0xFFFF) {
-                n0 += 24;
-                if (input < inputLimit - 5) {
-                    input += 2;
-                    bitStream = (uint32_t)rd_le(c, input, 4) >> (bitCount & 31);
-                }
-                else {
-                    bitStream >>= 16;
-                    bitCount += 16;
-                }
-            }
-            while ((bitStream & 3) == 3) {
-                n0 += 3;
-                bitStream >>= 2;
-                bitCount += 2;
-            }
-            n0 += (int32_t)(bitStream & 3);
-            bitCount += 2;
-            ZVERIFY(c, n0 <= maxSymbol, ACHIP_D_ZSTD_FSE_SYMBOL, input);
-            while (symbolNumber < n0) {
-                if (c.lane == 0) sh.norm[symbolNumber] = 0;
-                symbolNumber++;
-            }
-            if ((input <= inputLimit - 7) || (input + (bitCount >> 3) <= inputLimit - 4)) {
-                input += bitCount >> 3;
-                bitCount &= 7;
-                bitStream = (uint32_t)rd_le(c, input, 4) >> (bitCount & 31);
-            }
-            else {
-                bitStream >>= 2;
-            }
-        }
-        const int16_t max = (int16_t)((2 * threshold - 1) - remaining);
-        int16_t count;
-        if ((int32_t)(bitStream & (uint32_t)(threshold - 1)) < max) {
-            count = (int16_t)(bitStream & (uint32_t)(threshold - 1));
-            bitCount += numberOfBits - 1;
-        }
-        else {
-            count = (int16_t)(bitStream & (uint32_t)(2 * threshold - 1));
-            if (count >= threshold) {
-                count = (int16_t)(count - max);
-            }
-            bitCount += numberOfBits;
-        }
-        count--;
-        remaining -= count < 0 ? -count : count;
-        if (c.lane == 0) sh.norm[symbolNumber] = count;
-        symbolNumber++;
-        previousIsZero = count == 0;
-        while (remaining < threshold) {
-            numberOfBits--;
-            threshold >>= 1;
-        }
-        if ((input <= inputLimit - 7) || (input + (bitCount >> 3) <= inputLimit - 4)) {
-            input += bitCount >> 3;
-            bitCount &= 7;
-        }
-        else {
-            bitCount -= 8 * (inputLimit - 4 - input);
-            input = inputLimit - 4;
-        }
-        bitStream = (uint32_t)rd_le(c, input, 4) >> (bitCount & 31);
-    }
-    ZVERIFY(c, remaining == 1 && bitCount <= 32, ACHIP_D_ZSTD_CORRUPTED, input);
-    maxSymbol = symbolNumber - 1;
-    ZVERIFY(c, maxSymbol <= 255, ACHIP_D_ZSTD_FSE_SYMBOL, input);
-    input += (bitCount + 7) >> 3;
-    if (fse_build(c, sh, t, maxSymbol, tableLog, input) < 0) {
-        return -1;
-    }
-    *logOut = tableLog;
-    return input - inputAddress;
-}
-
-#define FSE_NEWSTATE(e) ((int32_t)(int16_t)((e) & 0xFFFFu))
-#define FSE_SYMBOL(e) ((int32_t)(((e) >> 16) & 0xFFu))
-#define FSE_NBITS(e) ((int32_t)((e) >> 24))
-
-// FiniteStateEntropy.decompress :38-151 (Huffman weights) into sh.hw ; returns count or -1
-__device__ int32_t fse_decompress_weights(Ctx& c, Shared& sh, const FseTable& t, int32_t log, int32_t inputAddress, int32_t inputLimit)
-{
-    const int32_t outputLimit = 256;
-    int32_t output = 0;
-    Bits b;
-    int32_t eo = 0;
-    const int32_t d = bit_init(c, b, inputAddress, inputLimit, &eo);
-    if (d != 0) ZFAIL(c, d, eo);
-    int32_t state1 = (int32_t)peek_bits(b.consumed, b.bits, log);
-    b.consumed += log;
-    bit_load(c, b);
-    int32_t state2 = (int32_t)peek_bits(b.consumed, b.bits, log);
-    b.consumed += log;
-    bit_load(c, b);
-#define W_EMIT(state)                                   \
-    {                                                   \
-        if (c.lane == 0) sh.hw[output] = (uint8_t)FSE_SYMBOL(t.e[state]); \
-        output++;                                       \
-    }
-#define W_STEP(state)                                                                      \
-    {                                                                                      \
-        const uint32_t e_ = t.e[state];                                                    \
-        const int32_t nb_ = FSE_NBITS(e_);                                                 \
-        state = FSE_NEWSTATE(e_) + (int32_t)peek_bits(b.consumed, b.bits, nb_);            \
-        b.consumed += nb_;                                                                 \
-    }
-    while (output <= outputLimit - 4) {
-        W_EMIT(state1) W_STEP(state1) W_EMIT(state2) W_STEP(state2) W_EMIT(state1) W_STEP(state1) W_EMIT(state2) W_STEP(state2)
-        if (bit_load(c, b)) {
-            break;
-        }
-    }
-    for (;;) {
-        ZVERIFY(c, output <= outputLimit - 2, ACHIP_D_ZSTD_FSE_OUTPUT_SMALL, inputAddress);
-        W_EMIT(state1) W_STEP(state1)
-        b.overflow = false;
-        bit_load(c, b);
-        if (b.overflow) {
-            W_EMIT(state2)
-            break;
-        }
-        ZVERIFY(c, output <= outputLimit - 2, ACHIP_D_ZSTD_FSE_OUTPUT_SMALL, inputAddress);
-        W_EMIT(state2) W_STEP(state2)
-        b.overflow = false;
-        bit_load(c, b);
-        if (b.overflow) {
-            W_EMIT(state1)
-            break;
-        }
-    }
-#undef W_EMIT
-#undef W_STEP
-    __syncthreads();
-    return output;
-}
-
-// Huffman.readTable :52-128 ; returns bytes consumed or -1 ; sets *tableLogOut
-__device__ int32_t huf_read_table(Ctx& c, Shared& sh, int32_t inputAddress, int32_t size, int32_t* tableLogOut)
-{
-    int32_t input = inputAddress;
-    ZVERIFY(c, size > 0, ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, input);
-    int32_t inputSize = (int32_t)rd_le(c, input++, 1);
-    int32_t outputSize;
-    __syncthreads();
-    if (inputSize >= 128) {
-        outputSize = inputSize - 127;
-        inputSize = (outputSize + 1) / 2;
-        ZVERIFY(c, inputSize + 1 <= size, ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, input);
-        ZVERIFY(c, outputSize <= 256, ACHIP_D_ZSTD_CORRUPTED, input);
-        for (int32_t i = c.lane * 2; i < outputSize; i += 128) {
-            const int32_t value = (int32_t)rd_le(c, input + i / 2, 1);
-            sh.hw[i] = (uint8_t)(value >> 4);
-            sh.hw[i + 1] = (uint8_t)(value & 0xF);
-        }
-        __syncthreads();
-    }
-    else {
-        ZVERIFY(c, inputSize + 1 <= size, ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, input);
-        const int32_t inputLimit = input + inputSize;
-        int32_t wlog = 0;
-        const int32_t n = read_fse_table(c, sh, sh.weights, input, inputLimit, 255, 6, &wlog);
-        if (n < 0) return -1;
-        input += n;
-        outputSize = fse_decompress_weights(c, sh, sh.weights, wlog, input, inputLimit);
-        if (outputSize < 0) return -1;
-    }
-
-    // rank statistics (wave-uniform serial; <= 256 symbols)
-    int32_t totalWeight = 0;
-    int32_t ranks[HUF_MAX_TABLE_LOG + 1];
-#pragma unroll
-    for (int i = 0; i <= HUF_MAX_TABLE_LOG; i++) ranks[i] = 0;
-    for (int32_t i = 0; i < outputSize; i++) {
-        const int32_t w = sh.hw[i];
-        ZVERIFY(c, w <= HUF_MAX_TABLE_LOG, ACHIP_D_ZSTD_CORRUPTED, input);  // Java: ArrayIndexOutOfBoundsException
-#pragma unroll
-        for (int k = 0; k <= HUF_MAX_TABLE_LOG; k++) ranks[k] += (w == k);
-        totalWeight += (1 << w) >> 1;
-    }
-    ZVERIFY(c, totalWeight != 0, ACHIP_D_ZSTD_CORRUPTED, input);
-    const int32_t tableLog = highest_bit((uint32_t)totalWeight) + 1;
-    ZVERIFY(c, tableLog <= HUF_MAX_TABLE_LOG, ACHIP_D_ZSTD_CORRUPTED, input);
-    const int32_t total = 1 << tableLog;
-    const int32_t rest = total - totalWeight;
-    ZVERIFY(c, (rest & (rest - 1)) == 0, ACHIP_D_ZSTD_CORRUPTED, input);
-    const int32_t lastWeight = highest_bit((uint32_t)rest) + 1;
-    ZVERIFY(c, outputSize <= 255, ACHIP_D_ZSTD_CORRUPTED, input);  // Java: weights[256] out of bounds
-    __syncthreads();
-    if (c.lane == 0) {
-        sh.hw[outputSize] = (uint8_t)lastWeight;
-    }
-#pragma unroll
-    for (int k = 0; k <= HUF_MAX_TABLE_LOG; k++) ranks[k] += (lastWeight == k);
-    const int32_t numberOfSymbols = outputSize + 1;
-
-    int32_t nextRankStart = 0;
-    if (c.lane == 0) {
-        sh.ranks[0] = ranks[0];
-    }
-#pragma unroll
-    for (int i = 1; i <= HUF_MAX_TABLE_LOG; i++) {
-        if (i < tableLog + 1) {
-            const int32_t current = nextRankStart;
-            nextRankStart += ranks[i] << (i - 1);
-            ranks[i] = current;
-        }
-        if (c.lane == 0) {
-            sh.ranks[i] = ranks[i];
-        }
-    }
-    __syncthreads();
-    // populate: symbol n occupies [start(n), start(n)+length) where start = rank start + (symbols of equal weight before n) * length
-    if (c.lane == 0) {
-        for (int32_t n = 0; n < numberOfSymbols; n++) {
-            const int32_t weight = sh.hw[n];
-            const int32_t length = (1 << weight) >> 1;
-            const uint16_t entry = (uint16_t)(n | ((tableLog + 1 - weight) << 8));
-            const int32_t begin = sh.ranks[weight];
-            for (int32_t i = begin; i < begin + length; i++) {
-                sh.huf[i] = entry;
-            }
-            sh.ranks[weight] = begin + length;
-        }
-    }
-    __syncthreads();
-    const int32_t r1 = sh.ranks[1];
-    ZVERIFY(c, r1 >= 2 && (r1 & 1) == 0, ACHIP_D_ZSTD_CORRUPTED, input);
-    *tableLogOut = tableLog;
-    return inputSize + 1;
-}
-
-// Huffman.decodeSymbol :319-324
-__device__ __forceinline__ int32_t huf_symbol(const Shared& sh, int32_t tableLog, uint64_t bits, int32_t& consumed)
-{
-    const uint32_t e = sh.huf[(int32_t)peek_bits_fast(consumed, bits, tableLog)];
-    consumed += (int32_t)(e >> 8);
-    return (int32_t)(e & 0xFF);
-}
-
-// One Huffman stream (decodeSingleStream :130-164 body + decodeTail :291-317) decoded by the calling lane.
-// Returns 0 or ACHIP_D_ZSTD_BITSTREAM_NOT_CONSUMED.
-__device__ __forceinline__ int32_t huf_decode_stream(const Ctx& c, const Shared& sh, int32_t tableLog, Bits& b, uint8_t* out, int32_t output, int32_t outputLimit)
-{
-    const int32_t fastLimit = outputLimit - 4;
-    bool done = false;
-    while (output < fastLimit) {
-        if (bit_load(c, b)) {
-            done = true;
-            break;
-        }
-        uint32_t w = (uint32_t)huf_symbol(sh, tableLog, b.bits, b.consumed);
-        w |= (uint32_t)huf_symbol(sh, tableLog, b.bits, b.consumed) << 8;
-        w |= (uint32_t)huf_symbol(sh, tableLog, b.bits, b.consumed) << 16;
-        w |= (uint32_t)huf_symbol(sh, tableLog, b.bits, b.consumed) << 24;
-        st4(out + output, w);
-        output += 4;
-    }
-    if (!done) {
-        while (output < outputLimit) {
-            if (bit_load(c, b)) {
-                break;
-            }
-            out[output++] = (uint8_t)huf_symbol(sh, tableLog, b.bits, b.consumed);
-        }
-    }
-    while (output < outputLimit) {
-        out[output++] = (uint8_t)huf_symbol(sh, tableLog, b.bits, b.consumed);
-    }
-    return (b.start == b.current && b.consumed == 64) ? 0 : ACHIP_D_ZSTD_BITSTREAM_NOT_CONSUMED;
-}
-
-// wave copy with byte-exact bounds (src, dst do not overlap)
-__device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, int32_t n, int lane) { group_copy<64>(dst, src, n, lane); }
 
 struct FrameState {
     int32_t prevOffsets[3];
@@ -678,7 +175,7 @@ __device__ int32_t decode_literals(Ctx& c, Shared& sh, FrameState& fs, const Fse
     int32_t myDetail = 0;
     if (c.lane < nStreams) {
         if (myOutStart <= myOutEnd) {
-            myDetail = huf_decode_stream(c, sh, tableLog, mine, c.lit, myOutStart, myOutEnd);
+            myDetail = huf_decode_stream(c, sh.huf, tableLog, mine, c.lit, myOutStart, myOutEnd);
         }
         else {
             myDetail = ACHIP_D_ZSTD_CORRUPTED;
@@ -1156,22 +653,24 @@ __global__ __launch_bounds__(64) void zstd_default_tables_kernel(zd::FseTable* d
     }
 }
 
-__global__ __launch_bounds__(64) void zstd_decompress_kernel(BatchArgs a, const zd::FseTable* __restrict__ dflt, uint8_t* litSlabs, int32_t* nextItem)
+__global__ __launch_bounds__(64) void zstd_decompress_kernel(BatchArgs a, const zd::FseTable* __restrict__ dflt, uint8_t* litSlabs, int32_t* nextItem, const int32_t* __restrict__ list,
+                                                              const int32_t* __restrict__ listCount)
 {
     using namespace zd;
     __shared__ Shared sh;
     __shared__ int32_t item;
     const int lane = threadIdx.x;
+    const int32_t nItems = list != nullptr ? *listCount : a.nBlocks;  // list mode: the pipeline's fallback list
     for (;;) {
         __syncthreads();
         if (lane == 0) {
             item = atomicAdd(nextItem, 1);
         }
         __syncthreads();
-        const int32_t block = item;
-        if (block >= a.nBlocks) {
+        if (item >= nItems) {
             return;
         }
+        const int32_t block = list != nullptr ? list[item] : item;
         Ctx c;
         c.in = a.srcBase + a.srcOff[block];
         c.inLen = a.srcLen[block];
@@ -1197,29 +696,51 @@ namespace {
 constexpr int ZD_MAX_WAVES = 256 * 8;  // persistent waves: 8 per CU
 }
 
-int64_t zstd_decompress_scratch_bytes(int32_t nBlocks)
+// scratch of the one-kernel decoder: [item counter | predefined tables | one literal slab per persistent wave]
+int64_t zstd_decompress_general_scratch_bytes() { return 4096 + (int64_t)sizeof(zd::FseTable) * 3 + (int64_t)ZD_MAX_WAVES * zd::LIT_SLAB; }
+
+int64_t zstd_decompress_pipe_scratch_bytes(int32_t nBlocks);
+hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, void* scratch, void* generalScratch);
+void* zstd_decompress_pipe_general_scratch(void* scratch, int32_t nBlocks);
+
+int64_t zstd_decompress_scratch_bytes(int32_t nBlocks) { return zstd_decompress_pipe_scratch_bytes(nBlocks); }
+
+// resets the item counter and builds the predefined FSE tables; returns them through *dflt
+hipError_t launch_zstd_decompress_prepare(hipStream_t stream, void* generalScratch, const zd::FseTable** dflt)
 {
-    (void)nBlocks;
-    return 4096 + (int64_t)sizeof(zd::FseTable) * 3 + (int64_t)ZD_MAX_WAVES * zd::LIT_SLAB;
+    uint8_t* base = (uint8_t*)generalScratch;
+    hipError_t e = hipMemsetAsync(base, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    zd::FseTable* t = (zd::FseTable*)(base + 1024);
+    hipLaunchKernelGGL(zstd_default_tables_kernel, dim3(1), dim3(64), 0, stream, t);
+    *dflt = t;
+    return hipGetLastError();
 }
 
+// the one-kernel decoder over a device-resident list of items (after launch_zstd_decompress_prepare on the same stream)
+hipError_t launch_zstd_decompress_list(const BatchArgs& a, hipStream_t stream, void* generalScratch, const int32_t* list, const int32_t* listCount)
+{
+    uint8_t* base = (uint8_t*)generalScratch;
+    const unsigned grid = (unsigned)(list != nullptr || a.nBlocks >= ZD_MAX_WAVES ? ZD_MAX_WAVES : a.nBlocks);
+    hipLaunchKernelGGL(zstd_decompress_kernel, dim3(grid), dim3(64), 0, stream, a, (const zd::FseTable*)(base + 1024), base + 4096 + sizeof(zd::FseTable) * 3, (int32_t*)base, list, listCount);
+    return hipGetLastError();
+}
+
+// variant 1 (default): five-stage pipeline + one-kernel decoder for whatever it hands back; variant 0: one-kernel decoder only
 hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant)
 {
-    (void)variant;
     (void)scratchBytes;
     if (a.nBlocks <= 0) {
         return hipSuccess;
     }
-    uint8_t* base = (uint8_t*)scratch;
-    int32_t* counter = (int32_t*)base;
-    zd::FseTable* dflt = (zd::FseTable*)(base + 1024);
-    uint8_t* slabs = base + 4096 + sizeof(zd::FseTable) * 3;
-    hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(zstd_default_tables_kernel, dim3(1), dim3(64), 0, stream, dflt);
-    const unsigned grid = (unsigned)(a.nBlocks < ZD_MAX_WAVES ? a.nBlocks : ZD_MAX_WAVES);
-    hipLaunchKernelGGL(zstd_decompress_kernel, dim3(grid), dim3(64), 0, stream, a, (const zd::FseTable*)dflt, slabs, counter);
-    return hipGetLastError();
+    void* general = zstd_decompress_pipe_general_scratch(scratch, a.nBlocks);
+    if (variant == 0) {
+        const zd::FseTable* dflt = nullptr;
+        hipError_t e = launch_zstd_decompress_prepare(stream, general, &dflt);
+        if (e != hipSuccess) return e;
+        return launch_zstd_decompress_list(a, stream, general, nullptr, nullptr);
+    }
+    return launch_zstd_decompress_pipe(a, stream, scratch, general);
 }
 
 }  // namespace achip

@@ -1,0 +1,964 @@
+// zstd_decompress_pipe.hip -- five-stage Zstd decode pipeline for gfx950 (the default for batches).
+//
+// The one-kernel decoder (zstd_decompress.hip) runs one wavefront per item and most of a Zstd block
+// is a serial chain (FSE states, Huffman bit positions), so 63 of 64 lanes idle there.  This file
+// spreads each serial chain over the LANES instead -- one chain per lane, many items per wavefront --
+// and gives every stage the launch shape it wants:
+//
+//   K1 parse      one wavefront per item   frame / block / literals / sequences headers, Huffman and FSE
+//                                          tables built in LDS and written to the item's scratch slot
+//   K2 literals   16 items per wavefront   the 4 Huffman streams of an item on 4 lanes, 16 x 4 KiB tables in LDS
+//   K3 sequences  16 items per wavefront   the three-state FSE stream of an item on one lane, 16 x 5 KiB tables
+//                                          in LDS; (litLen, matchLen, offset) records go to the item's arena range
+//   K4 execute    64 items per workgroup   4 lanes per item through the LDS rings of achip_rings.h
+//                                          (literal stream in, history window out, whole-line HBM stores)
+//   K5 checksum   16 items per wavefront   XXH64: the four accumulators of an item on 4 lanes
+//
+// Scope: items that hold exactly one frame with exactly one compressed block (what ZstdFrameCompressor and
+// libzstd emit for inputs <= 128 KiB -- BASELINE configs[3]) with a Huffman table log <= 11.  Everything else,
+// and every item in which ANY stage sees ANYTHING irregular, is appended to a fallback list and decoded from
+// scratch by the one-kernel decoder afterwards, which reports the Java-exact status / offset.  The stages
+// therefore only have to DETECT every condition the Java decoder rejects (in any order), never to classify it.
+//
+// Reference (same functions as zstd_decompress.hip): M/zstd/ZstdFrameDecompressor.java:135-607,708-962,
+// M/zstd/Huffman.java:52-324, M/zstd/FseTableReader.java:27-168, M/zstd/BitInputStream.java:28-206,
+// M/zstd/XxHash64.java:182-291.
+#include "zstd_dec_common.h"
+#include "zstd_codes.h"
+
+namespace achip {
+
+namespace zp {
+using namespace zd;
+
+constexpr int FAST_HUF_LOG = 11;
+constexpr int HUF_SLOT = 1 << FAST_HUF_LOG;  // u16 entries per item
+constexpr int FSE_LL = 0, FSE_OF = 512, FSE_ML = 768;
+constexpr int FSE_SLOT = 1280;               // u32 entries per item: LL 512, OF 256, ML 512
+constexpr int LIT_STRIDE = MAX_BLOCK_SIZE + 64;
+constexpr int ITEMS_PER_WAVE = 16;
+constexpr int SEQ_ITEMS_PER_WAVE = 15;  // K3: 15 x 5 KiB of FSE tables + the record staging area = half of a CU's LDS
+constexpr int SEQ_STAGE = 32;           // K3: records staged per item between bursts
+
+struct Desc {
+    int32_t state;     // 1 = on the fast path, 0 = handed to the fallback list
+    int32_t litMode;   // 0 raw (in the source), 1 RLE, 2 Huffman
+    int32_t litSize;
+    int32_t litSrc;    // raw: offset in the source; RLE: the byte
+    int32_t hufLog;
+    int32_t nStreams;
+    int32_t sStart[4];
+    int32_t sEnd[4];
+    int32_t nbSeq;
+    int32_t seqStart, seqEnd;  // the sequences bit stream
+    int32_t log[3];
+    uint32_t seqBase;  // first record in the sequence arena
+    int32_t nDecoded;  // K3: records written
+    int32_t hasChecksum;
+    uint32_t checksum;
+    int32_t outSize;   // K4
+    int32_t pad[7];
+};
+static_assert(sizeof(Desc) == 128, "Desc is 128 bytes");
+
+struct Pipe {
+    Desc* desc;
+    uint16_t* huf;
+    uint32_t* fse;
+    uint8_t* lit;
+    uint64_t* seq;
+    uint32_t seqCap;
+    uint32_t* seqCursor;
+    int32_t* fallbackCount;
+    int32_t* fallback;
+    int32_t first;  // first item of this tile
+    int32_t count;  // items in this tile
+};
+
+__device__ __forceinline__ void to_fallback(const Pipe& p, int32_t slot, int stage)
+{
+    p.desc[slot].state = 0;
+    atomicAdd(p.fallbackCount + 32 + stage, 1);  // per-stage diagnostics (achip_ctx_get_stat)
+    const int32_t k = atomicAdd(p.fallbackCount, 1);
+    p.fallback[k] = p.first + slot;
+}
+
+// ---- K1 ----
+// returns true when the item is on the fast path and d is complete (wave-uniform)
+__device__ bool parse_item(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot, const FseTable* dflt, Desc& d)
+{
+    if (c.outCap <= 0) {
+        return false;
+    }
+    const int32_t inputLimit = c.inLen;
+    if (inputLimit < 4 + 1 + 3 + 3) {
+        return false;
+    }
+    int32_t input = 0;
+    if ((uint32_t)rd_le(c, input, 4) != 0xFD2FB528u) {
+        return false;
+    }
+    input += 4;
+    const int32_t headerAddress = input;
+    const int32_t fhd = (int32_t)rd_le(c, input++, 1);
+    const bool singleSegment = (fhd & 0x20) != 0;
+    const int32_t dictDesc = fhd & 3;
+    const int32_t csDesc = fhd >> 6;
+    const int32_t headerSize = 1 + (singleSegment ? 0 : 1) + (dictDesc == 0 ? 0 : (1 << (dictDesc - 1))) + (csDesc == 0 ? (singleSegment ? 1 : 0) : (1 << csDesc));
+    if (dictDesc != 0 || headerSize > inputLimit - headerAddress) {
+        return false;
+    }
+    if (!singleSegment) {
+        const int32_t wd = (int32_t)rd_le(c, input++, 1);
+        const uint32_t base = 1u << ((10 + (wd >> 3)) & 31);
+        const int32_t windowSize = (int32_t)(base + (uint32_t)(((int32_t)base / 8) * (wd & 7)));
+        if (windowSize > MAX_WINDOW_SIZE || windowSize < 0) {
+            return false;
+        }
+    }
+    input = headerAddress + headerSize;
+    d.hasChecksum = (fhd & 4) != 0 ? 1 : 0;
+    if (input + 3 > inputLimit) {
+        return false;
+    }
+    const int32_t header = (int32_t)rd_le(c, input, 3);
+    input += 3;
+    const int32_t blockSize = (header >> 3) & 0x1FFFFF;
+    if ((header & 1) == 0 || ((header >> 1) & 3) != 2 || blockSize > MAX_BLOCK_SIZE || blockSize < 3) {
+        return false;  // more than one block, or a raw / RLE block
+    }
+    if ((int64_t)input + blockSize + (d.hasChecksum ? 4 : 0) != inputLimit) {
+        return false;  // truncated, or another frame follows
+    }
+    const int32_t blockStart = input;
+    const int32_t blockLimit = input + blockSize;
+    d.checksum = d.hasChecksum ? (uint32_t)rd_le(c, blockLimit, 4) : 0u;
+
+    // literals section header (decode*Literals, ZstdFrameDecompressor.java:708-858)
+    const int32_t b0 = (int32_t)rd_le(c, input, 1);
+    const int32_t literalsBlockType = b0 & 3;
+    const int32_t type = (b0 >> 2) & 3;
+    d.hufLog = 0;
+    d.nStreams = 0;
+    if (literalsBlockType == 0 || literalsBlockType == 1) {
+        int32_t size;
+        if (type == 0 || type == 2) {
+            size = b0 >> 3;
+            input += 1;
+        }
+        else if (type == 1) {
+            size = (int32_t)rd_le(c, input, 2) >> 4;
+            input += 2;
+        }
+        else {
+            if (literalsBlockType == 1 && blockSize < 4) {
+                return false;
+            }
+            size = (int32_t)(rd_le(c, input, 3) & 0xFFFFFF) >> 4;
+            input += 3;
+        }
+        if (size > MAX_BLOCK_SIZE) {
+            return false;
+        }
+        d.litSize = size;
+        if (literalsBlockType == 0) {
+            if (input + size > blockLimit) {
+                return false;
+            }
+            d.litMode = 0;
+            d.litSrc = input;
+            input += size;
+        }
+        else {
+            if (input + 1 > blockLimit) {
+                return false;
+            }
+            d.litMode = 1;
+            d.litSrc = (int32_t)rd_le(c, input++, 1);
+        }
+    }
+    else {
+        if (literalsBlockType == 3 || blockSize < 5) {
+            return false;  // a first block cannot reuse a table
+        }
+        int32_t compressedSize, uncompressedSize, headerBytes;
+        bool singleStream = false;
+        if (type == 0 || type == 1) {
+            singleStream = type == 0;
+            const uint32_t h = (uint32_t)rd_le(c, input, 4);
+            headerBytes = 3;
+            uncompressedSize = (int32_t)((h >> 4) & 0x3FF);
+            compressedSize = (int32_t)((h >> 14) & 0x3FF);
+        }
+        else if (type == 2) {
+            const uint32_t h = (uint32_t)rd_le(c, input, 4);
+            headerBytes = 4;
+            uncompressedSize = (int32_t)((h >> 4) & 0x3FFF);
+            compressedSize = (int32_t)((h >> 18) & 0x3FFF);
+        }
+        else {
+            const uint64_t h = rd_le(c, input, 5);
+            headerBytes = 5;
+            uncompressedSize = (int32_t)((h >> 4) & 0x3FFFF);
+            compressedSize = (int32_t)((h >> 22) & 0x3FFFF);
+        }
+        if (uncompressedSize > MAX_BLOCK_SIZE || headerBytes + compressedSize > blockSize) {
+            return false;
+        }
+        input += headerBytes;
+        const int32_t streamsLimit = input + compressedSize;
+        int32_t tl = 0;
+        const int32_t n = huf_read_table(c, sh, input, compressedSize, &tl);
+        if (n < 0 || tl > FAST_HUF_LOG) {
+            return false;
+        }
+        input += n;
+        d.litMode = 2;
+        d.litSize = uncompressedSize;
+        d.litSrc = 0;
+        d.hufLog = tl;
+        if (singleStream) {
+            d.nStreams = 1;
+            d.sStart[0] = input;
+            d.sEnd[0] = streamsLimit;
+            d.sStart[1] = d.sStart[2] = d.sStart[3] = 0;
+            d.sEnd[1] = d.sEnd[2] = d.sEnd[3] = 0;
+        }
+        else {
+            if (streamsLimit - input < 10) {
+                return false;
+            }
+            const int32_t start1 = input + 6;
+            const int32_t start2 = start1 + (int32_t)rd_le(c, input, 2);
+            const int32_t start3 = start2 + (int32_t)rd_le(c, input + 2, 2);
+            const int32_t start4 = start3 + (int32_t)rd_le(c, input + 4, 2);
+            if (!(start2 < start3 && start3 < start4 && start4 < streamsLimit)) {
+                return false;
+            }
+            d.nStreams = 4;
+            d.sStart[0] = start1; d.sEnd[0] = start2;
+            d.sStart[1] = start2; d.sEnd[1] = start3;
+            d.sStart[2] = start3; d.sEnd[2] = start4;
+            d.sStart[3] = start4; d.sEnd[3] = streamsLimit;
+            const int32_t seg = (uncompressedSize + 3) / 4;
+            if (3 * seg > uncompressedSize) {
+                return false;  // the fourth segment would be negative
+            }
+        }
+        // publish the table (1 << tl entries; the rest of the slot is never indexed)
+        uint16_t* g = p.huf + (size_t)slot * HUF_SLOT;
+        for (int32_t i = c.lane * 8; i < (1 << tl); i += 64 * 8) {
+            *(u32x4*)(g + i) = *(const u32x4*)(sh.huf + i);
+        }
+        input = streamsLimit;
+    }
+
+    // sequences section header (decompressSequences :312-376)
+    if (blockLimit - input < 1) {
+        return false;
+    }
+    int32_t sequenceCount = (int32_t)rd_le(c, input++, 1);
+    d.log[0] = d.log[1] = d.log[2] = 0;
+    d.seqBase = 0;
+    if (sequenceCount != 0) {
+        if (sequenceCount == 255) {
+            if (input + 2 > blockLimit) {
+                return false;
+            }
+            sequenceCount = (int32_t)rd_le(c, input, 2) + 0x7F00;
+            input += 2;
+        }
+        else if (sequenceCount > 127) {
+            if (input >= blockLimit) {
+                return false;
+            }
+            sequenceCount = ((sequenceCount - 128) << 8) + (int32_t)rd_le(c, input++, 1);
+        }
+        if (input + 4 > blockLimit) {
+            return false;
+        }
+        const int32_t modes = (int32_t)rd_le(c, input++, 1);
+        const int32_t maxSym[3] = {35, 28, 52};
+        const int32_t maxLog[3] = {9, 8, 9};
+        const int32_t dfltLog[3] = {6, 5, 6};
+        const int32_t base[3] = {FSE_LL, FSE_OF, FSE_ML};
+        uint32_t* g = p.fse + (size_t)slot * FSE_SLOT;
+        for (int k = 0; k < 3; k++) {
+            const int32_t mode = (modes >> (6 - 2 * k)) & 3;
+            if (mode == 3) {
+                return false;  // nothing to repeat in a first block
+            }
+            if (mode == 1) {
+                if (input >= blockLimit) {
+                    return false;
+                }
+                const int32_t value = (int8_t)rd_le(c, input++, 1);
+                if (value > maxSym[k] || value < 0) {
+                    return false;
+                }
+                if (c.lane == 0) {
+                    g[base[k]] = (uint32_t)value << 16;
+                }
+                d.log[k] = 0;
+            }
+            else if (mode == 0) {
+                for (int32_t i = c.lane; i < (1 << dfltLog[k]); i += 64) {
+                    g[base[k] + i] = dflt[k].e[i];
+                }
+                d.log[k] = dfltLog[k];
+            }
+            else {
+                int32_t log = 0;
+                const int32_t n = read_fse_table(c, sh, sh.fse[k], input, blockLimit, maxSym[k], maxLog[k], &log);
+                if (n < 0) {
+                    return false;
+                }
+                input += n;
+                for (int32_t i = c.lane; i < (1 << log); i += 64) {
+                    g[base[k] + i] = sh.fse[k].e[i];
+                }
+                d.log[k] = log;
+            }
+        }
+        uint32_t b = 0;
+        if (c.lane == 0) {
+            b = atomicAdd(p.seqCursor, (uint32_t)sequenceCount);
+        }
+        b = __shfl(b, 0);
+        if ((uint64_t)b + (uint32_t)sequenceCount > p.seqCap) {
+            return false;  // arena full: the one-kernel decoder takes it
+        }
+        d.seqBase = b;
+    }
+    d.nbSeq = sequenceCount;
+    d.nDecoded = 0;
+    d.seqStart = input;
+    d.seqEnd = blockLimit;
+    d.outSize = 0;
+    (void)blockStart;
+    return true;
+}
+
+}  // namespace zp
+
+__global__ __launch_bounds__(64) void zstd_pipe_parse_kernel(BatchArgs a, zp::Pipe p, const zd::FseTable* __restrict__ dflt)
+{
+    using namespace zp;
+    __shared__ TableShared sh;
+    const int32_t slot = blockIdx.x;
+    const int32_t block = p.first + slot;
+    Ctx c;
+    c.in = a.srcBase + a.srcOff[block];
+    c.inLen = a.srcLen[block];
+    c.out = a.dstBase + a.dstOff[block];
+    c.outCap = a.dstCap[block];
+    c.lit = nullptr;
+    c.R = nullptr;
+    c.lane = threadIdx.x;
+    c.detail = 0;
+    c.errOff = 0;
+    Desc d;
+    d.state = 0;
+    d.litMode = 0;
+    d.litSize = 0;
+    d.litSrc = 0;
+    d.hufLog = 0;
+    d.nStreams = 0;
+    for (int i = 0; i < 4; i++) {
+        d.sStart[i] = 0;
+        d.sEnd[i] = 0;
+    }
+    d.nbSeq = 0;
+    d.seqStart = d.seqEnd = 0;
+    d.log[0] = d.log[1] = d.log[2] = 0;
+    d.seqBase = 0;
+    d.nDecoded = 0;
+    d.hasChecksum = 0;
+    d.checksum = 0;
+    d.outSize = 0;
+    for (int i = 0; i < 7; i++) {
+        d.pad[i] = 0;
+    }
+    const bool ok = parse_item(c, sh, p, slot, dflt, d);
+    d.state = ok ? 1 : 0;
+    if (c.lane == 0) {
+        p.desc[slot] = d;
+        if (!ok) {
+            const int32_t k = atomicAdd(p.fallbackCount, 1);
+            p.fallback[k] = block;
+            atomicAdd(p.fallbackCount + 32 + 1, 1);
+        }
+    }
+}
+
+// ---- K2: literals ----
+__global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp::Pipe p)
+{
+    using namespace zp;
+    __shared__ __attribute__((aligned(16))) uint16_t tables[ITEMS_PER_WAVE * HUF_SLOT];  // 64 KiB
+    const int lane = threadIdx.x;
+    const int q = lane >> 2;  // item of this lane
+    const int s = lane & 3;   // stream of this lane
+    const int32_t slot = blockIdx.x * ITEMS_PER_WAVE + q;
+    const bool valid = slot < p.count;
+    Desc d;
+    d.state = 0;
+    if (valid) {
+        d = p.desc[slot];
+    }
+    const bool live = valid && d.state == 1;
+    // stage the 16 tables (each copy is done by the whole wavefront)
+    for (int k = 0; k < ITEMS_PER_WAVE; k++) {
+        const int32_t useHuf = __shfl((live && d.litMode == 2) ? d.hufLog : 0, k * 4);
+        if (useHuf > 0) {
+            const uint16_t* g = p.huf + (size_t)(blockIdx.x * ITEMS_PER_WAVE + k) * HUF_SLOT;
+            for (int32_t i = lane * 8; i < (1 << useHuf); i += 64 * 8) {
+                *(u32x4*)(tables + k * HUF_SLOT + i) = *(const u32x4*)(g + i);
+            }
+        }
+    }
+    __syncthreads();
+    int32_t bad = 0;
+    if (live && d.litMode != 0) {
+        const int32_t block = p.first + slot;
+        uint8_t* lit = p.lit + (size_t)slot * LIT_STRIDE;
+        if (d.litMode == 1) {
+            const uint32_t v = (uint32_t)(d.litSrc & 0xFF) * 0x01010101u;
+            const u32x4 vv = {v, v, v, v};
+            for (int32_t i = s * 16; i < d.litSize; i += 64) {
+                *(u32x4*)(lit + i) = vv;  // the slab has 64 bytes of slack
+            }
+        }
+        else if (s < d.nStreams) {
+            Ctx c;
+            c.in = a.srcBase + a.srcOff[block];
+            c.inLen = a.srcLen[block];
+            c.out = nullptr;
+            c.outCap = 0;
+            c.lit = lit;
+            c.R = nullptr;
+            c.lane = lane;
+            c.detail = 0;
+            c.errOff = 0;
+            const int32_t seg = (d.litSize + 3) / 4;
+            const int32_t oStart = d.nStreams == 1 ? 0 : s * seg;
+            const int32_t oEnd = d.nStreams == 1 ? d.litSize : (s == 3 ? d.litSize : (s + 1) * seg);
+            Bits b;
+            int32_t eo = 0;
+            const int32_t myStart = s == 0 ? d.sStart[0] : (s == 1 ? d.sStart[1] : (s == 2 ? d.sStart[2] : d.sStart[3]));
+            const int32_t myEnd = s == 0 ? d.sEnd[0] : (s == 1 ? d.sEnd[1] : (s == 2 ? d.sEnd[2] : d.sEnd[3]));
+            if (bit_init(c, b, myStart, myEnd, &eo) != 0 || oStart > oEnd) {
+                bad = 1;
+            }
+            else if (huf_decode_stream(c, tables + q * HUF_SLOT, d.hufLog, b, lit, oStart, oEnd) != 0) {
+                bad = 1;
+            }
+        }
+    }
+    // any failing stream sends the whole item to the fallback list
+    const unsigned long long badMask = __ballot(bad != 0);
+    if (live && s == 0 && ((badMask >> (q * 4)) & 0xFull) != 0) {
+        to_fallback(p, slot, 2);
+    }
+}
+
+// ---- K3: sequences ----
+// One item per QUAD of lanes: lane 0 owns the literal-length state, lane 1 the match-length state, lane 2 the offset
+// state, lane 3 assembles and stores the record.  The three table lookups, the code -> (baseline, extra bits)
+// conversions and the six bit-field extractions of a sequence run side by side; the fields' bit positions are a
+// prefix over the quad (DPP quad_perm broadcasts, no LDS traffic).  The bit container and the repeat-offset history
+// are replicated in the four lanes.  All 64 lanes of the wavefront work: 16 items per wavefront.
+template <int K>
+__device__ __forceinline__ int32_t quad_bcast(int32_t v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, false);  // quad_perm:[K,K,K,K]
+}
+
+struct QuadBits {
+    int32_t start, current, consumed, b;
+    uint64_t bits, A, B, P;
+    const uint8_t* in;
+
+    __device__ __forceinline__ uint64_t word_at(int32_t pos) const { return ld8(in + (pos > 0 ? pos : 0)); }  // a clamped address is never consumed
+    // Initializer.initialize :110-130 (end >= 8: a frame header and a block header precede every stream)
+    __device__ __forceinline__ bool init(const uint8_t* src, int32_t s, int32_t end)
+    {
+        in = src;
+        const int32_t size = end - s;
+        if (size < 1 || end < 8) {
+            return false;
+        }
+        const int32_t last = in[end - 1];
+        if (last == 0) {
+            return false;
+        }
+        start = s;
+        consumed = 8 - zd::highest_bit((uint32_t)last);
+        A = ld8(in + end - 8);
+        B = 0;
+        if (size >= 8) {
+            current = end - 8;
+        }
+        else {
+            current = s;  // the whole stream is in the container; load() never moves
+            A >>= 8 * (8 - size);
+            consumed += (8 - size) * 8;
+        }
+        b = current;
+        P = word_at(b - 8);
+        bits = A;
+        return true;
+    }
+    // Loader.load :171-204 without branches.  The three cases of the Java method move `current` down by the whole
+    // bytes consumed but never below `start`, and take 8 bits off `consumed` per byte moved; with consumed > 64 the
+    // Java method only raises its overflow flag, which is what this returns.
+    __device__ __forceinline__ bool load()
+    {
+        const bool over = consumed > 64;
+        int32_t nc = current - (int32_t)((uint32_t)consumed >> 3);
+        nc = nc > start ? nc : start;
+        nc = over ? current : nc;
+        consumed -= 8 * (current - nc);
+        current = nc;
+        // slide the 16-byte window (at most one word per load: current moves by <= 8) and request the next lower word
+        const bool need = current < b;
+        B = need ? A : B;
+        A = need ? P : A;
+        b = need ? b - 8 : b;
+        P = word_at(b - 8);
+        const int32_t sh = 8 * (current - b);  // 0..64
+        const uint64_t mid = (A >> (sh & 63)) | (B << ((64 - sh) & 63));
+        bits = sh == 0 ? A : (sh == 64 ? B : mid);
+        return over;
+    }
+    // BitInputStream.peekBits :64-67 for n <= 31, on 32-bit lanes after the one 64-bit alignment shift
+    __device__ __forceinline__ int32_t peek(int32_t at, int32_t n) const
+    {
+        const uint32_t hi = (uint32_t)((bits << (at & 63)) >> 32);
+        return (int32_t)((hi >> 1) >> ((31 - n) & 31));
+    }
+};
+
+__global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp::Pipe p)
+{
+    using namespace zp;
+    __shared__ __attribute__((aligned(16))) uint32_t tables[SEQ_ITEMS_PER_WAVE * FSE_SLOT];       // 75 KiB
+    __shared__ __attribute__((aligned(16))) uint64_t staged[SEQ_ITEMS_PER_WAVE * SEQ_STAGE];      // 3.75 KiB: records on their way to HBM
+    __shared__ uint32_t codeTab[128];  // literal-length codes at 0.., match-length codes at 64..: baseline | extra bits << 24
+    const int lane = threadIdx.x;
+    const int q = lane >> 2;
+    const int r = lane & 3;
+    {
+        int32_t base = 0, bits = 0;
+        achip_zstd_ll_code(lane < 36 ? lane : 0, &base, &bits);
+        codeTab[lane] = (uint32_t)base | ((uint32_t)bits << 24);
+        achip_zstd_ml_code(lane < 53 ? lane : 0, &base, &bits);
+        codeTab[64 + lane] = (uint32_t)base | ((uint32_t)bits << 24);
+    }
+    const int32_t slot = blockIdx.x * SEQ_ITEMS_PER_WAVE + q;
+    const bool valid = q < SEQ_ITEMS_PER_WAVE && slot < p.count;
+    Desc d;
+    d.state = 0;
+    d.nbSeq = 0;
+    if (valid) {
+        d = p.desc[slot];
+    }
+    const bool live = valid && d.state == 1 && d.nbSeq > 0;
+    for (int k = 0; k < SEQ_ITEMS_PER_WAVE; k++) {
+        if (__shfl(live ? 1 : 0, k * 4) != 0) {
+            const uint32_t* g = p.fse + (size_t)(blockIdx.x * SEQ_ITEMS_PER_WAVE + k) * FSE_SLOT;
+            for (int32_t i = lane * 4; i < FSE_SLOT; i += 64 * 4) {
+                *(u32x4*)(tables + k * FSE_SLOT + i) = *(const u32x4*)(g + i);
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) {
+        return;  // whole quads leave together
+    }
+    const int32_t block = p.first + slot;
+    const uint8_t* src = a.srcBase + a.srcOff[block];
+    // per-lane role: FSE table, state mask, code table
+    const uint32_t* tab = tables + q * FSE_SLOT + (r == 0 ? FSE_LL : (r == 1 ? FSE_ML : FSE_OF));
+    const int32_t stateMask = r >= 2 ? 255 : 511;
+    const bool isOF = r >= 2;
+    const uint32_t* codes = codeTab + (r == 1 ? 64 : 0);
+    const int32_t myLog = r == 0 ? d.log[0] : (r == 1 ? d.log[2] : d.log[1]);
+    uint64_t* rec = p.seq + d.seqBase;
+    uint64_t* stage = staged + q * SEQ_STAGE;
+
+    QuadBits b;
+    bool bad = !b.init(src, d.seqStart, d.seqEnd);
+    int32_t nDecoded = 0;
+    if (!bad) {
+        // initial states in stream order LL, OF, ML (:378-386)
+        const int32_t initOff = r == 0 ? 0 : (r == 1 ? d.log[0] + d.log[1] : d.log[0]);
+        int32_t state = (int32_t)peek_bits(b.consumed + initOff, b.bits, myLog) & stateMask;
+        b.consumed += d.log[0] + d.log[1] + d.log[2];
+        int32_t p0 = 1, p1 = 4, p2 = 8;
+        int32_t sequenceCount = d.nbSeq;
+        // ZstdFrameDecompressor.java:388-486.  The body is straight-line (selects, no early exits): an irregular
+        // stream sets `bad` and keeps decoding harmless garbage (every index is masked) until the count runs out.
+        while (sequenceCount > 0) {
+            sequenceCount--;
+            const bool over = b.load();
+            bad |= over && sequenceCount != 0;  // "Not all sequences were consumed"
+            sequenceCount = over ? 0 : sequenceCount;
+            const uint32_t e = tab[state];
+            const int32_t code = FSE_SYMBOL(e);
+            const int32_t nb = FSE_NBITS(e);
+            // code -> baseline, extra bits
+            const uint32_t t = codes[code & 63];
+            const int32_t x = isOF ? (code & 31) : (int32_t)(t >> 24);
+            const int32_t base = isOF ? (code < 2 ? code : (1 << (code & 31)) - 3) : (int32_t)(t & 0xFFFFFF);
+            const int32_t xLL = quad_bcast<0>(x), xML = quad_bcast<1>(x), xOF = quad_bcast<2>(x);
+            const int32_t cLL = quad_bcast<0>(code), cML = quad_bcast<1>(code), cOF = quad_bcast<2>(code);
+            bad |= cLL > 35 || cML > 52 || cOF > 28;  // only reachable through a table the Java reader would also have rejected or mis-indexed
+            // extra bits are read in the order offset, match length, literal length
+            const int32_t extraOff = r == 0 ? xOF + xML : (r == 1 ? xOF : 0);
+            const int32_t value = base + b.peek(b.consumed + extraOff, x);
+            const int32_t xsum = xLL + xML + xOF;
+            b.consumed += xsum;
+            if (xsum > 64 - 7 - (9 + 9 + 8)) {
+                b.load();
+            }
+            // state updates in the order LL, ML, OF
+            const int32_t nbLL = quad_bcast<0>(nb), nbML = quad_bcast<1>(nb), nbOF = quad_bcast<2>(nb);
+            const int32_t stateOff = r == 0 ? 0 : (r == 1 ? nbLL : nbLL + nbML);
+            state = (FSE_NEWSTATE(e) + b.peek(b.consumed + stateOff, nb)) & stateMask;
+            b.consumed += nbLL + nbML + nbOF;
+            // repeat-offset history (replicated), :419-452
+            const int32_t literalsLength = quad_bcast<0>(value), matchLength = quad_bcast<1>(value);
+            const int32_t raw = quad_bcast<2>(value) + ((cOF <= 1 && cLL == 0) ? 1 : 0);
+            const bool rep = cOF <= 1;
+            int32_t temp = raw == 3 ? p0 - 1 : (raw == 1 ? p1 : p2);
+            temp = temp == 0 ? 1 : temp;
+            const bool shift2 = rep ? (raw != 0 && raw != 1) : true;   // p2 = p1
+            const bool shift1 = rep ? raw != 0 : true;                 // p1 = p0, p0 = new
+            const int32_t offset = rep ? (raw != 0 ? temp : p0) : raw;
+            p2 = shift2 ? p1 : p2;
+            p1 = shift1 ? p0 : p1;
+            p0 = shift1 ? offset : p0;
+            bad |= offset <= 0 || offset > (1 << 24);  // cannot be a valid back-reference of a single <= 128 KiB block; keeps the record fields in range
+            // records are staged in LDS and leave in 256-byte bursts
+            if (r == 3 && !over) {
+                stage[nDecoded & (SEQ_STAGE - 1)] = (uint64_t)(uint32_t)literalsLength | ((uint64_t)(uint32_t)matchLength << 18) | ((uint64_t)(uint32_t)(offset & 0xFFFFFFF) << 36);
+            }
+            nDecoded += over ? 0 : 1;
+            if ((nDecoded & (SEQ_STAGE - 1)) == 0 && !over) {
+                wave_mem_order();
+                const u32x4* sv = (const u32x4*)stage + r * (SEQ_STAGE / 8);
+                uint8_t* dst = (uint8_t*)(rec + nDecoded - SEQ_STAGE) + r * (SEQ_STAGE * 2);
+#pragma unroll
+                for (int t2 = 0; t2 < SEQ_STAGE / 8; t2++) {
+                    st16(dst + 16 * t2, sv[t2]);
+                }
+                wave_mem_order();
+            }
+        }
+        if (!bad) {
+            wave_mem_order();
+            const int32_t rem = nDecoded & (SEQ_STAGE - 1);
+            for (int32_t t2 = r; t2 < rem; t2 += 4) {
+                rec[nDecoded - rem + t2] = stage[t2];
+            }
+        }
+    }
+    if (r == 0) {
+        if (bad) {
+            to_fallback(p, slot, 3);
+        }
+        else {
+            p.desc[slot].nDecoded = nDecoded;
+        }
+    }
+}
+
+// ---- K4: execute ----
+template <int GS, int IN_RING, int OUT_RING>
+__global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp::Pipe p)
+{
+    using namespace zp;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    static_assert(GS == 4, "the 16-byte far-match prefetch is spread as one dword per lane");
+    constexpr int GROUPS_PER_WG = 256 / GS;
+    const int g = threadIdx.x & (GS - 1);
+    const int grp = threadIdx.x / GS;
+    const int32_t slot = blockIdx.x * GROUPS_PER_WG + grp;
+    if (slot >= p.count) {
+        return;
+    }
+    const Desc d = p.desc[slot];
+    if (d.state != 1) {
+        return;
+    }
+    const int32_t block = p.first + slot;
+    const uint8_t* src = a.srcBase + a.srcOff[block];
+    uint8_t* out = a.dstBase + a.dstOff[block];
+    const int32_t outLimit = a.dstCap[block];
+    const uint8_t* lit = d.litMode == 0 ? src + d.litSrc : p.lit + (size_t)slot * LIT_STRIDE;
+    const int32_t litSize = d.litSize;
+    const uint64_t* rec = p.seq + d.seqBase;
+    const int32_t nSeq = d.nDecoded;
+
+    Rings<GS, IN_RING, OUT_RING> R;
+    R.init(smem + grp * (IN_RING + OUT_RING), smem + grp * (IN_RING + OUT_RING) + IN_RING, lit, litSize, out, g);
+
+    int32_t output = 0;
+    int32_t literalsInput = 0;
+    bool bad = false;
+    const int laneBase = (int)(threadIdx.x & 63) - g;
+    // GS records per step, one per lane; the next step's records are requested before this step runs
+    uint64_t next = g < nSeq ? rec[g] : 0ull;
+    for (int32_t i0 = 0; i0 < nSeq && !bad; i0 += GS) {
+        const uint64_t mine = next;
+        next = i0 + GS + g < nSeq ? rec[i0 + GS + g] : 0ull;
+        const int32_t n = nSeq - i0 < GS ? nSeq - i0 : GS;
+        const int32_t myLL = (int32_t)(mine & 0x3FFFF);
+        const int32_t myML = (int32_t)((mine >> 18) & 0x3FFFF);
+        const int32_t myOF = (int32_t)(mine >> 36);
+        // where this lane's sequence lands: exclusive prefix over the step (lanes past n hold zeros)
+        int32_t before = 0;
+#pragma unroll
+        for (int k = 0; k < GS - 1; k++) {
+            const int32_t t = __shfl(myLL + myML, laneBase + k);
+            before += k < g ? t : 0;
+        }
+        const int32_t myMatchPos = output + before + myLL;
+        // A back-reference that copy_match would serve from HBM (farther back than the LDS window) is requested NOW for
+        // all GS sequences at once, when its first 16 source bytes are already flushed: GS loads in flight, not one.
+        const int32_t flushedAbs = R.flushedV - R.outBase;
+        const bool pre = g < n && myOF > Rings<GS, IN_RING, OUT_RING>::LDS_REACH && myOF >= 16 && myMatchPos - myOF >= 0 && myMatchPos - myOF + 16 <= flushedAbs;
+        u32x4 far = {0, 0, 0, 0};
+        if (pre) {
+            far = ld16(out + (myMatchPos - myOF));
+        }
+        for (int k = 0; k < n; k++) {
+            const int32_t ll = __shfl(myLL, laneBase + k);
+            const int32_t ml = __shfl(myML, laneBase + k);
+            const int32_t of = __shfl(myOF, laneBase + k);
+            const int32_t hasFar = __shfl(pre ? 1 : 0, laneBase + k);
+            // ZstdFrameDecompressor.java:491-496
+            if ((int64_t)output + ll + ml > outLimit || literalsInput + ll > litSize || of > output + ll) {
+                bad = true;
+                break;
+            }
+            R.copy_literals(literalsInput, output, ll);
+            output += ll;
+            literalsInput += ll;
+            if (hasFar != 0) {
+                // dword g of the prefetched 16 bytes goes to lane g
+                uint32_t mineW = 0;
+#pragma unroll
+                for (int q = 0; q < GS; q++) {
+                    const uint32_t t = (uint32_t)__shfl((int)(q == 0 ? far.x : (q == 1 ? far.y : (q == 2 ? far.z : far.w))), laneBase + k);
+                    mineW = g == q ? t : mineW;
+                }
+                const int32_t head = ml < 16 ? ml : 16;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (4 * g + t < head) {
+                        R.out_put(output + 4 * g + t, (mineW >> (8 * t)) & 0xFF);
+                    }
+                }
+                R.flush_complete(output + head);
+                if (ml > head) {
+                    R.copy_match(output + head, of, ml - head);
+                }
+            }
+            else {
+                R.copy_match(output, of, ml);
+            }
+            output += ml;
+        }
+    }
+    if (!bad) {
+        const int32_t last = litSize - literalsInput;  // copyLastLiteral :518-525
+        if ((int64_t)output + last > outLimit) {
+            bad = true;
+        }
+        else {
+            R.copy_literals(literalsInput, output, last);
+            output += last;
+            R.flush_all(output);
+        }
+    }
+    if (g == 0) {
+        if (bad) {
+            to_fallback(p, slot, 4);
+        }
+        else if (d.hasChecksum) {
+            p.desc[slot].outSize = output;
+        }
+        else {
+            a.outLen[block] = output;
+            a.status[block] = 0;
+            a.errOffset[block] = 0;
+        }
+    }
+}
+
+// ---- K5: checksum ----
+__global__ __launch_bounds__(64) void zstd_pipe_checksum_kernel(BatchArgs a, zp::Pipe p)
+{
+    using namespace zp;
+    const int lane = threadIdx.x;
+    const int q = lane >> 2;
+    const int s = lane & 3;
+    const int32_t slot = blockIdx.x * ITEMS_PER_WAVE + q;
+    if (slot >= p.count) {
+        return;
+    }
+    const Desc d = p.desc[slot];
+    if (d.state != 1 || !d.hasChecksum) {
+        return;
+    }
+    const int32_t block = p.first + slot;
+    const uint8_t* out = a.dstBase + a.dstOff[block];
+    const int32_t len = d.outSize;
+    constexpr uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+    auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+    auto mix = [&](uint64_t cur, uint64_t v) { return rotl(cur + v * P2, 31) * P1; };
+    uint64_t hash;
+    if (len >= 32) {  // XxHash64.java:182-291, accumulator s of the item on this lane
+        uint64_t v = s == 0 ? P1 + P2 : (s == 1 ? P2 : (s == 2 ? 0 : (0 - P1)));
+        const int32_t stripes = len >> 5;
+        const uint8_t* ptr = out + s * 8;
+        int32_t k = 0;
+        for (; k + 4 <= stripes; k += 4) {
+            const uint64_t x0 = ld8(ptr + (int64_t)k * 32), x1 = ld8(ptr + (int64_t)k * 32 + 32), x2 = ld8(ptr + (int64_t)k * 32 + 64), x3 = ld8(ptr + (int64_t)k * 32 + 96);
+            v = mix(v, x0);
+            v = mix(v, x1);
+            v = mix(v, x2);
+            v = mix(v, x3);
+        }
+        for (; k < stripes; k++) {
+            v = mix(v, ld8(ptr + (int64_t)k * 32));
+        }
+        const int base = lane - s;
+        const uint64_t v1 = __shfl(v, base), v2 = __shfl(v, base + 1), v3 = __shfl(v, base + 2), v4 = __shfl(v, base + 3);
+        hash = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+        hash = (hash ^ mix(0, v1)) * P1 + P4;
+        hash = (hash ^ mix(0, v2)) * P1 + P4;
+        hash = (hash ^ mix(0, v3)) * P1 + P4;
+        hash = (hash ^ mix(0, v4)) * P1 + P4;
+    }
+    else {
+        hash = P5;
+    }
+    hash += (uint64_t)len;
+    int32_t index = len & ~31;
+    while (index <= len - 8) {
+        hash = rotl(hash ^ mix(0, ld8(out + index)), 27) * P1 + P4;
+        index += 8;
+    }
+    if (index <= len - 4) {
+        hash = rotl(hash ^ ((uint64_t)ld4(out + index) * P1), 23) * P2 + P3;
+        index += 4;
+    }
+    while (index < len) {
+        hash = rotl(hash ^ ((uint64_t)out[index] * P5), 11) * P1;
+        index++;
+    }
+    hash ^= hash >> 33;
+    hash *= P2;
+    hash ^= hash >> 29;
+    hash *= P3;
+    hash ^= hash >> 32;
+    if (s == 0) {
+        if ((uint32_t)hash == d.checksum) {
+            a.outLen[block] = len;
+            a.status[block] = 0;
+            a.errOffset[block] = 0;
+        }
+        else {
+            to_fallback(p, slot, 5);
+        }
+    }
+}
+
+// the one-kernel decoder, run over a list of items (zstd_decompress.hip)
+hipError_t launch_zstd_decompress_prepare(hipStream_t stream, void* generalScratch, const zd::FseTable** dflt);
+hipError_t launch_zstd_decompress_list(const BatchArgs& a, hipStream_t stream, void* generalScratch, const int32_t* list, const int32_t* listCount);
+int64_t zstd_decompress_general_scratch_bytes();
+
+namespace {
+constexpr int32_t PIPE_TILE = 32768;              // items per pass through the five stages
+constexpr uint32_t PIPE_SEQ_PER_ITEM = 20480;     // sequence arena: average records per item (text: 10-16 K per 128 KiB block) ...
+constexpr uint32_t PIPE_SEQ_FLOOR = 16 * 43691;   // ... plus room for 16 blocks of the maximum count (128 KiB / 3), so small batches always fit
+struct PipeLayout {
+    int64_t counters, fallback, desc, huf, fse, lit, seq, general, total;
+    int32_t tile;
+};
+PipeLayout pipe_layout(int32_t nBlocks)
+{
+    PipeLayout L;
+    L.tile = nBlocks < PIPE_TILE ? nBlocks : PIPE_TILE;
+    auto up = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
+    int64_t o = 0;
+    L.counters = o;
+    o = up(o + 256);
+    L.fallback = o;
+    o = up(o + (int64_t)nBlocks * 4);
+    L.desc = o;
+    o = up(o + (int64_t)L.tile * sizeof(zp::Desc));
+    L.huf = o;
+    o = up(o + (int64_t)L.tile * zp::HUF_SLOT * 2);
+    L.fse = o;
+    o = up(o + (int64_t)L.tile * zp::FSE_SLOT * 4);
+    L.lit = o;
+    o = up(o + (int64_t)L.tile * zp::LIT_STRIDE);
+    L.seq = o;
+    o = up(o + ((int64_t)L.tile * PIPE_SEQ_PER_ITEM + PIPE_SEQ_FLOOR) * 8);
+    L.general = o;
+    o = up(o + zstd_decompress_general_scratch_bytes());
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+int64_t zstd_decompress_pipe_scratch_bytes(int32_t nBlocks) { return pipe_layout(nBlocks).total; }
+void* zstd_decompress_pipe_general_scratch(void* scratch, int32_t nBlocks) { return (uint8_t*)scratch + pipe_layout(nBlocks).general; }
+
+hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, void* scratch, void* generalScratch)
+{
+    const PipeLayout L = pipe_layout(a.nBlocks);
+    uint8_t* base = (uint8_t*)scratch;
+    const zd::FseTable* dflt = nullptr;
+    {
+        hipError_t e0 = launch_zstd_decompress_prepare(stream, generalScratch, &dflt);
+        if (e0 != hipSuccess) return e0;
+    }
+    zp::Pipe p;
+    p.desc = (zp::Desc*)(base + L.desc);
+    p.huf = (uint16_t*)(base + L.huf);
+    p.fse = (uint32_t*)(base + L.fse);
+    p.lit = base + L.lit;
+    p.seq = (uint64_t*)(base + L.seq);
+    p.seqCap = (uint32_t)L.tile * PIPE_SEQ_PER_ITEM + PIPE_SEQ_FLOOR;
+    p.fallbackCount = (int32_t*)(base + L.counters);
+    p.seqCursor = (uint32_t*)(base + L.counters + 64);
+    p.fallback = (int32_t*)(base + L.fallback);
+    hipError_t e = hipMemsetAsync(base + L.counters, 0, 256, stream);
+    if (e != hipSuccess) return e;
+    for (int32_t first = 0; first < a.nBlocks; first += L.tile) {
+        p.first = first;
+        p.count = a.nBlocks - first < L.tile ? a.nBlocks - first : L.tile;
+        if (first != 0) {
+            e = hipMemsetAsync(p.seqCursor, 0, 4, stream);
+            if (e != hipSuccess) return e;
+        }
+        const unsigned w16 = (unsigned)((p.count + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE);
+        hipLaunchKernelGGL(zstd_pipe_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
+        hipLaunchKernelGGL(zstd_pipe_literals_kernel, dim3(w16), dim3(64), 0, stream, a, p);
+        hipLaunchKernelGGL(zstd_pipe_sequences_kernel, dim3((unsigned)((p.count + zp::SEQ_ITEMS_PER_WAVE - 1) / zp::SEQ_ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
+        constexpr int GS = 4, IN_RING = 128, OUT_RING = 256;
+        hipLaunchKernelGGL((zstd_pipe_execute_kernel<GS, IN_RING, OUT_RING>), dim3((unsigned)((p.count + 256 / GS - 1) / (256 / GS))), dim3(256), (size_t)(256 / GS) * (IN_RING + OUT_RING), stream, a, p);
+        hipLaunchKernelGGL(zstd_pipe_checksum_kernel, dim3(w16), dim3(64), 0, stream, a, p);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_zstd_decompress_list(a, stream, generalScratch, p.fallback, p.fallbackCount);
+}
+
+}  // namespace achip

@@ -34,6 +34,7 @@ SIGNATURES = {
     "achip_ctx_stream": (_vp, [_vp]),
     "achip_ctx_synchronize": (_i32, [_vp]),
     "achip_ctx_set_option": (_i32, [_vp, ctypes.c_char_p, _i64]),
+    "achip_ctx_get_stat": (_i64, [_vp, ctypes.c_char_p]),
     "achip_device_alloc": (_vp, [_vp, _i64]),
     "achip_device_free": (_i32, [_vp, _vp]),
     "achip_host_alloc_pinned": (_vp, [_i64]),
@@ -138,6 +139,9 @@ class HipNative:
         r = self.lib.achip_ctx_set_option(self.ctx, name.encode(), int(value))
         if r < 0:
             raise_for_status(r)
+
+    def get_stat(self, name):
+        return int(self.lib.achip_ctx_get_stat(self.ctx, name.encode()))
 
     def synchronize(self):
         r = self.lib.achip_ctx_synchronize(self.ctx)

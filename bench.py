@@ -49,6 +49,8 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--section", default="all", choices=["all", "zstd"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
+    p.add_argument("--zstd-variant", type=int, default=-1, help="zstd decoder: 1 = five-stage pipeline (default), 0 = one-kernel decoder")
     return p.parse_args()
 
 
@@ -122,6 +124,9 @@ def main():
     if args.ring_class >= 0:
         codec.native.set_option("decompress.ring_class", args.ring_class)
     codec.native.set_option("max_src_len_hint", bs)
+    if args.section == "zstd":
+        print(json.dumps(zstd_extra(torch, A, codec, torch.device("cuda", local_rank), args)), flush=True)
+        return
 
     wl = args.workload
     name = "lz4" if wl.startswith("lz4") else "snappy"
@@ -338,7 +343,9 @@ def zstd_extra(torch, A, codec, dev, args):
     import pyarrow as pa
     out = {}
     fs = 131072
-    pool_n, reps = 512, 16
+    pool_n, reps = 512, 64   # 32768 frames = 4 GiB of plaintext per launch
+    if args.zstd_variant >= 0:
+        codec.native.set_option("zstd.decompress.variant", args.zstd_variant)
     zc = pa.Codec("zstd", compression_level=3)
     for data_kind in ("fragments", "wordmix"):
         plain = gen_fragments(torch, dev, pool_n, fs, args.ratio, 4242) if data_kind == "fragments" else gen_wordmix(torch, dev, pool_n, fs, 4242)
@@ -369,6 +376,7 @@ def zstd_extra(torch, A, codec, dev, args):
         codec.synchronize()
         assert int((st != 0).sum()) == 0, "zstd decode failed"
         assert bool((dst[:n * fs].view(reps, pool_n * fs) == plain.unsqueeze(0)).all()), "zstd plaintext mismatch"
+        fallback = codec.native.get_stat("zstd.decompress.fallback_items")
         e0, e1 = codec.event(), codec.event()
         iters = 3
         codec.record(e0)
@@ -380,14 +388,14 @@ def zstd_extra(torch, A, codec, dev, args):
         entry = {
             "ratio": round(n * fs / cbytes, 3), "decompress_GiBps": round(n * fs / t / 2**30, 2),
             "decompress_hbm_frac": round((n * fs + cbytes) / t / 1e9 / HBM_PEAK_GBS, 4), "frames": n, "frame_bytes": fs,
-            "encoder": "libzstd level 3 via pyarrow %s" % pa.__version__,
+            "encoder": "libzstd level 3 via pyarrow %s" % pa.__version__, "one_kernel_fallback_items": fallback,
         }
         del d_pack, dst
         # GPU level-3 encoder (bit-exact with the Java encoder) over the same plaintext, then GPU decode of its frames
         max_c = lib_max = codec.lib.achip_zstd_max_compressed_length(fs)
         cstride = (max_c + 15) // 16 * 16
-        nz = pool_n * 4
-        zplain = plain.repeat(4)
+        nz = pool_n * 16
+        zplain = plain.repeat(16)
         z_src_off = torch.arange(nz, **i64) * fs
         z_src_len = torch.full((nz,), fs, **i32)
         z_dst = torch.empty(nz * cstride + 64, dtype=torch.uint8, device=dev)
@@ -412,6 +420,13 @@ def zstd_extra(torch, A, codec, dev, args):
         codec.launch(A.OP_ZSTD_DECOMPRESS, z_dst, z_dst_off, z_len, back, z_src_off, z_src_len, b_len, z_st, z_eo, nz)
         codec.synchronize()
         assert int((z_st != 0).sum()) == 0 and bool((back[:nz * fs] == zplain).all()), "zstd GPU encode -> GPU decode round trip failed"
+        codec.record(e0)
+        for _ in range(3):
+            codec.launch(A.OP_ZSTD_DECOMPRESS, z_dst, z_dst_off, z_len, back, z_src_off, z_src_len, b_len, z_st, z_eo, nz)
+        codec.record(e1)
+        tj = codec.elapsed_ms(e0, e1) / 3 * 1e-3
+        entry.update({"java_frames_decompress_GiBps": round(nz * fs / tj / 2**30, 2), "java_frames": nz,
+                      "java_frames_fallback_items": codec.native.get_stat("zstd.decompress.fallback_items")})
         entry.update({"gpu_encoder_ratio": round(nz * fs / zbytes, 3), "compress_GiBps": round(nz * fs / tz / 2**30, 2),
                       "compress_hbm_frac": round((nz * fs + zbytes) / tz / 1e9 / HBM_PEAK_GBS, 5), "compress_frames": nz})
         out["zstd_%s" % data_kind] = entry

@@ -137,6 +137,10 @@ void* achip_ctx_stream(achip_ctx* ctx);           /* the hipStream_t the batched
 int32_t achip_ctx_synchronize(achip_ctx* ctx);    /* hipStreamSynchronize */
 /* tuning knobs (kernel variant selection); name/value pairs documented in DESIGN.md. returns 0 or status */
 int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value);
+/* diagnostics of the LAST batched call on this context (synchronizes the stream); -1 = unknown name / nothing recorded.
+ * "zstd.decompress.fallback_items": items the five-stage pipeline handed to the one-kernel decoder;
+ * "zstd.decompress.fallback_stage1" .. "stage5": the same, by the stage that handed them over. */
+int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name);
 
 /* device / pinned memory helpers; addresses are usable as MemorySegment.ofAddress */
 void* achip_device_alloc(achip_ctx* ctx, int64_t bytes);

@@ -17,6 +17,15 @@ def gb():
     return GpuBatch(0)
 
 
+@pytest.fixture(scope="module", params=[1, 0], ids=["pipeline", "one-kernel"])
+def gbd(request):
+    """decoder under test: the five-stage pipeline (default) and the one-kernel decoder it falls back to"""
+    from tests.gpu_harness import GpuBatch
+    g = GpuBatch(0, options={"zstd.decompress.variant": request.param})
+    g.variant = request.param
+    return g
+
+
 @pytest.fixture(scope="module")
 def o():
     return oracle_lib.load()
@@ -37,10 +46,10 @@ def plain_blocks():
     return blocks
 
 
-def test_golden_fixtures(gb, o):
+def test_golden_fixtures(gbd, o):
     z1, p1 = common.golden_zstd("with-checksum.zst"), common.golden_zstd("with-checksum")
     z2, p2 = common.golden_zstd("multiple-frames.zst"), common.golden_zstd("multiple-frames")
-    outs, status, err = gb.run(OP_ZSTD_DECOMPRESS, [z1, z2, z1, z2], [len(p1), len(p2), len(p1) + 500, len(p2) + 1], unaligned=True)
+    outs, status, err = gbd.run(OP_ZSTD_DECOMPRESS, [z1, z2, z1, z2], [len(p1), len(p2), len(p1) + 500, len(p2) + 1], unaligned=True)
     assert status == [0, 0, 0, 0], (status, err)
     assert outs[0] == p1 and outs[2] == p1 and outs[1] == p2 and outs[3] == p2
 
@@ -52,7 +61,7 @@ def _expect(o, data, cap):
         return e.status, e.offset, None
 
 
-def test_error_fixtures_and_corruptions(gb, o):
+def test_error_fixtures_and_corruptions(gbd, o):
     rng = np.random.default_rng(5)
     z1, p1 = common.golden_zstd("with-checksum.zst"), common.golden_zstd("with-checksum")
     cases = [
@@ -77,7 +86,7 @@ def test_error_fixtures_and_corruptions(gb, o):
             for _ in range(int(rng.integers(1, 3))):
                 m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
             cases.append((bytes(m), len(p)))
-    outs, status, err = gb.run(OP_ZSTD_DECOMPRESS, [c for c, _ in cases], [cap for _, cap in cases])
+    outs, status, err = gbd.run(OP_ZSTD_DECOMPRESS, [c for c, _ in cases], [cap for _, cap in cases])
     for i, (c, cap) in enumerate(cases):
         est, eoff, eout = _expect(o, c, cap)
         assert status[i] == est, "case %d: gpu status %d oracle %d (gpu offset %d, oracle %d)" % (i, status[i], est, err[i], eoff)
@@ -88,11 +97,11 @@ def test_error_fixtures_and_corruptions(gb, o):
 
 
 @pytest.mark.parametrize("level", [1, 3, 9])
-def test_libzstd_frames_decode_to_plaintext(gb, o, level):
+def test_libzstd_frames_decode_to_plaintext(gbd, o, level):
     blocks = plain_blocks()
     frames = zstd_frames(blocks, level)
     for pad in (0, 64):
-        outs, status, err = gb.run(OP_ZSTD_DECOMPRESS, frames, [len(b) + pad for b in blocks], unaligned=(pad == 0))
+        outs, status, err = gbd.run(OP_ZSTD_DECOMPRESS, frames, [len(b) + pad for b in blocks], unaligned=(pad == 0))
         for i, (b, p, s) in enumerate(zip(blocks, outs, status)):
             assert s == 0, (i, len(b), s, err[i])
             assert p == b, "block %d (len %d)" % (i, len(b))
@@ -100,12 +109,12 @@ def test_libzstd_frames_decode_to_plaintext(gb, o, level):
         assert o.decompress("zstd", z, len(b)) == b
 
 
-def test_multi_block_frames_and_concatenated_frames(gb, o):
+def test_multi_block_frames_and_concatenated_frames(gbd, o):
     whole = b"".join(d for _, d, _ in common.corpus_sample())  # ~1.2 MB: ten 128 KiB blocks with cross-block history
     frames = zstd_frames([whole, whole[:300000], whole[100000:100000 + 131073]], 3)
     cat = frames[1] + frames[2] + zstd_frames([b""], 3)[0] + frames[1]
     plain_cat = whole[:300000] + whole[100000:100000 + 131073] + whole[:300000]
-    outs, status, err = gb.run(OP_ZSTD_DECOMPRESS, frames + [cat], [len(whole), 300000, 131073, len(plain_cat)])
+    outs, status, err = gbd.run(OP_ZSTD_DECOMPRESS, frames + [cat], [len(whole), 300000, 131073, len(plain_cat)])
     assert status == [0, 0, 0, 0], (status, err)
     assert outs[0] == whole and outs[1] == whole[:300000] and outs[2] == whole[100000:100000 + 131073] and outs[3] == plain_cat
     assert o.decompress("zstd", cat, len(plain_cat)) == plain_cat
@@ -128,7 +137,7 @@ def test_single_block_host_api(o):
     assert str(e.value).startswith("Invalid magic prefix")
 
 
-def test_many_frames_full_size_property(gb, o):
+def test_many_frames_full_size_property(gbd, o):
     """1024 x 128 KiB frames (libzstd level 3) -> GPU decode must restore every block (checked by hash)."""
     import hashlib
     rng = np.random.default_rng(77)
@@ -138,10 +147,37 @@ def test_many_frames_full_size_property(gb, o):
         off = int(rng.integers(0, len(sample) - 131072))
         blocks.append(sample[off:off + 131072])
     frames = zstd_frames(blocks, 3)
-    outs, status, err = gb.run(OP_ZSTD_DECOMPRESS, frames * 4, [131072] * 1024)
+    outs, status, err = gbd.run(OP_ZSTD_DECOMPRESS, frames * 4, [131072] * 1024)
     assert all(s == 0 for s in status)
     want = [hashlib.sha256(b).digest() for b in blocks] * 4
     assert [hashlib.sha256(p).digest() for p in outs] == want
+    if gbd.variant == 1:
+        # single-block frames must stay on the pipeline: none handed to the one-kernel decoder
+        stages = [gbd.codec.native.get_stat("zstd.decompress.fallback_stage%d" % k) for k in range(1, 6)]
+        assert gbd.codec.native.get_stat("zstd.decompress.fallback_items") == 0, stages
+
+
+def test_pipeline_takes_java_encoded_frames(gbd, o):
+    """Frames as ZstdFrameCompressor writes them (single segment, one block, checksum) stay on the fast path;
+    corrupting one sends exactly that item to the one-kernel decoder, which reports the Java-exact error."""
+    blocks = plain_blocks()
+    blocks = [b for b in blocks if 0 < len(b) <= 131072]
+    frames = [o.compress("zstd", b) for b in blocks]
+    outs, status, err = gbd.run(OP_ZSTD_DECOMPRESS, frames, [len(b) for b in blocks])
+    assert all(s == 0 for s in status), status
+    assert outs == blocks
+    if gbd.variant == 1:
+        raw = sum(1 for f in frames if ((f[4 + 2 + (0 if f[4] >> 6 == 0 else (1 << (f[4] >> 6)) - 1)] >> 1) & 3) != 2)
+        assert gbd.codec.native.get_stat("zstd.decompress.fallback_items") <= raw + sum(1 for b in blocks if len(b) < 16)
+    big = max(range(len(blocks)), key=lambda i: len(blocks[i]))
+    bad = bytearray(frames[big])
+    bad[len(bad) // 2] ^= 0x10
+    outs, status, err = gbd.run(OP_ZSTD_DECOMPRESS, [frames[big], bytes(bad), frames[big]], [len(blocks[big])] * 3)
+    est, eoff, eout = _expect(o, bytes(bad), len(blocks[big]))
+    assert status[0] == 0 and status[2] == 0 and outs[0] == blocks[big] and outs[2] == blocks[big]
+    assert status[1] == est and (est == 0 or err[1] == eoff)
+    if gbd.variant == 1:
+        assert gbd.codec.native.get_stat("zstd.decompress.fallback_items") <= 1
 
 
 # ---- encoder (level 3), rows a11-a14 -------------------------------------------------------------------------

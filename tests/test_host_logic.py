@@ -1,0 +1,43 @@
+"""Host-checkable pieces of the device code: headers that are plain C are compiled with gcc and compared with the
+oracle's restatement of the Java tables (no GPU involved)."""
+import os
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHECK = r"""
+#include <stdio.h>
+#include "oracle/zstd_dec.c"                     /* static tables restated from ZstdFrameDecompressor.java:68-83 */
+#include "aircompressor_amd/csrc/zstd_codes.h"
+int main(void)
+{
+    int bad = 0;
+    for (int c = 0; c < 36; c++) {
+        int32_t b, n;
+        achip_zstd_ll_code(c, &b, &n);
+        bad += b != LITERALS_LENGTH_BASE[c] || n != LITERALS_LENGTH_BITS[c];
+    }
+    for (int c = 0; c < 53; c++) {
+        int32_t b, n;
+        achip_zstd_ml_code(c, &b, &n);
+        bad += b != MATCH_LENGTH_BASE[c] || n != MATCH_LENGTH_BITS[c];
+    }
+    for (int c = 0; c < 29; c++) {
+        bad += achip_zstd_of_base(c) != OFFSET_CODES_BASE[c];
+    }
+    printf("%d\n", bad);
+    return bad != 0;
+}
+"""
+
+
+def test_zstd_code_arithmetic_equals_the_java_tables():
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "check.c")
+        exe = os.path.join(tmp, "check")
+        with open(src, "w") as f:
+            f.write(CHECK)
+        subprocess.run(["gcc", "-O1", "-std=gnu11", "-I", ROOT, "-I", os.path.join(ROOT, "oracle"), "-o", exe, src, os.path.join(ROOT, "oracle", "xxhash64.c")], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+        assert out.strip() == "0"
