@@ -57,7 +57,8 @@ struct Desc {
     int32_t hasChecksum;
     uint32_t checksum;
     int32_t outSize;   // K4
-    int32_t pad[7];
+    uint32_t litBase;  // regenerated literals (RLE / Huffman): first 64-byte unit in the literal arena
+    int32_t pad[6];
 };
 static_assert(sizeof(Desc) == 128, "Desc is 128 bytes");
 
@@ -69,6 +70,8 @@ struct Pipe {
     uint64_t* seq;
     uint32_t seqCap;
     uint32_t* seqCursor;
+    uint32_t litCap;      // literal arena, in 64-byte units
+    uint32_t* litCursor;
     int32_t* fallbackCount;
     int32_t* fallback;
     int32_t first;  // first item of this tile
@@ -253,6 +256,21 @@ __device__ bool parse_item(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot,
         input = streamsLimit;
     }
 
+    d.litBase = 0;
+    if (d.litMode != 0) {
+        // room for the regenerated literals (+ 64 bytes of slack for whole-vector stores)
+        const uint32_t units = (uint32_t)(d.litSize + 64 + 63) >> 6;
+        uint32_t lb = 0;
+        if (c.lane == 0) {
+            lb = atomicAdd(p.litCursor, units);
+        }
+        lb = __shfl(lb, 0);
+        if ((uint64_t)lb + units > p.litCap) {
+            return false;  // arena full: the one-kernel decoder takes it
+        }
+        d.litBase = lb;
+    }
+
     // sequences section header (decompressSequences :312-376)
     if (blockLimit - input < 1) {
         return false;
@@ -376,7 +394,8 @@ __global__ __launch_bounds__(64) void zstd_pipe_parse_kernel(BatchArgs a, zp::Pi
     d.hasChecksum = 0;
     d.checksum = 0;
     d.outSize = 0;
-    for (int i = 0; i < 7; i++) {
+    d.litBase = 0;
+    for (int i = 0; i < 6; i++) {
         d.pad[i] = 0;
     }
     const bool ok = parse_item(c, sh, p, slot, dflt, d);
@@ -421,7 +440,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp:
     int32_t bad = 0;
     if (live && d.litMode != 0) {
         const int32_t block = p.first + slot;
-        uint8_t* lit = p.lit + (size_t)slot * LIT_STRIDE;
+        uint8_t* lit = p.lit + (size_t)d.litBase * 64;
         if (d.litMode == 1) {
             const uint32_t v = (uint32_t)(d.litSrc & 0xFF) * 0x01010101u;
             const u32x4 vv = {v, v, v, v};
@@ -696,7 +715,7 @@ __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp:
     const uint8_t* src = a.srcBase + a.srcOff[block];
     uint8_t* out = a.dstBase + a.dstOff[block];
     const int32_t outLimit = a.dstCap[block];
-    const uint8_t* lit = d.litMode == 0 ? src + d.litSrc : p.lit + (size_t)slot * LIT_STRIDE;
+    const uint8_t* lit = d.litMode == 0 ? src + d.litSrc : p.lit + (size_t)d.litBase * 64;
     const int32_t litSize = d.litSize;
     const uint64_t* rec = p.seq + d.seqBase;
     const int32_t nSeq = d.nDecoded;
@@ -883,7 +902,9 @@ hipError_t launch_zstd_decompress_list(const BatchArgs& a, hipStream_t stream, v
 int64_t zstd_decompress_general_scratch_bytes();
 
 namespace {
-constexpr int32_t PIPE_TILE = 32768;              // items per pass through the five stages
+constexpr int32_t PIPE_TILE = 65536;              // items per pass through the five stages (K4 wants >= 64 Ki items in flight: 16 per wavefront)
+constexpr uint32_t PIPE_LIT_PER_ITEM = 80 * 1024 / 64;   // literal arena: average 64-byte units per item ...
+constexpr uint32_t PIPE_LIT_FLOOR = 16 * (zp::LIT_STRIDE / 64 + 1);  // ... plus 16 blocks of the maximum size
 constexpr uint32_t PIPE_SEQ_PER_ITEM = 20480;     // sequence arena: average records per item (text: 10-16 K per 128 KiB block) ...
 constexpr uint32_t PIPE_SEQ_FLOOR = 16 * 43691;   // ... plus room for 16 blocks of the maximum count (128 KiB / 3), so small batches always fit
 struct PipeLayout {
@@ -907,7 +928,7 @@ PipeLayout pipe_layout(int32_t nBlocks)
     L.fse = o;
     o = up(o + (int64_t)L.tile * zp::FSE_SLOT * 4);
     L.lit = o;
-    o = up(o + (int64_t)L.tile * zp::LIT_STRIDE);
+    o = up(o + ((int64_t)L.tile * PIPE_LIT_PER_ITEM + PIPE_LIT_FLOOR) * 64);
     L.seq = o;
     o = up(o + ((int64_t)L.tile * PIPE_SEQ_PER_ITEM + PIPE_SEQ_FLOOR) * 8);
     L.general = o;
@@ -938,6 +959,8 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
     p.seqCap = (uint32_t)L.tile * PIPE_SEQ_PER_ITEM + PIPE_SEQ_FLOOR;
     p.fallbackCount = (int32_t*)(base + L.counters);
     p.seqCursor = (uint32_t*)(base + L.counters + 64);
+    p.litCursor = (uint32_t*)(base + L.counters + 68);
+    p.litCap = (uint32_t)L.tile * PIPE_LIT_PER_ITEM + PIPE_LIT_FLOOR;
     p.fallback = (int32_t*)(base + L.fallback);
     hipError_t e = hipMemsetAsync(base + L.counters, 0, 256, stream);
     if (e != hipSuccess) return e;
@@ -945,7 +968,7 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
         p.first = first;
         p.count = a.nBlocks - first < L.tile ? a.nBlocks - first : L.tile;
         if (first != 0) {
-            e = hipMemsetAsync(p.seqCursor, 0, 4, stream);
+            e = hipMemsetAsync(p.seqCursor, 0, 8, stream);  // sequence and literal cursors
             if (e != hipSuccess) return e;
         }
         const unsigned w16 = (unsigned)((p.count + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE);

@@ -343,7 +343,7 @@ def zstd_extra(torch, A, codec, dev, args):
     import pyarrow as pa
     out = {}
     fs = 131072
-    pool_n, reps = 512, 64   # 32768 frames = 4 GiB of plaintext per launch
+    pool_n, reps = 512, 128   # 65536 frames = 8 GiB of plaintext per launch
     if args.zstd_variant >= 0:
         codec.native.set_option("zstd.decompress.variant", args.zstd_variant)
     zc = pa.Codec("zstd", compression_level=3)
