@@ -34,10 +34,11 @@ using namespace zd;
 constexpr int FAST_HUF_LOG = 11;
 constexpr int HUF_SLOT = 1 << FAST_HUF_LOG;  // u16 entries per item
 constexpr int FSE_LL = 0, FSE_OF = 512, FSE_ML = 768;
-constexpr int FSE_SLOT = 1280;               // u32 entries per item: LL 512, OF 256, ML 512
+constexpr int FSE_CNT = 1280;                // then three 64-entry regions of per-symbol counts (LL, OF, ML)
+constexpr int FSE_SLOT = 1280 + 192;         // u16 entries per item: LL 512, OF 256, ML 512 states (symbol | rank << 6), 3 x 64 counts
 constexpr int LIT_STRIDE = MAX_BLOCK_SIZE + 64;
 constexpr int ITEMS_PER_WAVE = 16;
-constexpr int SEQ_ITEMS_PER_WAVE = 15;  // K3: 15 x 5 KiB of FSE tables + the record staging area = half of a CU's LDS
+constexpr int SEQ_ITEMS_PER_WAVE = 16;  // K3: 16 x (2.9 KiB of FSE tables + 256 B of staged records): three wavefronts per CU
 constexpr int SEQ_STAGE = 32;           // K3: records staged per item between bursts
 
 struct Desc {
@@ -65,7 +66,7 @@ static_assert(sizeof(Desc) == 128, "Desc is 128 bytes");
 struct Pipe {
     Desc* desc;
     uint16_t* huf;
-    uint32_t* fse;
+    uint16_t* fse;
     uint8_t* lit;
     uint64_t* seq;
     uint32_t seqCap;
@@ -300,9 +301,17 @@ __device__ bool parse_item(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot,
         const int32_t maxLog[3] = {9, 8, 9};
         const int32_t dfltLog[3] = {6, 5, 6};
         const int32_t base[3] = {FSE_LL, FSE_OF, FSE_ML};
-        uint32_t* g = p.fse + (size_t)slot * FSE_SLOT;
+        // Published form of a decoding table (half the LDS of the {newState, symbol, bits} form, so K3 keeps 48 items per
+        // CU): per state  symbol | rank << 6  where rank = nextState - count[symbol]  (FseTableReader.java:143-158 walks
+        // the states of a symbol in order, handing out nextState = count, count + 1, ...), and per symbol its count.
+        // K3 recovers  bits = log - highBit(nextState),  newState = (nextState << bits) - (1 << log).
+        uint16_t* g = p.fse + (size_t)slot * FSE_SLOT;
+#pragma unroll
         for (int k = 0; k < 3; k++) {
             const int32_t mode = (modes >> (6 - 2 * k)) & 3;
+            uint16_t* cnt = g + FSE_CNT + 64 * k;
+            const int16_t* dnorm = k == 0 ? LL_DEFAULT_NORM : (k == 1 ? OF_DEFAULT_NORM : ML_DEFAULT_NORM);
+            int32_t tableLog = 0;
             if (mode == 3) {
                 return false;  // nothing to repeat in a first block
             }
@@ -315,15 +324,24 @@ __device__ bool parse_item(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot,
                     return false;
                 }
                 if (c.lane == 0) {
-                    g[base[k]] = (uint32_t)value << 16;
+                    g[base[k]] = (uint16_t)value;  // one state: nextState 1 = count 1 + rank 0
+                    cnt[value] = 1;
                 }
-                d.log[k] = 0;
             }
             else if (mode == 0) {
-                for (int32_t i = c.lane; i < (1 << dfltLog[k]); i += 64) {
-                    g[base[k] + i] = dflt[k].e[i];
+                const int32_t log = dfltLog[k];
+                for (int32_t i = c.lane; i < (1 << log); i += 64) {
+                    const uint32_t e = dflt[k].e[i];
+                    const int32_t sym = FSE_SYMBOL(e);
+                    const int32_t n = dnorm[sym];
+                    const int32_t next = (FSE_NEWSTATE(e) + (1 << log)) >> FSE_NBITS(e);
+                    g[base[k] + i] = (uint16_t)(sym | ((next - (n == -1 ? 1 : n)) << 6));
                 }
-                d.log[k] = dfltLog[k];
+                for (int32_t i = c.lane; i <= maxSym[k]; i += 64) {
+                    const int32_t n = dnorm[i];
+                    cnt[i] = (uint16_t)(n == -1 ? 1 : n);
+                }
+                tableLog = log;
             }
             else {
                 int32_t log = 0;
@@ -333,9 +351,27 @@ __device__ bool parse_item(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot,
                 }
                 input += n;
                 for (int32_t i = c.lane; i < (1 << log); i += 64) {
-                    g[base[k] + i] = sh.fse[k].e[i];
+                    const uint32_t e = sh.fse[k].e[i];
+                    const int32_t sym = FSE_SYMBOL(e);
+                    const int32_t cn = sh.norm[sym];
+                    const int32_t next = (FSE_NEWSTATE(e) + (1 << log)) >> FSE_NBITS(e);
+                    g[base[k] + i] = (uint16_t)(sym | ((next - (cn == -1 ? 1 : cn)) << 6));
                 }
-                d.log[k] = log;
+                for (int32_t i = c.lane; i <= maxSym[k]; i += 64) {
+                    const int32_t cn = sh.norm[i];
+                    cnt[i] = (uint16_t)(cn == -1 ? 1 : (cn < 0 ? 0 : cn));
+                }
+                __syncthreads();  // sh.norm is rewritten by the next table
+                tableLog = log;
+            }
+            if (k == 0) {
+                d.log[0] = tableLog;
+            }
+            else if (k == 1) {
+                d.log[1] = tableLog;
+            }
+            else {
+                d.log[2] = tableLog;
             }
         }
         uint32_t b = 0;
@@ -561,7 +597,7 @@ struct QuadBits {
 __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp::Pipe p)
 {
     using namespace zp;
-    __shared__ __attribute__((aligned(16))) uint32_t tables[SEQ_ITEMS_PER_WAVE * FSE_SLOT];       // 75 KiB
+    __shared__ __attribute__((aligned(16))) uint16_t tables[SEQ_ITEMS_PER_WAVE * FSE_SLOT];       // 46 KiB: three wavefronts per CU
     __shared__ __attribute__((aligned(16))) uint64_t staged[SEQ_ITEMS_PER_WAVE * SEQ_STAGE];      // 3.75 KiB: records on their way to HBM
     __shared__ uint32_t codeTab[128];  // literal-length codes at 0.., match-length codes at 64..: baseline | extra bits << 24
     const int lane = threadIdx.x;
@@ -585,8 +621,8 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
     const bool live = valid && d.state == 1 && d.nbSeq > 0;
     for (int k = 0; k < SEQ_ITEMS_PER_WAVE; k++) {
         if (__shfl(live ? 1 : 0, k * 4) != 0) {
-            const uint32_t* g = p.fse + (size_t)(blockIdx.x * SEQ_ITEMS_PER_WAVE + k) * FSE_SLOT;
-            for (int32_t i = lane * 4; i < FSE_SLOT; i += 64 * 4) {
+            const uint16_t* g = p.fse + (size_t)(blockIdx.x * SEQ_ITEMS_PER_WAVE + k) * FSE_SLOT;
+            for (int32_t i = lane * 8; i < FSE_SLOT; i += 64 * 8) {
                 *(u32x4*)(tables + k * FSE_SLOT + i) = *(const u32x4*)(g + i);
             }
         }
@@ -598,7 +634,8 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
     const int32_t block = p.first + slot;
     const uint8_t* src = a.srcBase + a.srcOff[block];
     // per-lane role: FSE table, state mask, code table
-    const uint32_t* tab = tables + q * FSE_SLOT + (r == 0 ? FSE_LL : (r == 1 ? FSE_ML : FSE_OF));
+    const uint16_t* tab = tables + q * FSE_SLOT + (r == 0 ? FSE_LL : (r == 1 ? FSE_ML : FSE_OF));
+    const uint16_t* cnt = tables + q * FSE_SLOT + FSE_CNT + (r == 0 ? 0 : (r == 1 ? 128 : 64));
     const int32_t stateMask = r >= 2 ? 255 : 511;
     const bool isOF = r >= 2;
     const uint32_t* codes = codeTab + (r == 1 ? 64 : 0);
@@ -624,10 +661,12 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
             bad |= over && sequenceCount != 0;  // "Not all sequences were consumed"
             sequenceCount = over ? 0 : sequenceCount;
             const uint32_t e = tab[state];
-            const int32_t code = FSE_SYMBOL(e);
-            const int32_t nb = FSE_NBITS(e);
-            // code -> baseline, extra bits
-            const uint32_t t = codes[code & 63];
+            const int32_t code = (int32_t)(e & 63);
+            // code -> baseline, extra bits; state transition (see K1 for the table form)
+            const uint32_t t = codes[code];
+            const int32_t next = (int32_t)cnt[code] + (int32_t)(e >> 6);
+            const int32_t nb = (myLog - (31 - __builtin_clz((uint32_t)next | 1u))) & 15;
+            const int32_t newState = (next << nb) - (1 << myLog);
             const int32_t x = isOF ? (code & 31) : (int32_t)(t >> 24);
             const int32_t base = isOF ? (code < 2 ? code : (1 << (code & 31)) - 3) : (int32_t)(t & 0xFFFFFF);
             const int32_t xLL = quad_bcast<0>(x), xML = quad_bcast<1>(x), xOF = quad_bcast<2>(x);
@@ -644,7 +683,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
             // state updates in the order LL, ML, OF
             const int32_t nbLL = quad_bcast<0>(nb), nbML = quad_bcast<1>(nb), nbOF = quad_bcast<2>(nb);
             const int32_t stateOff = r == 0 ? 0 : (r == 1 ? nbLL : nbLL + nbML);
-            state = (FSE_NEWSTATE(e) + b.peek(b.consumed + stateOff, nb)) & stateMask;
+            state = (newState + b.peek(b.consumed + stateOff, nb)) & stateMask;
             b.consumed += nbLL + nbML + nbOF;
             // repeat-offset history (replicated), :419-452
             const int32_t literalsLength = quad_bcast<0>(value), matchLength = quad_bcast<1>(value);
@@ -926,7 +965,7 @@ PipeLayout pipe_layout(int32_t nBlocks)
     L.huf = o;
     o = up(o + (int64_t)L.tile * zp::HUF_SLOT * 2);
     L.fse = o;
-    o = up(o + (int64_t)L.tile * zp::FSE_SLOT * 4);
+    o = up(o + (int64_t)L.tile * zp::FSE_SLOT * 2);
     L.lit = o;
     o = up(o + ((int64_t)L.tile * PIPE_LIT_PER_ITEM + PIPE_LIT_FLOOR) * 64);
     L.seq = o;
@@ -953,7 +992,7 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
     zp::Pipe p;
     p.desc = (zp::Desc*)(base + L.desc);
     p.huf = (uint16_t*)(base + L.huf);
-    p.fse = (uint32_t*)(base + L.fse);
+    p.fse = (uint16_t*)(base + L.fse);
     p.lit = base + L.lit;
     p.seq = (uint64_t*)(base + L.seq);
     p.seqCap = (uint32_t)L.tile * PIPE_SEQ_PER_ITEM + PIPE_SEQ_FLOOR;
