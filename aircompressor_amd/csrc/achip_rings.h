@@ -162,6 +162,22 @@ struct Rings {
         }
     }
 
+    // Short copies (n <= 4*GS, source entirely before the destination): lane g moves bytes [4g, 4g+4) -- one unaligned
+    // 4-byte read, up to four byte stores, no alignment cases.  Text-like data is almost all such copies.
+    __device__ __forceinline__ void put4(int32_t dV, uint32_t w, int32_t cnt)
+    {
+        if (cnt > 0) outRing[dV & (OUT_RING - 1)] = (uint8_t)w;
+        if (cnt > 1) outRing[(dV + 1) & (OUT_RING - 1)] = (uint8_t)(w >> 8);
+        if (cnt > 2) outRing[(dV + 2) & (OUT_RING - 1)] = (uint8_t)(w >> 16);
+        if (cnt > 3) outRing[(dV + 3) & (OUT_RING - 1)] = (uint8_t)(w >> 24);
+    }
+    template <int SRC_RING>
+    __device__ __forceinline__ void copy_small(const uint8_t* src, int32_t sV, int32_t dV, int32_t n)
+    {
+        const uint32_t w = ring_ld4<SRC_RING>(src, sV + 4 * g);
+        put4(dV + 4 * g, w, n - 4 * g);
+    }
+
     // ---- output side ----
     __device__ __forceinline__ void out_put(int32_t pos, uint32_t byte) { outRing[(pos + outBase) & (OUT_RING - 1)] = (uint8_t)byte; }
     __device__ __forceinline__ uint32_t out_get(int32_t pos) const { return outRing[(pos + outBase) & (OUT_RING - 1)]; }
@@ -230,6 +246,12 @@ struct Rings {
     // literals: n input bytes at ip -> output at op (n arbitrary; input ring refilled, output flushed as we go)
     __device__ __forceinline__ void copy_literals(int32_t ip, int32_t op, int32_t n)
     {
+        if (n <= 4 * GS) {
+            ensure_input(ip, n);
+            copy_small<IN_RING>(inRing, ip + inBase, op + outBase, n);
+            flush_complete(op + n);
+            return;
+        }
         while (n > 0) {
             const int32_t c = n < CHUNK ? n : CHUNK;
             ensure_input(ip, c);
@@ -254,6 +276,17 @@ struct Rings {
     // offsets the period is folded so all sources lie BEFORE the chunk (no intra-chunk dependency).
     __device__ __forceinline__ void copy_match(int32_t op, int32_t offset, int32_t n)
     {
+        if (n <= 4 * GS && offset >= n) {
+            wave_mem_order();
+            if (offset <= LDS_REACH) {
+                copy_small<OUT_RING>(outRing, op + outBase - offset, op + outBase, n);
+            }
+            else {
+                put4(op + outBase + 4 * g, ld4(outAligned + outBase + (op - offset) + 4 * g), n - 4 * g);  // flushed long ago (see below)
+            }
+            flush_complete(op + n);
+            return;
+        }
         int32_t c0 = op;
         while (n > 0) {
             const int32_t c = n < CHUNK ? n : CHUNK;
