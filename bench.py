@@ -42,7 +42,7 @@ def parse_args():
     p.add_argument("--pool", type=int, default=4096, help="distinct blocks generated; the batch tiles them at distinct addresses")
     p.add_argument("--ratio", type=float, default=0.5, help="RandomGenerator compressibility (0.5 => LZ4 ratio ~1.9)")
     p.add_argument("--workload", default="lz4_decompress", choices=["lz4_decompress", "snappy_decompress", "lz4_compress", "snappy_compress"])
-    p.add_argument("--data", default="fragments", choices=["fragments", "wordmix"])
+    p.add_argument("--data", default="fragments", choices=["fragments", "wordmix", "corpus"])
     p.add_argument("--group", type=int, default=0, help="decoder lanes per block (0 = library default)")
     p.add_argument("--variant", type=int, default=-1, help="decoder variant: 1 = LDS rings (default), 0 = direct-to-HBM groups")
     p.add_argument("--ring-class", type=int, default=-1, help="0 = compact LDS rings, 1 = large")
@@ -65,6 +65,24 @@ def gen_fragments(torch, dev, n_blocks, block_size, ratio, seed):
     reps = (100 + raw - 1) // raw
     data = frags.repeat(1, reps)[:, :100].reshape(-1)[:total].contiguous()
     return data
+
+
+def gen_corpus(torch, dev, n_blocks, block_size):
+    """Real data: the 19 x 64 KiB slices of the reference's calgary / canterbury / top-level test files committed under
+    tests/golden/ (corpus_sample.json lists them), tiled cyclically; every copy sits at its own address (SURVEY 8d, C2 primary)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "corpus_sample.bin")
+    sample = torch.from_numpy(np.fromfile(path, dtype=np.uint8)).to(dev)
+    unit = (sample.numel() // block_size) * block_size
+    total = n_blocks * block_size
+    return sample[:unit].repeat((total + unit - 1) // unit)[:total].contiguous()
+
+
+def gen_data(torch, dev, kind, n_blocks, block_size, ratio, seed):
+    if kind == "fragments":
+        return gen_fragments(torch, dev, n_blocks, block_size, ratio, seed)
+    if kind == "wordmix":
+        return gen_wordmix(torch, dev, n_blocks, block_size, seed)
+    return gen_corpus(torch, dev, n_blocks, block_size)
 
 
 def gen_wordmix(torch, dev, n_blocks, block_size, seed):
@@ -140,10 +158,7 @@ def main():
         pool_n -= 1
     reps = n_local // pool_n
     seed = 301 + 7919 * (lo // max(pool_n, 1))
-    if args.data == "fragments":
-        pool_plain = gen_fragments(torch, dev, pool_n, bs, args.ratio, seed)
-    else:
-        pool_plain = gen_wordmix(torch, dev, pool_n, bs, seed)
+    pool_plain = gen_data(torch, dev, args.data, pool_n, bs, args.ratio, seed)
     cstride = (max_c + 15) // 16 * 16
     i64 = dict(dtype=torch.int64, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
@@ -292,8 +307,8 @@ def extras(torch, A, codec, dev, args):
     lib = codec.lib
     bs = args.block_size
     n = 65536
-    for data_kind in ("fragments", "wordmix"):
-        plain = gen_fragments(torch, dev, n, bs, args.ratio, 977) if data_kind == "fragments" else gen_wordmix(torch, dev, n, bs, 977)
+    for data_kind in ("fragments", "wordmix", "corpus"):
+        plain = gen_data(torch, dev, data_kind, n, bs, args.ratio, 977)
         for name, cop, dop in (("lz4", A.OP_LZ4_COMPRESS, A.OP_LZ4_DECOMPRESS), ("snappy", A.OP_SNAPPY_COMPRESS, A.OP_SNAPPY_DECOMPRESS)):
             max_c = getattr(lib, "achip_%s_max_compressed_length" % name)(bs)
             cstride = (max_c + 15) // 16 * 16
@@ -338,8 +353,9 @@ def extras(torch, A, codec, dev, args):
 
 
 def zstd_extra(torch, A, codec, dev, args):
-    """Zstd level-3 frames of 128 KiB (BASELINE configs[3]); frames made on the host by libzstd via pyarrow
-    (a third-party encoder; no Zstd encoder in the product yet), decoded on the GPU, verified against the plaintext."""
+    """Zstd level-3 frames of 128 KiB (BASELINE configs[3]), two encodings: frames made on the host by
+    libzstd via pyarrow (a third-party encoder) and frames made by the product's GPU encoder (byte-identical to the
+    Java encoder's); both decoded on the GPU and verified against the plaintext."""
     import pyarrow as pa
     out = {}
     fs = 131072
@@ -347,8 +363,8 @@ def zstd_extra(torch, A, codec, dev, args):
     if args.zstd_variant >= 0:
         codec.native.set_option("zstd.decompress.variant", args.zstd_variant)
     zc = pa.Codec("zstd", compression_level=3)
-    for data_kind in ("fragments", "wordmix"):
-        plain = gen_fragments(torch, dev, pool_n, fs, args.ratio, 4242) if data_kind == "fragments" else gen_wordmix(torch, dev, pool_n, fs, 4242)
+    for data_kind in ("fragments", "wordmix", "corpus"):
+        plain = gen_data(torch, dev, data_kind, pool_n, fs, args.ratio, 4242)
         host = plain.cpu().numpy()
         frames = [zc.compress(host[i * fs:(i + 1) * fs].tobytes(), asbytes=True) for i in range(pool_n)]
         lens = np.array([len(f) for f in frames], dtype=np.int64)
