@@ -15,4 +15,4 @@ rocprofv3 --kernel-trace --output-format csv --pmc TCP_TCC_READ_REQ_sum TCP_TCC_
 python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # keep only small artefacts (gpurun copies back <= 64 MiB)
-mkdir -p $OUT/keep; find $OUT/stats -name '*kernel_stats.csv' -exec cp {} $OUT/keep/ \; ; find $OUT -name '*.log' -size -200k -exec cp {} $OUT/keep/ \; ; cp $OUT/summary.txt $OUT/keep/; rm -rf $OUT/stats $OUT/pmc_*; find gpurun_out -size +20M -delete
+mkdir -p $OUT/keep; find $OUT/stats -name '*kernel_stats.csv' -exec cp {} $OUT/keep/ \; ; find $OUT -name '*.log' -size -200k -exec cp {} $OUT/keep/ \; ; cp $OUT/summary.txt $OUT/keep/; cp $OUT/traffic.json $OUT/keep/ 2>/dev/null; rm -rf $OUT/stats $OUT/pmc_*; find gpurun_out -size +20M -delete

@@ -43,3 +43,36 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcp"):
         tail = [l for l in open(log).read().splitlines() if "rror" in l][:3]
         for l in tail:
             print("   log:", l[:200])
+
+# ---- traffic record for bench.py's roofline.traffic (profiles/traffic.json) ----
+# HBM bytes per launch of the dominant decode kernel = FETCH_SIZE x 2 (the gfx950 correction for wide coalesced reads,
+# MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both reported by rocprofv3 in KiB-ish units of 1024 bytes, from separate passes.
+try:
+    vals = {}
+    for d, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        tot, n = 0.0, 0
+        for f in find(d + "/**/*counter_collection.csv"):
+            for row in csv.DictReader(open(f)):
+                if row.get("Counter_Name") == name and "decompress_rings_kernel" in row.get("Kernel_Name", ""):
+                    tot += float(row.get("Counter_Value", 0))
+                    n += 1
+        if n:
+            vals[name] = tot / n
+    bench = None
+    for line in open(os.path.join(root, "stats.log")).read().splitlines():
+        if line.startswith("{"):
+            bench = json.loads(line)
+    if bench and len(vals) == 2:
+        rec = {
+            "blocks": bench["config"]["blocks_per_gpu"],
+            "hbm_bytes_per_launch": int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024),
+            "fetch_bytes_x2": int(vals["FETCH_SIZE"] * 1024 * 2), "write_bytes": int(vals["WRITE_SIZE"] * 1024),
+            "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md; WRITE_SIZE uncalibrated",
+        }
+        print("== traffic ==")
+        print(json.dumps({bench["config"]["workload"].split(",")[0]: rec}))
+        with open(os.path.join(root, "traffic.json"), "w") as w:
+            json.dump({bench["config"]["workload"].split(",")[0]: rec}, w, indent=1)
+except Exception as e:  # the summary above is still useful
+    print("traffic record not written:", e)
