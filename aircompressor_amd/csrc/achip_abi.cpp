@@ -40,6 +40,8 @@ struct achip_ctx {
     int snappycVariant = 1;  // 0 = serial probes, 1 = 64 probes per step (batch)
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 0;
+    int ringPad = 16;
+    int scratchPoison = -1;
     int32_t lastZstddBlocks = 0;  // achip_ctx_get_stat
     int lastZstddVariant = 0;
     int maxSrcLenHint = 0;
@@ -92,6 +94,7 @@ achip::BatchArgs make_args(const void* srcBase, const int64_t* srcOff, const int
     a.status = status;
     a.errOffset = errOffset;
     a.nBlocks = nBlocks;
+    a.ringPad = 0;
     return a;
 }
 
@@ -135,11 +138,14 @@ int32_t ensure_stage(achip_ctx* ctx, int64_t bytes)
     return 0;
 }
 
-int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& a)
+int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
 {
     if (!ctx) {
         return bad_argument("ctx is null");
     }
+    achip::BatchArgs a = args;
+    a.ringPad = ctx->ringPad;
+    if (op == ACHIP_OP_ZSTD_COMPRESS) a.ringPad = ctx->zstdcVariant == 100 ? 999 : (ctx->zstdcVariant == 1 ? 1 : 0);  // encoder variant rides in the spare field
     if (a.nBlocks < 0) {
         return bad_argument("nBlocks < 0");
     }
@@ -170,6 +176,9 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& a)
         case ACHIP_OP_ZSTD_COMPRESS: {
             int32_t r = ensure_scratch(ctx, achip::zstd_compress_scratch_bytes(a.nBlocks));
             if (r < 0) return r;
+            if (ctx->scratchPoison >= 0) {  // debugging aid: expose reads of uninitialised scratch
+                HIP_TRY(hipMemsetAsync(ctx->scratch, ctx->scratchPoison, (size_t)ctx->scratchBytes, ctx->stream));
+            }
             e = achip::launch_zstd_compress(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->zstdcVariant);
             break;
         }
@@ -408,6 +417,11 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     else if (k == "decompress.ring_class") ctx->ringClass = (int)value;
     else if (k == "lz4.compress.variant") ctx->lz4cVariant = (int)value;
     else if (k == "snappy.compress.variant") ctx->snappycVariant = (int)value;
+    else if (k == "decompress.ring_pad") {
+        if (value < 0 || value > 256 || (value & 15) != 0) return bad_argument("ring pad must be a multiple of 16 in 0..256");
+        ctx->ringPad = (int)value;
+    }
+    else if (k == "debug.scratch_poison") ctx->scratchPoison = (int)value;
     else if (k == "zstd.decompress.variant") ctx->zstddVariant = (int)value;
     else if (k == "zstd.compress.variant") ctx->zstdcVariant = (int)value;
     else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;

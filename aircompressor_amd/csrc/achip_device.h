@@ -26,6 +26,7 @@ struct BatchArgs {
     int32_t* __restrict__ status;
     int64_t* __restrict__ errOffset;
     int32_t nBlocks;
+    int32_t ringPad;  // LDS padding between the ring pairs of consecutive blocks (decoders)
 };
 
 __device__ __forceinline__ constexpr int32_t mk_status(int cls, int detail) { return -(cls + 16 * detail); }

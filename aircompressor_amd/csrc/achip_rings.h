@@ -15,6 +15,10 @@
 
 namespace achip {
 
+// Ring pairs of consecutive blocks are BatchArgs::ringPad bytes apart beyond their size (a multiple of 16): with a
+// 384 B = 96-dword slot the 16 blocks of a wavefront start on only two distinct LDS banks; 400 B = 100 dwords
+// spreads them over all banks (context option "decompress.ring_pad").
+
 template <int GS, int IN_RING, int OUT_RING, int GPL = 1>
 struct Rings {
     static constexpr int CHUNK = GS * 16 * GPL;                // bytes per refill / flush / copy step (GPL 16-byte granules per lane)

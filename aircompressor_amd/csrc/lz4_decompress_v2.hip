@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a)
     const int32_t outLimit = a.dstCap[block];
 
     Rings<GS, IN_RING, OUT_RING, GPL> R;
-    R.init(smem + grp * (IN_RING + OUT_RING), smem + grp * (IN_RING + OUT_RING) + IN_RING, in, inLimit, out, g);
+    R.init(smem + grp * (IN_RING + OUT_RING + a.ringPad), smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING, in, inLimit, out, g);
 
     int32_t st = 0;
     int32_t eo = 0;  // 32-bit on purpose (see lz4_decompress.hip)
@@ -126,7 +126,7 @@ static hipError_t lz4d2_launch(const BatchArgs& a, hipStream_t stream)
 {
     constexpr int GROUPS_PER_WG = 256 / GS;
     const unsigned grid = (unsigned)((a.nBlocks + GROUPS_PER_WG - 1) / GROUPS_PER_WG);
-    const size_t lds = (size_t)GROUPS_PER_WG * (IN_RING + OUT_RING);
+    const size_t lds = (size_t)GROUPS_PER_WG * (IN_RING + OUT_RING + a.ringPad);
     hipLaunchKernelGGL((lz4_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL>), dim3(grid), dim3(256), lds, stream, a);
     return hipGetLastError();
 }

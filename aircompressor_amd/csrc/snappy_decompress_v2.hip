@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs 
         const int32_t fastOutLimit = outLimit - 8;
         int32_t ip = 0;
         Rings<GS, IN_RING, OUT_RING, GPL> R;
-        R.init(smem + grp * (IN_RING + OUT_RING), smem + grp * (IN_RING + OUT_RING) + IN_RING, in, inLimit, out, g);
+        R.init(smem + grp * (IN_RING + OUT_RING + a.ringPad), smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING, in, inLimit, out, g);
 
 #define SN_FAIL(off)                                                     \
     {                                                                    \
@@ -141,7 +141,7 @@ static hipError_t snd2_launch(const BatchArgs& a, hipStream_t stream)
 {
     constexpr int GROUPS_PER_WG = 256 / GS;
     const unsigned grid = (unsigned)((a.nBlocks + GROUPS_PER_WG - 1) / GROUPS_PER_WG);
-    const size_t lds = (size_t)GROUPS_PER_WG * (IN_RING + OUT_RING);
+    const size_t lds = (size_t)GROUPS_PER_WG * (IN_RING + OUT_RING + a.ringPad);
     hipLaunchKernelGGL((snappy_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL>), dim3(grid), dim3(256), lds, stream, a);
     return hipGetLastError();
 }

@@ -84,6 +84,8 @@ struct Ctx {
     uint8_t* out;
     int32_t outCap;
     int lane;
+    int dbgStage;
+    int batchProbe;
     int32_t failStatus;  // 0 = ok
     // per-wave slab
     int32_t* hashTable;
@@ -1293,6 +1295,18 @@ __device__ __forceinline__ void store_sequence(Ctx& c, int32_t literalAddress, i
     c.sequenceCount = i + 1;
 }
 
+// for every lane, the mask of lanes whose `key` (low `bits` bits) equals its own
+__device__ __forceinline__ unsigned long long zc_match_any(uint32_t key, int bits, unsigned long long active)
+{
+    unsigned long long eq = active;
+    for (int b = 0; b < bits; b++) {
+        const bool bit = (key >> b) & 1u;
+        const unsigned long long m = __ballot(bit);
+        eq &= bit ? m : ~m;
+    }
+    return eq;
+}
+
 __device__ int32_t dfast_compress_block(Ctx& c, int32_t inputAddress, int32_t inputSize)
 {
     const uint8_t* __restrict__ in = c.in;
@@ -1319,24 +1333,98 @@ __device__ int32_t dfast_compress_block(Ctx& c, int32_t inputAddress, int32_t in
         savedOffset = offset1;
         offset1 = 0;
     }
+    int32_t width = 8;  // lanes of the next batch probe: narrow right after a match (text finds the next one within a few positions), 64 once a batch found nothing
     while (input < inputLimit) {
-        const uint64_t here = ld8(in + input);
-        const int32_t shortHash = c.searchLength == 5 ? hash5(here, c.chainLog) : hash4((uint32_t)here, c.chainLog);
-        int32_t shortMatch = shortTable[shortHash];
-        const int32_t longHash = hash8(here, longBits);
-        int32_t longMatch = longTable[longHash];
+        uint64_t here = 0;
+        int32_t shortHash = 0, longHash = 0, shortMatch = 0, longMatch = 0;
+        bool repHit = false, longHit = false, shortHit = false;
+        bool probed = false;
+        if (c.batchProbe && input - anchor < 256 - 64) {
+            // Batch probe: while nothing matches the serial loop visits input, input + 1, ... (its step is
+            // ((input - anchor) >> 8) + 1 = 1 here) and changes nothing but the two tables, so the lanes test the next
+            // `width` positions at once -- three dependent HBM round trips per batch instead of per position.  A lane
+            // sees the tables as the serial loop would: the latest earlier lane with the same hash, else the stored
+            // entry.  Lanes before the first candidate match commit their inserts (latest position per slot); the
+            // first candidate's position continues below with what its lane has already loaded.
+            const int lane = c.lane;
+            const int32_t p = input + lane;
+            const bool act = lane < width && p < inputLimit;
+            const unsigned long long actMask = __ballot(act);
+            const uint64_t hereB = act ? ld8(in + p) : 0ull;
+            const int32_t sh = c.searchLength == 5 ? hash5(hereB, c.chainLog) : hash4((uint32_t)hereB, c.chainLog);
+            const int32_t lh = hash8(hereB, longBits);
+            int32_t sm = act ? shortTable[sh] : 0;
+            int32_t lm = act ? longTable[lh] : 0;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned long long sameS = zc_match_any((uint32_t)sh, c.chainLog, actMask);
+            const unsigned long long sameL = zc_match_any((uint32_t)lh, longBits, actMask);
+            if (act && (sameS & below) != 0) {
+                sm = input + (63 - __builtin_clzll(sameS & below));
+            }
+            if (act && (sameL & below) != 0) {
+                lm = input + (63 - __builtin_clzll(sameL & below));
+            }
+            bool r = false, l = false, sHit = false;
+            if (act) {
+                r = offset1 > 0 && ld4(in + p + 1 - offset1) == (uint32_t)(hereB >> 8);
+                l = lm > windowBase && ld8(in + lm) == hereB;
+                sHit = sm > windowBase && ld4(in + sm) == (uint32_t)hereB;
+            }
+            const unsigned long long hitMask = __ballot(r || l || sHit);
+            const unsigned long long stop = hitMask | ~actMask;
+            const int first = stop != 0 ? __builtin_ctzll(stop) : 64;
+            const unsigned long long upTo = first >= 64 ? ~0ull : ((1ull << first) - 1ull);  // lanes that found nothing
+            const unsigned long long above = lane >= 63 ? 0ull : ~((2ull << lane) - 1ull);
+            if (lane < first) {
+                if ((sameL & upTo & above) == 0) {
+                    longTable[lh] = p;
+                }
+                if ((sameS & upTo & above) == 0) {
+                    shortTable[sh] = p;
+                }
+            }
+            wave_mem_order();
+            input += first;
+            if (first >= 64 || ((hitMask >> first) & 1ull) == 0) {
+                width = 64;  // nothing in this batch (or the end of the block): keep going, wide
+                continue;
+            }
+            here = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(hereB >> 32), first) << 32) | (uint32_t)__shfl((int)(uint32_t)hereB, first);
+            shortHash = __shfl(sh, first);
+            longHash = __shfl(lh, first);
+            shortMatch = __shfl(sm, first);
+            longMatch = __shfl(lm, first);
+            repHit = __shfl(r ? 1 : 0, first) != 0;
+            longHit = __shfl(l ? 1 : 0, first) != 0;
+            shortHit = __shfl(sHit ? 1 : 0, first) != 0;
+            probed = true;
+        }
+        if (!probed) {
+            here = ld8(in + input);
+            shortHash = c.searchLength == 5 ? hash5(here, c.chainLog) : hash4((uint32_t)here, c.chainLog);
+            shortMatch = shortTable[shortHash];
+            longHash = hash8(here, longBits);
+            longMatch = longTable[longHash];
+            repHit = offset1 > 0 && ld4(in + input + 1 - offset1) == ld4(in + input + 1);
+            if (!repHit) {
+                longHit = longMatch > windowBase && ld8(in + longMatch) == here;
+                if (!longHit) {
+                    shortHit = shortMatch > windowBase && ld4(in + shortMatch) == (uint32_t)here;
+                }
+            }
+        }
         const int32_t current = input;
         longTable[longHash] = current;
         shortTable[shortHash] = current;
         int32_t matchLength;
         int32_t offset;
-        if (offset1 > 0 && ld4(in + input + 1 - offset1) == ld4(in + input + 1)) {
+        if (repHit) {
             matchLength = wave_count(in, input + 1 + 4, input + 1 + 4 - offset1, inputEnd, c.lane) + 4;
             input++;
             store_sequence(c, anchor, input - anchor, 0, matchLength - 3);
         }
         else {
-            if (longMatch > windowBase && ld8(in + longMatch) == here) {
+            if (longHit) {
                 matchLength = wave_count(in, input + 8, longMatch + 8, inputEnd, c.lane) + 8;
                 offset = input - longMatch;
                 while (input > anchor && longMatch > windowBase && in[input - 1] == in[longMatch - 1]) {
@@ -1345,7 +1433,7 @@ __device__ int32_t dfast_compress_block(Ctx& c, int32_t inputAddress, int32_t in
                     matchLength++;
                 }
             }
-            else if (shortMatch > windowBase && ld4(in + shortMatch) == (uint32_t)here) {
+            else if (shortHit) {
                 const uint64_t next = ld8(in + input + 1);
                 const int32_t nextHash = hash8(next, longBits);
                 int32_t nextMatch = longTable[nextHash];
@@ -1378,6 +1466,7 @@ __device__ int32_t dfast_compress_block(Ctx& c, int32_t inputAddress, int32_t in
             offset1 = offset;
             store_sequence(c, anchor, input - anchor, offset + 2, matchLength - 3);
         }
+        width = input - anchor >= 24 ? 64 : 8;  // the literal run just closed predicts the next one: wide batches for long runs, narrow for text
         input += matchLength;
         anchor = input;
         if (input <= inputLimit) {
@@ -1420,6 +1509,9 @@ __device__ int32_t compress_block(Ctx& c, Shared& sh, int32_t inputAddress, int3
     c.sequenceCount = 0;
     c.longLengthField = 0;
     const int32_t lastLiteralsSize = dfast_compress_block(c, inputAddress, inputSize);
+    if (c.dbgStage == 1) {
+        return 0;  // DEBUG (timing split only): stop after the match finder
+    }
     wave_mem_order();
     group_copy<64>(c.litBuf + c.literalsLength, c.in + inputAddress + inputSize - lastLiteralsSize, lastLiteralsSize, c.lane);
     c.literalsLength += lastLiteralsSize;
@@ -1609,6 +1701,8 @@ __global__ __launch_bounds__(64) void zstd_compress_kernel(BatchArgs a, uint8_t*
         c.out = a.dstBase + a.dstOff[block];
         c.outCap = a.dstCap[block];
         c.lane = lane;
+        c.dbgStage = a.ringPad == 999 ? 1 : 0;
+        c.batchProbe = a.ringPad == 1 ? 0 : 1;  // variant 1 = serial probing
         c.failStatus = 0;
         uint8_t* p = slab;
         c.hashTable = (int32_t*)p;
@@ -1645,7 +1739,7 @@ __global__ __launch_bounds__(64) void zstd_compress_kernel(BatchArgs a, uint8_t*
 }
 
 namespace {
-constexpr int ZC_MAX_WAVES = 256 * 4;
+constexpr int ZC_MAX_WAVES = 256 * 8;  // 154 VGPRs => 2 waves per SIMD: all of them are needed to cover the HBM round trips of the match finder
 }
 
 int64_t zstd_compress_scratch_bytes(int32_t nBlocks)

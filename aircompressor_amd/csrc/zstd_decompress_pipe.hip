@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp:
     const int32_t nSeq = d.nDecoded;
 
     Rings<GS, IN_RING, OUT_RING> R;
-    R.init(smem + grp * (IN_RING + OUT_RING), smem + grp * (IN_RING + OUT_RING) + IN_RING, lit, litSize, out, g);
+    R.init(smem + grp * (IN_RING + OUT_RING + a.ringPad), smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING, lit, litSize, out, g);
 
     int32_t output = 0;
     int32_t literalsInput = 0;
@@ -1015,7 +1015,7 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
         hipLaunchKernelGGL(zstd_pipe_literals_kernel, dim3(w16), dim3(64), 0, stream, a, p);
         hipLaunchKernelGGL(zstd_pipe_sequences_kernel, dim3((unsigned)((p.count + zp::SEQ_ITEMS_PER_WAVE - 1) / zp::SEQ_ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
         constexpr int GS = 4, IN_RING = 128, OUT_RING = 256;
-        hipLaunchKernelGGL((zstd_pipe_execute_kernel<GS, IN_RING, OUT_RING>), dim3((unsigned)((p.count + 256 / GS - 1) / (256 / GS))), dim3(256), (size_t)(256 / GS) * (IN_RING + OUT_RING), stream, a, p);
+        hipLaunchKernelGGL((zstd_pipe_execute_kernel<GS, IN_RING, OUT_RING>), dim3((unsigned)((p.count + 256 / GS - 1) / (256 / GS))), dim3(256), (size_t)(256 / GS) * (IN_RING + OUT_RING + a.ringPad), stream, a, p);
         hipLaunchKernelGGL(zstd_pipe_checksum_kernel, dim3(w16), dim3(64), 0, stream, a, p);
     }
     e = hipGetLastError();

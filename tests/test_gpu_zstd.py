@@ -199,10 +199,16 @@ def encoder_inputs():
     return blocks
 
 
-def test_zstd_compress_is_bit_exact_with_oracle(gb, o):
+@pytest.mark.parametrize("variant", [0, 1], ids=["batch-probe", "serial-probe"])
+def test_zstd_compress_is_bit_exact_with_oracle(gb, o, variant):
     blocks = encoder_inputs()
+    blocks += [b for b in common.synthetic_blocks(77, 12)]   # RandomGenerator-style data: long literal runs, many same-hash positions per batch
     caps = [o.max_compressed_length("zstd", len(b)) for b in blocks]
-    outs, status, _ = gb.run(OP_ZSTD_COMPRESS, blocks, caps)
+    gb.set_option("zstd.compress.variant", variant)
+    try:
+        outs, status, _ = gb.run(OP_ZSTD_COMPRESS, blocks, caps)
+    finally:
+        gb.set_option("zstd.compress.variant", 0)
     assert all(s == 0 for s in status), status
     for i, (b, z) in enumerate(zip(blocks, outs)):
         assert z == o.compress("zstd", b, caps[i]), "block %d (len %d): gpu %d bytes" % (i, len(b), len(z))
