@@ -413,8 +413,8 @@ def zstd_extra(torch, A, codec, dev, args):
         # GPU level-3 encoder (bit-exact with the Java encoder) over the same plaintext, then GPU decode of its frames
         max_c = lib_max = codec.lib.achip_zstd_max_compressed_length(fs)
         cstride = (max_c + 15) // 16 * 16
-        nz = pool_n * 16
-        zplain = plain.repeat(16)
+        nz = pool_n * 64
+        zplain = plain.repeat(64)
         z_src_off = torch.arange(nz, **i64) * fs
         z_src_len = torch.full((nz,), fs, **i32)
         z_dst = torch.empty(nz * cstride + 64, dtype=torch.uint8, device=dev)

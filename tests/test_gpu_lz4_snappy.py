@@ -78,6 +78,34 @@ def test_decompress_matches_plaintext_all_decoder_configs(gb, o, codec, cfg):
     configure(gb, codec, DECODERS[0])
 
 
+@pytest.mark.parametrize("ring_class", [0, 1])
+def test_lz4_lane_per_block_decoder(gb, o, ring_class):
+    """variant 2 (lz4_decompress_v3.hip, one lane per block): plaintext, status and error offsets equal the oracle's"""
+    rng = np.random.default_rng(7)
+    blocks = all_blocks()
+    cases = [(o.compress("lz4", b), len(b)) for b in blocks] + [(o.compress("lz4", b), len(b) + 37) for b in blocks[:20]]
+    cases += [(bytes([15, 0, 0, 255, 255, 0x8A, 49, 255, 255, 0]), 1024), (b"", 10), (b"\x00", 0), (b"\x10a", 0), (bytes([0xF0]) + b"\xff" * 4000, 1 << 16)]
+    for b in [d for _, d, _ in common.corpus_sample()[:3]]:
+        c = bytearray(o.compress("lz4", b))
+        cases += [(bytes(c), len(b) - 1), (bytes(c[:len(c) // 2]), len(b)), (bytes(c[:-1]), len(b))]
+        for _ in range(8):
+            m = bytearray(c)
+            m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+            cases.append((bytes(m), len(b)))
+    configure(gb, "lz4", (2, 4, ring_class))
+    try:
+        outs, status, err = gb.run(CODECS["lz4"]["d"], [c for c, _ in cases], [cap for _, cap in cases], unaligned=True)
+    finally:
+        configure(gb, "lz4", DECODERS[0])
+    for i, (c, cap) in enumerate(cases):
+        est, eoff, eout = _oracle_status(o, "lz4", c, cap)
+        assert status[i] == est, "case %d: gpu status %d oracle %d" % (i, status[i], est)
+        if est != 0:
+            assert err[i] == eoff, "case %d: gpu offset %d oracle %d" % (i, err[i], eoff)
+        else:
+            assert outs[i] == eout, "case %d" % i
+
+
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
 def test_round_trip_gpu_only(gb, o, codec):
     blocks = [b for b in all_blocks() if len(b) > 0]

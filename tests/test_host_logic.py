@@ -41,3 +41,21 @@ def test_zstd_code_arithmetic_equals_the_java_tables():
         subprocess.run(["gcc", "-O1", "-std=gnu11", "-I", ROOT, "-I", os.path.join(ROOT, "oracle"), "-o", exe, src, os.path.join(ROOT, "oracle", "xxhash64.c")], check=True)
         out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
         assert out.strip() == "0"
+
+
+def test_lane_per_block_lz4_decoder_source_on_the_cpu():
+    """lz4_decompress_v3.hip uses no cross-lane operation, so its kernel source can be compiled for the host and run one
+    lane at a time (tools/hostemu): plaintext, status, error offset and guard bands against the oracle -- the same cases
+    as the GPU parity suite, without a GPU."""
+    import shutil
+    import sys
+    import pytest
+    clang = shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("no clang++ for the host build of the kernel source")
+    emu_dir = os.path.join(ROOT, "tools", "hostemu")
+    subprocess.run([clang, "-O1", "-std=c++17", "-fPIC", "-shared", "-I", emu_dir, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "aircompressor_amd", "csrc"),
+                    "-o", os.path.join(emu_dir, "libemu.so"), os.path.join(emu_dir, "emu.cpp")], check=True)
+    out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_v3.py"), "--quick"], check=True, capture_output=True, text=True, cwd=ROOT).stdout
+    lines = [l for l in out.splitlines() if "mismatches" in l]
+    assert lines and all(l.endswith(" 0 mismatches") for l in lines), out

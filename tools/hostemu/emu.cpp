@@ -1,13 +1,17 @@
-// tools/hostemu/emu.cpp -- runs the GS=1 decoder kernels on the CPU (sequential lanes are exact for GS=1).
+// tools/hostemu/emu.cpp -- runs the lane-private decoder kernels on the CPU (sequential lanes are exact when a kernel
+// uses no cross-lane operation: the GS=1 instantiations of the direct decoders and the lane-per-block v3 decoders).
 #include "hip/hip_runtime.h"
 thread_local dim3 threadIdx, blockIdx, blockDim;
 #include "../../aircompressor_amd/csrc/lz4_decompress.hip"
 #include "../../aircompressor_amd/csrc/snappy_decompress.hip"
+#include "../../aircompressor_amd/csrc/lz4_decompress_v3.hip"
 extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, const int32_t* srcLen, uint8_t* dstBase, const int64_t* dstOff,
                          const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n)
 {
-    achip::BatchArgs a{srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, n};
+    achip::BatchArgs a{srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, n, 0};
     if (op == 0) return achip::launch_lz4_decompress(a, nullptr, 1);
     if (op == 2) return achip::launch_snappy_decompress(a, nullptr, 1);
+    if (op == 10) return achip::launch_lz4_decompress_lanes(a, nullptr, 0);
+    if (op == 11) return achip::launch_lz4_decompress_lanes(a, nullptr, 1);
     return -1;
 }
