@@ -41,7 +41,7 @@ struct achip_ctx {
     int snappycVariant = 1;  // 0 = serial probes, 1 = 64 probes per step (batch)
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 0;
-    int ringPad = 16;
+    int ringPad = 80;        // 64 bytes of far-match staging + 16: consecutive blocks start on different LDS banks
     int scratchPoison = -1;
     int32_t lastZstddBlocks = 0;  // achip_ctx_get_stat
     int lastZstddVariant = 0;

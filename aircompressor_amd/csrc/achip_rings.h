@@ -36,11 +36,18 @@ struct Rings {
     int32_t flushedV;          // output flushed to HBM up to this virtual position (multiple of 16, or the final end)
     u32x4 pending[GPL];        // this lane's granules of the NEXT input chunk, requested one refill ahead (hides HBM latency)
     int g;
+    uint8_t* stage;            // CHUNK bytes of LDS behind the rings (or null): landing zone of back-references read from HBM
 
-    __device__ __forceinline__ void init(uint8_t* ldsIn, uint8_t* ldsOut, const uint8_t* in, int32_t inLimit, uint8_t* out, int lane)
+    // GS == 4: ONE generic <= CHUNK-byte move per loop trip, whatever its length and wherever it comes from.  The 16
+    // blocks of a wavefront diverge on every special case (short / long, near / far, overlapping), and a wavefront pays
+    // for every path any of its blocks takes: on text that was ~785 wave instructions per 16 sequences.
+    static constexpr bool UNIFIED = GS == 4 && GPL == 1;
+
+    __device__ __forceinline__ void init(uint8_t* ldsIn, uint8_t* ldsOut, const uint8_t* in, int32_t inLimit, uint8_t* out, int lane, uint8_t* ldsStage = nullptr)
     {
         inRing = ldsIn;
         outRing = ldsOut;
+        stage = ldsStage;
         inBase = (int32_t)((uintptr_t)in & 15);
         outBase = (int32_t)((uintptr_t)out & 15);
         inAligned = in - inBase;
@@ -129,7 +136,8 @@ struct Rings {
     template <int SRC_RING>
     __device__ __forceinline__ void copy_dwords(const uint8_t* src, int32_t sV, int32_t dV, int32_t c)
     {
-        const int32_t head = (4 - (dV & 3)) & 3;
+        int32_t head = (4 - (dV & 3)) & 3;
+        head = head < c ? head : c;  // c may be shorter than the run-up to the next destination dword
         const int32_t nd = (c - head) >> 2;
         const int32_t t0 = head + 4 * nd;
         constexpr int ITER = CHUNK / (4 * GS);  // = 4 * GPL
@@ -250,6 +258,18 @@ struct Rings {
     // literals: n input bytes at ip -> output at op (n arbitrary; input ring refilled, output flushed as we go)
     __device__ __forceinline__ void copy_literals(int32_t ip, int32_t op, int32_t n)
     {
+        if (UNIFIED && n > 4 * GS) {
+            while (n > 0) {
+                const int32_t c = n < CHUNK ? n : CHUNK;
+                ensure_input(ip, c);
+                copy_dwords<IN_RING>(inRing, ip + inBase, op + outBase, c);
+                ip += c;
+                op += c;
+                n -= c;
+                flush_complete(op);
+            }
+            return;
+        }
         if (n <= 4 * GS) {
             ensure_input(ip, n);
             copy_small<IN_RING>(inRing, ip + inBase, op + outBase, n);
@@ -280,6 +300,35 @@ struct Rings {
     // offsets the period is folded so all sources lie BEFORE the chunk (no intra-chunk dependency).
     __device__ __forceinline__ void copy_match(int32_t op, int32_t offset, int32_t n)
     {
+        if (UNIFIED && !(n <= 4 * GS && offset >= n)) {
+            if (stage != nullptr) {
+                // A trip never reads what it writes (c <= dist); a distance shorter than a chunk doubles once a whole
+                // period has been written -- the data is periodic, so out[x] = out[x - 2 * dist] as well.
+                int32_t dist = offset;
+                while (n > 0) {
+                    int32_t c = n < CHUNK ? n : CHUNK;
+                    c = c < dist ? c : dist;
+                    wave_mem_order();
+                    if (dist <= LDS_REACH) {
+                        copy_dwords<OUT_RING>(outRing, op + outBase - dist, op + outBase, c);
+                    }
+                    else {
+                        // flushed long ago (dist > LDS_REACH >= 2 * CHUNK): 64 source bytes land in the staging area,
+                        // then the same move as every other copy.  Reading past c stays inside this block's output.
+                        *(u32x4*)(stage + 16 * g) = ld16(outAligned + outBase + (op - dist) + 16 * g);
+                        wave_mem_order();
+                        copy_dwords<CHUNK>(stage, 0, op + outBase, c);
+                    }
+                    op += c;
+                    n -= c;
+                    if (dist < CHUNK) {
+                        dist += dist;
+                    }
+                    flush_complete(op);
+                }
+                return;
+            }
+        }
         if (n <= 4 * GS && offset >= n) {
             wave_mem_order();
             if (offset <= LDS_REACH) {

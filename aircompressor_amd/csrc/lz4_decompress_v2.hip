@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a)
     const int32_t outLimit = a.dstCap[block];
 
     Rings<GS, IN_RING, OUT_RING, GPL> R;
-    R.init(smem + grp * (IN_RING + OUT_RING + a.ringPad), smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING, in, inLimit, out, g);
+    R.init(smem + grp * (IN_RING + OUT_RING + a.ringPad), smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING, in, inLimit, out, g,
+           a.ringPad >= 16 * GS * GPL ? smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING + OUT_RING : nullptr);
 
     int32_t st = 0;
     int32_t eo = 0;  // 32-bit on purpose (see lz4_decompress.hip)

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs 
         const int32_t fastOutLimit = outLimit - 8;
         int32_t ip = 0;
         Rings<GS, IN_RING, OUT_RING, GPL> R;
-        R.init(smem + grp * (IN_RING + OUT_RING + a.ringPad), smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING, in, inLimit, out, g);
+        R.init(smem + grp * (IN_RING + OUT_RING + a.ringPad), smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING, in, inLimit, out, g,
+           a.ringPad >= 16 * GS * GPL ? smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING + OUT_RING : nullptr);
 
 #define SN_FAIL(off)                                                     \
     {                                                                    \

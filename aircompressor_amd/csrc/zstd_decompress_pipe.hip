@@ -760,7 +760,8 @@ __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp:
     const int32_t nSeq = d.nDecoded;
 
     Rings<GS, IN_RING, OUT_RING> R;
-    R.init(smem + grp * (IN_RING + OUT_RING + a.ringPad), smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING, lit, litSize, out, g);
+    R.init(smem + grp * (IN_RING + OUT_RING + a.ringPad), smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING, lit, litSize, out, g,
+           a.ringPad >= 16 * GS ? smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING + OUT_RING : nullptr);
 
     int32_t output = 0;
     int32_t literalsInput = 0;
