@@ -68,6 +68,23 @@ __device__ __forceinline__ void st2(uint8_t* p, uint32_t v)
     __builtin_memcpy(p, &w, 2);
 }
 
+// dynamic LDS of a kernel; tools/hostemu (plain clang++, kernels run one lane at a time) substitutes a host arena
+#if defined(__HIPCC__)
+#define ACHIP_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) uint8_t name[]
+#else
+#define ACHIP_DYNAMIC_LDS(name) uint8_t* name = hostemu_dynamic_lds
+#endif
+
+// (hi:lo) >> 8*s for s in 0..3 -- v_alignbyte_b32 on the device, plain C when the kernel sources are built for the host (tools/hostemu)
+__device__ __forceinline__ uint32_t alignbyte_u32(uint32_t hi, uint32_t lo, uint32_t s)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, s);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (s & 3)));
+#endif
+}
+
 // Compiler-level ordering point between a store phase and a load phase whose addresses
 // may be produced by OTHER lanes of the same wave.  The hardware issues a wave's vector
 // memory instructions to the CU's L1/TA in program order, so keeping the compiler from

@@ -21,16 +21,6 @@
 
 namespace achip {
 
-// (hi:lo) >> 8*s for s in 0..3
-__device__ __forceinline__ uint32_t lane_alignbyte(uint32_t hi, uint32_t lo, uint32_t s)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_alignbyte(hi, lo, s);
-#else
-    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (s & 3)));
-#endif
-}
-
 template <int IN_DW, int OUT_DW>
 struct LaneRings {
     static constexpr int IN_BYTES = IN_DW * 4, OUT_BYTES = OUT_DW * 4;
@@ -108,7 +98,7 @@ struct LaneRings {
         const int32_t d = v >> 2;
         const uint32_t w0 = inR[((d + 0) & (IN_DW - 1)) * 64], w1 = inR[((d + 1) & (IN_DW - 1)) * 64], w2 = inR[((d + 2) & (IN_DW - 1)) * 64];
         const uint32_t s = (uint32_t)(v & 3);
-        return ((uint64_t)lane_alignbyte(w2, w1, s) << 32) | lane_alignbyte(w1, w0, s);
+        return ((uint64_t)alignbyte_u32(w2, w1, s) << 32) | alignbyte_u32(w1, w0, s);
     }
     __device__ __forceinline__ uint32_t in_u8(int32_t pos) const
     {
@@ -124,7 +114,7 @@ struct LaneRings {
         const uint32_t r0 = ring[((d + 0) & (DW - 1)) * 64], r1 = ring[((d + 1) & (DW - 1)) * 64], r2 = ring[((d + 2) & (DW - 1)) * 64],
                        r3 = ring[((d + 3) & (DW - 1)) * 64], r4 = ring[((d + 4) & (DW - 1)) * 64];
         const uint32_t s = (uint32_t)(sV & 3);
-        return u32x4{lane_alignbyte(r1, r0, s), lane_alignbyte(r2, r1, s), lane_alignbyte(r3, r2, s), lane_alignbyte(r4, r3, s)};
+        return u32x4{alignbyte_u32(r1, r0, s), alignbyte_u32(r2, r1, s), alignbyte_u32(r3, r2, s), alignbyte_u32(r4, r3, s)};
     }
 
     // append c (1..16) bytes, the low bytes of w, at the output position
@@ -135,9 +125,9 @@ struct LaneRings {
         // stream = carry's low sh bytes followed by w: dword k = (w[k] : w[k-1]) >> 8*(4-sh)
         const uint32_t rs = (4u - sh) & 3u;
         uint32_t d0 = (carry & keep) | (w.x << (8 * sh));
-        uint32_t d1 = sh ? lane_alignbyte(w.y, w.x, rs) : w.y;
-        uint32_t d2 = sh ? lane_alignbyte(w.z, w.y, rs) : w.z;
-        uint32_t d3 = sh ? lane_alignbyte(w.w, w.z, rs) : w.w;
+        uint32_t d1 = sh ? alignbyte_u32(w.y, w.x, rs) : w.y;
+        uint32_t d2 = sh ? alignbyte_u32(w.z, w.y, rs) : w.z;
+        uint32_t d3 = sh ? alignbyte_u32(w.w, w.z, rs) : w.w;
         uint32_t d4 = sh ? (w.w >> (8 * rs)) : 0u;
         const int32_t d = opV >> 2;
         const int32_t total = (int32_t)sh + c;  // bytes of the stream that are real

@@ -126,7 +126,7 @@ struct Rings {
         const int32_t a = pv & ~3;
         const uint32_t lo = *(const uint32_t*)(ring + (a & (RING - 1)));
         const uint32_t hi = *(const uint32_t*)(ring + ((a + 4) & (RING - 1)));
-        return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(pv & 3));
+        return alignbyte_u32(hi, lo, (uint32_t)(pv & 3));
     }
 
 
@@ -188,6 +188,46 @@ struct Rings {
     {
         const uint32_t w = ring_ld4<SRC_RING>(src, sV + 4 * g);
         put4(dV + 4 * g, w, n - 4 * g);
+    }
+
+    // copy_dwords with the source ring's size given at run time (mask = size - 1): lets one instruction stream serve
+    // literal runs (input ring), near matches (output ring) and staged far matches alike -- see the *_steps kernels
+    static __device__ __forceinline__ uint32_t ring_ld4_rt(const uint8_t* ring, int32_t mask, int32_t pv)
+    {
+        const int32_t a = pv & ~3;
+        const uint32_t lo = *(const uint32_t*)(ring + (a & mask));
+        const uint32_t hi = *(const uint32_t*)(ring + ((a + 4) & mask));
+        return alignbyte_u32(hi, lo, (uint32_t)(pv & 3));
+    }
+    __device__ __forceinline__ void copy_dwords_rt(const uint8_t* src, int32_t mask, int32_t sV, int32_t dV, int32_t c)
+    {
+        int32_t head = (4 - (dV & 3)) & 3;
+        head = head < c ? head : c;
+        const int32_t nd = (c - head) >> 2;
+        const int32_t t0 = head + 4 * nd;
+        constexpr int ITER = CHUNK / (4 * GS);
+        uint32_t w[ITER];
+#pragma unroll
+        for (int q = 0; q < ITER; q++) {
+            const int32_t j = g + GS * q;
+            w[q] = j < nd ? ring_ld4_rt(src, mask, sV + head + 4 * j) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < ITER; q++) {
+            const int32_t j = g + GS * q;
+            if (j < nd) {
+                *(uint32_t*)(outRing + ((dV + head + 4 * j) & (OUT_RING - 1))) = w[q];
+            }
+        }
+        // <= 3 head and <= 3 tail bytes (source and destination never overlap within one move)
+        for (int32_t i = g; i < 3; i += GS) {
+            if (i < head) {
+                outRing[(dV + i) & (OUT_RING - 1)] = src[(sV + i) & mask];
+            }
+            if (t0 + i < c) {
+                outRing[(dV + t0 + i) & (OUT_RING - 1)] = src[(sV + t0 + i) & mask];
+            }
+        }
     }
 
     // ---- output side ----

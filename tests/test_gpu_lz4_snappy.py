@@ -78,9 +78,11 @@ def test_decompress_matches_plaintext_all_decoder_configs(gb, o, codec, cfg):
     configure(gb, codec, DECODERS[0])
 
 
-@pytest.mark.parametrize("ring_class", [0, 1])
-def test_lz4_lane_per_block_decoder(gb, o, ring_class):
-    """variant 2 (lz4_decompress_v3.hip, one lane per block): plaintext, status and error offsets equal the oracle's"""
+@pytest.mark.parametrize("cfg", [(2, 4, 0), (2, 4, 1), (3, 4, 0), (3, 4, 1), (3, 1, 0), (3, 2, 0), (3, 2, 1), (3, 8, 0), (3, 8, 1)],
+                         ids=lambda c: "variant%d-gs%d-rc%d" % c)
+def test_lz4_experimental_decoders(gb, o, cfg):
+    """variant 2 (lz4_decompress_v3.hip, one lane per block) and variant 3 (lz4_decompress_v4.hip, uniform-step state machine
+    over lane groups): plaintext, status and error offsets equal the oracle's"""
     rng = np.random.default_rng(7)
     blocks = all_blocks()
     cases = [(o.compress("lz4", b), len(b)) for b in blocks] + [(o.compress("lz4", b), len(b) + 37) for b in blocks[:20]]
@@ -92,7 +94,7 @@ def test_lz4_lane_per_block_decoder(gb, o, ring_class):
             m = bytearray(c)
             m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
             cases.append((bytes(m), len(b)))
-    configure(gb, "lz4", (2, 4, ring_class))
+    configure(gb, "lz4", cfg)
     try:
         outs, status, err = gb.run(CODECS["lz4"]["d"], [c for c, _ in cases], [cap for _, cap in cases], unaligned=True)
     finally:

@@ -28,3 +28,7 @@ inline hipError_t hipGetLastError() { return 0; }
 inline void __syncthreads() {}
 inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
 template <typename T> inline T __shfl(T v, int) { return v; }
+
+// dynamic shared memory of the emulated launch: one arena, re-used by every "workgroup"
+static uint8_t hostemu_dynamic_lds[1 << 20] __attribute__((aligned(64)));
+inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
