@@ -15,7 +15,7 @@
 //     Complete 16-byte granules are flushed with one 16-byte store per lane; L2 assembles the 128-byte lines.
 // Positions are virtual (position + (address & 15)) so that granules are 16-byte aligned in memory.
 // No cross-lane operation is used anywhere: lanes may leave at any time, and the code runs unchanged on a CPU
-// one lane at a time (tools/hostemu), which is how it is checked against the oracle before it goes to the GPU.
+// one lane at a time (tools/hostemu), which is how the test suite checks it on a CPU before it goes to the GPU.
 #pragma once
 #include "achip_device.h"
 
