@@ -130,48 +130,15 @@ struct Rings {
     }
 
 
-    // c bytes (GS < c <= CHUNK) from virtual position sV of ring `src` to virtual position dV of the output ring:
-    // aligned destination dwords (<= 4 per lane, reads issued back to back so one LDS latency covers them all),
-    // <= 3 head and <= 3 tail bytes.  The source must not overlap the c destination bytes.
+    // c bytes (1 <= c <= CHUNK) from virtual position sV of ring `src` to virtual position dV of the output ring.  The
+    // <= 3 bytes up to the next destination dword go as bytes; from there every lane moves its CHUNK / GS bytes as
+    // aligned destination dwords WHATEVER c is -- what lands beyond dV + c is scratch space of the ring (LDS_REACH leaves
+    // CHUNK + 16 bytes for it) that the next move overwrites, so the move has no length-dependent predicates and no tail.
+    // The source must not overlap the c destination bytes.
     template <int SRC_RING>
     __device__ __forceinline__ void copy_dwords(const uint8_t* src, int32_t sV, int32_t dV, int32_t c)
     {
-        int32_t head = (4 - (dV & 3)) & 3;
-        head = head < c ? head : c;  // c may be shorter than the run-up to the next destination dword
-        const int32_t nd = (c - head) >> 2;
-        const int32_t t0 = head + 4 * nd;
-        constexpr int ITER = CHUNK / (4 * GS);  // = 4 * GPL
-        uint32_t w[ITER];
-#pragma unroll
-        for (int q = 0; q < ITER; q++) {
-            const int32_t j = g + GS * q;
-            w[q] = j < nd ? ring_ld4<SRC_RING>(src, sV + head + 4 * j) : 0u;
-        }
-        uint32_t hb = 0, tb = 0;
-        const bool hasHead = g < head, hasTail = t0 + g < c;
-        if (GS >= 4) {
-            if (hasHead) hb = src[(sV + g) & (SRC_RING - 1)];
-            if (hasTail) tb = src[(sV + t0 + g) & (SRC_RING - 1)];
-        }
-#pragma unroll
-        for (int q = 0; q < ITER; q++) {
-            const int32_t j = g + GS * q;
-            if (j < nd) {
-                *(uint32_t*)(outRing + ((dV + head + 4 * j) & (OUT_RING - 1))) = w[q];
-            }
-        }
-        if (GS >= 4) {
-            if (hasHead) outRing[(dV + g) & (OUT_RING - 1)] = (uint8_t)hb;
-            if (hasTail) outRing[(dV + t0 + g) & (OUT_RING - 1)] = (uint8_t)tb;
-        }
-        else {
-            for (int32_t k = g; k < head; k += GS) {
-                outRing[(dV + k) & (OUT_RING - 1)] = src[(sV + k) & (SRC_RING - 1)];
-            }
-            for (int32_t k = t0 + g; k < c; k += GS) {
-                outRing[(dV + k) & (OUT_RING - 1)] = src[(sV + k) & (SRC_RING - 1)];
-            }
-        }
+        copy_dwords_rt(src, SRC_RING - 1, sV, dV, c);
     }
 
     // Short copies (n <= 4*GS, source entirely before the destination): lane g moves bytes [4g, 4g+4) -- one unaligned
@@ -203,29 +170,27 @@ struct Rings {
     {
         int32_t head = (4 - (dV & 3)) & 3;
         head = head < c ? head : c;
-        const int32_t nd = (c - head) >> 2;
-        const int32_t t0 = head + 4 * nd;
         constexpr int ITER = CHUNK / (4 * GS);
         uint32_t w[ITER];
 #pragma unroll
         for (int q = 0; q < ITER; q++) {
-            const int32_t j = g + GS * q;
-            w[q] = j < nd ? ring_ld4_rt(src, mask, sV + head + 4 * j) : 0u;
+            w[q] = ring_ld4_rt(src, mask, sV + head + 4 * (g + GS * q));
+        }
+        uint32_t hb[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {  // head byte k is lane (k mod GS)'s
+            if ((k & (GS - 1)) == g && k < head) {
+                hb[k] = src[(sV + k) & mask];
+            }
         }
 #pragma unroll
         for (int q = 0; q < ITER; q++) {
-            const int32_t j = g + GS * q;
-            if (j < nd) {
-                *(uint32_t*)(outRing + ((dV + head + 4 * j) & (OUT_RING - 1))) = w[q];
-            }
+            *(uint32_t*)(outRing + ((dV + head + 4 * (g + GS * q)) & (OUT_RING - 1))) = w[q];
         }
-        // <= 3 head and <= 3 tail bytes (source and destination never overlap within one move)
-        for (int32_t i = g; i < 3; i += GS) {
-            if (i < head) {
-                outRing[(dV + i) & (OUT_RING - 1)] = src[(sV + i) & mask];
-            }
-            if (t0 + i < c) {
-                outRing[(dV + t0 + i) & (OUT_RING - 1)] = src[(sV + t0 + i) & mask];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if ((k & (GS - 1)) == g && k < head) {
+                outRing[(dV + k) & (OUT_RING - 1)] = (uint8_t)hb[k];
             }
         }
     }
