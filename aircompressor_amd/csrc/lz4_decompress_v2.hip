@@ -12,7 +12,7 @@ namespace achip {
 template <int GS, int IN_RING, int OUT_RING, int GPL>
 __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    ACHIP_DYNAMIC_LDS(smem);
     constexpr int GROUPS_PER_WG = 256 / GS;
     const int g = threadIdx.x & (GS - 1);
     const int grp = threadIdx.x / GS;
@@ -51,19 +51,26 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a)
     }
     else {
         const int32_t fastOutLimit = outLimit - 8;
+        // The 4-byte windows at the token and at the offset are read one phase early (the next token's before the match
+        // copy, the offset's before the literal copy) so that they travel with that copy's own LDS reads: two dependent
+        // LDS round trips fewer per sequence.
+        R.ensure_input(ip, 4);
+        uint32_t t4 = R.template ring_ld4<IN_RING>(R.inRing, ip + R.inBase);  // token and the 3 bytes after it
         while (ip < inLimit) {
-            R.ensure_input(ip, 4);
-            const int32_t token = (int32_t)R.in_u8(ip++);
+            const int32_t token = (int32_t)(t4 & 0xFF);
+            ip++;
 
             int32_t lit = token >> 4;  // :62-77
             if (lit == 0xF) {
                 if (ip >= inLimit) LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
-                int32_t v;
-                do {
+                int32_t v = (int32_t)((t4 >> 8) & 0xFF);  // first extension byte (resident: bytes past the input read as 0 and are not used)
+                ip++;
+                lit = (int32_t)((uint32_t)lit + (uint32_t)v);
+                while (v == 255 && ip < inLimit - 15) {
                     R.ensure_input(ip, 1);
                     v = (int32_t)R.in_u8(ip++);
                     lit = (int32_t)((uint32_t)lit + (uint32_t)v);
-                } while (v == 255 && ip < inLimit - 15);
+                }
             }
             if (lit < 0) LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
 
@@ -77,20 +84,32 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a)
                 break;
             }
 
+            uint32_t o4 = 0;
+            const bool early = lit + 3 <= Rings<GS, IN_RING, OUT_RING, GPL>::CHUNK;
+            if (early) {
+                R.ensure_input(ip, lit + 3);
+                o4 = R.template ring_ld4<IN_RING>(R.inRing, (int32_t)litEnd + R.inBase);
+            }
             R.copy_literals(ip, op, lit);  // :99-109
             op += lit;
             ip = (int32_t)litEnd;
 
-            R.ensure_input(ip, 3);
-            const int32_t offset = (int32_t)(R.in_u8(ip) | (R.in_u8(ip + 1) << 8));  // :113-119
+            if (!early) {
+                R.ensure_input(ip, 3);
+                o4 = R.template ring_ld4<IN_RING>(R.inRing, ip + R.inBase);  // offset and the first length-extension byte
+            }
+            const int32_t offset = (int32_t)(o4 & 0xFFFF);  // :113-119
             ip += 2;
             if (offset == 0 || offset > op) LZ4_FAIL(ACHIP_D_LZ4_OFFSET_OUTSIDE, ip);
 
             int32_t ml = token & 0xF;  // :122-138
             if (ml == 0xF) {
-                int32_t v;
+                if (ip > inLimit - 5) LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
+                int32_t v = (int32_t)((o4 >> 16) & 0xFF);
+                ip++;
+                ml = (int32_t)((uint32_t)ml + (uint32_t)v);
                 bool bad = false;
-                do {
+                while (v == 255) {
                     if (ip > inLimit - 5) {
                         bad = true;
                         break;
@@ -98,7 +117,7 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a)
                     R.ensure_input(ip, 1);
                     v = (int32_t)R.in_u8(ip++);
                     ml = (int32_t)((uint32_t)ml + (uint32_t)v);
-                } while (v == 255);
+                }
                 if (bad) LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
             }
             ml = (int32_t)((uint32_t)ml + 4u);
@@ -108,6 +127,8 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a)
             if (matchOutLimit > fastOutLimit - 4 && matchOutLimit > outLimit - 5) {  // :168-171
                 LZ4_FAIL(ACHIP_D_LZ4_LAST_5_LITERALS, ip);
             }
+            R.ensure_input(ip, 4);
+            t4 = R.template ring_ld4<IN_RING>(R.inRing, ip + R.inBase);  // the next token, ahead of the match copy
             R.copy_match(op, offset, ml);  // :146-194
             op = (int32_t)matchOutLimit;
         }

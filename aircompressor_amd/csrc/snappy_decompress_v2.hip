@@ -23,7 +23,7 @@ __device__ __forceinline__ int32_t snappy_op_entry2(int32_t op)  // opLookupTabl
 template <int GS, int IN_RING, int OUT_RING, int GPL>
 __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    ACHIP_DYNAMIC_LDS(smem);
     constexpr int GROUPS_PER_WG = 256 / GS;
     const int g = threadIdx.x & (GS - 1);
     const int grp = threadIdx.x / GS;

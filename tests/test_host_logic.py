@@ -43,10 +43,11 @@ def test_zstd_code_arithmetic_equals_the_java_tables():
         assert out.strip() == "0"
 
 
-def test_lane_per_block_lz4_decoder_source_on_the_cpu():
-    """lz4_decompress_v3.hip uses no cross-lane operation, so its kernel source can be compiled for the host and run one
-    lane at a time (tools/hostemu): plaintext, status, error offset and guard bands against the oracle -- the same cases
-    as the GPU parity suite, without a GPU."""
+def test_lane_private_decoder_kernels_on_the_cpu():
+    """Kernel instantiations without cross-lane traffic -- the lane-per-block LZ4 decoder (v3), and the one-lane-per-block
+    (GS = 1) instantiations of the default LZ4 / Snappy ring decoders (v2) and of the uniform-step LZ4 decoder (v4) -- are
+    compiled from the same .hip sources for the host and run one lane at a time (tools/hostemu): plaintext, status, error
+    offset and guard bands against the oracle, on the cases of the GPU parity suite, without a GPU."""
     import shutil
     import sys
     import pytest

@@ -4,6 +4,8 @@
 thread_local dim3 threadIdx, blockIdx, blockDim;
 #include "../../aircompressor_amd/csrc/lz4_decompress.hip"
 #include "../../aircompressor_amd/csrc/snappy_decompress.hip"
+#include "../../aircompressor_amd/csrc/lz4_decompress_v2.hip"
+#include "../../aircompressor_amd/csrc/snappy_decompress_v2.hip"
 #include "../../aircompressor_amd/csrc/lz4_decompress_v3.hip"
 #include "../../aircompressor_amd/csrc/lz4_decompress_v4.hip"
 extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, const int32_t* srcLen, uint8_t* dstBase, const int64_t* dstOff,
@@ -15,5 +17,13 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
     if (op == 10) return achip::launch_lz4_decompress_lanes(a, nullptr, 0);
     if (op == 11) return achip::launch_lz4_decompress_lanes(a, nullptr, 1);
     if (op == 14) return achip::launch_lz4_decompress_steps(a, nullptr, 1, 0);  // GS = 1: lane-private, exact when run one lane at a time
+    if (op == 16 || op == 17) {  // default ring decoders at GS = 1 (compact / large rings)
+        a.ringPad = 16;
+        return achip::launch_lz4_decompress_rings(a, nullptr, 1, op - 16);
+    }
+    if (op == 12 || op == 13) {
+        a.ringPad = 16;
+        return achip::launch_snappy_decompress_rings(a, nullptr, 1, op - 12);
+    }
     return -1;
 }
