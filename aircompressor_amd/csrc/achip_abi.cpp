@@ -23,9 +23,9 @@ hipError_t launch_lz4_decompress_steps(const BatchArgs& a, hipStream_t stream, i
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
 hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant);
-hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
+hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant, int32_t tileMax);
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
-int64_t zstd_decompress_scratch_bytes(int32_t nBlocks);
+int64_t zstd_decompress_scratch_bytes(int32_t nBlocks, int32_t tileMax);
 int64_t zstd_compress_scratch_bytes(int32_t nBlocks);
 }  // namespace achip
 
@@ -42,6 +42,7 @@ struct achip_ctx {
     int snappycVariant = 1;  // 0 = serial probes, 1 = 64 probes per step (batch)
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 0;
+    int zstdTile = 65536;    // items per pass of the Zstd decode pipeline (halved automatically when its scratch cannot be allocated)
     int ringPad = 80;        // 64 bytes of far-match staging + 16: consecutive blocks start on different LDS banks
     int scratchPoison = -1;
     int32_t lastZstddBlocks = 0;  // achip_ctx_get_stat
@@ -112,7 +113,12 @@ int32_t ensure_scratch(achip_ctx* ctx, int64_t bytes)
         ctx->scratch = nullptr;
         ctx->scratchBytes = 0;
     }
-    HIP_TRY(hipMalloc(&ctx->scratch, (size_t)bytes));
+    const hipError_t e = hipMalloc(&ctx->scratch, (size_t)bytes);
+    if (e != hipSuccess) {
+        ctx->scratch = nullptr;
+        (void)hipGetLastError();  // not sticky: the caller may retry with a smaller request
+        return device_failure("hipMalloc(scratch)", e);
+    }
     ctx->scratchBytes = bytes;
     return 0;
 }
@@ -170,9 +176,15 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             break;
         case ACHIP_OP_SNAPPY_COMPRESS: e = achip::launch_snappy_compress(a, ctx->stream, ctx->snappycVariant); break;
         case ACHIP_OP_ZSTD_DECOMPRESS: {
-            int32_t r = ensure_scratch(ctx, achip::zstd_decompress_scratch_bytes(a.nBlocks));
+            // pipeline scratch scales with the tile (items per pass, <= 65536: ~17 GB); when the device cannot give that much,
+            // smaller tiles are tried before giving up (the one-kernel decoder's 270 MB are always part of it)
+            int32_t r = ensure_scratch(ctx, achip::zstd_decompress_scratch_bytes(a.nBlocks, ctx->zstdTile));
+            while (r < 0 && ctx->zstdTile > 1024 && ctx->zstdTile >= a.nBlocks / 64) {
+                ctx->zstdTile /= 2;
+                r = ensure_scratch(ctx, achip::zstd_decompress_scratch_bytes(a.nBlocks, ctx->zstdTile));
+            }
             if (r < 0) return r;
-            e = achip::launch_zstd_decompress(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->zstddVariant);
+            e = achip::launch_zstd_decompress(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->zstddVariant, ctx->zstdTile);
             ctx->lastZstddBlocks = a.nBlocks;
             ctx->lastZstddVariant = ctx->zstddVariant;
             break;
@@ -424,6 +436,10 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     else if (k == "decompress.ring_pad") {
         if (value < 0 || value > 256 || (value & 15) != 0) return bad_argument("ring pad must be a multiple of 16 in 0..256");
         ctx->ringPad = (int)value;
+    }
+    else if (k == "zstd.decompress.tile") {
+        if (value < 64 || value > 65536) return bad_argument("tile must be in 64..65536");
+        ctx->zstdTile = (int)value;
     }
     else if (k == "debug.scratch_poison") ctx->scratchPoison = (int)value;
     else if (k == "zstd.decompress.variant") ctx->zstddVariant = (int)value;

@@ -699,11 +699,11 @@ constexpr int ZD_MAX_WAVES = 256 * 8;  // persistent waves: 8 per CU
 // scratch of the one-kernel decoder: [item counter | predefined tables | one literal slab per persistent wave]
 int64_t zstd_decompress_general_scratch_bytes() { return 4096 + (int64_t)sizeof(zd::FseTable) * 3 + (int64_t)ZD_MAX_WAVES * zd::LIT_SLAB; }
 
-int64_t zstd_decompress_pipe_scratch_bytes(int32_t nBlocks);
-hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, void* scratch, void* generalScratch);
-void* zstd_decompress_pipe_general_scratch(void* scratch, int32_t nBlocks);
+int64_t zstd_decompress_pipe_scratch_bytes(int32_t nBlocks, int32_t tileMax);
+hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, void* scratch, void* generalScratch, int32_t tileMax);
+void* zstd_decompress_pipe_general_scratch(void* scratch, int32_t nBlocks, int32_t tileMax);
 
-int64_t zstd_decompress_scratch_bytes(int32_t nBlocks) { return zstd_decompress_pipe_scratch_bytes(nBlocks); }
+int64_t zstd_decompress_scratch_bytes(int32_t nBlocks, int32_t tileMax) { return zstd_decompress_pipe_scratch_bytes(nBlocks, tileMax); }
 
 // resets the item counter and builds the predefined FSE tables; returns them through *dflt
 hipError_t launch_zstd_decompress_prepare(hipStream_t stream, void* generalScratch, const zd::FseTable** dflt)
@@ -727,20 +727,20 @@ hipError_t launch_zstd_decompress_list(const BatchArgs& a, hipStream_t stream, v
 }
 
 // variant 1 (default): five-stage pipeline + one-kernel decoder for whatever it hands back; variant 0: one-kernel decoder only
-hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant)
+hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant, int32_t tileMax)
 {
     (void)scratchBytes;
     if (a.nBlocks <= 0) {
         return hipSuccess;
     }
-    void* general = zstd_decompress_pipe_general_scratch(scratch, a.nBlocks);
+    void* general = zstd_decompress_pipe_general_scratch(scratch, a.nBlocks, tileMax);
     if (variant == 0) {
         const zd::FseTable* dflt = nullptr;
         hipError_t e = launch_zstd_decompress_prepare(stream, general, &dflt);
         if (e != hipSuccess) return e;
         return launch_zstd_decompress_list(a, stream, general, nullptr, nullptr);
     }
-    return launch_zstd_decompress_pipe(a, stream, scratch, general);
+    return launch_zstd_decompress_pipe(a, stream, scratch, general, tileMax);
 }
 
 }  // namespace achip

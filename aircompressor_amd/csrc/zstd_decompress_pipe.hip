@@ -942,7 +942,7 @@ hipError_t launch_zstd_decompress_list(const BatchArgs& a, hipStream_t stream, v
 int64_t zstd_decompress_general_scratch_bytes();
 
 namespace {
-constexpr int32_t PIPE_TILE = 65536;              // items per pass through the five stages (K4 wants >= 64 Ki items in flight: 16 per wavefront)
+constexpr int32_t PIPE_TILE_DEFAULT = 65536;              // items per pass through the five stages (K4 wants >= 64 Ki items in flight: 16 per wavefront)
 constexpr uint32_t PIPE_LIT_PER_ITEM = 80 * 1024 / 64;   // literal arena: average 64-byte units per item ...
 constexpr uint32_t PIPE_LIT_FLOOR = 16 * (zp::LIT_STRIDE / 64 + 1);  // ... plus 16 blocks of the maximum size
 constexpr uint32_t PIPE_SEQ_PER_ITEM = 20480;     // sequence arena: average records per item (text: 10-16 K per 128 KiB block) ...
@@ -951,8 +951,9 @@ struct PipeLayout {
     int64_t counters, fallback, desc, huf, fse, lit, seq, general, total;
     int32_t tile;
 };
-PipeLayout pipe_layout(int32_t nBlocks)
+PipeLayout pipe_layout(int32_t nBlocks, int32_t tileMax)
 {
+    const int32_t PIPE_TILE = tileMax > 0 ? tileMax : PIPE_TILE_DEFAULT;
     PipeLayout L;
     L.tile = nBlocks < PIPE_TILE ? nBlocks : PIPE_TILE;
     auto up = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
@@ -978,12 +979,12 @@ PipeLayout pipe_layout(int32_t nBlocks)
 }
 }  // namespace
 
-int64_t zstd_decompress_pipe_scratch_bytes(int32_t nBlocks) { return pipe_layout(nBlocks).total; }
-void* zstd_decompress_pipe_general_scratch(void* scratch, int32_t nBlocks) { return (uint8_t*)scratch + pipe_layout(nBlocks).general; }
+int64_t zstd_decompress_pipe_scratch_bytes(int32_t nBlocks, int32_t tileMax) { return pipe_layout(nBlocks, tileMax).total; }
+void* zstd_decompress_pipe_general_scratch(void* scratch, int32_t nBlocks, int32_t tileMax) { return (uint8_t*)scratch + pipe_layout(nBlocks, tileMax).general; }
 
-hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, void* scratch, void* generalScratch)
+hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, void* scratch, void* generalScratch, int32_t tileMax)
 {
-    const PipeLayout L = pipe_layout(a.nBlocks);
+    const PipeLayout L = pipe_layout(a.nBlocks, tileMax);
     uint8_t* base = (uint8_t*)scratch;
     const zd::FseTable* dflt = nullptr;
     {

@@ -120,6 +120,19 @@ def test_multi_block_frames_and_concatenated_frames(gbd, o):
     assert o.decompress("zstd", cat, len(plain_cat)) == plain_cat
 
 
+def test_pipeline_small_tiles(o):
+    """a batch larger than the pipeline's tile goes through it in several passes (here: tiles of 64 items)"""
+    from tests.gpu_harness import GpuBatch
+    g = GpuBatch(0, options={"zstd.decompress.tile": 64})
+    blocks = [b for b in plain_blocks() if 0 < len(b) <= 131072]
+    blocks = (blocks * 6)[:300]
+    frames = zstd_frames(blocks, 3)
+    outs, status, err = g.run(OP_ZSTD_DECOMPRESS, frames, [len(b) for b in blocks])
+    assert all(s == 0 for s in status), status
+    assert outs == blocks
+    assert g.codec.native.get_stat("zstd.decompress.fallback_items") <= 6 * 12  # only the raw-block / tiny frames
+
+
 def test_single_block_host_api(o):
     import aircompressor_amd as A
     z1, p1 = common.golden_zstd("with-checksum.zst"), common.golden_zstd("with-checksum")
