@@ -446,78 +446,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_parse_kernel(BatchArgs a, zp::Pi
     }
 }
 
-// ---- K2: literals ----
-__global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp::Pipe p)
-{
-    using namespace zp;
-    __shared__ __attribute__((aligned(16))) uint16_t tables[ITEMS_PER_WAVE * HUF_SLOT];  // 64 KiB
-    const int lane = threadIdx.x;
-    const int q = lane >> 2;  // item of this lane
-    const int s = lane & 3;   // stream of this lane
-    const int32_t slot = blockIdx.x * ITEMS_PER_WAVE + q;
-    const bool valid = slot < p.count;
-    Desc d;
-    d.state = 0;
-    if (valid) {
-        d = p.desc[slot];
-    }
-    const bool live = valid && d.state == 1;
-    // stage the 16 tables (each copy is done by the whole wavefront)
-    for (int k = 0; k < ITEMS_PER_WAVE; k++) {
-        const int32_t useHuf = __shfl((live && d.litMode == 2) ? d.hufLog : 0, k * 4);
-        if (useHuf > 0) {
-            const uint16_t* g = p.huf + (size_t)(blockIdx.x * ITEMS_PER_WAVE + k) * HUF_SLOT;
-            for (int32_t i = lane * 8; i < (1 << useHuf); i += 64 * 8) {
-                *(u32x4*)(tables + k * HUF_SLOT + i) = *(const u32x4*)(g + i);
-            }
-        }
-    }
-    __syncthreads();
-    int32_t bad = 0;
-    if (live && d.litMode != 0) {
-        const int32_t block = p.first + slot;
-        uint8_t* lit = p.lit + (size_t)d.litBase * 64;
-        if (d.litMode == 1) {
-            const uint32_t v = (uint32_t)(d.litSrc & 0xFF) * 0x01010101u;
-            const u32x4 vv = {v, v, v, v};
-            for (int32_t i = s * 16; i < d.litSize; i += 64) {
-                *(u32x4*)(lit + i) = vv;  // the slab has 64 bytes of slack
-            }
-        }
-        else if (s < d.nStreams) {
-            Ctx c;
-            c.in = a.srcBase + a.srcOff[block];
-            c.inLen = a.srcLen[block];
-            c.out = nullptr;
-            c.outCap = 0;
-            c.lit = lit;
-            c.R = nullptr;
-            c.lane = lane;
-            c.detail = 0;
-            c.errOff = 0;
-            const int32_t seg = (d.litSize + 3) / 4;
-            const int32_t oStart = d.nStreams == 1 ? 0 : s * seg;
-            const int32_t oEnd = d.nStreams == 1 ? d.litSize : (s == 3 ? d.litSize : (s + 1) * seg);
-            Bits b;
-            int32_t eo = 0;
-            const int32_t myStart = s == 0 ? d.sStart[0] : (s == 1 ? d.sStart[1] : (s == 2 ? d.sStart[2] : d.sStart[3]));
-            const int32_t myEnd = s == 0 ? d.sEnd[0] : (s == 1 ? d.sEnd[1] : (s == 2 ? d.sEnd[2] : d.sEnd[3]));
-            if (bit_init(c, b, myStart, myEnd, &eo) != 0 || oStart > oEnd) {
-                bad = 1;
-            }
-            else if (huf_decode_stream(c, tables + q * HUF_SLOT, d.hufLog, b, lit, oStart, oEnd) != 0) {
-                bad = 1;
-            }
-        }
-    }
-    // any failing stream sends the whole item to the fallback list
-    const unsigned long long badMask = __ballot(bad != 0);
-    if (live && s == 0 && ((badMask >> (q * 4)) & 0xFull) != 0) {
-        to_fallback(p, slot, 2);
-    }
-}
-
-// ---- K3: sequences ----
+// ---- shared by K2 and K3: the backward bit reader, and K3's quad broadcasts ----
 // One item per QUAD of lanes: lane 0 owns the literal-length state, lane 1 the match-length state, lane 2 the offset
 // state, lane 3 assembles and stores the record.  The three table lookups, the code -> (baseline, extra bits)
 // conversions and the six bit-field extractions of a sequence run side by side; the fields' bit positions are a
@@ -586,6 +515,14 @@ struct QuadBits {
         bits = sh == 0 ? A : (sh == 64 ? B : mid);
         return over;
     }
+    // Loader.load with its return value (true: nothing more can be loaded -- overflow, already at the start, or the move
+    // was cut short at the start of the stream)
+    __device__ __forceinline__ bool load_java()
+    {
+        const bool stop = consumed > 64 || current == start || current - (int32_t)((uint32_t)consumed >> 3) < start;
+        load();
+        return stop;
+    }
     // BitInputStream.peekBits :64-67 for n <= 31, on 32-bit lanes after the one 64-bit alignment shift
     __device__ __forceinline__ int32_t peek(int32_t at, int32_t n) const
     {
@@ -594,6 +531,109 @@ struct QuadBits {
     }
 };
 
+// One Huffman stream (Huffman.decodeSingleStream :130-164 body + decodeTail :291-317) decoded by the calling lane through
+// the windowed reader: same loads, symbols and end-of-stream test as zd::huf_decode_stream.
+__device__ __forceinline__ bool huf_decode_stream_win(QuadBits& b, const uint16_t* huf, int32_t tableLog, uint8_t* out, int32_t output, int32_t outputLimit)
+{
+    const int32_t fastLimit = outputLimit - 4;
+    bool done = false;
+    while (output < fastLimit) {
+        if (b.load_java()) {
+            done = true;
+            break;
+        }
+        uint32_t w = (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed);
+        w |= (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed) << 8;
+        w |= (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed) << 16;
+        w |= (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed) << 24;
+        st4(out + output, w);
+        output += 4;
+    }
+    if (!done) {
+        while (output < outputLimit) {
+            if (b.load_java()) {
+                break;
+            }
+            out[output++] = (uint8_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed);
+        }
+    }
+    while (output < outputLimit) {
+        out[output++] = (uint8_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed);
+    }
+    return b.start == b.current && b.consumed == 64;
+}
+
+// ---- K2: literals ----
+__global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp::Pipe p)
+{
+    using namespace zp;
+    __shared__ __attribute__((aligned(16))) uint16_t tables[ITEMS_PER_WAVE * HUF_SLOT];  // 64 KiB
+    const int lane = threadIdx.x;
+    const int q = lane >> 2;  // item of this lane
+    const int s = lane & 3;   // stream of this lane
+    const int32_t slot = blockIdx.x * ITEMS_PER_WAVE + q;
+    const bool valid = slot < p.count;
+    Desc d;
+    d.state = 0;
+    if (valid) {
+        d = p.desc[slot];
+    }
+    const bool live = valid && d.state == 1;
+    // stage the 16 tables (each copy is done by the whole wavefront)
+    for (int k = 0; k < ITEMS_PER_WAVE; k++) {
+        const int32_t useHuf = __shfl((live && d.litMode == 2) ? d.hufLog : 0, k * 4);
+        if (useHuf > 0) {
+            const uint16_t* g = p.huf + (size_t)(blockIdx.x * ITEMS_PER_WAVE + k) * HUF_SLOT;
+            for (int32_t i = lane * 8; i < (1 << useHuf); i += 64 * 8) {
+                *(u32x4*)(tables + k * HUF_SLOT + i) = *(const u32x4*)(g + i);
+            }
+        }
+    }
+    __syncthreads();
+    int32_t bad = 0;
+    if (live && d.litMode != 0) {
+        const int32_t block = p.first + slot;
+        uint8_t* lit = p.lit + (size_t)d.litBase * 64;
+        if (d.litMode == 1) {
+            const uint32_t v = (uint32_t)(d.litSrc & 0xFF) * 0x01010101u;
+            const u32x4 vv = {v, v, v, v};
+            for (int32_t i = s * 16; i < d.litSize; i += 64) {
+                *(u32x4*)(lit + i) = vv;  // the slab has 64 bytes of slack
+            }
+        }
+        else if (s < d.nStreams) {
+            Ctx c;
+            c.in = a.srcBase + a.srcOff[block];
+            c.inLen = a.srcLen[block];
+            c.out = nullptr;
+            c.outCap = 0;
+            c.lit = lit;
+            c.R = nullptr;
+            c.lane = lane;
+            c.detail = 0;
+            c.errOff = 0;
+            const int32_t seg = (d.litSize + 3) / 4;
+            const int32_t oStart = d.nStreams == 1 ? 0 : s * seg;
+            const int32_t oEnd = d.nStreams == 1 ? d.litSize : (s == 3 ? d.litSize : (s + 1) * seg);
+            const int32_t myStart = s == 0 ? d.sStart[0] : (s == 1 ? d.sStart[1] : (s == 2 ? d.sStart[2] : d.sStart[3]));
+            const int32_t myEnd = s == 0 ? d.sEnd[0] : (s == 1 ? d.sEnd[1] : (s == 2 ? d.sEnd[2] : d.sEnd[3]));
+            QuadBits b;
+            if (!b.init(c.in, myStart, myEnd) || oStart > oEnd) {
+                bad = 1;
+            }
+            else if (!huf_decode_stream_win(b, tables + q * HUF_SLOT, d.hufLog, lit, oStart, oEnd)) {
+                bad = 1;
+            }
+        }
+    }
+    // any failing stream sends the whole item to the fallback list
+    const unsigned long long badMask = __ballot(bad != 0);
+    if (live && s == 0 && ((badMask >> (q * 4)) & 0xFull) != 0) {
+        to_fallback(p, slot, 2);
+    }
+}
+
+// ---- K3: sequences ----
 __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp::Pipe p)
 {
     using namespace zp;
