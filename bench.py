@@ -46,6 +46,7 @@ def parse_args():
     p.add_argument("--group", type=int, default=0, help="decoder lanes per block (0 = library default)")
     p.add_argument("--variant", type=int, default=-1, help="decoder variant: 1 = LDS rings (default), 0 = direct-to-HBM groups")
     p.add_argument("--ring-class", type=int, default=-1, help="0 = compact LDS rings, 1 = large")
+    p.add_argument("--compress-variant", type=int, default=-1, help="LZ4 / Snappy encoder variant (see lz4.compress.variant)")
     p.add_argument("--ring-pad", type=int, default=-1, help="LDS bytes between the ring pairs of consecutive blocks (multiple of 16)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true")
@@ -142,6 +143,10 @@ def main():
         codec.native.set_option("snappy.decompress.variant", args.variant)
     if args.ring_class >= 0:
         codec.native.set_option("decompress.ring_class", args.ring_class)
+    if args.compress_variant >= 0:
+        codec.native.set_option("lz4.compress.variant", args.compress_variant)
+        if args.compress_variant <= 1:
+            codec.native.set_option("snappy.compress.variant", args.compress_variant)
     if args.ring_pad >= 0:
         codec.native.set_option("decompress.ring_pad", args.ring_pad)
     codec.native.set_option("max_src_len_hint", bs)
