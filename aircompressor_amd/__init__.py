@@ -16,12 +16,13 @@ from .codecs import (
     ZstdHipCompressor,
     ZstdHipDecompressor,
 )
+from .xxhash import XxHash32HipHasher, XxHash64HipHasher
 from .sharding import shard_for_rank, aggregate_throughput
 from .batch import HipBatchCodec, OP_LZ4_DECOMPRESS, OP_LZ4_COMPRESS, OP_SNAPPY_DECOMPRESS, OP_SNAPPY_COMPRESS, OP_ZSTD_DECOMPRESS, OP_ZSTD_COMPRESS, partition_blocks
 
 __all__ = [
     "IllegalArgumentException", "MalformedInputException", "HipUnavailableError", "HipNative", "load_library",
     "Compressor", "Decompressor", "Lz4HipCompressor", "Lz4HipDecompressor", "SnappyHipCompressor", "SnappyHipDecompressor",
-    "ZstdHipCompressor", "ZstdHipDecompressor", "HipBatchCodec", "partition_blocks", "shard_for_rank", "aggregate_throughput",
+    "ZstdHipCompressor", "ZstdHipDecompressor", "XxHash32HipHasher", "XxHash64HipHasher", "HipBatchCodec", "partition_blocks", "shard_for_rank", "aggregate_throughput",
     "OP_LZ4_DECOMPRESS", "OP_LZ4_COMPRESS", "OP_SNAPPY_DECOMPRESS", "OP_SNAPPY_COMPRESS", "OP_ZSTD_DECOMPRESS", "OP_ZSTD_COMPRESS",
 ]

@@ -27,6 +27,8 @@ hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* 
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
 int64_t zstd_decompress_scratch_bytes(int32_t nBlocks, int32_t tileMax);
 int64_t zstd_compress_scratch_bytes(int32_t nBlocks);
+hipError_t launch_xxh64_batch(const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int32_t n, uint64_t seed, int64_t* out, hipStream_t stream);
+hipError_t launch_xxh32_batch(const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int32_t n, uint32_t seed, int32_t* out, hipStream_t stream);
 }  // namespace achip
 
 struct achip_ctx {
@@ -572,6 +574,75 @@ ACHIP_DEFINE_BATCH(achip_snappy_decompress_batch, ACHIP_OP_SNAPPY_DECOMPRESS)
 ACHIP_DEFINE_BATCH(achip_snappy_compress_batch, ACHIP_OP_SNAPPY_COMPRESS)
 ACHIP_DEFINE_BATCH(achip_zstd_decompress_batch, ACHIP_OP_ZSTD_DECOMPRESS)
 ACHIP_DEFINE_BATCH(achip_zstd_compress_batch, ACHIP_OP_ZSTD_COMPRESS)
+
+// ---- xxhash -------------------------------------------
+int32_t achip_xxhash64_batch(achip_ctx* ctx, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int64_t seed, int64_t* outHash, int32_t nBuffers)
+{
+    if (!ctx) return bad_argument("ctx is null");
+    if (nBuffers < 0) return bad_argument("nBuffers < 0");
+    if (nBuffers == 0) return 0;
+    if (!srcOff || !srcLen || !outHash) return bad_argument("null array");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(achip::launch_xxh64_batch(srcBase, srcOff, srcLen, nBuffers, (uint64_t)seed, outHash, ctx->stream));
+    return 0;
+}
+
+int32_t achip_xxhash32_batch(achip_ctx* ctx, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int32_t seed, int32_t* outHash, int32_t nBuffers)
+{
+    if (!ctx) return bad_argument("ctx is null");
+    if (nBuffers < 0) return bad_argument("nBuffers < 0");
+    if (nBuffers == 0) return 0;
+    if (!srcOff || !srcLen || !outHash) return bad_argument("null array");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(achip::launch_xxh32_batch(srcBase, srcOff, srcLen, nBuffers, (uint32_t)seed, outHash, ctx->stream));
+    return 0;
+}
+
+namespace {
+// one host buffer: staged to the device, hashed there, 8 bytes back
+int32_t hash_host(achip_ctx* ctx, const void* src, int64_t srcLen, int64_t seed, bool wide, int64_t* out)
+{
+    if (!ctx) return bad_argument("ctx is null");
+    if (srcLen < 0 || srcLen > 0x7FFFFFFF) return bad_argument("length out of range");
+    if (srcLen > 0 && !src) return bad_argument("src is null");
+    const int64_t metaOff = (srcLen + 63) & ~63LL;
+    int32_t r = ensure_stage(ctx, metaOff + 64);
+    if (r < 0) return r;
+    uint8_t* h = ctx->hostStage;
+    uint8_t* d = ctx->devStage;
+    if (srcLen > 0) memcpy(h, src, (size_t)srcLen);
+    *(int64_t*)(h + metaOff) = 0;                      // srcOff
+    *(int32_t*)(h + metaOff + 8) = (int32_t)srcLen;    // srcLen
+    *(int64_t*)(h + metaOff + 16) = 0;                 // result
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(d, h, (size_t)(metaOff + 64), hipMemcpyHostToDevice, ctx->stream));
+    if (wide) {
+        HIP_TRY(achip::launch_xxh64_batch(d, (const int64_t*)(d + metaOff), (const int32_t*)(d + metaOff + 8), 1, (uint64_t)seed, (int64_t*)(d + metaOff + 16), ctx->stream));
+    }
+    else {
+        HIP_TRY(achip::launch_xxh32_batch(d, (const int64_t*)(d + metaOff), (const int32_t*)(d + metaOff + 8), 1, (uint32_t)seed, (int32_t*)(d + metaOff + 16), ctx->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(h + metaOff + 16, d + metaOff + 16, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = *(int64_t*)(h + metaOff + 16);
+    return 0;
+}
+}  // namespace
+
+int32_t achip_xxhash64(achip_ctx* ctx, const void* src, int64_t srcLen, int64_t seed, int64_t* outHash)
+{
+    if (!outHash) return bad_argument("outHash is null");
+    return hash_host(ctx, src, srcLen, seed, true, outHash);
+}
+
+int32_t achip_xxhash32(achip_ctx* ctx, const void* src, int64_t srcLen, int32_t seed, int32_t* outHash)
+{
+    if (!outHash) return bad_argument("outHash is null");
+    int64_t v = 0;
+    const int32_t r = hash_host(ctx, src, srcLen, seed, false, &v);
+    *outHash = (int32_t)v;
+    return r;
+}
 
 // ---- host-pointer batch: stage in, run, stage out ------------------------
 int32_t achip_batch_host(int32_t codecOp, ACHIP_BATCH_ARGS)

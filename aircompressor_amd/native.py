@@ -35,6 +35,10 @@ SIGNATURES = {
     "achip_ctx_synchronize": (_i32, [_vp]),
     "achip_ctx_set_option": (_i32, [_vp, ctypes.c_char_p, _i64]),
     "achip_ctx_get_stat": (_i64, [_vp, ctypes.c_char_p]),
+    "achip_xxhash64_batch": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i32]),
+    "achip_xxhash32_batch": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _i32]),
+    "achip_xxhash64": (_i32, [_vp, _vp, _i64, _i64, _vp]),
+    "achip_xxhash32": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "achip_device_alloc": (_vp, [_vp, _i64]),
     "achip_device_free": (_i32, [_vp, _vp]),
     "achip_host_alloc_pinned": (_vp, [_i64]),

@@ -51,7 +51,7 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
-    p.add_argument("--section", default="all", choices=["all", "zstd"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
+    p.add_argument("--section", default="all", choices=["all", "zstd", "xxhash"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-variant", type=int, default=-1, help="zstd decoder: 1 = five-stage pipeline (default), 0 = one-kernel decoder")
     return p.parse_args()
 
@@ -150,6 +150,9 @@ def main():
     if args.ring_pad >= 0:
         codec.native.set_option("decompress.ring_pad", args.ring_pad)
     codec.native.set_option("max_src_len_hint", bs)
+    if args.section == "xxhash":
+        print(json.dumps(xxhash_extra(torch, A, codec, torch.device("cuda", local_rank), args)), flush=True)
+        return
     if args.section == "zstd":
         print(json.dumps(zstd_extra(torch, A, codec, torch.device("cuda", local_rank), args)), flush=True)
         return
@@ -296,6 +299,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extra:
         result["extra"] = extras(torch, A, codec, dev, args)
+        result["extra"].update(xxhash_extra(torch, A, codec, dev, args))
         try:
             result["extra"].update(zstd_extra(torch, A, codec, dev, args))
         except ImportError:
@@ -357,6 +361,37 @@ def extras(torch, A, codec, dev, args):
                 "blocks": n,
             }
             del comp, back
+    return out
+
+
+def xxhash_extra(torch, A, codec, dev, args):
+    """batched XXH64 / XXH32 of 65536 x 64 KiB device-resident buffers (read-once, HBM-bound)."""
+    out = {}
+    bs, n = args.block_size, 65536
+    data = gen_fragments(torch, dev, n, bs, args.ratio, 555)
+    off = torch.arange(n, dtype=torch.int64, device=dev) * bs
+    ln = torch.full((n,), bs, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for name, Hasher, dt in (("xxh64", A.XxHash64HipHasher, torch.int64), ("xxh32", A.XxHash32HipHasher, torch.int32)):
+        h = Hasher(native_ctx=codec.native)
+        res = torch.zeros(n, dtype=dt, device=dev)
+        h.hash_batch(data, off, ln, res, n, seed=7)
+        codec.synchronize()
+        e0, e1 = codec.event(), codec.event()
+        codec.record(e0)
+        for _ in range(5):
+            h.hash_batch(data, off, ln, res, n, seed=7)
+        codec.record(e1)
+        t = codec.elapsed_ms(e0, e1) / 5 * 1e-3
+        # spot check against the third-party xxhash module when it is there (the parity tests use the oracle)
+        try:
+            import xxhash
+            b0 = data[:bs].cpu().numpy().tobytes()
+            want = xxhash.xxh64(b0, seed=7).intdigest() if name == "xxh64" else xxhash.xxh32(b0, seed=7).intdigest()
+            assert int(res[0].item()) & ((1 << (64 if name == "xxh64" else 32)) - 1) == want
+        except ImportError:
+            pass
+        out[name] = {"GiBps": round(n * bs / t / 2**30, 2), "hbm_frac": round(n * bs / t / 1e9 / HBM_PEAK_GBS, 4), "buffers": n, "buffer_bytes": bs}
     return out
 
 

@@ -201,6 +201,17 @@ int32_t achip_snappy_decompress(achip_ctx* ctx, const void* src, void* dst, int3
 int32_t achip_zstd_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
 int32_t achip_zstd_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
 
+/* ---- xxhash: batched XXH64 / XXH32 of device-resident buffers ----
+ * Replace XxHash64Hasher.hash(MemorySegment input, long seed)   M/xxhash/XxHash64Hasher.java:78-86  (-> XxHash64JavaHasher.java:126)
+ *     and XxHash32Hasher.hash(MemorySegment input, int seed)    M/xxhash/XxHash32Hasher.java       (-> XxHash32JavaHasher.java:112)
+ * for nBuffers buffers per call: buffer i = srcBase + srcOff[i], srcLen[i] bytes; outHash[i] receives the hash
+ * (all arrays device memory; asynchronous on the context's stream).  Returns 0 or a negative status. */
+int32_t achip_xxhash64_batch(achip_ctx* ctx, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int64_t seed, int64_t* outHash, int32_t nBuffers);
+int32_t achip_xxhash32_batch(achip_ctx* ctx, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int32_t seed, int32_t* outHash, int32_t nBuffers);
+/* one HOST buffer (staged through the context's pinned buffer; synchronous): the one-shot form of the same two methods */
+int32_t achip_xxhash64(achip_ctx* ctx, const void* src, int64_t srcLen, int64_t seed, int64_t* outHash);
+int32_t achip_xxhash32(achip_ctx* ctx, const void* src, int64_t srcLen, int32_t seed, int32_t* outHash);
+
 /* Host-pointer batch: nBlocks independent blocks described by HOST arrays of HOST
  * pointers' offsets relative to srcBase/dstBase (host).  Stages in, launches the
  * device batch for `codecOp`, stages out, synchronizes.  codecOp: see below. */

@@ -47,6 +47,9 @@ int32_t orc_zstd_read_frame_header(const uint8_t* in, int64_t in_len, int64_t* o
 /* XXH64 -- M/zstd/XxHash64.java:182-291 */
 uint64_t orc_xxh64(const uint8_t* in, int64_t len, uint64_t seed);
 
+/* XXH32 -- M/xxhash/XxHash32JavaHasher.java:68-110,343-366 (public xxhash package; LZ4 frame checksums) */
+uint32_t orc_xxh32(const uint8_t* in, int64_t len, uint32_t seed);
+
 /* Synthetic data: the reference's test generator -- T/snappy/RandomGenerator.java:25-74 on java.util.Random(301) */
 void orc_random_generator(double compression_ratio, uint8_t* out, int64_t len);
 

@@ -42,6 +42,8 @@ class Oracle:
             getattr(lib, name).argtypes = [u8p, i64, ctypes.POINTER(i64)]
         lib.orc_xxh64.restype = ctypes.c_uint64
         lib.orc_xxh64.argtypes = [u8p, i64, ctypes.c_uint64]
+        lib.orc_xxh32.restype = ctypes.c_uint32
+        lib.orc_xxh32.argtypes = [u8p, i64, ctypes.c_uint32]
         lib.orc_random_generator.restype = None
         lib.orc_random_generator.argtypes = [ctypes.c_double, u8p, i64]
         lib.orc_batch.restype = i64
@@ -76,6 +78,10 @@ class Oracle:
         if r < 0:
             raise OracleError(r, eo.value)
         return dst[:r].tobytes()
+
+    def xxh32(self, data, seed=0):
+        src = np.frombuffer(bytes(data), dtype=np.uint8)
+        return self.lib.orc_xxh32(src.ctypes.data if len(src) else None, len(src), seed & 0xFFFFFFFF)
 
     def xxh64(self, data, seed=0):
         src = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))

@@ -97,6 +97,19 @@ def test_xxh64_kats(o):
         assert o.xxh64(bytes(buf[:n]), seed) == expected, (seed, n)
 
 
+def test_xxh32_kats_and_python_xxhash(o):
+    """T/xxhash/TestXxHash32.java:45-46 pins the two values; the third-party `xxhash` module checks every length class and
+    the seeds of T/xxhash/TestXxHash32.java:30"""
+    assert o.xxh32(b"", 0) == 0x02CC5D05
+    assert o.xxh32(b"abc", 0) == 0x32D153FF
+    xxhash = pytest.importorskip("xxhash")
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 256, size=5000, dtype=np.uint8).tobytes()
+    for seed in (0, 1, 0x9E3779B1, 0xFFFFFFFF, 0x7FFFFFFF, 0x80000000):
+        for n in list(range(0, 70)) + [255, 256, 1023, 4096, 5000]:
+            assert o.xxh32(data[:n], seed) == xxhash.xxh32(data[:n], seed=seed).intdigest(), (n, seed)
+
+
 def test_xxh64_vs_python_xxhash(o):
     xxhash = pytest.importorskip("xxhash")
     rng = np.random.default_rng(7)
