@@ -25,6 +25,7 @@
 // M/zstd/XxHash64.java:182-291.
 #include "zstd_dec_common.h"
 #include "zstd_codes.h"
+#include "achip_xxhash.h"
 
 namespace achip {
 
@@ -915,55 +916,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_checksum_kernel(BatchArgs a, zp:
     const int32_t block = p.first + slot;
     const uint8_t* out = a.dstBase + a.dstOff[block];
     const int32_t len = d.outSize;
-    constexpr uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
-    auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
-    auto mix = [&](uint64_t cur, uint64_t v) { return rotl(cur + v * P2, 31) * P1; };
-    uint64_t hash;
-    if (len >= 32) {  // XxHash64.java:182-291, accumulator s of the item on this lane
-        uint64_t v = s == 0 ? P1 + P2 : (s == 1 ? P2 : (s == 2 ? 0 : (0 - P1)));
-        const int32_t stripes = len >> 5;
-        const uint8_t* ptr = out + s * 8;
-        int32_t k = 0;
-        for (; k + 4 <= stripes; k += 4) {
-            const uint64_t x0 = ld8(ptr + (int64_t)k * 32), x1 = ld8(ptr + (int64_t)k * 32 + 32), x2 = ld8(ptr + (int64_t)k * 32 + 64), x3 = ld8(ptr + (int64_t)k * 32 + 96);
-            v = mix(v, x0);
-            v = mix(v, x1);
-            v = mix(v, x2);
-            v = mix(v, x3);
-        }
-        for (; k < stripes; k++) {
-            v = mix(v, ld8(ptr + (int64_t)k * 32));
-        }
-        const int base = lane - s;
-        const uint64_t v1 = __shfl(v, base), v2 = __shfl(v, base + 1), v3 = __shfl(v, base + 2), v4 = __shfl(v, base + 3);
-        hash = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
-        hash = (hash ^ mix(0, v1)) * P1 + P4;
-        hash = (hash ^ mix(0, v2)) * P1 + P4;
-        hash = (hash ^ mix(0, v3)) * P1 + P4;
-        hash = (hash ^ mix(0, v4)) * P1 + P4;
-    }
-    else {
-        hash = P5;
-    }
-    hash += (uint64_t)len;
-    int32_t index = len & ~31;
-    while (index <= len - 8) {
-        hash = rotl(hash ^ mix(0, ld8(out + index)), 27) * P1 + P4;
-        index += 8;
-    }
-    if (index <= len - 4) {
-        hash = rotl(hash ^ ((uint64_t)ld4(out + index) * P1), 23) * P2 + P3;
-        index += 4;
-    }
-    while (index < len) {
-        hash = rotl(hash ^ ((uint64_t)out[index] * P5), 11) * P1;
-        index++;
-    }
-    hash ^= hash >> 33;
-    hash *= P2;
-    hash ^= hash >> 29;
-    hash *= P3;
-    hash ^= hash >> 32;
+    const uint64_t hash = quad_xxh64(out, len, 0, s, lane - s);  // XxHash64.java:182-291 (xxhash.hip)
     if (s == 0) {
         if ((uint32_t)hash == d.checksum) {
             a.outLen[block] = len;
