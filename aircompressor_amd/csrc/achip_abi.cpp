@@ -223,6 +223,30 @@ const DetailText kDetailText[] = {
     {ACHIP_D_LZ4_EMPTY_OUTPUT, "Output buffer too small"},
     {ACHIP_D_LZ4_MAX_INPUT, "Max input length exceeded"},
     {ACHIP_D_LZ4_MAX_OUTPUT, "Max output length must be larger than the LZ4 bound"},
+    {ACHIP_D_LZ4F_TOO_SHORT, "Input is too short to be an LZ4 frame"},
+    {ACHIP_D_LZ4F_TRUNC_MAGIC, "Truncated LZ4 frame: incomplete magic number"},
+    {ACHIP_D_LZ4F_BAD_MAGIC, "Invalid LZ4 frame magic number"},
+    {ACHIP_D_LZ4F_TRUNC_HEADER, "Truncated LZ4 frame header"},
+    {ACHIP_D_LZ4F_VERSION_0, "Unsupported LZ4 frame version: 0"},
+    {ACHIP_D_LZ4F_VERSION_2, "Unsupported LZ4 frame version: 2"},
+    {ACHIP_D_LZ4F_VERSION_3, "Unsupported LZ4 frame version: 3"},
+    {ACHIP_D_LZ4F_RESERVED_BITS, "Corrupt LZ4 frame: reserved bits in the frame descriptor must be zero"},
+    {ACHIP_D_LZ4F_LINKED_BLOCKS, "LZ4 frames with linked blocks are not supported"},
+    {ACHIP_D_LZ4F_DICTIONARY, "LZ4 frames with a dictionary are not supported"},
+    {ACHIP_D_LZ4F_BLOCK_MAX_SIZE, "Invalid LZ4 frame block maximum size"},
+    {ACHIP_D_LZ4F_HEADER_CHECKSUM, "Corrupt LZ4 frame: invalid header checksum"},
+    {ACHIP_D_LZ4F_MISSING_BLOCK_SIZE, "Truncated LZ4 frame: missing block size"},
+    {ACHIP_D_LZ4F_BLOCK_PAST_END, "Truncated LZ4 frame: block extends past end of input"},
+    {ACHIP_D_LZ4F_OUTPUT_TOO_SMALL, "Output buffer too small"},
+    {ACHIP_D_LZ4F_BLOCK_EXCEEDS_MAX, "Corrupt LZ4 frame: decompressed block exceeds maximum block size"},
+    {ACHIP_D_LZ4F_MISSING_BLOCK_CHECKSUM, "Truncated LZ4 frame: missing block checksum"},
+    {ACHIP_D_LZ4F_BLOCK_CHECKSUM, "Corrupt LZ4 frame: invalid block checksum"},
+    {ACHIP_D_LZ4F_MISSING_CONTENT_CHECKSUM, "Truncated LZ4 frame: missing content checksum"},
+    {ACHIP_D_LZ4F_CONTENT_CHECKSUM, "Corrupt LZ4 frame: invalid content checksum"},
+    {ACHIP_D_LZ4F_CONTENT_SIZE, "Corrupt LZ4 frame: content size does not match frame header"},
+    {ACHIP_D_LZ4F_TRUNC_SKIP_SIZE, "Truncated LZ4 skippable frame: missing frame size"},
+    {ACHIP_D_LZ4F_TRUNC_SKIP, "Truncated LZ4 skippable frame"},
+    {ACHIP_D_LZ4F_MAX_OUTPUT, "Output buffer too small"},
     {ACHIP_D_SNAPPY_MALFORMED, "Malformed input"},
     {ACHIP_D_SNAPPY_TRUNCATED, "Input is truncated"},
     {ACHIP_D_SNAPPY_LEN_HIGH_BIT, "last byte of compressed length int has high bit set"},

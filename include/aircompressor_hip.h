@@ -89,6 +89,31 @@ enum achip_detail {
     ACHIP_D_ZSTD_FSE_OUTPUT_SMALL = 53,   /* FiniteStateEntropy.java:114,131 "Output buffer is too small" */
     /* Zstd encode */
     ACHIP_D_ZSTD_MAX_OUTPUT = 60,         /* Util.checkArgument "Output buffer too small"              */
+    /* LZ4 frame container -- M/lz4/Lz4FrameCompression.java */
+    ACHIP_D_LZ4F_TOO_SHORT = 64,          /* :150   "Input is too short to be an LZ4 frame"                 */
+    ACHIP_D_LZ4F_TRUNC_MAGIC = 65,        /* :158   "Truncated LZ4 frame: incomplete magic number"          */
+    ACHIP_D_LZ4F_BAD_MAGIC = 66,          /* :170   "Invalid LZ4 frame magic number"                        */
+    ACHIP_D_LZ4F_TRUNC_HEADER = 67,       /* :191,230 "Truncated LZ4 frame header"                          */
+    ACHIP_D_LZ4F_VERSION_0 = 68,          /* :198   "Unsupported LZ4 frame version: 0" (2, 3 follow)        */
+    ACHIP_D_LZ4F_VERSION_2 = 69,
+    ACHIP_D_LZ4F_VERSION_3 = 70,
+    ACHIP_D_LZ4F_RESERVED_BITS = 71,      /* :202   "Corrupt LZ4 frame: reserved bits in the frame descriptor must be zero" */
+    ACHIP_D_LZ4F_LINKED_BLOCKS = 72,      /* :213   "LZ4 frames with linked blocks are not supported"       */
+    ACHIP_D_LZ4F_DICTIONARY = 73,         /* :217   "LZ4 frames with a dictionary are not supported"        */
+    ACHIP_D_LZ4F_BLOCK_MAX_SIZE = 74,     /* :222   "Invalid LZ4 frame block maximum size"                  */
+    ACHIP_D_LZ4F_HEADER_CHECKSUM = 75,    /* :241   "Corrupt LZ4 frame: invalid header checksum"            */
+    ACHIP_D_LZ4F_MISSING_BLOCK_SIZE = 76, /* :248   "Truncated LZ4 frame: missing block size"               */
+    ACHIP_D_LZ4F_BLOCK_PAST_END = 77,     /* :260   "Truncated LZ4 frame: block extends past end of input"  */
+    ACHIP_D_LZ4F_OUTPUT_TOO_SMALL = 78,   /* :265,276 "Output buffer too small" (a MalformedInputException here)  */
+    ACHIP_D_LZ4F_BLOCK_EXCEEDS_MAX = 79,  /* :279   "Corrupt LZ4 frame: decompressed block exceeds maximum block size" */
+    ACHIP_D_LZ4F_MISSING_BLOCK_CHECKSUM = 80, /* :288 "Truncated LZ4 frame: missing block checksum"         */
+    ACHIP_D_LZ4F_BLOCK_CHECKSUM = 81,     /* :293   "Corrupt LZ4 frame: invalid block checksum"             */
+    ACHIP_D_LZ4F_MISSING_CONTENT_CHECKSUM = 82, /* :307 "Truncated LZ4 frame: missing content checksum"     */
+    ACHIP_D_LZ4F_CONTENT_CHECKSUM = 83,   /* :312   "Corrupt LZ4 frame: invalid content checksum"           */
+    ACHIP_D_LZ4F_CONTENT_SIZE = 84,       /* :318   "Corrupt LZ4 frame: content size does not match frame header" */
+    ACHIP_D_LZ4F_TRUNC_SKIP_SIZE = 85,    /* :334   "Truncated LZ4 skippable frame: missing frame size"     */
+    ACHIP_D_LZ4F_TRUNC_SKIP = 86,         /* :340   "Truncated LZ4 skippable frame"                         */
+    ACHIP_D_LZ4F_MAX_OUTPUT = 87,         /* :362   "Output buffer too small" (IllegalArgumentException, encoder) */
     /* runtime */
     ACHIP_D_NO_DEVICE = 100,
     ACHIP_D_HIP_ERROR = 101,

@@ -47,6 +47,11 @@ int32_t orc_zstd_read_frame_header(const uint8_t* in, int64_t in_len, int64_t* o
 /* XXH64 -- M/zstd/XxHash64.java:182-291 */
 uint64_t orc_xxh64(const uint8_t* in, int64_t len, uint64_t seed);
 
+/* LZ4 frame container -- M/lz4/Lz4FrameCompression.java:70-343 over the block codec above */
+int64_t orc_lz4frame_max_compressed_length(int64_t n);
+int64_t orc_lz4frame_compress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap);
+int64_t orc_lz4frame_decompress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap, int64_t* err_off);
+
 /* XXH32 -- M/xxhash/XxHash32JavaHasher.java:68-110,343-366 (public xxhash package; LZ4 frame checksums) */
 uint32_t orc_xxh32(const uint8_t* in, int64_t len, uint32_t seed);
 

@@ -28,13 +28,13 @@ class Oracle:
         self.lib = lib
         u8p = ctypes.c_void_p
         i64 = ctypes.c_int64
-        for name in ("orc_lz4_max_compressed_length", "orc_snappy_max_compressed_length", "orc_zstd_max_compressed_length"):
+        for name in ("orc_lz4_max_compressed_length", "orc_snappy_max_compressed_length", "orc_zstd_max_compressed_length", "orc_lz4frame_max_compressed_length"):
             getattr(lib, name).restype = i64
             getattr(lib, name).argtypes = [i64]
-        for name in ("orc_lz4_compress", "orc_snappy_compress", "orc_zstd_compress"):
+        for name in ("orc_lz4_compress", "orc_snappy_compress", "orc_zstd_compress", "orc_lz4frame_compress"):
             getattr(lib, name).restype = i64
             getattr(lib, name).argtypes = [u8p, i64, u8p, i64]
-        for name in ("orc_lz4_decompress", "orc_snappy_decompress", "orc_zstd_decompress"):
+        for name in ("orc_lz4_decompress", "orc_snappy_decompress", "orc_zstd_decompress", "orc_lz4frame_decompress"):
             getattr(lib, name).restype = i64
             getattr(lib, name).argtypes = [u8p, i64, u8p, i64, ctypes.POINTER(i64)]
         for name in ("orc_snappy_uncompressed_length", "orc_zstd_decompressed_size"):
