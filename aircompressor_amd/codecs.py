@@ -142,6 +142,25 @@ class Lz4HipDecompressor(_HipDecompressor):
         return r
 
 
+class Lz4FrameHipCompressor(_HipCompressor):
+    """Drop-in for Lz4FrameJavaCompressor (M/lz4/Lz4FrameJavaCompressor.java:26-44 -> Lz4FrameCompression.compress): one LZ4
+    frame of independent 4 MiB blocks, each through the HIP block encoder, stored uncompressed when that is not smaller."""
+    _codec = "lz4frame"
+
+    def max_compressed_length(self, uncompressed_size):
+        r = self._lib.achip_lz4frame_max_compressed_length(uncompressed_size)
+        if r < 0:
+            raise IllegalArgumentException("uncompressedSize is negative: %d" % uncompressed_size if uncompressed_size < 0 else
+                                           "Maximum compressed length exceeds Integer.MAX_VALUE for uncompressedSize: %d" % uncompressed_size)
+        return r
+
+
+class Lz4FrameHipDecompressor(_HipDecompressor):
+    """Drop-in for Lz4FrameJavaDecompressor (M/lz4/Lz4FrameJavaDecompressor.java:26-44 -> Lz4FrameCompression.decompress):
+    concatenated and skippable frames, header / block / content checksums, the reference's exception for every malformed input."""
+    _codec = "lz4frame"
+
+
 class SnappyHipCompressor(_HipCompressor):
     """Drop-in for SnappyJavaCompressor (M/snappy/SnappyJavaCompressor.java:26-91)."""
     _codec = "snappy"

@@ -27,6 +27,9 @@ hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* 
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
 int64_t zstd_decompress_scratch_bytes(int32_t nBlocks, int32_t tileMax);
 int64_t zstd_compress_scratch_bytes(int32_t nBlocks);
+hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch);
+hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch);
+int64_t lz4frame_compress_scratch_bytes();
 hipError_t launch_xxh64_batch(const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int32_t n, uint64_t seed, int64_t* out, hipStream_t stream);
 hipError_t launch_xxh32_batch(const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int32_t n, uint32_t seed, int32_t* out, hipStream_t stream);
 }  // namespace achip
@@ -191,6 +194,18 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             ctx->lastZstddVariant = ctx->zstddVariant;
             break;
         }
+        case ACHIP_OP_LZ4FRAME_DECOMPRESS: {
+            int32_t r = ensure_scratch(ctx, 4096);
+            if (r < 0) return r;
+            e = achip::launch_lz4frame_decompress(a, ctx->stream, ctx->scratch);
+            break;
+        }
+        case ACHIP_OP_LZ4FRAME_COMPRESS: {
+            int32_t r = ensure_scratch(ctx, achip::lz4frame_compress_scratch_bytes());
+            if (r < 0) return r;
+            e = achip::launch_lz4frame_compress(a, ctx->stream, ctx->scratch);
+            break;
+        }
         case ACHIP_OP_ZSTD_COMPRESS: {
             int32_t r = ensure_scratch(ctx, achip::zstd_compress_scratch_bytes(a.nBlocks));
             if (r < 0) return r;
@@ -318,6 +333,15 @@ const char* achip_last_error(void) { return g_lastError.c_str(); }
 // ---- size helpers -------------------------------------------------------
 int32_t achip_lz4_max_compressed_length(int32_t n) { return n + n / 255 + 16; }
 int32_t achip_snappy_max_compressed_length(int32_t n) { return 32 + n + n / 6; }
+int32_t achip_lz4frame_max_compressed_length(int32_t n)
+{
+    // Lz4FrameCompression.maxCompressedLength  M/lz4/Lz4FrameCompression.java:70-83
+    if (n < 0) return bad_argument("uncompressedSize is negative");
+    const int64_t blocks = ((int64_t)n + (4 << 20) - 1) / (4 << 20);
+    const int64_t maxLength = 7 + 4 + (int64_t)n + 4 * blocks;
+    if (maxLength > 0x7FFFFFFF) return bad_argument("Maximum compressed length exceeds Integer.MAX_VALUE");
+    return (int32_t)maxLength;
+}
 int32_t achip_zstd_max_compressed_length(int32_t n)
 {
     int32_t result = n + (int32_t)((uint32_t)n >> 8);
@@ -598,6 +622,8 @@ ACHIP_DEFINE_BATCH(achip_snappy_decompress_batch, ACHIP_OP_SNAPPY_DECOMPRESS)
 ACHIP_DEFINE_BATCH(achip_snappy_compress_batch, ACHIP_OP_SNAPPY_COMPRESS)
 ACHIP_DEFINE_BATCH(achip_zstd_decompress_batch, ACHIP_OP_ZSTD_DECOMPRESS)
 ACHIP_DEFINE_BATCH(achip_zstd_compress_batch, ACHIP_OP_ZSTD_COMPRESS)
+ACHIP_DEFINE_BATCH(achip_lz4frame_decompress_batch, ACHIP_OP_LZ4FRAME_DECOMPRESS)
+ACHIP_DEFINE_BATCH(achip_lz4frame_compress_batch, ACHIP_OP_LZ4FRAME_COMPRESS)
 
 // ---- xxhash -------------------------------------------
 int32_t achip_xxhash64_batch(achip_ctx* ctx, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int64_t seed, int64_t* outHash, int32_t nBuffers)
@@ -751,6 +777,14 @@ static int32_t single_block(int32_t op, achip_ctx* ctx, const void* src, void* d
     return status < 0 ? status : outLen;
 }
 
+int32_t achip_lz4frame_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_LZ4FRAME_COMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
+int32_t achip_lz4frame_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_LZ4FRAME_DECOMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
 int32_t achip_lz4_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
 {
     return single_block(ACHIP_OP_LZ4_COMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);

@@ -244,28 +244,13 @@ __device__ __forceinline__ int32_t lz4_scan_offset(int32_t m)
 }
 __device__ __forceinline__ int32_t lz4_scan_advance(int32_t k) { return k == 0 ? 1 : (63 + k) >> 6; }
 
-// Batch-probe variant: the 64 lanes evaluate the next 64 steps of the Java search loop at once.
-//   lane roles after a match (:157-184): lane 0 = the `input - 2` insert, lane 1 = the immediate re-probe at `input`,
-//   lanes 2.. = the probes of the search that follows if the re-probe fails (:113-138, skip schedule included).
-// Same-hash collisions inside the batch are resolved so that every probe sees exactly the table state the serial
-// loop would have produced (a probe's candidate is the latest earlier batch position with the same hash, else the
-// table entry); only the entries up to the winning probe are written back, latest position last.
+// The batch-probe encoder of one block (M/lz4/Lz4RawCompressor.java:74-187) by one wavefront; `table` is MAX_TABLE_SIZE
+// entries of LDS.  Returns the compressed length; stOut receives 0 or the status.  Shared by the batched block encoder
+// below and the LZ4 frame encoder (lz4_frame.hip).
 template <typename TableT>
-__global__ __launch_bounds__(64) void lz4_compress_batch_kernel(BatchArgs a)
+__device__ int32_t lz4_compress_block(const uint8_t* __restrict__ in, int32_t inLen, uint8_t* __restrict__ out, int32_t outCap, TableT* table, int lane, int32_t& stOut)
 {
     using namespace lz4c;
-    __shared__ TableT table[MAX_TABLE_SIZE];
-    const int lane = threadIdx.x;
-    const int64_t block = blockIdx.x;
-    const int32_t inLen = a.srcLen[block];
-    constexpr bool WIDE = sizeof(TableT) == 4;
-    if (WIDE ? (inLen <= 65536) : (inLen > 65536)) {
-        return;
-    }
-    const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
-    uint8_t* __restrict__ out = a.dstBase + a.dstOff[block];
-    const int32_t outCap = a.dstCap[block];
-
     int32_t st = 0;
     int32_t output = 0;
     const int64_t bound = (int64_t)inLen + inLen / 255 + 16;
@@ -464,11 +449,142 @@ __global__ __launch_bounds__(64) void lz4_compress_batch_kernel(BatchArgs a)
             output += length;
         }
     }
+    stOut = st;
+    return output;
+}
+
+// Batch-probe variant: the 64 lanes evaluate the next 64 steps of the Java search loop at once.
+//   lane roles after a match (:157-184): lane 0 = the `input - 2` insert, lane 1 = the immediate re-probe at `input`,
+//   lanes 2.. = the probes of the search that follows if the re-probe fails (:113-138, skip schedule included).
+// Same-hash collisions inside the batch are resolved so that every probe sees exactly the table state the serial
+// loop would have produced (a probe's candidate is the latest earlier batch position with the same hash, else the
+// table entry); only the entries up to the winning probe are written back, latest position last.
+template <typename TableT>
+__global__ __launch_bounds__(64) void lz4_compress_batch_kernel(BatchArgs a)
+{
+    using namespace lz4c;
+    __shared__ TableT table[MAX_TABLE_SIZE];
+    const int lane = threadIdx.x;
+    const int64_t block = blockIdx.x;
+    const int32_t inLen = a.srcLen[block];
+    constexpr bool WIDE = sizeof(TableT) == 4;
+    if (WIDE ? (inLen <= 65536) : (inLen > 65536)) {
+        return;
+    }
+    const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
+    uint8_t* __restrict__ out = a.dstBase + a.dstOff[block];
+    const int32_t outCap = a.dstCap[block];
+
+    int32_t st = 0;
+    const int32_t output = lz4_compress_block<TableT>(in, inLen, out, outCap, table, lane, st);
     if (lane == 0) {
         a.outLen[block] = st == 0 ? output : 0;
         a.status[block] = st;
         a.errOffset[block] = 0;
     }
+}
+
+// ---- LZ4 frame container, encoder -------------------------------------------------------------
+// Replaces Lz4FrameCompression.compress (M/lz4/Lz4FrameCompression.java:96-140): header (magic, FLG = version 01 +
+// independent blocks, BD = 4 MiB, xxHash32 header checksum byte), 4 MiB blocks each through the block encoder above into a
+// per-wave scratch slab, stored uncompressed when that is not smaller (:117-131), end mark.  One wavefront per item,
+// persistent grid; the capacity checks are made where the Java code makes them (writeInt / ensureCapacity).
+namespace lz4f {
+constexpr int32_t BLOCK_MAX_4MB = 4 * 1024 * 1024;
+constexpr int64_t SLAB_BYTES = ((int64_t)BLOCK_MAX_4MB + BLOCK_MAX_4MB / 255 + 16 + 255) & ~(int64_t)255;
+constexpr int32_t MAX_WAVES = 512;
+}  // namespace lz4f
+
+__global__ __launch_bounds__(64) void lz4frame_compress_kernel(BatchArgs a, uint8_t* slabs, int32_t* nextItem)
+{
+    using namespace lz4c;
+    __shared__ int32_t table[MAX_TABLE_SIZE];
+    __shared__ int32_t item;
+    const int lane = threadIdx.x;
+    uint8_t* slab = slabs + (size_t)blockIdx.x * lz4f::SLAB_BYTES;
+    for (;;) {
+        __syncthreads();
+        if (lane == 0) {
+            item = atomicAdd(nextItem, 1);
+        }
+        __syncthreads();
+        const int32_t block = item;
+        if (block >= a.nBlocks) {
+            return;
+        }
+        const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
+        uint8_t* out = a.dstBase + a.dstOff[block];
+        const int32_t inLen = a.srcLen[block];
+        const int64_t outCap = a.dstCap[block];
+        int64_t pos = 0;
+        bool tooSmall = false;
+        // frame header :102-107
+        if (outCap < 7) {
+            tooSmall = true;
+        }
+        else {
+            if (lane == 0) {
+                st4(out, 0x184D2204u);
+                out[4] = 0x60;  // FLG_VERSION | FLG_BLOCK_INDEPENDENCE
+                out[5] = 0x70;  // BD_4MB
+                out[6] = 0x73;  // (xxHash32({0x60, 0x70}) >>> 8) & 0xFF
+            }
+            pos = 7;
+        }
+        int32_t ipos = 0;
+        while (!tooSmall && ipos < inLen) {
+            const int32_t blockLen = inLen - ipos < lz4f::BLOCK_MAX_4MB ? inLen - ipos : lz4f::BLOCK_MAX_4MB;
+            int32_t st = 0;
+            wave_mem_order();
+            const int32_t clen = lz4_compress_block<int32_t>(in + ipos, blockLen, slab, (int32_t)lz4f::SLAB_BYTES, table, lane, st);
+            wave_mem_order();
+            const bool compressed = st == 0 && clen < blockLen;
+            const int32_t payload = compressed ? clen : blockLen;
+            if (pos + 4 > outCap || pos + 4 + payload > outCap) {
+                tooSmall = true;
+                break;
+            }
+            if (lane == 0) {
+                st4(out + pos, compressed ? (uint32_t)clen : ((uint32_t)blockLen | 0x80000000u));
+            }
+            pos += 4;
+            group_copy<64>(out + pos, compressed ? (const uint8_t*)slab : in + ipos, payload, lane);
+            pos += payload;
+            ipos += blockLen;
+            __syncthreads();
+        }
+        if (!tooSmall) {
+            if (pos + 4 > outCap) {
+                tooSmall = true;
+            }
+            else {
+                if (lane == 0) {
+                    st4(out + pos, 0u);
+                }
+                pos += 4;
+            }
+        }
+        if (lane == 0) {
+            a.outLen[block] = tooSmall ? 0 : (int32_t)pos;
+            a.status[block] = tooSmall ? mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_LZ4F_MAX_OUTPUT) : 0;
+            a.errOffset[block] = 0;
+        }
+    }
+}
+
+int64_t lz4frame_compress_scratch_bytes() { return 4096 + (int64_t)lz4f::MAX_WAVES * lz4f::SLAB_BYTES; }
+
+hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch)
+{
+    if (a.nBlocks <= 0) {
+        return hipSuccess;
+    }
+    int32_t* counter = (int32_t*)scratch;
+    hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (unsigned)(a.nBlocks < lz4f::MAX_WAVES ? a.nBlocks : lz4f::MAX_WAVES);
+    hipLaunchKernelGGL(lz4frame_compress_kernel, dim3(grid), dim3(64), 0, stream, a, (uint8_t*)scratch + 4096, counter);
+    return hipGetLastError();
 }
 
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint)

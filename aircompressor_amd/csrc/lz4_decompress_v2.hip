@@ -5,7 +5,7 @@
 // per-block LDS input ring (coalesced 16-byte granules), the output is produced into a per-block LDS
 // history ring and flushed to HBM in whole aligned chunks, and back-references within LDS_REACH are
 // served from LDS (achip_rings.h).  HBM traffic per block ~= compressed bytes + plaintext bytes.
-#include "achip_rings.h"
+#include "lz4_decode_body.h"
 
 namespace achip {
 
@@ -30,111 +30,9 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a)
            a.ringPad >= 16 * GS * GPL ? smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING + OUT_RING : nullptr);
 
     int32_t st = 0;
-    int32_t eo = 0;  // 32-bit on purpose (see lz4_decompress.hip)
-    int32_t ip = 0;
+    int32_t eo = 0;
     int32_t op = 0;
-
-#define LZ4_FAIL(detail, off)                          \
-    {                                                  \
-        st = mk_status(ACHIP_CLASS_MALFORMED, detail); \
-        eo = (int32_t)(off);                           \
-        break;                                         \
-    }
-
-    if (inLimit == 0) {  // :48-50
-        st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_LZ4_INPUT_EMPTY);
-    }
-    else if (outLimit == 0) {  // :52-57 (the Java method returns -1 here)
-        if (!(inLimit == 1 && in[0] == 0)) {
-            st = mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_LZ4_EMPTY_OUTPUT);
-        }
-    }
-    else {
-        const int32_t fastOutLimit = outLimit - 8;
-        // The 4-byte windows at the token and at the offset are read one phase early (the next token's before the match
-        // copy, the offset's before the literal copy) so that they travel with that copy's own LDS reads: two dependent
-        // LDS round trips fewer per sequence.
-        R.ensure_input(ip, 4);
-        uint32_t t4 = R.template ring_ld4<IN_RING>(R.inRing, ip + R.inBase);  // token and the 3 bytes after it
-        while (ip < inLimit) {
-            const int32_t token = (int32_t)(t4 & 0xFF);
-            ip++;
-
-            int32_t lit = token >> 4;  // :62-77
-            if (lit == 0xF) {
-                if (ip >= inLimit) LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
-                int32_t v = (int32_t)((t4 >> 8) & 0xFF);  // first extension byte (resident: bytes past the input read as 0 and are not used)
-                ip++;
-                lit = (int32_t)((uint32_t)lit + (uint32_t)v);
-                while (v == 255 && ip < inLimit - 15) {
-                    R.ensure_input(ip, 1);
-                    v = (int32_t)R.in_u8(ip++);
-                    lit = (int32_t)((uint32_t)lit + (uint32_t)v);
-                }
-            }
-            if (lit < 0) LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
-
-            const int64_t litEnd = (int64_t)ip + lit;
-            const int64_t litOutLimit = (int64_t)op + lit;
-            if (litOutLimit > fastOutLimit - 4 || litEnd > inLimit - 8) {  // :82-96 last literals
-                if (litOutLimit > outLimit) LZ4_FAIL(ACHIP_D_LZ4_LAST_LITERAL_OUTSIDE, ip);
-                if (litEnd != inLimit) LZ4_FAIL(ACHIP_D_LZ4_INPUT_NOT_CONSUMED, ip);
-                R.copy_literals(ip, op, lit);
-                op += lit;
-                break;
-            }
-
-            uint32_t o4 = 0;
-            const bool early = lit + 3 <= Rings<GS, IN_RING, OUT_RING, GPL>::CHUNK;
-            if (early) {
-                R.ensure_input(ip, lit + 3);
-                o4 = R.template ring_ld4<IN_RING>(R.inRing, (int32_t)litEnd + R.inBase);
-            }
-            R.copy_literals(ip, op, lit);  // :99-109
-            op += lit;
-            ip = (int32_t)litEnd;
-
-            if (!early) {
-                R.ensure_input(ip, 3);
-                o4 = R.template ring_ld4<IN_RING>(R.inRing, ip + R.inBase);  // offset and the first length-extension byte
-            }
-            const int32_t offset = (int32_t)(o4 & 0xFFFF);  // :113-119
-            ip += 2;
-            if (offset == 0 || offset > op) LZ4_FAIL(ACHIP_D_LZ4_OFFSET_OUTSIDE, ip);
-
-            int32_t ml = token & 0xF;  // :122-138
-            if (ml == 0xF) {
-                if (ip > inLimit - 5) LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
-                int32_t v = (int32_t)((o4 >> 16) & 0xFF);
-                ip++;
-                ml = (int32_t)((uint32_t)ml + (uint32_t)v);
-                bool bad = false;
-                while (v == 255) {
-                    if (ip > inLimit - 5) {
-                        bad = true;
-                        break;
-                    }
-                    R.ensure_input(ip, 1);
-                    v = (int32_t)R.in_u8(ip++);
-                    ml = (int32_t)((uint32_t)ml + (uint32_t)v);
-                }
-                if (bad) LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
-            }
-            ml = (int32_t)((uint32_t)ml + 4u);
-            if (ml < 0) LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
-
-            const int64_t matchOutLimit = (int64_t)op + ml;
-            if (matchOutLimit > fastOutLimit - 4 && matchOutLimit > outLimit - 5) {  // :168-171
-                LZ4_FAIL(ACHIP_D_LZ4_LAST_5_LITERALS, ip);
-            }
-            R.ensure_input(ip, 4);
-            t4 = R.template ring_ld4<IN_RING>(R.inRing, ip + R.inBase);  // the next token, ahead of the match copy
-            R.copy_match(op, offset, ml);  // :146-194
-            op = (int32_t)matchOutLimit;
-        }
-        R.flush_all(op);
-    }
-#undef LZ4_FAIL
+    lz4_block_decode<GS, IN_RING, OUT_RING, GPL>(R, in, inLimit, outLimit, st, eo, op);
 
     if (g == 0) {
         a.outLen[block] = st == 0 ? op : 0;

@@ -226,6 +226,19 @@ int32_t achip_snappy_decompress(achip_ctx* ctx, const void* src, void* dst, int3
 int32_t achip_zstd_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
 int32_t achip_zstd_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
 
+/* ---- LZ4 frame container ----
+ * Replace Lz4FrameCompression.maxCompressedLength / compress / decompress    M/lz4/Lz4FrameCompression.java:70-83, 96-140, 145-343
+ * (the methods behind Lz4FrameJavaCompressor / Lz4FrameJavaDecompressor, M/lz4/Lz4FrameJavaCompressor.java:26-44) with the
+ * HIP block codec underneath.  An item of the batch is a whole buffer: any number of concatenated and skippable frames on
+ * decode, one frame (4 MiB independent blocks, no checksums) on encode.  Same batch arguments, result convention and
+ * asynchrony as the block codecs; errOffset carries the MalformedInputException offset. */
+int32_t achip_lz4frame_max_compressed_length(int32_t uncompressedSize);  /* negative: IllegalArgumentException */
+int32_t achip_lz4frame_decompress_batch(ACHIP_BATCH_ARGS);
+int32_t achip_lz4frame_compress_batch(ACHIP_BATCH_ARGS);
+/* one HOST buffer, staged through the context's pinned buffer (Lz4FrameJava{De,}Compressor.{de,}compress(byte[]...)) */
+int32_t achip_lz4frame_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+int32_t achip_lz4frame_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+
 /* ---- xxhash: batched XXH64 / XXH32 of device-resident buffers ----
  * Replace XxHash64Hasher.hash(MemorySegment input, long seed)   M/xxhash/XxHash64Hasher.java:78-86  (-> XxHash64JavaHasher.java:126)
  *     and XxHash32Hasher.hash(MemorySegment input, int seed)    M/xxhash/XxHash32Hasher.java       (-> XxHash32JavaHasher.java:112)
@@ -246,6 +259,8 @@ int32_t achip_xxhash32(achip_ctx* ctx, const void* src, int64_t srcLen, int32_t 
 #define ACHIP_OP_SNAPPY_COMPRESS 3
 #define ACHIP_OP_ZSTD_DECOMPRESS 4
 #define ACHIP_OP_ZSTD_COMPRESS 5
+#define ACHIP_OP_LZ4FRAME_DECOMPRESS 6
+#define ACHIP_OP_LZ4FRAME_COMPRESS 7
 int32_t achip_batch_host(int32_t codecOp, ACHIP_BATCH_ARGS);
 
 /* Balanced contiguous partition of a batch over nParts GPUs: fills
