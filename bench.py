@@ -51,7 +51,7 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
-    p.add_argument("--section", default="all", choices=["all", "zstd", "xxhash"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
+    p.add_argument("--section", default="all", choices=["all", "zstd", "xxhash", "lz4frame"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-variant", type=int, default=-1, help="zstd decoder: 1 = five-stage pipeline (default), 0 = one-kernel decoder")
     return p.parse_args()
 
@@ -150,6 +150,9 @@ def main():
     if args.ring_pad >= 0:
         codec.native.set_option("decompress.ring_pad", args.ring_pad)
     codec.native.set_option("max_src_len_hint", bs)
+    if args.section == "lz4frame":
+        print(json.dumps(lz4frame_extra(torch, A, codec, torch.device("cuda", local_rank), args)), flush=True)
+        return
     if args.section == "xxhash":
         print(json.dumps(xxhash_extra(torch, A, codec, torch.device("cuda", local_rank), args)), flush=True)
         return
@@ -300,6 +303,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra:
         result["extra"] = extras(torch, A, codec, dev, args)
         result["extra"].update(xxhash_extra(torch, A, codec, dev, args))
+        result["extra"].update(lz4frame_extra(torch, A, codec, dev, args))
         try:
             result["extra"].update(zstd_extra(torch, A, codec, dev, args))
         except ImportError:
@@ -392,6 +396,53 @@ def xxhash_extra(torch, A, codec, dev, args):
         except ImportError:
             pass
         out[name] = {"GiBps": round(n * bs / t / 2**30, 2), "hbm_frac": round(n * bs / t / 1e9 / HBM_PEAK_GBS, 4), "buffers": n, "buffer_bytes": bs}
+    return out
+
+
+def lz4frame_extra(torch, A, codec, dev, args):
+    """SURVEY 8f row 1: LZ4 frame container, one frame of 4 MiB blocks per item (what Lz4FrameJavaCompressor writes);
+    GPU encode (byte-identical to the Java frame encoder), then GPU decode, verified against the plaintext."""
+    out = {}
+    fs, n = 4 << 20, 1024
+    lib = codec.lib
+    max_c = lib.achip_lz4frame_max_compressed_length(fs)
+    cstride = (max_c + 15) // 16 * 16
+    i64 = dict(dtype=torch.int64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    for data_kind in ("fragments", "corpus"):
+        plain = gen_data(torch, dev, data_kind, n * (fs // args.block_size), args.block_size, args.ratio, 99)
+        p_off = torch.arange(n, **i64) * fs
+        p_len = torch.full((n,), fs, **i32)
+        comp = torch.empty(n * cstride + 64, dtype=torch.uint8, device=dev)
+        c_off = torch.arange(n, **i64) * cstride
+        c_cap = torch.full((n,), max_c, **i32)
+        clen = torch.zeros(n, **i32)
+        st = torch.zeros(n, **i32)
+        eo = torch.zeros(n, **i64)
+        back = torch.empty(n * fs + 64, dtype=torch.uint8, device=dev)
+        blen = torch.zeros(n, **i32)
+        torch.cuda.synchronize()
+
+        def timed(fn, iters):
+            fn()
+            codec.synchronize()
+            e0, e1 = codec.event(), codec.event()
+            codec.record(e0)
+            for _ in range(iters):
+                fn()
+            codec.record(e1)
+            return codec.elapsed_ms(e0, e1) / iters * 1e-3
+
+        tc = timed(lambda: codec.launch(A.OP_LZ4FRAME_COMPRESS, plain, p_off, p_len, comp, c_off, c_cap, clen, st, eo, n), 1)
+        assert int((st != 0).sum()) == 0
+        cbytes = int(clen.to(torch.int64).sum())
+        td = timed(lambda: codec.launch(A.OP_LZ4FRAME_DECOMPRESS, comp, c_off, clen, back, p_off, p_len, blen, st, eo, n), 2)
+        assert int((st != 0).sum()) == 0 and bool((back[:n * fs] == plain).all())
+        out["lz4frame_%s" % data_kind] = {
+            "ratio": round(n * fs / cbytes, 3), "compress_GiBps": round(n * fs / tc / 2**30, 2), "decompress_GiBps": round(n * fs / td / 2**30, 2),
+            "decompress_hbm_frac": round((n * fs + cbytes) / td / 1e9 / HBM_PEAK_GBS, 4), "frames": n, "frame_bytes": fs,
+        }
+        del comp, back, plain
     return out
 
 
