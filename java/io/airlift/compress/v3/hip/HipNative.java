@@ -54,6 +54,8 @@ public final class HipNative
     public static final int OP_SNAPPY_COMPRESS = 3;
     public static final int OP_ZSTD_DECOMPRESS = 4;
     public static final int OP_ZSTD_COMPRESS = 5;
+    public static final int OP_LZ4FRAME_DECOMPRESS = 6;  // achip_lz4frame_decompress (SURVEY 8f row 1)
+    public static final int OP_LZ4FRAME_COMPRESS = 7;    // achip_lz4frame_compress
 
     private record MethodHandles(
             @NativeSignature(name = "achip_device_count", returnType = int.class, argumentTypes = {})
