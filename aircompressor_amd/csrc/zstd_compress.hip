@@ -87,6 +87,7 @@ struct Ctx {
     int dbgStage;
     int batchProbe;
     int32_t failStatus;  // 0 = ok
+    const int32_t* pre;  // match-finder results of this item (two-kernel path) or null
     // per-wave slab
     int32_t* hashTable;
     int32_t* chainTable;
@@ -1508,13 +1509,23 @@ __device__ int32_t compress_block(Ctx& c, Shared& sh, int32_t inputAddress, int3
     c.literalsLength = 0;
     c.sequenceCount = 0;
     c.longLengthField = 0;
-    const int32_t lastLiteralsSize = dfast_compress_block(c, inputAddress, inputSize);
-    if (c.dbgStage == 1) {
-        return 0;  // DEBUG (timing split only): stop after the match finder
+    if (c.pre != nullptr) {
+        c.sequenceCount = c.pre[1];
+        c.literalsLength = c.pre[2];
+        c.longLengthField = c.pre[3];
+        c.longLengthPosition = c.pre[4];
+        c.tempOffset0 = c.pre[5];
+        c.tempOffset1 = c.pre[6];
     }
-    wave_mem_order();
-    group_copy<64>(c.litBuf + c.literalsLength, c.in + inputAddress + inputSize - lastLiteralsSize, lastLiteralsSize, c.lane);
-    c.literalsLength += lastLiteralsSize;
+    else {
+        const int32_t lastLiteralsSize = dfast_compress_block(c, inputAddress, inputSize);
+        if (c.dbgStage == 1) {
+            return 0;  // DEBUG (timing split only): stop after the match finder
+        }
+        wave_mem_order();
+        group_copy<64>(c.litBuf + c.literalsLength, c.in + inputAddress + inputSize - lastLiteralsSize, lastLiteralsSize, c.lane);
+        c.literalsLength += lastLiteralsSize;
+    }
     wave_mem_order();
     // generateCodes :121-135 : one sequence per lane per step
     for (int32_t i = c.lane; i < c.sequenceCount; i += 64) {
@@ -1554,35 +1565,47 @@ __device__ int32_t compress_block(Ctx& c, Shared& sh, int32_t inputAddress, int3
     return compressedSize;
 }
 
+// CompressionParameters.compute :256-299 (level 3)
+__device__ __forceinline__ void compute_parameters(Ctx& c)
+{
+    const int32_t inputSize = c.inLen;
+    const int table = inputSize <= 16 * 1024 ? 3 : (inputSize <= 128 * 1024 ? 2 : (inputSize <= 256 * 1024 ? 1 : 0));
+    int32_t windowLog = LEVEL3[table][0], chainLog = LEVEL3[table][1], hashLog = LEVEL3[table][2];
+    c.searchLength = LEVEL3[table][3];
+    const int32_t inputSizeLog = inputSize < 64 ? 6 : highest_bit((uint32_t)(inputSize - 1)) + 1;
+    if (windowLog > inputSizeLog) {
+        windowLog = inputSizeLog;
+    }
+    if (hashLog > windowLog + 1) {
+        hashLog = windowLog + 1;
+    }
+    if (chainLog > windowLog) {
+        chainLog -= (chainLog - windowLog);
+    }
+    if (windowLog < 10) {
+        windowLog = 10;
+    }
+    c.windowLog = windowLog;
+    c.windowSize = 1 << windowLog;
+    c.blockSize = c.windowSize < MAX_BLOCK_SIZE ? c.windowSize : MAX_BLOCK_SIZE;
+    c.chainLog = chainLog;
+    c.hashLog = hashLog;
+}
+
+// Two-kernel path (inputs of one block, 7..128 KiB -- BASELINE configs[3] / [4]): the match finder is 84-98 % of the
+// encoder's time and needs neither the entropy stage's LDS nor most of its registers, so it runs as its own kernel with
+// more wavefronts per CU; its results (sequence store, literals, the two candidate repeat offsets) wait in the item's
+// scratch for the entropy kernel.  Larger inputs stay in the one kernel: whether block k's repeat offsets are committed
+// depends on block k's entropy outcome (ZstdFrameCompressor.java:246-258), so their match finding cannot run ahead.
+constexpr int32_t PRE_WORDS = 16;  // record: valid, sequenceCount, literalsLength, longLengthField, longLengthPosition, tempOffset0, tempOffset1
+__device__ __forceinline__ bool split_eligible(int32_t inLen) { return inLen >= 7 && inLen <= MAX_BLOCK_SIZE; }
+
 __device__ int32_t zstd_compress_item(Ctx& c, Shared& sh)
 {
     const int32_t inputSize = c.inLen;
     const int32_t outputLimit = c.outCap;
     int32_t output = 0;
-    // CompressionParameters.compute :256-299 (level 3)
-    {
-        const int table = inputSize <= 16 * 1024 ? 3 : (inputSize <= 128 * 1024 ? 2 : (inputSize <= 256 * 1024 ? 1 : 0));
-        int32_t windowLog = LEVEL3[table][0], chainLog = LEVEL3[table][1], hashLog = LEVEL3[table][2];
-        c.searchLength = LEVEL3[table][3];
-        const int32_t inputSizeLog = inputSize < 64 ? 6 : highest_bit((uint32_t)(inputSize - 1)) + 1;
-        if (windowLog > inputSizeLog) {
-            windowLog = inputSizeLog;
-        }
-        if (hashLog > windowLog + 1) {
-            hashLog = windowLog + 1;
-        }
-        if (chainLog > windowLog) {
-            chainLog -= (chainLog - windowLog);
-        }
-        if (windowLog < 10) {
-            windowLog = 10;
-        }
-        c.windowLog = windowLog;
-        c.windowSize = 1 << windowLog;
-        c.blockSize = c.windowSize < MAX_BLOCK_SIZE ? c.windowSize : MAX_BLOCK_SIZE;
-        c.chainLog = chainLog;
-        c.hashLog = hashLog;
-    }
+    compute_parameters(c);
     ZC_CHECK(c, outputLimit - output >= 4);  // writeMagic :55-61
     st4(c.out + output, 0xFD2FB528u);
     output += 4;
@@ -1618,8 +1641,10 @@ __device__ int32_t zstd_compress_item(Ctx& c, Shared& sh)
         c.offset1 = 4;
         c.tempOffset0 = c.tempOffset1 = 0;
         c.windowBaseOffset = 0;
-        wave_fill((uint8_t*)c.hashTable, 0, 4 << c.hashLog, c.lane);
-        wave_fill((uint8_t*)c.chainTable, 0, 4 << c.chainLog, c.lane);
+        if (c.pre == nullptr) {  // (with a precomputed record the match finder -- and its tables -- already ran elsewhere)
+            wave_fill((uint8_t*)c.hashTable, 0, 4 << c.hashLog, c.lane);
+            wave_fill((uint8_t*)c.chainTable, 0, 4 << c.chainLog, c.lane);
+        }
         for (int i = c.lane; i < 256; i += 64) {
             sh.huf[0].numberOfBits[i] = 0;
             sh.huf[1].numberOfBits[i] = 0;
@@ -1674,7 +1699,91 @@ __device__ int32_t zstd_compress_item(Ctx& c, Shared& sh)
 
 }  // namespace zc
 
-__global__ __launch_bounds__(64) void zstd_compress_kernel(BatchArgs a, uint8_t* slabs, int32_t* nextItem)
+namespace zc {
+// per-item scratch of the two-kernel path: [record | seqOffset | seqLitLen | seqMatchLen | literals]
+constexpr int64_t ITEM_BYTES = 256 + (int64_t)3 * 4 * MAX_SEQUENCES + MAX_BLOCK_SIZE + 64;
+__device__ __forceinline__ void point_item_scratch(Ctx& c, uint8_t* itemScratch)
+{
+    uint8_t* p = itemScratch + 256;
+    c.seqOffset = (int32_t*)p;
+    p += 4 * MAX_SEQUENCES;
+    c.seqLitLen = (int32_t*)p;
+    p += 4 * MAX_SEQUENCES;
+    c.seqMatchLen = (int32_t*)p;
+    p += 4 * MAX_SEQUENCES;
+    c.litBuf = p;
+}
+}  // namespace zc
+
+// K_m: the match finder alone (DoubleFastBlockCompressor.compressBlock) for the eligible items [first, first + count)
+__global__ __launch_bounds__(64) void zstd_match_kernel(BatchArgs a, uint8_t* tableSlabs, uint8_t* itemScratch, int32_t first, int32_t count, int32_t* nextItem, int32_t batchProbe)
+{
+    using namespace zc;
+    __shared__ int32_t item;
+    const int lane = threadIdx.x;
+    uint8_t* slab = tableSlabs + (size_t)blockIdx.x * (4 * (HASH_TABLE_INTS + CHAIN_TABLE_INTS));
+    for (;;) {
+        __syncthreads();
+        if (lane == 0) {
+            item = atomicAdd(nextItem, 1);
+        }
+        __syncthreads();
+        const int32_t slot = item;
+        if (slot >= count) {
+            return;
+        }
+        const int32_t block = first + slot;
+        uint8_t* mine = itemScratch + (size_t)slot * ITEM_BYTES;
+        int32_t* rec = (int32_t*)mine;
+        Ctx c;
+        c.in = a.srcBase + a.srcOff[block];
+        c.inLen = a.srcLen[block];
+        c.out = nullptr;
+        c.outCap = 0;
+        c.lane = lane;
+        c.dbgStage = 0;
+        c.batchProbe = batchProbe;
+        c.failStatus = 0;
+        c.pre = nullptr;
+        if (!split_eligible(c.inLen)) {
+            if (lane == 0) {
+                rec[0] = 0;
+            }
+            continue;
+        }
+        c.hashTable = (int32_t*)slab;
+        c.chainTable = (int32_t*)(slab + 4 * HASH_TABLE_INTS);
+        point_item_scratch(c, mine);
+        c.codeLL = c.codeML = c.codeOF = nullptr;
+        compute_parameters(c);
+        c.offset0 = 1;  // a fresh CompressionContext (ZstdFrameCompressor.java:162)
+        c.offset1 = 4;
+        c.tempOffset0 = c.tempOffset1 = 0;
+        c.windowBaseOffset = 0;
+        wave_fill((uint8_t*)c.hashTable, 0, 4 << c.hashLog, lane);
+        wave_fill((uint8_t*)c.chainTable, 0, 4 << c.chainLog, lane);
+        wave_mem_order();
+        c.literalsLength = 0;
+        c.sequenceCount = 0;
+        c.longLengthField = 0;
+        c.longLengthPosition = 0;
+        const int32_t lastLiteralsSize = dfast_compress_block(c, 0, c.inLen);
+        wave_mem_order();
+        group_copy<64>(c.litBuf + c.literalsLength, c.in + c.inLen - lastLiteralsSize, lastLiteralsSize, lane);
+        c.literalsLength += lastLiteralsSize;
+        if (lane == 0) {
+            rec[1] = c.sequenceCount;
+            rec[2] = c.literalsLength;
+            rec[3] = c.longLengthField;
+            rec[4] = c.longLengthPosition;
+            rec[5] = c.tempOffset0;
+            rec[6] = c.tempOffset1;
+            rec[0] = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void zstd_compress_kernel(BatchArgs a, uint8_t* slabs, int32_t* nextItem, uint8_t* itemScratch, int32_t first, int32_t count)
 {
     using namespace zc;
     __shared__ Shared sh;
@@ -1691,10 +1800,10 @@ __global__ __launch_bounds__(64) void zstd_compress_kernel(BatchArgs a, uint8_t*
             item = atomicAdd(nextItem, 1);
         }
         __syncthreads();
-        const int32_t block = item;
-        if (block >= a.nBlocks) {
+        if (item >= count) {
             return;
         }
+        const int32_t block = first + item;
         Ctx c;
         c.in = a.srcBase + a.srcOff[block];
         c.inLen = a.srcLen[block];
@@ -1704,6 +1813,7 @@ __global__ __launch_bounds__(64) void zstd_compress_kernel(BatchArgs a, uint8_t*
         c.dbgStage = a.ringPad == 999 ? 1 : 0;
         c.batchProbe = a.ringPad == 1 ? 0 : 1;  // variant 1 = serial probing
         c.failStatus = 0;
+        c.pre = nullptr;
         uint8_t* p = slab;
         c.hashTable = (int32_t*)p;
         p += 4 * HASH_TABLE_INTS;
@@ -1722,6 +1832,13 @@ __global__ __launch_bounds__(64) void zstd_compress_kernel(BatchArgs a, uint8_t*
         c.codeOF = p;
         p += MAX_SEQUENCES;
         c.litBuf = p;
+        if (itemScratch != nullptr) {
+            uint8_t* mine = itemScratch + (size_t)item * ITEM_BYTES;
+            if (((const int32_t*)mine)[0] == 1) {  // the match kernel has been here: sequence store and literals live in the item's scratch
+                c.pre = (const int32_t*)mine;
+                point_item_scratch(c, mine);
+            }
+        }
         int32_t r;
         if (c.inLen < 0 || c.outCap < 0) {
             r = -1;
@@ -1739,28 +1856,47 @@ __global__ __launch_bounds__(64) void zstd_compress_kernel(BatchArgs a, uint8_t*
 }
 
 namespace {
-constexpr int ZC_MAX_WAVES = 256 * 8;  // 154 VGPRs => 2 waves per SIMD: all of them are needed to cover the HBM round trips of the match finder
+constexpr int ZC_MAX_WAVES = 256 * 8;     // entropy (and one-kernel) path: 154 VGPRs => 2 waves per SIMD
+constexpr int ZM_MAX_WAVES = 256 * 24;    // match kernel: 62 VGPRs, no LDS; 16 -> 24 waves per CU measured +4..12 %, 28 no better
+constexpr int32_t ZC_TILE = 8192;         // items per pass of the two-kernel path (their scratch: 608 KB each)
+constexpr int64_t ZM_TABLE_BYTES = 4 * (zc::HASH_TABLE_INTS + zc::CHAIN_TABLE_INTS);
 }
 
 int64_t zstd_compress_scratch_bytes(int32_t nBlocks)
 {
-    (void)nBlocks;
-    return 4096 + (int64_t)ZC_MAX_WAVES * zc::SLAB_BYTES;
+    // three regions, each sized for the waves / items a batch of nBlocks can put in flight (a one-frame call needs 2.7 MB)
+    const int64_t n = nBlocks < 1 ? 1 : nBlocks;
+    const int64_t tile = n < ZC_TILE ? n : ZC_TILE;
+    const int64_t cWaves = n < ZC_MAX_WAVES ? n : ZC_MAX_WAVES, mWaves = n < ZM_MAX_WAVES ? n : ZM_MAX_WAVES;
+    return 4096 + cWaves * zc::SLAB_BYTES + mWaves * ZM_TABLE_BYTES + tile * zc::ITEM_BYTES;
 }
 
+// variant 0 (default): match-finder kernel + entropy kernel for one-block inputs, one kernel for the rest; 1: the same with
+// serial probing; 2: everything in the one kernel; 100: timing aid (one kernel, stop after the match finder)
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant)
 {
-    (void)variant;
     (void)scratchBytes;
     if (a.nBlocks <= 0) {
         return hipSuccess;
     }
     uint8_t* base = (uint8_t*)scratch;
     int32_t* counter = (int32_t*)base;
-    hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
-    if (e != hipSuccess) return e;
-    const unsigned grid = (unsigned)(a.nBlocks < ZC_MAX_WAVES ? a.nBlocks : ZC_MAX_WAVES);
-    hipLaunchKernelGGL(zstd_compress_kernel, dim3(grid), dim3(64), 0, stream, a, base + 4096, counter);
+    uint8_t* slabs = base + 4096;
+    uint8_t* tableSlabs = slabs + (int64_t)(a.nBlocks < ZC_MAX_WAVES ? a.nBlocks : ZC_MAX_WAVES) * zc::SLAB_BYTES;
+    uint8_t* itemScratch = tableSlabs + (int64_t)(a.nBlocks < ZM_MAX_WAVES ? a.nBlocks : ZM_MAX_WAVES) * ZM_TABLE_BYTES;
+    const bool split = variant == 0 || variant == 1;
+    const int32_t tile = split ? ZC_TILE : a.nBlocks;
+    for (int32_t first = 0; first < a.nBlocks; first += tile) {
+        const int32_t count = a.nBlocks - first < tile ? a.nBlocks - first : tile;
+        hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
+        if (e != hipSuccess) return e;
+        if (split) {
+            const unsigned mgrid = (unsigned)(count < ZM_MAX_WAVES ? count : ZM_MAX_WAVES);
+            hipLaunchKernelGGL(zstd_match_kernel, dim3(mgrid), dim3(64), 0, stream, a, tableSlabs, itemScratch, first, count, counter, variant == 1 ? 0 : 1);
+        }
+        const unsigned grid = (unsigned)(count < ZC_MAX_WAVES ? count : ZC_MAX_WAVES);
+        hipLaunchKernelGGL(zstd_compress_kernel, dim3(grid), dim3(64), 0, stream, a, slabs, counter + 8, split ? itemScratch : (uint8_t*)nullptr, first, count);
+    }
     return hipGetLastError();
 }
 

@@ -212,7 +212,7 @@ def encoder_inputs():
     return blocks
 
 
-@pytest.mark.parametrize("variant", [0, 1], ids=["batch-probe", "serial-probe"])
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["two-kernel", "two-kernel-serial-probe", "one-kernel"])
 def test_zstd_compress_is_bit_exact_with_oracle(gb, o, variant):
     blocks = encoder_inputs()
     blocks += [b for b in common.synthetic_blocks(77, 12)]   # RandomGenerator-style data: long literal runs, many same-hash positions per batch
