@@ -20,6 +20,7 @@ hipError_t launch_snappy_decompress(const BatchArgs& a, hipStream_t stream, int 
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass);
 hipError_t launch_lz4_decompress_lanes(const BatchArgs& a, hipStream_t stream, int ringClass);
 hipError_t launch_lz4_decompress_steps(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass);
+hipError_t launch_lz4_decompress_seqpar(const BatchArgs& a, hipStream_t stream);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
 hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant);
@@ -40,7 +41,7 @@ struct achip_ctx {
     // options
     int lz4dGroup = 4;       // lanes per block: measured best on MI355X (profiles/r01_sweep_v2_rings.txt)
     int snappydGroup = 4;
-    int lz4dVariant = 1;     // 0 = direct-to-HBM groups (lz4_decompress.hip), 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 2 = LDS rings, a lane per block (lz4_decompress_v3.hip), 3 = lane groups driven as a uniform-step state machine (lz4_decompress_v4.hip)
+    int lz4dVariant = 1;     // 0 = direct-to-HBM groups (lz4_decompress.hip), 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 2 = LDS rings, a lane per block (lz4_decompress_v3.hip), 3 = lane groups driven as a uniform-step state machine (lz4_decompress_v4.hip), 4 = lane-per-block parse + lane-per-sequence execute (lz4_decompress_v5.hip)
     int snappydVariant = 1;
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
     int lz4cVariant = 1;     // 0 = serial probes, 1 = 64 probes per step (batch)
@@ -172,6 +173,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             e = ctx->lz4dVariant == 0   ? achip::launch_lz4_decompress(a, ctx->stream, ctx->lz4dGroup)
                 : ctx->lz4dVariant == 2 ? achip::launch_lz4_decompress_lanes(a, ctx->stream, ctx->ringClass)
                 : ctx->lz4dVariant == 3 ? achip::launch_lz4_decompress_steps(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass)
+                : ctx->lz4dVariant == 4 ? achip::launch_lz4_decompress_seqpar(a, ctx->stream)
                                         : achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass);
             break;
         case ACHIP_OP_LZ4_COMPRESS: e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint); break;

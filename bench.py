@@ -50,6 +50,7 @@ def parse_args():
     p.add_argument("--ring-pad", type=int, default=-1, help="LDS bytes between the ring pairs of consecutive blocks (multiple of 16)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true")
+    p.add_argument("--no-verify", action="store_true", help="DEBUG: skip the bit-exact check (kernel timing aids that leave work out); the line is then not a result")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--section", default="all", choices=["all", "zstd", "xxhash", "lz4frame"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-variant", type=int, default=-1, help="zstd decoder: 1 = five-stage pipeline (default), 0 = one-kernel decoder")
@@ -252,7 +253,9 @@ def main():
 
     # ---- untimed verification: every block ok and bit-exact ----
     assert int((status != 0).sum()) == 0, "a block failed"
-    if wl.endswith("decompress"):
+    if args.no_verify:
+        print("DEBUG RUN: output not verified", file=sys.stderr)
+    elif wl.endswith("decompress"):
         assert int((out_len != bs).sum()) == 0
         ok = bool((dst[:n_local * bs].view(reps, pool_n * bs) == pool_plain.unsqueeze(0)).all())
         assert ok, "decompressed output differs from the plaintext"

@@ -78,11 +78,11 @@ def test_decompress_matches_plaintext_all_decoder_configs(gb, o, codec, cfg):
     configure(gb, codec, DECODERS[0])
 
 
-@pytest.mark.parametrize("cfg", [(2, 4, 0), (2, 4, 1), (3, 4, 0), (3, 4, 1), (3, 1, 0), (3, 2, 0), (3, 2, 1), (3, 8, 0), (3, 8, 1)],
+@pytest.mark.parametrize("cfg", [(2, 4, 0), (2, 4, 1), (3, 4, 0), (3, 4, 1), (3, 1, 0), (3, 2, 0), (3, 2, 1), (3, 8, 0), (3, 8, 1), (4, 4, 0)],
                          ids=lambda c: "variant%d-gs%d-rc%d" % c)
 def test_lz4_experimental_decoders(gb, o, cfg):
     """variant 2 (lz4_decompress_v3.hip, one lane per block) and variant 3 (lz4_decompress_v4.hip, uniform-step state machine
-    over lane groups): plaintext, status and error offsets equal the oracle's"""
+    over lane groups), variant 4 (lz4_decompress_v5.hip, lane-per-block parse + lane-per-sequence execute): plaintext, status and error offsets equal the oracle's"""
     rng = np.random.default_rng(7)
     blocks = all_blocks()
     cases = [(o.compress("lz4", b), len(b)) for b in blocks] + [(o.compress("lz4", b), len(b) + 37) for b in blocks[:20]]
