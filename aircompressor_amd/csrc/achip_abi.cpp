@@ -17,10 +17,11 @@
 namespace achip {
 hipError_t launch_lz4_decompress(const BatchArgs& a, hipStream_t stream, int groupSize);
 hipError_t launch_snappy_decompress(const BatchArgs& a, hipStream_t stream, int groupSize);
-hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass);
+hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 hipError_t launch_lz4_decompress_lanes(const BatchArgs& a, hipStream_t stream, int ringClass);
 hipError_t launch_lz4_decompress_steps(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass);
-hipError_t launch_lz4_decompress_seqpar(const BatchArgs& a, hipStream_t stream);
+hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
+hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
 hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant);
@@ -41,7 +42,8 @@ struct achip_ctx {
     // options
     int lz4dGroup = 4;       // lanes per block: measured best on MI355X (profiles/r01_sweep_v2_rings.txt)
     int snappydGroup = 4;
-    int lz4dVariant = 1;     // 0 = direct-to-HBM groups (lz4_decompress.hip), 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 2 = LDS rings, a lane per block (lz4_decompress_v3.hip), 3 = lane groups driven as a uniform-step state machine (lz4_decompress_v4.hip), 4 = lane-per-block parse + lane-per-sequence execute (lz4_decompress_v5.hip)
+    int lz4dAutoMinBlocks = 131072;  // auto mode considers the lane-per-block decoder (64 blocks per wavefront) from this batch size on
+    int lz4dVariant = 5;     // 0 = direct-to-HBM groups (lz4_decompress.hip), 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 2 = LDS rings, a lane per block (lz4_decompress_v3.hip), 3 = lane groups driven as a uniform-step state machine (lz4_decompress_v4.hip), 4 = a lane per block, copies straight between the global buffers (lz4_decompress_v5.hip), 5 = auto: 4 for large mixed batches, else 1
     int snappydVariant = 1;
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
     int lz4cVariant = 1;     // 0 = serial probes, 1 = 64 probes per step (batch)
@@ -53,6 +55,7 @@ struct achip_ctx {
     int scratchPoison = -1;
     int32_t lastZstddBlocks = 0;  // achip_ctx_get_stat
     int lastZstddVariant = 0;
+    bool lastLz4dAuto = false;  // the last LZ4 decode ran in auto mode: its probe count leads the scratch
     int maxSrcLenHint = 0;
     // scratch for the zstd pipeline (grown on demand)
     void* scratch = nullptr;
@@ -168,13 +171,28 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
     }
     HIP_TRY(hipSetDevice(ctx->device));
     hipError_t e = hipSuccess;
+    ctx->lastLz4dAuto = false;
     switch (op) {
         case ACHIP_OP_LZ4_DECOMPRESS:
+            if (ctx->lz4dVariant == 5 && a.nBlocks >= ctx->lz4dAutoMinBlocks) {
+                // auto: large batches whose neighbouring blocks are of different kinds go to the lane-per-block decoder, the
+                // rest to the rings.  The choice is made on the device (no host round trip): a probe counts the mixed groups,
+                // both decoders are launched and the one not chosen returns at once.
+                int32_t r = ensure_scratch(ctx, 4096);
+                if (r < 0) return r;
+                int32_t* mixedGroups = (int32_t*)ctx->scratch;
+                ctx->lastLz4dAuto = true;
+                ctx->lastZstddBlocks = 0;
+                e = achip::launch_lz4_mixed_groups(a, ctx->stream, mixedGroups);
+                if (e == hipSuccess) e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, mixedGroups);
+                if (e == hipSuccess) e = achip::launch_lz4_decompress_lanecopy(a, ctx->stream, mixedGroups);
+                break;
+            }
             e = ctx->lz4dVariant == 0   ? achip::launch_lz4_decompress(a, ctx->stream, ctx->lz4dGroup)
                 : ctx->lz4dVariant == 2 ? achip::launch_lz4_decompress_lanes(a, ctx->stream, ctx->ringClass)
                 : ctx->lz4dVariant == 3 ? achip::launch_lz4_decompress_steps(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass)
-                : ctx->lz4dVariant == 4 ? achip::launch_lz4_decompress_seqpar(a, ctx->stream)
-                                        : achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass);
+                : ctx->lz4dVariant == 4 ? achip::launch_lz4_decompress_lanecopy(a, ctx->stream, nullptr)
+                                        : achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, nullptr);
             break;
         case ACHIP_OP_LZ4_COMPRESS: e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint); break;
         case ACHIP_OP_SNAPPY_DECOMPRESS:
@@ -481,6 +499,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->snappydGroup = (int)value;
     }
     else if (k == "lz4.decompress.variant") ctx->lz4dVariant = (int)value;
+    else if (k == "lz4.decompress.auto_min_blocks") ctx->lz4dAutoMinBlocks = (int)value;
     else if (k == "snappy.decompress.variant") ctx->snappydVariant = (int)value;
     else if (k == "decompress.ring_class") ctx->ringClass = (int)value;
     else if (k == "lz4.compress.variant") ctx->lz4cVariant = (int)value;
@@ -505,6 +524,13 @@ int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name)
 {
     if (!ctx || !name) return -1;
     std::string k(name);
+    if (k == "lz4.decompress.mixed_groups") {  // auto mode's probe result of the last LZ4 decode (-1: it did not run)
+        if (!ctx->lastLz4dAuto || ctx->scratch == nullptr) return -1;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+        int32_t v = 0;
+        if (hipMemcpy(&v, ctx->scratch, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        return v;
+    }
     const std::string prefix = "zstd.decompress.fallback_";
     if (k.compare(0, prefix.size(), prefix) == 0) {
         // "items": all items handed to the one-kernel decoder; "stage1".."stage5": by the stage that handed them over

@@ -31,6 +31,10 @@ struct BatchArgs {
 
 __device__ __forceinline__ constexpr int32_t mk_status(int cls, int detail) { return -(cls + 16 * detail); }
 
+// LZ4 decoder choice of the auto mode: a batch is "mixed" when in more than a quarter of its groups of 16 consecutive
+// blocks (= the blocks one wavefront of the ring decoder works on) the compressed sizes differ by more than 2x
+__device__ __forceinline__ bool lz4_batch_is_mixed(int32_t mixedGroups, int32_t nBlocks) { return (int64_t)mixedGroups * 4 > (nBlocks + 15) / 16; }
+
 // ---- unaligned little-endian accessors (global memory; gfx950 runs in unaligned-access mode) ----
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));

@@ -10,8 +10,12 @@
 namespace achip {
 
 template <int GS, int IN_RING, int OUT_RING, int GPL>
-__global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a)
+__global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
+    // auto mode (achip_abi.cpp): both LZ4 decoders are launched, the probe's count of mixed 16-block groups picks one
+    if (mixedGroups != nullptr && lz4_batch_is_mixed(*mixedGroups, a.nBlocks)) {
+        return;
+    }
     ACHIP_DYNAMIC_LDS(smem);
     constexpr int GROUPS_PER_WG = 256 / GS;
     const int g = threadIdx.x & (GS - 1);
@@ -42,26 +46,26 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a)
 }
 
 template <int GS, int IN_RING, int OUT_RING, int GPL = 1>
-static hipError_t lz4d2_launch(const BatchArgs& a, hipStream_t stream)
+static hipError_t lz4d2_launch(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups)
 {
     constexpr int GROUPS_PER_WG = 256 / GS;
     const unsigned grid = (unsigned)((a.nBlocks + GROUPS_PER_WG - 1) / GROUPS_PER_WG);
     const size_t lds = (size_t)GROUPS_PER_WG * (IN_RING + OUT_RING + a.ringPad);
-    hipLaunchKernelGGL((lz4_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((lz4_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
     return hipGetLastError();
 }
 
 // ringClass: 0 = compact rings (more blocks per CU), 1 = large rings (longer LDS reach)
-hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass)
+hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups)
 {
     switch (groupSize) {
-        case 1: return ringClass ? lz4d2_launch<1, 128, 256, 4>(a, stream) : lz4d2_launch<1, 64, 128, 2>(a, stream);
-        case 2: return ringClass ? lz4d2_launch<2, 128, 256, 2>(a, stream) : lz4d2_launch<2, 64, 128, 1>(a, stream);
-        case 4: return ringClass ? lz4d2_launch<4, 256, 512>(a, stream) : lz4d2_launch<4, 128, 256>(a, stream);
-        case 8: return ringClass ? lz4d2_launch<8, 512, 1024>(a, stream) : lz4d2_launch<8, 256, 512>(a, stream);
-        case 32: return ringClass ? lz4d2_launch<32, 2048, 4096>(a, stream) : lz4d2_launch<32, 1024, 2048>(a, stream);
-        case 64: return ringClass ? lz4d2_launch<64, 4096, 8192>(a, stream) : lz4d2_launch<64, 2048, 4096>(a, stream);
-        default: return ringClass ? lz4d2_launch<16, 1024, 2048>(a, stream) : lz4d2_launch<16, 512, 1024>(a, stream);
+        case 1: return ringClass ? lz4d2_launch<1, 128, 256, 4>(a, stream, mixedGroups) : lz4d2_launch<1, 64, 128, 2>(a, stream, mixedGroups);
+        case 2: return ringClass ? lz4d2_launch<2, 128, 256, 2>(a, stream, mixedGroups) : lz4d2_launch<2, 64, 128, 1>(a, stream, mixedGroups);
+        case 4: return ringClass ? lz4d2_launch<4, 256, 512>(a, stream, mixedGroups) : lz4d2_launch<4, 128, 256>(a, stream, mixedGroups);
+        case 8: return ringClass ? lz4d2_launch<8, 512, 1024>(a, stream, mixedGroups) : lz4d2_launch<8, 256, 512>(a, stream, mixedGroups);
+        case 32: return ringClass ? lz4d2_launch<32, 2048, 4096>(a, stream, mixedGroups) : lz4d2_launch<32, 1024, 2048>(a, stream, mixedGroups);
+        case 64: return ringClass ? lz4d2_launch<64, 4096, 8192>(a, stream, mixedGroups) : lz4d2_launch<64, 2048, 4096>(a, stream, mixedGroups);
+        default: return ringClass ? lz4d2_launch<16, 1024, 2048>(a, stream, mixedGroups) : lz4d2_launch<16, 512, 1024>(a, stream, mixedGroups);
     }
 }
 

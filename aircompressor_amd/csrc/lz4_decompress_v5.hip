@@ -1,26 +1,34 @@
-// lz4_decompress_v5.hip -- batched LZ4 block decode for gfx950: lane-per-block PARSE, sequence-parallel EXECUTE.
+// lz4_decompress_v5.hip -- batched LZ4 block decode for gfx950: a lane per block, copies straight between global buffers.
 //
 // Same contract and the same Java-order checks as lz4_decompress_v2.hip (M/lz4/Lz4RawDecompressor.java:35-198).
 //
 // The ring decoders (v2) spend their time issuing instructions: a wavefront walks 16 blocks, one sequence of each at a
 // time, and executes the union of the paths those 16 state machines take (profiles/r01_notes.md: 2.3x the instructions
-// of a converged wavefront; ~128 SIMD cycles per sequence on text).  Here the two halves of the work are separated so
-// that each is converged:
-//   PARSE    every lane owns a block (64 blocks per wavefront) and walks its token stream without touching the literal
-//            bytes: token, length extensions, offset, the Java checks in their order.  Up to K sequence records
-//            {literal source, literal length, match length, offset} per block go to LDS.  One record per trip for
-//            every lane, whatever the lengths are.
-//   EXECUTE  the wavefront then takes 64/K blocks at a time, one LANE PER SEQUENCE: a row scan of the lengths gives every
-//            sequence its output position; all literal runs are copied at once (they depend on nothing); matches are
-//            resolved in rounds (a match may run once its source lies below the block's high-water mark -- the start of
-//            the first match still pending -- or when it is that first match); in text most matches reach back farther
-//            than the 16 sequences of a row, so a row takes two or three rounds.  Copies are exact (no scribbling: the
-//            neighbouring bytes belong to another lane).  Long copies are done by the whole wavefront.
-// Output goes straight to HBM (L2 combines the pieces); there is no output ring.
+// of a converged wavefront; ~128 SIMD cycles per sequence on text).  Here every LANE owns a block (64 blocks per
+// wavefront) and a trip of the loop is the same straight line for all of them:
+//   parse    token, length extensions, offset -- from the lane's LDS window on its compressed stream (16-byte granules,
+//            requested ahead; literal bytes are jumped over) -- with the Java checks in their order;
+//   copy     ONE wavefront-wide copy step moves the literal run and the match of all 64 sequences: all loads of the step
+//            are issued before its stores, so a trip costs about one memory round trip.  Up to 32 bytes of a copy are
+//            moved by its own lane (two overlapping 16-byte pieces, or 8/4/2/1); what is longer is cut into 16-byte
+//            chunks that are dealt out evenly to the 64 lanes (consecutive lanes take consecutive chunks), so neither a
+//            64 KiB literal run nor a skewed mix of lengths leaves lanes idle.  Copies are exact.
+//   A match that overlaps itself (offset < length) or reads this trip's literals takes extra steps: one period first,
+//   then -- the written part repeating the period -- twice as much per step.
+// There are no output rings: sources are read from, and bytes written to, the output buffer itself (the L2 holds the
+// recent window; a wavefront's vector memory operations are performed in program order).
 #include "achip_device.h"
 
 namespace achip {
 namespace sp {
+
+// 16-byte load that does not ask the L2 to keep the line: back-reference sources are touched once, and every line they
+// would park in the L2 pushes out a half-written output line of some other block (262144 blocks are open at once)
+__device__ __forceinline__ u32x4 ld16_once(const uint8_t* p, bool nt)
+{
+    typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
+    return nt ? __builtin_nontemporal_load((const u32x4_unaligned*)p) : ld16(p);
+}
 
 // the lane's window on its compressed stream: an LDS ring column fed with aligned 16-byte granules, one requested ahead
 template <int IN_DW>
@@ -33,6 +41,7 @@ struct LaneInput {
     int32_t inEndV;
     int32_t inLoadedV;  // virtual [.., inLoadedV) is in the ring (as far back as the ring reaches)
     u32x4 pending;      // the granule at inLoadedV
+    bool ntIn = false;
 
     __device__ __forceinline__ void init(uint32_t* lds, const uint8_t* in, int32_t inLimit)
     {
@@ -47,7 +56,7 @@ struct LaneInput {
     {
         u32x4 d = {0, 0, 0, 0};
         if (v >= inBase && v + 16 <= inEndV) {
-            d = *(const u32x4*)(inAligned + v);
+            d = ntIn ? __builtin_nontemporal_load((const u32x4*)(inAligned + v)) : *(const u32x4*)(inAligned + v);
         }
         else if (v + 16 > inBase && v < inEndV) {  // first / last granule: byte-guarded (cold)
             uint32_t w[4] = {0, 0, 0, 0};
@@ -95,6 +104,16 @@ struct LaneInput {
         const int32_t v = pos + inBase;
         return (inR[((v >> 2) & (IN_DW - 1)) * 64] >> (8 * (v & 3))) & 0xFF;
     }
+    // 16 input bytes at pos (resident: ensure_input(pos, 20))
+    __device__ __forceinline__ u32x4 in_u128(int32_t pos) const
+    {
+        const int32_t v = pos + inBase;
+        const int32_t d = v >> 2;
+        const uint32_t r0 = inR[((d + 0) & (IN_DW - 1)) * 64], r1 = inR[((d + 1) & (IN_DW - 1)) * 64], r2 = inR[((d + 2) & (IN_DW - 1)) * 64],
+                       r3 = inR[((d + 3) & (IN_DW - 1)) * 64], r4 = inR[((d + 4) & (IN_DW - 1)) * 64];
+        const uint32_t s = (uint32_t)(v & 3);
+        return u32x4{alignbyte_u32(r1, r0, s), alignbyte_u32(r2, r1, s), alignbyte_u32(r3, r2, s), alignbyte_u32(r4, r3, s)};
+    }
 };
 
 // inclusive prefix sum over aligned segments of SEG (8 or 16) lanes
@@ -125,102 +144,200 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int srcLane)
     return ((uint64_t)(uint32_t)__shfl((int32_t)(v >> 32), srcLane) << 32) | (uint32_t)__shfl((int32_t)v, srcLane);
 }
 
-constexpr int REC_STRIDE = 65;  // dwords between consecutive (record, field) rows: spreads a block's records over the banks
-constexpr int HEAD = 32;        // bytes of a copy its own lane moves; the rest of all copies is dealt out to the lanes in 16-byte chunks
+constexpr int HEAD = 32;   // bytes of a copy its own lane moves per trip
+constexpr int BIG = 1024;  // ... and with more than this, moved by the whole wavefront, one copy after the other
+constexpr int LONG = 128;  // a copy with more than this left is cut into 16-byte chunks that are dealt out to all lanes
 
-struct CopyScratch {  // LDS, per wavefront
-    uint32_t pre[64], n[64];
-    uint64_t dst[64], src[64];
+struct CopyScratch {  // LDS, per wavefront: the copies of the current step, for the chunk loop
+    uint32_t pre[64];    // running chunk count (inclusive) over the lanes
+    uint32_t c0[64];     // chunks of the lane's first copy
+    uint32_t n[2][64];
+    uint64_t dst[2][64], src[2][64];
 };
 
-// One wavefront-wide copy step: every active lane has n bytes to move from src to dst; the ranges of a lane do not
-// overlap and every source is final.  Exact (no byte outside [dst, dst + n) is written, none outside [src, src + n) read).
-// All loads of a step are issued before its stores, so a step costs about one memory round trip however the lengths are
-// distributed: <= HEAD bytes by the lane itself (two overlapping 16-byte pieces, or 8/4/2/1), the remainders as 16-byte
-// chunks handed out evenly (a binary search over the running chunk count finds a chunk's owner), the last chunk of a copy
-// ending exactly at its end.
-__device__ __forceinline__ void copy_step(CopyScratch& S, int lane, bool active, uint8_t* dst, const uint8_t* src, int32_t n)
+struct HeadRegs {
+    u32x4 A, B;
+};
+
+// first <= HEAD bytes of a copy: loads.  `srcEnd` bounds what may be read: a short run is fetched with one 16-byte load
+// when that stays inside the buffer (the bytes past the run are not used), byte by byte otherwise (cold).
+__device__ __forceinline__ void head_load(HeadRegs& r, const uint8_t* src, int32_t m, const uint8_t* srcEnd, bool nt)
 {
-    const int32_t m = active ? (n < HEAD ? n : HEAD) : 0;
-    const bool wide = m >= 16;
-    u32x4 A = {0, 0, 0, 0}, B = {0, 0, 0, 0};
-    uint64_t v8 = 0;
-    uint32_t v4 = 0, v2 = 0, v1 = 0;
-    if (wide) {
-        A = ld16(src);
-        B = ld16(src + m - 16);
-    }
-    else {
-        if (m & 8) v8 = ld8(src);
-        if (m & 4) v4 = ld4(src + (m & 8));
-        if (m & 2) v2 = ld2(src + (m & 12));
-        if (m & 1) v1 = src[m & 14];
-    }
-    const int32_t chunks = (active && n > HEAD) ? (n - HEAD + 15) >> 4 : 0;
-    const int32_t incl = wave_scan(chunks, lane);
-    const int32_t total = __builtin_amdgcn_readlane(incl, 63);
-    if (total > 0) {  // (uniform) publish the copies for the chunk loop below
-        S.pre[lane] = (uint32_t)incl;
-        S.n[lane] = (uint32_t)n;
-        S.dst[lane] = (uint64_t)(uintptr_t)dst;
-        S.src[lane] = (uint64_t)(uintptr_t)src;
-    }
-    if (wide) {
-        st16(dst, A);
-        st16(dst + m - 16, B);
-    }
-    else {
-        if (m & 8) st8(dst, v8);
-        if (m & 4) st4(dst + (m & 8), v4);
-        if (m & 2) st2(dst + (m & 12), v2);
-        if (m & 1) dst[m & 14] = (uint8_t)v1;
-    }
-    if (total > 0) {
-        wave_mem_order();
-        for (int32_t c0 = 0; c0 < total; c0 += 256) {
-            u32x4 v[4];
-            uint8_t* d[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int32_t c = c0 + 64 * t + lane;
-                d[t] = nullptr;
-                if (c < total) {
-                    int i = 0;
-#pragma unroll
-                    for (int step = 32; step >= 1; step >>= 1) {
-                        if ((int32_t)S.pre[i + step - 1] <= c) {
-                            i += step;
-                        }
-                    }
-                    const int32_t before = i > 0 ? (int32_t)S.pre[i - 1] : 0;
-                    const int32_t len = (int32_t)S.n[i];
-                    int32_t p = HEAD + 16 * (c - before);
-                    p = p + 16 > len ? len - 16 : p;
-                    v[t] = ld16((const uint8_t*)(uintptr_t)S.src[i] + p);
-                    d[t] = (uint8_t*)(uintptr_t)S.dst[i] + p;
-                }
+    r.A = u32x4{0, 0, 0, 0};
+    r.B = r.A;
+    if (m > 0) {
+        if (src + 16 <= srcEnd) {
+            r.A = ld16_once(src, nt);
+        }
+        else {
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll 1
+            for (int i = 0; i < m && i < 16; i++) {
+                w[i >> 2] |= (uint32_t)src[i] << (8 * (i & 3));
             }
+            r.A = u32x4{w[0], w[1], w[2], w[3]};
+        }
+        if (m >= 16) {
+            r.B = ld16_once(src + m - 16, nt);
+        }
+    }
+}
+// Stores.  A run shorter than 16 bytes is written with ONE 16-byte store when that stays inside the block's output
+// capacity `dstEnd`: the bytes behind the run are the lane's own next output positions and are written again, in program
+// order, by its later copies (the Java fast path overshoots the same way, within the buffer, 8 bytes at a time
+// M/lz4/Lz4RawDecompressor.java:98-104,174-187).  Close to the end of the capacity: exact, 8/4/2/1.
+__device__ __forceinline__ void head_store(const HeadRegs& r, uint8_t* dst, int32_t m, const uint8_t* dstEnd)
+{
+    if (m >= 16) {
+        st16(dst, r.A);
+        st16(dst + m - 16, r.B);
+    }
+    else if (m > 0 && dst + 16 <= dstEnd) {
+        st16(dst, r.A);
+    }
+    else if (m > 0) {
+        const uint64_t lo = ((uint64_t)r.A.y << 32) | r.A.x, hi = ((uint64_t)r.A.w << 32) | r.A.z;
+        if (m & 8) st8(dst, lo);
+        const uint64_t x8 = (m & 8) ? hi : lo;
+        if (m & 4) st4(dst + (m & 8), (uint32_t)x8);
+        const uint32_t x4 = (m & 4) ? (uint32_t)(x8 >> 32) : (uint32_t)x8;
+        if (m & 2) st2(dst + (m & 12), x4);
+        const uint32_t x2 = (m & 2) ? x4 >> 16 : x4;
+        if (m & 1) dst[m & 14] = (uint8_t)x2;
+    }
+}
+
+// One wavefront-wide copy step: every lane has up to two copies (n0 bytes src0 -> dst0, then n1 bytes src1 -> dst1; a
+// length of 0 = none).  Within a lane the ranges do not overlap and every source byte is final before the step.  Exact.
+// `have0`: the first 16 bytes of copy 0 are in h0.A already (a literal run of <= 16 bytes comes from the LDS window).
+// `end1` is the end of the output capacity (copy 1 reads the output buffer; both copies write it).
+template <bool TWO>
+__device__ __forceinline__ void copy_step(CopyScratch& S, int lane, HeadRegs h0, bool have0, uint8_t* dst0, const uint8_t* src0, int32_t n0,
+                                          const uint8_t* end0, uint8_t* dst1, const uint8_t* src1, int32_t n1, const uint8_t* end1, bool nt)
+{
+    HeadRegs h1;
+    const int32_t m0 = n0 < HEAD ? n0 : HEAD, m1 = n1 < HEAD ? n1 : HEAD;
+    if constexpr (TWO) {
+        if (!have0) {
+            head_load(h0, src0, m0, end0, nt);
+        }
+    }
+    head_load(h1, src1, m1, end1, nt);
+    const bool longer = (TWO && n0 > HEAD) || n1 > HEAD;
+    const bool anyLonger = __ballot(longer) != 0;
+    if (anyLonger) {  // (uniform)
+        // more than BIG bytes: a plain memcpy by the whole wavefront, bases in scalar registers, 4 KiB per round
+        const bool big0 = TWO && n0 > BIG, big1 = n1 > BIG;
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                if (d[t] != nullptr) {
-                    st16(d[t], v[t]);
+        for (int which = TWO ? 0 : 1; which < 2; which++) {
+            for (unsigned long long m = __ballot(which ? big1 : big0); m != 0; m &= m - 1) {
+                const int l = __builtin_ctzll(m);
+                const uint64_t sv = (uint64_t)(uintptr_t)(which ? src1 : src0), dv = (uint64_t)(uintptr_t)(which ? dst1 : dst0);
+                const uint8_t* const s = (const uint8_t*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int32_t)(sv >> 32), l) << 32) |
+                                                                     (uint32_t)__builtin_amdgcn_readlane((int32_t)sv, l));
+                uint8_t* const d = (uint8_t*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int32_t)(dv >> 32), l) << 32) |
+                                                         (uint32_t)__builtin_amdgcn_readlane((int32_t)dv, l));
+                const int32_t len = __builtin_amdgcn_readlane(which ? n1 : n0, l);
+                for (int32_t base = HEAD + 16 * lane; base < len; base += 4096) {
+                    u32x4 v[4];
+                    int32_t p[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        p[t] = base + 1024 * t;
+                        p[t] = p[t] + 16 > len ? len - 16 : p[t];  // (the last piece ends at the end; pieces past it repeat it)
+                        v[t] = ld16_once(s + p[t], nt);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        st16(d + p[t], v[t]);
+                    }
                 }
             }
         }
-        wave_mem_order();
+        // the rest: publish the copies for the chunk loop below
+        const int32_t c0 = (TWO && n0 > HEAD && !big0) ? (n0 - HEAD + 15) >> 4 : 0;
+        const int32_t c1 = (n1 > HEAD && !big1) ? (n1 - HEAD + 15) >> 4 : 0;
+        S.pre[lane] = (uint32_t)wave_scan(c0 + c1, lane);
+        S.c0[lane] = (uint32_t)c0;
+        S.n[0][lane] = (uint32_t)n0;
+        S.n[1][lane] = (uint32_t)n1;
+        S.dst[0][lane] = (uint64_t)(uintptr_t)dst0;
+        S.src[0][lane] = (uint64_t)(uintptr_t)src0;
+        S.dst[1][lane] = (uint64_t)(uintptr_t)dst1;
+        S.src[1][lane] = (uint64_t)(uintptr_t)src1;
     }
+    if (!anyLonger) {
+        if constexpr (TWO) {
+            head_store(h0, dst0, m0, end1);
+        }
+        head_store(h1, dst1, m1, end1);
+        wave_mem_order();
+        return;
+    }
+    wave_mem_order();
+    const int32_t total = (int32_t)S.pre[63];
+    // first batch of chunks is loaded before the heads are stored: everything of a short step is in flight together
+    bool headsStored = false;
+    constexpr int T = 2;  // chunks per lane in flight
+    for (int32_t c0 = 0; c0 < total; c0 += 64 * T) {
+        u32x4 v[T];
+        uint8_t* d[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const int32_t c = c0 + 64 * t + lane;
+            d[t] = nullptr;
+            if (c < total) {
+                int i = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    if ((int32_t)S.pre[i + step - 1] <= c) {
+                        i += step;
+                    }
+                }
+                int32_t q = c - (i > 0 ? (int32_t)S.pre[i - 1] : 0);
+                const int32_t first = (int32_t)S.c0[i];
+                const int which = q >= first ? 1 : 0;
+                q -= which ? first : 0;
+                const int32_t len = (int32_t)S.n[which][i];
+                int32_t p = HEAD + 16 * q;
+                p = p + 16 > len ? len - 16 : p;
+                v[t] = ld16_once((const uint8_t*)(uintptr_t)S.src[which][i] + p, nt);
+                d[t] = (uint8_t*)(uintptr_t)S.dst[which][i] + p;
+            }
+        }
+        if (!headsStored) {
+            if constexpr (TWO) {
+                head_store(h0, dst0, m0, end1);
+            }
+            head_store(h1, dst1, m1, end1);
+            headsStored = true;
+        }
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            if (d[t] != nullptr) {
+                st16(d[t], v[t]);
+            }
+        }
+    }
+    if (!headsStored) {  // (only big copies this step)
+        if constexpr (TWO) {
+            head_store(h0, dst0, m0, end1);
+        }
+        head_store(h1, dst1, m1, end1);
+    }
+    wave_mem_order();
 }
 
 }  // namespace sp
 
-// K: records per block per round (8 or 16); 64 / K blocks are executed side by side
-template <int IN_DW, int K>
-__global__ __launch_bounds__(64) void lz4_decompress_seqpar_kernel(BatchArgs a)
+template <int IN_DW>
+__global__ __launch_bounds__(64) void lz4_decompress_lanecopy_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
     using namespace sp;
-    constexpr int ROWS = 64 / K;
+    if (mixedGroups != nullptr && !lz4_batch_is_mixed(*mixedGroups, a.nBlocks)) {  // auto mode: the ring decoder takes this batch
+        return;
+    }
     __shared__ uint32_t ldsIn[IN_DW * 64];
-    __shared__ uint32_t ldsRec[4 * K * REC_STRIDE];
     __shared__ CopyScratch S;
     const int lane = threadIdx.x;
     const int64_t block = (int64_t)blockIdx.x * 64 + lane;
@@ -231,6 +348,7 @@ __global__ __launch_bounds__(64) void lz4_decompress_seqpar_kernel(BatchArgs a)
     const int32_t outLimit = have ? a.dstCap[block] : 0;
 
     LaneInput<IN_DW> R;
+    R.ntIn = a.ringPad == 112;
     R.init(ldsIn + lane, in, inLimit);
 
     int32_t st = 0;
@@ -260,22 +378,35 @@ __global__ __launch_bounds__(64) void lz4_decompress_seqpar_kernel(BatchArgs a)
         }
     }
 
-    while (__ballot(!done) != 0) {
-        // ---------------- PARSE: up to K records per lane ----------------
-        const int32_t opStart = op;
-        int32_t cnt = 0;
-        for (int k = 0; k < K; k++) {
-            if (__ballot(!done) == 0) {
-                break;
+    // the copies in progress, as offsets: literal run (litRem bytes left: in[litPos..] -> out[litOut..]) and match (rem
+    // bytes left at out[cur..], distance dist -- the offset, doubled with every whole period written)
+    int32_t litPos = 0, litOut = 0, litRem = 0;
+    int32_t cur = 0, rem = 0, dist = 0;
+    int32_t periodic = 0;  // out[periodic .. cur) repeats with the match's offset: dist may be any multiple of it that stays inside
+    const uint8_t* const inEnd = in + inLimit;
+    const uint8_t* const outEnd = out + outLimit;
+    int32_t tokenMl = 0;     // low nibble of the token whose match header is still to be parsed
+    bool headerDue = false;  // the literal run was too long for the window: its match header is parsed when the run is copied
+    while (__ballot(!done || rem > 0 || litRem > 0) != 0) {
+        // ---- parse (lanes whose copies are complete): ONE 16-byte window at ip holds the token, a literal run of up to 12
+        // bytes, the offset and the first match-length extension byte -- a whole sequence of the common kind.  A longer run
+        // is copied from the input buffer over the next trips and its match header is parsed after it. ----
+        HeadRegs h0;
+        h0.A = u32x4{0, 0, 0, 0};
+        h0.B = h0.A;
+        bool have0 = false;
+        if (rem == 0 && litRem == 0 && !done) {
+            if (!headerDue && ip >= inLimit) {  // the Java loop condition :59
+                done = true;
             }
-            if (!done) {
-                if (ip >= inLimit) {  // the Java loop condition :59
-                    done = true;
-                }
-                else {
-                    R.ensure_input(ip, 12);
-                    uint64_t w = R.in_u64(ip);
-                    const int32_t token = (int32_t)(w & 0xFF);
+            else {
+                R.ensure_input(ip, 20);
+                const u32x4 W = R.in_u128(ip);
+                uint32_t hdr = W.x;  // header bytes: offset (2), first extension byte
+                bool parseHeader = headerDue;
+                if (!headerDue) {
+                    const int32_t token = (int32_t)(W.x & 0xFF);
+                    tokenMl = token & 0xF;
                     ip++;
                     int32_t lit = token >> 4;  // :62-77
                     if (lit == 0xF) {
@@ -283,12 +414,14 @@ __global__ __launch_bounds__(64) void lz4_decompress_seqpar_kernel(BatchArgs a)
                             LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
                         }
                         else {
-                            int32_t v;
-                            do {
+                            int32_t v = (int32_t)((W.x >> 8) & 0xFF);  // first extension byte: in the window
+                            ip++;
+                            lit += v;
+                            while (v == 255 && ip < inLimit - 15) {
                                 R.ensure_input(ip, 4);
                                 v = (int32_t)R.in_u8(ip++);
                                 lit = (int32_t)((uint32_t)lit + (uint32_t)v);
-                            } while (v == 255 && ip < inLimit - 15);
+                            }
                         }
                     }
                     if (!done && lit < 0) {
@@ -311,113 +444,102 @@ __global__ __launch_bounds__(64) void lz4_decompress_seqpar_kernel(BatchArgs a)
                         }
                     }
                     if (!done) {
-                        const int32_t litSrc = ip;
+                        litPos = ip;
+                        litOut = op;
+                        litRem = lit;
                         ip += lit;
                         op += lit;
-                        int32_t ml = 0;
-                        int32_t offset = 0;
+                        cur = op;
                         if (lastLiterals) {
                             done = true;
                         }
-                        else {
-                            R.ensure_input(ip, 12);
-                            w = R.in_u64(ip);
-                            offset = (int32_t)(w & 0xFFFF);  // :113-119
-                            ip += 2;
-                            if (offset == 0 || offset > op) {
-                                LZ4_FAIL(ACHIP_D_LZ4_OFFSET_OUTSIDE, ip);
-                            }
-                            else {
-                                ml = token & 0xF;  // :122-138
-                                bool bad = false;
-                                if (ml == 0xF) {
-                                    int32_t v;
-                                    do {
-                                        if (ip > inLimit - 5) {
-                                            bad = true;
-                                            break;
-                                        }
-                                        R.ensure_input(ip, 4);
-                                        v = (int32_t)R.in_u8(ip++);
-                                        ml = (int32_t)((uint32_t)ml + (uint32_t)v);
-                                    } while (v == 255);
-                                }
-                                ml = (int32_t)((uint32_t)ml + 4u);
-                                if (bad || ml < 0) {
-                                    LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
-                                }
-                                else {
-                                    const int64_t matchOutLimit = (int64_t)op + ml;
-                                    if (matchOutLimit > fastOutLimit - 4 && matchOutLimit > outLimit - 5) {  // :168-171
-                                        LZ4_FAIL(ACHIP_D_LZ4_LAST_5_LITERALS, ip);
-                                    }
-                                }
-                            }
-                            if (done) {  // the sequence failed after its literals: Java has copied them, nobody can tell
-                                ml = 0;
-                            }
-                            op += ml;
+                        if (lit <= 12) {  // (then there was no extension byte) the run sits in window bytes 1..12, the header behind it
+                            h0.A = u32x4{alignbyte_u32(W.y, W.x, 1), alignbyte_u32(W.z, W.y, 1), alignbyte_u32(W.w, W.z, 1), W.w >> 8};
+                            h0.B = h0.A;
+                            have0 = lit > 0;
+                            const uint32_t at = (uint32_t)lit + 1u;  // 1..13
+                            const uint32_t lo = at < 4 ? W.x : (at < 8 ? W.y : (at < 12 ? W.z : W.w));
+                            const uint32_t hi = at < 4 ? W.y : (at < 8 ? W.z : W.w);  // (at >= 12: bytes 12..15 are all in W.w, hi unused)
+                            hdr = at >= 12 ? (W.w >> (8 * (at - 12))) : (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (at & 3)));
+                            parseHeader = !lastLiterals;
                         }
-                        uint32_t* r = ldsRec + (cnt * 4) * REC_STRIDE + lane;
-                        r[0] = (uint32_t)litSrc;
-                        r[REC_STRIDE] = (uint32_t)lit;
-                        r[2 * REC_STRIDE] = (uint32_t)ml;
-                        r[3 * REC_STRIDE] = (uint32_t)offset;
-                        cnt++;
+                        else {
+                            headerDue = !lastLiterals;
+                        }
                     }
                 }
+                if (parseHeader && !done) {
+                    headerDue = false;
+                    const int32_t offset = (int32_t)(hdr & 0xFFFF);  // :113-119
+                    ip += 2;
+                    int32_t ml = 0;
+                    if (offset == 0 || offset > op) {
+                        LZ4_FAIL(ACHIP_D_LZ4_OFFSET_OUTSIDE, ip);
+                    }
+                    else {
+                        ml = tokenMl;  // :122-138
+                        bool bad = false;
+                        if (ml == 0xF) {
+                            if (ip > inLimit - 5) {
+                                bad = true;
+                            }
+                            else {
+                                int32_t v = (int32_t)((hdr >> 16) & 0xFF);  // first extension byte: in the window
+                                ip++;
+                                ml += v;
+                                while (v == 255) {
+                                    if (ip > inLimit - 5) {
+                                        bad = true;
+                                        break;
+                                    }
+                                    R.ensure_input(ip, 4);
+                                    v = (int32_t)R.in_u8(ip++);
+                                    ml = (int32_t)((uint32_t)ml + (uint32_t)v);
+                                }
+                            }
+                        }
+                        ml = (int32_t)((uint32_t)ml + 4u);
+                        if (bad || ml < 0) {
+                            LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
+                            ml = 0;
+                        }
+                        else {
+                            const int64_t matchOutLimit = (int64_t)op + ml;
+                            if (matchOutLimit > fastOutLimit - 4 && matchOutLimit > outLimit - 5) {  // :168-171
+                                LZ4_FAIL(ACHIP_D_LZ4_LAST_5_LITERALS, ip);
+                                ml = 0;
+                            }
+                        }
+                    }
+                    rem = ml;
+                    dist = offset;
+                    periodic = cur - offset;
+                    op += ml;
+                }
             }
         }
-        wave_mem_order();
-
-        // ---------------- EXECUTE: ROWS blocks at a time, one lane per sequence ----------------
-        const unsigned long long busy = a.ringPad == 240 ? 0ull : __ballot(cnt > 0);  // (ring pad 240 / 224: timing aids -- parse only / no matches)
-        const int j = lane & (K - 1);
-        const int segBase = lane & ~(K - 1);
-        for (int first = 0; first < 64; first += ROWS) {
-            if (((busy >> first) & ((1ull << ROWS) - 1ull)) == 0) {
-                continue;
-            }
-            const int b = first + lane / K;  // the block (= parse lane) this lane works for
-            const int32_t bCnt = __shfl(cnt, b);
-            const int32_t bOp = __shfl(opStart, b);
-            const uint8_t* const bIn = (const uint8_t*)(uintptr_t)shfl_u64((uint64_t)(uintptr_t)in, b);
-            uint8_t* const bOut = (uint8_t*)(uintptr_t)shfl_u64((uint64_t)(uintptr_t)out, b);
-            const bool valid = j < bCnt;
-            const uint32_t* r = ldsRec + (j * 4) * REC_STRIDE + b;
-            const int32_t litSrc = valid ? (int32_t)r[0] : 0;
-            const int32_t lit = valid ? (int32_t)r[REC_STRIDE] : 0;
-            int32_t rem = valid ? (int32_t)r[2 * REC_STRIDE] : 0;
-            int32_t dist = valid ? (int32_t)r[3 * REC_STRIDE] : 0;
-            const int32_t incl = seg_scan<K>(lit + rem, j);
-            uint8_t* const dstLit = bOut + bOp + (incl - lit - rem);
-            uint8_t* cur = dstLit + lit;  // where the match (what is left of it) goes
-
-            // literal runs: nothing depends on them
-            copy_step(S, lane, lit > 0, dstLit, bIn + litSrc, lit);
-
-            // matches, in rounds.  `cur` of the first pending match of a block is its high-water mark: everything below is
-            // final.  A match whose source ends below the mark runs; the first pending match always runs -- if it overlaps
-            // itself (dist < rem) one period now, and as the written part repeats the period, twice as much the next round.
-            for (;;) {
-                const unsigned long long pm = a.ringPad == 224 ? 0ull : __ballot(rem > 0);
-                if (pm == 0) {
-                    break;
-                }
-                const uint32_t segMask = (uint32_t)(pm >> segBase) & ((1u << K) - 1u);
-                const int firstPending = segBase + (segMask ? __builtin_ctz(segMask) : 0);
-                const uint64_t mark = shfl_u64((uint64_t)(uintptr_t)cur, firstPending);
-                const bool ready = rem > 0 && (lane == firstPending || (uint64_t)(uintptr_t)(cur - dist + rem) <= mark);
-                const int32_t n = ready ? (rem < dist ? rem : dist) : 0;
-                copy_step(S, lane, n > 0, cur, cur - dist, n);
-                cur += n;
-                rem -= n;
-                if (n > 0 && rem > 0 && dist < (1 << 28)) {
-                    dist += dist;
-                }
-            }
+        // ---- copy.  Per trip a lane moves at most HEAD bytes of its literal run and HEAD bytes of its match itself and keeps
+        // the rest for its next trips (it then parses nothing new) -- unless more than LONG bytes are left: those go out at once,
+        // dealt to all lanes.  Of the match at most one period, and nothing while its source reaches into bytes of this trip.
+        if (a.ringPad == 240 || a.ringPad == 224) {  // timing aids (ring pad 240: parse only, 224: literals only, 208: matches only)
+            rem = 0;
         }
-        wave_mem_order();
+        if (a.ringPad == 240 || a.ringPad == 208) {
+            litRem = 0;
+        }
+        const int32_t n0 = (litRem > LONG || litRem < HEAD) ? litRem : HEAD;
+        int32_t n1 = rem < dist ? rem : dist;
+        n1 = (n1 > LONG || n1 < HEAD) ? n1 : HEAD;
+        n1 = (litRem > n0 || dist < n0 + n1) ? 0 : n1;
+        copy_step<true>(S, lane, h0, have0, out + litOut, in + litPos, n0, inEnd, out + cur, out + cur - dist, n1, outEnd, a.ringPad == 96 || a.ringPad == 112);
+        litOut += n0;
+        litPos += n0;
+        litRem -= n0;
+        cur += n1;
+        rem -= n1;
+        if (rem > dist && 2 * (int64_t)dist <= (int64_t)(cur - periodic)) {
+            dist += dist;  // enough periods are written: out[x] = out[x - 2 * dist] holds as well
+        }
     }
 #undef LZ4_FAIL
     if (have) {
@@ -427,10 +549,40 @@ __global__ __launch_bounds__(64) void lz4_decompress_seqpar_kernel(BatchArgs a)
     }
 }
 
-hipError_t launch_lz4_decompress_seqpar(const BatchArgs& a, hipStream_t stream)
+// counts the groups of 16 consecutive blocks whose compressed sizes differ by more than 2x
+__global__ __launch_bounds__(256) void lz4_mixed_groups_kernel(BatchArgs a, int32_t* mixedGroups)
+{
+    const int64_t group = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t first = group * 16;
+    bool mixed = false;
+    if (first < a.nBlocks) {
+        int32_t lo = 0x7FFFFFFF, hi = 0;
+        for (int64_t b = first; b < first + 16 && b < a.nBlocks; b++) {
+            const int32_t len = a.srcLen[b];
+            lo = len < lo ? len : lo;
+            hi = len > hi ? len : hi;
+        }
+        mixed = (int64_t)hi > 2 * (int64_t)lo;
+    }
+    const int n = __popcll(__ballot(mixed));
+    if ((threadIdx.x & 63) == 0 && n > 0) {
+        atomicAdd(mixedGroups, n);
+    }
+}
+
+hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups)
+{
+    const hipError_t e = hipMemsetAsync(mixedGroups, 0, sizeof(int32_t), stream);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (unsigned)(((a.nBlocks + 15) / 16 + 255) / 256);
+    hipLaunchKernelGGL(lz4_mixed_groups_kernel, dim3(grid), dim3(256), 0, stream, a, mixedGroups);
+    return hipGetLastError();
+}
+
+hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups)
 {
     const unsigned grid = (unsigned)((a.nBlocks + 63) / 64);
-    hipLaunchKernelGGL((lz4_decompress_seqpar_kernel<8, 8>), dim3(grid), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((lz4_decompress_lanecopy_kernel<16>), dim3(grid), dim3(64), 0, stream, a, mixedGroups);
     return hipGetLastError();
 }
 

@@ -108,6 +108,31 @@ def test_lz4_experimental_decoders(gb, o, cfg):
             assert outs[i] == eout, "case %d" % i
 
 
+def test_lz4_auto_mode_picks_a_decoder_on_the_device(gb, o):
+    """variant 5 (the default): batches of at least auto_min_blocks blocks are probed on the device -- groups of 16 consecutive
+    blocks whose compressed sizes differ by more than 2x count as mixed -- and a mostly mixed batch goes to the lane-per-block
+    decoder, any other to the rings; both give the oracle's plaintext"""
+    text = [d for _, d, _ in common.corpus_sample()][:2]
+    flat = [bytes(65536), bytes(range(256)) * 256]
+    uniform = (text * 40)[:64]
+    mixed = [text[i % 2] if i % 2 == 0 else flat[(i // 2) % 2] for i in range(64)]
+    gb.set_option("lz4.decompress.variant", 5)
+    gb.set_option("lz4.decompress.auto_min_blocks", 32)
+    try:
+        for blocks, expect_mixed in ((uniform, False), (mixed, True), (mixed[:16], None)):
+            comp = [o.compress("lz4", b) for b in blocks]
+            outs, status, _ = gb.run(CODECS["lz4"]["d"], comp, [len(b) for b in blocks], unaligned=True)
+            assert all(s == 0 for s in status) and outs == blocks
+            groups = gb.codec.native.get_stat("lz4.decompress.mixed_groups")
+            if expect_mixed is None:
+                assert groups == -1           # below auto_min_blocks: no probe, the rings
+            else:
+                assert (groups * 4 > len(blocks) // 16) == expect_mixed, groups
+    finally:
+        gb.set_option("lz4.decompress.auto_min_blocks", 131072)
+        configure(gb, "lz4", DECODERS[0])
+
+
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
 def test_round_trip_gpu_only(gb, o, codec):
     blocks = [b for b in all_blocks() if len(b) > 0]

@@ -19,7 +19,7 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
     if (op == 14) return achip::launch_lz4_decompress_steps(a, nullptr, 1, 0);  // GS = 1: lane-private, exact when run one lane at a time
     if (op == 16 || op == 17) {  // default ring decoders at GS = 1 (compact / large rings)
         a.ringPad = 16;
-        return achip::launch_lz4_decompress_rings(a, nullptr, 1, op - 16);
+        return achip::launch_lz4_decompress_rings(a, nullptr, 1, op - 16, nullptr);
     }
     if (op == 12 || op == 13) {
         a.ringPad = 16;
