@@ -22,7 +22,8 @@ hipError_t launch_lz4_decompress_lanes(const BatchArgs& a, hipStream_t stream, i
 hipError_t launch_lz4_decompress_steps(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass);
 hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups);
-hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass);
+hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
+hipError_t launch_snappy_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
 hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant);
 hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant, int32_t tileMax);
@@ -42,9 +43,9 @@ struct achip_ctx {
     // options
     int lz4dGroup = 4;       // lanes per block: measured best on MI355X (profiles/r01_sweep_v2_rings.txt)
     int snappydGroup = 4;
-    int lz4dAutoMinBlocks = 131072;  // auto mode considers the lane-per-block decoder (64 blocks per wavefront) from this batch size on
+    int lz4dAutoMinBlocks = 65536;  // auto mode considers the lane-per-block decoder (64 blocks per wavefront) from this batch size on
     int lz4dVariant = 5;     // 0 = direct-to-HBM groups (lz4_decompress.hip), 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 2 = LDS rings, a lane per block (lz4_decompress_v3.hip), 3 = lane groups driven as a uniform-step state machine (lz4_decompress_v4.hip), 4 = a lane per block, copies straight between the global buffers (lz4_decompress_v5.hip), 5 = auto: 4 for large mixed batches, else 1
-    int snappydVariant = 1;
+    int snappydVariant = 5;  // 0 direct, 1 rings (snappy_decompress_v2.hip), 4 a lane per block (snappy_decompress_v3.hip), 5 auto as for LZ4
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
     int lz4cVariant = 1;     // 0 = serial probes, 1 = 64 probes per step (batch)
     int snappycVariant = 1;  // 0 = serial probes, 1 = 64 probes per step (batch)
@@ -196,8 +197,20 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             break;
         case ACHIP_OP_LZ4_COMPRESS: e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint); break;
         case ACHIP_OP_SNAPPY_DECOMPRESS:
-            e = ctx->snappydVariant == 0 ? achip::launch_snappy_decompress(a, ctx->stream, ctx->snappydGroup)
-                                         : achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass);
+            if (ctx->snappydVariant == 5 && a.nBlocks >= ctx->lz4dAutoMinBlocks) {  // auto, as for LZ4
+                int32_t r = ensure_scratch(ctx, 4096);
+                if (r < 0) return r;
+                int32_t* mixedGroups = (int32_t*)ctx->scratch;
+                ctx->lastLz4dAuto = true;
+                ctx->lastZstddBlocks = 0;
+                e = achip::launch_lz4_mixed_groups(a, ctx->stream, mixedGroups);
+                if (e == hipSuccess) e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, mixedGroups);
+                if (e == hipSuccess) e = achip::launch_snappy_decompress_lanecopy(a, ctx->stream, mixedGroups);
+                break;
+            }
+            e = ctx->snappydVariant == 0   ? achip::launch_snappy_decompress(a, ctx->stream, ctx->snappydGroup)
+                : ctx->snappydVariant == 4 ? achip::launch_snappy_decompress_lanecopy(a, ctx->stream, nullptr)
+                                           : achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, nullptr);
             break;
         case ACHIP_OP_SNAPPY_COMPRESS: e = achip::launch_snappy_compress(a, ctx->stream, ctx->snappycVariant); break;
         case ACHIP_OP_ZSTD_DECOMPRESS: {

@@ -21,8 +21,11 @@ __device__ __forceinline__ int32_t snappy_op_entry2(int32_t op)  // opLookupTabl
 }
 
 template <int GS, int IN_RING, int OUT_RING, int GPL>
-__global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs a)
+__global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
+    if (mixedGroups != nullptr && lz4_batch_is_mixed(*mixedGroups, a.nBlocks)) {  // auto mode (achip_abi.cpp): the lane-per-block decoder takes this batch
+        return;
+    }
     ACHIP_DYNAMIC_LDS(smem);
     constexpr int GROUPS_PER_WG = 256 / GS;
     const int g = threadIdx.x & (GS - 1);
@@ -138,25 +141,25 @@ __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs 
 }
 
 template <int GS, int IN_RING, int OUT_RING, int GPL = 1>
-static hipError_t snd2_launch(const BatchArgs& a, hipStream_t stream)
+static hipError_t snd2_launch(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups)
 {
     constexpr int GROUPS_PER_WG = 256 / GS;
     const unsigned grid = (unsigned)((a.nBlocks + GROUPS_PER_WG - 1) / GROUPS_PER_WG);
     const size_t lds = (size_t)GROUPS_PER_WG * (IN_RING + OUT_RING + a.ringPad);
-    hipLaunchKernelGGL((snappy_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((snappy_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
     return hipGetLastError();
 }
 
-hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass)
+hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups)
 {
     switch (groupSize) {
-        case 1: return ringClass ? snd2_launch<1, 128, 256, 4>(a, stream) : snd2_launch<1, 64, 128, 2>(a, stream);
-        case 2: return ringClass ? snd2_launch<2, 128, 256, 2>(a, stream) : snd2_launch<2, 64, 128, 1>(a, stream);
-        case 4: return ringClass ? snd2_launch<4, 256, 512>(a, stream) : snd2_launch<4, 128, 256>(a, stream);
-        case 8: return ringClass ? snd2_launch<8, 512, 1024>(a, stream) : snd2_launch<8, 256, 512>(a, stream);
-        case 32: return ringClass ? snd2_launch<32, 2048, 4096>(a, stream) : snd2_launch<32, 1024, 2048>(a, stream);
-        case 64: return ringClass ? snd2_launch<64, 4096, 8192>(a, stream) : snd2_launch<64, 2048, 4096>(a, stream);
-        default: return ringClass ? snd2_launch<16, 1024, 2048>(a, stream) : snd2_launch<16, 512, 1024>(a, stream);
+        case 1: return ringClass ? snd2_launch<1, 128, 256, 4>(a, stream, mixedGroups) : snd2_launch<1, 64, 128, 2>(a, stream, mixedGroups);
+        case 2: return ringClass ? snd2_launch<2, 128, 256, 2>(a, stream, mixedGroups) : snd2_launch<2, 64, 128, 1>(a, stream, mixedGroups);
+        case 4: return ringClass ? snd2_launch<4, 256, 512>(a, stream, mixedGroups) : snd2_launch<4, 128, 256>(a, stream, mixedGroups);
+        case 8: return ringClass ? snd2_launch<8, 512, 1024>(a, stream, mixedGroups) : snd2_launch<8, 256, 512>(a, stream, mixedGroups);
+        case 32: return ringClass ? snd2_launch<32, 2048, 4096>(a, stream, mixedGroups) : snd2_launch<32, 1024, 2048>(a, stream, mixedGroups);
+        case 64: return ringClass ? snd2_launch<64, 4096, 8192>(a, stream, mixedGroups) : snd2_launch<64, 2048, 4096>(a, stream, mixedGroups);
+        default: return ringClass ? snd2_launch<16, 1024, 2048>(a, stream, mixedGroups) : snd2_launch<16, 512, 1024>(a, stream, mixedGroups);
     }
 }
 

@@ -262,6 +262,8 @@ def main():
     else:
         assert bool((out_len == pool_clen.repeat(reps)).all())
 
+    mixed_groups = codec.native.get_stat("lz4.decompress.mixed_groups") if wl.endswith("decompress") else -1
+    decoder = "n/a" if not wl.endswith("decompress") else ("rings" if mixed_groups < 0 or mixed_groups * 4 <= (n_local + 15) // 16 else "lane-per-block")
     ms_per_step = elapsed / args.steps * 1e3
     total_plain = plain_bytes_local * world  # weak scaling: every rank owns n_local blocks
     value = total_plain * args.steps / elapsed / 2**30
@@ -286,6 +288,7 @@ def main():
                 wl, n_local, bs, name.upper(), args.data, (" ratio=%.2f" % args.ratio) if args.data == "fragments" else "", plain_bytes_local / comp_bytes_local),
             "blocks_per_gpu": n_local, "block_bytes": bs, "distinct_blocks": pool_n, "compression_ratio": round(plain_bytes_local / comp_bytes_local, 4),
             "parallelism": "block-sharded x%d, no collective" % world,
+            "decoder": decoder + (" (chosen on the device: %d of %d 16-block groups mixed)" % (mixed_groups, (n_local + 15) // 16) if mixed_groups >= 0 else ""),
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -325,8 +328,8 @@ def extras(torch, A, codec, dev, args):
     out = {}
     lib = codec.lib
     bs = args.block_size
-    n = 65536
     for data_kind in ("fragments", "wordmix", "corpus"):
+        n = args.blocks if data_kind == "corpus" else 65536  # corpus-tiled is the primary data of BASELINE configs[1]: at its size
         plain = gen_data(torch, dev, data_kind, n, bs, args.ratio, 977)
         for name, cop, dop in (("lz4", A.OP_LZ4_COMPRESS, A.OP_LZ4_DECOMPRESS), ("snappy", A.OP_SNAPPY_COMPRESS, A.OP_SNAPPY_DECOMPRESS)):
             max_c = getattr(lib, "achip_%s_max_compressed_length" % name)(bs)
@@ -359,6 +362,7 @@ def extras(torch, A, codec, dev, args):
             assert int((st != 0).sum()) == 0
             cbytes = int(clen.to(torch.int64).sum())
             td = timed(lambda: codec.launch(dop, comp, c_off, clen, back, p_off, p_len, blen, st, eo, n))
+            mixed_groups = codec.native.get_stat("lz4.decompress.mixed_groups")  # -1: no probe ran (fixed variant / small batch)
             assert int((st != 0).sum()) == 0 and bool((back[:n * bs] == plain).all())
             key = "%s_%s" % (name, data_kind)
             out[key] = {
@@ -366,6 +370,7 @@ def extras(torch, A, codec, dev, args):
                 "compress_GiBps": round(n * bs / tc / 2**30, 2), "compress_hbm_frac": round((n * bs + cbytes) / tc / 1e9 / HBM_PEAK_GBS, 4),
                 "decompress_GiBps": round(n * bs / td / 2**30, 2), "decompress_hbm_frac": round((n * bs + cbytes) / td / 1e9 / HBM_PEAK_GBS, 4),
                 "blocks": n,
+                "decoder": "rings" if mixed_groups < 0 or mixed_groups * 4 <= (n + 15) // 16 else "lane-per-block",
             }
             del comp, back
     return out

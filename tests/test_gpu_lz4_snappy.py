@@ -108,7 +108,35 @@ def test_lz4_experimental_decoders(gb, o, cfg):
             assert outs[i] == eout, "case %d" % i
 
 
-def test_lz4_auto_mode_picks_a_decoder_on_the_device(gb, o):
+def test_snappy_lane_per_block_decoder(gb, o):
+    """variant 4 (snappy_decompress_v3.hip): plaintext, status and error offsets equal the oracle's, corrupt streams included"""
+    rng = np.random.default_rng(11)
+    blocks = all_blocks()
+    cases = [(o.compress("snappy", b), len(b)) for b in blocks] + [(o.compress("snappy", b), len(b) + 37) for b in blocks[:20]]
+    cases += [(b"", 10), (b"\x00", 0), (b"\x05", 16), (bytes([0x80] * 5 + [1]), 16), (bytes([0xFF, 0xFF, 0xFF, 0xFF, 0x0F]), 16)]
+    for b in [d for _, d, _ in common.corpus_sample()[:4]]:
+        c = bytearray(o.compress("snappy", b))
+        cases += [(bytes(c), len(b) - 1), (bytes(c[:len(c) // 2]), len(b)), (bytes(c[:-1]), len(b))]
+        for _ in range(12):
+            m = bytearray(c)
+            m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+            cases.append((bytes(m), len(b)))
+    configure(gb, "snappy", (4, 4, 0))
+    try:
+        outs, status, err = gb.run(CODECS["snappy"]["d"], [c for c, _ in cases], [cap for _, cap in cases], unaligned=True)
+    finally:
+        configure(gb, "snappy", DECODERS[0])
+    for i, (c, cap) in enumerate(cases):
+        est, eoff, eout = _oracle_status(o, "snappy", c, cap)
+        assert status[i] == est, "case %d: gpu status %d oracle %d" % (i, status[i], est)
+        if est != 0:
+            assert err[i] == eoff, "case %d: gpu offset %d oracle %d" % (i, err[i], eoff)
+        else:
+            assert outs[i] == eout, "case %d" % i
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy"])
+def test_auto_mode_picks_a_decoder_on_the_device(gb, o, codec):
     """variant 5 (the default): batches of at least auto_min_blocks blocks are probed on the device -- groups of 16 consecutive
     blocks whose compressed sizes differ by more than 2x count as mixed -- and a mostly mixed batch goes to the lane-per-block
     decoder, any other to the rings; both give the oracle's plaintext"""
@@ -116,12 +144,12 @@ def test_lz4_auto_mode_picks_a_decoder_on_the_device(gb, o):
     flat = [bytes(65536), bytes(range(256)) * 256]
     uniform = (text * 40)[:64]
     mixed = [text[i % 2] if i % 2 == 0 else flat[(i // 2) % 2] for i in range(64)]
-    gb.set_option("lz4.decompress.variant", 5)
-    gb.set_option("lz4.decompress.auto_min_blocks", 32)
+    gb.set_option("%s.decompress.variant" % codec, 5)
+    gb.set_option("lz4.decompress.auto_min_blocks", 32)  # (one threshold for both codecs)
     try:
         for blocks, expect_mixed in ((uniform, False), (mixed, True), (mixed[:16], None)):
-            comp = [o.compress("lz4", b) for b in blocks]
-            outs, status, _ = gb.run(CODECS["lz4"]["d"], comp, [len(b) for b in blocks], unaligned=True)
+            comp = [o.compress(codec, b) for b in blocks]
+            outs, status, _ = gb.run(CODECS[codec]["d"], comp, [len(b) for b in blocks], unaligned=True)
             assert all(s == 0 for s in status) and outs == blocks
             groups = gb.codec.native.get_stat("lz4.decompress.mixed_groups")
             if expect_mixed is None:
@@ -129,8 +157,8 @@ def test_lz4_auto_mode_picks_a_decoder_on_the_device(gb, o):
             else:
                 assert (groups * 4 > len(blocks) // 16) == expect_mixed, groups
     finally:
-        gb.set_option("lz4.decompress.auto_min_blocks", 131072)
-        configure(gb, "lz4", DECODERS[0])
+        gb.set_option("lz4.decompress.auto_min_blocks", 65536)
+        configure(gb, codec, DECODERS[0])
 
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])

@@ -23,7 +23,7 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
     }
     if (op == 12 || op == 13) {
         a.ringPad = 16;
-        return achip::launch_snappy_decompress_rings(a, nullptr, 1, op - 12);
+        return achip::launch_snappy_decompress_rings(a, nullptr, 1, op - 12, nullptr);
     }
     return -1;
 }
