@@ -10,39 +10,49 @@ namespace sp {
 
 // 16-byte load that does not ask the L2 to keep the line: back-reference sources are touched once, and every line they
 // would park in the L2 pushes out a half-written output line of some other block (262144 blocks are open at once)
-__device__ __forceinline__ u32x4 ld16_once(const uint8_t* p, bool nt)
+template <bool NT>
+__device__ __forceinline__ u32x4 ld16_once(const uint8_t* p)
 {
-    typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
-    return nt ? __builtin_nontemporal_load((const u32x4_unaligned*)p) : ld16(p);
+    // (the address need not be 16-byte aligned: gfx950 runs in unaligned-access mode and this is one load instruction)
+    if constexpr (NT) {
+        return __builtin_nontemporal_load((const u32x4*)p);
+    }
+    else {
+        return ld16(p);
+    }
 }
 
-// the lane's window on its compressed stream: an LDS ring column fed with aligned 16-byte granules, one requested ahead
+// The lane's window on its compressed stream: an LDS ring column fed with aligned 32-byte pieces (two 16-byte loads of one
+// half line), one piece requested ahead.  With 262144 streams open a cache line does not survive in the L2 until its
+// stream comes back for the next piece (measured with 16-byte pieces: 69 GB fetched for 8.7 GB of input); larger pieces
+// fetch a line fewer times (64-byte pieces cost 18 more registers and a wave per SIMD: slower overall).
 template <int IN_DW>
 struct LaneInput {
     static constexpr int IN_BYTES = IN_DW * 4;
-    static_assert((IN_DW & (IN_DW - 1)) == 0 && IN_DW >= 8, "ring size");
+    static constexpr int PIECE = 32;
+    static_assert((IN_DW & (IN_DW - 1)) == 0 && IN_DW >= 16, "ring size");
     uint32_t* inR;  // dword d of this lane's ring at inR[(d & (IN_DW-1)) * 64]
     const uint8_t* inAligned;
     int32_t inBase;
     int32_t inEndV;
-    int32_t inLoadedV;  // virtual [.., inLoadedV) is in the ring (as far back as the ring reaches)
-    u32x4 pending;      // the granule at inLoadedV
-    bool ntIn = false;
+    int32_t inLoadedV;     // virtual [.., inLoadedV) is in the ring (as far back as the ring reaches)
+    u32x4 pendingA, pendingB;  // the piece at inLoadedV
 
     __device__ __forceinline__ void init(uint32_t* lds, const uint8_t* in, int32_t inLimit)
     {
         inR = lds;
-        inBase = (int32_t)((uintptr_t)in & 15);
+        inBase = (int32_t)((uintptr_t)in & (PIECE - 1));
         inAligned = in - inBase;
         inEndV = inLimit + inBase;
         inLoadedV = 0;
-        pending = fetch_granule(0);
+        pendingA = fetch_granule(0);
+        pendingB = fetch_granule(16);
     }
     __device__ __forceinline__ u32x4 fetch_granule(int32_t v) const
     {
         u32x4 d = {0, 0, 0, 0};
         if (v >= inBase && v + 16 <= inEndV) {
-            d = ntIn ? __builtin_nontemporal_load((const u32x4*)(inAligned + v)) : *(const u32x4*)(inAligned + v);
+            d = *(const u32x4*)(inAligned + v);
         }
         else if (v + 16 > inBase && v < inEndV) {  // first / last granule: byte-guarded (cold)
             uint32_t w[4] = {0, 0, 0, 0};
@@ -57,23 +67,29 @@ struct LaneInput {
         }
         return d;
     }
-    // make [pos, pos + need) resident (need <= IN_BYTES - 16; bytes past the end read as 0).  The stream is only read
-    // forwards, so a jump over literal bytes restarts the ring at the granule of pos.
+    // make [pos, pos + need) resident (need <= IN_BYTES - PIECE; bytes past the end read as 0).  The stream is only read
+    // forwards, so a jump over literal bytes restarts the ring at the piece of pos.
     __device__ __forceinline__ void ensure_input(int32_t pos, int32_t need)
     {
         const int32_t v = pos + inBase;
-        if (v >= inLoadedV + 16) {
-            inLoadedV = v & ~15;
-            pending = fetch_granule(inLoadedV);
+        if (v >= inLoadedV + PIECE) {
+            inLoadedV = v & ~(PIECE - 1);
+            pendingA = fetch_granule(inLoadedV);
+            pendingB = fetch_granule(inLoadedV + 16);
         }
         while (v + need > inLoadedV && inLoadedV < inEndV) {
             const int32_t d = inLoadedV >> 2;
-            inR[((d + 0) & (IN_DW - 1)) * 64] = pending.x;
-            inR[((d + 1) & (IN_DW - 1)) * 64] = pending.y;
-            inR[((d + 2) & (IN_DW - 1)) * 64] = pending.z;
-            inR[((d + 3) & (IN_DW - 1)) * 64] = pending.w;
-            inLoadedV += 16;
-            pending = fetch_granule(inLoadedV);
+            inR[((d + 0) & (IN_DW - 1)) * 64] = pendingA.x;
+            inR[((d + 1) & (IN_DW - 1)) * 64] = pendingA.y;
+            inR[((d + 2) & (IN_DW - 1)) * 64] = pendingA.z;
+            inR[((d + 3) & (IN_DW - 1)) * 64] = pendingA.w;
+            inR[((d + 4) & (IN_DW - 1)) * 64] = pendingB.x;
+            inR[((d + 5) & (IN_DW - 1)) * 64] = pendingB.y;
+            inR[((d + 6) & (IN_DW - 1)) * 64] = pendingB.z;
+            inR[((d + 7) & (IN_DW - 1)) * 64] = pendingB.w;
+            inLoadedV += PIECE;
+            pendingA = fetch_granule(inLoadedV);
+            pendingB = fetch_granule(inLoadedV + 16);
         }
         wave_mem_order();
     }
@@ -147,13 +163,14 @@ struct HeadRegs {
 
 // first <= HEAD bytes of a copy: loads.  `srcEnd` bounds what may be read: a short run is fetched with one 16-byte load
 // when that stays inside the buffer (the bytes past the run are not used), byte by byte otherwise (cold).
-__device__ __forceinline__ void head_load(HeadRegs& r, const uint8_t* src, int32_t m, const uint8_t* srcEnd, bool nt)
+template <bool NT>
+__device__ __forceinline__ void head_load(HeadRegs& r, const uint8_t* src, int32_t m, const uint8_t* srcEnd)
 {
     r.A = u32x4{0, 0, 0, 0};
     r.B = r.A;
     if (m > 0) {
         if (src + 16 <= srcEnd) {
-            r.A = ld16_once(src, nt);
+            r.A = ld16_once<NT>(src);
         }
         else {
             uint32_t w[4] = {0, 0, 0, 0};
@@ -164,7 +181,7 @@ __device__ __forceinline__ void head_load(HeadRegs& r, const uint8_t* src, int32
             r.A = u32x4{w[0], w[1], w[2], w[3]};
         }
         if (m >= 16) {
-            r.B = ld16_once(src + m - 16, nt);
+            r.B = ld16_once<NT>(src + m - 16);
         }
     }
 }
@@ -197,18 +214,18 @@ __device__ __forceinline__ void head_store(const HeadRegs& r, uint8_t* dst, int3
 // length of 0 = none).  Within a lane the ranges do not overlap and every source byte is final before the step.  Exact.
 // `have0`: the first 16 bytes of copy 0 are in h0.A already (a literal run of <= 16 bytes comes from the LDS window).
 // `end1` is the end of the output capacity (copy 1 reads the output buffer; both copies write it).
-template <bool TWO>
+template <bool TWO, bool NT = false>
 __device__ __forceinline__ void copy_step(CopyScratch& S, int lane, HeadRegs h0, bool have0, uint8_t* dst0, const uint8_t* src0, int32_t n0,
-                                          const uint8_t* end0, uint8_t* dst1, const uint8_t* src1, int32_t n1, const uint8_t* end1, bool nt)
+                                          const uint8_t* end0, uint8_t* dst1, const uint8_t* src1, int32_t n1, const uint8_t* end1)
 {
     HeadRegs h1;
     const int32_t m0 = n0 < HEAD ? n0 : HEAD, m1 = n1 < HEAD ? n1 : HEAD;
     if constexpr (TWO) {
         if (!have0) {
-            head_load(h0, src0, m0, end0, nt);
+            head_load<false>(h0, src0, m0, end0);
         }
     }
-    head_load(h1, src1, m1, end1, nt);
+    head_load<NT>(h1, src1, m1, end1);
     const bool longer = (TWO && n0 > HEAD) || n1 > HEAD;
     const bool anyLonger = __ballot(longer) != 0;
     if (anyLonger) {  // (uniform)
@@ -231,7 +248,7 @@ __device__ __forceinline__ void copy_step(CopyScratch& S, int lane, HeadRegs h0,
                     for (int t = 0; t < 4; t++) {
                         p[t] = base + 1024 * t;
                         p[t] = p[t] + 16 > len ? len - 16 : p[t];  // (the last piece ends at the end; pieces past it repeat it)
-                        v[t] = ld16_once(s + p[t], nt);
+                        v[t] = ld16_once<NT>(s + p[t]);
                     }
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
@@ -287,7 +304,7 @@ __device__ __forceinline__ void copy_step(CopyScratch& S, int lane, HeadRegs h0,
                 const int32_t len = (int32_t)S.n[which][i];
                 int32_t p = HEAD + 16 * q;
                 p = p + 16 > len ? len - 16 : p;
-                v[t] = ld16_once((const uint8_t*)(uintptr_t)S.src[which][i] + p, nt);
+                v[t] = ld16_once<NT>((const uint8_t*)(uintptr_t)S.src[which][i] + p);
                 d[t] = (uint8_t*)(uintptr_t)S.dst[which][i] + p;
             }
         }

@@ -21,8 +21,8 @@
 
 namespace achip {
 
-template <int IN_DW>
-__global__ __launch_bounds__(64) void lz4_decompress_lanecopy_kernel(BatchArgs a, const int32_t* mixedGroups)
+template <int IN_DW, bool NT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void lz4_decompress_lanecopy_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
     using namespace sp;
     if (mixedGroups != nullptr && !lz4_batch_is_mixed(*mixedGroups, a.nBlocks)) {  // auto mode: the ring decoder takes this batch
@@ -39,7 +39,6 @@ __global__ __launch_bounds__(64) void lz4_decompress_lanecopy_kernel(BatchArgs a
     const int32_t outLimit = have ? a.dstCap[block] : 0;
 
     LaneInput<IN_DW> R;
-    R.ntIn = a.ringPad == 112;
     R.init(ldsIn + lane, in, inLimit);
 
     int32_t st = 0;
@@ -222,7 +221,7 @@ __global__ __launch_bounds__(64) void lz4_decompress_lanecopy_kernel(BatchArgs a
         int32_t n1 = rem < dist ? rem : dist;
         n1 = (n1 > LONG || n1 < HEAD) ? n1 : HEAD;
         n1 = (litRem > n0 || dist < n0 + n1) ? 0 : n1;
-        copy_step<true>(S, lane, h0, have0, out + litOut, in + litPos, n0, inEnd, out + cur, out + cur - dist, n1, outEnd, a.ringPad == 96 || a.ringPad == 112);
+        copy_step<true, NT>(S, lane, h0, have0, out + litOut, in + litPos, n0, inEnd, out + cur, out + cur - dist, n1, outEnd);
         litOut += n0;
         litPos += n0;
         litRem -= n0;
@@ -273,7 +272,7 @@ hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32
 hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups)
 {
     const unsigned grid = (unsigned)((a.nBlocks + 63) / 64);
-    hipLaunchKernelGGL((lz4_decompress_lanecopy_kernel<16>), dim3(grid), dim3(64), 0, stream, a, mixedGroups);
+    hipLaunchKernelGGL((lz4_decompress_lanecopy_kernel<16, false>), dim3(grid), dim3(64), 0, stream, a, mixedGroups);
     return hipGetLastError();
 }
 

@@ -24,7 +24,7 @@ __device__ __forceinline__ int32_t snappy_op_entry3(int32_t op)  // opLookupTabl
 }
 
 template <int IN_DW>
-__global__ __launch_bounds__(64) void snappy_decompress_lanecopy_kernel(BatchArgs a, const int32_t* mixedGroups)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void snappy_decompress_lanecopy_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
     using namespace sp;
     if (mixedGroups != nullptr && !lz4_batch_is_mixed(*mixedGroups, a.nBlocks)) {  // auto mode: the ring decoder takes this batch
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void snappy_decompress_lanecopy_kernel(BatchArg
         const int32_t n0 = (litRem > LONG || litRem < HEAD) ? litRem : HEAD;
         int32_t n1 = rem < dist ? rem : dist;
         n1 = (n1 > LONG || n1 < HEAD) ? n1 : HEAD;
-        copy_step<true>(S, lane, h0, have0, out + litOut, in + litPos, n0, inEnd, out + cur, out + cur - dist, n1, outEnd, false);
+        copy_step<true>(S, lane, h0, have0, out + litOut, in + litPos, n0, inEnd, out + cur, out + cur - dist, n1, outEnd);
         litOut += n0;
         litPos += n0;
         litRem -= n0;
