@@ -114,6 +114,17 @@ enum achip_detail {
     ACHIP_D_LZ4F_TRUNC_SKIP_SIZE = 85,    /* :334   "Truncated LZ4 skippable frame: missing frame size"     */
     ACHIP_D_LZ4F_TRUNC_SKIP = 86,         /* :340   "Truncated LZ4 skippable frame"                         */
     ACHIP_D_LZ4F_MAX_OUTPUT = 87,         /* :362   "Output buffer too small" (IllegalArgumentException, encoder) */
+    /* x-snappy-framed streams (M/snappy/SnappyFramedInputStream.java; IOException / EOFException unless noted) */
+    ACHIP_D_SNF_EOF_STREAM_HEADER = 88,   /* :68    "encountered EOF while reading stream header"           */
+    ACHIP_D_SNF_BAD_STREAM_HEADER = 89,   /* :71    "invalid stream header"                                 */
+    ACHIP_D_SNF_EOF_BLOCK_HEADER = 90,    /* :323   "encountered EOF while reading block header"            */
+    ACHIP_D_SNF_EOF_FRAME = 91,           /* :177   "unexpectd EOF when reading frame" (sic)                */
+    ACHIP_D_SNF_STREAM_ID_LENGTH = 92,    /* :255   "stream identifier chunk with invalid length: N"        */
+    ACHIP_D_SNF_UNSKIPPABLE = 93,         /* :263   "unsupported unskippable chunk: XX"                     */
+    ACHIP_D_SNF_INVALID_LENGTH = 94,      /* :273   "invalid length: N for chunk flag: XX"                  */
+    ACHIP_D_SNF_CHECKSUM = 95,            /* :207   "Corrupt input: invalid checksum"                       */
+    ACHIP_D_SNF_OUTPUT_TOO_SMALL = 96,    /* this API: the destination cannot hold the stream's plaintext   */
+    ACHIP_D_SNF_MAX_OUTPUT = 97,          /* this API (encoder): dstCap < achip_snappyframed_max_compressed_length */
     /* runtime */
     ACHIP_D_NO_DEVICE = 100,
     ACHIP_D_HIP_ERROR = 101,
@@ -261,6 +272,8 @@ int32_t achip_xxhash32(achip_ctx* ctx, const void* src, int64_t srcLen, int32_t 
 #define ACHIP_OP_ZSTD_COMPRESS 5
 #define ACHIP_OP_LZ4FRAME_DECOMPRESS 6
 #define ACHIP_OP_LZ4FRAME_COMPRESS 7
+#define ACHIP_OP_SNAPPYFRAMED_DECOMPRESS 8
+#define ACHIP_OP_SNAPPYFRAMED_COMPRESS 9
 int32_t achip_batch_host(int32_t codecOp, ACHIP_BATCH_ARGS);
 
 /* Balanced contiguous partition of a batch over nParts GPUs: fills

@@ -52,6 +52,13 @@ int64_t orc_lz4frame_max_compressed_length(int64_t n);
 int64_t orc_lz4frame_compress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap);
 int64_t orc_lz4frame_decompress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap, int64_t* err_off);
 
+/* x-snappy-framed streams -- M/snappy/SnappyFramedOutputStream.java, SnappyFramedInputStream.java, Crc32C.java (snappy_framed.c) */
+int64_t orc_snappyframed_max_compressed_length(int64_t n);
+int64_t orc_snappyframed_compress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap);
+int64_t orc_snappyframed_decompress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap, int64_t* err_off);
+uint32_t orc_crc32c(const uint8_t* in, int64_t len);
+uint32_t orc_masked_crc32c(const uint8_t* in, int64_t len);
+
 /* XXH32 -- M/xxhash/XxHash32JavaHasher.java:68-110,343-366 (public xxhash package; LZ4 frame checksums) */
 uint32_t orc_xxh32(const uint8_t* in, int64_t len, uint32_t seed);
 

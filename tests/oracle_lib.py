@@ -28,13 +28,13 @@ class Oracle:
         self.lib = lib
         u8p = ctypes.c_void_p
         i64 = ctypes.c_int64
-        for name in ("orc_lz4_max_compressed_length", "orc_snappy_max_compressed_length", "orc_zstd_max_compressed_length", "orc_lz4frame_max_compressed_length"):
+        for name in ("orc_lz4_max_compressed_length", "orc_snappy_max_compressed_length", "orc_zstd_max_compressed_length", "orc_lz4frame_max_compressed_length", "orc_snappyframed_max_compressed_length"):
             getattr(lib, name).restype = i64
             getattr(lib, name).argtypes = [i64]
-        for name in ("orc_lz4_compress", "orc_snappy_compress", "orc_zstd_compress", "orc_lz4frame_compress"):
+        for name in ("orc_lz4_compress", "orc_snappy_compress", "orc_zstd_compress", "orc_lz4frame_compress", "orc_snappyframed_compress"):
             getattr(lib, name).restype = i64
             getattr(lib, name).argtypes = [u8p, i64, u8p, i64]
-        for name in ("orc_lz4_decompress", "orc_snappy_decompress", "orc_zstd_decompress", "orc_lz4frame_decompress"):
+        for name in ("orc_lz4_decompress", "orc_snappy_decompress", "orc_zstd_decompress", "orc_lz4frame_decompress", "orc_snappyframed_decompress"):
             getattr(lib, name).restype = i64
             getattr(lib, name).argtypes = [u8p, i64, u8p, i64, ctypes.POINTER(i64)]
         for name in ("orc_snappy_uncompressed_length", "orc_zstd_decompressed_size"):
@@ -44,6 +44,9 @@ class Oracle:
         lib.orc_xxh64.argtypes = [u8p, i64, ctypes.c_uint64]
         lib.orc_xxh32.restype = ctypes.c_uint32
         lib.orc_xxh32.argtypes = [u8p, i64, ctypes.c_uint32]
+        for name in ("orc_crc32c", "orc_masked_crc32c"):
+            getattr(lib, name).restype = ctypes.c_uint32
+            getattr(lib, name).argtypes = [u8p, i64]
         lib.orc_random_generator.restype = None
         lib.orc_random_generator.argtypes = [ctypes.c_double, u8p, i64]
         lib.orc_batch.restype = i64
@@ -82,6 +85,10 @@ class Oracle:
     def xxh32(self, data, seed=0):
         src = np.frombuffer(bytes(data), dtype=np.uint8)
         return self.lib.orc_xxh32(src.ctypes.data if len(src) else None, len(src), seed & 0xFFFFFFFF)
+
+    def crc32c(self, data, masked=False):
+        src = np.frombuffer(bytes(data), dtype=np.uint8)
+        return getattr(self.lib, "orc_masked_crc32c" if masked else "orc_crc32c")(src.ctypes.data if len(src) else None, len(src))
 
     def xxh64(self, data, seed=0):
         src = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
