@@ -12,7 +12,7 @@ import numpy as np
 from . import native
 from .native import HipNative
 
-OP_LZ4_DECOMPRESS, OP_LZ4_COMPRESS, OP_SNAPPY_DECOMPRESS, OP_SNAPPY_COMPRESS, OP_ZSTD_DECOMPRESS, OP_ZSTD_COMPRESS, OP_LZ4FRAME_DECOMPRESS, OP_LZ4FRAME_COMPRESS = range(8)
+OP_LZ4_DECOMPRESS, OP_LZ4_COMPRESS, OP_SNAPPY_DECOMPRESS, OP_SNAPPY_COMPRESS, OP_ZSTD_DECOMPRESS, OP_ZSTD_COMPRESS, OP_LZ4FRAME_DECOMPRESS, OP_LZ4FRAME_COMPRESS, OP_SNAPPYFRAMED_DECOMPRESS, OP_SNAPPYFRAMED_COMPRESS = range(10)
 _FN = {
     OP_LZ4_DECOMPRESS: "achip_lz4_decompress_batch",
     OP_LZ4_COMPRESS: "achip_lz4_compress_batch",
@@ -22,6 +22,8 @@ _FN = {
     OP_ZSTD_COMPRESS: "achip_zstd_compress_batch",
     OP_LZ4FRAME_DECOMPRESS: "achip_lz4frame_decompress_batch",
     OP_LZ4FRAME_COMPRESS: "achip_lz4frame_compress_batch",
+    OP_SNAPPYFRAMED_DECOMPRESS: "achip_snappyframed_decompress_batch",
+    OP_SNAPPYFRAMED_COMPRESS: "achip_snappyframed_compress_batch",
 }
 
 

@@ -161,6 +161,28 @@ class Lz4FrameHipDecompressor(_HipDecompressor):
     _codec = "lz4frame"
 
 
+class SnappyFramedHipCompressor(_HipCompressor):
+    """One-shot form of SnappyFramedOutputStream (M/snappy/SnappyFramedOutputStream.java:73-96, 113-145, 200-255): what
+    `new SnappyFramedOutputStream(c, out); write(data); close()` leaves in `out` -- the stream header, then per 64 KiB block a
+    chunk with the masked CRC-32C of its plaintext, Snappy-compressed by the HIP block encoder or stored raw when it does not
+    reach 0.85.  max_compressed_length is the capacity this form asks for (the stream class has none)."""
+    _codec = "snappyframed"
+
+    def max_compressed_length(self, uncompressed_size):
+        r = self._lib.achip_snappyframed_max_compressed_length(uncompressed_size)
+        if r < 0:
+            raise IllegalArgumentException("uncompressedSize is negative: %d" % uncompressed_size if uncompressed_size < 0 else
+                                           "Maximum compressed length exceeds Integer.MAX_VALUE for uncompressedSize: %d" % uncompressed_size)
+        return r
+
+
+class SnappyFramedHipDecompressor(_HipDecompressor):
+    """One-shot form of SnappyFramedInputStream read to the end of the stream (M/snappy/SnappyFramedInputStream.java:52-73,
+    135-305; checksums verified): compressed, raw, skippable and stream-identifier chunks, the reference's error for every
+    malformed stream (its IOException / EOFException texts are the ACHIP_D_SNF_* messages)."""
+    _codec = "snappyframed"
+
+
 class SnappyHipCompressor(_HipCompressor):
     """Drop-in for SnappyJavaCompressor (M/snappy/SnappyJavaCompressor.java:26-91)."""
     _codec = "snappy"

@@ -30,6 +30,9 @@ hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* 
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
 int64_t zstd_decompress_scratch_bytes(int32_t nBlocks, int32_t tileMax);
 int64_t zstd_compress_scratch_bytes(int32_t nBlocks);
+hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream, void* scratch);
+hipError_t launch_snappyframed_compress(const BatchArgs& a, hipStream_t stream, void* scratch);
+int64_t snappyframed_compress_scratch_bytes();
 hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch);
 hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch);
 int64_t lz4frame_compress_scratch_bytes();
@@ -233,6 +236,18 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             e = achip::launch_lz4frame_decompress(a, ctx->stream, ctx->scratch);
             break;
         }
+        case ACHIP_OP_SNAPPYFRAMED_DECOMPRESS: {
+            int32_t r = ensure_scratch(ctx, 4096);
+            if (r < 0) return r;
+            e = achip::launch_snappyframed_decompress(a, ctx->stream, ctx->scratch);
+            break;
+        }
+        case ACHIP_OP_SNAPPYFRAMED_COMPRESS: {
+            int32_t r = ensure_scratch(ctx, achip::snappyframed_compress_scratch_bytes());
+            if (r < 0) return r;
+            e = achip::launch_snappyframed_compress(a, ctx->stream, ctx->scratch);
+            break;
+        }
         case ACHIP_OP_LZ4FRAME_COMPRESS: {
             int32_t r = ensure_scratch(ctx, achip::lz4frame_compress_scratch_bytes());
             if (r < 0) return r;
@@ -295,6 +310,16 @@ const DetailText kDetailText[] = {
     {ACHIP_D_LZ4F_TRUNC_SKIP_SIZE, "Truncated LZ4 skippable frame: missing frame size"},
     {ACHIP_D_LZ4F_TRUNC_SKIP, "Truncated LZ4 skippable frame"},
     {ACHIP_D_LZ4F_MAX_OUTPUT, "Output buffer too small"},
+    {ACHIP_D_SNF_EOF_STREAM_HEADER, "encountered EOF while reading stream header"},
+    {ACHIP_D_SNF_BAD_STREAM_HEADER, "invalid stream header"},
+    {ACHIP_D_SNF_EOF_BLOCK_HEADER, "encountered EOF while reading block header"},
+    {ACHIP_D_SNF_EOF_FRAME, "unexpectd EOF when reading frame"},
+    {ACHIP_D_SNF_STREAM_ID_LENGTH, "stream identifier chunk with invalid length"},
+    {ACHIP_D_SNF_UNSKIPPABLE, "unsupported unskippable chunk"},
+    {ACHIP_D_SNF_INVALID_LENGTH, "invalid length for chunk flag"},
+    {ACHIP_D_SNF_CHECKSUM, "Corrupt input: invalid checksum"},
+    {ACHIP_D_SNF_OUTPUT_TOO_SMALL, "Output buffer too small for the stream"},
+    {ACHIP_D_SNF_MAX_OUTPUT, "Output buffer too small"},
     {ACHIP_D_SNAPPY_MALFORMED, "Malformed input"},
     {ACHIP_D_SNAPPY_TRUNCATED, "Input is truncated"},
     {ACHIP_D_SNAPPY_LEN_HIGH_BIT, "last byte of compressed length int has high bit set"},
@@ -372,6 +397,16 @@ int32_t achip_lz4frame_max_compressed_length(int32_t n)
     if (n < 0) return bad_argument("uncompressedSize is negative");
     const int64_t blocks = ((int64_t)n + (4 << 20) - 1) / (4 << 20);
     const int64_t maxLength = 7 + 4 + (int64_t)n + 4 * blocks;
+    if (maxLength > 0x7FFFFFFF) return bad_argument("Maximum compressed length exceeds Integer.MAX_VALUE");
+    return (int32_t)maxLength;
+}
+int32_t achip_snappyframed_max_compressed_length(int32_t n)
+{
+    // stream header + per 64 KiB block a chunk header, the masked CRC and at most the block itself (a compressed chunk is kept
+    // only at <= 0.85 of its block: M/snappy/SnappyFramedOutputStream.java:214)
+    if (n < 0) return bad_argument("uncompressedSize is negative");
+    const int64_t blocks = ((int64_t)n + 65535) / 65536;
+    const int64_t maxLength = 10 + 8 * blocks + (int64_t)n;
     if (maxLength > 0x7FFFFFFF) return bad_argument("Maximum compressed length exceeds Integer.MAX_VALUE");
     return (int32_t)maxLength;
 }
@@ -665,6 +700,8 @@ ACHIP_DEFINE_BATCH(achip_zstd_decompress_batch, ACHIP_OP_ZSTD_DECOMPRESS)
 ACHIP_DEFINE_BATCH(achip_zstd_compress_batch, ACHIP_OP_ZSTD_COMPRESS)
 ACHIP_DEFINE_BATCH(achip_lz4frame_decompress_batch, ACHIP_OP_LZ4FRAME_DECOMPRESS)
 ACHIP_DEFINE_BATCH(achip_lz4frame_compress_batch, ACHIP_OP_LZ4FRAME_COMPRESS)
+ACHIP_DEFINE_BATCH(achip_snappyframed_decompress_batch, ACHIP_OP_SNAPPYFRAMED_DECOMPRESS)
+ACHIP_DEFINE_BATCH(achip_snappyframed_compress_batch, ACHIP_OP_SNAPPYFRAMED_COMPRESS)
 
 // ---- xxhash -------------------------------------------
 int32_t achip_xxhash64_batch(achip_ctx* ctx, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int64_t seed, int64_t* outHash, int32_t nBuffers)
@@ -818,6 +855,14 @@ static int32_t single_block(int32_t op, achip_ctx* ctx, const void* src, void* d
     return status < 0 ? status : outLen;
 }
 
+int32_t achip_snappyframed_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_SNAPPYFRAMED_COMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
+int32_t achip_snappyframed_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_SNAPPYFRAMED_DECOMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
 int32_t achip_lz4frame_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
 {
     return single_block(ACHIP_OP_LZ4FRAME_COMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);

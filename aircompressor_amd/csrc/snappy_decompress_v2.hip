@@ -3,22 +3,9 @@
 // Same contract and Java-order checks as snappy_decompress.hip (M/snappy/SnappyRawDecompressor.java:35-322);
 // bytes move through the per-block LDS rings of achip_rings.h (input pulled from HBM once, output
 // flushed in whole aligned chunks, near back-references served from LDS).
-#include "achip_rings.h"
+#include "snappy_decode_body.h"
 
 namespace achip {
-
-__device__ __forceinline__ int32_t snappy_op_entry2(int32_t op)  // opLookupTable layout :223-271
-{
-    const int32_t kind = op & 3;
-    const int32_t hi = op >> 2;
-    if (kind == 0) {
-        return hi < 60 ? hi + 1 : (((hi - 59) << 11) | 1);
-    }
-    if (kind == 1) {
-        return (1 << 11) | ((hi >> 3) << 8) | ((hi & 7) + 4);
-    }
-    return ((kind == 2 ? 2 : 4) << 11) | (hi + 1);
-}
 
 template <int GS, int IN_RING, int OUT_RING, int GPL>
 __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs a, const int32_t* mixedGroups)
@@ -42,96 +29,9 @@ __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs 
     int32_t st = 0;
     int32_t eo = 0;
     int32_t op = 0;
-
-    // readUncompressedLength :277-321 (at most 5 bytes: read straight from HBM)
-    uint32_t expected = 0;
-    int32_t nread = 0;
-    for (int i = 0; i < 5; i++) {
-        if (nread >= inLen0) {
-            st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_TRUNCATED);
-            eo = inLen0 - nread;
-            break;
-        }
-        const uint32_t b = in0[nread++];
-        expected |= (b & 0x7f) << (7 * i);
-        if ((b & 0x80) == 0) {
-            break;
-        }
-        if (i == 4) {
-            st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_LEN_HIGH_BIT);
-            eo = nread;
-        }
-    }
-    if (st == 0 && (int32_t)expected < 0) {
-        st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_INVALID_LENGTH);
-        eo = 0;
-    }
-    if (st == 0 && (int64_t)expected > (int64_t)outLimit) {  // :49-50
-        st = mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_SNAPPY_OUTPUT_TOO_SMALL);
-        eo = 0;
-    }
-
-    if (st == 0) {
-        // uncompressAll :70-220 ; offsets relative to the first byte after the varint
-        const uint8_t* __restrict__ in = in0 + nread;
-        const int32_t inLimit = inLen0 - nread;
-        const int32_t fastOutLimit = outLimit - 8;
-        int32_t ip = 0;
-        Rings<GS, IN_RING, OUT_RING, GPL> R;
-        R.init(smem + grp * (IN_RING + OUT_RING + a.ringPad), smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING, in, inLimit, out, g,
-           a.ringPad >= 16 * GS * GPL ? smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING + OUT_RING : nullptr);
-
-#define SN_FAIL(off)                                                     \
-    {                                                                    \
-        st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_MALFORMED); \
-        eo = (int32_t)(off);                                             \
-        break;                                                           \
-    }
-        while (ip < inLimit) {
-            R.ensure_input(ip, 5);
-            const int32_t opc = (int32_t)R.in_u8(ip++);
-            const int32_t entry = snappy_op_entry2(opc);
-            const int32_t trailerBytes = entry >> 11;
-            if (!(ip + 4 < inLimit)) {  // :90-92
-                if (ip + trailerBytes > inLimit) SN_FAIL(ip);
-            }
-            // little-endian trailer: one unaligned 4-byte ring read, masked to trailerBytes (bytes past the input end are never selected)
-            const uint32_t t = trailerBytes == 0 ? 0u : (R.template ring_ld4<IN_RING>(R.inRing, ip + R.inBase) & (0xFFFFFFFFu >> (32 - 8 * trailerBytes)));
-            const int32_t trailer = (int32_t)t;
-            if (trailer < 0) SN_FAIL(ip);
-            ip += trailerBytes;
-
-            const int32_t length = entry & 0xff;
-            if (length == 0) {
-                continue;
-            }
-
-            if ((opc & 3) == 0) {  // literal :116-146
-                const int32_t lit = (int32_t)((uint32_t)length + (uint32_t)trailer);
-                if (lit < 0) SN_FAIL(ip);
-                const int64_t litOutLimit = (int64_t)op + lit;
-                if (litOutLimit > fastOutLimit || (int64_t)ip + lit > inLimit - 8) {
-                    if (litOutLimit > outLimit || (int64_t)ip + lit > inLimit) SN_FAIL(ip);
-                }
-                R.copy_literals(ip, op, lit);
-                ip += lit;
-                op += lit;
-            }
-            else {  // copy :147-216
-                const int32_t matchOffset = (int32_t)((uint32_t)(entry & 0x700) + (uint32_t)trailer);
-                if (matchOffset <= 0) SN_FAIL(ip);
-                if (matchOffset > op || (int64_t)op + length > outLimit) SN_FAIL(ip);
-                R.copy_match(op, matchOffset, length);
-                op += length;
-            }
-        }
-#undef SN_FAIL
-        R.flush_all(op);
-        if (st == 0 && (int64_t)expected != (int64_t)op) {  // :61-65
-            st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_LENGTH_MISMATCH);
-            eo = 0;
-        }
-    }
+    uint8_t* const slot = smem + grp * (IN_RING + OUT_RING + a.ringPad);
+    snappy_buffer_decode<GS, IN_RING, OUT_RING, GPL>(slot, slot + IN_RING, a.ringPad >= 16 * GS * GPL ? slot + IN_RING + OUT_RING : nullptr, in0, inLen0, out, outLimit, g, st,
+                                                      eo, op);
 
     if (g == 0) {
         a.outLen[block] = st == 0 ? op : 0;

@@ -1,0 +1,293 @@
+// snappy_frame.hip -- batched x-snappy-framed stream decode / encode for gfx950.
+//
+// Replaces the read-to-the-end use of SnappyFramedInputStream (M/snappy/SnappyFramedInputStream.java:52-73 stream header,
+// :135-214 ensureBuffer, :226-305 chunk headers) and the write-all-then-close use of SnappyFramedOutputStream
+// (M/snappy/SnappyFramedOutputStream.java:73-96, :113-145, :200-255) over the HIP block codec.  An item of the batch is
+// a whole stream.  One wavefront per item, persistent grid: the chunk walk is a serial chain (a chunk's position is known
+// only after the one before it), so the wavefront runs the Java loop itself -- same checks in the same order -- and puts
+// its 64 lanes into each step: the ring block decoder of snappy_decode_body.h (64 lanes per chunk), 64 x 16-byte copies
+// for stored chunks, the row-parallel CRC-32C of achip_crc32c.h for the masked checksums, the batch-probing block encoder
+// of snappy_compress_body.h.  Throughput comes from many streams per batch.
+// What the one-shot form adds to the Java classes: the destination capacity (ACHIP_D_SNF_OUTPUT_TOO_SMALL / _MAX_OUTPUT); the
+// offset reported with the stream-level IOExceptions, which carry none (the position of the chunk header); the capacity handed
+// to the block decoder (the Java reader's buffer of max(65541, everything seen so far) bytes, limited by what the destination
+// has left); a chunk that ends inside its length preamble is ACHIP_D_SNAPPY_TRUNCATED (Java would read stale buffer bytes).
+#include "snappy_decode_body.h"
+#include "snappy_compress_body.h"
+#include "achip_crc32c.h"
+
+namespace achip {
+
+namespace snf {
+constexpr int COMPRESSED_DATA_FLAG = 0x00, UNCOMPRESSED_DATA_FLAG = 0x01, STREAM_IDENTIFIER_FLAG = 0xff;
+constexpr int MAX_BLOCK_SIZE = 65536;
+constexpr int IN_RING = 2048, OUT_RING = 4096;
+
+#define SNF_FAIL(detail, off)                          \
+    {                                                  \
+        eo = (int64_t)(off);                           \
+        return mk_status(ACHIP_CLASS_MALFORMED, detail); \
+    }
+
+// readUncompressedLength (M/snappy/SnappyRawDecompressor.java:277-321) of a chunk's data
+__device__ __forceinline__ int32_t read_uncompressed_length(const uint8_t* in, int32_t len, int32_t& expectedOut, int32_t& eoOut)
+{
+    uint32_t expected = 0;
+    int32_t nread = 0;
+    for (int i = 0; i < 5; i++) {
+        if (nread >= len) {
+            eoOut = len - nread;
+            return mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_TRUNCATED);
+        }
+        const uint32_t b = in[nread++];
+        expected |= (b & 0x7f) << (7 * i);
+        if ((b & 0x80) == 0) {
+            break;
+        }
+        if (i == 4) {
+            eoOut = nread;
+            return mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_LEN_HIGH_BIT);
+        }
+    }
+    if ((int32_t)expected < 0) {
+        eoOut = 0;
+        return mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_INVALID_LENGTH);
+    }
+    expectedOut = (int32_t)expected;
+    return 0;
+}
+
+__device__ int32_t decompress_item(const Crc32cTables& tables, const uint8_t* __restrict__ in, int32_t inLen, uint8_t* out, int32_t outCap, uint8_t* lds, int lane,
+                                   int32_t& opOut, int64_t& eo)
+{
+    eo = 0;
+    opOut = 0;
+    if (inLen < 10) SNF_FAIL(ACHIP_D_SNF_EOF_STREAM_HEADER, 0);  // :66-69
+    if (ld8(in) != 0x50614E73000006FFull || in[8] != 0x70 || in[9] != 0x59) SNF_FAIL(ACHIP_D_SNF_BAD_STREAM_HEADER, 0);  // ff 06 00 00 "sNaPpY" :70-72
+    int32_t pos = 10;
+    int32_t o = 0;
+    int32_t javaInput = MAX_BLOCK_SIZE + 5, javaUncompressed = MAX_BLOCK_SIZE + 5;  // allocateBuffersBasedOnSize(MAX_BLOCK_SIZE + 5) :61
+    for (;;) {
+        const int32_t chunk = pos;
+        if (pos == inLen) {
+            break;  // readBlockHeader: end of stream :295-297
+        }
+        if (inLen - pos < 4) SNF_FAIL(ACHIP_D_SNF_EOF_BLOCK_HEADER, chunk);  // :299-301
+        const uint32_t header = ld4(in + pos);
+        const int flag = (int)(header & 0xFF);
+        const int32_t length = (int32_t)(header >> 8);
+        pos += 4;
+        bool skip = false;
+        int32_t minLength;
+        if (flag == COMPRESSED_DATA_FLAG || flag == UNCOMPRESSED_DATA_FLAG) {  // getFrameMetaData :234-277
+            minLength = 5;
+        }
+        else if (flag == STREAM_IDENTIFIER_FLAG) {
+            if (length != 6) SNF_FAIL(ACHIP_D_SNF_STREAM_ID_LENGTH, chunk);
+            skip = true;
+            minLength = 6;
+        }
+        else {
+            if (flag <= 0x7f) SNF_FAIL(ACHIP_D_SNF_UNSKIPPABLE, chunk);
+            skip = true;
+            minLength = 0;
+        }
+        if (length < minLength) SNF_FAIL(ACHIP_D_SNF_INVALID_LENGTH, chunk);
+        if (skip) {  // :151-154; skip stops quietly at the end of the stream
+            pos += length < inLen - pos ? length : inLen - pos;
+            continue;
+        }
+        if (length > javaInput) {  // :156-158
+            javaInput = length;
+            javaUncompressed = javaUncompressed < length ? length : javaUncompressed;
+        }
+        if (inLen - pos < length) SNF_FAIL(ACHIP_D_SNF_EOF_FRAME, chunk);  // :160-163
+        const uint32_t stored = ld4(in + pos);                             // getFrameData :279-288
+        const uint8_t* data = in + pos + 4;
+        const int32_t dlen = length - 4;
+        int32_t produced;
+        if (flag == COMPRESSED_DATA_FLAG) {  // :167-177
+            int32_t ulen = 0, beo = 0;
+            const int32_t pst = read_uncompressed_length(data, dlen, ulen, beo);
+            if (pst != 0) {
+                eo = (int64_t)beo;
+                return pst;
+            }
+            javaUncompressed = javaUncompressed < ulen ? ulen : javaUncompressed;
+            if (ulen > outCap - o) {
+                eo = (int64_t)chunk;
+                return mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_SNF_OUTPUT_TOO_SMALL);
+            }
+            const int32_t limit = javaUncompressed < outCap - o ? javaUncompressed : outCap - o;
+            int32_t bst = 0, bop = 0;
+            wave_mem_order();
+            snappy_buffer_decode<64, IN_RING, OUT_RING, 1>(lds, lds + IN_RING, nullptr, data, dlen, out + o, limit, lane, bst, beo, bop);
+            wave_mem_order();
+            if (bst != 0) {
+                eo = (int64_t)beo;  // the block codec's exception propagates with its own offset
+                return bst;
+            }
+            produced = bop;
+        }
+        else {  // raw :178-186
+            if (dlen > outCap - o) {
+                eo = (int64_t)chunk;
+                return mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_SNF_OUTPUT_TOO_SMALL);
+            }
+            wave_mem_order();
+            group_copy<64>(out + o, data, dlen, lane);
+            wave_mem_order();
+            produced = dlen;
+        }
+        if (stored != crc32c_mask(wave_crc32c(tables, out + o, produced, lane))) SNF_FAIL(ACHIP_D_SNF_CHECKSUM, chunk);  // :188-193
+        o += produced;
+        pos += length;
+    }
+    opOut = o;
+    return 0;
+}
+#undef SNF_FAIL
+
+}  // namespace snf
+
+__global__ __launch_bounds__(64) void snappyframed_decompress_kernel(BatchArgs a, int32_t* nextItem)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[snf::IN_RING + snf::OUT_RING];
+    __shared__ Crc32cTables tables;
+    __shared__ int32_t item;
+    const int lane = threadIdx.x;
+    crc32c_tables_init(tables, lane);
+    for (;;) {
+        __syncthreads();
+        if (lane == 0) {
+            item = atomicAdd(nextItem, 1);
+        }
+        __syncthreads();
+        const int32_t block = item;
+        if (block >= a.nBlocks) {
+            return;
+        }
+        int32_t op = 0;
+        int64_t eo = 0;
+        const int32_t st = snf::decompress_item(tables, a.srcBase + a.srcOff[block], a.srcLen[block], a.dstBase + a.dstOff[block], a.dstCap[block], lds, lane, op, eo);
+        if (lane == 0) {
+            a.outLen[block] = st == 0 ? op : 0;
+            a.status[block] = st;
+            a.errOffset[block] = st == 0 ? 0 : eo;
+        }
+    }
+}
+
+namespace snf {
+constexpr int64_t SLAB_BYTES = (32 + MAX_BLOCK_SIZE + MAX_BLOCK_SIZE / 6 + 63) / 64 * 64;  // maxCompressedLength(65536), rounded
+
+// new SnappyFramedOutputStream(c, out); write(all); close()  -- M/snappy/SnappyFramedOutputStream.java:73-96, 113-145, 158-171
+__device__ int32_t compress_item(const Crc32cTables& tables, uint16_t* table, const uint8_t* __restrict__ in, int32_t inLen, uint8_t* out, int32_t outCap, uint8_t* slab,
+                                 int lane, int32_t& opOut)
+{
+    opOut = 0;
+    if (inLen < 0) {
+        return mk_status(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_BAD_ARGUMENT);
+    }
+    const int64_t blocks = ((int64_t)inLen + MAX_BLOCK_SIZE - 1) / MAX_BLOCK_SIZE;
+    const int64_t bound = 10 + 8 * blocks + (int64_t)inLen;  // achip_snappyframed_max_compressed_length
+    if (bound > 0x7FFFFFFF) {
+        return mk_status(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_BAD_ARGUMENT);
+    }
+    if ((int64_t)outCap < bound) {
+        return mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_SNF_MAX_OUTPUT);
+    }
+    if (lane == 0) {  // constructor :94
+        st8(out, 0x50614E73000006FFull);
+        out[8] = 0x70;
+        out[9] = 0x59;
+    }
+    int32_t o = 10;
+    for (int64_t pos = 0; pos < inLen; pos += MAX_BLOCK_SIZE) {  // full blocks straight from the input, the rest through the buffer :126-145, :186-192
+        const int32_t length = (int32_t)(inLen - pos < MAX_BLOCK_SIZE ? inLen - pos : MAX_BLOCK_SIZE);
+        const uint8_t* block = in + pos;
+        const uint32_t crc = crc32c_mask(wave_crc32c(tables, block, length, lane));  // writeCompressed :204
+        int32_t cst = 0, compressed = 0;
+        snappy_compress_buffer(table, block, length, slab, (int32_t)SLAB_BYTES, lane, cst, compressed);  // :206-211
+        wave_mem_order();
+        if (cst != 0) {
+            return cst;
+        }
+        const bool keep = ((double)compressed / (double)length) <= 0.85;  // :214
+        const uint8_t* data = keep ? slab : block;
+        const int32_t dlen = keep ? compressed : length;
+        if (lane == 0) {  // writeBlock :241-254
+            const uint32_t headerLength = (uint32_t)dlen + 4u;
+            st4(out + o, (keep ? (uint32_t)COMPRESSED_DATA_FLAG : (uint32_t)UNCOMPRESSED_DATA_FLAG) | (headerLength << 8));
+            st4(out + o + 4, crc);
+        }
+        group_copy<64>(out + o + 8, data, dlen, lane);
+        wave_mem_order();
+        o += 8 + dlen;
+    }
+    opOut = o;
+    return 0;
+}
+}  // namespace snf
+
+__global__ __launch_bounds__(64) void snappyframed_compress_kernel(BatchArgs a, uint8_t* slabs, int32_t* nextItem)
+{
+    __shared__ uint16_t table[snc::MAX_HASH_TABLE_SIZE];
+    __shared__ Crc32cTables tables;
+    __shared__ int32_t item;
+    const int lane = threadIdx.x;
+    crc32c_tables_init(tables, lane);
+    uint8_t* slab = slabs + (size_t)blockIdx.x * snf::SLAB_BYTES;
+    for (;;) {
+        __syncthreads();
+        if (lane == 0) {
+            item = atomicAdd(nextItem, 1);
+        }
+        __syncthreads();
+        const int32_t block = item;
+        if (block >= a.nBlocks) {
+            return;
+        }
+        int32_t op = 0;
+        const int32_t st = snf::compress_item(tables, table, a.srcBase + a.srcOff[block], a.srcLen[block], a.dstBase + a.dstOff[block], a.dstCap[block], slab, lane, op);
+        if (lane == 0) {
+            a.outLen[block] = st == 0 ? op : 0;
+            a.status[block] = st;
+            a.errOffset[block] = 0;
+        }
+    }
+}
+
+namespace {
+constexpr int SNF_COMPRESS_WAVES = 256 * 3;  // 44 KB of LDS per wavefront
+}
+int64_t snappyframed_compress_scratch_bytes() { return 4096 + (int64_t)SNF_COMPRESS_WAVES * snf::SLAB_BYTES; }
+
+hipError_t launch_snappyframed_compress(const BatchArgs& a, hipStream_t stream, void* scratch)
+{
+    if (a.nBlocks <= 0) {
+        return hipSuccess;
+    }
+    int32_t* counter = (int32_t*)scratch;
+    hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (unsigned)(a.nBlocks < SNF_COMPRESS_WAVES ? a.nBlocks : SNF_COMPRESS_WAVES);
+    hipLaunchKernelGGL(snappyframed_compress_kernel, dim3(grid), dim3(64), 0, stream, a, (uint8_t*)scratch + 4096, counter);
+    return hipGetLastError();
+}
+
+hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream, void* scratch)
+{
+    if (a.nBlocks <= 0) {
+        return hipSuccess;
+    }
+    int32_t* counter = (int32_t*)scratch;
+    hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    const int32_t maxWaves = 256 * 8;
+    const unsigned grid = (unsigned)(a.nBlocks < maxWaves ? a.nBlocks : maxWaves);
+    hipLaunchKernelGGL(snappyframed_decompress_kernel, dim3(grid), dim3(64), 0, stream, a, counter);
+    return hipGetLastError();
+}
+
+}  // namespace achip

@@ -35,6 +35,11 @@ SIGNATURES = {
     "achip_ctx_synchronize": (_i32, [_vp]),
     "achip_ctx_set_option": (_i32, [_vp, ctypes.c_char_p, _i64]),
     "achip_ctx_get_stat": (_i64, [_vp, ctypes.c_char_p]),
+    "achip_snappyframed_max_compressed_length": (_i32, [_i32]),
+    "achip_snappyframed_decompress_batch": (_i32, _BATCH),
+    "achip_snappyframed_compress_batch": (_i32, _BATCH),
+    "achip_snappyframed_compress": (_i32, [_vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_i64)]),
+    "achip_snappyframed_decompress": (_i32, [_vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_i64)]),
     "achip_lz4frame_max_compressed_length": (_i32, [_i32]),
     "achip_lz4frame_decompress_batch": (_i32, _BATCH),
     "achip_lz4frame_compress_batch": (_i32, _BATCH),

@@ -250,6 +250,20 @@ int32_t achip_lz4frame_compress_batch(ACHIP_BATCH_ARGS);
 int32_t achip_lz4frame_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
 int32_t achip_lz4frame_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
 
+/* ---- x-snappy-framed streams ----
+ * Replace SnappyFramedOutputStream used as "write everything, close"   M/snappy/SnappyFramedOutputStream.java:73-96, 113-145, 200-255
+ *     and SnappyFramedInputStream read to the end of the stream       M/snappy/SnappyFramedInputStream.java:52-73, 135-305
+ * (64 KiB blocks, masked CRC-32C of every block's plaintext  M/snappy/Crc32C.java:29-50, a block stored raw when it does not
+ * reach 0.85) with the HIP block codec underneath.  An item of the batch is a whole stream.  Same batch arguments, result
+ * convention and asynchrony as the block codecs.  The stream-level IOExceptions (details ACHIP_D_SNF_*) report the position of
+ * the offending chunk header in errOffset; a block codec error keeps its own detail and offset. */
+int32_t achip_snappyframed_max_compressed_length(int32_t uncompressedSize);  /* bound this API asks of dstCap; negative: IllegalArgumentException */
+int32_t achip_snappyframed_decompress_batch(ACHIP_BATCH_ARGS);
+int32_t achip_snappyframed_compress_batch(ACHIP_BATCH_ARGS);
+/* one HOST buffer, staged through the context's pinned buffer */
+int32_t achip_snappyframed_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+int32_t achip_snappyframed_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+
 /* ---- xxhash: batched XXH64 / XXH32 of device-resident buffers ----
  * Replace XxHash64Hasher.hash(MemorySegment input, long seed)   M/xxhash/XxHash64Hasher.java:78-86  (-> XxHash64JavaHasher.java:126)
  *     and XxHash32Hasher.hash(MemorySegment input, int seed)    M/xxhash/XxHash32Hasher.java       (-> XxHash32JavaHasher.java:112)
