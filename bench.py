@@ -409,11 +409,18 @@ def xxhash_extra(torch, A, codec, dev, args):
 
 def lz4frame_extra(torch, A, codec, dev, args):
     """SURVEY 8f row 1: LZ4 frame container, one frame of 4 MiB blocks per item (what Lz4FrameJavaCompressor writes);
-    GPU encode (byte-identical to the Java frame encoder), then GPU decode, verified against the plaintext."""
+    GPU encode (byte-identical to the Java frame encoder), then GPU decode, verified against the plaintext.
+    SURVEY 8f row 2: x-snappy-framed streams of 4 MiB (what SnappyFramedOutputStream writes: 64 KiB chunks with masked CRC-32C)."""
+    out = container_extra(torch, A, codec, dev, args, "lz4frame", A.OP_LZ4FRAME_COMPRESS, A.OP_LZ4FRAME_DECOMPRESS)
+    out.update(container_extra(torch, A, codec, dev, args, "snappyframed", A.OP_SNAPPYFRAMED_COMPRESS, A.OP_SNAPPYFRAMED_DECOMPRESS))
+    return out
+
+
+def container_extra(torch, A, codec, dev, args, name, cop, dop):
     out = {}
     fs, n = 4 << 20, 1024
     lib = codec.lib
-    max_c = lib.achip_lz4frame_max_compressed_length(fs)
+    max_c = getattr(lib, "achip_%s_max_compressed_length" % name)(fs)
     cstride = (max_c + 15) // 16 * 16
     i64 = dict(dtype=torch.int64, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
@@ -441,12 +448,12 @@ def lz4frame_extra(torch, A, codec, dev, args):
             codec.record(e1)
             return codec.elapsed_ms(e0, e1) / iters * 1e-3
 
-        tc = timed(lambda: codec.launch(A.OP_LZ4FRAME_COMPRESS, plain, p_off, p_len, comp, c_off, c_cap, clen, st, eo, n), 1)
+        tc = timed(lambda: codec.launch(cop, plain, p_off, p_len, comp, c_off, c_cap, clen, st, eo, n), 1)
         assert int((st != 0).sum()) == 0
         cbytes = int(clen.to(torch.int64).sum())
-        td = timed(lambda: codec.launch(A.OP_LZ4FRAME_DECOMPRESS, comp, c_off, clen, back, p_off, p_len, blen, st, eo, n), 2)
+        td = timed(lambda: codec.launch(dop, comp, c_off, clen, back, p_off, p_len, blen, st, eo, n), 2)
         assert int((st != 0).sum()) == 0 and bool((back[:n * fs] == plain).all())
-        out["lz4frame_%s" % data_kind] = {
+        out["%s_%s" % (name, data_kind)] = {
             "ratio": round(n * fs / cbytes, 3), "compress_GiBps": round(n * fs / tc / 2**30, 2), "decompress_GiBps": round(n * fs / td / 2**30, 2),
             "decompress_hbm_frac": round((n * fs + cbytes) / td / 1e9 / HBM_PEAK_GBS, 4), "frames": n, "frame_bytes": fs,
         }

@@ -56,6 +56,8 @@ public final class HipNative
     public static final int OP_ZSTD_COMPRESS = 5;
     public static final int OP_LZ4FRAME_DECOMPRESS = 6;  // achip_lz4frame_decompress (SURVEY 8f row 1)
     public static final int OP_LZ4FRAME_COMPRESS = 7;    // achip_lz4frame_compress
+    public static final int OP_SNAPPYFRAMED_DECOMPRESS = 8;  // achip_snappyframed_decompress (SURVEY 8f row 2)
+    public static final int OP_SNAPPYFRAMED_COMPRESS = 9;    // achip_snappyframed_compress
 
     private record MethodHandles(
             @NativeSignature(name = "achip_device_count", returnType = int.class, argumentTypes = {})
@@ -105,6 +107,18 @@ public final class HipNative
             MethodHandle zstdCompress,
             @NativeSignature(name = "achip_zstd_decompress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
             MethodHandle zstdDecompress,
+            @NativeSignature(name = "achip_lz4frame_compress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle lz4FrameCompress,
+            @NativeSignature(name = "achip_lz4frame_decompress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle lz4FrameDecompress,
+            @NativeSignature(name = "achip_snappyframed_compress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle snappyFramedCompress,
+            @NativeSignature(name = "achip_snappyframed_decompress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle snappyFramedDecompress,
+            @NativeSignature(name = "achip_lz4frame_max_compressed_length", returnType = int.class, argumentTypes = int.class)
+            MethodHandle lz4FrameMaxCompressedLength,
+            @NativeSignature(name = "achip_snappyframed_max_compressed_length", returnType = int.class, argumentTypes = int.class)
+            MethodHandle snappyFramedMaxCompressedLength,
             // batched, device-resident: (op, ctx, srcBase, srcOff*, srcLen*, dstBase, dstOff*, dstCap*, outLen*, status*, errOffset*, nBlocks)
             @NativeSignature(name = "achip_batch_host", returnType = int.class, argumentTypes = {int.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
                     MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
@@ -189,7 +203,7 @@ public final class HipNative
         return status < 0 ? ((-status) >> 4) : 0;
     }
 
-    static String detailMessage(int detail)
+    public static String detailMessage(int detail)
     {
         try {
             MemorySegment text = (MemorySegment) HANDLES.detailMessage().invokeExact(detail);
@@ -241,6 +255,40 @@ public final class HipNative
     {
         try {
             return (int) HANDLES.snappyMaxCompressedLength().invokeExact(n);
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
+    public static int lz4FrameMaxCompressedLength(int n)
+    {
+        try {
+            int result = (int) HANDLES.lz4FrameMaxCompressedLength().invokeExact(n);
+            if (result < 0) {
+                throw new IllegalArgumentException(n < 0 ? "uncompressedSize is negative: " + n : "Maximum compressed length exceeds Integer.MAX_VALUE for uncompressedSize: " + n);
+            }
+            return result;
+        }
+        catch (RuntimeException e) {
+            throw e;
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
+    public static int snappyFramedMaxCompressedLength(int n)
+    {
+        try {
+            int result = (int) HANDLES.snappyFramedMaxCompressedLength().invokeExact(n);
+            if (result < 0) {
+                throw new IllegalArgumentException(n < 0 ? "uncompressedSize is negative: " + n : "Maximum compressed length exceeds Integer.MAX_VALUE for uncompressedSize: " + n);
+            }
+            return result;
+        }
+        catch (RuntimeException e) {
+            throw e;
         }
         catch (Throwable e) {
             throw new AssertionError("should not reach here", e);
@@ -359,6 +407,10 @@ public final class HipNative
                     case OP_SNAPPY_DECOMPRESS -> HANDLES.snappyDecompress();
                     case OP_ZSTD_COMPRESS -> HANDLES.zstdCompress();
                     case OP_ZSTD_DECOMPRESS -> HANDLES.zstdDecompress();
+                    case OP_LZ4FRAME_COMPRESS -> HANDLES.lz4FrameCompress();
+                    case OP_LZ4FRAME_DECOMPRESS -> HANDLES.lz4FrameDecompress();
+                    case OP_SNAPPYFRAMED_COMPRESS -> HANDLES.snappyFramedCompress();
+                    case OP_SNAPPYFRAMED_DECOMPRESS -> HANDLES.snappyFramedDecompress();
                     default -> throw new IllegalArgumentException("unknown op " + op);
                 };
                 result = (int) method.invokeExact(handle, input, output, inputLength, outputLength, errorOffset);
