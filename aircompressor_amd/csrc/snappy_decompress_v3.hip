@@ -110,76 +110,87 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             else {
                 R.ensure_input(ip, 20);
                 const u32x4 W = R.in_u128(ip);
-                const int32_t opc = (int32_t)(W.x & 0xFF);
-                ip++;
-                const int32_t entry = snappy_op_entry3(opc);
-                const int32_t trailerBytes = entry >> 11;
-                bool ok = true;
-                if (!(ip + 4 < inLimit)) {  // :90-92
-                    if (ip + trailerBytes > inLimit) {
-                        SN_FAIL(ip);
-                        ok = false;
+                // one element: tag byte at ip, `t4` the four bytes behind it.  Returns 1 after a literal, 2 after a copy, 0 otherwise
+                // (end or failure).  The checks and their order: uncompressAll :84-216.
+                auto element = [&](int32_t opc, uint32_t t4) -> int {
+                    ip++;
+                    const int32_t entry = snappy_op_entry3(opc);
+                    const int32_t trailerBytes = entry >> 11;
+                    if (!(ip + 4 < inLimit)) {  // :90-92
+                        if (ip + trailerBytes > inLimit) {
+                            SN_FAIL(ip);
+                            return 0;
+                        }
                     }
-                }
-                int32_t trailer = 0;
-                if (ok) {
-                    // little-endian trailer: window bytes 1..4, masked to trailerBytes (bytes past the input end are never selected)
-                    const uint32_t t4 = alignbyte_u32(W.y, W.x, 1);
-                    trailer = trailerBytes == 0 ? 0 : (int32_t)(t4 & (0xFFFFFFFFu >> (32 - 8 * trailerBytes)));
+                    // little-endian trailer, masked to trailerBytes (bytes past the input end are never selected)
+                    const int32_t trailer = trailerBytes == 0 ? 0 : (int32_t)(t4 & (0xFFFFFFFFu >> (32 - 8 * trailerBytes)));
                     if (trailer < 0) {
                         SN_FAIL(ip);
-                        ok = false;
+                        return 0;
                     }
-                }
-                if (ok) {
                     ip += trailerBytes;
                     const int32_t length = entry & 0xff;
-                    if (length != 0) {
-                        if ((opc & 3) == 0) {  // literal :116-146
-                            const int32_t lit = (int32_t)((uint32_t)length + (uint32_t)trailer);
-                            if (lit < 0) {
-                                SN_FAIL(ip);
-                            }
-                            else {
-                                const int64_t litOutLimit = (int64_t)op + lit;
-                                if ((litOutLimit > fastOutLimit || (int64_t)ip + lit > inLimit - 8) && (litOutLimit > outLimit || (int64_t)ip + lit > inLimit)) {
-                                    SN_FAIL(ip);
-                                }
-                                else {
-                                    litPos = ip;
-                                    litOut = op;
-                                    litRem = lit;
-                                    if (trailerBytes == 0 && lit <= 15) {  // the run sits in window bytes 1..15
-                                        h0.A = u32x4{alignbyte_u32(W.y, W.x, 1), alignbyte_u32(W.z, W.y, 1), alignbyte_u32(W.w, W.z, 1), W.w >> 8};
-                                        h0.B = h0.A;
-                                        have0 = true;
-                                    }
-                                    ip += lit;
-                                    op += lit;
-                                }
-                            }
+                    if (length == 0) {
+                        return 0;
+                    }
+                    if ((opc & 3) == 0) {  // literal :116-146
+                        const int32_t lit = (int32_t)((uint32_t)length + (uint32_t)trailer);
+                        if (lit < 0) {
+                            SN_FAIL(ip);
+                            return 0;
                         }
-                        else {  // copy :147-216
-                            const int32_t matchOffset = (int32_t)((uint32_t)(entry & 0x700) + (uint32_t)trailer);
-                            if (matchOffset <= 0 || matchOffset > op || (int64_t)op + length > outLimit) {
-                                SN_FAIL(ip);
-                            }
-                            else {
-                                cur = op;
-                                rem = length;
-                                dist = matchOffset;
-                                periodic = cur - matchOffset;
-                                op += length;
-                            }
+                        const int64_t litOutLimit = (int64_t)op + lit;
+                        if ((litOutLimit > fastOutLimit || (int64_t)ip + lit > inLimit - 8) && (litOutLimit > outLimit || (int64_t)ip + lit > inLimit)) {
+                            SN_FAIL(ip);
+                            return 0;
+                        }
+                        litPos = ip;
+                        litOut = op;
+                        litRem = lit;
+                        ip += lit;
+                        op += lit;
+                        return 1;
+                    }
+                    // copy :147-216
+                    const int32_t matchOffset = (int32_t)((uint32_t)(entry & 0x700) + (uint32_t)trailer);
+                    if (matchOffset <= 0 || matchOffset > op || (int64_t)op + length > outLimit) {
+                        SN_FAIL(ip);
+                        return 0;
+                    }
+                    cur = op;
+                    rem = length;
+                    dist = matchOffset;
+                    periodic = cur - matchOffset;
+                    op += length;
+                    return 2;
+                };
+                const int32_t tag = (int32_t)(W.x & 0xFF);
+                const int kind = element(tag, alignbyte_u32(W.y, W.x, 1));
+                if (kind == 1 && (tag >> 2) < 60 && litRem <= 15) {  // the run sits in window bytes 1..15
+                    h0.A = u32x4{alignbyte_u32(W.y, W.x, 1), alignbyte_u32(W.z, W.y, 1), alignbyte_u32(W.w, W.z, 1), W.w >> 8};
+                    h0.B = h0.A;
+                    have0 = true;
+                    // a copy right behind a run of <= 10 bytes is in the window too (its tag and up to 4 trailer bytes): same trip
+                    const uint32_t at = (uint32_t)litRem + 1u;  // window offset of the next tag: 2..11 for runs of 1..10
+                    if (litRem <= 10 && ip < inLimit) {
+                        const uint32_t d0 = at < 4 ? W.x : (at < 8 ? W.y : W.z);
+                        const uint32_t d1 = at < 4 ? W.y : (at < 8 ? W.z : W.w);
+                        const uint32_t d2 = at < 4 ? W.z : (at < 8 ? W.w : 0u);
+                        const uint32_t sh = at & 3u;
+                        const uint32_t lo = alignbyte_u32(d1, d0, sh), hi = alignbyte_u32(d2, d1, sh);  // window bytes at .. at + 7
+                        const int32_t tag2 = (int32_t)(lo & 0xFF);
+                        if ((tag2 & 3) != 0) {
+                            element(tag2, alignbyte_u32(hi, lo, 1));
                         }
                     }
                 }
             }
         }
-        // ---- copy (as in lz4_decompress_v5.hip; a trip has a literal run or a copy, the step takes both forms) ----
+        // ---- copy (as in lz4_decompress_v5.hip; a trip has a literal run, a copy, or a short run and the copy behind it) ----
         const int32_t n0 = (litRem > LONG || litRem < HEAD) ? litRem : HEAD;
         int32_t n1 = rem < dist ? rem : dist;
         n1 = (n1 > LONG || n1 < HEAD) ? n1 : HEAD;
+        n1 = (litRem > n0 || dist < n0 + n1) ? 0 : n1;  // the copy waits for the run in front of it, and for bytes of this trip
         copy_step<true>(S, lane, h0, have0, out + litOut, in + litPos, n0, inEnd, out + cur, out + cur - dist, n1, outEnd);
         litOut += n0;
         litPos += n0;
