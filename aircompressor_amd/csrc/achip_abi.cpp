@@ -25,7 +25,8 @@ hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 hipError_t launch_snappy_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
-hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant);
+hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant, void* scratch);
+int64_t snappy_compress_scratch_bytes();
 hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant, int32_t tileMax);
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
 int64_t zstd_decompress_scratch_bytes(int32_t nBlocks, int32_t tileMax);
@@ -51,7 +52,7 @@ struct achip_ctx {
     int snappydVariant = 5;  // 0 direct, 1 rings (snappy_decompress_v2.hip), 4 a lane per block (snappy_decompress_v3.hip), 5 auto as for LZ4
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
     int lz4cVariant = 1;     // 0 = serial probes, 1 = 64 probes per step (batch)
-    int snappycVariant = 1;  // 0 = serial probes, 1 = 64 probes per step (batch)
+    int snappycVariant = 2;  // 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 0;
     int zstdTile = 65536;    // items per pass of the Zstd decode pipeline (halved automatically when its scratch cannot be allocated)
@@ -215,7 +216,14 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 : ctx->snappydVariant == 4 ? achip::launch_snappy_decompress_lanecopy(a, ctx->stream, nullptr)
                                            : achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, nullptr);
             break;
-        case ACHIP_OP_SNAPPY_COMPRESS: e = achip::launch_snappy_compress(a, ctx->stream, ctx->snappycVariant); break;
+        case ACHIP_OP_SNAPPY_COMPRESS: {
+            if (ctx->snappycVariant == 2) {
+                int32_t r = ensure_scratch(ctx, achip::snappy_compress_scratch_bytes());
+                if (r < 0) return r;
+            }
+            e = achip::launch_snappy_compress(a, ctx->stream, ctx->snappycVariant, ctx->scratch);
+            break;
+        }
         case ACHIP_OP_ZSTD_DECOMPRESS: {
             // pipeline scratch scales with the tile (items per pass, <= 65536: ~17 GB); when the device cannot give that much,
             // smaller tiles are tried before giving up (the one-kernel decoder's 270 MB are always part of it)

@@ -140,10 +140,65 @@ __global__ __launch_bounds__(64) void snappy_compress_batch_kernel(BatchArgs a)
     }
 }
 
-hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant)
+// Two-tier variant (the default).  The 32 KB hash table allows five wavefronts per CU when it sits in LDS, and the encoder is a
+// serial chain per buffer, so throughput is (wavefronts in flight) x (chain speed).  A workgroup here is FOUR wavefronts around one
+// LDS table: wavefront 0 encodes with the table in LDS, the other three with tables in global memory (a 32 KB slab each, resident
+// in the L2 / Infinity Cache) -- slower chains, but fifteen more of them per CU.  Wavefronts are independent and persistent (each
+// draws its next buffer from a counter), so the faster ones simply take more buffers.
+__global__ __launch_bounds__(256) void snappy_compress_tiers_kernel(BatchArgs a, uint16_t* slabs, int32_t* nextItem)
+{
+    using namespace snc;
+    __shared__ uint16_t ldsTable[MAX_HASH_TABLE_SIZE];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint16_t* const slab = slabs + ((size_t)blockIdx.x * 3 + (wave > 0 ? wave - 1 : 0)) * MAX_HASH_TABLE_SIZE;
+    for (;;) {
+        int32_t block = 0;
+        if (lane == 0) {
+            block = atomicAdd(nextItem, 1);
+        }
+        block = __builtin_amdgcn_readfirstlane(block);
+        if (block >= a.nBlocks) {
+            return;
+        }
+        const uint8_t* __restrict__ in0 = a.srcBase + a.srcOff[block];
+        uint8_t* __restrict__ out = a.dstBase + a.dstOff[block];
+        int32_t st = 0;
+        int32_t output = 0;
+        if (wave == 0) {
+            snappy_compress_buffer(ldsTable, in0, a.srcLen[block], out, a.dstCap[block], lane, st, output);
+        }
+        else {
+            snappy_compress_buffer(slab, in0, a.srcLen[block], out, a.dstCap[block], lane, st, output);
+        }
+        if (lane == 0) {
+            a.outLen[block] = st == 0 ? output : 0;
+            a.status[block] = st;
+            a.errOffset[block] = 0;
+        }
+        wave_mem_order();
+    }
+}
+
+namespace {
+constexpr int SNC_TIER_WORKGROUPS = 256 * 5;  // five 32 KB LDS tables per CU
+}
+int64_t snappy_compress_scratch_bytes() { return 4096 + (int64_t)SNC_TIER_WORKGROUPS * 3 * snc::MAX_HASH_TABLE_SIZE * 2; }
+
+// variant 0: serial probing, 1: batch probing with the table in LDS (a wavefront per buffer), 2 (default): batch probing, two tiers
+hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant, void* scratch)
 {
     if (a.nBlocks <= 0) {
         return hipSuccess;
+    }
+    if (variant == 2) {
+        int32_t* counter = (int32_t*)scratch;
+        const hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
+        if (e != hipSuccess) return e;
+        const unsigned need = (unsigned)((a.nBlocks + 3) / 4);
+        const unsigned grid = need < (unsigned)SNC_TIER_WORKGROUPS ? need : (unsigned)SNC_TIER_WORKGROUPS;
+        hipLaunchKernelGGL(snappy_compress_tiers_kernel, dim3(grid), dim3(256), 0, stream, a, (uint16_t*)((uint8_t*)scratch + 4096), counter);
+        return hipGetLastError();
     }
     if (variant == 0) {
         hipLaunchKernelGGL(snappy_compress_kernel, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a);

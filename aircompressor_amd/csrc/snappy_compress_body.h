@@ -95,7 +95,8 @@ __device__ __forceinline__ int32_t snappy_scan_offset(int32_t m)
 
 // SnappyRawCompressor.compress (M/snappy/SnappyRawCompressor.java:47-232) of one buffer by one wavefront, 64 steps of the
 // search loop per wave step ("batch probing": see snappy_compress.hip).  `table`: MAX_HASH_TABLE_SIZE u16 entries in LDS.
-// The block must consist of this one wavefront (__syncthreads is its barrier).  All lanes return the same values.
+// `table` may live in LDS or in global memory; only this wavefront touches it (a wavefront's LDS and vector memory operations are
+// performed in program order, so ordering points are compiler-level).  All lanes return the same values.
 __device__ __forceinline__ void snappy_compress_buffer(uint16_t* table, const uint8_t* __restrict__ in0, int32_t inLen, uint8_t* __restrict__ out, int32_t outCap, int lane,
                                                        int32_t& stOut, int32_t& outputOut)
 {
@@ -122,11 +123,11 @@ __device__ __forceinline__ void snappy_compress_buffer(uint16_t* table, const ui
             const int32_t blockLimit = (int32_t)((inLen - blockAddress) < BLOCK_SIZE ? (inLen - blockAddress) : BLOCK_SIZE);
             int32_t tableSize = blockLimit <= 1 ? 0 : (int32_t)((0x80000000u >> __builtin_clz((uint32_t)(blockLimit - 1))) << 1);
             tableSize = tableSize < 256 ? 256 : (tableSize > MAX_HASH_TABLE_SIZE ? MAX_HASH_TABLE_SIZE : tableSize);
-            __syncthreads();
+            wave_mem_order();
             for (int i = lane; i < tableSize; i += 64) {
                 table[i] = 0;
             }
-            __syncthreads();
+            wave_mem_order();
             const int hashBits = 31 - __builtin_clz((uint32_t)tableSize);
             const int32_t shift = 32 - hashBits;
             const int32_t fastInputLimit = blockLimit - INPUT_MARGIN_BYTES;
@@ -209,7 +210,7 @@ __device__ __forceinline__ void snappy_compress_buffer(uint16_t* table, const ui
                             table[h] = (uint16_t)pos;
                         }
                     }
-                    __syncthreads();
+                    wave_mem_order();
 
                     if (winner < 0) {
                         if (firstInvalid < 64) {

@@ -46,10 +46,10 @@ def all_blocks():
     return blocks
 
 
-@pytest.mark.parametrize("codec", ["lz4", "snappy"])
-@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("codec, variant", [("lz4", 1), ("lz4", 0), ("snappy", 2), ("snappy", 1), ("snappy", 0)])
 def test_compress_is_bit_exact_with_oracle(gb, o, codec, variant):
-    gb.set_option("%s.compress.variant" % codec, variant)  # 1 = 64 probes per step (default), 0 = serial probes
+    # 0 = serial probes, 1 = 64 probes per step (LZ4 default), 2 = the same in two tiers: hash tables in LDS and in global memory (Snappy default)
+    gb.set_option("%s.compress.variant" % codec, variant)
     blocks = all_blocks()
     caps = [o.max_compressed_length(codec, len(b)) for b in blocks]
     outs, status, _ = gb.run(CODECS[codec]["c"], blocks, caps)
@@ -60,7 +60,7 @@ def test_compress_is_bit_exact_with_oracle(gb, o, codec, variant):
     n_hand = len(common.HAND_CASES)
     for k, (_, _, e) in enumerate(common.corpus_sample()):
         assert hashlib.sha256(outs[n_hand + k]).hexdigest() == e[codec]["sha256"]
-    gb.set_option("%s.compress.variant" % codec, 1)
+    gb.set_option("%s.compress.variant" % codec, 2 if codec == "snappy" else 1)
 
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
