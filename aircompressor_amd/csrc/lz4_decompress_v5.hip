@@ -211,12 +211,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // ---- copy.  Per trip a lane moves at most HEAD bytes of its literal run and HEAD bytes of its match itself and keeps
         // the rest for its next trips (it then parses nothing new) -- unless more than LONG bytes are left: those go out at once,
         // dealt to all lanes.  Of the match at most one period, and nothing while its source reaches into bytes of this trip.
-        if (a.ringPad == 240 || a.ringPad == 224) {  // timing aids (ring pad 240: parse only, 224: literals only, 208: matches only)
-            rem = 0;
-        }
-        if (a.ringPad == 240 || a.ringPad == 208) {
-            litRem = 0;
-        }
         const int32_t n0 = (litRem > LONG || litRem < HEAD) ? litRem : HEAD;
         int32_t n1 = rem < dist ? rem : dist;
         n1 = (n1 > LONG || n1 < HEAD) ? n1 : HEAD;
