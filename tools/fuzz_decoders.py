@@ -7,59 +7,63 @@ from tests import common, oracle_lib
 from tests.gpu_harness import GpuBatch
 from tests.oracle_lib import OracleError
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-o = oracle_lib.load()
-gb = GpuBatch(0)
-blocks = [d for _, d, _ in common.corpus_sample()] + common.synthetic_blocks(9, 24) + [d for _, d in common.HAND_CASES if len(d) > 0]
-blocks += [b[:n] for b in blocks[:6] for n in (17, 300, 5000)]
-OPS = {"lz4": 0, "snappy": 2}
-VARIANTS = {"lz4": [1, 4, 3, 2], "snappy": [1, 4]}
+def run(n_cases, seed):
+    rng = np.random.default_rng(seed)
+    o = oracle_lib.load()
+    gb = GpuBatch(0)
+    blocks = [d for _, d, _ in common.corpus_sample()] + common.synthetic_blocks(9, 24) + [d for _, d in common.HAND_CASES if len(d) > 0]
+    blocks += [b[:n] for b in blocks[:6] for n in (17, 300, 5000)]
+    OPS = {"lz4": 0, "snappy": 2}
+    VARIANTS = {"lz4": [1, 4, 3, 2], "snappy": [1, 4]}
 
 
-def expect(codec, data, cap):
-    try:
-        return 0, 0, o.decompress(codec, data, cap)
-    except OracleError as e:
-        return e.status, e.offset, None
+    def expect(codec, data, cap):
+        try:
+            return 0, 0, o.decompress(codec, data, cap)
+        except OracleError as e:
+            return e.status, e.offset, None
 
 
-bad = 0
-for codec in ("lz4", "snappy"):
-    comp = [o.compress(codec, b) for b in blocks]
-    cases = []
-    for _ in range(n_cases):
-        k = int(rng.integers(0, len(blocks)))
-        c = bytearray(comp[k])
-        cap = len(blocks[k])
-        kind = int(rng.integers(0, 6))
-        if kind <= 2:      # 1..4 byte mutations
-            for _ in range(int(rng.integers(1, 5))):
-                c[int(rng.integers(0, len(c)))] = int(rng.integers(0, 256))
-        elif kind == 3:    # truncation / extension
-            if rng.integers(0, 2) and len(c) > 1:
-                c = c[:int(rng.integers(1, len(c)))]
-            else:
-                c += bytes(rng.integers(0, 256, int(rng.integers(1, 20)), dtype=np.uint8))
-        elif kind == 4:    # capacity
-            cap = max(0, cap + int(rng.integers(-40, 41)))
-        else:              # a mutation near the start (headers, first tokens) and a capacity change
-            c[int(rng.integers(0, min(len(c), 24)))] ^= 1 << int(rng.integers(0, 8))
-            cap = max(0, cap + int(rng.integers(-8, 9)))
-        cases.append((bytes(c), cap))
-    want = [expect(codec, c, cap) for c, cap in cases]
-    for variant in VARIANTS[codec]:
-        gb.set_option("%s.decompress.variant" % codec, variant)
-        outs, status, err = gb.run(OPS[codec], [c for c, _ in cases], [cap for _, cap in cases], unaligned=True)
-        wrong = 0
-        for i, (est, eoff, eout) in enumerate(want):
-            ok = status[i] == est and (err[i] == eoff if est != 0 else outs[i] == eout)
-            if not ok:
-                wrong += 1
-                if wrong <= 5:
-                    print("MISMATCH", codec, "variant", variant, "case", i, "gpu", status[i], err[i], "oracle", est, eoff, "len", len(cases[i][0]), "cap", cases[i][1], flush=True)
-        bad += wrong
-        n_err = sum(1 for w in want if w[0] != 0)
-        print("%s variant %d: %d cases (%d malformed), %d mismatches" % (codec, variant, len(cases), n_err, wrong), flush=True)
-print("TOTAL MISMATCHES", bad)
-sys.exit(1 if bad else 0)
+    bad = 0
+    for codec in ("lz4", "snappy"):
+        comp = [o.compress(codec, b) for b in blocks]
+        cases = []
+        for _ in range(n_cases):
+            k = int(rng.integers(0, len(blocks)))
+            c = bytearray(comp[k])
+            cap = len(blocks[k])
+            kind = int(rng.integers(0, 6))
+            if kind <= 2:      # 1..4 byte mutations
+                for _ in range(int(rng.integers(1, 5))):
+                    c[int(rng.integers(0, len(c)))] = int(rng.integers(0, 256))
+            elif kind == 3:    # truncation / extension
+                if rng.integers(0, 2) and len(c) > 1:
+                    c = c[:int(rng.integers(1, len(c)))]
+                else:
+                    c += bytes(rng.integers(0, 256, int(rng.integers(1, 20)), dtype=np.uint8))
+            elif kind == 4:    # capacity
+                cap = max(0, cap + int(rng.integers(-40, 41)))
+            else:              # a mutation near the start (headers, first tokens) and a capacity change
+                c[int(rng.integers(0, min(len(c), 24)))] ^= 1 << int(rng.integers(0, 8))
+                cap = max(0, cap + int(rng.integers(-8, 9)))
+            cases.append((bytes(c), cap))
+        want = [expect(codec, c, cap) for c, cap in cases]
+        for variant in VARIANTS[codec]:
+            gb.set_option("%s.decompress.variant" % codec, variant)
+            outs, status, err = gb.run(OPS[codec], [c for c, _ in cases], [cap for _, cap in cases], unaligned=True)
+            wrong = 0
+            for i, (est, eoff, eout) in enumerate(want):
+                ok = status[i] == est and (err[i] == eoff if est != 0 else outs[i] == eout)
+                if not ok:
+                    wrong += 1
+                    if wrong <= 5:
+                        print("MISMATCH", codec, "variant", variant, "case", i, "gpu", status[i], err[i], "oracle", est, eoff, "len", len(cases[i][0]), "cap", cases[i][1], flush=True)
+            bad += wrong
+            n_err = sum(1 for w in want if w[0] != 0)
+            print("%s variant %d: %d cases (%d malformed), %d mismatches" % (codec, variant, len(cases), n_err, wrong), flush=True)
+    print("TOTAL MISMATCHES", bad)
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 6000, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
