@@ -7,14 +7,14 @@ from tests import common, oracle_lib
 from tests.gpu_harness import GpuBatch
 from tests.oracle_lib import OracleError
 
-def run(n_cases, seed):
+def run(n_cases, seed, codecs=("lz4", "snappy")):
     rng = np.random.default_rng(seed)
     o = oracle_lib.load()
     gb = GpuBatch(0)
     blocks = [d for _, d, _ in common.corpus_sample()] + common.synthetic_blocks(9, 24) + [d for _, d in common.HAND_CASES if len(d) > 0]
     blocks += [b[:n] for b in blocks[:6] for n in (17, 300, 5000)]
-    OPS = {"lz4": 0, "snappy": 2}
-    VARIANTS = {"lz4": [1, 4, 3, 2], "snappy": [1, 4]}
+    OPS = {"lz4": 0, "snappy": 2, "zstd": 4, "lz4frame": 6, "snappyframed": 8}
+    VARIANTS = {"lz4": [1, 4, 3, 2], "snappy": [1, 4], "zstd": [1, 0], "lz4frame": [None], "snappyframed": [None]}
 
 
     def expect(codec, data, cap):
@@ -25,8 +25,16 @@ def run(n_cases, seed):
 
 
     bad = 0
-    for codec in ("lz4", "snappy"):
+    for codec in codecs:
         comp = [o.compress(codec, b) for b in blocks]
+        if codec == "zstd":  # third-party frames as well (no checksum, other header forms, treeless / repeat modes never from the Java encoder)
+            try:
+                import pyarrow as pa
+                z = pa.Codec("zstd", compression_level=3)
+                comp = comp + [z.compress(b, asbytes=True) for b in blocks]
+                blocks = blocks + blocks
+            except ImportError:
+                pass
         cases = []
         for _ in range(n_cases):
             k = int(rng.integers(0, len(blocks)))
@@ -49,7 +57,8 @@ def run(n_cases, seed):
             cases.append((bytes(c), cap))
         want = [expect(codec, c, cap) for c, cap in cases]
         for variant in VARIANTS[codec]:
-            gb.set_option("%s.decompress.variant" % codec, variant)
+            if variant is not None:
+                gb.set_option("%s.decompress.variant" % codec, variant)
             outs, status, err = gb.run(OPS[codec], [c for c, _ in cases], [cap for _, cap in cases], unaligned=True)
             wrong = 0
             for i, (est, eoff, eout) in enumerate(want):
@@ -60,10 +69,11 @@ def run(n_cases, seed):
                         print("MISMATCH", codec, "variant", variant, "case", i, "gpu", status[i], err[i], "oracle", est, eoff, "len", len(cases[i][0]), "cap", cases[i][1], flush=True)
             bad += wrong
             n_err = sum(1 for w in want if w[0] != 0)
-            print("%s variant %d: %d cases (%d malformed), %d mismatches" % (codec, variant, len(cases), n_err, wrong), flush=True)
+            print("%s variant %s: %d cases (%d malformed), %d mismatches" % (codec, variant, len(cases), n_err, wrong), flush=True)
     print("TOTAL MISMATCHES", bad)
     return bad
 
 
 if __name__ == "__main__":
-    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 6000, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 6000, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+                      tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("lz4", "snappy")) else 0)
