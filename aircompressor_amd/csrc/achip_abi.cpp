@@ -21,7 +21,7 @@ hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, i
 hipError_t launch_lz4_decompress_lanes(const BatchArgs& a, hipStream_t stream, int ringClass);
 hipError_t launch_lz4_decompress_steps(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass);
 hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
-hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups);
+hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 hipError_t launch_snappy_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
@@ -31,7 +31,8 @@ hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* 
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
 int64_t zstd_decompress_scratch_bytes(int32_t nBlocks, int32_t tileMax);
 int64_t zstd_compress_scratch_bytes(int32_t nBlocks);
-hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream, void* scratch);
+hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant);
+int64_t snappyframed_decompress_scratch_bytes(int32_t nStreams);
 hipError_t launch_snappyframed_compress(const BatchArgs& a, hipStream_t stream, void* scratch);
 int64_t snappyframed_compress_scratch_bytes();
 hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch);
@@ -55,6 +56,7 @@ struct achip_ctx {
     int snappycVariant = 2;  // 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 0;
+    int snappyFramedVariant = 1;  // framed reader: 1 = chunk list + batched block decoders (default), 0 = one wavefront per stream
     int zstdTile = 65536;    // items per pass of the Zstd decode pipeline (halved automatically when its scratch cannot be allocated)
     int ringPad = 80;        // 64 bytes of far-match staging + 16: consecutive blocks start on different LDS banks
     int scratchPoison = -1;
@@ -112,6 +114,7 @@ achip::BatchArgs make_args(const void* srcBase, const int64_t* srcOff, const int
     a.errOffset = errOffset;
     a.nBlocks = nBlocks;
     a.ringPad = 0;
+    a.nBlocksDev = nullptr;
     return a;
 }
 
@@ -188,7 +191,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 int32_t* mixedGroups = (int32_t*)ctx->scratch;
                 ctx->lastLz4dAuto = true;
                 ctx->lastZstddBlocks = 0;
-                e = achip::launch_lz4_mixed_groups(a, ctx->stream, mixedGroups);
+                e = achip::launch_lz4_mixed_groups(a, ctx->stream, mixedGroups, 0);
                 if (e == hipSuccess) e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, mixedGroups);
                 if (e == hipSuccess) e = achip::launch_lz4_decompress_lanecopy(a, ctx->stream, mixedGroups);
                 break;
@@ -207,7 +210,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 int32_t* mixedGroups = (int32_t*)ctx->scratch;
                 ctx->lastLz4dAuto = true;
                 ctx->lastZstddBlocks = 0;
-                e = achip::launch_lz4_mixed_groups(a, ctx->stream, mixedGroups);
+                e = achip::launch_lz4_mixed_groups(a, ctx->stream, mixedGroups, 0);
                 if (e == hipSuccess) e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, mixedGroups);
                 if (e == hipSuccess) e = achip::launch_snappy_decompress_lanecopy(a, ctx->stream, mixedGroups);
                 break;
@@ -245,9 +248,9 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             break;
         }
         case ACHIP_OP_SNAPPYFRAMED_DECOMPRESS: {
-            int32_t r = ensure_scratch(ctx, 4096);
+            int32_t r = ensure_scratch(ctx, achip::snappyframed_decompress_scratch_bytes(a.nBlocks));
             if (r < 0) return r;
-            e = achip::launch_snappyframed_decompress(a, ctx->stream, ctx->scratch);
+            e = achip::launch_snappyframed_decompress(a, ctx->stream, ctx->scratch, ctx->snappyFramedVariant);
             break;
         }
         case ACHIP_OP_SNAPPYFRAMED_COMPRESS: {
@@ -560,6 +563,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     else if (k == "decompress.ring_class") ctx->ringClass = (int)value;
     else if (k == "lz4.compress.variant") ctx->lz4cVariant = (int)value;
     else if (k == "snappy.compress.variant") ctx->snappycVariant = (int)value;
+    else if (k == "snappyframed.decompress.variant") ctx->snappyFramedVariant = (int)value;
     else if (k == "decompress.ring_pad") {
         if (value < 0 || value > 256 || (value & 15) != 0) return bad_argument("ring pad must be a multiple of 16 in 0..256");
         ctx->ringPad = (int)value;

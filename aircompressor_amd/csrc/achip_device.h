@@ -27,7 +27,11 @@ struct BatchArgs {
     int64_t* __restrict__ errOffset;
     int32_t nBlocks;
     int32_t ringPad;  // LDS padding between the ring pairs of consecutive blocks (decoders)
+    const int32_t* nBlocksDev;  // when set: the number of blocks is this device word (<= nBlocks, which then sizes the launch): a
+                                // batch assembled on the device (the chunk list of the framed readers)
 };
+
+__device__ __forceinline__ int32_t batch_count(const BatchArgs& a) { return a.nBlocksDev != nullptr ? *a.nBlocksDev : a.nBlocks; }
 
 __device__ __forceinline__ constexpr int32_t mk_status(int cls, int detail) { return -(cls + 16 * detail); }
 

@@ -234,32 +234,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 }
 
 // counts the groups of 16 consecutive blocks whose compressed sizes differ by more than 2x
-__global__ __launch_bounds__(256) void lz4_mixed_groups_kernel(BatchArgs a, int32_t* mixedGroups)
+__global__ __launch_bounds__(256) void lz4_mixed_groups_kernel(BatchArgs a, int32_t* mixedGroups, int32_t minBlocks)
 {
+    const int32_t n = batch_count(a);
+    if (n < minBlocks) {
+        return;  // too few blocks for the lane-per-block decoder: the count stays 0
+    }
     const int64_t group = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t first = group * 16;
     bool mixed = false;
-    if (first < a.nBlocks) {
+    if (first < n) {
         int32_t lo = 0x7FFFFFFF, hi = 0;
-        for (int64_t b = first; b < first + 16 && b < a.nBlocks; b++) {
+        for (int64_t b = first; b < first + 16 && b < n; b++) {
             const int32_t len = a.srcLen[b];
             lo = len < lo ? len : lo;
             hi = len > hi ? len : hi;
         }
         mixed = (int64_t)hi > 2 * (int64_t)lo;
     }
-    const int n = __popcll(__ballot(mixed));
-    if ((threadIdx.x & 63) == 0 && n > 0) {
-        atomicAdd(mixedGroups, n);
+    const int found = __popcll(__ballot(mixed));
+    if ((threadIdx.x & 63) == 0 && found > 0) {
+        atomicAdd(mixedGroups, found);
     }
 }
 
-hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups)
+hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks)
 {
     const hipError_t e = hipMemsetAsync(mixedGroups, 0, sizeof(int32_t), stream);
     if (e != hipSuccess) return e;
     const unsigned grid = (unsigned)(((a.nBlocks + 15) / 16 + 255) / 256);
-    hipLaunchKernelGGL(lz4_mixed_groups_kernel, dim3(grid), dim3(256), 0, stream, a, mixedGroups);
+    hipLaunchKernelGGL(lz4_mixed_groups_kernel, dim3(grid), dim3(256), 0, stream, a, mixedGroups, minBlocks);
     return hipGetLastError();
 }
 

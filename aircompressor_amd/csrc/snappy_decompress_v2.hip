@@ -10,7 +10,7 @@ namespace achip {
 template <int GS, int IN_RING, int OUT_RING, int GPL>
 __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
-    if (mixedGroups != nullptr && lz4_batch_is_mixed(*mixedGroups, a.nBlocks)) {  // auto mode (achip_abi.cpp): the lane-per-block decoder takes this batch
+    if (mixedGroups != nullptr && lz4_batch_is_mixed(*mixedGroups, batch_count(a))) {  // auto mode (achip_abi.cpp): the lane-per-block decoder takes this batch
         return;
     }
     ACHIP_DYNAMIC_LDS(smem);
@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs 
     const int g = threadIdx.x & (GS - 1);
     const int grp = threadIdx.x / GS;
     const int64_t block = (int64_t)blockIdx.x * GROUPS_PER_WG + grp;
-    if (block >= a.nBlocks) {
+    if (block >= batch_count(a)) {
         return;
     }
     const uint8_t* __restrict__ in0 = a.srcBase + a.srcOff[block];

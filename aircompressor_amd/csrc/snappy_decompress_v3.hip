@@ -27,14 +27,14 @@ template <int IN_DW>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void snappy_decompress_lanecopy_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
     using namespace sp;
-    if (mixedGroups != nullptr && !lz4_batch_is_mixed(*mixedGroups, a.nBlocks)) {  // auto mode: the ring decoder takes this batch
+    if (mixedGroups != nullptr && !lz4_batch_is_mixed(*mixedGroups, batch_count(a))) {  // auto mode: the ring decoder takes this batch
         return;
     }
     __shared__ uint32_t ldsIn[IN_DW * 64];
     __shared__ CopyScratch S;
     const int lane = threadIdx.x;
     const int64_t block = (int64_t)blockIdx.x * 64 + lane;
-    const bool have = block < a.nBlocks;
+    const bool have = block < batch_count(a);
     const uint8_t* in0 = have ? a.srcBase + a.srcOff[block] : a.srcBase;
     uint8_t* out = have ? a.dstBase + a.dstOff[block] : a.dstBase;
     const int32_t inLen0 = have ? a.srcLen[block] : 0;
@@ -97,7 +97,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     int32_t cur = 0, rem = 0, dist = 0;
     int32_t periodic = 0;
     const uint8_t* const inEnd = in + inLimit;
-    const uint8_t* const outEnd = out + outLimit;
+    // bound of the one-store short runs: the announced length, not the capacity -- a caller may hand out capacities that reach into
+    // the next block's output (the framed reader does: the Java reader's buffer is larger than a chunk's plaintext)
+    const uint8_t* const outEnd = out + (done ? 0 : (int32_t)expected);
     while (__ballot(!done || rem > 0 || litRem > 0) != 0) {
         HeadRegs h0;
         h0.A = u32x4{0, 0, 0, 0};

@@ -150,7 +150,7 @@ __device__ int32_t decompress_item(const Crc32cTables& tables, const uint8_t* __
 
 }  // namespace snf
 
-__global__ __launch_bounds__(64) void snappyframed_decompress_kernel(BatchArgs a, int32_t* nextItem)
+__global__ __launch_bounds__(64) void snappyframed_decompress_kernel(BatchArgs a, int32_t* nextItem, const int32_t* only)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[snf::IN_RING + snf::OUT_RING];
     __shared__ Crc32cTables tables;
@@ -166,6 +166,9 @@ __global__ __launch_bounds__(64) void snappyframed_decompress_kernel(BatchArgs a
         const int32_t block = item;
         if (block >= a.nBlocks) {
             return;
+        }
+        if (only != nullptr && only[block] == 0) {
+            continue;  // done by the chunk-parallel path
         }
         int32_t op = 0;
         int64_t eo = 0;
@@ -276,17 +279,353 @@ hipError_t launch_snappyframed_compress(const BatchArgs& a, hipStream_t stream, 
     return hipGetLastError();
 }
 
-hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream, void* scratch)
+// ---------------------------------------------------------------------------------------------------------------------
+// Chunk-parallel reader (the default).  A stream's chunks are independent of each other except for where they start and
+// where their plaintext goes, and both follow from the chunk headers alone (a compressed chunk announces its plaintext
+// length in its preamble).  So:
+//   walk    one LANE per stream runs the Java loop over the chunk headers only (same checks, same order, everything that
+//           does not need the chunk's body) and writes one descriptor per data chunk -- source, destination, the capacity
+//           the Java reader would hand its block decoder -- into a batch assembled on the device;
+//   decode  that batch goes through the batched Snappy block decoders (rings / lane-per-block, chosen on the device as for
+//           any other batch): a 64 KiB chunk is exactly the unit those kernels are built for;
+//   verify  one wavefront per chunk copies a stored chunk or takes the decoded one and checks the masked CRC-32C;
+//   fold    one lane per stream looks at its chunks in stream order: the first chunk that failed (block codec error before
+//           checksum error) gives the stream's status, else the error the walk stopped at, else the length.
+// A stream whose chunks do not fit into the descriptor arrays is left to the one-wavefront-per-stream kernel below.
+namespace snf {
+constexpr int32_t MAX_CHUNKS = 1 << 20;
+
+struct ChunkList {
+    // per stream
+    int32_t* sFirst;
+    int32_t* sCount;
+    int32_t* sStatus;   // what the walk stopped at (0: end of stream)
+    int64_t* sErrOff;
+    int32_t* sOut;      // plaintext bytes if every chunk decodes
+    int32_t* sSerial;   // 1: handled by the serial kernel
+    // per chunk: a batch for the block decoders ...
+    int64_t* cSrcOff;
+    int32_t* cSrcLen;
+    int64_t* cDstOff;
+    int32_t* cDstCap;
+    int32_t* cOutLen;
+    int32_t* cStatus;
+    int64_t* cErrOff;
+    // ... and what the verify / fold steps need
+    uint32_t* cCrc;
+    int32_t* cRawLen;   // >= 0: a stored chunk of this many bytes (the decoders see an empty input and are overruled); -1: compressed
+    int32_t* cPos;      // position of the chunk header in its stream
+    int32_t* counters;  // [0] chunks allocated, [1] chunks in the batch (= min(allocated, MAX_CHUNKS)), [2] verify cursor, [16] mixed groups
+};
+
+__device__ __forceinline__ uint32_t rd_bytes(const uint8_t* p, int n)  // little-endian, n <= 4 (cold: byte loads)
+{
+    uint32_t v = 0;
+    for (int i = 0; i < n; i++) {
+        v |= (uint32_t)p[i] << (8 * i);
+    }
+    return v;
+}
+
+// The Java loop over one stream without the chunk bodies.  FILL = false: count the data chunks; true: write their descriptors.
+template <bool FILL>
+__device__ void walk_stream(const BatchArgs& a, const ChunkList& L, int32_t stream, int32_t first, int32_t& countOut, int32_t& stOut, int64_t& eoOut, int32_t& outOut)
+{
+    const uint8_t* __restrict__ in = a.srcBase + a.srcOff[stream];
+    const int32_t inLen = a.srcLen[stream];
+    const int32_t outCap = a.dstCap[stream];
+    countOut = 0;
+    outOut = 0;
+    stOut = 0;
+    eoOut = 0;
+#define WALK_FAIL(detail, off)                              \
+    {                                                       \
+        stOut = mk_status(ACHIP_CLASS_MALFORMED, detail);   \
+        eoOut = (int64_t)(off);                             \
+        outOut = o;                                         \
+        countOut = n;                                       \
+        return;                                             \
+    }
+    int32_t o = 0;
+    int32_t n = 0;
+    if (inLen < 10) WALK_FAIL(ACHIP_D_SNF_EOF_STREAM_HEADER, 0);
+    if (rd_bytes(in, 4) != 0x000006FFu || rd_bytes(in + 4, 4) != 0x50614E73u || in[8] != 0x70 || in[9] != 0x59) WALK_FAIL(ACHIP_D_SNF_BAD_STREAM_HEADER, 0);
+    int32_t pos = 10;
+    int32_t javaInput = MAX_BLOCK_SIZE + 5, javaUncompressed = MAX_BLOCK_SIZE + 5;
+    for (;;) {
+        const int32_t chunk = pos;
+        if (pos == inLen) {
+            break;
+        }
+        if (inLen - pos < 4) WALK_FAIL(ACHIP_D_SNF_EOF_BLOCK_HEADER, chunk);
+        const uint32_t header = rd_bytes(in + pos, 4);
+        const int flag = (int)(header & 0xFF);
+        const int32_t length = (int32_t)(header >> 8);
+        pos += 4;
+        bool skip = false;
+        int32_t minLength;
+        if (flag == COMPRESSED_DATA_FLAG || flag == UNCOMPRESSED_DATA_FLAG) {
+            minLength = 5;
+        }
+        else if (flag == STREAM_IDENTIFIER_FLAG) {
+            if (length != 6) WALK_FAIL(ACHIP_D_SNF_STREAM_ID_LENGTH, chunk);
+            skip = true;
+            minLength = 6;
+        }
+        else {
+            if (flag <= 0x7f) WALK_FAIL(ACHIP_D_SNF_UNSKIPPABLE, chunk);
+            skip = true;
+            minLength = 0;
+        }
+        if (length < minLength) WALK_FAIL(ACHIP_D_SNF_INVALID_LENGTH, chunk);
+        if (skip) {
+            pos += length < inLen - pos ? length : inLen - pos;
+            continue;
+        }
+        if (length > javaInput) {
+            javaInput = length;
+            javaUncompressed = javaUncompressed < length ? length : javaUncompressed;
+        }
+        if (inLen - pos < length) WALK_FAIL(ACHIP_D_SNF_EOF_FRAME, chunk);
+        const uint32_t stored = rd_bytes(in + pos, 4);
+        const int32_t dlen = length - 4;
+        int32_t produced, limit, rawLen;
+        if (flag == COMPRESSED_DATA_FLAG) {
+            int32_t ulen = 0, beo = 0;
+            const int32_t pst = read_uncompressed_length(in + pos + 4, dlen, ulen, beo);
+            if (pst != 0) {  // the block codec's own exception, before any byte is decoded
+                stOut = pst;
+                eoOut = (int64_t)beo;
+                outOut = o;
+                countOut = n;
+                return;
+            }
+            javaUncompressed = javaUncompressed < ulen ? ulen : javaUncompressed;
+            if (ulen > outCap - o) {
+                stOut = mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_SNF_OUTPUT_TOO_SMALL);
+                eoOut = (int64_t)chunk;
+                outOut = o;
+                countOut = n;
+                return;
+            }
+            limit = javaUncompressed < outCap - o ? javaUncompressed : outCap - o;
+            produced = ulen;
+            rawLen = -1;
+        }
+        else {
+            if (dlen > outCap - o) {
+                stOut = mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_SNF_OUTPUT_TOO_SMALL);
+                eoOut = (int64_t)chunk;
+                outOut = o;
+                countOut = n;
+                return;
+            }
+            limit = 0;
+            produced = dlen;
+            rawLen = dlen;
+        }
+        if (FILL) {
+            const int32_t c = first + n;
+            L.cSrcOff[c] = a.srcOff[stream] + pos + 4;
+            L.cSrcLen[c] = rawLen >= 0 ? 0 : dlen;
+            L.cDstOff[c] = a.dstOff[stream] + o;
+            L.cDstCap[c] = limit;
+            L.cCrc[c] = stored;
+            L.cRawLen[c] = rawLen;
+            L.cPos[c] = chunk;
+        }
+        n++;
+        o += produced;
+        pos += length;
+    }
+#undef WALK_FAIL
+    countOut = n;
+    outOut = o;
+}
+
+__global__ __launch_bounds__(64) void snappyframed_walk_kernel(BatchArgs a, ChunkList L)
+{
+    const int32_t stream = blockIdx.x * 64 + threadIdx.x;
+    if (stream >= a.nBlocks) {
+        return;
+    }
+    int32_t n = 0, st = 0, out = 0;
+    int64_t eo = 0;
+    walk_stream<false>(a, L, stream, 0, n, st, eo, out);
+    const int32_t first = n > 0 ? atomicAdd(L.counters, n) : 0;
+    const bool fits = (int64_t)first + n <= MAX_CHUNKS;
+    L.sFirst[stream] = first;
+    L.sCount[stream] = fits ? n : 0;
+    L.sStatus[stream] = st;
+    L.sErrOff[stream] = eo;
+    L.sOut[stream] = out;
+    L.sSerial[stream] = fits ? 0 : 1;
+    if (fits && n > 0) {
+        walk_stream<true>(a, L, stream, first, n, st, eo, out);
+    }
+    else if (!fits) {  // the part of this stream's range that lies inside the arrays: empty blocks nobody looks at
+        for (int64_t c = first; c < (int64_t)first + n && c < MAX_CHUNKS; c++) {
+            L.cSrcOff[c] = 0;
+            L.cSrcLen[c] = 0;
+            L.cDstOff[c] = 0;
+            L.cDstCap[c] = 0;
+            L.cCrc[c] = 0;
+            L.cRawLen[c] = -1;
+            L.cPos[c] = 0;
+        }
+    }
+}
+
+// the batch holds the chunks that fit: a stream that does not fit leaves a hole of descriptors nobody reads (src length 0 below)
+__global__ void snappyframed_seal_kernel(ChunkList L)
+{
+    const int32_t allocated = L.counters[0];
+    L.counters[1] = allocated < MAX_CHUNKS ? allocated : MAX_CHUNKS;
+}
+
+__global__ __launch_bounds__(64) void snappyframed_verify_kernel(BatchArgs a, ChunkList L)
+{
+    __shared__ Crc32cTables tables;
+    __shared__ int32_t item;
+    const int lane = threadIdx.x;
+    crc32c_tables_init(tables, lane);
+    const int32_t total = L.counters[1];
+    for (;;) {
+        __syncthreads();
+        if (lane == 0) {
+            item = atomicAdd(L.counters + 2, 1);
+        }
+        __syncthreads();
+        const int32_t c = item;
+        if (c >= total) {
+            return;
+        }
+        const int32_t rawLen = L.cRawLen[c];
+        uint8_t* dst = a.dstBase + L.cDstOff[c];
+        int32_t produced;
+        if (rawLen >= 0) {
+            group_copy<64>(dst, a.srcBase + L.cSrcOff[c], rawLen, lane);
+            wave_mem_order();
+            produced = rawLen;
+        }
+        else {
+            if (L.cStatus[c] != 0) {
+                continue;  // the block decoder's verdict stands
+            }
+            produced = L.cOutLen[c];
+        }
+        const bool ok = L.cCrc[c] == crc32c_mask(wave_crc32c(tables, dst, produced, lane));
+        if (lane == 0) {
+            L.cStatus[c] = ok ? 0 : mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNF_CHECKSUM);
+            L.cErrOff[c] = ok ? 0 : (int64_t)L.cPos[c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void snappyframed_fold_kernel(BatchArgs a, ChunkList L)
+{
+    const int32_t stream = blockIdx.x * 64 + threadIdx.x;
+    if (stream >= a.nBlocks || L.sSerial[stream] != 0) {
+        return;
+    }
+    int32_t st = L.sStatus[stream];
+    int64_t eo = L.sErrOff[stream];
+    const int32_t first = L.sFirst[stream], n = L.sCount[stream];
+    for (int32_t k = 0; k < n; k++) {
+        const int32_t cs = L.cStatus[first + k];
+        if (cs != 0) {
+            st = cs;
+            eo = L.cErrOff[first + k];
+            break;
+        }
+    }
+    a.outLen[stream] = st == 0 ? L.sOut[stream] : 0;
+    a.status[stream] = st;
+    a.errOffset[stream] = st == 0 ? 0 : eo;
+}
+}  // namespace snf
+
+hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
+hipError_t launch_snappy_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
+hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
+
+int64_t snappyframed_decompress_scratch_bytes(int32_t nStreams)
+{
+    const int64_t n = nStreams < 1 ? 1 : nStreams;
+    return 4096 + n * (4 * 5 + 8) + (int64_t)snf::MAX_CHUNKS * (8 * 3 + 4 * 7) + 4096;
+}
+
+hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant)
 {
     if (a.nBlocks <= 0) {
         return hipSuccess;
     }
-    int32_t* counter = (int32_t*)scratch;
-    hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
+    uint8_t* base = (uint8_t*)scratch;
+    int32_t* counters = (int32_t*)base;
+    hipError_t e = hipMemsetAsync(counters, 0, 4096, stream);
     if (e != hipSuccess) return e;
     const int32_t maxWaves = 256 * 8;
-    const unsigned grid = (unsigned)(a.nBlocks < maxWaves ? a.nBlocks : maxWaves);
-    hipLaunchKernelGGL(snappyframed_decompress_kernel, dim3(grid), dim3(64), 0, stream, a, counter);
+    if (variant == 0) {  // one wavefront per stream
+        const unsigned grid = (unsigned)(a.nBlocks < maxWaves ? a.nBlocks : maxWaves);
+        hipLaunchKernelGGL(snappyframed_decompress_kernel, dim3(grid), dim3(64), 0, stream, a, counters + 32, (const int32_t*)nullptr);
+        return hipGetLastError();
+    }
+    // carve the lists out of the scratch
+    snf::ChunkList L;
+    uint8_t* p = base + 4096;
+    const int64_t n = a.nBlocks;
+    auto take = [&](int64_t bytes) {
+        uint8_t* r = p;
+        p += (bytes + 15) & ~(int64_t)15;
+        return r;
+    };
+    L.counters = counters;
+    L.sErrOff = (int64_t*)take(8 * n);
+    L.sFirst = (int32_t*)take(4 * n);
+    L.sCount = (int32_t*)take(4 * n);
+    L.sStatus = (int32_t*)take(4 * n);
+    L.sOut = (int32_t*)take(4 * n);
+    L.sSerial = (int32_t*)take(4 * n);
+    const int64_t C = snf::MAX_CHUNKS;
+    L.cSrcOff = (int64_t*)take(8 * C);
+    L.cDstOff = (int64_t*)take(8 * C);
+    L.cErrOff = (int64_t*)take(8 * C);
+    L.cSrcLen = (int32_t*)take(4 * C);
+    L.cDstCap = (int32_t*)take(4 * C);
+    L.cOutLen = (int32_t*)take(4 * C);
+    L.cStatus = (int32_t*)take(4 * C);
+    L.cCrc = (uint32_t*)take(4 * C);
+    L.cRawLen = (int32_t*)take(4 * C);
+    L.cPos = (int32_t*)take(4 * C);
+    const unsigned perStream = (unsigned)((a.nBlocks + 63) / 64);
+    hipLaunchKernelGGL(snf::snappyframed_walk_kernel, dim3(perStream), dim3(64), 0, stream, a, L);
+    hipLaunchKernelGGL(snf::snappyframed_seal_kernel, dim3(1), dim3(1), 0, stream, L);
+    // the chunks as a batch of Snappy blocks whose size is known on the device only: launches are sized for the arrays
+    BatchArgs c;
+    c.srcBase = a.srcBase;
+    c.srcOff = L.cSrcOff;
+    c.srcLen = L.cSrcLen;
+    c.dstBase = a.dstBase;
+    c.dstOff = L.cDstOff;
+    c.dstCap = L.cDstCap;
+    c.outLen = L.cOutLen;
+    c.status = L.cStatus;
+    c.errOffset = L.cErrOff;
+    c.nBlocks = snf::MAX_CHUNKS;
+    c.ringPad = a.ringPad;
+    c.nBlocksDev = counters + 1;
+    int32_t* mixedGroups = counters + 16;
+    e = launch_lz4_mixed_groups(c, stream, mixedGroups, 65536);  // (the lane-per-block decoder wants 64 blocks per wavefront)
+    if (e == hipSuccess) e = launch_snappy_decompress_rings(c, stream, 4, 0, mixedGroups);
+    if (e == hipSuccess) e = launch_snappy_decompress_lanecopy(c, stream, mixedGroups);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(snf::snappyframed_verify_kernel, dim3(maxWaves), dim3(64), 0, stream, a, L);
+    hipLaunchKernelGGL(snf::snappyframed_fold_kernel, dim3(perStream), dim3(64), 0, stream, a, L);
+    // streams that did not fit into the lists
+    {
+        const unsigned grid = (unsigned)(a.nBlocks < maxWaves ? a.nBlocks : maxWaves);
+        hipLaunchKernelGGL(snappyframed_decompress_kernel, dim3(grid), dim3(64), 0, stream, a, counters + 32, (const int32_t*)L.sSerial);
+    }
     return hipGetLastError();
 }
 

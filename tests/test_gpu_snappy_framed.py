@@ -14,10 +14,11 @@ OP_DECOMPRESS, OP_COMPRESS = 8, 9
 HEADER = bytes([0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59])
 
 
-@pytest.fixture(scope="module")
-def gb():
+@pytest.fixture(scope="module", params=[1, 0], ids=["chunk-list", "wave-per-stream"])
+def gb(request):
+    """reader under test: chunk list + batched block decoders (default) and one wavefront per stream (its fallback)"""
     from tests.gpu_harness import GpuBatch
-    return GpuBatch(0)
+    return GpuBatch(0, options={"snappyframed.decompress.variant": request.param})
 
 
 @pytest.fixture(scope="module")
