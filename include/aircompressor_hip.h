@@ -202,7 +202,10 @@ float achip_event_elapsed_ms(void* evStart, void* evStop); /* synchronizes on ev
 /* outLen[i] = bytes written, status[i] = 0 or an ACHIP status,               */
 /* errOffset[i] = the offset the reference's exception would carry.           */
 /* The call itself is asynchronous on the ctx stream; its return value only   */
-/* reports launch failures.  Regions of distinct blocks must not overlap.     */
+/* reports launch failures.  Regions of distinct blocks must not overlap --    */
+/* the WHOLE capacity [dstOff[i], dstOff[i] + dstCap[i]) belongs to block i    */
+/* for the call: as with the Java decoders' 8-byte copies, bytes between      */
+/* outLen[i] and dstCap[i] may be written (their content is unspecified).     */
 /* ------------------------------------------------------------------------- */
 #define ACHIP_BATCH_ARGS                                                            \
     achip_ctx *ctx, const void *srcBase, const int64_t *srcOff, const int32_t *srcLen, \
