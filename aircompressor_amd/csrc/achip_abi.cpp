@@ -33,8 +33,8 @@ int64_t zstd_decompress_scratch_bytes(int32_t nBlocks, int32_t tileMax);
 int64_t zstd_compress_scratch_bytes(int32_t nBlocks);
 hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant);
 int64_t snappyframed_decompress_scratch_bytes(int32_t nStreams);
-hipError_t launch_snappyframed_compress(const BatchArgs& a, hipStream_t stream, void* scratch);
-int64_t snappyframed_compress_scratch_bytes();
+hipError_t launch_snappyframed_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant);
+int64_t snappyframed_compress_scratch_bytes(int32_t nStreams);
 hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch);
 hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch);
 int64_t lz4frame_compress_scratch_bytes();
@@ -56,6 +56,7 @@ struct achip_ctx {
     int snappycVariant = 2;  // 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 0;
+    int snappyFramedCompressVariant = 1;  // framed writer: 1 = block list + two-tier block encoder + compaction (default), 0 = one wavefront per stream
     int snappyFramedVariant = 1;  // framed reader: 1 = chunk list + batched block decoders (default), 0 = one wavefront per stream
     int zstdTile = 65536;    // items per pass of the Zstd decode pipeline (halved automatically when its scratch cannot be allocated)
     int ringPad = 80;        // 64 bytes of far-match staging + 16: consecutive blocks start on different LDS banks
@@ -254,9 +255,9 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             break;
         }
         case ACHIP_OP_SNAPPYFRAMED_COMPRESS: {
-            int32_t r = ensure_scratch(ctx, achip::snappyframed_compress_scratch_bytes());
+            int32_t r = ensure_scratch(ctx, achip::snappyframed_compress_scratch_bytes(a.nBlocks));
             if (r < 0) return r;
-            e = achip::launch_snappyframed_compress(a, ctx->stream, ctx->scratch);
+            e = achip::launch_snappyframed_compress(a, ctx->stream, ctx->scratch, ctx->snappyFramedCompressVariant);
             break;
         }
         case ACHIP_OP_LZ4FRAME_COMPRESS: {
@@ -564,6 +565,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     else if (k == "lz4.compress.variant") ctx->lz4cVariant = (int)value;
     else if (k == "snappy.compress.variant") ctx->snappycVariant = (int)value;
     else if (k == "snappyframed.decompress.variant") ctx->snappyFramedVariant = (int)value;
+    else if (k == "snappyframed.compress.variant") ctx->snappyFramedCompressVariant = (int)value;
     else if (k == "decompress.ring_pad") {
         if (value < 0 || value > 256 || (value & 15) != 0) return bad_argument("ring pad must be a multiple of 16 in 0..256");
         ctx->ringPad = (int)value;

@@ -233,7 +233,7 @@ __device__ int32_t compress_item(const Crc32cTables& tables, uint16_t* table, co
 }
 }  // namespace snf
 
-__global__ __launch_bounds__(64) void snappyframed_compress_kernel(BatchArgs a, uint8_t* slabs, int32_t* nextItem)
+__global__ __launch_bounds__(64) void snappyframed_compress_kernel(BatchArgs a, uint8_t* slabs, int32_t* nextItem, const int32_t* only)
 {
     __shared__ uint16_t table[snc::MAX_HASH_TABLE_SIZE];
     __shared__ Crc32cTables tables;
@@ -251,6 +251,9 @@ __global__ __launch_bounds__(64) void snappyframed_compress_kernel(BatchArgs a, 
         if (block >= a.nBlocks) {
             return;
         }
+        if (only != nullptr && only[block] == 0) {
+            continue;  // done by the block-parallel path
+        }
         int32_t op = 0;
         const int32_t st = snf::compress_item(tables, table, a.srcBase + a.srcOff[block], a.srcLen[block], a.dstBase + a.dstOff[block], a.dstCap[block], slab, lane, op);
         if (lane == 0) {
@@ -261,21 +264,220 @@ __global__ __launch_bounds__(64) void snappyframed_compress_kernel(BatchArgs a, 
     }
 }
 
-namespace {
-constexpr int SNF_COMPRESS_WAVES = 256 * 3;  // 44 KB of LDS per wavefront
-}
-int64_t snappyframed_compress_scratch_bytes() { return 4096 + (int64_t)SNF_COMPRESS_WAVES * snf::SLAB_BYTES; }
+// ---------------------------------------------------------------------------------------------------------------------
+// Block-parallel writer (the default).  The blocks of a stream are independent; only a chunk's position depends on the
+// sizes of the chunks before it.  But every block except a stream's last is full, and a chunk is never larger than its block
+// stored raw, so block k can be written at its WORST-CASE position 10 + k * (8 + 65536) without knowing anything else:
+//   plan     one lane per stream checks the arguments and appends its blocks to one list;
+//   encode   persistent wavefronts (two tiers, as in snappy_compress.hip) take blocks from the list: masked CRC-32C, the block
+//            encoder into a private slab, the 0.85 rule, chunk header + body to the worst-case position, the chunk's size noted;
+//   compact  one wavefront per stream writes the stream header and moves the chunks left into place, in order (a move to the
+//            left with all loads of a round before its stores is safe at any distance).
+// Streams whose blocks do not fit into the list go to the one-wavefront-per-stream kernel above.
+namespace snf {
+constexpr int32_t MAX_BLOCKS = 1 << 20;
+constexpr int32_t WORST_CHUNK = 8 + MAX_BLOCK_SIZE;
 
-hipError_t launch_snappyframed_compress(const BatchArgs& a, hipStream_t stream, void* scratch)
+struct BlockList {
+    int32_t* sFirst;   // per stream
+    int32_t* sCount;
+    int32_t* sStatus;
+    int32_t* sSerial;
+    int32_t* bStream;  // per block
+    int32_t* bIndex;
+    int32_t* bSize;    // chunk bytes written at the worst-case position (header included)
+    int32_t* counters; // [0] blocks allocated, [1] blocks in the list, [2] encode cursor, [3] compact cursor, [32] serial cursor
+};
+
+__global__ __launch_bounds__(64) void snappyframed_plan_kernel(BatchArgs a, BlockList L)
+{
+    const int32_t stream = blockIdx.x * 64 + threadIdx.x;
+    if (stream >= a.nBlocks) {
+        return;
+    }
+    const int32_t inLen = a.srcLen[stream];
+    int32_t st = 0;
+    int64_t blocks = 0;
+    if (inLen < 0) {
+        st = mk_status(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_BAD_ARGUMENT);
+    }
+    else {
+        blocks = ((int64_t)inLen + MAX_BLOCK_SIZE - 1) / MAX_BLOCK_SIZE;
+        const int64_t bound = 10 + 8 * blocks + (int64_t)inLen;  // achip_snappyframed_max_compressed_length
+        if (bound > 0x7FFFFFFF) {
+            st = mk_status(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_BAD_ARGUMENT);
+        }
+        else if ((int64_t)a.dstCap[stream] < bound) {
+            st = mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_SNF_MAX_OUTPUT);
+        }
+    }
+    const int32_t n = st == 0 ? (int32_t)blocks : 0;
+    const int32_t first = n > 0 ? atomicAdd(L.counters, n) : 0;
+    const bool fits = (int64_t)first + n <= MAX_BLOCKS;
+    L.sFirst[stream] = first;
+    L.sCount[stream] = fits ? n : 0;
+    L.sStatus[stream] = st;
+    L.sSerial[stream] = fits ? 0 : 1;
+    for (int64_t k = 0; k < n && first + k < MAX_BLOCKS; k++) {
+        L.bStream[first + k] = fits ? stream : -1;  // -1: a hole (its stream goes the other way)
+        L.bIndex[first + k] = (int32_t)k;
+    }
+}
+
+__global__ void snappyframed_seal_blocks_kernel(BlockList L)
+{
+    const int32_t allocated = L.counters[0];
+    L.counters[1] = allocated < MAX_BLOCKS ? allocated : MAX_BLOCKS;
+}
+
+__global__ __launch_bounds__(256) void snappyframed_encode_kernel(BatchArgs a, BlockList L, uint8_t* outSlabs, uint16_t* tableSlabs)
+{
+    __shared__ uint16_t ldsTable[snc::MAX_HASH_TABLE_SIZE];
+    __shared__ Crc32cTables tables;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    crc32c_tables_init(tables, lane);  // (all four wavefronts write the same values between the same barriers)
+    uint8_t* const slab = outSlabs + ((size_t)blockIdx.x * 4 + wave) * SLAB_BYTES;
+    uint16_t* const tableSlab = tableSlabs + ((size_t)blockIdx.x * 3 + (wave > 0 ? wave - 1 : 0)) * snc::MAX_HASH_TABLE_SIZE;
+    const int32_t total = L.counters[1];
+    for (;;) {
+        int32_t b = 0;
+        if (lane == 0) {
+            b = atomicAdd(L.counters + 2, 1);
+        }
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (b >= total) {
+            return;
+        }
+        const int32_t stream = L.bStream[b];
+        if (stream < 0) {
+            continue;
+        }
+        const int32_t k = L.bIndex[b];
+        const int64_t pos = (int64_t)k * MAX_BLOCK_SIZE;
+        const int32_t inLen = a.srcLen[stream];
+        const int32_t length = (int32_t)(inLen - pos < MAX_BLOCK_SIZE ? inLen - pos : MAX_BLOCK_SIZE);
+        const uint8_t* block = a.srcBase + a.srcOff[stream] + pos;
+        uint8_t* out = a.dstBase + a.dstOff[stream] + 10 + (int64_t)k * WORST_CHUNK;
+        const uint32_t crc = crc32c_mask(wave_crc32c(tables, block, length, lane));  // writeCompressed :204
+        int32_t cst = 0, compressed = 0;
+        if (wave == 0) {
+            snappy_compress_buffer(ldsTable, block, length, slab, (int32_t)SLAB_BYTES, lane, cst, compressed);  // :206-211
+        }
+        else {
+            snappy_compress_buffer(tableSlab, block, length, slab, (int32_t)SLAB_BYTES, lane, cst, compressed);
+        }
+        wave_mem_order();
+        const bool keep = ((double)compressed / (double)length) <= 0.85;  // :214
+        const uint8_t* data = keep ? slab : block;
+        const int32_t dlen = keep ? compressed : length;
+        if (lane == 0) {  // writeBlock :241-254
+            const uint32_t headerLength = (uint32_t)dlen + 4u;
+            st4(out, (keep ? (uint32_t)COMPRESSED_DATA_FLAG : (uint32_t)UNCOMPRESSED_DATA_FLAG) | (headerLength << 8));
+            st4(out + 4, crc);
+            L.bSize[b] = 8 + dlen;
+        }
+        group_copy<64>(out + 8, data, dlen, lane);
+        wave_mem_order();
+    }
+}
+
+__global__ __launch_bounds__(64) void snappyframed_compact_kernel(BatchArgs a, BlockList L)
+{
+    const int lane = threadIdx.x;
+    for (;;) {
+        int32_t stream = 0;
+        if (lane == 0) {
+            stream = atomicAdd(L.counters + 3, 1);
+        }
+        stream = __builtin_amdgcn_readfirstlane(stream);
+        if (stream >= a.nBlocks) {
+            return;
+        }
+        if (L.sSerial[stream] != 0) {
+            continue;
+        }
+        const int32_t st = L.sStatus[stream];
+        int32_t o = 0;
+        if (st == 0) {
+            uint8_t* out = a.dstBase + a.dstOff[stream];
+            if (lane == 0) {  // constructor :94
+                st8(out, 0x50614E73000006FFull);
+                out[8] = 0x70;
+                out[9] = 0x59;
+            }
+            o = 10;
+            const int32_t first = L.sFirst[stream], n = L.sCount[stream];
+            for (int32_t k = 0; k < n; k++) {
+                const int32_t size = L.bSize[first + k];
+                const int64_t from = 10 + (int64_t)k * WORST_CHUNK;
+                if (from != o) {
+                    wave_mem_order();
+                    group_copy<64>(out + o, out + from, size, lane);  // to the left; every lane loads before it stores
+                    wave_mem_order();
+                }
+                o += size;
+            }
+        }
+        if (lane == 0) {
+            a.outLen[stream] = st == 0 ? o : 0;
+            a.status[stream] = st;
+            a.errOffset[stream] = 0;
+        }
+    }
+}
+}  // namespace snf
+
+namespace {
+constexpr int SNF_COMPRESS_WAVES = 256 * 3;    // one wavefront per stream: 44 KB of LDS each
+constexpr int SNF_ENCODE_WORKGROUPS = 256 * 3; // four wavefronts around one LDS table + the CRC tables
+}
+int64_t snappyframed_compress_scratch_bytes(int32_t nStreams)
+{
+    const int64_t n = nStreams < 1 ? 1 : nStreams;
+    return 4096 + (int64_t)SNF_COMPRESS_WAVES * snf::SLAB_BYTES + (int64_t)SNF_ENCODE_WORKGROUPS * (4 * snf::SLAB_BYTES + 3 * snc::MAX_HASH_TABLE_SIZE * 2) +
+           n * 16 + (int64_t)snf::MAX_BLOCKS * 12 + 4096;
+}
+
+hipError_t launch_snappyframed_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant)
 {
     if (a.nBlocks <= 0) {
         return hipSuccess;
     }
-    int32_t* counter = (int32_t*)scratch;
-    hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
+    uint8_t* base = (uint8_t*)scratch;
+    int32_t* counters = (int32_t*)base;
+    hipError_t e = hipMemsetAsync(counters, 0, 4096, stream);
     if (e != hipSuccess) return e;
-    const unsigned grid = (unsigned)(a.nBlocks < SNF_COMPRESS_WAVES ? a.nBlocks : SNF_COMPRESS_WAVES);
-    hipLaunchKernelGGL(snappyframed_compress_kernel, dim3(grid), dim3(64), 0, stream, a, (uint8_t*)scratch + 4096, counter);
+    uint8_t* serialSlabs = base + 4096;
+    const unsigned serialGrid = (unsigned)(a.nBlocks < SNF_COMPRESS_WAVES ? a.nBlocks : SNF_COMPRESS_WAVES);
+    if (variant == 0) {  // one wavefront per stream
+        hipLaunchKernelGGL(snappyframed_compress_kernel, dim3(serialGrid), dim3(64), 0, stream, a, serialSlabs, counters + 32, (const int32_t*)nullptr);
+        return hipGetLastError();
+    }
+    uint8_t* p = serialSlabs + (int64_t)SNF_COMPRESS_WAVES * snf::SLAB_BYTES;
+    auto take = [&](int64_t bytes) {
+        uint8_t* r = p;
+        p += (bytes + 63) & ~(int64_t)63;
+        return r;
+    };
+    uint8_t* outSlabs = take((int64_t)SNF_ENCODE_WORKGROUPS * 4 * snf::SLAB_BYTES);
+    uint16_t* tableSlabs = (uint16_t*)take((int64_t)SNF_ENCODE_WORKGROUPS * 3 * snc::MAX_HASH_TABLE_SIZE * 2);
+    snf::BlockList L;
+    const int64_t n = a.nBlocks;
+    L.counters = counters;
+    L.sFirst = (int32_t*)take(4 * n);
+    L.sCount = (int32_t*)take(4 * n);
+    L.sStatus = (int32_t*)take(4 * n);
+    L.sSerial = (int32_t*)take(4 * n);
+    L.bStream = (int32_t*)take(4 * (int64_t)snf::MAX_BLOCKS);
+    L.bIndex = (int32_t*)take(4 * (int64_t)snf::MAX_BLOCKS);
+    L.bSize = (int32_t*)take(4 * (int64_t)snf::MAX_BLOCKS);
+    const unsigned perStream = (unsigned)((a.nBlocks + 63) / 64);
+    hipLaunchKernelGGL(snf::snappyframed_plan_kernel, dim3(perStream), dim3(64), 0, stream, a, L);
+    hipLaunchKernelGGL(snf::snappyframed_seal_blocks_kernel, dim3(1), dim3(1), 0, stream, L);
+    hipLaunchKernelGGL(snf::snappyframed_encode_kernel, dim3(SNF_ENCODE_WORKGROUPS), dim3(256), 0, stream, a, L, outSlabs, tableSlabs);
+    hipLaunchKernelGGL(snf::snappyframed_compact_kernel, dim3((unsigned)(a.nBlocks < 2048 ? a.nBlocks : 2048)), dim3(64), 0, stream, a, L);
+    hipLaunchKernelGGL(snappyframed_compress_kernel, dim3(serialGrid), dim3(64), 0, stream, a, serialSlabs, counters + 32, (const int32_t*)L.sSerial);
     return hipGetLastError();
 }
 

@@ -14,11 +14,12 @@ OP_DECOMPRESS, OP_COMPRESS = 8, 9
 HEADER = bytes([0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59])
 
 
-@pytest.fixture(scope="module", params=[1, 0], ids=["chunk-list", "wave-per-stream"])
+@pytest.fixture(scope="module", params=[1, 0], ids=["block-lists", "wave-per-stream"])
 def gb(request):
-    """reader under test: chunk list + batched block decoders (default) and one wavefront per stream (its fallback)"""
+    """reader / writer under test: chunk list + batched block decoders, block list + two-tier block encoder + compaction (defaults);
+    one wavefront per stream (their fallback)"""
     from tests.gpu_harness import GpuBatch
-    return GpuBatch(0, options={"snappyframed.decompress.variant": request.param})
+    return GpuBatch(0, options={"snappyframed.decompress.variant": request.param, "snappyframed.compress.variant": request.param})
 
 
 @pytest.fixture(scope="module")
