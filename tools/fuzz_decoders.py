@@ -7,12 +7,16 @@ from tests import common, oracle_lib
 from tests.gpu_harness import GpuBatch
 from tests.oracle_lib import OracleError
 
-def run(n_cases, seed, codecs=("lz4", "snappy")):
+def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
     rng = np.random.default_rng(seed)
     o = oracle_lib.load()
     gb = GpuBatch(0)
     blocks = [d for _, d, _ in common.corpus_sample()] + common.synthetic_blocks(9, 24) + [d for _, d in common.HAND_CASES if len(d) > 0]
     blocks += [b[:n] for b in blocks[:6] for n in (17, 300, 5000)]
+    if big:  # long runs, long periods, blocks beyond 64 KiB: the wide / doubling / memcpy paths of the decoders
+        text = b"".join(d for _, d, _ in common.corpus_sample()[:5])
+        blocks += [bytes(1 << 20), bytes(range(256)) * 2048, (b"abc" * 100000)[:250001], text, text[:100000] + bytes(50000) + text[:70000],
+                   bytes(rng.integers(0, 256, 300000, dtype=np.uint8)), (bytes(rng.integers(0, 256, 1000, dtype=np.uint8)) * 400)]
     OPS = {"lz4": 0, "snappy": 2, "zstd": 4, "lz4frame": 6, "snappyframed": 8}
     VARIANTS = {"lz4": [1, 4, 3, 2], "snappy": [1, 4], "zstd": [1, 0], "lz4frame": [None], "snappyframed": [None]}
 
@@ -76,4 +80,4 @@ def run(n_cases, seed, codecs=("lz4", "snappy")):
 
 if __name__ == "__main__":
     sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 6000, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
-                      tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("lz4", "snappy")) else 0)
+                      tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("lz4", "snappy"), big=len(sys.argv) > 4) else 0)
