@@ -125,3 +125,7 @@ def test_codecs_fail_loudly_without_gpu(lib):
         A.Lz4HipCompressor()
     with pytest.raises(A.HipUnavailableError):
         A.HipBatchCodec()
+    for cls in (A.Lz4HipDecompressor, A.SnappyHipCompressor, A.SnappyHipDecompressor, A.ZstdHipCompressor, A.ZstdHipDecompressor, A.Lz4FrameHipCompressor,
+                A.Lz4FrameHipDecompressor, A.SnappyFramedHipCompressor, A.SnappyFramedHipDecompressor):
+        with pytest.raises(A.HipUnavailableError):
+            cls()

@@ -129,6 +129,32 @@ def test_wave_crc32c_at_every_length_class(gb, o):
     check_decode(gb, o, good + bad, unaligned=True)
 
 
+def test_host_api_twins(o):
+    """SnappyFramedHipCompressor / SnappyFramedHipDecompressor: the Compressor / Decompressor call shapes over host buffers"""
+    import aircompressor_amd as A
+    comp, decomp = A.SnappyFramedHipCompressor(), A.SnappyFramedHipDecompressor()
+    data = common.corpus_sample()[1][1] + common.corpus_sample()[2][1][:1234]
+    cap = comp.max_compressed_length(len(data))
+    assert cap == o.max_compressed_length("snappyframed", len(data)) == 10 + 2 * 8 + len(data)
+    out = bytearray(cap + 5)
+    n = comp.compress(data, 0, len(data), out, 5, cap)
+    assert bytes(out[5:5 + n]) == o.compress("snappyframed", data)
+    back = bytearray(len(data))
+    assert decomp.decompress(out, 5, n, back, 0, len(data)) == len(data) and bytes(back) == data
+    with pytest.raises(A.MalformedInputException) as e:
+        decomp.decompress(bytes(out[5:5 + n - 3]), 0, n - 3, back, 0, len(data))
+    assert str(e.value).startswith("unexpectd EOF when reading frame")
+    corrupt = bytearray(out[5:5 + n])
+    corrupt[14] ^= 1  # the first chunk's stored CRC
+    with pytest.raises(A.MalformedInputException) as e:
+        decomp.decompress(bytes(corrupt), 0, n, back, 0, len(data))
+    assert str(e.value).startswith("Corrupt input: invalid checksum")
+    with pytest.raises(A.IllegalArgumentException):
+        comp.compress(data, 0, len(data), bytearray(cap - 1), 0, cap - 1)
+    with pytest.raises(A.IllegalArgumentException):
+        comp.max_compressed_length(-1)
+
+
 def test_full_size_property(gb, o):
     """1024 streams of 1 MiB: encode -> decode restores the plaintext; every stream equals the oracle's for a sample"""
     import torch
