@@ -1597,7 +1597,7 @@ __device__ __forceinline__ void compute_parameters(Ctx& c)
 // more wavefronts per CU; its results (sequence store, literals, the two candidate repeat offsets) wait in the item's
 // scratch for the entropy kernel.  Larger inputs stay in the one kernel: whether block k's repeat offsets are committed
 // depends on block k's entropy outcome (ZstdFrameCompressor.java:246-258), so their match finding cannot run ahead.
-constexpr int32_t PRE_WORDS = 16;  // record: valid, sequenceCount, literalsLength, longLengthField, longLengthPosition, tempOffset0, tempOffset1
+// the match kernel's record (first 256 bytes of an item's scratch): valid, sequenceCount, literalsLength, longLengthField, longLengthPosition, tempOffset0, tempOffset1
 __device__ __forceinline__ bool split_eligible(int32_t inLen) { return inLen >= 7 && inLen <= MAX_BLOCK_SIZE; }
 
 __device__ int32_t zstd_compress_item(Ctx& c, Shared& sh)
