@@ -21,7 +21,9 @@ hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, i
 hipError_t launch_lz4_decompress_lanes(const BatchArgs& a, hipStream_t stream, int ringClass);
 hipError_t launch_lz4_decompress_steps(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass);
 hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
+hipError_t launch_lz4_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
+hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 hipError_t launch_snappy_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
@@ -63,6 +65,8 @@ struct achip_ctx {
     int scratchPoison = -1;
     int32_t lastZstddBlocks = 0;  // achip_ctx_get_stat
     int lastZstddVariant = 0;
+    int32_t lastAutoBlocks = 0;  // ... and this many blocks
+    bool lastAutoIsLz4 = false;
     bool lastLz4dAuto = false;  // the last LZ4 decode ran in auto mode: its probe count leads the scratch
     int maxSrcLenHint = 0;
     // scratch for the zstd pipeline (grown on demand)
@@ -191,16 +195,21 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 if (r < 0) return r;
                 int32_t* mixedGroups = (int32_t*)ctx->scratch;
                 ctx->lastLz4dAuto = true;
+                ctx->lastAutoBlocks = a.nBlocks;
+                ctx->lastAutoIsLz4 = true;
                 ctx->lastZstddBlocks = 0;
                 e = achip::launch_lz4_mixed_groups(a, ctx->stream, mixedGroups, 0);
+                if (e == hipSuccess) e = achip::launch_lz4_sequence_sample(a, ctx->stream, mixedGroups, 0);
                 if (e == hipSuccess) e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, mixedGroups);
                 if (e == hipSuccess) e = achip::launch_lz4_decompress_lanecopy(a, ctx->stream, mixedGroups);
+                if (e == hipSuccess) e = achip::launch_lz4_decompress_lanewindow(a, ctx->stream, mixedGroups);
                 break;
             }
             e = ctx->lz4dVariant == 0   ? achip::launch_lz4_decompress(a, ctx->stream, ctx->lz4dGroup)
                 : ctx->lz4dVariant == 2 ? achip::launch_lz4_decompress_lanes(a, ctx->stream, ctx->ringClass)
                 : ctx->lz4dVariant == 3 ? achip::launch_lz4_decompress_steps(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass)
                 : ctx->lz4dVariant == 4 ? achip::launch_lz4_decompress_lanecopy(a, ctx->stream, nullptr)
+                : ctx->lz4dVariant == 6 ? achip::launch_lz4_decompress_lanewindow(a, ctx->stream, nullptr)
                                         : achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, nullptr);
             break;
         case ACHIP_OP_LZ4_COMPRESS: e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint); break;
@@ -210,6 +219,8 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 if (r < 0) return r;
                 int32_t* mixedGroups = (int32_t*)ctx->scratch;
                 ctx->lastLz4dAuto = true;
+                ctx->lastAutoBlocks = a.nBlocks;
+                ctx->lastAutoIsLz4 = false;
                 ctx->lastZstddBlocks = 0;
                 e = achip::launch_lz4_mixed_groups(a, ctx->stream, mixedGroups, 0);
                 if (e == hipSuccess) e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, mixedGroups);
@@ -592,6 +603,14 @@ int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name)
         int32_t v = 0;
         if (hipMemcpy(&v, ctx->scratch, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
         return v;
+    }
+    if (k == "decompress.choice") {  // which decoder auto mode ran last: 0 rings, 1 lane per block (copy steps), 2 lane per block (LDS window); -1: no probe ran
+        if (!ctx->lastLz4dAuto || ctx->scratch == nullptr) return -1;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+        int32_t v[3] = {0, 0, 0};
+        if (hipMemcpy(v, ctx->scratch, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if ((int64_t)v[0] * 4 > (ctx->lastAutoBlocks + 15) / 16) return 1;
+        return (ctx->lastAutoIsLz4 && v[1] > 0 && (int64_t)v[2] < 12 * (int64_t)v[1]) ? 2 : 0;
     }
     const std::string prefix = "zstd.decompress.fallback_";
     if (k.compare(0, prefix.size(), prefix) == 0) {

@@ -39,6 +39,19 @@ __device__ __forceinline__ constexpr int32_t mk_status(int cls, int detail) { re
 // blocks (= the blocks one wavefront of the ring decoder works on) the compressed sizes differ by more than 2x
 __device__ __forceinline__ bool lz4_batch_is_mixed(int32_t mixedGroups, int32_t nBlocks) { return (int64_t)mixedGroups * 4 > (nBlocks + 15) / 16; }
 
+// The LZ4 choice has a third candidate.  stats: [0] mixed groups, [1] sequences parsed from the heads of 1024 sampled blocks, [2] the
+// bytes they produce, in units of 4.  Mixed batch: the lane-per-block decoder with wavefront-wide copy steps (long copies next to short ones);
+// otherwise short sequences (text: 10-40 bytes per sequence at a block's head; the long-copy sets: >= 100): the lane-per-block decoder
+// with the LDS output window; otherwise the rings.
+constexpr int LZ4_PICK_RINGS = 0, LZ4_PICK_LANECOPY = 1, LZ4_PICK_LANEWINDOW = 2;
+__device__ __forceinline__ int lz4_pick(const int32_t* stats, int32_t nBlocks)
+{
+    if (lz4_batch_is_mixed(stats[0], nBlocks)) {
+        return LZ4_PICK_LANECOPY;
+    }
+    return (stats[1] > 0 && (int64_t)stats[2] < 12 * (int64_t)stats[1]) ? LZ4_PICK_LANEWINDOW : LZ4_PICK_RINGS;
+}
+
 // ---- unaligned little-endian accessors (global memory; gfx950 runs in unaligned-access mode) ----
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));

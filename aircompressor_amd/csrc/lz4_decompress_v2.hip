@@ -13,7 +13,7 @@ template <int GS, int IN_RING, int OUT_RING, int GPL>
 __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
     // auto mode (achip_abi.cpp): both LZ4 decoders are launched, the probe's count of mixed 16-block groups picks one
-    if (mixedGroups != nullptr && lz4_batch_is_mixed(*mixedGroups, a.nBlocks)) {
+    if (mixedGroups != nullptr && lz4_pick(mixedGroups, a.nBlocks) != LZ4_PICK_RINGS) {
         return;
     }
     ACHIP_DYNAMIC_LDS(smem);

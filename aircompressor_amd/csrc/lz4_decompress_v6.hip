@@ -1,35 +1,135 @@
-// lz4_decompress_v5.hip -- batched LZ4 block decode for gfx950: a lane per block, copies straight between global buffers.
+// lz4_decompress_v6.hip -- batched LZ4 block decode for gfx950: a lane per block (as lz4_decompress_v5.hip) with the block's recent
+// output in an LDS window.
 //
-// Same contract and the same Java-order checks as lz4_decompress_v2.hip (M/lz4/Lz4RawDecompressor.java:35-198).
-//
-// The ring decoders (v2) spend their time issuing instructions: a wavefront walks 16 blocks, one sequence of each at a
-// time, and executes the union of the paths those 16 state machines take (profiles/r01_notes.md: 2.3x the instructions
-// of a converged wavefront; ~128 SIMD cycles per sequence on text).  Here every LANE owns a block (64 blocks per
-// wavefront) and a trip of the loop is the same straight line for all of them:
-//   parse    token, length extensions, offset -- from the lane's LDS window on its compressed stream (16-byte granules,
-//            requested ahead; literal bytes are jumped over) -- with the Java checks in their order;
-//   copy     ONE wavefront-wide copy step moves the literal run and the match of all 64 sequences: all loads of the step
-//            are issued before its stores, so a trip costs about one memory round trip.  Up to 32 bytes of a copy are
-//            moved by its own lane (two overlapping 16-byte pieces, or 8/4/2/1); what is longer is cut into 16-byte
-//            chunks that are dealt out evenly to the 64 lanes (consecutive lanes take consecutive chunks), so neither a
-//            64 KiB literal run nor a skewed mix of lengths leaves lanes idle.  Copies are exact.
-//   A match that overlaps itself (offset < length) or reads this trip's literals takes extra steps: one period first,
-//   then -- the written part repeating the period -- twice as much per step.
-// There are no output rings: sources are read from, and bytes written to, the output buffer itself (the L2 holds the
-// recent window; a wavefront's vector memory operations are performed in program order).
+// Same contract and the same Java-order checks as lz4_decompress_v2.hip (M/lz4/Lz4RawDecompressor.java:35-198); the parse is v5's.
+// v5 writes every copy straight to the output buffer and reads every back-reference from it, and is bound by the memory traffic that
+// causes with 262144 blocks open at once (profiles/r01_notes.md: 16-byte partial-line stores written to HBM 3.6-5.7 times over, a
+// 128-byte line fetched per back-reference).  Here a lane keeps the last 256 bytes of its block in an LDS ring column:
+//   * bytes are appended to the ring (funnel-shifted whole dwords) and leave for the output buffer in aligned 64-byte pieces -- four
+//     16-byte stores to one line, each byte written once;
+//   * a back-reference of up to 224 bytes is read from the ring; a farther one from the flushed part of the output buffer.
+// Every copy goes 32 bytes per trip through the ring (no wavefront-wide copy steps): the kernel has no cross-lane operation at all,
+// which also lets the test suite run it on a CPU one lane at a time (tools/hostemu).
 #include "achip_lanecopy.h"
 
 namespace achip {
+namespace sp {
 
-template <int IN_DW, bool NT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void lz4_decompress_lanecopy_kernel(BatchArgs a, const int32_t* mixedGroups)
+// 16 bytes at p when they lie inside the buffer ending at `end`, else what does (the rest zero; cold)
+__device__ __forceinline__ u32x4 safe_ld16(const uint8_t* p, const uint8_t* end)
+{
+    if (p + 16 <= end) {
+        return ld16(p);
+    }
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16 && p + i < end; i++) {
+        w[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
+    }
+    return u32x4{w[0], w[1], w[2], w[3]};
+}
+
+// the lane's output: an LDS ring column of OUT_DW dwords (dword d at ring[(d & (OUT_DW-1)) * 64]) in front of the output buffer.
+// Positions are virtual (position + (address & 63)) so that the 64-byte pieces are aligned in memory.
+template <int OUT_DW>
+struct LaneOutput {
+    static constexpr int OUT_BYTES = OUT_DW * 4;
+    static constexpr int REACH = OUT_BYTES - 32;  // farthest back-reference read from the ring (a read takes five dwords)
+    static_assert((OUT_DW & (OUT_DW - 1)) == 0 && OUT_DW >= 64, "ring size");
+    uint32_t* ring;
+    uint8_t* outAligned;
+    int32_t outBase;
+    int32_t opV;       // virtual output position
+    int32_t flushedV;  // output flushed up to here (multiple of 64)
+    uint32_t carry;    // content of the dword holding opV (valid below opV)
+
+    __device__ __forceinline__ void init(uint32_t* lds, uint8_t* out)
+    {
+        ring = lds;
+        outBase = (int32_t)((uintptr_t)out & 63);
+        outAligned = out - outBase;
+        opV = outBase;
+        flushedV = 0;
+        carry = 0;
+    }
+    __device__ __forceinline__ u32x4 read16(int32_t sV) const
+    {
+        const int32_t d = sV >> 2;
+        const uint32_t r0 = ring[((d + 0) & (OUT_DW - 1)) * 64], r1 = ring[((d + 1) & (OUT_DW - 1)) * 64], r2 = ring[((d + 2) & (OUT_DW - 1)) * 64],
+                       r3 = ring[((d + 3) & (OUT_DW - 1)) * 64], r4 = ring[((d + 4) & (OUT_DW - 1)) * 64];
+        const uint32_t s = (uint32_t)(sV & 3);
+        return u32x4{alignbyte_u32(r1, r0, s), alignbyte_u32(r2, r1, s), alignbyte_u32(r3, r2, s), alignbyte_u32(r4, r3, s)};
+    }
+    // append c (1..16) bytes, the low bytes of w
+    __device__ __forceinline__ void append(u32x4 w, int32_t c)
+    {
+        const uint32_t sh = (uint32_t)(opV & 3);  // bytes of the current dword already produced
+        const uint32_t keep = sh == 0 ? 0u : ((1u << (8 * sh)) - 1u);
+        const uint32_t rs = (4u - sh) & 3u;
+        const uint32_t d0 = (carry & keep) | (w.x << (8 * sh));
+        const uint32_t d1 = sh ? alignbyte_u32(w.y, w.x, rs) : w.y;
+        const uint32_t d2 = sh ? alignbyte_u32(w.z, w.y, rs) : w.z;
+        const uint32_t d3 = sh ? alignbyte_u32(w.w, w.z, rs) : w.w;
+        const uint32_t d4 = sh ? (w.w >> (8 * rs)) : 0u;
+        const int32_t d = opV >> 2;
+        const int32_t total = (int32_t)sh + c;  // bytes of the stream that are real
+        ring[((d + 0) & (OUT_DW - 1)) * 64] = d0;
+        if (total > 4) ring[((d + 1) & (OUT_DW - 1)) * 64] = d1;
+        if (total > 8) ring[((d + 2) & (OUT_DW - 1)) * 64] = d2;
+        if (total > 12) ring[((d + 3) & (OUT_DW - 1)) * 64] = d3;
+        if (total > 16) ring[((d + 4) & (OUT_DW - 1)) * 64] = d4;
+        const int32_t last = total >> 2;  // dword that holds the new position
+        carry = last == 0 ? d0 : (last == 1 ? d1 : (last == 2 ? d2 : (last == 3 ? d3 : d4)));
+        opV += c;
+        wave_mem_order();
+    }
+    __device__ __forceinline__ void flush_piece()
+    {
+        const int32_t d = flushedV >> 2;
+        if (flushedV >= outBase) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u32x4 g = {ring[((d + 4 * k + 0) & (OUT_DW - 1)) * 64], ring[((d + 4 * k + 1) & (OUT_DW - 1)) * 64], ring[((d + 4 * k + 2) & (OUT_DW - 1)) * 64],
+                                 ring[((d + 4 * k + 3) & (OUT_DW - 1)) * 64]};
+                *(u32x4*)(outAligned + flushedV + 16 * k) = g;
+            }
+        }
+        else {  // the piece straddling the start of the output buffer (cold)
+            for (int32_t p = outBase; p < flushedV + 64; p++) {
+                outAligned[p] = (uint8_t)(ring[((p >> 2) & (OUT_DW - 1)) * 64] >> (8 * (p & 3)));
+            }
+        }
+        flushedV += 64;
+        wave_mem_order();
+    }
+    __device__ __forceinline__ void flush_complete()
+    {
+        while (opV - flushedV >= 64) {
+            flush_piece();
+        }
+    }
+    // end of block: what is left of the last piece
+    __device__ __forceinline__ void flush_tail()
+    {
+        flush_complete();
+        const int32_t lo = flushedV > outBase ? flushedV : outBase;
+        for (int32_t p = lo; p < opV; p++) {
+            outAligned[p] = (uint8_t)(ring[((p >> 2) & (OUT_DW - 1)) * 64] >> (8 * (p & 3)));
+        }
+        wave_mem_order();
+    }
+};
+
+}  // namespace sp
+
+template <int IN_DW, int OUT_DW>
+__global__ __launch_bounds__(64) void lz4_decompress_lanewindow_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
     using namespace sp;
-    if (mixedGroups != nullptr && lz4_pick(mixedGroups, a.nBlocks) != LZ4_PICK_LANECOPY) {  // auto mode: another decoder takes this batch
+    if (mixedGroups != nullptr && lz4_pick(mixedGroups, a.nBlocks) != LZ4_PICK_LANEWINDOW) {  // auto mode: another decoder takes this batch
         return;
     }
     __shared__ uint32_t ldsIn[IN_DW * 64];
-    __shared__ CopyScratch S;
+    __shared__ uint32_t ldsOut[OUT_DW * 64];
     const int lane = threadIdx.x;
     const int64_t block = (int64_t)blockIdx.x * 64 + lane;
     const bool have = block < a.nBlocks;
@@ -40,6 +140,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
     LaneInput<IN_DW> R;
     R.init(ldsIn + lane, in, inLimit);
+    LaneOutput<OUT_DW> W2;
+    W2.init(ldsOut + lane, out);
 
     int32_t st = 0;
     int32_t eo = 0;
@@ -77,7 +179,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const uint8_t* const outEnd = out + outLimit;
     int32_t tokenMl = 0;     // low nibble of the token whose match header is still to be parsed
     bool headerDue = false;  // the literal run was too long for the window: its match header is parsed when the run is copied
-    while (__ballot(!done || rem > 0 || litRem > 0) != 0) {
+    while (!done || rem > 0 || litRem > 0) {  // (lane-private: no cross-lane operation anywhere in this kernel)
         // ---- parse (lanes whose copies are complete): ONE 16-byte window at ip holds the token, a literal run of up to 12
         // bytes, the offset and the first match-length extension byte -- a whole sequence of the common kind.  A longer run
         // is copied from the input buffer over the next trips and its match header is parsed after it. ----
@@ -208,120 +310,74 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
             }
         }
-        // ---- copy.  Per trip a lane moves at most HEAD bytes of its literal run and HEAD bytes of its match itself and keeps
-        // the rest for its next trips (it then parses nothing new) -- unless more than LONG bytes are left: those go out at once,
-        // dealt to all lanes.  Of the match at most one period, and nothing while its source reaches into bytes of this trip.
-        const int32_t n0 = (litRem > LONG || litRem < HEAD) ? litRem : HEAD;
-        int32_t n1 = rem < dist ? rem : dist;
-        n1 = (n1 > LONG || n1 < HEAD) ? n1 : HEAD;
-        n1 = (litRem > n0 || dist < n0 + n1) ? 0 : n1;
-        copy_step<true, NT>(S, lane, h0, have0, out + litOut, in + litPos, n0, inEnd, out + cur, out + cur - dist, n1, outEnd);
-        litOut += n0;
-        litPos += n0;
-        litRem -= n0;
-        cur += n1;
-        rem -= n1;
-        if (rem > dist && 2 * (int64_t)dist <= (int64_t)(cur - periodic)) {
-            dist += dist;  // enough periods are written: out[x] = out[x - 2 * dist] holds as well
+        // ---- copy through the lane's LDS window: <= 32 bytes of the literal run, then <= 32 bytes of the match (one period at most);
+        // what is left continues in the next trips.  The run is appended before the match reads, so a match may start in it. ----
+        {
+            const int32_t n0 = litRem < 32 ? litRem : 32;
+            if (n0 > 0) {
+                u32x4 A, B = {0, 0, 0, 0};
+                if (have0) {
+                    A = h0.A;
+                }
+                else {
+                    A = safe_ld16(in + litPos, inEnd);
+                    if (n0 > 16) {
+                        B = safe_ld16(in + litPos + 16, inEnd);
+                    }
+                }
+                W2.append(A, n0 < 16 ? n0 : 16);
+                if (n0 > 16) {
+                    W2.append(B, n0 - 16);
+                }
+                litPos += n0;
+                litRem -= n0;
+            }
+            int32_t n1 = rem < dist ? rem : dist;
+            n1 = n1 < 32 ? n1 : 32;
+            n1 = litRem > 0 ? 0 : n1;
+            if (n1 > 0) {
+                const int32_t sV = W2.opV - dist;
+                u32x4 A, B = {0, 0, 0, 0};
+                if (dist <= LaneOutput<OUT_DW>::REACH) {
+                    A = W2.read16(sV);
+                    if (n1 > 16) {
+                        B = W2.read16(sV + 16);
+                    }
+                }
+                else {  // flushed long ago
+                    A = ld16(W2.outAligned + sV);
+                    if (n1 > 16) {
+                        B = ld16(W2.outAligned + sV + 16);
+                    }
+                }
+                W2.append(A, n1 < 16 ? n1 : 16);
+                if (n1 > 16) {
+                    W2.append(B, n1 - 16);
+                }
+                cur += n1;
+                rem -= n1;
+                if (rem > dist && 2 * (int64_t)dist <= (int64_t)(cur - periodic)) {
+                    dist += dist;  // enough periods are written: out[x] = out[x - 2 * dist] holds as well
+                }
+            }
+            W2.flush_complete();
         }
     }
 #undef LZ4_FAIL
     if (have) {
+        if (st == 0) {
+            W2.flush_tail();
+        }
         a.outLen[block] = st == 0 ? op : 0;
         a.status[block] = st;
         a.errOffset[block] = (int64_t)eo;
     }
 }
 
-// counts the groups of 16 consecutive blocks whose compressed sizes differ by more than 2x
-__global__ __launch_bounds__(256) void lz4_mixed_groups_kernel(BatchArgs a, int32_t* mixedGroups, int32_t minBlocks)
-{
-    const int32_t n = batch_count(a);
-    if (n < minBlocks) {
-        return;  // too few blocks for the lane-per-block decoder: the count stays 0
-    }
-    const int64_t group = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t first = group * 16;
-    bool mixed = false;
-    if (first < n) {
-        int32_t lo = 0x7FFFFFFF, hi = 0;
-        for (int64_t b = first; b < first + 16 && b < n; b++) {
-            const int32_t len = a.srcLen[b];
-            lo = len < lo ? len : lo;
-            hi = len > hi ? len : hi;
-        }
-        mixed = (int64_t)hi > 2 * (int64_t)lo;
-    }
-    const int found = __popcll(__ballot(mixed));
-    if ((threadIdx.x & 63) == 0 && found > 0) {
-        atomicAdd(mixedGroups, found);
-    }
-}
-
-// auto mode, LZ4 only: how long are the sequences?  1024 sampled blocks, the first <= 96 sequences of each (a lane per sample; headers only)
-__global__ __launch_bounds__(64) void lz4_sequence_sample_kernel(BatchArgs a, int32_t* stats, int32_t minBlocks)
-{
-    const int32_t n = batch_count(a);
-    if (n < minBlocks) {
-        return;
-    }
-    const int32_t t = blockIdx.x * 64 + threadIdx.x;
-    const int64_t block = (int64_t)t * n / 1024;
-    const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
-    const int32_t inLimit = a.srcLen[block];
-    int32_t ip = 0, seqs = 0;
-    int64_t bytes = 0;
-    while (ip < inLimit && seqs < 96) {
-        const int32_t token = in[ip++];
-        int32_t lit = token >> 4;
-        if (lit == 15) {
-            int32_t v = 255;
-            while (v == 255 && ip < inLimit) {
-                v = in[ip++];
-                lit += v;
-            }
-        }
-        bytes += lit;
-        ip += lit;
-        seqs++;
-        if (ip + 2 > inLimit || lit < 0) {
-            break;  // last literals (or nonsense: the decoders will say)
-        }
-        ip += 2;
-        int32_t ml = token & 15;
-        if (ml == 15) {
-            int32_t v = 255;
-            while (v == 255 && ip < inLimit) {
-                v = in[ip++];
-                ml += v;
-            }
-        }
-        bytes += ml + 4;
-    }
-    bytes = bytes < 0 || bytes > (1 << 24) ? (1 << 24) : bytes;
-    atomicAdd(stats + 1, seqs);
-    atomicAdd(stats + 2, (int32_t)(bytes >> 2));  // (in units of 4 bytes: 1024 samples x 16 MiB stay inside 32 bits)
-}
-
-hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks)
-{
-    hipLaunchKernelGGL(lz4_sequence_sample_kernel, dim3(16), dim3(64), 0, stream, a, stats, minBlocks);
-    return hipGetLastError();
-}
-
-hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks)
-{
-    const hipError_t e = hipMemsetAsync(mixedGroups, 0, 4 * sizeof(int32_t), stream);
-    if (e != hipSuccess) return e;
-    const unsigned grid = (unsigned)(((a.nBlocks + 15) / 16 + 255) / 256);
-    hipLaunchKernelGGL(lz4_mixed_groups_kernel, dim3(grid), dim3(256), 0, stream, a, mixedGroups, minBlocks);
-    return hipGetLastError();
-}
-
-hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups)
+hipError_t launch_lz4_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups)
 {
     const unsigned grid = (unsigned)((a.nBlocks + 63) / 64);
-    hipLaunchKernelGGL((lz4_decompress_lanecopy_kernel<16, false>), dim3(grid), dim3(64), 0, stream, a, mixedGroups);
+    hipLaunchKernelGGL((lz4_decompress_lanewindow_kernel<16, 64>), dim3(grid), dim3(64), 0, stream, a, mixedGroups);
     return hipGetLastError();
 }
 

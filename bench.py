@@ -263,7 +263,8 @@ def main():
         assert bool((out_len == pool_clen.repeat(reps)).all())
 
     mixed_groups = codec.native.get_stat("lz4.decompress.mixed_groups") if wl.endswith("decompress") else -1
-    decoder = "n/a" if not wl.endswith("decompress") else ("rings" if mixed_groups < 0 or mixed_groups * 4 <= (n_local + 15) // 16 else "lane-per-block")
+    choice = codec.native.get_stat("decompress.choice") if wl.endswith("decompress") else -1
+    decoder = "n/a" if not wl.endswith("decompress") else DECODER_NAMES.get(choice, "rings")
     ms_per_step = elapsed / args.steps * 1e3
     total_plain = plain_bytes_local * world  # weak scaling: every rank owns n_local blocks
     value = total_plain * args.steps / elapsed / 2**30
@@ -323,9 +324,14 @@ def main():
         dist.destroy_process_group()
 
 
+DECODER_NAMES = {0: "rings", 1: "lane-per-block", 2: "lane-per-block with LDS window"}
+
+
 def kernel_symbol(wl, decoder):
     """the dominant kernel of the timed launch as rocprofv3 names it (profiles/*_kernel_stats.csv)"""
     if wl == "lz4_decompress":
+        if decoder.endswith("LDS window"):
+            return "achip::lz4_decompress_lanewindow_kernel<16, 64>"
         return "achip::lz4_decompress_lanecopy_kernel<16, false>" if decoder.startswith("lane") else "achip::lz4_decompress_rings_kernel<4, 128, 256, 1>"
     if wl == "snappy_decompress":
         return "achip::snappy_decompress_lanecopy_kernel<16>" if decoder.startswith("lane") else "achip::snappy_decompress_rings_kernel<4, 128, 256, 1>"
@@ -371,7 +377,7 @@ def extras(torch, A, codec, dev, args):
             assert int((st != 0).sum()) == 0
             cbytes = int(clen.to(torch.int64).sum())
             td = timed(lambda: codec.launch(dop, comp, c_off, clen, back, p_off, p_len, blen, st, eo, n))
-            mixed_groups = codec.native.get_stat("lz4.decompress.mixed_groups")  # -1: no probe ran (fixed variant / small batch)
+            choice = codec.native.get_stat("decompress.choice")  # -1: no probe ran (fixed variant / small batch)
             assert int((st != 0).sum()) == 0 and bool((back[:n * bs] == plain).all())
             key = "%s_%s" % (name, data_kind)
             out[key] = {
@@ -379,7 +385,7 @@ def extras(torch, A, codec, dev, args):
                 "compress_GiBps": round(n * bs / tc / 2**30, 2), "compress_hbm_frac": round((n * bs + cbytes) / tc / 1e9 / HBM_PEAK_GBS, 4),
                 "decompress_GiBps": round(n * bs / td / 2**30, 2), "decompress_hbm_frac": round((n * bs + cbytes) / td / 1e9 / HBM_PEAK_GBS, 4),
                 "blocks": n,
-                "decoder": "rings" if mixed_groups < 0 or mixed_groups * 4 <= (n + 15) // 16 else "lane-per-block",
+                "decoder": DECODER_NAMES.get(choice, "rings"),
             }
             del comp, back
     return out

@@ -78,7 +78,7 @@ def test_decompress_matches_plaintext_all_decoder_configs(gb, o, codec, cfg):
     configure(gb, codec, DECODERS[0])
 
 
-@pytest.mark.parametrize("cfg", [(2, 4, 0), (2, 4, 1), (3, 4, 0), (3, 4, 1), (3, 1, 0), (3, 2, 0), (3, 2, 1), (3, 8, 0), (3, 8, 1), (4, 4, 0)],
+@pytest.mark.parametrize("cfg", [(2, 4, 0), (2, 4, 1), (3, 4, 0), (3, 4, 1), (3, 1, 0), (3, 2, 0), (3, 2, 1), (3, 8, 0), (3, 8, 1), (4, 4, 0), (6, 4, 0)],
                          ids=lambda c: "variant%d-gs%d-rc%d" % c)
 def test_lz4_experimental_decoders(gb, o, cfg):
     """variant 2 (lz4_decompress_v3.hip, one lane per block) and variant 3 (lz4_decompress_v4.hip, uniform-step state machine
@@ -152,10 +152,13 @@ def test_auto_mode_picks_a_decoder_on_the_device(gb, o, codec):
             outs, status, _ = gb.run(CODECS[codec]["d"], comp, [len(b) for b in blocks], unaligned=True)
             assert all(s == 0 for s in status) and outs == blocks
             groups = gb.codec.native.get_stat("lz4.decompress.mixed_groups")
+            choice = gb.codec.native.get_stat("decompress.choice")
             if expect_mixed is None:
-                assert groups == -1           # below auto_min_blocks: no probe, the rings
+                assert groups == -1 and choice == -1  # below auto_min_blocks: no probe, the rings
             else:
                 assert (groups * 4 > len(blocks) // 16) == expect_mixed, groups
+                # mixed: the lane-per-block decoder with copy steps; uniform text: for LZ4 the one with the LDS window, for Snappy the rings
+                assert choice == (1 if expect_mixed else (2 if codec == "lz4" else 0)), choice
     finally:
         gb.set_option("lz4.decompress.auto_min_blocks", 65536)
         configure(gb, codec, DECODERS[0])
