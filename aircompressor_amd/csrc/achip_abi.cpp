@@ -26,6 +26,8 @@ hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32
 hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 hipError_t launch_snappy_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
+hipError_t launch_snappy_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* stats);
+hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
 hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant, void* scratch);
 int64_t snappy_compress_scratch_bytes();
@@ -223,12 +225,15 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 ctx->lastAutoIsLz4 = false;
                 ctx->lastZstddBlocks = 0;
                 e = achip::launch_lz4_mixed_groups(a, ctx->stream, mixedGroups, 0);
+                if (e == hipSuccess) e = achip::launch_snappy_element_sample(a, ctx->stream, mixedGroups, 0);
                 if (e == hipSuccess) e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, mixedGroups);
                 if (e == hipSuccess) e = achip::launch_snappy_decompress_lanecopy(a, ctx->stream, mixedGroups);
+                if (e == hipSuccess) e = achip::launch_snappy_decompress_lanewindow(a, ctx->stream, mixedGroups);
                 break;
             }
             e = ctx->snappydVariant == 0   ? achip::launch_snappy_decompress(a, ctx->stream, ctx->snappydGroup)
                 : ctx->snappydVariant == 4 ? achip::launch_snappy_decompress_lanecopy(a, ctx->stream, nullptr)
+                : ctx->snappydVariant == 6 ? achip::launch_snappy_decompress_lanewindow(a, ctx->stream, nullptr)
                                            : achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, nullptr);
             break;
         case ACHIP_OP_SNAPPY_COMPRESS: {
@@ -610,7 +615,7 @@ int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name)
         int32_t v[3] = {0, 0, 0};
         if (hipMemcpy(v, ctx->scratch, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if ((int64_t)v[0] * 4 > (ctx->lastAutoBlocks + 15) / 16) return 1;
-        return (ctx->lastAutoIsLz4 && v[1] > 0 && (int64_t)v[2] < 12 * (int64_t)v[1]) ? 2 : 0;
+        return (v[1] > 0 && (int64_t)v[2] < (ctx->lastAutoIsLz4 ? 12 : 6) * (int64_t)v[1]) ? 2 : 0;
     }
     const std::string prefix = "zstd.decompress.fallback_";
     if (k.compare(0, prefix.size(), prefix) == 0) {

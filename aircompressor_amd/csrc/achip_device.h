@@ -44,13 +44,15 @@ __device__ __forceinline__ bool lz4_batch_is_mixed(int32_t mixedGroups, int32_t 
 // otherwise short sequences (text: 10-40 bytes per sequence at a block's head; the long-copy sets: >= 100): the lane-per-block decoder
 // with the LDS output window; otherwise the rings.
 constexpr int LZ4_PICK_RINGS = 0, LZ4_PICK_LANECOPY = 1, LZ4_PICK_LANEWINDOW = 2;
-__device__ __forceinline__ int lz4_pick(const int32_t* stats, int32_t nBlocks)
+__device__ __forceinline__ int lz4_pick(const int32_t* stats, int32_t nBlocks, int32_t shortLimit = 12)
 {
     if (lz4_batch_is_mixed(stats[0], nBlocks)) {
         return LZ4_PICK_LANECOPY;
     }
-    return (stats[1] > 0 && (int64_t)stats[2] < 12 * (int64_t)stats[1]) ? LZ4_PICK_LANEWINDOW : LZ4_PICK_RINGS;
+    return (stats[1] > 0 && (int64_t)stats[2] < (int64_t)shortLimit * (int64_t)stats[1]) ? LZ4_PICK_LANEWINDOW : LZ4_PICK_RINGS;
 }
+// Snappy: the sample counts elements (a literal run or a copy -- half an LZ4 sequence)
+__device__ __forceinline__ int snappy_pick(const int32_t* stats, int32_t nBlocks) { return lz4_pick(stats, nBlocks, 6); }
 
 // ---- unaligned little-endian accessors (global memory; gfx950 runs in unaligned-access mode) ----
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

@@ -10,7 +10,7 @@ namespace achip {
 template <int GS, int IN_RING, int OUT_RING, int GPL>
 __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
-    if (mixedGroups != nullptr && lz4_batch_is_mixed(*mixedGroups, batch_count(a))) {  // auto mode (achip_abi.cpp): the lane-per-block decoder takes this batch
+    if (mixedGroups != nullptr && snappy_pick(mixedGroups, batch_count(a)) != LZ4_PICK_RINGS) {  // auto mode (achip_abi.cpp): the lane-per-block decoder takes this batch
         return;
     }
     ACHIP_DYNAMIC_LDS(smem);

@@ -1,16 +1,15 @@
-// snappy_decompress_v3.hip -- batched Snappy raw-format decode for gfx950, a lane per block (achip_lanecopy.h).
+// snappy_decompress_v4.hip -- batched Snappy raw-format decode for gfx950: a lane per block with the block's recent output in an LDS
+// window (the Snappy counterpart of lz4_decompress_v6.hip; the parse is snappy_decompress_v3.hip's).
 //
-// Same contract and Java-order checks as snappy_decompress_v2.hip (M/snappy/SnappyRawDecompressor.java:35-322).  The
-// structure is that of lz4_decompress_v5.hip: every lane owns a block, a trip parses one element (tag byte + trailer, from
-// one 16-byte window of the lane's LDS view of its stream) and the wavefront-wide copy step moves what the 64 elements
-// ask for -- a literal run (short ones come out of the window itself) or a copy, one period at a time when it overlaps
-// itself.  The instruction stream is the same whatever the blocks of a wavefront contain, which is what a batch of mixed
-// data needs (profiles/r01_notes.md).
-#include "achip_lanecopy.h"
+// Same contract and Java-order checks as snappy_decompress_v2.hip (M/snappy/SnappyRawDecompressor.java:35-322).  Output is appended to a
+// 256-byte LDS ring column per lane and leaves for the output buffer in aligned 64-byte pieces; a copy of up to 224 bytes back is read
+// from the ring, a farther one from the flushed part of the output buffer.  No cross-lane operation: the test suite also runs the kernel
+// on a CPU, one lane at a time (tools/hostemu).
+#include "achip_lanewindow.h"
 
 namespace achip {
 
-__device__ __forceinline__ int32_t snappy_op_entry3(int32_t op)  // opLookupTable layout :223-271
+__device__ __forceinline__ int32_t snappy_op_entry4(int32_t op)  // opLookupTable layout :223-271
 {
     const int32_t kind = op & 3;
     const int32_t hi = op >> 2;
@@ -23,15 +22,15 @@ __device__ __forceinline__ int32_t snappy_op_entry3(int32_t op)  // opLookupTabl
     return ((kind == 2 ? 2 : 4) << 11) | (hi + 1);
 }
 
-template <int IN_DW>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void snappy_decompress_lanecopy_kernel(BatchArgs a, const int32_t* mixedGroups)
+template <int IN_DW, int OUT_DW>
+__global__ __launch_bounds__(64) void snappy_decompress_lanewindow_kernel(BatchArgs a, const int32_t* stats)
 {
     using namespace sp;
-    if (mixedGroups != nullptr && snappy_pick(mixedGroups, batch_count(a)) != LZ4_PICK_LANECOPY) {  // auto mode: the ring decoder takes this batch
+    if (stats != nullptr && snappy_pick(stats, batch_count(a)) != LZ4_PICK_LANEWINDOW) {  // auto mode: another decoder takes this batch
         return;
     }
     __shared__ uint32_t ldsIn[IN_DW * 64];
-    __shared__ CopyScratch S;
+    __shared__ uint32_t ldsOut[OUT_DW * 64];
     const int lane = threadIdx.x;
     const int64_t block = (int64_t)blockIdx.x * 64 + lane;
     const bool have = block < batch_count(a);
@@ -85,6 +84,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     int32_t ip = 0;
     LaneInput<IN_DW> R;
     R.init(ldsIn + lane, in, inLimit);
+    LaneOutput<OUT_DW> W2;
+    W2.init(ldsOut + lane, out);
 
 #define SN_FAIL(off)                                                     \
     {                                                                    \
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // bound of the one-store short runs: the announced length, not the capacity -- a caller may hand out capacities that reach into
     // the next block's output (the framed reader does: the Java reader's buffer is larger than a chunk's plaintext)
     const uint8_t* const outEnd = out + (done ? 0 : (int32_t)expected);
-    while (__ballot(!done || rem > 0 || litRem > 0) != 0) {
+    while (!done || rem > 0 || litRem > 0) {  // (lane-private: no cross-lane operation anywhere in this kernel)
         HeadRegs h0;
         h0.A = u32x4{0, 0, 0, 0};
         h0.B = h0.A;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 // (end or failure).  The checks and their order: uncompressAll :84-216.
                 auto element = [&](int32_t opc, uint32_t t4) -> int {
                     ip++;
-                    const int32_t entry = snappy_op_entry3(opc);
+                    const int32_t entry = snappy_op_entry4(opc);
                     const int32_t trailerBytes = entry >> 11;
                     if (!(ip + 4 < inLimit)) {  // :90-92
                         if (ip + trailerBytes > inLimit) {
@@ -188,19 +189,56 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
             }
         }
-        // ---- copy (as in lz4_decompress_v5.hip; a trip has a literal run, a copy, or a short run and the copy behind it) ----
-        const int32_t n0 = (litRem > LONG || litRem < HEAD) ? litRem : HEAD;
-        int32_t n1 = rem < dist ? rem : dist;
-        n1 = (n1 > LONG || n1 < HEAD) ? n1 : HEAD;
-        n1 = (litRem > n0 || dist < n0 + n1) ? 0 : n1;  // the copy waits for the run in front of it, and for bytes of this trip
-        copy_step<true>(S, lane, h0, have0, out + litOut, in + litPos, n0, inEnd, out + cur, out + cur - dist, n1, outEnd);
-        litOut += n0;
-        litPos += n0;
-        litRem -= n0;
-        cur += n1;
-        rem -= n1;
-        if (rem > dist && 2 * (int64_t)dist <= (int64_t)(cur - periodic)) {
-            dist += dist;
+        // ---- copy through the lane's LDS window (as in lz4_decompress_v6.hip) ----
+        {
+            const int32_t n0 = litRem < 32 ? litRem : 32;
+            if (n0 > 0) {
+                u32x4 A, B = {0, 0, 0, 0};
+                if (have0) {
+                    A = h0.A;
+                }
+                else {
+                    A = safe_ld16(in + litPos, inEnd);
+                    if (n0 > 16) {
+                        B = safe_ld16(in + litPos + 16, inEnd);
+                    }
+                }
+                W2.append(A, n0 < 16 ? n0 : 16);
+                if (n0 > 16) {
+                    W2.append(B, n0 - 16);
+                }
+                litPos += n0;
+                litRem -= n0;
+            }
+            int32_t n1 = rem < dist ? rem : dist;
+            n1 = n1 < 32 ? n1 : 32;
+            n1 = litRem > 0 ? 0 : n1;
+            if (n1 > 0) {
+                const int32_t sV = W2.opV - dist;
+                u32x4 A, B = {0, 0, 0, 0};
+                if (dist <= LaneOutput<OUT_DW>::REACH) {
+                    A = W2.read16(sV);
+                    if (n1 > 16) {
+                        B = W2.read16(sV + 16);
+                    }
+                }
+                else {  // flushed long ago
+                    A = ld16(W2.outAligned + sV);
+                    if (n1 > 16) {
+                        B = ld16(W2.outAligned + sV + 16);
+                    }
+                }
+                W2.append(A, n1 < 16 ? n1 : 16);
+                if (n1 > 16) {
+                    W2.append(B, n1 - 16);
+                }
+                cur += n1;
+                rem -= n1;
+                if (rem > dist && 2 * (int64_t)dist <= (int64_t)(cur - periodic)) {
+                    dist += dist;
+                }
+            }
+            W2.flush_complete();
         }
     }
 #undef SN_FAIL
@@ -209,16 +247,67 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_LENGTH_MISMATCH);
             eo = 0;
         }
+        if (st == 0) {
+            W2.flush_tail();
+        }
         a.outLen[block] = st == 0 ? op : 0;
         a.status[block] = st;
         a.errOffset[block] = (int64_t)eo;
     }
 }
 
-hipError_t launch_snappy_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups)
+// auto mode: how long are the elements?  1024 sampled blocks, the first <= 192 elements of each (a lane per sample; tags only)
+__global__ __launch_bounds__(64) void snappy_element_sample_kernel(BatchArgs a, int32_t* stats, int32_t minBlocks)
+{
+    const int32_t n = batch_count(a);
+    if (n < minBlocks) {
+        return;
+    }
+    const int32_t t = blockIdx.x * 64 + threadIdx.x;
+    const int64_t block = (int64_t)t * n / 1024;
+    const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
+    const int32_t inLimit = a.srcLen[block];
+    int32_t ip = 0, elements = 0;
+    int64_t bytes = 0;
+    while (ip < inLimit && ip < 5 && (in[ip] & 0x80) != 0) {  // the length preamble
+        ip++;
+    }
+    ip++;
+    while (ip < inLimit && elements < 192) {
+        const int32_t opc = in[ip++];
+        const int32_t entry = snappy_op_entry4(opc);
+        const int32_t trailerBytes = entry >> 11;
+        if (ip + trailerBytes > inLimit) {
+            break;
+        }
+        uint32_t trailer = 0;
+        for (int i = 0; i < trailerBytes; i++) {
+            trailer |= (uint32_t)in[ip + i] << (8 * i);
+        }
+        ip += trailerBytes;
+        int64_t length = entry & 0xff;
+        if ((opc & 3) == 0) {
+            length += trailer;
+            ip += (int32_t)(length < (int64_t)(inLimit - ip) ? length : inLimit - ip);
+        }
+        bytes += length;
+        elements++;
+    }
+    bytes = bytes < 0 || bytes > (1 << 24) ? (1 << 24) : bytes;
+    atomicAdd(stats + 1, elements);
+    atomicAdd(stats + 2, (int32_t)(bytes >> 2));
+}
+
+hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks)
+{
+    hipLaunchKernelGGL(snappy_element_sample_kernel, dim3(16), dim3(64), 0, stream, a, stats, minBlocks);
+    return hipGetLastError();
+}
+
+hipError_t launch_snappy_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* stats)
 {
     const unsigned grid = (unsigned)((a.nBlocks + 63) / 64);
-    hipLaunchKernelGGL((snappy_decompress_lanecopy_kernel<16>), dim3(grid), dim3(64), 0, stream, a, mixedGroups);
+    hipLaunchKernelGGL((snappy_decompress_lanewindow_kernel<16, 64>), dim3(grid), dim3(64), 0, stream, a, stats);
     return hipGetLastError();
 }
 

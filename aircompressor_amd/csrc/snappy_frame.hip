@@ -749,6 +749,8 @@ __global__ __launch_bounds__(64) void snappyframed_fold_kernel(BatchArgs a, Chun
 
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 hipError_t launch_snappy_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
+hipError_t launch_snappy_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* stats);
+hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
 
 int64_t snappyframed_decompress_scratch_bytes(int32_t nStreams)
@@ -818,8 +820,10 @@ hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream
     c.nBlocksDev = counters + 1;
     int32_t* mixedGroups = counters + 16;
     e = launch_lz4_mixed_groups(c, stream, mixedGroups, 65536);  // (the lane-per-block decoder wants 64 blocks per wavefront)
+    if (e == hipSuccess) e = launch_snappy_element_sample(c, stream, mixedGroups, 65536);
     if (e == hipSuccess) e = launch_snappy_decompress_rings(c, stream, 4, 0, mixedGroups);
     if (e == hipSuccess) e = launch_snappy_decompress_lanecopy(c, stream, mixedGroups);
+    if (e == hipSuccess) e = launch_snappy_decompress_lanewindow(c, stream, mixedGroups);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(snf::snappyframed_verify_kernel, dim3(maxWaves), dim3(64), 0, stream, a, L);
     hipLaunchKernelGGL(snf::snappyframed_fold_kernel, dim3(perStream), dim3(64), 0, stream, a, L);

@@ -108,8 +108,10 @@ def test_lz4_experimental_decoders(gb, o, cfg):
             assert outs[i] == eout, "case %d" % i
 
 
-def test_snappy_lane_per_block_decoder(gb, o):
-    """variant 4 (snappy_decompress_v3.hip): plaintext, status and error offsets equal the oracle's, corrupt streams included"""
+@pytest.mark.parametrize("variant", [4, 6], ids=["copy-steps", "lds-window"])
+def test_snappy_lane_per_block_decoder(gb, o, variant):
+    """variants 4 (snappy_decompress_v3.hip) and 6 (snappy_decompress_v4.hip): plaintext, status and error offsets equal the oracle's,
+    corrupt streams included"""
     rng = np.random.default_rng(11)
     blocks = all_blocks()
     cases = [(o.compress("snappy", b), len(b)) for b in blocks] + [(o.compress("snappy", b), len(b) + 37) for b in blocks[:20]]
@@ -121,7 +123,7 @@ def test_snappy_lane_per_block_decoder(gb, o):
             m = bytearray(c)
             m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
             cases.append((bytes(m), len(b)))
-    configure(gb, "snappy", (4, 4, 0))
+    configure(gb, "snappy", (variant, 4, 0))
     try:
         outs, status, err = gb.run(CODECS["snappy"]["d"], [c for c, _ in cases], [cap for _, cap in cases], unaligned=True)
     finally:
@@ -157,8 +159,8 @@ def test_auto_mode_picks_a_decoder_on_the_device(gb, o, codec):
                 assert groups == -1 and choice == -1  # below auto_min_blocks: no probe, the rings
             else:
                 assert (groups * 4 > len(blocks) // 16) == expect_mixed, groups
-                # mixed: the lane-per-block decoder with copy steps; uniform text: for LZ4 the one with the LDS window, for Snappy the rings
-                assert choice == (1 if expect_mixed else (2 if codec == "lz4" else 0)), choice
+                # mixed: the lane-per-block decoder with copy steps; uniform text: the one with the LDS window
+                assert choice == (1 if expect_mixed else 2), choice
     finally:
         gb.set_option("lz4.decompress.auto_min_blocks", 65536)
         configure(gb, codec, DECODERS[0])

@@ -30,6 +30,7 @@ inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
 // cross-lane builtins that only the NOT emulated kernels of a shared header use (they must compile, they never run here)
 inline int __builtin_amdgcn_update_dpp(int old, int src, int, int, int, bool) { (void)old; return src; }
 inline int __builtin_amdgcn_readlane(int v, int) { return v; }
+template <typename T> inline T atomicAdd(T* p, T v) { T old = *p; *p += v; return old; }
 template <typename T> inline T __shfl(T v, int) { return v; }
 
 // dynamic shared memory of the emulated launch: one arena, re-used by every "workgroup"
