@@ -615,7 +615,7 @@ int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name)
         int32_t v[3] = {0, 0, 0};
         if (hipMemcpy(v, ctx->scratch, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if ((int64_t)v[0] * 4 > (ctx->lastAutoBlocks + 15) / 16) return 1;
-        return (v[1] > 0 && (int64_t)v[2] < (ctx->lastAutoIsLz4 ? 12 : 6) * (int64_t)v[1]) ? 2 : 0;
+        return (ctx->lastAutoBlocks >= 131072 && v[1] > 0 && (int64_t)v[2] < (ctx->lastAutoIsLz4 ? 12 : 6) * (int64_t)v[1]) ? 2 : 0;
     }
     const std::string prefix = "zstd.decompress.fallback_";
     if (k.compare(0, prefix.size(), prefix) == 0) {

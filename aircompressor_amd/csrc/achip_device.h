@@ -49,7 +49,8 @@ __device__ __forceinline__ int lz4_pick(const int32_t* stats, int32_t nBlocks, i
     if (lz4_batch_is_mixed(stats[0], nBlocks)) {
         return LZ4_PICK_LANECOPY;
     }
-    return (stats[1] > 0 && (int64_t)stats[2] < (int64_t)shortLimit * (int64_t)stats[1]) ? LZ4_PICK_LANEWINDOW : LZ4_PICK_RINGS;
+    // (the LDS-window decoder runs 8 wavefronts of 64 blocks per CU: below 131072 blocks it cannot fill the chip and the rings win)
+    return (nBlocks >= 131072 && stats[1] > 0 && (int64_t)stats[2] < (int64_t)shortLimit * (int64_t)stats[1]) ? LZ4_PICK_LANEWINDOW : LZ4_PICK_RINGS;
 }
 // Snappy: the sample counts elements (a literal run or a copy -- half an LZ4 sequence)
 __device__ __forceinline__ int snappy_pick(const int32_t* stats, int32_t nBlocks) { return lz4_pick(stats, nBlocks, 6); }

@@ -159,8 +159,8 @@ def test_auto_mode_picks_a_decoder_on_the_device(gb, o, codec):
                 assert groups == -1 and choice == -1  # below auto_min_blocks: no probe, the rings
             else:
                 assert (groups * 4 > len(blocks) // 16) == expect_mixed, groups
-                # mixed: the lane-per-block decoder with copy steps; uniform text: the one with the LDS window
-                assert choice == (1 if expect_mixed else 2), choice
+                # mixed: the lane-per-block decoder with copy steps; uniform: the rings (the LDS-window decoder is picked from 131072 blocks on)
+                assert choice == (1 if expect_mixed else 0), choice
     finally:
         gb.set_option("lz4.decompress.auto_min_blocks", 65536)
         configure(gb, codec, DECODERS[0])
