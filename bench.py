@@ -346,7 +346,7 @@ def extras(torch, A, codec, dev, args):
     lib = codec.lib
     bs = args.block_size
     for data_kind in ("fragments", "wordmix", "corpus"):
-        n = args.blocks if data_kind == "corpus" else 65536  # corpus-tiled is the primary data of BASELINE configs[1]: at its size
+        n = 65536 if data_kind == "fragments" else args.blocks  # text-like and corpus-tiled (the primary data of BASELINE configs[1]) at its size
         plain = gen_data(torch, dev, data_kind, n, bs, args.ratio, 977)
         for name, cop, dop in (("lz4", A.OP_LZ4_COMPRESS, A.OP_LZ4_DECOMPRESS), ("snappy", A.OP_SNAPPY_COMPRESS, A.OP_SNAPPY_DECOMPRESS)):
             max_c = getattr(lib, "achip_%s_max_compressed_length" % name)(bs)
