@@ -175,7 +175,10 @@ int32_t achip_ctx_synchronize(achip_ctx* ctx);    /* hipStreamSynchronize */
 int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value);
 /* diagnostics of the LAST batched call on this context (synchronizes the stream); -1 = unknown name / nothing recorded.
  * "zstd.decompress.fallback_items": items the five-stage pipeline handed to the one-kernel decoder;
- * "zstd.decompress.fallback_stage1" .. "stage5": the same, by the stage that handed them over. */
+ * "zstd.decompress.fallback_stage1" .. "stage5": the same, by the stage that handed them over;
+ * "lz4.decompress.mixed_groups": auto mode's count of mixed 16-block groups of the last LZ4 / Snappy decode (-1: no probe ran);
+ * "decompress.choice": the decoder auto mode ran (0 LDS rings, 1 a lane per block with copy steps, 2 a lane per block with an LDS
+ *   output window; -1: no probe ran).  DESIGN.md 8b lists every option and statistic. */
 int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name);
 
 /* device / pinned memory helpers; addresses are usable as MemorySegment.ofAddress */
