@@ -59,8 +59,38 @@ class HipBatchCodec:
         if r < 0:
             native.raise_for_status(r)
 
+    def launch_mixed(self, ops, src, src_off, src_len, dst, dst_off, dst_cap, out_len, status, err_off, n_blocks):
+        """A mixed batch (BASELINE configs[4]): item i is processed by ops[i] (OP_*), any interleaving.  `ops` is a HOST int32 array;
+        everything else is device-accessible as for `launch`.  The items are bucketed by codec op inside the library (each kernel
+        launch is homogeneous) and the results come back in item order.  Asynchronous on the context stream."""
+        ops = np.ascontiguousarray(ops, dtype=np.int32)
+        if len(ops) != int(n_blocks):
+            raise native.IllegalArgumentException("ops must have one entry per item")
+        r = self.lib.achip_mixed_batch(self.native.ctx, ops.ctypes.data, _ptr(src), _ptr(src_off), _ptr(src_len), _ptr(dst), _ptr(dst_off), _ptr(dst_cap),
+                                       _ptr(out_len), _ptr(status), _ptr(err_off), int(n_blocks))
+        if r < 0:
+            native.raise_for_status(r)
+
     def synchronize(self):
         self.native.synchronize()
+
+    def run_host_mixed(self, ops, src, src_off, src_len, dst, dst_off, dst_cap):
+        """Host numpy arrays in/out through achip_mixed_batch_host: one op per item."""
+        n = len(src_off)
+        ops = np.ascontiguousarray(ops, dtype=np.int32)
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        src_off = np.ascontiguousarray(src_off, dtype=np.int64)
+        src_len = np.ascontiguousarray(src_len, dtype=np.int32)
+        dst_off = np.ascontiguousarray(dst_off, dtype=np.int64)
+        dst_cap = np.ascontiguousarray(dst_cap, dtype=np.int32)
+        out_len = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        err_off = np.zeros(n, dtype=np.int64)
+        r = self.lib.achip_mixed_batch_host(self.native.ctx, ops.ctypes.data, src.ctypes.data, src_off.ctypes.data, src_len.ctypes.data, dst.ctypes.data,
+                                            dst_off.ctypes.data, dst_cap.ctypes.data, out_len.ctypes.data, status.ctypes.data, err_off.ctypes.data, n)
+        if r < 0:
+            native.raise_for_status(r)
+        return out_len, status, err_off
 
     def run_host(self, op, src, src_off, src_len, dst, dst_off, dst_cap):
         """Host numpy arrays in/out through achip_batch_host (stages through pinned memory)."""

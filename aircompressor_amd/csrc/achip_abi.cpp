@@ -6,6 +6,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -15,11 +19,7 @@
 #include "achip_device.h"
 
 namespace achip {
-hipError_t launch_lz4_decompress(const BatchArgs& a, hipStream_t stream, int groupSize);
-hipError_t launch_snappy_decompress(const BatchArgs& a, hipStream_t stream, int groupSize);
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
-hipError_t launch_lz4_decompress_lanes(const BatchArgs& a, hipStream_t stream, int ringClass);
-hipError_t launch_lz4_decompress_steps(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass);
 hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
@@ -42,6 +42,8 @@ int64_t snappyframed_compress_scratch_bytes(int32_t nStreams);
 hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch);
 hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch);
 int64_t lz4frame_compress_scratch_bytes();
+hipError_t launch_mix_gather(const int32_t* perm, int32_t n, const BatchArgs& a, int64_t* gSrcOff, int32_t* gSrcLen, int64_t* gDstOff, int32_t* gDstCap, hipStream_t stream);
+hipError_t launch_mix_scatter(const int32_t* perm, int32_t n, const int32_t* gOutLen, const int32_t* gStatus, const int64_t* gErr, const BatchArgs& a, hipStream_t stream);
 hipError_t launch_xxh64_batch(const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int32_t n, uint64_t seed, int64_t* out, hipStream_t stream);
 hipError_t launch_xxh32_batch(const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int32_t n, uint32_t seed, int32_t* out, hipStream_t stream);
 }  // namespace achip
@@ -53,8 +55,8 @@ struct achip_ctx {
     int lz4dGroup = 4;       // lanes per block: measured best on MI355X (profiles/r01_sweep_v2_rings.txt)
     int snappydGroup = 4;
     int lz4dAutoMinBlocks = 65536;  // auto mode considers the lane-per-block decoder (64 blocks per wavefront) from this batch size on
-    int lz4dVariant = 5;     // 0 = direct-to-HBM groups (lz4_decompress.hip), 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 2 = LDS rings, a lane per block (lz4_decompress_v3.hip), 3 = lane groups driven as a uniform-step state machine (lz4_decompress_v4.hip), 4 = a lane per block, copies straight between the global buffers (lz4_decompress_v5.hip), 5 = auto: 4 for large mixed batches, else 1
-    int snappydVariant = 5;  // 0 direct, 1 rings (snappy_decompress_v2.hip), 4 a lane per block (snappy_decompress_v3.hip), 5 auto as for LZ4
+    int lz4dVariant = 5;     // 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 4 = a lane per block, copies straight between the global buffers (lz4_decompress_v5.hip), 6 = a lane per block with an LDS output window (lz4_decompress_v6.hip), 5 = auto
+    int snappydVariant = 5;  // 1 rings (snappy_decompress_v2.hip), 4 / 6 a lane per block (snappy_decompress_v3.hip / _v4.hip), 5 auto as for LZ4
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
     int lz4cVariant = 1;     // 0 = serial probes, 1 = 64 probes per step (batch)
     int snappycVariant = 2;  // 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory
@@ -74,13 +76,29 @@ struct achip_ctx {
     // scratch for the zstd pipeline (grown on demand)
     void* scratch = nullptr;
     int64_t scratchBytes = 0;
-    // staging for the host-pointer entry points (grown on demand)
+    // mixed batches (achip_mixed_batch): item permutation (pinned host + device) and the bucketed descriptor / result arrays
+    int32_t* mixHost = nullptr;
+    uint8_t* mixDev = nullptr;
+    int64_t mixItems = 0;
+    hipEvent_t mixUploaded = nullptr;  // the last permutation upload: the pinned buffer may be rewritten once it has completed
+    // host-pointer batches (achip_batch_host / achip_mixed_batch_host): two staging slots, chunks pipelined over three streams
+    struct CopyPool* pool = nullptr;
+    uint8_t* slotHost[2] = {nullptr, nullptr};  // pinned
+    uint8_t* slotDev[2] = {nullptr, nullptr};
+    int64_t slotBytes = 0;
+    hipStream_t copyIn = nullptr, copyOut = nullptr;
+    hipEvent_t evH2D[2] = {nullptr, nullptr}, evK[2] = {nullptr, nullptr}, evD2H[2] = {nullptr, nullptr};
+    int64_t hostChunkBytes = 48 << 20;  // staging bytes (inputs + output capacities) per pipeline chunk
+    int hostCopyThreads = 0;            // 0 = min(8, hardware threads)
+    // staging for the one-shot hashers (grown on demand)
     uint8_t* hostStage = nullptr;  // pinned
     uint8_t* devStage = nullptr;
     int64_t stageBytes = 0;
 };
 
 namespace {
+
+void destroy_host_path(achip_ctx* ctx);
 
 thread_local std::string g_lastError;
 
@@ -207,10 +225,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 if (e == hipSuccess) e = achip::launch_lz4_decompress_lanewindow(a, ctx->stream, mixedGroups);
                 break;
             }
-            e = ctx->lz4dVariant == 0   ? achip::launch_lz4_decompress(a, ctx->stream, ctx->lz4dGroup)
-                : ctx->lz4dVariant == 2 ? achip::launch_lz4_decompress_lanes(a, ctx->stream, ctx->ringClass)
-                : ctx->lz4dVariant == 3 ? achip::launch_lz4_decompress_steps(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass)
-                : ctx->lz4dVariant == 4 ? achip::launch_lz4_decompress_lanecopy(a, ctx->stream, nullptr)
+            e = ctx->lz4dVariant == 4 ? achip::launch_lz4_decompress_lanecopy(a, ctx->stream, nullptr)
                 : ctx->lz4dVariant == 6 ? achip::launch_lz4_decompress_lanewindow(a, ctx->stream, nullptr)
                                         : achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, nullptr);
             break;
@@ -231,8 +246,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 if (e == hipSuccess) e = achip::launch_snappy_decompress_lanewindow(a, ctx->stream, mixedGroups);
                 break;
             }
-            e = ctx->snappydVariant == 0   ? achip::launch_snappy_decompress(a, ctx->stream, ctx->snappydGroup)
-                : ctx->snappydVariant == 4 ? achip::launch_snappy_decompress_lanecopy(a, ctx->stream, nullptr)
+            e = ctx->snappydVariant == 4 ? achip::launch_snappy_decompress_lanecopy(a, ctx->stream, nullptr)
                 : ctx->snappydVariant == 6 ? achip::launch_snappy_decompress_lanewindow(a, ctx->stream, nullptr)
                                            : achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, nullptr);
             break;
@@ -511,7 +525,12 @@ int64_t achip_zstd_decompressed_size(const void* src, int64_t srcLen, int64_t* e
         case 0: return singleSegment ? (int64_t)rd(input, 1) : -1;
         case 1: return (int64_t)rd(input, 2) + 256;
         case 2: return (int64_t)rd(input, 4);
-        default: return (int64_t)rd(input, 8);
+        default: {
+            // the reference returns the raw long; a field >= 2^63 would collide with this API's negative statuses, so it is
+            // reported as what it is (no such frame can be decoded: the window check rejects it)
+            const uint64_t v = rd(input, 8);
+            return v > (uint64_t)INT64_MAX ? fail(ACHIP_D_ZSTD_WINDOW_TOO_LARGE, input) : (int64_t)v;
+        }
     }
 }
 
@@ -546,6 +565,10 @@ void achip_ctx_destroy(achip_ctx* ctx)
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->hostStage) (void)hipHostFree(ctx->hostStage);
     if (ctx->devStage) (void)hipFree(ctx->devStage);
+    if (ctx->mixHost) (void)hipHostFree(ctx->mixHost);
+    if (ctx->mixDev) (void)hipFree(ctx->mixDev);
+    if (ctx->mixUploaded) (void)hipEventDestroy(ctx->mixUploaded);
+    destroy_host_path(ctx);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -574,9 +597,15 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         if (!pow2(value)) return bad_argument("group size must be a power of two in 1..64");
         ctx->snappydGroup = (int)value;
     }
-    else if (k == "lz4.decompress.variant") ctx->lz4dVariant = (int)value;
+    else if (k == "lz4.decompress.variant") {
+        if (value != 1 && value != 4 && value != 5 && value != 6) return bad_argument("lz4.decompress.variant: 1 rings, 4 / 6 a lane per block, 5 auto");
+        ctx->lz4dVariant = (int)value;
+    }
     else if (k == "lz4.decompress.auto_min_blocks") ctx->lz4dAutoMinBlocks = (int)value;
-    else if (k == "snappy.decompress.variant") ctx->snappydVariant = (int)value;
+    else if (k == "snappy.decompress.variant") {
+        if (value != 1 && value != 4 && value != 5 && value != 6) return bad_argument("snappy.decompress.variant: 1 rings, 4 / 6 a lane per block, 5 auto");
+        ctx->snappydVariant = (int)value;
+    }
     else if (k == "decompress.ring_class") ctx->ringClass = (int)value;
     else if (k == "lz4.compress.variant") ctx->lz4cVariant = (int)value;
     else if (k == "snappy.compress.variant") ctx->snappycVariant = (int)value;
@@ -594,6 +623,15 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     else if (k == "zstd.decompress.variant") ctx->zstddVariant = (int)value;
     else if (k == "zstd.compress.variant") ctx->zstdcVariant = (int)value;
     else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;
+    else if (k == "host.chunk_bytes") {
+        if (value < (1 << 16) || value > (1LL << 32)) return bad_argument("host.chunk_bytes must be in 64 KiB .. 4 GiB");
+        ctx->hostChunkBytes = value;
+    }
+    else if (k == "host.copy_threads") {
+        if (value < 0 || value > 64) return bad_argument("host.copy_threads must be in 0..64");
+        if (ctx->pool) return bad_argument("host.copy_threads must be set before the first host-pointer batch");
+        ctx->hostCopyThreads = (int)value;
+    }
     else return bad_argument("unknown option");
     return 0;
 }
@@ -741,6 +779,75 @@ ACHIP_DEFINE_BATCH(achip_lz4frame_compress_batch, ACHIP_OP_LZ4FRAME_COMPRESS)
 ACHIP_DEFINE_BATCH(achip_snappyframed_decompress_batch, ACHIP_OP_SNAPPYFRAMED_DECOMPRESS)
 ACHIP_DEFINE_BATCH(achip_snappyframed_compress_batch, ACHIP_OP_SNAPPYFRAMED_COMPRESS)
 
+// ---- mixed batch: bucket by codec op, run every op over its slice, un-bucket (BASELINE configs[4]) ----
+namespace {
+int32_t ensure_mix(achip_ctx* ctx, int64_t n)
+{
+    if (n <= ctx->mixItems) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->mixHost) { HIP_TRY(hipHostFree(ctx->mixHost)); ctx->mixHost = nullptr; }
+    if (ctx->mixDev) { HIP_TRY(hipFree(ctx->mixDev)); ctx->mixDev = nullptr; }
+    ctx->mixItems = 0;
+    const int64_t want = std::max<int64_t>(n, 4096);
+    HIP_TRY(hipHostMalloc((void**)&ctx->mixHost, (size_t)(want * 4), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&ctx->mixDev, (size_t)(want * 48 + 256)));
+    if (!ctx->mixUploaded) HIP_TRY(hipEventCreateWithFlags(&ctx->mixUploaded, hipEventDisableTiming));
+    ctx->mixItems = want;
+    return 0;
+}
+constexpr int kNumOps = 10;
+}  // namespace
+
+int32_t achip_mixed_batch(achip_ctx* ctx, const int32_t* codecOp, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, void* dstBase,
+                          const int64_t* dstOff, const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t nBlocks)
+{
+    if (!ctx) return bad_argument("ctx is null");
+    if (nBlocks < 0) return bad_argument("nBlocks < 0");
+    if (nBlocks == 0) return 0;
+    if (!codecOp || !srcOff || !srcLen || !dstOff || !dstCap || !outLen || !status) return bad_argument("null metadata array");
+    const int64_t n = nBlocks;
+    int64_t count[kNumOps + 1] = {0};
+    for (int64_t i = 0; i < n; i++) {
+        if (codecOp[i] < 0 || codecOp[i] >= kNumOps) return bad_argument("codecOp out of range");
+        count[codecOp[i] + 1]++;
+    }
+    int32_t r = ensure_mix(ctx, n);
+    if (r < 0) return r;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(ctx->mixUploaded));  // the previous call's upload has left the pinned buffer (no-op on the first call)
+    int64_t start[kNumOps + 1];
+    start[0] = 0;
+    for (int k = 0; k < kNumOps; k++) start[k + 1] = start[k] + count[k + 1];
+    {
+        int64_t fill[kNumOps];
+        for (int k = 0; k < kNumOps; k++) fill[k] = start[k];
+        for (int64_t i = 0; i < n; i++) ctx->mixHost[fill[codecOp[i]]++] = (int32_t)i;  // stable: items of one codec keep their order
+    }
+    const int64_t cap = ctx->mixItems;
+    uint8_t* d = ctx->mixDev;
+    int64_t* gSrcOff = (int64_t*)d;
+    int64_t* gDstOff = gSrcOff + cap;
+    int64_t* gErr = gDstOff + cap;
+    int32_t* gSrcLen = (int32_t*)(gErr + cap);
+    int32_t* gDstCap = gSrcLen + cap;
+    int32_t* gOutLen = gDstCap + cap;
+    int32_t* gStatus = gOutLen + cap;
+    int32_t* perm = gStatus + cap;
+    HIP_TRY(hipMemcpyAsync(perm, ctx->mixHost, (size_t)(n * 4), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->mixUploaded, ctx->stream));
+    const achip::BatchArgs all = make_args(srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, nBlocks);
+    HIP_TRY(achip::launch_mix_gather(perm, nBlocks, all, gSrcOff, gSrcLen, gDstOff, gDstCap, ctx->stream));
+    for (int k = 0; k < kNumOps; k++) {
+        if (count[k + 1] == 0) continue;
+        const int64_t s = start[k];
+        r = launch_op(k, ctx, make_args(srcBase, gSrcOff + s, gSrcLen + s, dstBase, gDstOff + s, gDstCap + s, gOutLen + s, gStatus + s, gErr + s, (int32_t)count[k + 1]));
+        if (r < 0) return r;
+    }
+    HIP_TRY(achip::launch_mix_scatter(perm, nBlocks, gOutLen, gStatus, gErr, all, ctx->stream));
+    return 0;
+}
+
 // ---- xxhash -------------------------------------------
 int32_t achip_xxhash64_batch(achip_ctx* ctx, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int64_t seed, int64_t* outHash, int32_t nBuffers)
 {
@@ -810,74 +917,317 @@ int32_t achip_xxhash32(achip_ctx* ctx, const void* src, int64_t srcLen, int32_t 
     return r;
 }
 
-// ---- host-pointer batch: stage in, run, stage out ------------------------
+// ---- host-pointer batches: chunked, double-buffered staging (H2D || kernels || D2H || host copies) ---------------
+// What a Compressor.compress(byte[]...) / decompress(MemorySegment...) caller gets.  The items are cut into chunks of about
+// host.chunk_bytes of staging; chunk c uses slot c & 1.  Per chunk: the host gathers the inputs into the slot's pinned buffer (a few
+// copy threads), `copyIn` uploads, the context stream runs the codec kernels, `copyOut` downloads, and the host scatters the outputs
+// to the caller's buffers -- while the next chunk is already being gathered / uploaded / run.  Kernels stay on ONE stream (they share
+// the context's scratch); events order the slots.  A mixed batch is first ordered by codec op so that every chunk is homogeneous.
+struct CopyPool {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cvWork, cvDone;
+    std::function<void(int64_t)> fn;
+    int64_t nTasks = 0;
+    std::atomic<int64_t> next{0};
+    int64_t generation = 0;
+    int active = 0;
+    bool stop = false;
+
+    explicit CopyPool(int n)
+    {
+        for (int t = 0; t < n; t++) {
+            threads.emplace_back([this] { worker(); });
+        }
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m);
+            stop = true;
+        }
+        cvWork.notify_all();
+        for (auto& t : threads) t.join();
+    }
+    void worker()
+    {
+        int64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m);
+                cvWork.wait(g, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+            }
+            drain();
+            {
+                std::lock_guard<std::mutex> g(m);
+                if (--active == 0) cvDone.notify_all();
+            }
+        }
+    }
+    void drain()
+    {
+        for (;;) {
+            const int64_t i = next.fetch_add(1);
+            if (i >= nTasks) return;
+            fn(i);
+        }
+    }
+    // runs f(0..n-1) on the pool's threads and the calling thread; returns when all are done
+    void run(int64_t n, std::function<void(int64_t)> f)
+    {
+        if (n <= 0) return;
+        if (threads.empty() || n == 1) {
+            for (int64_t i = 0; i < n; i++) f(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m);
+            fn = std::move(f);
+            nTasks = n;
+            next.store(0);
+            active = (int)threads.size();
+            generation++;
+        }
+        cvWork.notify_all();
+        drain();
+        std::unique_lock<std::mutex> g(m);
+        cvDone.wait(g, [&] { return active == 0; });
+    }
+};
+
+namespace {
+
+void destroy_host_path(achip_ctx* ctx)
+{
+    delete ctx->pool;
+    ctx->pool = nullptr;
+    for (int s = 0; s < 2; s++) {
+        if (ctx->slotHost[s]) (void)hipHostFree(ctx->slotHost[s]);
+        if (ctx->slotDev[s]) (void)hipFree(ctx->slotDev[s]);
+        if (ctx->evH2D[s]) (void)hipEventDestroy(ctx->evH2D[s]);
+        if (ctx->evK[s]) (void)hipEventDestroy(ctx->evK[s]);
+        if (ctx->evD2H[s]) (void)hipEventDestroy(ctx->evD2H[s]);
+    }
+    if (ctx->copyIn) (void)hipStreamDestroy(ctx->copyIn);
+    if (ctx->copyOut) (void)hipStreamDestroy(ctx->copyOut);
+}
+
+int32_t ensure_host_path(achip_ctx* ctx, int64_t slotBytes)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->copyIn) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->copyIn, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->copyOut, hipStreamNonBlocking));
+        for (int s = 0; s < 2; s++) {
+            HIP_TRY(hipEventCreateWithFlags(&ctx->evH2D[s], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->evK[s], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->evD2H[s], hipEventDisableTiming));
+        }
+    }
+    if (!ctx->pool) {
+        int t = ctx->hostCopyThreads;
+        if (t == 0) t = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+        ctx->pool = new CopyPool(t - 1);  // the calling thread is one of the copiers
+    }
+    if (slotBytes > ctx->slotBytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->copyIn));
+        HIP_TRY(hipStreamSynchronize(ctx->copyOut));
+        for (int s = 0; s < 2; s++) {
+            if (ctx->slotHost[s]) { HIP_TRY(hipHostFree(ctx->slotHost[s])); ctx->slotHost[s] = nullptr; }
+            if (ctx->slotDev[s]) { HIP_TRY(hipFree(ctx->slotDev[s])); ctx->slotDev[s] = nullptr; }
+        }
+        ctx->slotBytes = 0;
+        const int64_t want = std::max<int64_t>(slotBytes, 1 << 20);
+        for (int s = 0; s < 2; s++) {
+            HIP_TRY(hipHostMalloc((void**)&ctx->slotHost[s], (size_t)want, hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void**)&ctx->slotDev[s], (size_t)want));
+        }
+        ctx->slotBytes = want;
+    }
+    return 0;
+}
+
+struct HostChunk {
+    int64_t first = 0, count = 0;     // range of the processing order
+    int32_t op = 0;
+    int64_t srcBytes = 0, dstBytes = 0, metaOff = 0, metaEnd = 0;
+    int64_t oSrcOff = 0, oDstOff = 0, oErr = 0, oSrcLen = 0, oDstCap = 0, oOutLen = 0, oStatus = 0;
+    int32_t maxLen = 0;
+};
+
+constexpr int64_t kCopyGrain = 256 << 10;  // bytes per copy task: small blocks are grouped, large ones split
+
+// order[j] = caller's item index of the j-th processed item (nullptr: identity); ops: per item (mixed) or nullptr (all `op`)
+int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t* order, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen,
+                   void* dstBase, const int64_t* dstOff, const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int64_t n)
+{
+    auto item = [&](int64_t j) -> int64_t { return order ? order[j] : j; };
+    // ---- cut into chunks: homogeneous op, about hostChunkBytes of staging each, at least one item ----
+    std::vector<HostChunk> chunks;
+    std::vector<int64_t> sOff(n), dOff(n);  // per processed item: offsets inside its chunk's src / dst regions
+    int64_t maxSlot = 0;
+    {
+        HostChunk c;
+        bool open = false;
+        auto close = [&]() {
+            c.metaOff = (c.srcBytes + c.dstBytes + 63) & ~63LL;
+            int64_t m = c.metaOff;
+            c.oSrcOff = m; m += c.count * 8;
+            c.oDstOff = m; m += c.count * 8;
+            c.oErr = m; m += c.count * 8;
+            c.oSrcLen = m; m += c.count * 4;
+            c.oDstCap = m; m += c.count * 4;
+            c.oOutLen = m; m += c.count * 4;
+            c.oStatus = m; m += c.count * 4;
+            c.metaEnd = m;
+            maxSlot = std::max(maxSlot, m + 64);
+            chunks.push_back(c);
+            open = false;
+        };
+        for (int64_t j = 0; j < n; j++) {
+            const int64_t i = item(j);
+            if (srcLen[i] < 0 || dstCap[i] < 0) return bad_argument("negative length");
+            const int32_t o = ops ? ops[i] : op;
+            const int64_t sb = ((int64_t)srcLen[i] + 15) & ~15LL, db = ((int64_t)dstCap[i] + 15) & ~15LL;
+            if (open && (o != c.op || c.srcBytes + c.dstBytes + sb + db > ctx->hostChunkBytes)) close();
+            if (!open) {
+                c = HostChunk();
+                c.first = j;
+                c.op = o;
+                open = true;
+            }
+            sOff[j] = c.srcBytes;
+            dOff[j] = c.dstBytes;
+            c.srcBytes += sb;
+            c.dstBytes += db;
+            c.count++;
+            c.maxLen = std::max(c.maxLen, srcLen[i]);
+        }
+        if (open) close();
+    }
+    int32_t r = ensure_host_path(ctx, maxSlot);
+    if (r < 0) return r;
+    CopyPool& pool = *ctx->pool;
+
+    // copy tasks over a chunk's items: consecutive items are grouped up to kCopyGrain bytes, one task per group
+    auto for_items = [&](const HostChunk& c, bool outputs, const std::function<void(int64_t)>& body) {
+        std::vector<int64_t> cut;
+        cut.push_back(c.first);
+        int64_t acc = 0;
+        for (int64_t j = c.first; j < c.first + c.count; j++) {
+            const int64_t i = item(j);
+            acc += outputs ? std::max(outLen[i], 0) : srcLen[i];
+            if (acc >= kCopyGrain) {
+                cut.push_back(j + 1);
+                acc = 0;
+            }
+        }
+        if (cut.back() != c.first + c.count) cut.push_back(c.first + c.count);
+        pool.run((int64_t)cut.size() - 1, [&](int64_t t) {
+            for (int64_t j = cut[t]; j < cut[t + 1]; j++) body(j);
+        });
+    };
+
+    auto finalize = [&](const HostChunk& c, int slot) -> int32_t {
+        HIP_TRY(hipEventSynchronize(ctx->evD2H[slot]));
+        const uint8_t* h = ctx->slotHost[slot];
+        for (int64_t j = c.first; j < c.first + c.count; j++) {
+            const int64_t i = item(j), k = j - c.first;
+            outLen[i] = ((const int32_t*)(h + c.oOutLen))[k];
+            status[i] = ((const int32_t*)(h + c.oStatus))[k];
+            if (errOffset) errOffset[i] = ((const int64_t*)(h + c.oErr))[k];
+        }
+        for_items(c, true, [&](int64_t j) {
+            const int64_t i = item(j);
+            if (status[i] == 0 && outLen[i] > 0) {
+                memcpy((uint8_t*)dstBase + dstOff[i], h + c.srcBytes + dOff[j], (size_t)outLen[i]);
+            }
+        });
+        return 0;
+    };
+
+    const int savedHint = ctx->maxSrcLenHint;
+    for (size_t ci = 0; ci < chunks.size(); ci++) {
+        const HostChunk& c = chunks[ci];
+        const int slot = (int)(ci & 1);
+        uint8_t* h = ctx->slotHost[slot];
+        uint8_t* d = ctx->slotDev[slot];
+        // (the slot's previous chunk, ci - 2, was finalized at the end of iteration ci - 1: its buffers are free)
+        for_items(c, false, [&](int64_t j) {
+            const int64_t i = item(j);
+            if (srcLen[i] > 0) memcpy(h + sOff[j], (const uint8_t*)srcBase + srcOff[i], (size_t)srcLen[i]);
+        });
+        for (int64_t j = c.first; j < c.first + c.count; j++) {
+            const int64_t i = item(j), k = j - c.first;
+            ((int64_t*)(h + c.oSrcOff))[k] = sOff[j];
+            ((int64_t*)(h + c.oDstOff))[k] = c.srcBytes + dOff[j];
+            ((int32_t*)(h + c.oSrcLen))[k] = srcLen[i];
+            ((int32_t*)(h + c.oDstCap))[k] = dstCap[i];
+        }
+        if (c.srcBytes > 0) HIP_TRY(hipMemcpyAsync(d, h, (size_t)c.srcBytes, hipMemcpyHostToDevice, ctx->copyIn));
+        HIP_TRY(hipMemcpyAsync(d + c.metaOff, h + c.metaOff, (size_t)(c.oOutLen - c.metaOff), hipMemcpyHostToDevice, ctx->copyIn));
+        HIP_TRY(hipEventRecord(ctx->evH2D[slot], ctx->copyIn));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->evH2D[slot], 0));
+        achip::BatchArgs a = make_args(d, (const int64_t*)(d + c.oSrcOff), (const int32_t*)(d + c.oSrcLen), d, (const int64_t*)(d + c.oDstOff),
+                                       (const int32_t*)(d + c.oDstCap), (int32_t*)(d + c.oOutLen), (int32_t*)(d + c.oStatus), (int64_t*)(d + c.oErr), (int32_t)c.count);
+        ctx->maxSrcLenHint = std::max(c.maxLen, 1);
+        r = launch_op(c.op, ctx, a);
+        ctx->maxSrcLenHint = savedHint;
+        if (r < 0) {
+            (void)hipStreamSynchronize(ctx->copyIn);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(ctx->copyOut);
+            return r;
+        }
+        HIP_TRY(hipEventRecord(ctx->evK[slot], ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->copyOut, ctx->evK[slot], 0));
+        if (c.dstBytes > 0) HIP_TRY(hipMemcpyAsync(h + c.srcBytes, d + c.srcBytes, (size_t)c.dstBytes, hipMemcpyDeviceToHost, ctx->copyOut));
+        HIP_TRY(hipMemcpyAsync(h + c.oErr, d + c.oErr, (size_t)(c.count * 8), hipMemcpyDeviceToHost, ctx->copyOut));
+        HIP_TRY(hipMemcpyAsync(h + c.oOutLen, d + c.oOutLen, (size_t)(c.metaEnd - c.oOutLen), hipMemcpyDeviceToHost, ctx->copyOut));
+        HIP_TRY(hipEventRecord(ctx->evD2H[slot], ctx->copyOut));
+        if (ci >= 1) {
+            r = finalize(chunks[ci - 1], (int)((ci - 1) & 1));  // overlaps with this chunk's upload / kernels / download
+            if (r < 0) return r;
+        }
+    }
+    r = finalize(chunks.back(), (int)((chunks.size() - 1) & 1));
+    if (r < 0) return r;
+    // the context stream is idle again for the caller (everything it launched was awaited through evK -> evD2H)
+    return 0;
+}
+
+}  // namespace
+
 int32_t achip_batch_host(int32_t codecOp, ACHIP_BATCH_ARGS)
 {
     if (!ctx) return bad_argument("ctx is null");
     if (nBlocks < 0) return bad_argument("nBlocks < 0");
     if (nBlocks == 0) return 0;
+    if (codecOp < 0 || codecOp >= kNumOps) return bad_argument("unknown codecOp");
     if (!srcOff || !srcLen || !dstOff || !dstCap || !outLen || !status) return bad_argument("null metadata array");
-    // device layout: [src blocks packed, 16-aligned][dst blocks packed, 16-aligned][metadata]
-    const int64_t n = nBlocks;
-    std::vector<int64_t> dSrcOff(n), dDstOff(n);
-    int64_t srcBytes = 0, dstBytes = 0;
-    int32_t maxLen = 0;
-    for (int64_t i = 0; i < n; i++) {
-        if (srcLen[i] < 0 || dstCap[i] < 0) return bad_argument("negative length");
-        dSrcOff[i] = srcBytes;
-        srcBytes += ((int64_t)srcLen[i] + 15) & ~15LL;
-        dDstOff[i] = dstBytes;
-        dstBytes += ((int64_t)dstCap[i] + 15) & ~15LL;
-        maxLen = std::max(maxLen, srcLen[i]);
-    }
-    const int64_t metaOff = ((srcBytes + dstBytes) + 63) & ~63LL;
-    const int64_t metaBytes = n * (8 + 4 + 8 + 4 + 4 + 4 + 8) + 64;
-    int32_t r = ensure_stage(ctx, metaOff + metaBytes);
-    if (r < 0) return r;
+    return host_batch(ctx, codecOp, nullptr, nullptr, srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, nBlocks);
+}
 
-    uint8_t* h = ctx->hostStage;
-    uint8_t* d = ctx->devStage;
-    for (int64_t i = 0; i < n; i++) {
-        if (srcLen[i] > 0) memcpy(h + dSrcOff[i], (const uint8_t*)srcBase + srcOff[i], (size_t)srcLen[i]);
+int32_t achip_mixed_batch_host(achip_ctx* ctx, const int32_t* codecOp, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, void* dstBase,
+                               const int64_t* dstOff, const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t nBlocks)
+{
+    if (!ctx) return bad_argument("ctx is null");
+    if (nBlocks < 0) return bad_argument("nBlocks < 0");
+    if (nBlocks == 0) return 0;
+    if (!codecOp || !srcOff || !srcLen || !dstOff || !dstCap || !outLen || !status) return bad_argument("null metadata array");
+    // bucket by codec op (stable): every chunk of the pipeline is then homogeneous
+    std::vector<int32_t> order((size_t)nBlocks);
+    int64_t start[kNumOps + 1] = {0};
+    for (int32_t i = 0; i < nBlocks; i++) {
+        if (codecOp[i] < 0 || codecOp[i] >= kNumOps) return bad_argument("codecOp out of range");
+        start[codecOp[i] + 1]++;
     }
-    // metadata block
-    int64_t m = metaOff;
-    int64_t oSrcOff = m; m += n * 8;
-    int64_t oDstOff = m; m += n * 8;
-    int64_t oErr = m; m += n * 8;
-    int64_t oSrcLen = m; m += n * 4;
-    int64_t oDstCap = m; m += n * 4;
-    int64_t oOutLen = m; m += n * 4;
-    int64_t oStatus = m; m += n * 4;
-    for (int64_t i = 0; i < n; i++) {
-        ((int64_t*)(h + oSrcOff))[i] = dSrcOff[i];
-        ((int64_t*)(h + oDstOff))[i] = srcBytes + dDstOff[i];
-        ((int32_t*)(h + oSrcLen))[i] = srcLen[i];
-        ((int32_t*)(h + oDstCap))[i] = dstCap[i];
-    }
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(d, h, (size_t)srcBytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d + metaOff, h + metaOff, (size_t)(m - metaOff), hipMemcpyHostToDevice, ctx->stream));
-    achip::BatchArgs a = make_args(d, (const int64_t*)(d + oSrcOff), (const int32_t*)(d + oSrcLen), d, (const int64_t*)(d + oDstOff),
-                                   (const int32_t*)(d + oDstCap), (int32_t*)(d + oOutLen), (int32_t*)(d + oStatus), (int64_t*)(d + oErr), nBlocks);
-    const int savedHint = ctx->maxSrcLenHint;
-    ctx->maxSrcLenHint = std::max(maxLen, 1);
-    r = launch_op(codecOp, ctx, a);
-    ctx->maxSrcLenHint = savedHint;
-    if (r < 0) return r;
-    HIP_TRY(hipMemcpyAsync(h + srcBytes, d + srcBytes, (size_t)dstBytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(h + oErr, d + oErr, (size_t)(m - oErr), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int64_t i = 0; i < n; i++) {
-        const int32_t len = ((int32_t*)(h + oOutLen))[i];
-        outLen[i] = len;
-        status[i] = ((int32_t*)(h + oStatus))[i];
-        if (errOffset) errOffset[i] = ((int64_t*)(h + oErr))[i];
-        if (status[i] == 0 && len > 0) {
-            memcpy((uint8_t*)dstBase + dstOff[i], h + srcBytes + dDstOff[i], (size_t)len);
-        }
-    }
-    return 0;
+    for (int k = 0; k < kNumOps; k++) start[k + 1] += start[k];
+    for (int32_t i = 0; i < nBlocks; i++) order[(size_t)start[codecOp[i]]++] = i;
+    return host_batch(ctx, 0, codecOp, order.data(), srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, nBlocks);
 }
 
 // ---- single block, host pointers -----------------------------------------

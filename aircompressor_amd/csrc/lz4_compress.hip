@@ -60,7 +60,7 @@ __device__ __forceinline__ void lz4_write_run_length(uint8_t* out, int32_t o, in
 }
 
 template <typename TableT>
-__global__ __launch_bounds__(64) void lz4_compress_kernel(BatchArgs a, int32_t wideOnly)
+__global__ __launch_bounds__(64) void lz4_compress_kernel(BatchArgs a, int32_t bothWidths)
 {
     using namespace lz4c;
     __shared__ TableT table[MAX_TABLE_SIZE];
@@ -70,9 +70,13 @@ __global__ __launch_bounds__(64) void lz4_compress_kernel(BatchArgs a, int32_t w
     constexpr bool WIDE = sizeof(TableT) == 4;
     // two launches cover a batch: u16 tables for blocks <= 64 KiB, i32 tables for the rest
     if (WIDE ? (inLen <= 65536) : (inLen > 65536)) {
+        if (!bothWidths && lane == 0) {  // the caller's max_src_len_hint was wrong: say so instead of leaving the block's results unwritten
+            a.outLen[block] = 0;
+            a.status[block] = mk_status(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_BAD_ARGUMENT);
+            a.errOffset[block] = 0;
+        }
         return;
     }
-    (void)wideOnly;
     const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
     uint8_t* __restrict__ out = a.dstBase + a.dstOff[block];
     const int32_t outCap = a.dstCap[block];
@@ -460,7 +464,7 @@ __device__ int32_t lz4_compress_block(const uint8_t* __restrict__ in, int32_t in
 // loop would have produced (a probe's candidate is the latest earlier batch position with the same hash, else the
 // table entry); only the entries up to the winning probe are written back, latest position last.
 template <typename TableT>
-__global__ __launch_bounds__(64) void lz4_compress_batch_kernel(BatchArgs a)
+__global__ __launch_bounds__(64) void lz4_compress_batch_kernel(BatchArgs a, int32_t bothWidths)
 {
     using namespace lz4c;
     __shared__ TableT table[MAX_TABLE_SIZE];
@@ -469,6 +473,11 @@ __global__ __launch_bounds__(64) void lz4_compress_batch_kernel(BatchArgs a)
     const int32_t inLen = a.srcLen[block];
     constexpr bool WIDE = sizeof(TableT) == 4;
     if (WIDE ? (inLen <= 65536) : (inLen > 65536)) {
+        if (!bothWidths && lane == 0) {  // the caller's max_src_len_hint was wrong: say so instead of leaving the block's results unwritten
+            a.outLen[block] = 0;
+            a.status[block] = mk_status(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_BAD_ARGUMENT);
+            a.errOffset[block] = 0;
+        }
         return;
     }
     const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
@@ -592,21 +601,23 @@ hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int varia
     if (a.nBlocks <= 0) {
         return hipSuccess;
     }
-    // maxSrcLenHint: 0 = unknown (launch both table widths), else the largest srcLen in the batch
+    // maxSrcLenHint: 0 = unknown (launch both table widths), else the caller's promise about the largest srcLen in the batch;
+    // a block of the width that was not launched gets an INVALID_ARGUMENT status from the kernel that was
+    const int32_t both = maxSrcLenHint == 0;
     if (maxSrcLenHint == 0 || maxSrcLenHint <= 65536) {
         if (variant == 0) {
-            hipLaunchKernelGGL(lz4_compress_kernel<uint16_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, 0);
+            hipLaunchKernelGGL(lz4_compress_kernel<uint16_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, both);
         }
         else {
-            hipLaunchKernelGGL(lz4_compress_batch_kernel<uint16_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a);
+            hipLaunchKernelGGL(lz4_compress_batch_kernel<uint16_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, both);
         }
     }
     if (maxSrcLenHint == 0 || maxSrcLenHint > 65536) {
         if (variant == 0) {
-            hipLaunchKernelGGL(lz4_compress_kernel<int32_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, 1);
+            hipLaunchKernelGGL(lz4_compress_kernel<int32_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, both);
         }
         else {
-            hipLaunchKernelGGL(lz4_compress_batch_kernel<int32_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a);
+            hipLaunchKernelGGL(lz4_compress_batch_kernel<int32_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, both);
         }
     }
     return hipGetLastError();

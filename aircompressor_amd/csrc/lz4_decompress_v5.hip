@@ -269,11 +269,12 @@ __global__ __launch_bounds__(64) void lz4_sequence_sample_kernel(BatchArgs a, in
     const int64_t block = (int64_t)t * n / 1024;
     const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
     const int32_t inLimit = a.srcLen[block];
-    int32_t ip = 0, seqs = 0;
+    int64_t ip = 0;  // 64-bit: a run of length-extension bytes must not wrap the cursor
+    int32_t seqs = 0;
     int64_t bytes = 0;
     while (ip < inLimit && seqs < 96) {
         const int32_t token = in[ip++];
-        int32_t lit = token >> 4;
+        int64_t lit = token >> 4;
         if (lit == 15) {
             int32_t v = 255;
             while (v == 255 && ip < inLimit) {
@@ -284,11 +285,11 @@ __global__ __launch_bounds__(64) void lz4_sequence_sample_kernel(BatchArgs a, in
         bytes += lit;
         ip += lit;
         seqs++;
-        if (ip + 2 > inLimit || lit < 0) {
+        if (ip + 2 > inLimit) {
             break;  // last literals (or nonsense: the decoders will say)
         }
         ip += 2;
-        int32_t ml = token & 15;
+        int64_t ml = token & 15;
         if (ml == 15) {
             int32_t v = 255;
             while (v == 255 && ip < inLimit) {

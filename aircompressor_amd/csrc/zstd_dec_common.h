@@ -45,7 +45,7 @@ struct TableShared {
 };
 
 struct Shared : TableShared {
-    uint64_t seq[SEQ_RING];                 // litLen (18) | matchLen (18) << 18 | offset (24+) << 36
+    uint64_t seq[SEQ_RING];                 // litLen (17: <= 131071) | matchLen (18: <= 131074) << 17 | offset (29: <= 0x1FFFFFFC) << 35
     int32_t bS[65];                         // batch execution: exclusive prefix of (litLen + matchLen), bS[n..64] = span
     int32_t bLL[64];                        // literal length per sequence
     int32_t bLP[64];                        // exclusive prefix of literal lengths

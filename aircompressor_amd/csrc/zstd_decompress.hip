@@ -243,9 +243,9 @@ __device__ int32_t execute_batch(Ctx& c, Shared& sh, int32_t i0, int32_t n, int3
     int32_t ll = 0, ml = 0, of = 0;
     if (lane < n) {
         const uint64_t s = sh.seq[i0 + lane];
-        ll = (int32_t)(s & 0x3FFFF);
-        ml = (int32_t)((s >> 18) & 0x3FFFF);
-        of = (int32_t)(s >> 36);
+        ll = (int32_t)(s & 0x1FFFF);
+        ml = (int32_t)((s >> 17) & 0x3FFFF);
+        of = (int32_t)(s >> 35);  // 29 bits: the largest offset the format can express is 0x1FFFFFFC (code 28)
     }
     // inclusive scans of litLen and litLen + matchLen
     int32_t lsum = ll, osum = ll + ml;
@@ -269,7 +269,7 @@ __device__ int32_t execute_batch(Ctx& c, Shared& sh, int32_t i0, int32_t n, int3
         else if ((int64_t)literalsInput + lsum > litSize) {
             err = 2;  // "Input is corrupted" (literals exhausted)
         }
-        else if ((int64_t)output + op + ll - of < 0) {
+        else if (of <= 0 || (int64_t)output + op + ll - of < 0) {
             err = 3;  // "Input is corrupted" (match before the start of the call's output)
         }
     }
@@ -311,7 +311,7 @@ __device__ int32_t execute_batch(Ctx& c, Shared& sh, int32_t i0, int32_t n, int3
         const int32_t chunkAbs = output + chunk;
         // pointer jumping for match bytes whose source is inside this 64-byte step
         for (;;) {
-            const bool pending = active && kind == 1 && src >= chunkAbs;
+            const bool pending = active && kind == 1 && src >= chunkAbs && src < chunkAbs + lane;  // a source is always an earlier lane
             if (__ballot(pending) == 0) {
                 break;
             }
@@ -476,7 +476,7 @@ __device__ int32_t decompress_sequences(Ctx& c, Shared& sh, FrameState& fs, cons
                 mlState &= 511;
                 ofState &= 511;
                 if (c.lane == 0) {
-                    sh.seq[nDecoded] = (uint64_t)(uint32_t)literalsLength | ((uint64_t)(uint32_t)matchLength << 18) | ((uint64_t)(uint32_t)offset << 36);
+                    sh.seq[nDecoded] = (uint64_t)((uint32_t)literalsLength & 0x1FFFFu) | ((uint64_t)((uint32_t)matchLength & 0x3FFFFu) << 17) | ((uint64_t)((uint32_t)offset & 0x1FFFFFFFu) << 35);
                 }
                 nDecoded++;
             }

@@ -73,6 +73,8 @@ SIGNATURES = {
     "achip_zstd_compress": (_i32, [_vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_i64)]),
     "achip_zstd_decompress": (_i32, [_vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_i64)]),
     "achip_batch_host": (_i32, [_i32] + _BATCH),
+    "achip_mixed_batch": (_i32, [_vp, _vp] + _BATCH[1:]),
+    "achip_mixed_batch_host": (_i32, [_vp, _vp] + _BATCH[1:]),
     "achip_partition_blocks": (_i32, [_vp, _i32, _i32, _vp]),
 }
 

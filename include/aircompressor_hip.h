@@ -295,6 +295,22 @@ int32_t achip_xxhash32(achip_ctx* ctx, const void* src, int64_t srcLen, int32_t 
 #define ACHIP_OP_SNAPPYFRAMED_DECOMPRESS 8
 #define ACHIP_OP_SNAPPYFRAMED_COMPRESS 9
 int32_t achip_batch_host(int32_t codecOp, ACHIP_BATCH_ARGS);
+/* (Staging is chunked and double-buffered: while chunk c runs on the GPU, chunk c+1 is gathered into pinned memory and uploaded
+ * and chunk c-1 is downloaded and scattered to dstBase by a few host copy threads -- options "host.chunk_bytes",
+ * "host.copy_threads".  Replaces N calls of Compressor.compress(byte[]...) / Decompressor.decompress(byte[]...),
+ * M/Compressor.java:20-35, M/Decompressor.java:23-30, over one device.) */
+
+/* Mixed batches (BASELINE configs[4]): item i is processed by codecOp[i] (ACHIP_OP_*), any interleaving.  The items are
+ * bucketed by codec op so that every kernel launch is homogeneous -- what a caller holding e.g. one ORC / Parquet stripe with
+ * LZ4, Snappy and Zstd pages would otherwise do by hand with one Decompressor per codec (M/Decompressor.java:23-30) -- and the
+ * results land in the caller's item order.
+ *   achip_mixed_batch:      codecOp is a HOST array (the caller's own knowledge of its items); every other array and both buffers are
+ *                           DEVICE-accessible as for the homogeneous batch calls; asynchronous on the ctx stream.
+ *   achip_mixed_batch_host: everything is HOST memory; staged like achip_batch_host; synchronous. */
+int32_t achip_mixed_batch(achip_ctx* ctx, const int32_t* codecOp, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, void* dstBase,
+                          const int64_t* dstOff, const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t nBlocks);
+int32_t achip_mixed_batch_host(achip_ctx* ctx, const int32_t* codecOp, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, void* dstBase,
+                               const int64_t* dstOff, const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t nBlocks);
 
 /* Balanced contiguous partition of a batch over nParts GPUs: fills
  * starts[0..nParts] with block indices so that each part's sum of weight[i] is

@@ -24,6 +24,34 @@ def corpus_sample():
     return [("%s@%d" % (e["file"], e["offset"]), blob[e["blob_offset"]:e["blob_offset"] + e["length"]], e) for e in index]
 
 
+_corpus_full = None
+
+
+def corpus_full():
+    """{file: bytes} -- every file of the reference's test corpus (T/benchmark/DataSet.java:28-89 as far as the checkout holds them:
+    42 files, 14 MB), shipped as one xz blob + index by tools/make_golden.py so that it travels to the GPU box."""
+    global _corpus_full
+    if _corpus_full is None:
+        import lzma
+        blob = lzma.decompress(open(os.path.join(GOLDEN, "corpus_full.bin.xz"), "rb").read())
+        index = json.load(open(os.path.join(GOLDEN, "corpus_full.json")))
+        _corpus_full = {e["file"]: blob[e["offset"]:e["offset"] + e["length"]] for e in index}
+    return _corpus_full
+
+
+def read_manifest_tsv(name):
+    """[(file, offset, length, codec, compressed_length, sha256)] of tests/golden/<name> (oracle_manifest.tsv / java_manifest.tsv)."""
+    path = os.path.join(GOLDEN, name)
+    if not os.path.exists(path):
+        return None
+    rows = []
+    for line in open(path):
+        f = line.rstrip("\n").split("\t")
+        if len(f) == 6:
+            rows.append((f[0], int(f[1]), int(f[2]), f[3], int(f[4]), f[5]))
+    return rows
+
+
 def golden_zstd(name):
     return open(os.path.join(GOLDEN, "zstd", name), "rb").read()
 

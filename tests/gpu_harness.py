@@ -30,7 +30,8 @@ class GpuBatch:
         return buf, offs, lens
 
     def run(self, op, blocks, caps, fill=0xA5, unaligned=False):
-        """blocks: list[bytes]; caps: output capacity per block.  Returns (outputs, status, err_off)."""
+        """blocks: list[bytes]; caps: output capacity per block.  Returns (outputs, status, err_off).
+        `op` may be a list with one op per block: the batch then goes through achip_mixed_batch (bucketed by codec)."""
         torch = self.torch
         n = len(blocks)
         src, src_off, src_len = self.pack(blocks, align=1 if unaligned else 16)
@@ -50,7 +51,10 @@ class GpuBatch:
         d_status = torch.full((n,), -7, dtype=torch.int32, device=self.dev)
         d_err = torch.zeros((n,), dtype=torch.int64, device=self.dev)
         torch.cuda.synchronize()
-        self.codec.launch(op, d_src, d_src_off, d_src_len, d_dst, d_dst_off, d_dst_cap, d_out_len, d_status, d_err, n)
+        if isinstance(op, (list, tuple, np.ndarray)):
+            self.codec.launch_mixed(op, d_src, d_src_off, d_src_len, d_dst, d_dst_off, d_dst_cap, d_out_len, d_status, d_err, n)
+        else:
+            self.codec.launch(op, d_src, d_src_off, d_src_len, d_dst, d_dst_off, d_dst_cap, d_out_len, d_status, d_err, n)
         self.codec.synchronize()
         out = d_dst.cpu().numpy()
         out_len = d_out_len.cpu().numpy()
@@ -63,4 +67,24 @@ class GpuBatch:
             assert (gap == fill).all(), "block %d wrote past its capacity" % i
         assert (out[max(pos, 16):] == fill).all(), "wrote past the end of the destination buffer"
         outputs = [out[dst_off[i]:dst_off[i] + max(int(out_len[i]), 0)].tobytes() for i in range(n)]
+        return outputs, status.tolist(), err.tolist()
+
+    def run_host(self, op, blocks, caps, fill=0xA5):
+        """The same through the host-pointer entry points (achip_batch_host / achip_mixed_batch_host): numpy buffers in and out."""
+        n = len(blocks)
+        src, src_off, src_len = self.pack(blocks, align=1)
+        caps = np.asarray(caps, dtype=np.int32)
+        dst_off = np.zeros(n, dtype=np.int64)
+        pos = 0
+        for i, c in enumerate(caps):
+            dst_off[i] = pos
+            pos += int(c) + 3
+        dst = np.full(max(pos, 16) + 64, fill, dtype=np.uint8)
+        if isinstance(op, (list, tuple, np.ndarray)):
+            out_len, status, err = self.codec.run_host_mixed(op, src, src_off, src_len, dst, dst_off, caps)
+        else:
+            out_len, status, err = self.codec.run_host(op, src, src_off, src_len, dst, dst_off, caps)
+        for i in range(n):
+            assert (dst[dst_off[i] + caps[i]:dst_off[i] + caps[i] + 3] == fill).all(), "block %d wrote past its capacity" % i
+        outputs = [dst[dst_off[i]:dst_off[i] + max(int(out_len[i]), 0)].tobytes() for i in range(n)]
         return outputs, status.tolist(), err.tolist()

@@ -1,0 +1,193 @@
+"""GPU parity on the WHOLE reference corpus (all 42 files, 14 MB: tests/golden/corpus_full.bin.xz) through the C ABI:
+
+  * every file in one call per codec (LZ4 single block up to 4 MB, Snappy with its 64 KiB sub-blocks, Zstd multi-block frames):
+    the GPU's stream must hash to the committed line of tests/golden/oracle_manifest.tsv (and of java_manifest.tsv when a JDK box
+    has produced it), and the GPU decoders must restore the plaintext;
+  * every 64 KiB (LZ4 / Snappy) and 128 KiB (Zstd) cut of every file, both directions, every decoder;
+  * BASELINE configs[4]: ONE interleaved batch of (codec, direction) items over the corpus through the codec-bucketing scheduler
+    (achip_mixed_batch, device-resident, and achip_mixed_batch_host), byte-exact per item.
+Mirrors T/AbstractTestCompression.java:61-67 (testDecompress / testCompress over DataSet) for the Hip codecs."""
+import hashlib
+import threading
+
+import numpy as np
+import pytest
+
+from tests import common, oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+OPS = {"lz4": (1, 0), "snappy": (3, 2), "zstd": (5, 4)}  # codec -> (compress op, decompress op)
+CUT = {"lz4": 65536, "snappy": 65536, "zstd": 131072}
+
+
+@pytest.fixture(scope="module")
+def gb():
+    from tests.gpu_harness import GpuBatch
+    return GpuBatch(0)
+
+
+@pytest.fixture(scope="module")
+def o():
+    return oracle_lib.load()
+
+
+def manifest_lines(codec, whole):
+    """whole=True: the one-call-per-file lines; whole=False: the block cuts (a file that fits one cut is its own single cut)"""
+    corpus = common.corpus_full()
+    rows = []
+    for r in common.read_manifest_tsv("oracle_manifest.tsv"):
+        file, off, length = r[0], r[1], r[2]
+        is_whole = off == 0 and length == len(corpus[file])
+        if r[3] == codec and (is_whole if whole else (not is_whole or length <= CUT[codec])):
+            rows.append(r)
+    java = common.read_manifest_tsv("java_manifest.tsv")
+    java = {(r[0], r[1], r[2], r[3]): r for r in java} if java else None
+    return corpus, rows, java
+
+
+def check_streams(codec, rows, outs, status, java):
+    for (file, off, length, _, clen, sha), c, s in zip(rows, outs, status):
+        assert s == 0, (file, off, length, s)
+        assert len(c) == clen and hashlib.sha256(c).hexdigest() == sha, "%s %s@%d+%d: GPU stream differs from the oracle's" % (codec, file, off, length)
+        if java is not None:
+            assert java[(file, off, length, codec)][4:] == (clen, sha), "%s %s@%d+%d: GPU stream differs from the Java encoder's" % (codec, file, off, length)
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy", "zstd"])
+def test_whole_files_one_call_each(gb, o, codec):
+    corpus, rows, java = manifest_lines(codec, whole=True)
+    assert len(rows) == 42
+    plain = [corpus[r[0]] for r in rows]
+    outs, status, _ = gb.run(OPS[codec][0], plain, [o.max_compressed_length(codec, len(b)) for b in plain])
+    check_streams(codec, rows, outs, status, java)
+    back, status, _ = gb.run(OPS[codec][1], outs, [len(b) for b in plain], unaligned=True)
+    for r, b, p, s in zip(rows, plain, back, status):
+        assert s == 0 and p == b, (codec, r[0], s)
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy", "zstd"])
+def test_every_block_cut_both_directions(gb, o, codec):
+    corpus, rows, java = manifest_lines(codec, whole=False)
+    assert len(rows) > (100 if codec == "zstd" else 200)
+    plain = [corpus[f][off:off + n] for f, off, n, *_ in rows]
+    outs, status, _ = gb.run(OPS[codec][0], plain, [o.max_compressed_length(codec, len(b)) for b in plain])
+    check_streams(codec, rows, outs, status, java)
+    variants = {"lz4": [5, 1, 4, 6], "snappy": [5, 1, 4, 6], "zstd": [1, 0]}[codec]
+    try:
+        for v in variants:
+            gb.set_option("%s.decompress.variant" % codec, v)
+            back, status, _ = gb.run(OPS[codec][1], outs, [len(b) for b in plain], unaligned=(v % 2 == 0))
+            for r, b, p, s in zip(rows, plain, back, status):
+                assert s == 0 and p == b, (codec, v, r[0], r[1], s)
+    finally:
+        gb.set_option("%s.decompress.variant" % codec, variants[0])
+
+
+def mixed_items(o, stride=1):
+    """configs[4]: (op, input, capacity, expected output) for every whole file and every cut, all three codecs, both directions,
+    interleaved deterministically (not grouped by codec)."""
+    corpus = common.corpus_full()
+    items = []
+    rows = common.read_manifest_tsv("oracle_manifest.tsv")[::stride]
+    for k, (f, off, n, codec, clen, sha) in enumerate(rows):
+        p = corpus[f][off:off + n]
+        c = o.compress(codec, p)
+        assert hashlib.sha256(c).hexdigest() == sha
+        cop, dop = OPS[codec]
+        items.append((cop, p, o.max_compressed_length(codec, n), c))
+        if n > 0:
+            items.append((dop, c, n, p))
+    order = np.random.default_rng(4).permutation(len(items))
+    return [items[i] for i in order]
+
+
+def test_mixed_batch_device_resident(gb, o):
+    items = mixed_items(o)
+    assert len(items) > 1200 and len({it[0] for it in items}) == 6
+    outs, status, _ = gb.run([it[0] for it in items], [it[1] for it in items], [it[2] for it in items])
+    for k, (it, out, s) in enumerate(zip(items, outs, status)):
+        assert s == 0, (k, it[0], len(it[1]), s)
+        assert out == it[3], "item %d (op %d, %d bytes in)" % (k, it[0], len(it[1]))
+
+
+def test_mixed_batch_host_pointers(gb, o):
+    items = mixed_items(o, stride=2)
+    gb.set_option("host.chunk_bytes", 4 << 20)  # many chunks: the staging pipeline wraps around its two slots many times
+    try:
+        outs, status, _ = gb.run_host([it[0] for it in items], [it[1] for it in items], [it[2] for it in items])
+    finally:
+        gb.set_option("host.chunk_bytes", 48 << 20)
+    for k, (it, out, s) in enumerate(zip(items, outs, status)):
+        assert s == 0, (k, it[0], len(it[1]), s)
+        assert out == it[3], "item %d (op %d, %d bytes in)" % (k, it[0], len(it[1]))
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy", "zstd"])
+def test_batch_host_hundreds_of_ragged_blocks(gb, o, codec):
+    """achip_batch_host with n >> 1 (what HipBatchCodec.java calls): ragged real blocks, both directions, small and default chunking;
+    malformed items keep their status without disturbing their neighbours."""
+    corpus = common.corpus_full()
+    rng = np.random.default_rng(12)
+    blob = corpus["calgary/book2"] + corpus["canterbury/kennedy.xls"] + corpus["calgary/pic"] + corpus["house.jpg"]
+    plain = []
+    pos = 0
+    while pos < len(blob) and len(plain) < 400:
+        n = int(rng.choice([1, 13, 300, 4096, 20000, 65536, 100000])) if codec != "zstd" else int(rng.choice([1, 300, 4096, 65536, 131072]))
+        plain.append(blob[pos:pos + n])
+        pos += n
+    cop, dop = OPS[codec]
+    for chunk in (1 << 20, 48 << 20):
+        gb.set_option("host.chunk_bytes", chunk)
+        outs, status, _ = gb.run_host(cop, plain, [o.max_compressed_length(codec, len(b)) for b in plain])
+        for b, c, s in zip(plain, outs, status):
+            assert s == 0 and c == o.compress(codec, b)
+        bad = list(outs)
+        bad[7] = bad[7][:max(1, len(bad[7]) // 2)]
+        bad[100] = b"\xff" * 40
+        back, status, err = gb.run_host(dop, bad, [len(b) for b in plain])
+        for k, (b, p, s) in enumerate(zip(plain, back, status)):
+            if k in (7, 100):
+                try:
+                    o.decompress(codec, bad[k], len(b))
+                    expect = (0, 0)
+                except oracle_lib.OracleError as e:
+                    expect = (e.status, e.offset)
+                assert (s, err[k] if s else 0) == expect, (k, s, err[k], expect)
+            else:
+                assert s == 0 and p == b, (k, s)
+    gb.set_option("host.chunk_bytes", 48 << 20)
+
+
+def test_two_contexts_two_threads(o):
+    """include/aircompressor_hip.h: "distinct contexts may be used concurrently from distinct threads" (one Java codec object per thread,
+    M/lz4/Lz4JavaCompressor.java:27-29; HipBatchCodec.java runs one thread per GPU): two contexts on device 0, two threads, each running
+    compress + decompress of all three codecs on its own data at the same time; results equal the oracle's."""
+    from tests.gpu_harness import GpuBatch
+    corpus = common.corpus_full()
+    data = [corpus["calgary/book1"], corpus["canterbury/ptt5"] + corpus["calgary/obj2"]]
+    errors = []
+
+    def worker(t):
+        try:
+            g = GpuBatch(0)
+            for rounds in range(3):
+                for codec in ("lz4", "snappy", "zstd"):
+                    cut = CUT[codec]
+                    plain = [data[t][i:i + cut] for i in range(0, len(data[t]), cut)]
+                    cop, dop = OPS[codec]
+                    outs, status, _ = g.run(cop, plain, [o.max_compressed_length(codec, len(b)) for b in plain])
+                    assert all(s == 0 for s in status)
+                    for b, c in zip(plain, outs):
+                        assert c == o.compress(codec, b), (t, codec)
+                    back, status, _ = g.run_host(dop, outs, [len(b) for b in plain])
+                    assert all(s == 0 for s in status) and back == plain, (t, codec)
+        except BaseException as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors

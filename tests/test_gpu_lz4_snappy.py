@@ -15,8 +15,8 @@ CODECS = {
     "lz4": dict(c=1, d=0, group_opt="lz4.decompress.group", variant_opt="lz4.decompress.variant"),
     "snappy": dict(c=3, d=2, group_opt="snappy.decompress.group", variant_opt="snappy.decompress.variant"),
 }
-# decoder configurations: (variant, lanes per block, ring class); variant 1 = LDS rings (default), 0 = direct-to-HBM groups
-DECODERS = [(1, 16, 0), (1, 16, 1), (1, 4, 0), (1, 4, 1), (1, 2, 0), (1, 2, 1), (1, 1, 0), (1, 1, 1), (1, 8, 0), (1, 8, 1), (1, 32, 0), (1, 32, 1), (1, 64, 0), (1, 64, 1)] + [(0, g, 0) for g in (1, 2, 4, 8, 16, 32, 64)]
+# ring decoder configurations: (variant, lanes per block, ring class); variant 1 = LDS rings
+DECODERS = [(1, 16, 0), (1, 16, 1), (1, 4, 0), (1, 4, 1), (1, 2, 0), (1, 2, 1), (1, 1, 0), (1, 1, 1), (1, 8, 0), (1, 8, 1), (1, 32, 0), (1, 32, 1), (1, 64, 0), (1, 64, 1)]
 
 
 def configure(gb, codec, cfg):
@@ -78,11 +78,10 @@ def test_decompress_matches_plaintext_all_decoder_configs(gb, o, codec, cfg):
     configure(gb, codec, DECODERS[0])
 
 
-@pytest.mark.parametrize("cfg", [(2, 4, 0), (2, 4, 1), (3, 4, 0), (3, 4, 1), (3, 1, 0), (3, 2, 0), (3, 2, 1), (3, 8, 0), (3, 8, 1), (4, 4, 0), (6, 4, 0)],
-                         ids=lambda c: "variant%d-gs%d-rc%d" % c)
-def test_lz4_experimental_decoders(gb, o, cfg):
-    """variant 2 (lz4_decompress_v3.hip, one lane per block) and variant 3 (lz4_decompress_v4.hip, uniform-step state machine
-    over lane groups), variant 4 (lz4_decompress_v5.hip, lane-per-block parse + lane-per-sequence execute): plaintext, status and error offsets equal the oracle's"""
+@pytest.mark.parametrize("cfg", [(4, 4, 0), (6, 4, 0)], ids=lambda c: "variant%d-gs%d-rc%d" % c)
+def test_lz4_lane_per_block_decoders(gb, o, cfg):
+    """variant 4 (lz4_decompress_v5.hip, a lane per block with wavefront-wide copy steps) and variant 6 (lz4_decompress_v6.hip, a lane per
+    block with an LDS output window): plaintext, status and error offsets equal the oracle's"""
     rng = np.random.default_rng(7)
     blocks = all_blocks()
     cases = [(o.compress("lz4", b), len(b)) for b in blocks] + [(o.compress("lz4", b), len(b) + 37) for b in blocks[:20]]

@@ -96,6 +96,26 @@ def test_error_fixtures_and_corruptions(gbd, o):
             assert err[i] == eoff, "case %d: gpu offset %d oracle %d" % (i, err[i], eoff)
 
 
+def test_offsets_beyond_28_bits_are_rejected(gbd, o):
+    """Offset code 28 expresses offsets up to 0x1FFFFFFC.  A hand-made 20-byte frame (one raw literal, one sequence, RLE tables: literal
+    length code 0, offset code 28, match length code 3) whose offset is 0x10000000 + the extra bits: "Input is corrupted" at offset 16
+    in the Java decoder (the match starts before the output).  Round 1's one-kernel decoder kept 28 bits of the offset -- such an
+    offset wrapped to 0 and the pointer-jumping loop never ended.  The extra bits are varied over the wrap point."""
+    base = bytes.fromhex("28b52ffd20045d000008410154001c0003000010")
+    cases = [base]
+    for b0 in (0, 1, 2, 3, 4, 8, 0x80, 0xFF):
+        for b1 in (0, 0x40):
+            for b2 in (0x10, 0x11, 0x14, 0x18, 0x1F):
+                cases.append(base[:-3] + bytes([b0, b1, b2]))
+    for cap in (4, 1 << 16):
+        outs, status, err = gbd.run(OP_ZSTD_DECOMPRESS, cases, [cap] * len(cases))
+        for i, c in enumerate(cases):
+            est, eoff, eout = _expect(o, c, cap)
+            assert (status[i], err[i] if est else 0) == (est, eoff), "case %d: gpu %d@%d oracle %d@%d" % (i, status[i], err[i], est, eoff)
+            if est == 0:
+                assert outs[i] == eout
+
+
 @pytest.mark.parametrize("level", [1, 3, 9])
 def test_libzstd_frames_decode_to_plaintext(gbd, o, level):
     blocks = plain_blocks()

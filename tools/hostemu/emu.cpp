@@ -1,26 +1,17 @@
 // tools/hostemu/emu.cpp -- runs the lane-private decoder kernels on the CPU (sequential lanes are exact when a kernel
-// uses no cross-lane operation: the GS=1 instantiations of the direct decoders and the lane-per-block v3 decoders).
+// uses no cross-lane operation: the GS=1 instantiations of the ring decoders and the lane-per-block decoders with an LDS window).
 #include "hip/hip_runtime.h"
 thread_local dim3 threadIdx, blockIdx, blockDim;
-#include "../../aircompressor_amd/csrc/lz4_decompress.hip"
-#include "../../aircompressor_amd/csrc/snappy_decompress.hip"
 #include "../../aircompressor_amd/csrc/lz4_decompress_v2.hip"
 #include "../../aircompressor_amd/csrc/snappy_decompress_v2.hip"
-#include "../../aircompressor_amd/csrc/lz4_decompress_v3.hip"
-#include "../../aircompressor_amd/csrc/lz4_decompress_v4.hip"
 #include "../../aircompressor_amd/csrc/lz4_decompress_v6.hip"
 #include "../../aircompressor_amd/csrc/snappy_decompress_v4.hip"
 extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, const int32_t* srcLen, uint8_t* dstBase, const int64_t* dstOff,
                          const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n)
 {
     achip::BatchArgs a{srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, n, 0};
-    if (op == 0) return achip::launch_lz4_decompress(a, nullptr, 1);
-    if (op == 2) return achip::launch_snappy_decompress(a, nullptr, 1);
-    if (op == 10) return achip::launch_lz4_decompress_lanes(a, nullptr, 0);
-    if (op == 11) return achip::launch_lz4_decompress_lanes(a, nullptr, 1);
     if (op == 19) return achip::launch_snappy_decompress_lanewindow(a, nullptr, nullptr);
     if (op == 18) return achip::launch_lz4_decompress_lanewindow(a, nullptr, nullptr);  // lane per block + LDS output window: lane-private
-    if (op == 14) return achip::launch_lz4_decompress_steps(a, nullptr, 1, 0);  // GS = 1: lane-private, exact when run one lane at a time
     if (op == 16 || op == 17) {  // default ring decoders at GS = 1 (compact / large rings)
         a.ringPad = 16;
         return achip::launch_lz4_decompress_rings(a, nullptr, 1, op - 16, nullptr);

@@ -69,6 +69,49 @@ def main():
         manifest[rel] = entry
     json.dump(manifest, open(os.path.join(GOLD, "manifest.json"), "w"), indent=1, sort_keys=True)
     print("golden: %d sample slices (%d bytes), %d corpus files" % (len(index), len(blob), len(manifest)))
+    full_corpus(o, sha)
+
+
+# T/benchmark/DataSet.java:28-89 (silesia/* and large/E.coli are not in the checkout)
+DATASET_ORDER = [
+    "canterbury/alice29.txt", "canterbury/asyoulik.txt", "canterbury/cp.html", "canterbury/fields.c", "canterbury/grammar.lsp",
+    "canterbury/kennedy.xls", "canterbury/lcet10.txt", "canterbury/plrabn12.txt", "canterbury/ptt5", "canterbury/sum", "canterbury/xargs.1",
+    "calgary/bib", "calgary/book1", "calgary/book2", "calgary/geo", "calgary/news", "calgary/obj1", "calgary/obj2", "calgary/paper1",
+    "calgary/paper2", "calgary/paper3", "calgary/paper4", "calgary/paper5", "calgary/paper6", "calgary/pic", "calgary/progc", "calgary/progl",
+    "calgary/progp", "calgary/trans",
+    "artificial/a.txt", "artificial/aaa.txt", "artificial/alphabet.txt", "artificial/random.txt", "artificial/uniform_ascii.bin",
+    "large/bible.txt", "large/world192.txt",
+    "geo.protodata", "house.jpg", "html", "kppkn.gtb", "mapreduce-osdi-1.pdf", "urls.10K",
+]
+
+
+def full_corpus(o, sha):
+    """The whole test corpus as ONE xz blob + index (the GPU box has no /root/reference), and tests/golden/oracle_manifest.tsv:
+    one line per (file, offset, length, codec) with the length and SHA-256 of the oracle's compressed stream -- whole files (one call)
+    and the block cuts of BASELINE configs[4] (64 KiB for LZ4 / Snappy, 128 KiB for Zstd; the last partial block included).
+    tools/GoldenDump.java writes the same lines from the real Java classes (-> tests/golden/java_manifest.tsv)."""
+    import lzma
+    blob = bytearray()
+    index = []
+    for rel in DATASET_ORDER:
+        d = open(os.path.join(REF, "testdata", rel), "rb").read()
+        index.append({"file": rel, "offset": len(blob), "length": len(d), "sha256": sha(d)})
+        blob += d
+    open(os.path.join(GOLD, "corpus_full.bin.xz"), "wb").write(lzma.compress(bytes(blob), preset=9 | lzma.PRESET_EXTREME))
+    json.dump(index, open(os.path.join(GOLD, "corpus_full.json"), "w"), indent=1)
+    lines = []
+    for e in index:
+        d = bytes(blob[e["offset"]:e["offset"] + e["length"]])
+        for codec, cut in (("lz4", 65536), ("snappy", 65536), ("zstd", 131072)):
+            c = o.compress(codec, d)
+            lines.append("%s\t0\t%d\t%s\t%d\t%s" % (e["file"], len(d), codec, len(c), sha(c)))
+            if len(d) > cut:
+                for off in range(0, len(d), cut):
+                    piece = d[off:off + cut]
+                    c = o.compress(codec, piece)
+                    lines.append("%s\t%d\t%d\t%s\t%d\t%s" % (e["file"], off, len(piece), codec, len(c), sha(c)))
+    open(os.path.join(GOLD, "oracle_manifest.tsv"), "w").write("\n".join(lines) + "\n")
+    print("golden: full corpus %d files, %d bytes; oracle manifest %d lines" % (len(index), len(blob), len(lines)))
 
 
 if __name__ == "__main__":
