@@ -601,18 +601,16 @@ hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int varia
     if (a.nBlocks <= 0) {
         return hipSuccess;
     }
-    // maxSrcLenHint: 0 = unknown (launch both table widths), else the caller's promise about the largest srcLen in the batch;
-    // a block of the width that was not launched gets an INVALID_ARGUMENT status from the kernel that was
-    const int32_t both = maxSrcLenHint == 0;
-    if (maxSrcLenHint == 0 || maxSrcLenHint <= 65536) {
-        if (variant == 0) {
-            hipLaunchKernelGGL(lz4_compress_kernel<uint16_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, both);
-        }
-        else {
-            hipLaunchKernelGGL(lz4_compress_batch_kernel<uint16_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, both);
-        }
+    // maxSrcLenHint: 0 = unknown, else the caller's promise about the largest srcLen in the batch: when it is <= 64 KiB the launch of
+    // the wide-table kernel is skipped (a block that breaks the promise gets an INVALID_ARGUMENT status, not silence)
+    const int32_t both = maxSrcLenHint == 0 || maxSrcLenHint > 65536;
+    if (variant == 0) {
+        hipLaunchKernelGGL(lz4_compress_kernel<uint16_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, both);
     }
-    if (maxSrcLenHint == 0 || maxSrcLenHint > 65536) {
+    else {
+        hipLaunchKernelGGL(lz4_compress_batch_kernel<uint16_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, both);
+    }
+    if (both) {
         if (variant == 0) {
             hipLaunchKernelGGL(lz4_compress_kernel<int32_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, both);
         }
