@@ -6,7 +6,7 @@
 A "step" is one pass of the hot path (achip_lz4_decompress_batch) over this rank's batch of
 synthetic blocks (BASELINE.json configs[1]: 262144 x 64 KiB per GPU).  Blocks are independent, so ranks
 own contiguous slices of the global batch (achip_partition_blocks) and there is NO data-path
-collective; torch.distributed (RCCL) only provides the barrier and the max-over-ranks of the time.
+collective; torch.distributed (gloo, CPU tensors) only provides the barrier and the max-over-ranks of the time.
 Inputs (compressed blocks, offsets) and outputs are resident in HBM before the timed region.
 
 Synthetic data: the reference's test generator shape (T/snappy/RandomGenerator.java:25-74): 100-byte
@@ -51,7 +51,9 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true")
     p.add_argument("--no-verify", action="store_true", help="DEBUG: skip the bit-exact check (kernel timing aids that leave work out); the line is then not a result")
-    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time of the headline's cpu_baseline leg")
+    p.add_argument("--cpu-leg-seconds", type=float, default=0.6, help="CPU time of each extra entry's CPU leg (per direction)")
+    p.add_argument("--no-sweep", action="store_true")
     p.add_argument("--section", default="all", choices=["all", "zstd", "xxhash", "lz4frame"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-variant", type=int, default=-1, help="zstd decoder: 1 = five-stage pipeline (default), 0 = one-kernel decoder")
     return p.parse_args()
@@ -70,14 +72,60 @@ def gen_fragments(torch, dev, n_blocks, block_size, ratio, seed):
     return data
 
 
+_corpus_blocks = {}
+
+
+def corpus_blocks(block_size):
+    """SURVEY 8d, C2 primary / C4: every FULL block_size slice (last partial slice dropped) of the calgary, canterbury, large and
+    top-level files of the reference's test corpus in T/benchmark/DataSet.java:28-89 order -- 191 distinct 64 KiB blocks, 86 of 128 KiB
+    (tests/golden/corpus_full.bin.xz: the corpus travels as a fixture; /root/reference does not exist on the GPU box)."""
+    if block_size not in _corpus_blocks:
+        import lzma
+        gold = os.path.join(ROOT, "tests", "golden")
+        blob = lzma.decompress(open(os.path.join(gold, "corpus_full.bin.xz"), "rb").read())
+        out = []
+        for e in json.load(open(os.path.join(gold, "corpus_full.json"))):
+            if e["file"].startswith("artificial/"):
+                continue
+            for off in range(0, e["length"] - block_size + 1, block_size):
+                out.append(blob[e["offset"] + off:e["offset"] + off + block_size])
+        _corpus_blocks[block_size] = np.frombuffer(b"".join(out), dtype=np.uint8)
+    return _corpus_blocks[block_size]
+
+
 def gen_corpus(torch, dev, n_blocks, block_size):
-    """Real data: the 19 x 64 KiB slices of the reference's calgary / canterbury / top-level test files committed under
-    tests/golden/ (corpus_sample.json lists them), tiled cyclically; every copy sits at its own address (SURVEY 8d, C2 primary)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "corpus_sample.bin")
-    sample = torch.from_numpy(np.fromfile(path, dtype=np.uint8)).to(dev)
-    unit = (sample.numel() // block_size) * block_size
+    """Real data: the corpus blocks above tiled cyclically; every copy sits at its own address (distinct HBM traffic)."""
+    sample = torch.from_numpy(corpus_blocks(block_size).copy()).to(dev)
+    unit = sample.numel()
     total = n_blocks * block_size
-    return sample[:unit].repeat((total + unit - 1) // unit)[:total].contiguous()
+    return sample.repeat((total + unit - 1) // unit)[:total].contiguous()
+
+
+def java_random_generator(ratio, length=1048576):
+    """T/snappy/RandomGenerator.java:25-74 restated: java.util.Random(301) (48-bit LCG), 100-byte fragments made of max(1, int(100 *
+    ratio)) random bytes repeated.  nextInt(256) is bits 47..40 of the seed; the LCG is jumped ahead in closed form (numpy, wrapping
+    uint64 arithmetic is exact modulo 2^48).  Checked against the oracle's generator in tests/test_host_logic.py."""
+    raw = max(1, int(100 * ratio))
+    n_frag = (length + 99) // 100
+    n_calls = n_frag * raw
+    A = np.uint64(0x5DEECE66D)
+    C = np.uint64(0xB)
+    mask = np.uint64((1 << 48) - 1)
+    with np.errstate(over="ignore"):
+        a = np.multiply.accumulate(np.full(n_calls, A, dtype=np.uint64))             # A^k, k = 1..n
+        geo = np.cumsum(np.concatenate([np.ones(1, dtype=np.uint64), a[:-1]]))      # 1 + A + ... + A^(k-1)
+        s0 = np.uint64((301 ^ 0x5DEECE66D) & ((1 << 48) - 1))
+        seeds = (a * s0 + C * geo) & mask
+    rnd = ((seeds >> np.uint64(40)) & np.uint64(0xFF)).astype(np.uint8).reshape(n_frag, raw)
+    reps = (100 + raw - 1) // raw
+    return np.tile(rnd, (1, reps))[:, :100].reshape(-1)[:length].copy()
+
+
+def gen_random301(torch, dev, n_blocks, block_size, ratio):
+    """SURVEY 8d C2 secondary: block k = generator bytes [(k * block_size) mod 1 MiB, + block_size) -- 16 distinct 64 KiB blocks."""
+    data = torch.from_numpy(java_random_generator(ratio)).to(dev)
+    total = n_blocks * block_size
+    return data.repeat((total + data.numel() - 1) // data.numel())[:total].contiguous()
 
 
 def gen_data(torch, dev, kind, n_blocks, block_size, ratio, seed):
@@ -120,9 +168,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
+        # control plane only (barrier + MAX of the elapsed time, on CPU tensors): gloo -- the data path has no collective and needs no
+        # RCCL (north_star: "per-GPU batch split, no RCCL needed")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend="gloo")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -246,7 +296,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = [codec.elapsed_ms(a, b) for a, b in ev]
@@ -308,13 +359,27 @@ def main():
             pass
 
     if rank == 0 and world == 1 and not args.no_extra:
-        result["extra"] = extras(torch, A, codec, dev, args)
-        result["extra"].update(xxhash_extra(torch, A, codec, dev, args))
-        result["extra"].update(lz4frame_extra(torch, A, codec, dev, args))
+        # release the headline's buffers first: the extras allocate batches of the same size
+        del src, dst
+        torch.cuda.empty_cache()
+        ex = extras(torch, A, codec, dev, args)
+        ex.update(xxhash_extra(torch, A, codec, dev, args))
+        ex.update(lz4frame_extra(torch, A, codec, dev, args))
         try:
-            result["extra"].update(zstd_extra(torch, A, codec, dev, args))
+            ex.update(zstd_extra(torch, A, codec, dev, args))
         except ImportError:
             pass
+        result["extra"] = ex
+        # the real-data and Zstd numbers next to `value` (same unit; the headline stays BASELINE configs[1] on synthetic blocks)
+        result["value_corpus"] = ex["lz4_corpus"]["decompress_GiBps"]            # LZ4 decompress, corpus-tiled 64 KiB blocks (SURVEY 8d C2 primary)
+        result["value_corpus_hbm_frac"] = ex["lz4_corpus"]["decompress_hbm_frac"]
+        result["value_snappy"] = ex["snappy_fragments"]["decompress_GiBps"]
+        result["value_snappy_corpus"] = ex["snappy_corpus"]["decompress_GiBps"]
+        if "zstd_fragments" in ex:
+            result["value_zstd"] = ex["zstd_fragments"]["decompress_GiBps"]      # Zstd level-3 128 KiB frames (BASELINE configs[3]), synthetic
+            result["value_zstd_corpus"] = ex["zstd_corpus"]["decompress_GiBps"]  # the same on corpus-tiled data
+        if not args.no_sweep:
+            result["sweep_random301"] = sweep_random301(torch, A, codec, dev, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(torch, pool_pack, pool_pack_off, pool_clen, pool_plain, bs, op, wl, args.cpu_seconds)
     if rank == 0:
@@ -340,56 +405,78 @@ def kernel_symbol(wl, decoder):
     return "achip::lz4_compress_batch_kernel<unsigned short>" if wl == "lz4_compress" else "achip::snappy_compress_tiers_kernel"
 
 
-def extras(torch, A, codec, dev, args):
-    """Secondary numbers in the same run (smaller batches, same measurement): other codecs/directions and text-like data."""
-    out = {}
+def run_pair(torch, codec, args, name, cop, dop, plain, n, bs, cpu_seconds):
+    """One (codec, data) entry: GPU compress of `plain` (n blocks of bs bytes), GPU decompress of the result, verified; CPU legs beside it."""
     lib = codec.lib
+    dev = plain.device
+    max_c = getattr(lib, "achip_%s_max_compressed_length" % name)(bs)
+    cstride = (max_c + 15) // 16 * 16
+    i64 = dict(dtype=torch.int64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    p_off = torch.arange(n, **i64) * bs
+    p_len = torch.full((n,), bs, **i32)
+    c_off = torch.arange(n, **i64) * cstride
+    c_cap = torch.full((n,), max_c, **i32)
+    comp = torch.empty(n * cstride + 64, dtype=torch.uint8, device=dev)
+    clen = torch.zeros(n, **i32)
+    st = torch.zeros(n, **i32)
+    eo = torch.zeros(n, **i64)
+    back = torch.empty(n * bs + 64, dtype=torch.uint8, device=dev)
+    blen = torch.zeros(n, **i32)
+    torch.cuda.synchronize()
+
+    def timed(fn, iters=3):
+        fn()
+        codec.synchronize()
+        e0, e1 = codec.event(), codec.event()
+        codec.record(e0)
+        for _ in range(iters):
+            fn()
+        codec.record(e1)
+        return codec.elapsed_ms(e0, e1) / iters * 1e-3
+
+    tc = timed(lambda: codec.launch(cop, plain, p_off, p_len, comp, c_off, c_cap, clen, st, eo, n), iters=2)
+    assert int((st != 0).sum()) == 0
+    cbytes = int(clen.to(torch.int64).sum())
+    td = timed(lambda: codec.launch(dop, comp, c_off, clen, back, p_off, p_len, blen, st, eo, n))
+    choice = codec.native.get_stat("decompress.choice")  # -1: no probe ran (fixed variant / small batch)
+    assert int((st != 0).sum()) == 0 and bool((back[:n * bs] == plain).all())
+    entry = {
+        "ratio": round(n * bs / cbytes, 3),
+        "compress_GiBps": round(n * bs / tc / 2**30, 2), "compress_hbm_frac": round((n * bs + cbytes) / tc / 1e9 / HBM_PEAK_GBS, 4),
+        "decompress_GiBps": round(n * bs / td / 2**30, 2), "decompress_hbm_frac": round((n * bs + cbytes) / td / 1e9 / HBM_PEAK_GBS, 4),
+        "blocks": n,
+        "decoder": DECODER_NAMES.get(choice, "rings"),
+    }
+    if cpu_seconds > 0 and not args.no_cpu_baseline:
+        entry.update(cpu_pair(torch, dop, cop, plain, comp, c_off, clen, min(n, 4096), bs, max_c, cpu_seconds))
+    return entry
+
+
+def extras(torch, A, codec, dev, args):
+    """Secondary numbers in the same run (same measurement): the other codec / direction, text-like and corpus-tiled data -- each with the
+    CPU rate of the same blocks beside it."""
+    out = {}
     bs = args.block_size
     for data_kind in ("fragments", "wordmix", "corpus"):
         n = 65536 if data_kind == "fragments" else args.blocks  # text-like and corpus-tiled (the primary data of BASELINE configs[1]) at its size
         plain = gen_data(torch, dev, data_kind, n, bs, args.ratio, 977)
         for name, cop, dop in (("lz4", A.OP_LZ4_COMPRESS, A.OP_LZ4_DECOMPRESS), ("snappy", A.OP_SNAPPY_COMPRESS, A.OP_SNAPPY_DECOMPRESS)):
-            max_c = getattr(lib, "achip_%s_max_compressed_length" % name)(bs)
-            cstride = (max_c + 15) // 16 * 16
-            i64 = dict(dtype=torch.int64, device=dev)
-            i32 = dict(dtype=torch.int32, device=dev)
-            p_off = torch.arange(n, **i64) * bs
-            p_len = torch.full((n,), bs, **i32)
-            c_off = torch.arange(n, **i64) * cstride
-            c_cap = torch.full((n,), max_c, **i32)
-            comp = torch.empty(n * cstride + 64, dtype=torch.uint8, device=dev)
-            clen = torch.zeros(n, **i32)
-            st = torch.zeros(n, **i32)
-            eo = torch.zeros(n, **i64)
-            back = torch.empty(n * bs + 64, dtype=torch.uint8, device=dev)
-            blen = torch.zeros(n, **i32)
-            torch.cuda.synchronize()
+            out["%s_%s" % (name, data_kind)] = run_pair(torch, codec, args, name, cop, dop, plain, n, bs, args.cpu_leg_seconds)
+        del plain
+    return out
 
-            def timed(fn, iters=3):
-                fn()
-                codec.synchronize()
-                e0, e1 = codec.event(), codec.event()
-                codec.record(e0)
-                for _ in range(iters):
-                    fn()
-                codec.record(e1)
-                return codec.elapsed_ms(e0, e1) / iters * 1e-3
 
-            tc = timed(lambda: codec.launch(cop, plain, p_off, p_len, comp, c_off, c_cap, clen, st, eo, n), iters=2)
-            assert int((st != 0).sum()) == 0
-            cbytes = int(clen.to(torch.int64).sum())
-            td = timed(lambda: codec.launch(dop, comp, c_off, clen, back, p_off, p_len, blen, st, eo, n))
-            choice = codec.native.get_stat("decompress.choice")  # -1: no probe ran (fixed variant / small batch)
-            assert int((st != 0).sum()) == 0 and bool((back[:n * bs] == plain).all())
-            key = "%s_%s" % (name, data_kind)
-            out[key] = {
-                "ratio": round(n * bs / cbytes, 3),
-                "compress_GiBps": round(n * bs / tc / 2**30, 2), "compress_hbm_frac": round((n * bs + cbytes) / tc / 1e9 / HBM_PEAK_GBS, 4),
-                "decompress_GiBps": round(n * bs / td / 2**30, 2), "decompress_hbm_frac": round((n * bs + cbytes) / td / 1e9 / HBM_PEAK_GBS, 4),
-                "blocks": n,
-                "decoder": DECODER_NAMES.get(choice, "rings"),
-            }
-            del comp, back
+def sweep_random301(torch, A, codec, dev, args):
+    """SURVEY 8d C2 secondary: the reference's own synthetic generator (java.util.Random(301), T/snappy/RandomGenerator.java:25-74) at
+    compressibility 0.1 / 0.25 / 0.5 / 0.75 / 1.0; 65536 blocks (the generator's 1 MiB = 16 distinct 64 KiB blocks, tiled)."""
+    out = {}
+    bs, n = args.block_size, 65536
+    for ratio in (0.1, 0.25, 0.5, 0.75, 1.0):
+        plain = gen_random301(torch, dev, n, bs, ratio)
+        for name, cop, dop in (("lz4", A.OP_LZ4_COMPRESS, A.OP_LZ4_DECOMPRESS), ("snappy", A.OP_SNAPPY_COMPRESS, A.OP_SNAPPY_DECOMPRESS)):
+            out["%s_ratio_%s" % (name, ratio)] = run_pair(torch, codec, args, name, cop, dop, plain, n, bs, 0.0)
+        del plain
     return out
 
 
@@ -571,64 +658,98 @@ def zstd_extra(torch, A, codec, dev, args):
                       "java_frames_fallback_items": codec.native.get_stat("zstd.decompress.fallback_items")})
         entry.update({"gpu_encoder_ratio": round(nz * fs / zbytes, 3), "compress_GiBps": round(nz * fs / tz / 2**30, 2),
                       "compress_hbm_frac": round((nz * fs + zbytes) / tz / 1e9 / HBM_PEAK_GBS, 5), "compress_frames": nz})
+        if not args.no_cpu_baseline and args.cpu_leg_seconds > 0:
+            # CPU legs: the oracle's Zstd decoder over the same libzstd frames (pool x 8 per pass) and its level-3 encoder over the same plaintext
+            T = host_threads()
+            d, _ = cpu_rate(A.OP_ZSTD_DECOMPRESS, pack, np.tile(offs, 8), np.tile(lens.astype(np.int32), 8), fs, T, args.cpu_leg_seconds)
+            c, _ = cpu_rate(A.OP_ZSTD_COMPRESS, host, np.tile(np.arange(pool_n, dtype=np.int64) * fs, 8), np.full(pool_n * 8, fs, dtype=np.int32), int(max_c), T, args.cpu_leg_seconds)
+            entry.update({"cpu_decompress_GiBps": round(d, 2), "cpu_compress_GiBps": round(c, 2), "cpu_threads": T, "cpu_sample_blocks": pool_n * 8})
         out["zstd_%s" % data_kind] = entry
         del z_dst, back, zplain
     return out
 
 
+_oracle = None
+
+
+def oracle_bench_lib():
+    """oracle/liboracle.so (the C restatement of the Java codecs; no JVM on the box) -- ONLY the cpu_baseline legs come here."""
+    global _oracle
+    if _oracle is None:
+        from tests import oracle_lib
+        lib = oracle_lib.load().lib
+        lib.orc_bench.restype = ctypes.c_double
+        lib.orc_bench.argtypes = [ctypes.c_int32] + [ctypes.c_void_p] * 6 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_double,
+                                                                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
+        _oracle = lib
+    return _oracle
+
+
+def cpu_rate(op, src, src_off, src_len, cap, threads, seconds):
+    """GiB/s of plaintext for `op` over the given host blocks: T pthreads inside the oracle library, each on its own contiguous range of
+    blocks with its own output ranges, passes repeated for `seconds` (oracle/misc.c orc_bench -- no Python in the timed loop)."""
+    lib = oracle_bench_lib()
+    n = len(src_off)
+    stride = (cap + 63) // 64 * 64
+    dst = np.empty(n * stride + 64, dtype=np.uint8)
+    dst_off = np.arange(n, dtype=np.int64) * stride
+    dst_cap = np.full(n, cap, dtype=np.int32)
+    src = np.ascontiguousarray(src)
+    src_off = np.ascontiguousarray(src_off, dtype=np.int64)
+    src_len = np.ascontiguousarray(src_len, dtype=np.int32)
+    passes, failures = ctypes.c_double(), ctypes.c_int64()
+    rate = lib.orc_bench(op, src.ctypes.data, src_off.ctypes.data, src_len.ctypes.data, dst.ctypes.data, dst_off.ctypes.data, dst_cap.ctypes.data,
+                         n, threads, seconds, ctypes.byref(passes), ctypes.byref(failures))
+    assert failures.value == 0, "the CPU baseline failed on %d blocks" % failures.value
+    return rate / 2**30, passes.value
+
+
+def host_threads():
+    return max(1, min(os.cpu_count() or 1, 1024))
+
+
+def cpu_pair(torch, dop, cop, plain, comp, c_off, clen, n_sample, bs, max_c, seconds):
+    """CPU rates of one extra entry: the first n_sample blocks of the same batch, decompress and compress, all host threads."""
+    if seconds <= 0:
+        return {}
+    T = host_threads()
+    k = int(n_sample)
+    h_plain = plain[:k * bs].cpu().numpy()
+    offs = c_off[:k].cpu().numpy().astype(np.int64)
+    lens = clen[:k].cpu().numpy().astype(np.int32)
+    end = int(offs[-1]) + int(lens[-1])
+    h_comp = comp[:end].cpu().numpy()
+    d, _ = cpu_rate(dop, h_comp, offs, lens, bs, T, seconds)
+    c, _ = cpu_rate(cop, h_plain, np.arange(k, dtype=np.int64) * bs, np.full(k, bs, dtype=np.int32), max_c, T, seconds)
+    return {"cpu_decompress_GiBps": round(d, 2), "cpu_compress_GiBps": round(c, 2), "cpu_threads": T, "cpu_sample_blocks": k}
+
+
 def cpu_baseline(torch, pool_pack, pool_pack_off, pool_clen, pool_plain, bs, op, wl, seconds):
-    """The oracle (C restatement of the Java codec -- no JVM on this box) on the host cores, same blocks, bounded sample."""
-    from concurrent.futures import ThreadPoolExecutor
-    from tests import oracle_lib
-    o = oracle_lib.load()
+    """The headline's CPU leg: the oracle (C restatement of the Java codec -- no JVM on this box) on the GPU box's host cores over the
+    SAME blocks: the pool's distinct blocks repeated to >= 1 GiB of plaintext per pass, one codec state per thread."""
     n = int(pool_clen.numel())
-    sample = min(n, 2048)
-    threads = max(1, min(os.cpu_count() or 1, 64))
+    reps = max(1, (16384 + n - 1) // n)
+    T = host_threads()
+    codec = "lz4" if wl.startswith("lz4") else "snappy"
     if wl.endswith("decompress"):
-        end = int(pool_pack_off[sample - 1].item()) + int(pool_clen[sample - 1].item())
-        src = pool_pack[:end].cpu().numpy()
-        src_off = pool_pack_off[:sample].cpu().numpy().astype(np.int64)
-        src_len = pool_clen[:sample].cpu().numpy().astype(np.int32)
+        src = pool_pack.cpu().numpy()
+        src_off = np.tile(pool_pack_off.cpu().numpy().astype(np.int64), reps)
+        src_len = np.tile(pool_clen.cpu().numpy().astype(np.int32), reps)
         cap = bs
     else:
-        src = pool_plain[:sample * bs].cpu().numpy()
-        src_off = (np.arange(sample, dtype=np.int64) * bs)
-        src_len = np.full(sample, bs, dtype=np.int32)
-        cap = int(o.max_compressed_length("lz4" if wl.startswith("lz4") else "snappy", bs))
-    dst_off = np.arange(sample, dtype=np.int64) * ((cap + 15) // 16 * 16)
-    dst_cap = np.full(sample, cap, dtype=np.int32)
-    dst = np.zeros(int(dst_off[-1]) + cap + 64, dtype=np.uint8)
-    per = (sample + threads - 1) // threads
-    slices = [(i, min(sample, i + per)) for i in range(0, sample, per)]
-
-    def work(sl):
-        a, b = sl
-        return o.batch(op, src, src_off[a:b], src_len[a:b], dst, dst_off[a:b], dst_cap[a:b])[3]
-
-    def one_pass(pool):
-        return sum(pool.map(work, slices)) if pool else work((0, sample))
-
-    # single thread
-    t0 = time.perf_counter()
-    passes1 = 0
-    while time.perf_counter() - t0 < seconds * 0.35 or passes1 == 0:
-        one_pass(None)
-        passes1 += 1
-    t1 = (time.perf_counter() - t0) / passes1
-    with ThreadPoolExecutor(threads) as pool:
-        one_pass(pool)  # warm
-        t0 = time.perf_counter()
-        passes = 0
-        while time.perf_counter() - t0 < seconds * 0.65 or passes == 0:
-            one_pass(pool)
-            passes += 1
-        tN = (time.perf_counter() - t0) / passes
-    plain = sample * bs
+        src = pool_plain.cpu().numpy()
+        src_off = np.tile(np.arange(n, dtype=np.int64) * bs, reps)
+        src_len = np.full(n * reps, bs, dtype=np.int32)
+        from tests import oracle_lib
+        cap = int(oracle_lib.load().max_compressed_length(codec, bs))
+    r1, p1 = cpu_rate(op, src, src_off[:max(64, n // 16)], src_len[:max(64, n // 16)], cap, 1, seconds * 0.3)
+    rN, pN = cpu_rate(op, src, src_off, src_len, cap, T, seconds * 0.7)
     return {
-        "value": round(plain / tN / 2**30, 3), "unit": "GiB/s", "cores": threads, "kind": "port",
-        "value_1_thread": round(plain / t1 / 2**30, 3),
-        "sample": "%d of the same %d-byte blocks (%s), oracle/liboracle.so = C restatement of the Java codec (no JVM on the box); %d passes x %d threads, %d passes x 1 thread" % (
-            sample, bs, wl, passes, threads, passes1),
+        "value": round(rN, 3), "unit": "GiB/s", "cores": T, "kind": "port",
+        "value_1_thread": round(r1, 3),
+        "sample": "%d blocks of %d bytes per pass (the same %d distinct %s blocks, %s), %.1f passes per thread on %d pthreads for %.1f s; oracle/liboracle.so = "
+                  "C restatement of the Java codec (no JVM on the box), one codec state per thread, disjoint block ranges" % (
+                      n * reps, bs, n, codec.upper(), wl, pN, T, seconds * 0.7),
     }
 
 

@@ -71,3 +71,94 @@ int64_t orc_batch(int32_t op, const uint8_t* src_base, const int64_t* src_off, c
     }
     return total;
 }
+
+/* ---- multi-threaded timing driver for bench.py's cpu_baseline leg ---------------------------------------------
+ * The reference scales on a CPU the only way it can: one codec instance per thread, threads on disjoint block
+ * ranges (SURVEY 2.3 / 8d "CPU baseline beside it").  T pthreads, thread t owns blocks [t*n/T, (t+1)*n/T) and
+ * its own output ranges, and repeats passes over its range until `seconds` have elapsed (no Python in the loop:
+ * round 1's ThreadPoolExecutor version measured dispatch overhead).  Returns plaintext bytes per second summed
+ * over the threads (decompress: bytes produced; compress: bytes consumed), *passes = mean passes per thread. */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+    int32_t op;
+    const uint8_t* src_base;
+    const int64_t* src_off;
+    const int32_t* src_len;
+    uint8_t* dst_base;
+    const int64_t* dst_off;
+    const int32_t* dst_cap;
+    int32_t first, last;
+    double seconds;
+    pthread_barrier_t* start;
+    int64_t plain_bytes;
+    int64_t passes;
+    int64_t failures;
+    double elapsed;
+} orc_bench_task;
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void* orc_bench_thread(void* arg)
+{
+    orc_bench_task* t = (orc_bench_task*)arg;
+    const int compress = t->op & 1;
+    pthread_barrier_wait(t->start);
+    const double t0 = now_s();
+    double t1 = t0;
+    do {
+        for (int32_t i = t->first; i < t->last; i++) {
+            int32_t ol = 0, st = 0;
+            int64_t eo = 0;
+            orc_batch(t->op, t->src_base, t->src_off + i, t->src_len + i, t->dst_base, t->dst_off + i, t->dst_cap + i, &ol, &st, &eo, 1);
+            if (st != 0) t->failures++;
+            t->plain_bytes += compress ? t->src_len[i] : ol;
+        }
+        t->passes++;
+        t1 = now_s();
+    } while (t1 - t0 < t->seconds && t->last > t->first);
+    t->elapsed = t1 - t0;
+    orc_zstd_enc_thread_free();
+    orc_zstd_dec_thread_free();
+    return 0;
+}
+
+double orc_bench(int32_t op, const uint8_t* src_base, const int64_t* src_off, const int32_t* src_len, uint8_t* dst_base, const int64_t* dst_off,
+                 const int32_t* dst_cap, int32_t n_blocks, int32_t threads, double seconds, double* passes, int64_t* failures)
+{
+    if (n_blocks > 0 && (op == ACHIP_OP_ZSTD_COMPRESS)) {  /* one-time table setup on the calling thread (not inside the timed threads) */
+        static uint8_t warm_in[64], warm_out[256];
+        (void)orc_zstd_compress(warm_in, sizeof(warm_in), warm_out, sizeof(warm_out));
+    }
+    if (threads < 1) threads = 1;
+    if (threads > n_blocks) threads = n_blocks > 0 ? n_blocks : 1;
+    pthread_t tid[1024];
+    static orc_bench_task task[1024];
+    if (threads > 1024) threads = 1024;
+    pthread_barrier_t start;
+    pthread_barrier_init(&start, 0, (unsigned)threads);
+    for (int32_t t = 0; t < threads; t++) {
+        orc_bench_task k = {op, src_base, src_off, src_len, dst_base, dst_off, dst_cap, (int32_t)((int64_t)n_blocks * t / threads),
+                            (int32_t)((int64_t)n_blocks * (t + 1) / threads), seconds, &start, 0, 0, 0, 0.0};
+        task[t] = k;
+        pthread_create(&tid[t], 0, orc_bench_thread, &task[t]);
+    }
+    double rate = 0.0, p = 0.0;
+    int64_t f = 0;
+    for (int32_t t = 0; t < threads; t++) {
+        pthread_join(tid[t], 0);
+        if (task[t].elapsed > 0) rate += (double)task[t].plain_bytes / task[t].elapsed;
+        p += (double)task[t].passes;
+        f += task[t].failures;
+    }
+    pthread_barrier_destroy(&start);
+    if (passes) *passes = p / threads;
+    if (failures) *failures = f;
+    return rate;
+}

@@ -66,6 +66,11 @@ uint32_t orc_xxh32(const uint8_t* in, int64_t len, uint32_t seed);
 void orc_random_generator(double compression_ratio, uint8_t* out, int64_t len);
 
 /* batch drivers used by bench.py's cpu_baseline leg (plain loops, one thread) */
+void orc_zstd_enc_thread_free(void);
+void orc_zstd_dec_thread_free(void);
+/* cpu_baseline timing driver (misc.c): T pthreads on disjoint block ranges; returns plaintext bytes / second */
+double orc_bench(int32_t op, const uint8_t* src_base, const int64_t* src_off, const int32_t* src_len, uint8_t* dst_base, const int64_t* dst_off,
+                 const int32_t* dst_cap, int32_t n_blocks, int32_t threads, double seconds, double* passes, int64_t* failures);
 int64_t orc_batch(int32_t op, const uint8_t* src_base, const int64_t* src_off, const int32_t* src_len,
                   uint8_t* dst_base, const int64_t* dst_off, const int32_t* dst_cap,
                   int32_t* out_len, int32_t* status, int64_t* err_off, int32_t n_blocks);

@@ -1132,3 +1132,10 @@ int64_t orc_zstd_max_compressed_length(int64_t n)
     }
     return result;
 }
+
+/* frees the calling thread's decoder context (the timing driver's threads are short-lived) */
+void orc_zstd_dec_thread_free(void)
+{
+    free(g_ctx);
+    g_ctx = 0;
+}

@@ -1683,3 +1683,22 @@ int64_t orc_zstd_compress(const uint8_t* in, int64_t in_len, uint8_t* out, int64
     }
     return r;
 }
+
+/* frees the calling thread's encoder context (the timing driver's threads are short-lived) */
+void orc_zstd_enc_thread_free(void)
+{
+    if (g_cctx) {
+        cctx* c = g_cctx;
+        free(c->hashTable);
+        free(c->chainTable);
+        free(c->ss.literalsBuffer);
+        free(c->ss.offsets);
+        free(c->ss.literalLengths);
+        free(c->ss.matchLengths);
+        free(c->ss.literalLengthCodes);
+        free(c->ss.matchLengthCodes);
+        free(c->ss.offsetCodes);
+        free(c);
+        g_cctx = 0;
+    }
+}

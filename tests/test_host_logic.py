@@ -60,3 +60,17 @@ def test_lane_private_decoder_kernels_on_the_cpu():
     out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_v3.py"), "--quick"], check=True, capture_output=True, text=True, cwd=ROOT).stdout
     lines = [l for l in out.splitlines() if "mismatches" in l]
     assert lines and all(l.endswith(" 0 mismatches") for l in lines), out
+
+
+def test_bench_java_random_generator_equals_the_oracles(oracle):
+    """bench.py restates java.util.Random(301) + RandomGenerator in numpy (jump-ahead LCG) for its ratio sweep; the oracle's generator
+    (oracle/misc.c, following T/snappy/RandomGenerator.java:25-74) is the checker."""
+    import bench
+    for ratio in (0.1, 0.25, 0.5, 0.75, 1.0, 0.001):
+        assert (bench.java_random_generator(ratio) == oracle.random_generator(ratio)[:1048576]).all(), ratio
+
+
+def test_bench_corpus_blocks_match_the_survey_counts():
+    import bench
+    assert bench.corpus_blocks(65536).size == 191 * 65536   # SURVEY 8d C2: calgary 40 + canterbury 38 + large 97 + top-level 16
+    assert bench.corpus_blocks(131072).size == 86 * 131072  # SURVEY 8d C4
