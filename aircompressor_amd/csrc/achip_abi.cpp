@@ -22,6 +22,8 @@ namespace achip {
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
+hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass);
+int64_t lz4_twopass_scratch_bytes(int32_t nBlocks);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
 hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
@@ -140,6 +142,7 @@ achip::BatchArgs make_args(const void* srcBase, const int64_t* srcOff, const int
     a.nBlocks = nBlocks;
     a.ringPad = 0;
     a.nBlocksDev = nullptr;
+    a.only = nullptr;
     return a;
 }
 
@@ -223,6 +226,12 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 if (e == hipSuccess) e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, mixedGroups);
                 if (e == hipSuccess) e = achip::launch_lz4_decompress_lanecopy(a, ctx->stream, mixedGroups);
                 if (e == hipSuccess) e = achip::launch_lz4_decompress_lanewindow(a, ctx->stream, mixedGroups);
+                break;
+            }
+            if (ctx->lz4dVariant == 7) {  // two passes: parse to records, a wavefront per block executes them (lz4_decompress_v7.hip)
+                int32_t r = ensure_scratch(ctx, achip::lz4_twopass_scratch_bytes(a.nBlocks));
+                if (r < 0) return r;
+                e = achip::launch_lz4_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->lz4dGroup, ctx->ringClass);
                 break;
             }
             e = ctx->lz4dVariant == 4 ? achip::launch_lz4_decompress_lanecopy(a, ctx->stream, nullptr)
@@ -598,7 +607,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->snappydGroup = (int)value;
     }
     else if (k == "lz4.decompress.variant") {
-        if (value != 1 && value != 4 && value != 5 && value != 6) return bad_argument("lz4.decompress.variant: 1 rings, 4 / 6 a lane per block, 5 auto");
+        if (value != 1 && value != 4 && value != 5 && value != 6 && value != 7) return bad_argument("lz4.decompress.variant: 1 rings, 4 / 6 a lane per block, 7 two passes, 5 auto");
         ctx->lz4dVariant = (int)value;
     }
     else if (k == "lz4.decompress.auto_min_blocks") ctx->lz4dAutoMinBlocks = (int)value;

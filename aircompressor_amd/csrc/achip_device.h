@@ -29,6 +29,8 @@ struct BatchArgs {
     int32_t ringPad;  // LDS padding between the ring pairs of consecutive blocks (decoders)
     const int32_t* nBlocksDev;  // when set: the number of blocks is this device word (<= nBlocks, which then sizes the launch): a
                                 // batch assembled on the device (the chunk list of the framed readers)
+    const int32_t* only;        // when set (ring decoders): decode block i only if only[i] != 0 -- the blocks the two-pass decoders
+                                // hand over (lz4_decompress_v7.hip)
 };
 
 __device__ __forceinline__ int32_t batch_count(const BatchArgs& a) { return a.nBlocksDev != nullptr ? *a.nBlocksDev : a.nBlocks; }
@@ -114,6 +116,20 @@ __device__ __forceinline__ uint32_t alignbyte_u32(uint32_t hi, uint32_t lo, uint
 // memory instructions to the CU's L1/TA in program order, so keeping the compiler from
 // reordering across this point is sufficient inside one wave.
 __device__ __forceinline__ void wave_mem_order() { asm volatile("" ::: "memory"); }
+
+// The same ordering point for kernels whose lanes COOPERATE on one block: everything the lanes of this wave stored before it (LDS or
+// global) is visible to every lane after it.  On the device a compiler barrier is all it takes (a wavefront's memory operations are
+// performed in program order; wavefront-scope fences are no-ops on gfx950).  Must be called in wave-uniform control flow: tools/hostemu
+// runs the lanes as fibers and makes this a rendezvous, which is how the cooperative kernels are tested on a CPU.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+#else
+#define wave_sync() hostemu::wave_sync(__FILE__, __LINE__)
+#endif
 
 // ---- group copy: n bytes, src and dst ranges do not overlap (or src+n <= dst) ----
 // Lane g of a GS-lane group moves bytes [16g,16g+16) of every GS*16-byte step; the

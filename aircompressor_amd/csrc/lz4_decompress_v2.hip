@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a, 
     const int g = threadIdx.x & (GS - 1);
     const int grp = threadIdx.x / GS;
     const int64_t block = (int64_t)blockIdx.x * GROUPS_PER_WG + grp;
-    if (block >= a.nBlocks) {
+    if (block >= a.nBlocks || (a.only != nullptr && a.only[block] == 0)) {
         return;
     }
     const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];

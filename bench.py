@@ -190,8 +190,7 @@ def main():
         codec.native.set_option("lz4.decompress.group", args.group)
         codec.native.set_option("snappy.decompress.group", args.group)
     if args.variant >= 0:
-        codec.native.set_option("lz4.decompress.variant", args.variant)
-        codec.native.set_option("snappy.decompress.variant", args.variant)
+        codec.native.set_option("%s.decompress.variant" % ("lz4" if args.workload.startswith("lz4") else "snappy"), args.variant)
     if args.ring_class >= 0:
         codec.native.set_option("decompress.ring_class", args.ring_class)
     if args.compress_variant >= 0:
@@ -389,7 +388,7 @@ def main():
         dist.destroy_process_group()
 
 
-DECODER_NAMES = {0: "rings", 1: "lane-per-block", 2: "lane-per-block with LDS window"}
+DECODER_NAMES = {0: "rings", 1: "lane-per-block", 2: "lane-per-block with LDS window", 3: "two-pass (parse to records, a wavefront per block executes)"}
 
 
 def kernel_symbol(wl, decoder):

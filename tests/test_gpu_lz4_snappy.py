@@ -78,7 +78,7 @@ def test_decompress_matches_plaintext_all_decoder_configs(gb, o, codec, cfg):
     configure(gb, codec, DECODERS[0])
 
 
-@pytest.mark.parametrize("cfg", [(4, 4, 0), (6, 4, 0)], ids=lambda c: "variant%d-gs%d-rc%d" % c)
+@pytest.mark.parametrize("cfg", [(4, 4, 0), (6, 4, 0), (7, 4, 0)], ids=lambda c: "variant%d-gs%d-rc%d" % c)
 def test_lz4_lane_per_block_decoders(gb, o, cfg):
     """variant 4 (lz4_decompress_v5.hip, a lane per block with wavefront-wide copy steps) and variant 6 (lz4_decompress_v6.hip, a lane per
     block with an LDS output window): plaintext, status and error offsets equal the oracle's"""
@@ -185,10 +185,12 @@ def _oracle_status(o, codec, data, cap):
 
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
-@pytest.mark.parametrize("cfg", [(1, 16, 0), (1, 4, 0), (1, 2, 1), (1, 1, 0), (1, 8, 1), (1, 64, 0), (4, 4, 0), (6, 4, 0)])
+@pytest.mark.parametrize("cfg", [(1, 16, 0), (1, 4, 0), (1, 2, 1), (1, 1, 0), (1, 8, 1), (1, 64, 0), (4, 4, 0), (6, 4, 0), (7, 4, 0)])
 def test_malformed_inputs_report_the_reference_errors(gb, o, codec, cfg):
     """Error KATs of the reference plus systematic corruption: status class/detail and offset must equal the oracle's
     (= what the Java decoder throws), and nothing is written outside the block's output."""
+    if cfg[0] == 7 and codec == "snappy":
+        pytest.skip("the two-pass decoder is LZ4 only")
     configure(gb, codec, cfg)
     rng = np.random.default_rng(99)
     cases = []

@@ -1,15 +1,24 @@
 // tools/hostemu/emu.cpp -- runs the lane-private decoder kernels on the CPU (sequential lanes are exact when a kernel
 // uses no cross-lane operation: the GS=1 instantiations of the ring decoders and the lane-per-block decoders with an LDS window).
 #include "hip/hip_runtime.h"
-thread_local dim3 threadIdx, blockIdx, blockDim;
+thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 #include "../../aircompressor_amd/csrc/lz4_decompress_v2.hip"
 #include "../../aircompressor_amd/csrc/snappy_decompress_v2.hip"
 #include "../../aircompressor_amd/csrc/lz4_decompress_v6.hip"
 #include "../../aircompressor_amd/csrc/snappy_decompress_v4.hip"
+#include "../../aircompressor_amd/csrc/lz4_decompress_v7.hip"
+#include <vector>
 extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, const int32_t* srcLen, uint8_t* dstBase, const int64_t* dstOff,
                          const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n)
 {
     achip::BatchArgs a{srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, n, 0};
+    if (op == 20 || op == 21) {  // two-pass LZ4: lane-per-block parse + wavefront-per-block execute (op 21: a tiny arena, so that blocks fall back)
+        static std::vector<uint8_t> scratch;
+        const int64_t bytes = op == 21 ? 4096 + ((n * 12 + 4095) & ~4095LL) + 3 * 4096 : achip::lz4_twopass_scratch_bytes(n);
+        scratch.assign((size_t)bytes, 0xCD);
+        a.ringPad = 16;
+        return achip::launch_lz4_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0);
+    }
     if (op == 19) return achip::launch_snappy_decompress_lanewindow(a, nullptr, nullptr);
     if (op == 18) return achip::launch_lz4_decompress_lanewindow(a, nullptr, nullptr);  // lane per block + LDS output window: lane-private
     if (op == 16 || op == 17) {  // default ring decoders at GS = 1 (compact / large rings)

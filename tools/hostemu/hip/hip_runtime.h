@@ -1,8 +1,21 @@
-// Host shim used ONLY by tools/hostemu: lets the single-lane (GS=1) instantiations of the decoder
-// kernels be compiled with g++ and stepped through on the CPU while debugging.  Not part of the product.
+// Host shim used ONLY by tools/hostemu: compiles the kernel sources of aircompressor_amd/csrc with a host C++ compiler and runs them on
+// the CPU -- test infrastructure for developing and fuzzing kernels without a GPU.  Not part of the product.
+//
+// Execution model: every thread of a workgroup is a FIBER (its own stack, cooperative switching).  A fiber runs until it reaches a
+// cross-lane operation (__ballot, __shfl*, __syncthreads, wave_sync, readfirstlane ...); the scheduler then runs the other fibers to the same
+// point, performs the operation over the wave (64 consecutive threads) or the workgroup, and releases them.  That is exact for kernels
+// that (1) call cross-lane operations only in wave-uniform control flow (lanes that have left the kernel do not take part -- as on the
+// hardware) and (2) separate memory traffic BETWEEN lanes with wave_sync() / __syncthreads() (on the device the former is only a compiler
+// barrier: a wavefront's memory operations are performed in program order; here it is a rendezvous).  A cross-lane operation reached
+// by only some lanes of a wave (at different source lines) is reported and aborts: such code would depend on EXEC-mask semantics that
+// this shim does not model.  Lane-private kernels (no cross-lane operation at all) simply run one lane after the other.
 #pragma once
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+
 #define __global__
 #define __device__
 #define __host__
@@ -10,28 +23,251 @@
 #define __launch_bounds__(...)
 #define __shared__ static
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
-extern thread_local dim3 threadIdx, blockIdx, blockDim;
+extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 typedef int hipError_t;
 typedef void* hipStream_t;
 #define hipSuccess 0
 inline hipError_t hipGetLastError() { return 0; }
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)              \
-    do {                                                                         \
-        blockDim = block;                                                        \
-        for (unsigned bx_ = 0; bx_ < dim3(grid).x; bx_++)                        \
-            for (unsigned tx_ = 0; tx_ < dim3(block).x; tx_++) {                 \
-                blockIdx = dim3(bx_);                                            \
-                threadIdx = dim3(tx_);                                           \
-                kernel(__VA_ARGS__);                                             \
-            }                                                                    \
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+
+namespace hostemu {
+
+constexpr int MAX_THREADS = 1024;
+constexpr size_t STACK_BYTES = 512 << 10;
+enum Wait { RUNNABLE = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2 };
+
+struct Fiber {
+    void* sp = nullptr;
+    char* stack = nullptr;
+    bool done = true;
+    int wait = RUNNABLE;
+    const char* file = nullptr;
+    int line = 0;
+    uint64_t post = 0;
+};
+
+struct State {
+    Fiber f[MAX_THREADS];
+    int n = 0;
+    int cur = -1;
+    void* schedSp = nullptr;
+    std::function<void()> body;
+};
+inline State& S()
+{
+    static thread_local State s;
+    return s;
+}
+
+extern "C" void hostemu_switch(void** saveSp, void* loadSp);
+// x86-64 System V: callee-saved registers + stack pointer
+__asm__(
+    ".text\n"
+    ".globl hostemu_switch\n"
+    ".type hostemu_switch,@function\n"
+    "hostemu_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size hostemu_switch,.-hostemu_switch\n");
+
+inline void fiber_entry()
+{
+    State& s = S();
+    s.body();
+    Fiber& me = s.f[s.cur];
+    me.done = true;
+    hostemu_switch(&me.sp, s.schedSp);
+    abort();  // a finished fiber is never resumed
+}
+
+inline void wait_here(int kind, const char* file, int line)
+{
+    State& s = S();
+    Fiber& me = s.f[s.cur];
+    me.wait = kind;
+    me.file = file;
+    me.line = line;
+    hostemu_switch(&me.sp, s.schedSp);
+}
+
+inline void run_workgroup(int nThreads, const std::function<void()>& body)
+{
+    State& s = S();
+    if (nThreads > MAX_THREADS) {
+        fprintf(stderr, "hostemu: workgroup too large\n");
+        abort();
+    }
+    s.n = nThreads;
+    s.body = body;
+    for (int t = 0; t < nThreads; t++) {
+        Fiber& f = s.f[t];
+        if (!f.stack) {
+            f.stack = (char*)aligned_alloc(64, STACK_BYTES);
+        }
+        uintptr_t top = ((uintptr_t)f.stack + STACK_BYTES) & ~(uintptr_t)15;
+        void** p = (void**)top;
+        *--p = nullptr;                 // fake return address of fiber_entry
+        *--p = (void*)&fiber_entry;     // `ret` of the first switch lands here
+        for (int k = 0; k < 6; k++) *--p = nullptr;
+        f.sp = (void*)p;
+        f.done = false;
+        f.wait = RUNNABLE;
+    }
+    for (;;) {
+        bool any = false, ran = false;
+        for (int t = 0; t < nThreads; t++) {
+            Fiber& f = s.f[t];
+            if (f.done) continue;
+            any = true;
+            if (f.wait != RUNNABLE) continue;
+            s.cur = t;
+            threadIdx = dim3((unsigned)t);
+            hostemu_switch(&s.schedSp, f.sp);
+            ran = true;
+        }
+        if (!any) break;
+        // release complete rendezvous
+        bool released = false;
+        bool blockReady = true;
+        for (int t = 0; t < nThreads; t++) {
+            if (!s.f[t].done && s.f[t].wait != WAIT_BLOCK) blockReady = false;
+        }
+        if (blockReady) {
+            for (int t = 0; t < nThreads; t++) {
+                if (!s.f[t].done) s.f[t].wait = RUNNABLE;
+            }
+            released = true;
+        }
+        else {
+            for (int w = 0; w < nThreads; w += 64) {
+                const int e = w + 64 < nThreads ? w + 64 : nThreads;
+                bool ready = true, some = false;
+                const char* file = nullptr;
+                int line = 0;
+                for (int t = w; t < e; t++) {
+                    Fiber& f = s.f[t];
+                    if (f.done) continue;
+                    if (f.wait != WAIT_WAVE) {
+                        ready = false;
+                        continue;
+                    }
+                    if (!some) {
+                        file = f.file;
+                        line = f.line;
+                        some = true;
+                    }
+                    else if (f.line != line || f.file != file) {
+                        fprintf(stderr, "hostemu: lanes of one wave wait at different cross-lane operations: %s:%d and %s:%d (thread %d)\n", file, line, f.file, f.line, t);
+                        abort();
+                    }
+                }
+                if (ready && some) {
+                    for (int t = w; t < e; t++) {
+                        if (!s.f[t].done) s.f[t].wait = RUNNABLE;
+                    }
+                    released = true;
+                }
+            }
+        }
+        if (!ran && !released) {
+            fprintf(stderr, "hostemu: deadlock -- some lanes wait at a cross-lane operation the others never reach:\n");
+            for (int t = 0; t < nThreads; t++) {
+                if (!s.f[t].done) fprintf(stderr, "  thread %d: wait %d at %s:%d\n", t, s.f[t].wait, s.f[t].file ? s.f[t].file : "?", s.f[t].line);
+            }
+            abort();
+        }
+    }
+}
+
+inline int lane_id() { return S().cur & 63; }
+inline int wave_base() { return S().cur & ~63; }
+
+// all lanes post a value; after the first rendezvous every lane may read every post; the second rendezvous keeps a fast lane from posting
+// its NEXT value before a slow lane has read this one
+template <typename F>
+inline auto collective(uint64_t mine, const char* file, int line, F&& read) -> decltype(read())
+{
+    State& s = S();
+    s.f[s.cur].post = mine;
+    wait_here(WAIT_WAVE, file, line);
+    auto r = read();
+    wait_here(WAIT_WAVE, file, line);
+    return r;
+}
+inline bool lane_active(int t)
+{
+    State& s = S();
+    return t < s.n && !s.f[t].done;
+}
+inline unsigned long long ballot(int p, const char* file, int line)
+{
+    return collective(p ? 1 : 0, file, line, [&]() {
+        unsigned long long m = 0;
+        const int w = wave_base();
+        for (int i = 0; i < 64; i++) {
+            if (lane_active(w + i) && S().f[w + i].post) m |= 1ull << i;
+        }
+        return m;
+    });
+}
+template <typename T>
+inline uint64_t to_bits(T v)
+{
+    static_assert(sizeof(T) <= 8, "shuffle of a wide type");
+    uint64_t b = 0;
+    memcpy(&b, &v, sizeof(T));
+    return b;
+}
+template <typename T>
+inline T from_bits(uint64_t b)
+{
+    T v;
+    memcpy(&v, &b, sizeof(T));
+    return v;
+}
+template <typename T>
+inline T shfl_from(T v, int srcLane, const char* file, int line)
+{
+    return collective(to_bits(v), file, line, [&]() {
+        const int t = wave_base() + (srcLane & 63);
+        // an inactive source lane: the hardware returns what its register holds; here: the reader's own value
+        return lane_active(t) ? from_bits<T>(S().f[t].post) : v;
+    });
+}
+inline void wave_sync(const char* file, int line) { wait_here(WAIT_WAVE, file, line); }
+inline void block_sync(const char* file, int line) { wait_here(WAIT_BLOCK, file, line); }
+
+}  // namespace hostemu
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                             \
+    do {                                                                                        \
+        blockDim = block;                                                                       \
+        gridDim = grid;                                                                         \
+        for (unsigned bx_ = 0; bx_ < dim3(grid).x; bx_++) {                                     \
+            blockIdx = dim3(bx_);                                                               \
+            hostemu::run_workgroup((int)dim3(block).x, [&]() { kernel(__VA_ARGS__); });         \
+        }                                                                                       \
     } while (0)
-inline void __syncthreads() {}
-inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
-// cross-lane builtins that only the NOT emulated kernels of a shared header use (they must compile, they never run here)
+
+#define __syncthreads() hostemu::block_sync(__FILE__, __LINE__)
+#define __ballot(p) hostemu::ballot((p), __FILE__, __LINE__)
+#define __shfl(v, src) hostemu::shfl_from((v), (src), __FILE__, __LINE__)
+#define __shfl_up(v, d) hostemu::shfl_from((v), hostemu::lane_id() >= (int)(d) ? hostemu::lane_id() - (int)(d) : hostemu::lane_id(), __FILE__, __LINE__)
+#define __shfl_down(v, d) hostemu::shfl_from((v), hostemu::lane_id() + (int)(d) < 64 ? hostemu::lane_id() + (int)(d) : hostemu::lane_id(), __FILE__, __LINE__)
+#define __shfl_xor(v, m) hostemu::shfl_from((v), hostemu::lane_id() ^ (int)(m), __FILE__, __LINE__)
+#define __builtin_amdgcn_readfirstlane(v) hostemu::shfl_from((v), __builtin_ctzll(hostemu::ballot(1, __FILE__, __LINE__)), __FILE__, __LINE__)
+#define __builtin_amdgcn_readlane(v, l) hostemu::shfl_from((v), (l), __FILE__, __LINE__)
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
+inline int __ffsll(unsigned long long v) { return v == 0 ? 0 : __builtin_ctzll(v) + 1; }
+// cross-lane builtins that only NOT emulated kernels of a shared header use (they must compile, they never run here)
 inline int __builtin_amdgcn_update_dpp(int old, int src, int, int, int, bool) { (void)old; return src; }
-inline int __builtin_amdgcn_readlane(int v, int) { return v; }
 template <typename T> inline T atomicAdd(T* p, T v) { T old = *p; *p += v; return old; }
-template <typename T> inline T __shfl(T v, int) { return v; }
+template <typename T> inline T atomicMax(T* p, T v) { T old = *p; if (v > old) *p = v; return old; }
 
 // dynamic shared memory of the emulated launch: one arena, re-used by every "workgroup"
 static uint8_t hostemu_dynamic_lds[1 << 20] __attribute__((aligned(64)));

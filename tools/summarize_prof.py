@@ -33,7 +33,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcp"):
             acc[k][row.get("Counter_Name")] += float(row.get("Counter_Value", 0))
             cnt[k][row.get("Counter_Name")] += 1
     for k in acc:
-        if "decompress" not in k and "compress" not in k:
+        if "achip" not in k:
             continue
         for name, v in acc[k].items():
             n = cnt[k][name]
