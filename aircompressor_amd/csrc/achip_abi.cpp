@@ -22,7 +22,7 @@ namespace achip {
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
-hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass);
+hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant);
 int64_t lz4_twopass_scratch_bytes(int32_t nBlocks);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
 hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
@@ -75,6 +75,7 @@ struct achip_ctx {
     bool lastAutoIsLz4 = false;
     bool lastLz4dAuto = false;  // the last LZ4 decode ran in auto mode: its probe count leads the scratch
     int maxSrcLenHint = 0;
+    int execVariant = 1;     // two-pass decoders: 1 = executor with an LDS output ring (default), 0 = straight to the output buffer
     // scratch for the zstd pipeline (grown on demand)
     void* scratch = nullptr;
     int64_t scratchBytes = 0;
@@ -231,7 +232,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             if (ctx->lz4dVariant == 7) {  // two passes: parse to records, a wavefront per block executes them (lz4_decompress_v7.hip)
                 int32_t r = ensure_scratch(ctx, achip::lz4_twopass_scratch_bytes(a.nBlocks));
                 if (r < 0) return r;
-                e = achip::launch_lz4_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->lz4dGroup, ctx->ringClass);
+                e = achip::launch_lz4_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->lz4dGroup, ctx->ringClass, ctx->execVariant);
                 break;
             }
             e = ctx->lz4dVariant == 4 ? achip::launch_lz4_decompress_lanecopy(a, ctx->stream, nullptr)
@@ -632,6 +633,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     else if (k == "zstd.decompress.variant") ctx->zstddVariant = (int)value;
     else if (k == "zstd.compress.variant") ctx->zstdcVariant = (int)value;
     else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;
+    else if (k == "decompress.exec_variant") ctx->execVariant = (int)value;
     else if (k == "host.chunk_bytes") {
         if (value < (1 << 16) || value > (1LL << 32)) return bad_argument("host.chunk_bytes must be in 64 KiB .. 4 GiB");
         ctx->hostChunkBytes = value;

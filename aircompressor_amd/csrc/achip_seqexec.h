@@ -75,6 +75,10 @@ __device__ __forceinline__ int32_t wave_scan_incl(int32_t x, int lane)
 #endif
 }
 __device__ __forceinline__ int32_t wave_bcast(int32_t v, int srcLane) { return __builtin_amdgcn_readlane(v, srcLane); }
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int srcLane)  // (uniform srcLane)
+{
+    return ((uint64_t)(uint32_t)wave_bcast((int32_t)(v >> 32), srcLane) << 32) | (uint32_t)wave_bcast((int32_t)(uint32_t)v, srcLane);
+}
 __device__ __forceinline__ const uint8_t* wave_bcast_ptr(const uint8_t* p, int srcLane)
 {
     const uint64_t v = (uint64_t)(uintptr_t)p;
@@ -251,6 +255,361 @@ __device__ __forceinline__ void exec_block(const uint8_t* __restrict__ in, int32
             slot = 0;
         }
     }
+}
+
+// ---- the executor with an LDS output window -----------------------------------------------------------------------------------------
+// The batch's output is composed in a per-wavefront LDS window first: byte-exact writes are cheap there, matches that read what the same
+// batch (or the last batches) produced never leave the CU -- a dependency round costs an LDS round trip, not a trip to the L2 and back --
+// and the window is drained to the output buffer in whole aligned 16-byte pieces, 1 KiB per store instruction.
+//   win[p - winBase] holds output byte p for winBase <= p < outPos (a LINEAR buffer: no wrap-around cases in the copy paths; when a batch
+//   would not fit behind outPos any more, the last SLIDE_KEEP bytes are moved to the front -- one 16-byte LDS read and write per lane);
+//   bytes below flushPos are in the output buffer (flushPos >= winBase, so every byte is readable from the one or the other).
+//   A batch takes as many records as fit CAP output bytes; a single record beyond that is moved straight between the global buffers by
+//   the whole wavefront and the window restarts behind it.
+constexpr int WIN = 4096;
+constexpr int CAP = 1920;          // output bytes of one batch
+constexpr int SLIDE_KEEP = 1024;   // history kept when the window slides (what is older is read from the output buffer)
+
+struct WinIo {
+    uint8_t* win;  // LDS, WIN + 16 bytes
+    uint8_t* out;
+    int32_t winBase;   // (uniform) output position of win[0]
+    int32_t flushPos;  // (uniform)
+
+    // 16 bytes at output position p (only bytes below the write frontier are meaningful)
+    __device__ __forceinline__ u32x4 read16(int32_t p) const
+    {
+        if (p >= winBase) {
+            uint64_t a, b;
+            __builtin_memcpy(&a, win + (p - winBase), 8);
+            __builtin_memcpy(&b, win + (p - winBase) + 8, 8);
+            return u32x4{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+        }
+        if (p + 16 <= winBase) {
+            return ld16(out + p);  // flushed long ago
+        }
+        uint32_t w[4] = {0, 0, 0, 0};  // across winBase (cold)
+#pragma unroll 1
+        for (int k = 0; k < 16; k++) {
+            const int32_t q = p + k;
+            const uint32_t b = q >= winBase ? win[q - winBase] : out[q];
+            w[k >> 2] |= b << (8 * (k & 3));
+        }
+        return u32x4{w[0], w[1], w[2], w[3]};
+    }
+    // the first n (0..16) bytes of v to output position p (inside the window)
+    __device__ __forceinline__ void write_upto16(int32_t p, u32x4 v, int32_t n)
+    {
+        uint8_t* d = win + (p - winBase);
+        const uint64_t lo = ((uint64_t)v.y << 32) | v.x, hi = ((uint64_t)v.w << 32) | v.z;
+        if (n >= 16) {
+            __builtin_memcpy(d, &lo, 8);
+            __builtin_memcpy(d + 8, &hi, 8);
+            return;
+        }
+        if (n & 8) __builtin_memcpy(d, &lo, 8);
+        const uint64_t x8 = (n & 8) ? hi : lo;
+        const uint32_t x4lo = (uint32_t)x8;
+        if (n & 4) __builtin_memcpy(d + (n & 8), &x4lo, 4);
+        const uint32_t x4 = (n & 4) ? (uint32_t)(x8 >> 32) : (uint32_t)x8;
+        const uint16_t x2lo = (uint16_t)x4;
+        if (n & 2) __builtin_memcpy(d + (n & 12), &x2lo, 2);
+        const uint32_t x2 = (n & 2) ? x4 >> 16 : x4;
+        if (n & 1) d[n & 14] = (uint8_t)x2;
+    }
+    // a match: n bytes at position d repeat what lies `off` before them
+    __device__ __forceinline__ void copy_match(int32_t d, int32_t off, int32_t n)
+    {
+        if (n <= 16 && off >= n) {  // (text is almost all this)
+            write_upto16(d, read16(d - off), n);
+            return;
+        }
+        if (off >= 16) {
+            int32_t k = 0;
+#pragma unroll 1
+            for (; k < n; k += 16) {
+                write_upto16(d + k, read16(d - off + k), n - k < 16 ? n - k : 16);
+            }
+            return;
+        }
+        int32_t c = 0, dist = off;  // short period: one period first, then twice as far back each step
+#pragma unroll 1
+        while (c < n) {
+            const int32_t m = dist < n - c ? dist : n - c;
+#pragma unroll 1
+            for (int32_t k = 0; k < m; k += 16) {
+                write_upto16(d + c + k, read16(d + c - dist + k), m - k < 16 ? m - k : 16);
+            }
+            c += m;
+            dist += dist;
+        }
+    }
+    // literal bytes from the compressed stream
+    __device__ __forceinline__ void copy_literals(int32_t d, const uint8_t* src, int32_t n, const uint8_t* srcEnd)
+    {
+#pragma unroll 1
+        for (int32_t k = 0; k < n; k += 16) {
+            const int32_t m = n - k < 16 ? n - k : 16;
+            write_upto16(d + k, load_upto16(src + k, m, srcEnd), m);
+        }
+    }
+    // drains the window to the output buffer up to position `to` (uniform; everything below `to` is final): whole 16-byte pieces
+    // (positions, not addresses, are 16-aligned: winBase is) by all lanes, a ragged first / last part byte by byte
+    __device__ __forceinline__ void flush(int32_t to, bool exactEnd, int lane)
+    {
+        int32_t from = flushPos;
+        if ((from & 15) != 0) {  // ragged start (the window restarted here)
+            const int32_t edge = (from + 15) & ~15;
+            const int32_t e = edge < to ? edge : to;
+            if (from + lane < e) {
+                out[from + lane] = win[from + lane - winBase];
+            }
+            if (e < edge) {
+                flushPos = e;
+                return;
+            }
+            from = e;
+        }
+        const int32_t wholeEnd = to & ~15;
+        for (int32_t base = from; base < wholeEnd; base += 1024) {  // (uniform)
+            const int32_t p = base + lane * 16;
+            if (p < wholeEnd) {
+                st16(out + p, *(const u32x4*)(win + (p - winBase)));
+            }
+        }
+        int32_t done = wholeEnd > from ? wholeEnd : from;
+        if (exactEnd && done < to) {
+            if (done + lane < to) {
+                out[done + lane] = win[done + lane - winBase];
+            }
+            done = to;
+        }
+        flushPos = done;
+    }
+    // makes room for a batch behind outPos (uniform): the last SLIDE_KEEP bytes move to the front
+    __device__ __forceinline__ void slide(int32_t outPos, int lane)
+    {
+        if (outPos - winBase + CAP <= WIN) {
+            return;
+        }
+        wave_sync();
+        int32_t nb = (outPos - SLIDE_KEEP) & ~15;  // new base (16-aligned position)
+        nb = nb > winBase ? nb : winBase;
+        const int32_t n = outPos - nb;  // bytes to keep (<= SLIDE_KEEP + 15)
+        const int32_t i = lane * 16;
+        u32x4 v0 = u32x4{0, 0, 0, 0}, v1 = v0;
+        if (i < n) v0 = *(const u32x4*)(win + (nb - winBase) + i);
+        if (i + 1024 < n) v1 = *(const u32x4*)(win + (nb - winBase) + i + 1024);
+        wave_sync();
+        if (i < n) *(u32x4*)(win + i) = v0;
+        if (i + 1024 < n) *(u32x4*)(win + i + 1024) = v1;
+        wave_sync();
+        winBase = nb;
+    }
+};
+
+// One batch of the pipelined executor: what `prepare` derives from 64 records -- and the loads it has started for them.
+struct Batch {
+    int32_t lit, ml, off;    // this lane's record (zero lengths beyond k)
+    int32_t dstLit, srcLit;  // output position of the literal run, its position in the compressed stream
+    u32x4 litData;           // the first 16 bytes of the literal run (requested by prepare)
+    u32x4 farData;           // the first 16 bytes of a match source that lies in the output buffer only (requested by prepare)
+    bool farPre;
+    int32_t k;               // (uniform) records in the batch; 0: the first record alone exceeds a batch
+    int32_t total, sTotal;   // (uniform) output / compressed bytes of the batch
+};
+
+// the records of the next batch: lane i gets record slot + i (i < nb); when the batch ends its chunk, lane nb gets the link
+__device__ __forceinline__ uint64_t load_records(const uint64_t* __restrict__ arena, int32_t chunk, int32_t slot, int32_t count, int lane)
+{
+    int32_t nb = CHUNK_RECS - slot;
+    nb = nb < 64 ? nb : 64;
+    nb = nb < count ? nb : count;
+    const bool link = slot + nb == CHUNK_RECS && nb < 64;
+    uint64_t r = 0;
+    if (lane < nb || (link && lane == nb)) {
+        r = arena[(int64_t)chunk * CHUNK_SLOTS + slot + lane];
+    }
+    return r;
+}
+
+// Same contract as exec_block; `win` = WIN + 16 bytes of LDS owned by this wavefront.  Software pipeline: while batch i is composed in
+// the window, the records of batch i + 2 and the literal / far-match bytes of batch i + 1 are on their way.
+template <int DBG = 0>  // DBG: timing aids (output not valid)
+__device__ __forceinline__ void exec_block_ring(uint8_t* win, const uint8_t* __restrict__ in, int32_t inLen, uint8_t* out, int32_t outCap,
+                                                const uint64_t* __restrict__ arena, int32_t chunk, int32_t count, int lane)
+{
+    const uint8_t* const inEnd = in + inLen;
+    WinIo io;
+    io.win = win;
+    io.out = out;
+    io.winBase = 0;
+    io.flushPos = 0;
+    (void)outCap;
+
+    // cursor of `prepare` (one batch ahead of the composing side)
+    int32_t pChunk = chunk, pSlot = 0, pCount = count, pOut = 0, pSrc = 0;
+    bool pPrevLong = false;  // the batch prepared last is a long record: what lies before the next batch is not in the output buffer yet
+
+    auto prepare = [&](uint64_t r, Batch& b) {
+        int32_t nb = CHUNK_RECS - pSlot;
+        nb = nb < 64 ? nb : 64;
+        nb = nb < pCount ? nb : pCount;
+        const bool haveLink = pSlot + nb == CHUNK_RECS && nb < 64;
+        const int32_t linkChunk = haveLink ? (int32_t)(uint32_t)shfl_u64(r, nb) : 0;  // (uniform)
+        if (lane >= nb) {
+            r = 0;
+        }
+        b.lit = rec_lit(r);
+        b.ml = rec_ml(r);
+        b.off = rec_off(r);
+        const int32_t skip = rec_skip(r);
+        const int32_t tot = b.lit + b.ml, adv = skip + b.lit;
+        const int32_t oEnd = wave_scan_incl(tot, lane), sEnd = wave_scan_incl(adv, lane);
+        b.k = (int32_t)__popcll(__ballot(lane < nb && oEnd <= CAP));  // a prefix: oEnd is monotone
+        b.farPre = false;
+        b.litData = u32x4{0, 0, 0, 0};
+        b.farData = u32x4{0, 0, 0, 0};
+        if (b.k == 0) {  // (uniform) the first record alone: moved straight between the global buffers when its turn comes
+            b.total = wave_bcast(tot, 0);
+            b.sTotal = wave_bcast(adv, 0);
+            b.dstLit = pOut;
+            b.srcLit = pSrc + wave_bcast(skip, 0);
+            b.lit = wave_bcast(b.lit, 0);
+            b.ml = wave_bcast(b.ml, 0);
+            b.off = wave_bcast(b.off, 0);
+        }
+        else {
+            if (lane >= b.k) {
+                b.lit = 0;
+                b.ml = 0;
+            }
+            b.total = wave_bcast(oEnd, b.k - 1);
+            b.sTotal = wave_bcast(sEnd, b.k - 1);
+            b.dstLit = pOut + oEnd - tot;
+            b.srcLit = pSrc + sEnd - (tot - rec_ml(r));
+            if (b.lit > 0) {
+                b.litData = load_upto16(in + b.srcLit, b.lit, inEnd);
+            }
+            // a match source that is surely below the window when this batch is composed (the window then starts at or behind
+            // pOut - (WIN - CAP)) and was flushed before the PREVIOUS batch began (pOut - WIN + CAP + 16 <= that batch's start - 16)
+            const int32_t srcM = b.dstLit + b.lit - b.off;
+            if (b.ml > 0 && !pPrevLong && srcM + 16 <= pOut - (WIN - CAP)) {
+                b.farData = ld16(out + srcM);
+                b.farPre = true;
+            }
+        }
+        pPrevLong = b.k == 0;
+        const int32_t consumed = b.k == 0 ? 1 : b.k;
+        pOut += b.total;
+        pSrc += b.sTotal;
+        pSlot += consumed;
+        pCount -= consumed;
+        if (pSlot == CHUNK_RECS && pCount > 0) {
+            pChunk = linkChunk;
+            pSlot = 0;
+        }
+    };
+
+    Batch cur, nxt;
+    uint64_t rNext = load_records(arena, pChunk, pSlot, pCount, lane);
+    prepare(rNext, cur);
+    rNext = pCount > 0 ? load_records(arena, pChunk, pSlot, pCount, lane) : 0;
+    int32_t outPos = 0;
+    int32_t left = count;
+    while (left > 0) {  // (uniform)
+        const bool more = pCount > 0;  // (uniform) there is a batch behind `cur`
+        if (more) {
+            prepare(rNext, nxt);
+            rNext = pCount > 0 ? load_records(arena, pChunk, pSlot, pCount, lane) : 0;
+        }
+        // ---- compose `cur` ----
+        if (cur.k == 0) {  // (uniform) one long record
+            io.flush(outPos, true, lane);
+            wave_sync();
+            wave_copy(out + outPos, in + cur.srcLit, cur.lit, lane);
+            wave_sync();
+            uint8_t* const d = out + outPos + cur.lit;
+            if (cur.ml > 0) {
+                if (cur.off >= 1024) {
+                    wave_copy(d, d - cur.off, cur.ml, lane);
+                }
+                else if (lane == 0) {
+                    copy_match(d, cur.off, cur.ml, d + cur.ml);
+                }
+            }
+            wave_sync();
+            outPos += cur.total;
+            io.flushPos = outPos;
+            io.winBase = outPos & ~15;  // the window restarts here: its first bytes (up to 15) come back from the output buffer
+            if (io.winBase + lane < outPos) {
+                win[lane] = out[io.winBase + lane];
+            }
+            wave_sync();
+            left -= 1;
+        }
+        else {
+            io.slide(outPos, lane);
+            const int32_t dstM = cur.dstLit + cur.lit;
+            const int32_t srcM = dstM - cur.off;
+            const int32_t span = cur.ml < cur.off ? cur.ml : cur.off;  // source bytes that are not the match's own output
+            bool pending = cur.ml > 0 && DBG != 1 && DBG != 4;
+            // literal runs (the first 16 bytes are here already) and the far matches whose bytes are here as well
+            if (cur.lit > 0 && DBG != 2 && DBG != 4) {
+                io.write_upto16(cur.dstLit, cur.litData, cur.lit < 16 ? cur.lit : 16);
+                if (cur.lit > 16) {
+                    io.copy_literals(cur.dstLit + 16, in + cur.srcLit + 16, cur.lit - 16, inEnd);
+                }
+            }
+            if (pending && cur.farPre && cur.ml <= 16) {
+                io.write_upto16(dstM, cur.farData, cur.ml);
+                pending = false;
+            }
+            // a match whose source reaches into this batch's output waits for exactly the lanes a .. b-1 that produce it (outputs are
+            // contiguous and ordered over the lanes: two binary searches by lane shuffles), as far as they are pending themselves
+            unsigned long long dep = 0;
+            const bool inBatch = pending && srcM + span > outPos;
+            const unsigned long long producers = __ballot(pending);  // every match still to be written may be somebody's source
+            if (__ballot(inBatch) != 0 && DBG != 6) {  // (uniform)
+                const int32_t myStart = cur.dstLit, myEnd = dstM + cur.ml;
+                int32_t a = 0, bnd = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const int32_t e = __shfl(myEnd, a + step - 1);
+                    const int32_t st = __shfl(myStart, bnd + step - 1);
+                    a += e <= srcM ? step : 0;            // lanes that end at or before the source's start
+                    bnd += st < srcM + span ? step : 0;   // lanes that start before the source's end
+                }
+                bnd = bnd < lane ? bnd : lane;
+                if (inBatch && a < bnd) {
+                    dep = producers & ((bnd >= 64 ? ~0ull : ((1ull << bnd) - 1)) & ~((1ull << a) - 1));
+                }
+            }
+            if (DBG == 6 && inBatch) pending = false;
+            wave_sync();
+            for (;;) {  // (uniform) round 1: everything that waits for nothing; the first pending lane is always ready
+                const unsigned long long pm = __ballot(pending);
+                if (pm == 0) {
+                    break;
+                }
+                if (pending && (dep & pm) == 0) {
+                    io.copy_match(dstM, cur.off, cur.ml);
+                    pending = false;
+                }
+                wave_sync();
+            }
+            outPos += cur.total;
+            if (DBG != 3 && DBG != 4) {
+                io.flush(outPos, false, lane);
+            }
+            left -= cur.k;
+        }
+        if (more) {
+            cur = nxt;
+        }
+    }
+    wave_sync();
+    io.flush(outPos, true, lane);
 }
 
 }  // namespace sx

@@ -272,14 +272,21 @@ __global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHea
     }
 }
 
+template <bool RING, int DBG = 0>
 __global__ __launch_bounds__(64) void lz4_execute_kernel(BatchArgs a, const sx::BlockMeta* meta, const uint64_t* arena)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t ring[RING ? sx::WIN + 16 : 16];
     const int64_t block = blockIdx.x;
     const sx::BlockMeta m = meta[block];
     if (m.count <= 0) {
         return;
     }
-    sx::exec_block(a.srcBase + a.srcOff[block], a.srcLen[block], a.dstBase + a.dstOff[block], a.dstCap[block], arena, m.firstChunk, m.count, (int)threadIdx.x);
+    if constexpr (RING) {
+        sx::exec_block_ring<DBG>(ring, a.srcBase + a.srcOff[block], a.srcLen[block], a.dstBase + a.dstOff[block], a.dstCap[block], arena, m.firstChunk, m.count, (int)threadIdx.x);
+    }
+    else {
+        sx::exec_block(a.srcBase + a.srcOff[block], a.srcLen[block], a.dstBase + a.dstOff[block], a.dstCap[block], arena, m.firstChunk, m.count, (int)threadIdx.x);
+    }
 }
 
 // scratch: [header 256 B][meta n x 8][only n x 4][arena, 4 KiB aligned]
@@ -292,7 +299,7 @@ int64_t lz4_twopass_scratch_bytes(int32_t nBlocks)
 
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 
-hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass)
+hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant)
 {
     if (a.nBlocks <= 0) {
         return hipSuccess;
@@ -308,7 +315,33 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream,
     hipError_t e = hipMemsetAsync(hdr, 0, sizeof(sx::ArenaHeader), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lz4_parse_kernel, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks);
-    hipLaunchKernelGGL(lz4_execute_kernel, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    if (execVariant == 0) {
+        hipLaunchKernelGGL(lz4_execute_kernel<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else if (execVariant == 101) {
+        hipLaunchKernelGGL((lz4_execute_kernel<true, 1>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else if (execVariant == 102) {
+        hipLaunchKernelGGL((lz4_execute_kernel<true, 2>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else if (execVariant == 103) {
+        hipLaunchKernelGGL((lz4_execute_kernel<true, 3>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else if (execVariant == 105) {
+        hipLaunchKernelGGL((lz4_execute_kernel<true, 5>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else if (execVariant == 106) {
+        hipLaunchKernelGGL((lz4_execute_kernel<true, 6>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else if (execVariant == 107) {
+        hipLaunchKernelGGL((lz4_execute_kernel<true, 7>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else if (execVariant == 104) {
+        hipLaunchKernelGGL((lz4_execute_kernel<true, 4>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else {
+        hipLaunchKernelGGL((lz4_execute_kernel<true, 0>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
     BatchArgs f = a;
     f.only = only;
     e = launch_lz4_decompress_rings(f, stream, groupSize, ringClass, nullptr);

@@ -54,6 +54,7 @@ def parse_args():
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time of the headline's cpu_baseline leg")
     p.add_argument("--cpu-leg-seconds", type=float, default=0.6, help="CPU time of each extra entry's CPU leg (per direction)")
     p.add_argument("--no-sweep", action="store_true")
+    p.add_argument("--exec-variant", type=int, default=-1, help="DEBUG: decompress.exec_variant (two-pass decoders)")
     p.add_argument("--section", default="all", choices=["all", "zstd", "xxhash", "lz4frame"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-variant", type=int, default=-1, help="zstd decoder: 1 = five-stage pipeline (default), 0 = one-kernel decoder")
     return p.parse_args()
@@ -200,6 +201,8 @@ def main():
     if args.ring_pad >= 0:
         codec.native.set_option("decompress.ring_pad", args.ring_pad)
     codec.native.set_option("max_src_len_hint", bs)
+    if args.exec_variant >= 0:
+        codec.native.set_option("decompress.exec_variant", args.exec_variant)
     if args.section == "lz4frame":
         print(json.dumps(lz4frame_extra(torch, A, codec, torch.device("cuda", local_rank), args)), flush=True)
         return

@@ -118,7 +118,12 @@ inline void run_workgroup(int nThreads, const std::function<void()>& body)
     }
     for (;;) {
         bool any = false, ran = false;
-        for (int t = 0; t < nThreads; t++) {
+        static thread_local unsigned pass = 0;
+        pass++;
+        for (int t0 = 0; t0 < nThreads; t0++) {
+            // lanes run in a different order from pass to pass (ascending, descending, interleaved): code that works only because a lower
+            // lane happens to run first between two rendezvous is a race on the hardware and should fail here too
+            const int t = (pass & 3) == 0 ? t0 : ((pass & 3) == 1 ? nThreads - 1 - t0 : ((pass & 3) == 2 ? (t0 ^ 1) < nThreads ? (t0 ^ 1) : t0 : (t0 * 37 + 11) % nThreads));
             Fiber& f = s.f[t];
             if (f.done) continue;
             any = true;
