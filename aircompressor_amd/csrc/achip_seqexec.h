@@ -35,9 +35,10 @@ __device__ __forceinline__ int32_t rec_ml(uint64_t r) { return (int32_t)((r >> 1
 __device__ __forceinline__ int32_t rec_off(uint64_t r) { return (int32_t)((r >> 34) & 0xFFFF); }
 __device__ __forceinline__ int32_t rec_skip(uint64_t r) { return (int32_t)(r >> 50); }
 
-// ---- arena: chunks of 512 slots (4 KiB); slots 0..510 hold records, slot 511 the index of the block's next chunk -------------------
+// ---- arena: chunks of 512 slots (4 KiB); slots 0..503 hold records (an all-zero record does nothing), slot 504 the index of the
+// block's next chunk ----
 constexpr int CHUNK_SLOTS = 512;
-constexpr int CHUNK_RECS = CHUNK_SLOTS - 1;
+constexpr int CHUNK_RECS = 504;  // (a multiple of 8: the parser writes records in 64-byte pieces; the link sits in slot 504)
 
 struct BlockMeta {  // per block, written by the parser
     int32_t firstChunk;
@@ -506,7 +507,8 @@ __device__ __forceinline__ void exec_block_ring(uint8_t* win, const uint8_t* __r
         pSlot += consumed;
         pCount -= consumed;
         if (pSlot == CHUNK_RECS && pCount > 0) {
-            pChunk = linkChunk;
+            // (a batch of exactly 64 records that ends its chunk had no free lane for the link: read it now)
+            pChunk = haveLink ? linkChunk : (int32_t)(uint32_t)arena[(int64_t)pChunk * CHUNK_SLOTS + CHUNK_RECS];
             pSlot = 0;
         }
     };

@@ -16,10 +16,11 @@
 
 namespace achip {
 
+template <int DBG>
 __global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHeader* hdr, sx::BlockMeta* meta, int32_t* only, uint64_t* arena, int32_t maxChunks)
 {
-    using namespace sp;
     __shared__ uint32_t ldsIn[16 * 64];
+    __shared__ uint64_t ldsRec[8 * 64];  // 8 records per lane, flushed as one 64-byte piece
     const int lane = threadIdx.x;
     const int64_t block = (int64_t)blockIdx.x * 64 + lane;
     const bool have = block < a.nBlocks;
@@ -27,6 +28,7 @@ __global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHea
     const int32_t inLimit = have ? a.srcLen[block] : 0;
     const int32_t outLimit = have ? a.dstCap[block] : 0;
 
+    using namespace sp;
     LaneInput<16> R;
     R.init(ldsIn + lane, in, inLimit);
 
@@ -58,14 +60,16 @@ __global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHea
         }
     }
 
-    // record output: the lane's current chunk and fill
-    int32_t firstChunk = -1, chunk = -1, fill = sx::CHUNK_RECS, count = 0;
+    // record output: 8 staged in LDS, the lane's current chunk and its fill
+    int32_t firstChunk = -1, chunk = -1, fill = sx::CHUNK_RECS, count = 0, recFill = 0;
     int32_t litEndPrev = 0;  // compressed position behind the previous record's literals (for `skip`)
 
-    while (__ballot(!done) != 0) {  // (uniform)
-        // ---- a chunk for every lane that has none or has filled its own: one atomic per wavefront ----
+    while (__ballot(!done || recFill > 0) != 0) {  // (uniform)
+        // ---- staged records leave as one 64-byte piece when there are 8 of them (or the lane is done: padded with empty records);
+        // a chunk for every lane that needs one: one atomic per wavefront ----
         {
-            const bool need = !done && fill == sx::CHUNK_RECS;
+            const bool flushDue = recFill == 8 || (done && recFill > 0);
+            const bool need = flushDue && fill == sx::CHUNK_RECS;
             const unsigned long long nm = __ballot(need);
             if (nm != 0) {  // (uniform)
                 int32_t base = 0;
@@ -78,6 +82,7 @@ __global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHea
                     if (c >= maxChunks) {  // arena exhausted: the ring decoder takes this block
                         fallback = true;
                         done = true;
+                        recFill = 0;
                     }
                     else {
                         if (chunk >= 0) {
@@ -90,6 +95,23 @@ __global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHea
                         fill = 0;
                     }
                 }
+            }
+            if (flushDue && recFill > 0) {
+                uint64_t r[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    r[k] = k < recFill ? ldsRec[k * 64 + lane] : 0ull;
+                }
+                if (DBG != 1) {
+                    uint8_t* const dst = (uint8_t*)(arena + (int64_t)chunk * sx::CHUNK_SLOTS + fill);
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        st16(dst + 8 * k, u32x4{(uint32_t)r[k], (uint32_t)(r[k] >> 32), (uint32_t)r[k + 1], (uint32_t)(r[k + 1] >> 32)});
+                    }
+                }
+                fill += 8;
+                count += 8;
+                recFill = 0;
             }
         }
         if (!done) {
@@ -211,44 +233,18 @@ __global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHea
                     }
                 }
             }
-            // ---- the record (a failed sequence leaves none: the block's output is void anyway).  Lengths beyond the record fields
-            // are split: gaps first, then literal pieces, then match pieces with the same offset (cold paths). ----
+            // ---- the record (a failed sequence leaves none: the block's output is void anyway) ----
             if (emit) {
-                uint32_t skip = (uint32_t)(litStart - litEndPrev);
+                const int32_t skip = litStart - litEndPrev;
                 litEndPrev = litStart + (int32_t)rLit;
-                for (;;) {
-                    uint32_t pSkip = skip, pLit = 0, pMl = 0;
-                    if (skip > (uint32_t)sx::MAX_SKIP) {
-                        pSkip = sx::MAX_SKIP;
-                    }
-                    else if (rLit > (uint32_t)sx::MAX_LEN) {
-                        pLit = sx::MAX_LEN;
-                    }
-                    else {
-                        pLit = rLit;
-                        pMl = rMl > (uint32_t)sx::MAX_LEN ? (uint32_t)sx::MAX_LEN : rMl;
-                    }
-                    if (fill == sx::CHUNK_RECS) {
-                        // (cold: a split record and a full chunk in the same trip) claim a chunk alone
-                        const int32_t c = atomicAdd(&hdr->nextChunk, 1);
-                        if (c >= maxChunks) {
-                            fallback = true;
-                            done = true;
-                            break;
-                        }
-                        arena[(int64_t)chunk * sx::CHUNK_SLOTS + sx::CHUNK_RECS] = (uint64_t)(uint32_t)c;
-                        chunk = c;
-                        fill = 0;
-                    }
-                    arena[(int64_t)chunk * sx::CHUNK_SLOTS + fill] = sx::rec_pack(pLit, pMl, rOff, pSkip);
-                    fill++;
-                    count++;
-                    skip -= pSkip;
-                    rLit -= pLit;
-                    rMl -= pMl;
-                    if (skip == 0 && rLit == 0 && rMl == 0) {
-                        break;
-                    }
+                if (rLit > (uint32_t)sx::MAX_LEN || rMl > (uint32_t)sx::MAX_LEN || skip > sx::MAX_SKIP) {
+                    fallback = true;  // lengths beyond the record fields (blocks of many megabytes): the ring decoder takes the block
+                    done = true;
+                    recFill = 0;
+                }
+                else {
+                    ldsRec[recFill * 64 + lane] = sx::rec_pack(rLit, rMl, rOff, (uint32_t)skip);
+                    recFill++;
                 }
             }
         }
@@ -314,7 +310,12 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream,
     const int32_t maxChunks = (int32_t)(chunks > 0x7FFFFFFF ? 0x7FFFFFFF : chunks);
     hipError_t e = hipMemsetAsync(hdr, 0, sizeof(sx::ArenaHeader), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(lz4_parse_kernel, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks);
+    if (execVariant == 201) {
+        hipLaunchKernelGGL(lz4_parse_kernel<1>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks);
+    }
+    else {
+        hipLaunchKernelGGL(lz4_parse_kernel<0>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks);
+    }
     if (execVariant == 0) {
         hipLaunchKernelGGL(lz4_execute_kernel<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
     }
