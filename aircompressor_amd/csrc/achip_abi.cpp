@@ -24,6 +24,7 @@ hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream
 hipError_t launch_lz4_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant);
 int64_t lz4_twopass_scratch_bytes(int32_t nBlocks);
+hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
 hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
@@ -73,6 +74,7 @@ struct achip_ctx {
     int lastZstddVariant = 0;
     int32_t lastAutoBlocks = 0;  // ... and this many blocks
     bool lastAutoIsLz4 = false;
+    bool lastTwopass = false;   // the last decode was a two-pass one: its arena header leads the scratch
     bool lastLz4dAuto = false;  // the last LZ4 decode ran in auto mode: its probe count leads the scratch
     int maxSrcLenHint = 0;
     int execVariant = 1;     // two-pass decoders: 1 = executor with an LDS output ring (default), 0 = straight to the output buffer
@@ -209,6 +211,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
     HIP_TRY(hipSetDevice(ctx->device));
     hipError_t e = hipSuccess;
     ctx->lastLz4dAuto = false;
+    ctx->lastTwopass = false;
     switch (op) {
         case ACHIP_OP_LZ4_DECOMPRESS:
             if (ctx->lz4dVariant == 5 && a.nBlocks >= ctx->lz4dAutoMinBlocks) {
@@ -232,6 +235,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             if (ctx->lz4dVariant == 7) {  // two passes: parse to records, a wavefront per block executes them (lz4_decompress_v7.hip)
                 int32_t r = ensure_scratch(ctx, achip::lz4_twopass_scratch_bytes(a.nBlocks));
                 if (r < 0) return r;
+                ctx->lastTwopass = true;
                 e = achip::launch_lz4_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->lz4dGroup, ctx->ringClass, ctx->execVariant);
                 break;
             }
@@ -254,6 +258,13 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 if (e == hipSuccess) e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, mixedGroups);
                 if (e == hipSuccess) e = achip::launch_snappy_decompress_lanecopy(a, ctx->stream, mixedGroups);
                 if (e == hipSuccess) e = achip::launch_snappy_decompress_lanewindow(a, ctx->stream, mixedGroups);
+                break;
+            }
+            if (ctx->snappydVariant == 7) {  // two passes (snappy_decompress_v5.hip)
+                int32_t r = ensure_scratch(ctx, achip::lz4_twopass_scratch_bytes(a.nBlocks));
+                if (r < 0) return r;
+                ctx->lastTwopass = true;
+                e = achip::launch_snappy_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->snappydGroup, ctx->ringClass, ctx->execVariant);
                 break;
             }
             e = ctx->snappydVariant == 4 ? achip::launch_snappy_decompress_lanecopy(a, ctx->stream, nullptr)
@@ -613,7 +624,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     }
     else if (k == "lz4.decompress.auto_min_blocks") ctx->lz4dAutoMinBlocks = (int)value;
     else if (k == "snappy.decompress.variant") {
-        if (value != 1 && value != 4 && value != 5 && value != 6) return bad_argument("snappy.decompress.variant: 1 rings, 4 / 6 a lane per block, 5 auto");
+        if (value != 1 && value != 4 && value != 5 && value != 6 && value != 7) return bad_argument("snappy.decompress.variant: 1 rings, 4 / 6 a lane per block, 7 two passes, 5 auto");
         ctx->snappydVariant = (int)value;
     }
     else if (k == "decompress.ring_class") ctx->ringClass = (int)value;
@@ -665,6 +676,13 @@ int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name)
         if (hipMemcpy(v, ctx->scratch, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if ((int64_t)v[0] * 4 > (ctx->lastAutoBlocks + 15) / 16) return 1;
         return (ctx->lastAutoBlocks >= 131072 && v[1] > 0 && (int64_t)v[2] < (ctx->lastAutoIsLz4 ? 12 : 6) * (int64_t)v[1]) ? 2 : 0;
+    }
+    if (k == "decompress.twopass_fallback_blocks") {  // blocks the last two-pass LZ4 / Snappy decode handed to the ring decoder (-1: none ran)
+        if (!ctx->lastTwopass || ctx->scratch == nullptr) return -1;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+        int32_t v[3] = {0, 0, 0};
+        if (hipMemcpy(v, ctx->scratch, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        return v[2];
     }
     const std::string prefix = "zstd.decompress.fallback_";
     if (k.compare(0, prefix.size(), prefix) == 0) {

@@ -87,6 +87,79 @@ __device__ __forceinline__ const uint8_t* wave_bcast_ptr(const uint8_t* p, int s
     return (const uint8_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
 
+// ---- the parser's record output: 8 records staged per lane in LDS, written as one 64-byte piece -----------------------------------------
+// (one 8-byte store per trip and lane would be a partial write of its own cache line every time: measured 56 GB written for 8 GB of records)
+struct RecordWriter {
+    uint64_t* stage;  // this lane's LDS column: record k at stage[k * 64]
+    int32_t firstChunk, chunk, fill, count, recFill;
+
+    __device__ __forceinline__ void init(uint64_t* lds)
+    {
+        stage = lds;
+        firstChunk = -1;
+        chunk = -1;
+        fill = CHUNK_RECS;
+        count = 0;
+        recFill = 0;
+    }
+    __device__ __forceinline__ void put(uint64_t r)
+    {
+        stage[recFill * 64] = r;
+        recFill++;
+    }
+    // once per trip, in wave-uniform control flow: staged records leave when there are 8 of them (or the lane is done: padded with empty
+    // records); a chunk for every lane that needs one -- one atomic per wavefront; an exhausted arena hands the block to the fallback
+    template <int DBG>
+    __device__ __forceinline__ void service(bool& done, bool& fallback, ArenaHeader* hdr, uint64_t* arena, int32_t maxChunks, int lane, int32_t flushAt = 8)
+    {
+        const bool flushDue = recFill >= flushAt || (done && recFill > 0);
+        const bool need = flushDue && fill == CHUNK_RECS;
+        const unsigned long long nm = __ballot(need);
+        if (nm != 0) {  // (uniform)
+            int32_t base = 0;
+            if (lane == __builtin_ctzll(nm)) {
+                base = atomicAdd(&hdr->nextChunk, (int32_t)__popcll(nm));
+            }
+            base = wave_bcast(base, __builtin_ctzll(nm));
+            if (need) {
+                const int32_t c = base + (int32_t)__popcll(nm & ((1ull << lane) - 1));
+                if (c >= maxChunks) {
+                    fallback = true;
+                    done = true;
+                    recFill = 0;
+                }
+                else {
+                    if (chunk >= 0) {
+                        arena[(int64_t)chunk * CHUNK_SLOTS + CHUNK_RECS] = (uint64_t)(uint32_t)c;  // link
+                    }
+                    else {
+                        firstChunk = c;
+                    }
+                    chunk = c;
+                    fill = 0;
+                }
+            }
+        }
+        if (flushDue && recFill > 0) {
+            uint64_t r[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                r[k] = k < recFill ? stage[k * 64] : 0ull;
+            }
+            if (DBG != 1) {
+                uint8_t* const dst = (uint8_t*)(arena + (int64_t)chunk * CHUNK_SLOTS + fill);
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    st16(dst + 8 * k, u32x4{(uint32_t)r[k], (uint32_t)(r[k] >> 32), (uint32_t)r[k + 1], (uint32_t)(r[k + 1] >> 32)});
+                }
+            }
+            fill += 8;
+            count += 8;
+            recFill = 0;
+        }
+    }
+};
+
 // ---- lane-private exact copies ------------------------------------------------------------------------------------------------------
 // n bytes (n < 16) of v to dst, nothing else written
 __device__ __forceinline__ void store_exact16(uint8_t* dst, u32x4 v, int32_t n)

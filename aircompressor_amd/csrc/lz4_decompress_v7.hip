@@ -10,7 +10,7 @@
 //                        Java checks in their order, one 8-byte record out.  Records go to 4 KiB chunks claimed from an arena with
 //                        one atomic per wavefront and trip; a block whose records do not fit (arena exhausted) is handed to the ring
 //                        decoder afterwards (`only` filter).
-//   lz4_execute_kernel   a wavefront per block: sx::exec_block.
+//   seq_execute_kernel   a wavefront per block: sx::exec_block.
 #include "achip_lanecopy.h"
 #include "achip_seqexec.h"
 
@@ -60,60 +60,12 @@ __global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHea
         }
     }
 
-    // record output: 8 staged in LDS, the lane's current chunk and its fill
-    int32_t firstChunk = -1, chunk = -1, fill = sx::CHUNK_RECS, count = 0, recFill = 0;
+    sx::RecordWriter W;
+    W.init(ldsRec + lane);
     int32_t litEndPrev = 0;  // compressed position behind the previous record's literals (for `skip`)
 
-    while (__ballot(!done || recFill > 0) != 0) {  // (uniform)
-        // ---- staged records leave as one 64-byte piece when there are 8 of them (or the lane is done: padded with empty records);
-        // a chunk for every lane that needs one: one atomic per wavefront ----
-        {
-            const bool flushDue = recFill == 8 || (done && recFill > 0);
-            const bool need = flushDue && fill == sx::CHUNK_RECS;
-            const unsigned long long nm = __ballot(need);
-            if (nm != 0) {  // (uniform)
-                int32_t base = 0;
-                if (lane == __builtin_ctzll(nm)) {
-                    base = atomicAdd(&hdr->nextChunk, (int32_t)__popcll(nm));
-                }
-                base = sx::wave_bcast(base, __builtin_ctzll(nm));
-                if (need) {
-                    const int32_t c = base + (int32_t)__popcll(nm & ((1ull << lane) - 1));
-                    if (c >= maxChunks) {  // arena exhausted: the ring decoder takes this block
-                        fallback = true;
-                        done = true;
-                        recFill = 0;
-                    }
-                    else {
-                        if (chunk >= 0) {
-                            arena[(int64_t)chunk * sx::CHUNK_SLOTS + sx::CHUNK_RECS] = (uint64_t)(uint32_t)c;  // link
-                        }
-                        else {
-                            firstChunk = c;
-                        }
-                        chunk = c;
-                        fill = 0;
-                    }
-                }
-            }
-            if (flushDue && recFill > 0) {
-                uint64_t r[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    r[k] = k < recFill ? ldsRec[k * 64 + lane] : 0ull;
-                }
-                if (DBG != 1) {
-                    uint8_t* const dst = (uint8_t*)(arena + (int64_t)chunk * sx::CHUNK_SLOTS + fill);
-#pragma unroll
-                    for (int k = 0; k < 8; k += 2) {
-                        st16(dst + 8 * k, u32x4{(uint32_t)r[k], (uint32_t)(r[k] >> 32), (uint32_t)r[k + 1], (uint32_t)(r[k + 1] >> 32)});
-                    }
-                }
-                fill += 8;
-                count += 8;
-                recFill = 0;
-            }
-        }
+    while (__ballot(!done || W.recFill > 0) != 0) {  // (uniform)
+        W.service<DBG>(done, fallback, hdr, arena, maxChunks, lane);
         if (!done) {
             // ---- one sequence (the Java loop body :59-195 without its copies) ----
             uint32_t rLit = 0, rMl = 0, rOff = 0;
@@ -240,11 +192,10 @@ __global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHea
                 if (rLit > (uint32_t)sx::MAX_LEN || rMl > (uint32_t)sx::MAX_LEN || skip > sx::MAX_SKIP) {
                     fallback = true;  // lengths beyond the record fields (blocks of many megabytes): the ring decoder takes the block
                     done = true;
-                    recFill = 0;
+                    W.recFill = 0;
                 }
                 else {
-                    ldsRec[recFill * 64 + lane] = sx::rec_pack(rLit, rMl, rOff, (uint32_t)skip);
-                    recFill++;
+                    W.put(sx::rec_pack(rLit, rMl, rOff, (uint32_t)skip));
                 }
             }
         }
@@ -259,8 +210,8 @@ __global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHea
         }
         else {
             only[block] = 0;
-            meta[block].firstChunk = firstChunk < 0 ? 0 : firstChunk;
-            meta[block].count = st == 0 ? count : 0;
+            meta[block].firstChunk = W.firstChunk < 0 ? 0 : W.firstChunk;
+            meta[block].count = st == 0 ? W.count : 0;
             a.outLen[block] = st == 0 ? op : 0;
             a.status[block] = st;
             a.errOffset[block] = (int64_t)eo;
@@ -269,7 +220,7 @@ __global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHea
 }
 
 template <bool RING, int DBG = 0>
-__global__ __launch_bounds__(64) void lz4_execute_kernel(BatchArgs a, const sx::BlockMeta* meta, const uint64_t* arena)
+__global__ __launch_bounds__(64) void seq_execute_kernel(BatchArgs a, const sx::BlockMeta* meta, const uint64_t* arena)
 {
     __shared__ __attribute__((aligned(16))) uint8_t ring[RING ? sx::WIN + 16 : 16];
     const int64_t block = blockIdx.x;
@@ -291,6 +242,39 @@ int64_t lz4_twopass_scratch_bytes(int32_t nBlocks)
     const int64_t fixed = 4096 + (((int64_t)nBlocks * 12 + 4095) & ~4095LL);
     int64_t arena = (int64_t)nBlocks * 65536 + (64LL << 20);
     return fixed + arena;
+}
+
+// the execute pass (shared with snappy_decompress_v5.hip): a wavefront per block
+hipError_t launch_seq_execute(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant)
+{
+    if (execVariant == 0) {
+        hipLaunchKernelGGL(seq_execute_kernel<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else if (execVariant == 101) {
+        hipLaunchKernelGGL((seq_execute_kernel<true, 1>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else if (execVariant == 102) {
+        hipLaunchKernelGGL((seq_execute_kernel<true, 2>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else if (execVariant == 103) {
+        hipLaunchKernelGGL((seq_execute_kernel<true, 3>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else if (execVariant == 105) {
+        hipLaunchKernelGGL((seq_execute_kernel<true, 5>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else if (execVariant == 106) {
+        hipLaunchKernelGGL((seq_execute_kernel<true, 6>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else if (execVariant == 107) {
+        hipLaunchKernelGGL((seq_execute_kernel<true, 7>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else if (execVariant == 104) {
+        hipLaunchKernelGGL((seq_execute_kernel<true, 4>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    else {
+        hipLaunchKernelGGL((seq_execute_kernel<true, 0>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
@@ -316,33 +300,8 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream,
     else {
         hipLaunchKernelGGL(lz4_parse_kernel<0>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks);
     }
-    if (execVariant == 0) {
-        hipLaunchKernelGGL(lz4_execute_kernel<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
-    }
-    else if (execVariant == 101) {
-        hipLaunchKernelGGL((lz4_execute_kernel<true, 1>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
-    }
-    else if (execVariant == 102) {
-        hipLaunchKernelGGL((lz4_execute_kernel<true, 2>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
-    }
-    else if (execVariant == 103) {
-        hipLaunchKernelGGL((lz4_execute_kernel<true, 3>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
-    }
-    else if (execVariant == 105) {
-        hipLaunchKernelGGL((lz4_execute_kernel<true, 5>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
-    }
-    else if (execVariant == 106) {
-        hipLaunchKernelGGL((lz4_execute_kernel<true, 6>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
-    }
-    else if (execVariant == 107) {
-        hipLaunchKernelGGL((lz4_execute_kernel<true, 7>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
-    }
-    else if (execVariant == 104) {
-        hipLaunchKernelGGL((lz4_execute_kernel<true, 4>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
-    }
-    else {
-        hipLaunchKernelGGL((lz4_execute_kernel<true, 0>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
-    }
+    e = launch_seq_execute(a, stream, meta, arena, execVariant);
+    if (e != hipSuccess) return e;
     BatchArgs f = a;
     f.only = only;
     e = launch_lz4_decompress_rings(f, stream, groupSize, ringClass, nullptr);

@@ -315,6 +315,7 @@ def main():
     else:
         assert bool((out_len == pool_clen.repeat(reps)).all())
 
+    twopass_fallback = codec.native.get_stat("decompress.twopass_fallback_blocks") if wl.endswith("decompress") else -1
     mixed_groups = codec.native.get_stat("lz4.decompress.mixed_groups") if wl.endswith("decompress") else -1
     choice = codec.native.get_stat("decompress.choice") if wl.endswith("decompress") else -1
     decoder = "n/a" if not wl.endswith("decompress") else DECODER_NAMES.get(choice, "rings")
@@ -343,6 +344,7 @@ def main():
             "blocks_per_gpu": n_local, "block_bytes": bs, "distinct_blocks": pool_n, "compression_ratio": round(plain_bytes_local / comp_bytes_local, 4),
             "parallelism": "block-sharded x%d, no collective" % world,
             "decoder": decoder + (" (chosen on the device: %d of %d 16-block groups mixed)" % (mixed_groups, (n_local + 15) // 16) if mixed_groups >= 0 else ""),
+            "twopass_fallback_blocks": twopass_fallback,
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -107,7 +107,7 @@ def test_lz4_lane_per_block_decoders(gb, o, cfg):
             assert outs[i] == eout, "case %d" % i
 
 
-@pytest.mark.parametrize("variant", [4, 6], ids=["copy-steps", "lds-window"])
+@pytest.mark.parametrize("variant", [4, 6, 7], ids=["copy-steps", "lds-window", "two-pass"])
 def test_snappy_lane_per_block_decoder(gb, o, variant):
     """variants 4 (snappy_decompress_v3.hip) and 6 (snappy_decompress_v4.hip): plaintext, status and error offsets equal the oracle's,
     corrupt streams included"""
@@ -189,8 +189,6 @@ def _oracle_status(o, codec, data, cap):
 def test_malformed_inputs_report_the_reference_errors(gb, o, codec, cfg):
     """Error KATs of the reference plus systematic corruption: status class/detail and offset must equal the oracle's
     (= what the Java decoder throws), and nothing is written outside the block's output."""
-    if cfg[0] == 7 and codec == "snappy":
-        pytest.skip("the two-pass decoder is LZ4 only")
     configure(gb, codec, cfg)
     rng = np.random.default_rng(99)
     cases = []

@@ -7,6 +7,7 @@ thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 #include "../../aircompressor_amd/csrc/lz4_decompress_v6.hip"
 #include "../../aircompressor_amd/csrc/snappy_decompress_v4.hip"
 #include "../../aircompressor_amd/csrc/lz4_decompress_v7.hip"
+#include "../../aircompressor_amd/csrc/snappy_decompress_v5.hip"
 #include <vector>
 extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, const int32_t* srcLen, uint8_t* dstBase, const int64_t* dstOff,
                          const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n)
@@ -20,6 +21,13 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
         scratch.assign((size_t)bytes, 0xCD);
         a.ringPad = 16;
         return achip::launch_lz4_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, direct ? 0 : 1);
+    }
+    if (op == 30 || op == 31) {  // two-pass Snappy (31: a tiny arena, so that blocks fall back)
+        static std::vector<uint8_t> scratch;
+        const int64_t bytes = op == 31 ? 4096 + ((n * 12 + 4095) & ~4095LL) + 3 * 4096 : achip::lz4_twopass_scratch_bytes(n);
+        scratch.assign((size_t)bytes, 0xCD);
+        a.ringPad = 16;
+        return achip::launch_snappy_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, 1);
     }
     if (op == 19) return achip::launch_snappy_decompress_lanewindow(a, nullptr, nullptr);
     if (op == 18) return achip::launch_lz4_decompress_lanewindow(a, nullptr, nullptr);  // lane per block + LDS output window: lane-private
