@@ -22,9 +22,9 @@ namespace achip {
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
-hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant);
+hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
 int64_t lz4_twopass_scratch_bytes(int32_t nBlocks);
-hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant);
+hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
 hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
@@ -57,7 +57,7 @@ struct achip_ctx {
     // options
     int lz4dGroup = 4;       // lanes per block: measured best on MI355X (profiles/r01_sweep_v2_rings.txt)
     int snappydGroup = 4;
-    int lz4dAutoMinBlocks = 65536;  // auto mode considers the lane-per-block decoder (64 blocks per wavefront) from this batch size on
+    int lz4dAutoMinBlocks = 4096;  // auto mode probes batches from this size on (smaller ones always take the rings)
     int lz4dVariant = 5;     // 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 4 = a lane per block, copies straight between the global buffers (lz4_decompress_v5.hip), 6 = a lane per block with an LDS output window (lz4_decompress_v6.hip), 5 = auto
     int snappydVariant = 5;  // 1 rings (snappy_decompress_v2.hip), 4 / 6 a lane per block (snappy_decompress_v3.hip / _v4.hip), 5 auto as for LZ4
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
@@ -146,6 +146,8 @@ achip::BatchArgs make_args(const void* srcBase, const int64_t* srcOff, const int
     a.ringPad = 0;
     a.nBlocksDev = nullptr;
     a.only = nullptr;
+    a.onlyStats = nullptr;
+    a.onlyShortLimit = 12;
     return a;
 }
 
@@ -215,28 +217,30 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
     switch (op) {
         case ACHIP_OP_LZ4_DECOMPRESS:
             if (ctx->lz4dVariant == 5 && a.nBlocks >= ctx->lz4dAutoMinBlocks) {
-                // auto: large batches whose neighbouring blocks are of different kinds go to the lane-per-block decoder, the
-                // rest to the rings.  The choice is made on the device (no host round trip): a probe counts the mixed groups,
-                // both decoders are launched and the one not chosen returns at once.
-                int32_t r = ensure_scratch(ctx, 4096);
+                // auto: the choice is made on the device (no host round trip): probes count the mixed 16-block groups and sample the
+                // sequence lengths, every candidate decoder is launched and the ones not chosen return at once.  Mixed or short-sequence
+                // batches go to the two-pass decoder (parse to records + a wavefront per block), the rest to the rings.
+                // scratch: [probe statistics: the first 4 KiB][two-pass header, meta, arena]
+                int32_t r = ensure_scratch(ctx, 4096 + achip::lz4_twopass_scratch_bytes(a.nBlocks));
                 if (r < 0) return r;
-                int32_t* mixedGroups = (int32_t*)ctx->scratch;
+                int32_t* stats = (int32_t*)ctx->scratch;
                 ctx->lastLz4dAuto = true;
                 ctx->lastAutoBlocks = a.nBlocks;
                 ctx->lastAutoIsLz4 = true;
                 ctx->lastZstddBlocks = 0;
-                e = achip::launch_lz4_mixed_groups(a, ctx->stream, mixedGroups, 0);
-                if (e == hipSuccess) e = achip::launch_lz4_sequence_sample(a, ctx->stream, mixedGroups, 0);
-                if (e == hipSuccess) e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, mixedGroups);
-                if (e == hipSuccess) e = achip::launch_lz4_decompress_lanecopy(a, ctx->stream, mixedGroups);
-                if (e == hipSuccess) e = achip::launch_lz4_decompress_lanewindow(a, ctx->stream, mixedGroups);
+                e = achip::launch_lz4_mixed_groups(a, ctx->stream, stats, 0);
+                if (e == hipSuccess) e = hipMemsetAsync(stats + 3, 1, 1, ctx->stream);  // stats[3] = 1: the two-pass scheme (achip_device.h lz4_pick)
+                if (e == hipSuccess) e = achip::launch_lz4_sequence_sample(a, ctx->stream, stats, 0);
+                if (e == hipSuccess) e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, stats);
+                ctx->lastTwopass = true;
+                if (e == hipSuccess) e = achip::launch_lz4_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, ctx->lz4dGroup, ctx->ringClass, ctx->execVariant, stats);
                 break;
             }
             if (ctx->lz4dVariant == 7) {  // two passes: parse to records, a wavefront per block executes them (lz4_decompress_v7.hip)
                 int32_t r = ensure_scratch(ctx, achip::lz4_twopass_scratch_bytes(a.nBlocks));
                 if (r < 0) return r;
                 ctx->lastTwopass = true;
-                e = achip::launch_lz4_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->lz4dGroup, ctx->ringClass, ctx->execVariant);
+                e = achip::launch_lz4_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->lz4dGroup, ctx->ringClass, ctx->execVariant, nullptr);
                 break;
             }
             e = ctx->lz4dVariant == 4 ? achip::launch_lz4_decompress_lanecopy(a, ctx->stream, nullptr)
@@ -246,25 +250,26 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
         case ACHIP_OP_LZ4_COMPRESS: e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint); break;
         case ACHIP_OP_SNAPPY_DECOMPRESS:
             if (ctx->snappydVariant == 5 && a.nBlocks >= ctx->lz4dAutoMinBlocks) {  // auto, as for LZ4
-                int32_t r = ensure_scratch(ctx, 4096);
+                int32_t r = ensure_scratch(ctx, 4096 + achip::lz4_twopass_scratch_bytes(a.nBlocks));
                 if (r < 0) return r;
-                int32_t* mixedGroups = (int32_t*)ctx->scratch;
+                int32_t* stats = (int32_t*)ctx->scratch;
                 ctx->lastLz4dAuto = true;
                 ctx->lastAutoBlocks = a.nBlocks;
                 ctx->lastAutoIsLz4 = false;
                 ctx->lastZstddBlocks = 0;
-                e = achip::launch_lz4_mixed_groups(a, ctx->stream, mixedGroups, 0);
-                if (e == hipSuccess) e = achip::launch_snappy_element_sample(a, ctx->stream, mixedGroups, 0);
-                if (e == hipSuccess) e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, mixedGroups);
-                if (e == hipSuccess) e = achip::launch_snappy_decompress_lanecopy(a, ctx->stream, mixedGroups);
-                if (e == hipSuccess) e = achip::launch_snappy_decompress_lanewindow(a, ctx->stream, mixedGroups);
+                e = achip::launch_lz4_mixed_groups(a, ctx->stream, stats, 0);
+                if (e == hipSuccess) e = hipMemsetAsync(stats + 3, 1, 1, ctx->stream);
+                if (e == hipSuccess) e = achip::launch_snappy_element_sample(a, ctx->stream, stats, 0);
+                if (e == hipSuccess) e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, stats);
+                ctx->lastTwopass = true;
+                if (e == hipSuccess) e = achip::launch_snappy_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, ctx->snappydGroup, ctx->ringClass, ctx->execVariant, stats);
                 break;
             }
             if (ctx->snappydVariant == 7) {  // two passes (snappy_decompress_v5.hip)
                 int32_t r = ensure_scratch(ctx, achip::lz4_twopass_scratch_bytes(a.nBlocks));
                 if (r < 0) return r;
                 ctx->lastTwopass = true;
-                e = achip::launch_snappy_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->snappydGroup, ctx->ringClass, ctx->execVariant);
+                e = achip::launch_snappy_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->snappydGroup, ctx->ringClass, ctx->execVariant, nullptr);
                 break;
             }
             e = ctx->snappydVariant == 4 ? achip::launch_snappy_decompress_lanecopy(a, ctx->stream, nullptr)
@@ -674,14 +679,15 @@ int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name)
         if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
         int32_t v[3] = {0, 0, 0};
         if (hipMemcpy(v, ctx->scratch, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        if ((int64_t)v[0] * 4 > (ctx->lastAutoBlocks + 15) / 16) return 1;
-        return (ctx->lastAutoBlocks >= 131072 && v[1] > 0 && (int64_t)v[2] < (ctx->lastAutoIsLz4 ? 12 : 6) * (int64_t)v[1]) ? 2 : 0;
+        const bool mixed = (int64_t)v[0] * 4 > (ctx->lastAutoBlocks + 15) / 16;
+        const bool isShort = v[1] > 0 && (int64_t)v[2] < (ctx->lastAutoIsLz4 ? 12 : 6) * (int64_t)v[1];
+        return (mixed || isShort) ? 3 : 0;
     }
     if (k == "decompress.twopass_fallback_blocks") {  // blocks the last two-pass LZ4 / Snappy decode handed to the ring decoder (-1: none ran)
         if (!ctx->lastTwopass || ctx->scratch == nullptr) return -1;
         if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
         int32_t v[3] = {0, 0, 0};
-        if (hipMemcpy(v, ctx->scratch, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (hipMemcpy(v, (const uint8_t*)ctx->scratch + (ctx->lastLz4dAuto ? 4096 : 0), sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
         return v[2];
     }
     const std::string prefix = "zstd.decompress.fallback_";

@@ -27,10 +27,12 @@ struct BatchArgs {
     int64_t* __restrict__ errOffset;
     int32_t nBlocks;
     int32_t ringPad;  // LDS padding between the ring pairs of consecutive blocks (decoders)
-    const int32_t* nBlocksDev;  // when set: the number of blocks is this device word (<= nBlocks, which then sizes the launch): a
+    const int32_t* nBlocksDev = nullptr;  // when set: the number of blocks is this device word (<= nBlocks, which then sizes the launch): a
                                 // batch assembled on the device (the chunk list of the framed readers)
-    const int32_t* only;        // when set (ring decoders): decode block i only if only[i] != 0 -- the blocks the two-pass decoders
+    const int32_t* only = nullptr;        // when set (ring decoders): decode block i only if only[i] != 0 -- the blocks the two-pass decoders
                                 // hand over (lz4_decompress_v7.hip)
+    const int32_t* onlyStats = nullptr;   // ... and only if these probe statistics picked the two-pass decoder (auto mode; else null)
+    int32_t onlyShortLimit = 12;
 };
 
 __device__ __forceinline__ int32_t batch_count(const BatchArgs& a) { return a.nBlocksDev != nullptr ? *a.nBlocksDev : a.nBlocks; }
@@ -45,14 +47,21 @@ __device__ __forceinline__ bool lz4_batch_is_mixed(int32_t mixedGroups, int32_t 
 // bytes they produce, in units of 4.  Mixed batch: the lane-per-block decoder with wavefront-wide copy steps (long copies next to short ones);
 // otherwise short sequences (text: 10-40 bytes per sequence at a block's head; the long-copy sets: >= 100): the lane-per-block decoder
 // with the LDS output window; otherwise the rings.
-constexpr int LZ4_PICK_RINGS = 0, LZ4_PICK_LANECOPY = 1, LZ4_PICK_LANEWINDOW = 2;
+constexpr int LZ4_PICK_RINGS = 0, LZ4_PICK_LANECOPY = 1, LZ4_PICK_LANEWINDOW = 2, LZ4_PICK_TWOPASS = 3;
 __device__ __forceinline__ int lz4_pick(const int32_t* stats, int32_t nBlocks, int32_t shortLimit = 12)
 {
+    // stats[3] != 0 (set by the batched block API): mixed or short-sequence batches of any size go to the two-pass decoder
+    // (parse to records + a wavefront per block), which beats both lane-per-block decoders from 16384 blocks up; the framed readers
+    // (whose batch exists on the device only) keep the three-way choice below
+    const bool isShort = stats[1] > 0 && (int64_t)stats[2] < (int64_t)shortLimit * (int64_t)stats[1];
+    if (stats[3] != 0) {
+        return (lz4_batch_is_mixed(stats[0], nBlocks) || isShort) ? LZ4_PICK_TWOPASS : LZ4_PICK_RINGS;
+    }
     if (lz4_batch_is_mixed(stats[0], nBlocks)) {
         return LZ4_PICK_LANECOPY;
     }
     // (the LDS-window decoder runs 8 wavefronts of 64 blocks per CU: below 131072 blocks it cannot fill the chip and the rings win)
-    return (nBlocks >= 131072 && stats[1] > 0 && (int64_t)stats[2] < (int64_t)shortLimit * (int64_t)stats[1]) ? LZ4_PICK_LANEWINDOW : LZ4_PICK_RINGS;
+    return (nBlocks >= 131072 && isShort) ? LZ4_PICK_LANEWINDOW : LZ4_PICK_RINGS;
 }
 // Snappy: the sample counts elements (a literal run or a copy -- half an LZ4 sequence)
 __device__ __forceinline__ int snappy_pick(const int32_t* stats, int32_t nBlocks) { return lz4_pick(stats, nBlocks, 6); }

@@ -21,8 +21,13 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a, 
     const int g = threadIdx.x & (GS - 1);
     const int grp = threadIdx.x / GS;
     const int64_t block = (int64_t)blockIdx.x * GROUPS_PER_WG + grp;
-    if (block >= a.nBlocks || (a.only != nullptr && a.only[block] == 0)) {
+    if (block >= a.nBlocks) {
         return;
+    }
+    if (a.only != nullptr) {  // the blocks a two-pass decode handed over -- if it ran at all (auto mode)
+        if ((a.onlyStats != nullptr && lz4_pick(a.onlyStats, a.nBlocks, a.onlyShortLimit) != LZ4_PICK_TWOPASS) || a.only[block] == 0) {
+            return;
+        }
     }
     const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
     uint8_t* out = a.dstBase + a.dstOff[block];

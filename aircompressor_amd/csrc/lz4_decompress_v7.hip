@@ -17,8 +17,11 @@
 namespace achip {
 
 template <int DBG>
-__global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHeader* hdr, sx::BlockMeta* meta, int32_t* only, uint64_t* arena, int32_t maxChunks)
+__global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHeader* hdr, sx::BlockMeta* meta, int32_t* only, uint64_t* arena, int32_t maxChunks, const int32_t* stats)
 {
+    if (stats != nullptr && lz4_pick(stats, a.nBlocks) != LZ4_PICK_TWOPASS) {  // auto mode: the ring decoder takes this batch
+        return;
+    }
     __shared__ uint32_t ldsIn[16 * 64];
     __shared__ uint64_t ldsRec[8 * 64];  // 8 records per lane, flushed as one 64-byte piece
     const int lane = threadIdx.x;
@@ -220,8 +223,11 @@ __global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHea
 }
 
 template <bool RING, int DBG = 0>
-__global__ __launch_bounds__(64) void seq_execute_kernel(BatchArgs a, const sx::BlockMeta* meta, const uint64_t* arena)
+__global__ __launch_bounds__(64) void seq_execute_kernel(BatchArgs a, const sx::BlockMeta* meta, const uint64_t* arena, const int32_t* stats, int32_t shortLimit)
 {
+    if (stats != nullptr && lz4_pick(stats, a.nBlocks, shortLimit) != LZ4_PICK_TWOPASS) {  // auto mode: the ring decoder takes this batch
+        return;
+    }
     __shared__ __attribute__((aligned(16))) uint8_t ring[RING ? sx::WIN + 16 : 16];
     const int64_t block = blockIdx.x;
     const sx::BlockMeta m = meta[block];
@@ -245,41 +251,41 @@ int64_t lz4_twopass_scratch_bytes(int32_t nBlocks)
 }
 
 // the execute pass (shared with snappy_decompress_v5.hip): a wavefront per block
-hipError_t launch_seq_execute(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant)
+hipError_t launch_seq_execute(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant, const int32_t* stats, int32_t shortLimit)
 {
     if (execVariant == 0) {
-        hipLaunchKernelGGL(seq_execute_kernel<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+        hipLaunchKernelGGL(seq_execute_kernel<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, shortLimit);
     }
     else if (execVariant == 101) {
-        hipLaunchKernelGGL((seq_execute_kernel<true, 1>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+        hipLaunchKernelGGL((seq_execute_kernel<true, 1>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, shortLimit);
     }
     else if (execVariant == 102) {
-        hipLaunchKernelGGL((seq_execute_kernel<true, 2>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+        hipLaunchKernelGGL((seq_execute_kernel<true, 2>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, shortLimit);
     }
     else if (execVariant == 103) {
-        hipLaunchKernelGGL((seq_execute_kernel<true, 3>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+        hipLaunchKernelGGL((seq_execute_kernel<true, 3>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, shortLimit);
     }
     else if (execVariant == 105) {
-        hipLaunchKernelGGL((seq_execute_kernel<true, 5>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+        hipLaunchKernelGGL((seq_execute_kernel<true, 5>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, shortLimit);
     }
     else if (execVariant == 106) {
-        hipLaunchKernelGGL((seq_execute_kernel<true, 6>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+        hipLaunchKernelGGL((seq_execute_kernel<true, 6>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, shortLimit);
     }
     else if (execVariant == 107) {
-        hipLaunchKernelGGL((seq_execute_kernel<true, 7>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+        hipLaunchKernelGGL((seq_execute_kernel<true, 7>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, shortLimit);
     }
     else if (execVariant == 104) {
-        hipLaunchKernelGGL((seq_execute_kernel<true, 4>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+        hipLaunchKernelGGL((seq_execute_kernel<true, 4>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, shortLimit);
     }
     else {
-        hipLaunchKernelGGL((seq_execute_kernel<true, 0>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena);
+        hipLaunchKernelGGL((seq_execute_kernel<true, 0>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, shortLimit);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 
-hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant)
+hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats)
 {
     if (a.nBlocks <= 0) {
         return hipSuccess;
@@ -295,15 +301,17 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream,
     hipError_t e = hipMemsetAsync(hdr, 0, sizeof(sx::ArenaHeader), stream);
     if (e != hipSuccess) return e;
     if (execVariant == 201) {
-        hipLaunchKernelGGL(lz4_parse_kernel<1>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks);
+        hipLaunchKernelGGL(lz4_parse_kernel<1>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
     }
     else {
-        hipLaunchKernelGGL(lz4_parse_kernel<0>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks);
+        hipLaunchKernelGGL(lz4_parse_kernel<0>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
     }
-    e = launch_seq_execute(a, stream, meta, arena, execVariant);
+    e = launch_seq_execute(a, stream, meta, arena, execVariant, stats, 12);
     if (e != hipSuccess) return e;
     BatchArgs f = a;
     f.only = only;
+    f.onlyStats = stats;
+    f.onlyShortLimit = 12;
     e = launch_lz4_decompress_rings(f, stream, groupSize, ringClass, nullptr);
     return e != hipSuccess ? e : hipGetLastError();
 }

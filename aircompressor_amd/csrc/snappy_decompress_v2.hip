@@ -18,7 +18,10 @@ __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs 
     const int g = threadIdx.x & (GS - 1);
     const int grp = threadIdx.x / GS;
     const int64_t block = (int64_t)blockIdx.x * GROUPS_PER_WG + grp;
-    if (block >= batch_count(a) || (a.only != nullptr && a.only[block] == 0)) {
+    if (a.only != nullptr && ((a.onlyStats != nullptr && lz4_pick(a.onlyStats, a.nBlocks, a.onlyShortLimit) != LZ4_PICK_TWOPASS) || (block < a.nBlocks && a.only[block] == 0))) {
+        return;  // (the blocks a two-pass decode handed over -- if it ran at all)
+    }
+    if (block >= batch_count(a)) {
         return;
     }
     const uint8_t* __restrict__ in0 = a.srcBase + a.srcOff[block];

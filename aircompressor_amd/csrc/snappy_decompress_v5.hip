@@ -26,8 +26,11 @@ __device__ __forceinline__ int32_t snappy_op_entry5(int32_t op)  // opLookupTabl
 }
 
 template <int DBG>
-__global__ __launch_bounds__(64) void snappy_parse_kernel(BatchArgs a, sx::ArenaHeader* hdr, sx::BlockMeta* meta, int32_t* only, uint64_t* arena, int32_t maxChunks)
+__global__ __launch_bounds__(64) void snappy_parse_kernel(BatchArgs a, sx::ArenaHeader* hdr, sx::BlockMeta* meta, int32_t* only, uint64_t* arena, int32_t maxChunks, const int32_t* stats)
 {
+    if (stats != nullptr && snappy_pick(stats, a.nBlocks) != LZ4_PICK_TWOPASS) {  // auto mode: the ring decoder takes this batch
+        return;
+    }
     using namespace sp;
     __shared__ uint32_t ldsIn[16 * 64];
     __shared__ uint64_t ldsRec[8 * 64];
@@ -235,13 +238,13 @@ __global__ __launch_bounds__(64) void snappy_parse_kernel(BatchArgs a, sx::Arena
     }
 }
 
-hipError_t launch_seq_execute(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant);
+hipError_t launch_seq_execute(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant, const int32_t* stats, int32_t shortLimit);
 int64_t lz4_twopass_scratch_bytes(int32_t nBlocks);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 
 int64_t snappy_twopass_scratch_bytes(int32_t nBlocks) { return lz4_twopass_scratch_bytes(nBlocks); }
 
-hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant)
+hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats)
 {
     if (a.nBlocks <= 0) {
         return hipSuccess;
@@ -257,15 +260,17 @@ hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stre
     hipError_t e = hipMemsetAsync(hdr, 0, sizeof(sx::ArenaHeader), stream);
     if (e != hipSuccess) return e;
     if (execVariant == 201) {
-        hipLaunchKernelGGL(snappy_parse_kernel<1>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks);
+        hipLaunchKernelGGL(snappy_parse_kernel<1>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
     }
     else {
-        hipLaunchKernelGGL(snappy_parse_kernel<0>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks);
+        hipLaunchKernelGGL(snappy_parse_kernel<0>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
     }
-    e = launch_seq_execute(a, stream, meta, arena, execVariant);
+    e = launch_seq_execute(a, stream, meta, arena, execVariant, stats, 6);
     if (e != hipSuccess) return e;
     BatchArgs f = a;
     f.only = only;
+    f.onlyStats = stats;
+    f.onlyShortLimit = 6;
     e = launch_snappy_decompress_rings(f, stream, groupSize, ringClass, nullptr);
     return e != hipSuccess ? e : hipGetLastError();
 }

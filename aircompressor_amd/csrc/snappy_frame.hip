@@ -805,7 +805,7 @@ hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream
     hipLaunchKernelGGL(snf::snappyframed_walk_kernel, dim3(perStream), dim3(64), 0, stream, a, L);
     hipLaunchKernelGGL(snf::snappyframed_seal_kernel, dim3(1), dim3(1), 0, stream, L);
     // the chunks as a batch of Snappy blocks whose size is known on the device only: launches are sized for the arrays
-    BatchArgs c;
+    BatchArgs c = a;  // (every field the chunk batch does not set keeps the caller's value: no filter, no device count yet)
     c.srcBase = a.srcBase;
     c.srcOff = L.cSrcOff;
     c.srcLen = L.cSrcLen;
@@ -818,6 +818,8 @@ hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream
     c.nBlocks = snf::MAX_CHUNKS;
     c.ringPad = a.ringPad;
     c.nBlocksDev = counters + 1;
+    c.only = nullptr;
+    c.onlyStats = nullptr;
     int32_t* mixedGroups = counters + 16;
     e = launch_lz4_mixed_groups(c, stream, mixedGroups, 65536);  // (the lane-per-block decoder wants 64 blocks per wavefront)
     if (e == hipSuccess) e = launch_snappy_element_sample(c, stream, mixedGroups, 65536);

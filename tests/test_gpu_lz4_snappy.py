@@ -138,17 +138,21 @@ def test_snappy_lane_per_block_decoder(gb, o, variant):
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
 def test_auto_mode_picks_a_decoder_on_the_device(gb, o, codec):
-    """variant 5 (the default): batches of at least auto_min_blocks blocks are probed on the device -- groups of 16 consecutive
-    blocks whose compressed sizes differ by more than 2x count as mixed -- and a mostly mixed batch goes to the lane-per-block
-    decoder, any other to the rings; both give the oracle's plaintext"""
+    """variant 5 (the default): batches of at least auto_min_blocks blocks are probed on the device -- groups of 16 consecutive blocks
+    whose compressed sizes differ by more than 2x count as mixed, and the heads of sampled blocks give the bytes per sequence -- and a
+    mostly mixed or short-sequence batch goes to the two-pass decoder (3), a batch of long copies to the rings (0); all give the
+    oracle's plaintext"""
     text = [d for _, d, _ in common.corpus_sample()][:2]
     flat = [bytes(65536), bytes(range(256)) * 256]
+    rng = np.random.default_rng(3)
+    frag = [np.tile(rng.integers(0, 256, size=(656, 50), dtype=np.uint8), (1, 2)).reshape(-1)[:65536].tobytes() for _ in range(4)]
     uniform = (text * 40)[:64]
     mixed = [text[i % 2] if i % 2 == 0 else flat[(i // 2) % 2] for i in range(64)]
+    longcopies = (frag * 16)[:64]
     gb.set_option("%s.decompress.variant" % codec, 5)
     gb.set_option("lz4.decompress.auto_min_blocks", 32)  # (one threshold for both codecs)
     try:
-        for blocks, expect_mixed in ((uniform, False), (mixed, True), (mixed[:16], None)):
+        for blocks, expect_mixed, expect_choice in ((uniform, False, 3), (mixed, True, 3), (longcopies, False, 0), (mixed[:16], None, -1)):
             comp = [o.compress(codec, b) for b in blocks]
             outs, status, _ = gb.run(CODECS[codec]["d"], comp, [len(b) for b in blocks], unaligned=True)
             assert all(s == 0 for s in status) and outs == blocks
@@ -158,10 +162,10 @@ def test_auto_mode_picks_a_decoder_on_the_device(gb, o, codec):
                 assert groups == -1 and choice == -1  # below auto_min_blocks: no probe, the rings
             else:
                 assert (groups * 4 > len(blocks) // 16) == expect_mixed, groups
-                # mixed: the lane-per-block decoder with copy steps; uniform: the rings (the LDS-window decoder is picked from 131072 blocks on)
-                assert choice == (1 if expect_mixed else 0), choice
+                assert choice == expect_choice, choice
+                assert gb.codec.native.get_stat("decompress.twopass_fallback_blocks") == 0
     finally:
-        gb.set_option("lz4.decompress.auto_min_blocks", 65536)
+        gb.set_option("lz4.decompress.auto_min_blocks", 4096)
         configure(gb, codec, DECODERS[0])
 
 

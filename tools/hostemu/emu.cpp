@@ -20,14 +20,14 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
         const int64_t bytes = op == 21 ? 4096 + ((n * 12 + 4095) & ~4095LL) + 3 * 4096 : achip::lz4_twopass_scratch_bytes(n);
         scratch.assign((size_t)bytes, 0xCD);
         a.ringPad = 16;
-        return achip::launch_lz4_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, direct ? 0 : 1);
+        return achip::launch_lz4_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, direct ? 0 : 1, nullptr);
     }
     if (op == 30 || op == 31) {  // two-pass Snappy (31: a tiny arena, so that blocks fall back)
         static std::vector<uint8_t> scratch;
         const int64_t bytes = op == 31 ? 4096 + ((n * 12 + 4095) & ~4095LL) + 3 * 4096 : achip::lz4_twopass_scratch_bytes(n);
         scratch.assign((size_t)bytes, 0xCD);
         a.ringPad = 16;
-        return achip::launch_snappy_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, 1);
+        return achip::launch_snappy_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, 1, nullptr);
     }
     if (op == 19) return achip::launch_snappy_decompress_lanewindow(a, nullptr, nullptr);
     if (op == 18) return achip::launch_lz4_decompress_lanewindow(a, nullptr, nullptr);  // lane per block + LDS output window: lane-private
