@@ -160,6 +160,100 @@ struct RecordWriter {
     }
 };
 
+// ---- the parser's view of its compressed stream: a byte-addressable LDS ring per lane, fed by loads that are in flight for NS trips -----
+// RING bytes of the stream are resident per lane, contiguous in LDS (the first 16 bytes once more behind the ring, so that any resident
+// 16 bytes [v, v + 16) can be read at ring + (v % RING) without a wrap case), fed with aligned 32-byte granules.
+// The point of the structure is WHEN the loads are waited for.  A wavefront's vector memory operations complete in order and are waited
+// for by count, so a lane that refilled "when it ran dry, one piece ahead" made the whole wavefront wait for the load some other lane
+// had issued a moment ago: one memory latency per trip (measured: 2.1 us per trip of ~200 instructions).  Here every trip has ONE place
+// where granules are requested (`issue`, slot = trip mod NS) and ONE place where the granule requested NS trips earlier enters the ring
+// (`land`, same slot): the loop is unrolled, the slots are distinct registers, and the wait the compiler places before `land` lets the
+// NS - 1 younger requests stay in flight.  A lane whose bytes are not resident yet sits the trip out.
+// "Virtual" positions count from the 32-byte aligned address at or before the stream's first byte.
+template <int NS>
+struct LaneFeed {
+    static constexpr int RING = 128;
+    static constexpr int GRAN = 32;
+    static constexpr int STRIDE = RING + 16;  // (a multiple of 16: the granules are written as aligned 16-byte pieces)
+    uint8_t* ring;
+    const uint8_t* inAligned;
+    const uint8_t* safe;  // what a lane that wants nothing loads from (the load itself is unconditional, see issue)
+    int32_t inBase;    // virtual position of the stream's first byte (0..31)
+    int32_t lastV;     // virtual position of the last 16-byte piece that holds a byte of the stream
+    int32_t loadedV;   // (a multiple of 32) the ring holds virtual [.., loadedV)
+    int32_t issueV;    // the next granule to request; loadedV + 32 * (granules in flight)
+    u32x4 ga[NS], gb[NS];
+    uint32_t validBits;  // bit s: slot s holds a granule of this lane (flags live in vector registers: no lane-mask bookkeeping at branches)
+
+    // `anywhere`: an address (16-byte aligned, 16 bytes) that can always be read
+    __device__ __forceinline__ void init(uint8_t* lds, int lane, const uint8_t* in, int32_t inLimit, const void* anywhere)
+    {
+        ring = lds + lane * STRIDE;
+        inBase = (int32_t)((uintptr_t)in & (GRAN - 1));
+        inAligned = in - inBase;
+        lastV = inLimit > 0 ? ((inLimit + inBase - 1) & ~15) : 0;
+        safe = (const uint8_t*)anywhere;
+        loadedV = 0;
+        issueV = 0;
+        validBits = 0;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            ga[s] = u32x4{0, 0, 0, 0};
+            gb[s] = u32x4{0, 0, 0, 0};
+        }
+    }
+    // the granule requested NS trips ago enters the ring
+    template <int SLOT>
+    __device__ __forceinline__ void land()
+    {
+        const uint32_t have = (validBits >> SLOT) & 1u;
+        const int32_t slot = loadedV & (RING - 1);
+        if (have != 0) {  // (only stores inside the branch: no state to merge behind it)
+            *(u32x4*)(ring + slot) = ga[SLOT];
+            *(u32x4*)(ring + slot + 16) = gb[SLOT];
+            if (slot == 0) {
+                *(u32x4*)(ring + RING) = ga[SLOT];
+            }
+        }
+        loadedV += have != 0 ? GRAN : 0;
+        validBits &= ~(1u << SLOT);
+    }
+    // Requests the next granule if the ring has room for it behind virtual position v (everything below v is consumed).  The load
+    // instructions are executed by every lane on every trip -- lanes that want nothing read `safe`, all the same address -- so that the
+    // compiler can count: with a request on every trip, "all but the NS - 1 youngest have completed" is what `land` has to wait for.  (A
+    // request under a branch makes that count unknown and every wait a wait for everything.)  A 16-byte piece is read whole even where
+    // the stream starts or ends inside it: the bytes around the stream lie in the same aligned 16 bytes, hence on the same page, and no
+    // parse decision looks at them (positions at or beyond the stream's end only ever reach the general path, which reads the stream
+    // itself).  Pieces entirely beyond the end repeat the last one.
+    template <int SLOT>
+    __device__ __forceinline__ void issue(int32_t v, bool active)
+    {
+        const bool want = active && issueV + GRAN - RING <= v;
+        const int32_t a0 = issueV < lastV ? issueV : lastV;
+        const int32_t a1 = issueV + 16 < lastV ? issueV + 16 : lastV;
+        const uint8_t* p0 = want ? inAligned + a0 : safe;
+        const uint8_t* p1 = want ? inAligned + a1 : safe;
+        ga[SLOT] = *(const u32x4*)p0;
+        gb[SLOT] = *(const u32x4*)p1;
+        validBits |= want ? (1u << SLOT) : 0u;
+        issueV += want ? GRAN : 0;
+    }
+    // the stream continues at virtual position v, beyond everything requested so far: what is in flight is dropped
+    __device__ __forceinline__ void restart(int32_t v, bool doIt = true)
+    {
+        loadedV = doIt ? (v & ~(GRAN - 1)) : loadedV;
+        issueV = doIt ? loadedV : issueV;
+        validBits = doIt ? 0u : validBits;
+    }
+    __device__ __forceinline__ bool resident(int32_t v, int32_t n) const { return v + n <= loadedV; }
+    __device__ __forceinline__ uint32_t rd32(int32_t v) const
+    {
+        uint32_t x;
+        __builtin_memcpy(&x, ring + (v & (RING - 1)), 4);
+        return x;
+    }
+};
+
 // ---- lane-private exact copies ------------------------------------------------------------------------------------------------------
 // n bytes (n < 16) of v to dst, nothing else written
 __device__ __forceinline__ void store_exact16(uint8_t* dst, u32x4 v, int32_t n)
@@ -340,10 +434,10 @@ __device__ __forceinline__ void exec_block(const uint8_t* __restrict__ in, int32
 //   bytes below flushPos are in the output buffer (flushPos >= winBase, so every byte is readable from the one or the other).
 //   A batch takes as many records as fit CAP output bytes; a single record beyond that is moved straight between the global buffers by
 //   the whole wavefront and the window restarts behind it.
-constexpr int WIN = 4096;
 constexpr int CAP = 1920;          // output bytes of one batch
-constexpr int SLIDE_KEEP = 1024;   // history kept when the window slides (what is older is read from the output buffer)
+// WIN: bytes of the window; SLIDE_KEEP: history kept when the window slides (what is older is read from the output buffer)
 
+template <int WIN, int SLIDE_KEEP>
 struct WinIo {
     uint8_t* win;  // LDS, WIN + 16 bytes
     uint8_t* out;
@@ -470,14 +564,17 @@ struct WinIo {
         int32_t nb = (outPos - SLIDE_KEEP) & ~15;  // new base (16-aligned position)
         nb = nb > winBase ? nb : winBase;
         const int32_t n = outPos - nb;  // bytes to keep (<= SLIDE_KEEP + 15)
-        const int32_t i = lane * 16;
-        u32x4 v0 = u32x4{0, 0, 0, 0}, v1 = v0;
-        if (i < n) v0 = *(const u32x4*)(win + (nb - winBase) + i);
-        if (i + 1024 < n) v1 = *(const u32x4*)(win + (nb - winBase) + i + 1024);
-        wave_sync();
-        if (i < n) *(u32x4*)(win + i) = v0;
-        if (i + 1024 < n) *(u32x4*)(win + i + 1024) = v1;
-        wave_sync();
+        const int32_t shift = nb - winBase;
+        // towards lower addresses, 1 KiB per pass, the passes in ascending order: a pass reads before it writes, and what it overwrites
+        // lies below everything later passes read
+        for (int32_t base = 0; base < n; base += 1024) {  // (uniform)
+            const int32_t i = base + lane * 16;
+            u32x4 v0 = u32x4{0, 0, 0, 0};
+            if (i < n) v0 = *(const u32x4*)(win + shift + i);
+            wave_sync();
+            if (i < n) *(u32x4*)(win + i) = v0;
+            wave_sync();
+        }
         winBase = nb;
     }
 };
@@ -509,12 +606,12 @@ __device__ __forceinline__ uint64_t load_records(const uint64_t* __restrict__ ar
 
 // Same contract as exec_block; `win` = WIN + 16 bytes of LDS owned by this wavefront.  Software pipeline: while batch i is composed in
 // the window, the records of batch i + 2 and the literal / far-match bytes of batch i + 1 are on their way.
-template <int DBG = 0>  // DBG: timing aids (output not valid)
+template <int DBG = 0, int WIN = 4096, int SLIDE_KEEP = 1024>  // DBG: timing aids (output not valid)
 __device__ __forceinline__ void exec_block_ring(uint8_t* win, const uint8_t* __restrict__ in, int32_t inLen, uint8_t* out, int32_t outCap,
                                                 const uint64_t* __restrict__ arena, int32_t chunk, int32_t count, int lane)
 {
     const uint8_t* const inEnd = in + inLen;
-    WinIo io;
+    WinIo<WIN, SLIDE_KEEP> io;
     io.win = win;
     io.out = out;
     io.winBase = 0;

@@ -11,6 +11,8 @@
 //                        one atomic per wavefront and trip; a block whose records do not fit (arena exhausted) is handed to the ring
 //                        decoder afterwards (`only` filter).
 //   seq_execute_kernel   a wavefront per block: sx::exec_block.
+#include <type_traits>
+
 #include "achip_lanecopy.h"
 #include "achip_seqexec.h"
 
@@ -222,20 +224,341 @@ __global__ __launch_bounds__(64) void lz4_parse_kernel(BatchArgs a, sx::ArenaHea
     }
 }
 
-template <bool RING, int DBG = 0>
+// The same pass, restructured (the default; DESIGN 4c has the measurements).  Two things made the first version slow, neither of them
+// the amount of arithmetic: (1) its lanes refilled their input windows whenever they ran dry, so that every trip some lane waited for
+// a load another lane had just issued -- a wavefront waits for its memory operations in order, by count -- and the trip took one memory
+// latency; (2) a dozen divergent branches per sequence.  Here the input comes through sx::LaneFeed (loads in flight for NS trips, one
+// place per trip where they are requested and one where they land), and sequences that are nothing special -- no second length-extension
+// byte, not within the last bytes of either buffer, offset inside the output -- take a straight-line FAST PATH: for those every Java
+// check is known to pass (its conditions are exactly the complement of the Java loop's failure and last-literals branches).  Any other
+// sequence is parsed by lz4_parse_general: the Java loop body restated check by check, reading the stream directly.
+#if defined(__HIPCC__)
+#define ACHIP_EMU_COUNT(k, cond)
+#else
+extern "C" long long achip_emu_counters[16];
+#define ACHIP_EMU_COUNT(k, cond) achip_emu_counters[k] += (cond) ? 1 : 0
+#endif
+struct Lz4ParseState {
+    int32_t ip, op, st, eo, litEndPrev;
+    bool done, fallback;
+};
+
+// one sequence, the general way (M/lz4/Lz4RawDecompressor.java:59-195 without the copies); returns true when a record is to be emitted
+__device__ __forceinline__ bool lz4_parse_general(const uint8_t* __restrict__ in, Lz4ParseState& S, int32_t inLimit, int32_t outLimit, uint32_t& rLit, uint32_t& rMl, uint32_t& rOff,
+                                                  int32_t& litStart)
+{
+    const int32_t fastOutLimit = outLimit - 8;
+#define LZ4_FAIL(detail, off)                            \
+    {                                                    \
+        S.st = mk_status(ACHIP_CLASS_MALFORMED, detail); \
+        S.eo = (int32_t)(off);                           \
+        S.done = true;                                   \
+        return false;                                    \
+    }
+    int32_t ip = S.ip, op = S.op;
+    if (ip >= inLimit) {  // the loop condition :59
+        S.done = true;
+        return false;
+    }
+    const int32_t token = (int32_t)in[ip];
+    ip++;
+    int32_t lit = token >> 4;  // :62-77
+    if (lit == 0xF) {
+        if (ip >= inLimit) LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
+        int32_t v;
+        do {
+            v = (int32_t)in[ip];
+            ip++;
+            lit = (int32_t)((uint32_t)lit + (uint32_t)v);
+        } while (v == 255 && ip < inLimit - 15);
+    }
+    if (lit < 0) LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
+    const int64_t litEnd = (int64_t)ip + lit;
+    const int64_t litOutLimit = (int64_t)op + lit;
+    litStart = ip;
+    rLit = (uint32_t)lit;
+    rMl = 0;
+    rOff = 0;
+    if (litOutLimit > fastOutLimit - 4 || litEnd > inLimit - 8) {  // :82-96 last literals
+        if (litOutLimit > outLimit) LZ4_FAIL(ACHIP_D_LZ4_LAST_LITERAL_OUTSIDE, ip);
+        if (litEnd != inLimit) LZ4_FAIL(ACHIP_D_LZ4_INPUT_NOT_CONSUMED, ip);
+        S.ip = ip + lit;
+        S.op = op + lit;
+        S.done = true;
+        return true;
+    }
+    ip += lit;
+    op += lit;
+    const int32_t offset = (int32_t)in[ip] | ((int32_t)in[ip + 1] << 8);  // :113-119
+    ip += 2;
+    if (offset == 0 || offset > op) LZ4_FAIL(ACHIP_D_LZ4_OFFSET_OUTSIDE, ip);
+    int32_t ml = token & 0xF;  // :122-138
+    if (ml == 0xF) {
+        int32_t v;
+        do {
+            if (ip > inLimit - 5) LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
+            v = (int32_t)in[ip];
+            ip++;
+            ml = (int32_t)((uint32_t)ml + (uint32_t)v);
+        } while (v == 255);
+    }
+    ml = (int32_t)((uint32_t)ml + 4u);
+    if (ml < 0) LZ4_FAIL(ACHIP_D_LZ4_MALFORMED, ip);
+    const int64_t matchOutLimit = (int64_t)op + ml;
+    if (matchOutLimit > fastOutLimit - 4 && matchOutLimit > outLimit - 5) LZ4_FAIL(ACHIP_D_LZ4_LAST_5_LITERALS, ip);  // :168-171
+#undef LZ4_FAIL
+    rMl = (uint32_t)ml;
+    rOff = (uint32_t)offset;
+    S.ip = ip;
+    S.op = op + ml;
+    return true;
+}
+
+// largest multiple of off (1..65535) that is <= x (off <= x <= 65535)
+__device__ __forceinline__ int32_t largest_multiple(int32_t off, int32_t x)
+{
+    int32_t m = (int32_t)((float)x / (float)off);  // within one of the quotient (both below 2^24: exact operands)
+    m -= m * off > x ? 1 : 0;
+    m += (m + 1) * off <= x ? 1 : 0;
+    return m * off;
+}
+
+template <int DBG>
+__global__ __launch_bounds__(64) void lz4_parse2_kernel(BatchArgs a, sx::ArenaHeader* hdr, sx::BlockMeta* meta, int32_t* only, uint64_t* arena, int32_t maxChunks, const int32_t* stats)
+{
+    if (stats != nullptr && lz4_pick(stats, a.nBlocks) != LZ4_PICK_TWOPASS) {  // auto mode: the ring decoder takes this batch
+        return;
+    }
+    constexpr int NS = 4;
+    using Feed = sx::LaneFeed<NS>;
+    __shared__ __attribute__((aligned(16))) uint8_t ldsIn[Feed::STRIDE * 64];
+    const int lane = threadIdx.x;
+    const int64_t block = (int64_t)blockIdx.x * 64 + lane;
+    const bool have = block < a.nBlocks;
+    const uint8_t* in = have ? a.srcBase + a.srcOff[block] : a.srcBase;
+    const int32_t inLimit = have ? a.srcLen[block] : 0;
+    const int32_t outLimit = have ? a.dstCap[block] : 0;
+
+    Feed L;
+    {
+        // what lanes that request nothing read: one address per WAVEFRONT (one request per load instruction, hot in this CU's L1) -- the
+        // start of the first non-empty stream of the wavefront; a single address for the whole grid would queue every wavefront of the
+        // chip at one L2 channel
+        const unsigned long long nonEmpty = __ballot(inLimit > 0);
+        const uint8_t* anywhere = (const uint8_t*)hdr;
+        if (nonEmpty != 0) {  // (uniform)
+            // (an offset from the batch's base travels, not a pointer: the loads stay global_load, not flat_load)
+            anywhere = a.srcBase + (int64_t)sx::shfl_u64((uint64_t)((in - a.srcBase) - (int64_t)((uintptr_t)in & 31)), __builtin_ctzll(nonEmpty));
+        }
+        L.init(ldsIn, lane, in, inLimit, anywhere);
+    }
+    Lz4ParseState S;
+    S.ip = 0;
+    S.op = 0;
+    S.st = 0;
+    S.eo = 0;
+    S.litEndPrev = 0;
+    S.done = !have;
+    S.fallback = false;
+    if (have) {
+        if (inLimit == 0) {  // :48-50
+            S.st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_LZ4_INPUT_EMPTY);
+            S.done = true;
+        }
+        else if (outLimit == 0) {  // :52-57 (the Java method returns -1 here)
+            if (!(inLimit == 1 && in[0] == 0)) {
+                S.st = mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_LZ4_EMPTY_OUTPUT);
+            }
+            S.done = true;
+        }
+    }
+    const int32_t B = L.inBase;
+    const int32_t fastIn = inLimit - 8;        // a literal run may end here at the latest (:82)
+    const int32_t fastOut = outLimit - 8 - 4;  // a match may end here at the latest (:82, :168)
+
+    // ---- state of the sequence under way (every flag is an int in a vector register and every common-path update a select: flags
+    // kept as lane masks cost three scalar instructions each at every branch they live across -- the first version of this loop spent
+    // more scalar than vector instructions) ----
+    // phase 0: at its token; 1: token read (tMl0, tLit, tStart), at the offset field q; 2: parsed, its pieces are being emitted
+    int32_t phase = 0;
+    uint32_t tMl0 = 0;
+    int32_t tLit = 0, tStart = 0, q = 0;
+    int32_t sLit = 0, sLitPos = 0, sMl = 0, sOff = 0, sK = 0;  // literal bytes left, where they are, match bytes left, the offset, match pieces emitted
+    int32_t sLast = 0;                                         // the block ends behind this sequence
+    int32_t finished = S.done ? 1 : 0;                         // nothing more to emit
+    int32_t fallback = 0;
+    // ---- the record output: exactly one record per lane and trip (an empty one when there is nothing to say), eight trips to a
+    // 64-byte piece, kept in registers ----
+    uint64_t rec[8];
+    int32_t groupAny = 0;  // this group of eight holds a record of this lane
+    int32_t firstChunk = -1, chunk = -1, fill = sx::CHUNK_RECS, count = 0;
+
+    auto trip = [&](auto tTag) {
+        constexpr int T = decltype(tTag)::value;
+        constexpr int SLOT = T % NS;
+        L.template land<SLOT>();
+        const bool active = finished == 0;
+        // ---- phase 0: the token (computed by every lane from whatever its ring holds there; committed where it applies) ----
+        const int32_t v0 = S.ip + B;
+        const uint32_t w = L.rd32(v0);
+        const uint32_t token = w & 0xFF;
+        const uint32_t lit0 = token >> 4;
+        const uint32_t e1 = (w >> 8) & 0xFF;
+        const bool litExt = lit0 == 0xF;
+        const int32_t nLit = (int32_t)(litExt ? 15u + e1 : lit0);
+        const int32_t nStart = S.ip + (litExt ? 2 : 1);
+        const int32_t nQ = nStart + nLit;
+        const bool do0 = active && phase == 0 && L.resident(v0, 4);
+        const bool gen0 = (litExt && e1 == 255) || nQ > fastIn;
+        const bool ok0 = do0 && !gen0;
+        tMl0 = ok0 ? (token & 0xF) : tMl0;
+        tLit = ok0 ? nLit : tLit;
+        tStart = ok0 ? nStart : tStart;
+        q = ok0 ? nQ : q;
+        phase = ok0 ? 1 : phase;
+        L.restart(nQ + B, ok0 && nQ + B >= L.issueV + 64);  // a literal run that reaches well beyond everything requested: continue there
+        // ---- phase 1: the offset field ----
+        const int32_t v1 = q + B;
+        const uint32_t x = L.rd32(v1);
+        const int32_t offset = (int32_t)(x & 0xFFFF);
+        const uint32_t e2 = (x >> 16) & 0xFF;
+        const bool mlExt = tMl0 == 0xF;
+        const int32_t ml = (int32_t)(mlExt ? 15u + e2 : tMl0) + 4;
+        const int32_t opLit = S.op + tLit;
+        const int32_t opEnd = opLit + ml;
+        const bool do1 = active && phase == 1 && L.resident(v1, 4);
+        const bool gen1 = (mlExt && e2 == 255) || offset == 0 || offset > opLit || opEnd > fastOut;
+        const bool ok1 = do1 && !gen1;
+        sLit = ok1 ? tLit : sLit;
+        sLitPos = ok1 ? tStart : sLitPos;
+        sMl = ok1 ? ml : sMl;
+        sOff = ok1 ? offset : sOff;
+        sK = ok1 ? 0 : sK;
+        sLast = ok1 ? 0 : sLast;
+        S.ip = ok1 ? q + (mlExt ? 3 : 2) : S.ip;
+        S.op = ok1 ? opEnd : S.op;
+        phase = ok1 ? 2 : (do1 ? 0 : phase);
+        if ((do0 && gen0) || (do1 && gen1)) {  // (rare) from the token again, reading the stream directly
+            uint32_t rLit = 0, rMl = 0, rOff = 0;
+            int32_t rStart = 0;
+            const bool emit = lz4_parse_general(in, S, inLimit, outLimit, rLit, rMl, rOff, rStart);
+            sLit = (int32_t)rLit;
+            sLitPos = rStart;
+            sMl = (int32_t)rMl;
+            sOff = (int32_t)rOff;
+            sK = 0;
+            sLast = S.done ? 1 : 0;
+            phase = emit ? 2 : 0;
+            finished = emit ? 0 : 1;  // (no record: the end of the block, or an error -- S.st)
+            L.restart(S.ip + B, emit && !S.done && S.ip + B >= L.issueV + 64);
+        }
+        // ---- phase 2: one piece -- at most 16 literal bytes and, behind a sequence's last literal bytes, at most 16 match bytes.  A
+        // match's later pieces name the largest multiple of its offset that stays inside the match's periodic source region
+        // [start - offset, ..): the same bytes, but never the output of the piece before (no chains of dependent pieces) ----
+        const bool do2 = finished == 0 && phase == 2;
+        const int32_t pl = sLit < 16 ? sLit : 16;
+        const int32_t pm = sLit > 16 ? 0 : (sMl < 16 ? sMl : 16);
+        const int32_t xm = 16 * sK + sOff;
+        const int32_t o = sK > 0 ? largest_multiple(sOff > 0 ? sOff : 1, xm < 65535 ? xm : 65535) : sOff;
+        const int32_t skip = sLitPos - S.litEndPrev;
+        const bool fb = do2 && skip > sx::MAX_SKIP;  // (a gap beyond the record field: megabytes of length bytes) the ring decoder takes the block
+        const bool ok2 = do2 && !fb;
+        rec[T] = ok2 ? sx::rec_pack((uint32_t)pl, (uint32_t)pm, pm > 0 ? (uint32_t)o : 0u, (uint32_t)skip) : 0ull;
+        groupAny |= ok2 ? 1 : 0;
+        fallback |= fb ? 1 : 0;
+        S.litEndPrev = ok2 ? sLitPos + pl : S.litEndPrev;
+        sLitPos += ok2 ? pl : 0;
+        sLit -= ok2 ? pl : 0;
+        sMl -= ok2 ? pm : 0;
+        sK += ok2 && pm > 0 ? 1 : 0;
+        const bool seqEnd = ok2 && sLit == 0 && sMl == 0;
+        phase = seqEnd ? 0 : phase;
+        finished |= (seqEnd && sLast != 0) || fb ? 1 : 0;
+        L.template issue<SLOT>((phase == 1 ? q : S.ip) + B, finished == 0);
+    };
+
+    while (__ballot(finished == 0) != 0) {  // (uniform)
+        groupAny = 0;
+        trip(std::integral_constant<int, 0>{});
+        trip(std::integral_constant<int, 1>{});
+        trip(std::integral_constant<int, 2>{});
+        trip(std::integral_constant<int, 3>{});
+        trip(std::integral_constant<int, 4>{});
+        trip(std::integral_constant<int, 5>{});
+        trip(std::integral_constant<int, 6>{});
+        trip(std::integral_constant<int, 7>{});
+        // ---- the group leaves: a chunk for every lane that needs one (one atomic per wavefront), then one 64-byte piece per lane ----
+        const bool flush = groupAny != 0 && fallback == 0;
+        const bool need = flush && fill == sx::CHUNK_RECS;
+        const unsigned long long nm = __ballot(need);
+        if (nm != 0) {  // (uniform)
+            int32_t base = 0;
+            if (lane == __builtin_ctzll(nm)) {
+                base = atomicAdd(&hdr->nextChunk, (int32_t)__popcll(nm));
+            }
+            base = sx::wave_bcast(base, __builtin_ctzll(nm));
+            if (need) {
+                const int32_t c = base + (int32_t)__popcll(nm & ((1ull << lane) - 1));
+                if (c >= maxChunks) {  // the arena is exhausted: the ring decoder takes the block
+                    fallback = 1;
+                    finished = 1;
+                }
+                else {
+                    if (chunk >= 0) {
+                        arena[(int64_t)chunk * sx::CHUNK_SLOTS + sx::CHUNK_RECS] = (uint64_t)(uint32_t)c;  // link
+                    }
+                    else {
+                        firstChunk = c;
+                    }
+                    chunk = c;
+                    fill = 0;
+                }
+            }
+        }
+        if (flush && fallback == 0) {
+            if (DBG != 1) {
+                uint8_t* const dst = (uint8_t*)(arena + (int64_t)chunk * sx::CHUNK_SLOTS + fill);
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    st16(dst + 8 * k, u32x4{(uint32_t)rec[k], (uint32_t)(rec[k] >> 32), (uint32_t)rec[k + 1], (uint32_t)(rec[k + 1] >> 32)});
+                }
+            }
+            fill += 8;
+            count += 8;
+        }
+    }
+    if (have) {
+        if (fallback != 0) {
+            only[block] = 1;
+            meta[block].firstChunk = 0;
+            meta[block].count = 0;
+            atomicAdd(&hdr->fallbackBlocks, 1);
+        }
+        else {
+            only[block] = 0;
+            meta[block].firstChunk = firstChunk < 0 ? 0 : firstChunk;
+            meta[block].count = S.st == 0 ? count : 0;
+            a.outLen[block] = S.st == 0 ? S.op : 0;
+            a.status[block] = S.st;
+            a.errOffset[block] = (int64_t)S.eo;
+        }
+    }
+}
+
+template <bool RING, int DBG = 0, int WIN = 4096, int KEEP = 1024, int PAD = 0>
 __global__ __launch_bounds__(64) void seq_execute_kernel(BatchArgs a, const sx::BlockMeta* meta, const uint64_t* arena, const int32_t* stats, int32_t shortLimit)
 {
     if (stats != nullptr && lz4_pick(stats, a.nBlocks, shortLimit) != LZ4_PICK_TWOPASS) {  // auto mode: the ring decoder takes this batch
         return;
     }
-    __shared__ __attribute__((aligned(16))) uint8_t ring[RING ? sx::WIN + 16 : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[(RING ? WIN + 16 : 16) + PAD];
     const int64_t block = blockIdx.x;
     const sx::BlockMeta m = meta[block];
     if (m.count <= 0) {
         return;
     }
     if constexpr (RING) {
-        sx::exec_block_ring<DBG>(ring, a.srcBase + a.srcOff[block], a.srcLen[block], a.dstBase + a.dstOff[block], a.dstCap[block], arena, m.firstChunk, m.count, (int)threadIdx.x);
+        sx::exec_block_ring<DBG, WIN, KEEP>(ring, a.srcBase + a.srcOff[block], a.srcLen[block], a.dstBase + a.dstOff[block], a.dstCap[block], arena, m.firstChunk, m.count, (int)threadIdx.x);
     }
     else {
         sx::exec_block(a.srcBase + a.srcOff[block], a.srcLen[block], a.dstBase + a.dstOff[block], a.dstCap[block], arena, m.firstChunk, m.count, (int)threadIdx.x);
@@ -253,6 +576,19 @@ int64_t lz4_twopass_scratch_bytes(int32_t nBlocks)
 // the execute pass (shared with snappy_decompress_v5.hip): a wavefront per block
 hipError_t launch_seq_execute(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant, const int32_t* stats, int32_t shortLimit)
 {
+#define ACHIP_EXEC_VARIANT(id, ...)                                                                                                                              \
+    if (execVariant == id) {                                                                                                                                      \
+        hipLaunchKernelGGL((seq_execute_kernel<__VA_ARGS__>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, shortLimit); \
+        return hipGetLastError();                                                                                                                                 \
+    }
+    ACHIP_EXEC_VARIANT(110, true, 0, 8192, 4096)
+    ACHIP_EXEC_VARIANT(111, true, 0, 8192, 2048)
+    ACHIP_EXEC_VARIANT(112, true, 0, 16384, 8192)
+    ACHIP_EXEC_VARIANT(113, true, 0, 4096, 1024, 4096)
+    ACHIP_EXEC_VARIANT(114, true, 0, 4096, 1024, 8192)
+    ACHIP_EXEC_VARIANT(115, true, 0, 4096, 2048)
+    ACHIP_EXEC_VARIANT(116, true, 0, 12288, 8192)
+#undef ACHIP_EXEC_VARIANT
     if (execVariant == 0) {
         hipLaunchKernelGGL(seq_execute_kernel<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, shortLimit);
     }
@@ -300,11 +636,15 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream,
     const int32_t maxChunks = (int32_t)(chunks > 0x7FFFFFFF ? 0x7FFFFFFF : chunks);
     hipError_t e = hipMemsetAsync(hdr, 0, sizeof(sx::ArenaHeader), stream);
     if (e != hipSuccess) return e;
-    if (execVariant == 201) {
-        hipLaunchKernelGGL(lz4_parse_kernel<1>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+    if (execVariant >= 1000) {  // the first parser (kept for comparison: decompress.exec_variant = 1000 + executor variant)
+        execVariant -= 1000;
+        hipLaunchKernelGGL(lz4_parse_kernel<0>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+    }
+    else if (execVariant == 201) {
+        hipLaunchKernelGGL(lz4_parse2_kernel<1>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
     }
     else {
-        hipLaunchKernelGGL(lz4_parse_kernel<0>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+        hipLaunchKernelGGL(lz4_parse2_kernel<0>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
     }
     e = launch_seq_execute(a, stream, meta, arena, execVariant, stats, 12);
     if (e != hipSuccess) return e;

@@ -2,6 +2,7 @@
 // uses no cross-lane operation: the GS=1 instantiations of the ring decoders and the lane-per-block decoders with an LDS window).
 #include "hip/hip_runtime.h"
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+extern "C" { long long achip_emu_counters[16]; }  // development counters of kernels under emulation (ACHIP_EMU_COUNT)
 #include "../../aircompressor_amd/csrc/lz4_decompress_v2.hip"
 #include "../../aircompressor_amd/csrc/snappy_decompress_v2.hip"
 #include "../../aircompressor_amd/csrc/lz4_decompress_v6.hip"
