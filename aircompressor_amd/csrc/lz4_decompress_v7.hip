@@ -15,6 +15,7 @@
 
 #include "achip_lanecopy.h"
 #include "achip_seqexec.h"
+#include "achip_seqexec2.h"
 
 namespace achip {
 
@@ -565,11 +566,27 @@ __global__ __launch_bounds__(64) void seq_execute_kernel(BatchArgs a, const sx::
     }
 }
 
+// the second executor (achip_seqexec2.h): pieces of at most 16 + 16 bytes, every global load one batch ahead
+template <int DBG = 0, int WIN = sx2::WIN_DEFAULT, int WAVES = 0>
+__global__ __launch_bounds__(64, WAVES) void seq_execute2_kernel(BatchArgs a, const sx::BlockMeta* meta, const uint64_t* arena, const int32_t* stats, int32_t shortLimit)
+{
+    if (stats != nullptr && lz4_pick(stats, a.nBlocks, shortLimit) != LZ4_PICK_TWOPASS) {  // auto mode: the ring decoder takes this batch
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) uint8_t win[WIN + 16];
+    const int64_t block = blockIdx.x;
+    const sx::BlockMeta m = meta[block];
+    if (m.count <= 0) {
+        return;
+    }
+    sx2::exec_block<DBG, WIN>(win, a.srcBase + a.srcOff[block], a.srcLen[block], a.dstBase + a.dstOff[block], arena, m.firstChunk, m.count, (int)threadIdx.x);
+}
+
 // scratch: [header 256 B][meta n x 8][only n x 4][arena, 4 KiB aligned]
 int64_t lz4_twopass_scratch_bytes(int32_t nBlocks)
 {
     const int64_t fixed = 4096 + (((int64_t)nBlocks * 12 + 4095) & ~4095LL);
-    int64_t arena = (int64_t)nBlocks * 65536 + (64LL << 20);
+    int64_t arena = (int64_t)nBlocks * 65536 + (64LL << 20) + 4096;  // (+ the chunk the executor's record loads may run into)
     return fixed + arena;
 }
 
@@ -632,7 +649,7 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream,
     int32_t* only = (int32_t*)(s + 4096 + (int64_t)a.nBlocks * 8);
     const int64_t fixed = 4096 + (((int64_t)a.nBlocks * 12 + 4095) & ~4095LL);
     uint64_t* arena = (uint64_t*)(s + fixed);
-    const int64_t chunks = (scratchBytes - fixed) / (sx::CHUNK_SLOTS * 8);
+    const int64_t chunks = (scratchBytes - fixed) / (sx::CHUNK_SLOTS * 8) - 1;  // (one to spare: the executor's unconditional record loads)
     const int32_t maxChunks = (int32_t)(chunks > 0x7FFFFFFF ? 0x7FFFFFFF : chunks);
     hipError_t e = hipMemsetAsync(hdr, 0, sizeof(sx::ArenaHeader), stream);
     if (e != hipSuccess) return e;
@@ -646,7 +663,21 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream,
     else {
         hipLaunchKernelGGL(lz4_parse2_kernel<0>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
     }
-    e = launch_seq_execute(a, stream, meta, arena, execVariant, stats, 12);
+    if (execVariant == 2 || (execVariant >= 120 && execVariant <= 129)) {  // the second executor (the default): needs the pieces of lz4_parse2_kernel
+        const dim3 grid((unsigned)a.nBlocks), wg(64);
+        if (execVariant == 121) hipLaunchKernelGGL(seq_execute2_kernel<1>, grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
+        else if (execVariant == 122) hipLaunchKernelGGL(seq_execute2_kernel<2>, grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
+        else if (execVariant == 124) hipLaunchKernelGGL((seq_execute2_kernel<0, 8192>), grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
+        else if (execVariant == 125) hipLaunchKernelGGL((seq_execute2_kernel<0, 16384>), grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
+        else if (execVariant == 126) hipLaunchKernelGGL((seq_execute2_kernel<0, 4096, 8>), grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
+        else if (execVariant == 127) hipLaunchKernelGGL((seq_execute2_kernel<0, 8192, 8>), grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
+        else if (execVariant == 123) hipLaunchKernelGGL(seq_execute2_kernel<3>, grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
+        else hipLaunchKernelGGL(seq_execute2_kernel<0>, grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
+        e = hipGetLastError();
+    }
+    else {
+        e = launch_seq_execute(a, stream, meta, arena, execVariant, stats, 12);
+    }
     if (e != hipSuccess) return e;
     BatchArgs f = a;
     f.only = only;

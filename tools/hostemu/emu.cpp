@@ -14,14 +14,15 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
                          const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n)
 {
     achip::BatchArgs a{srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, n, 0};
-    if (op >= 20 && op <= 23) {  // 22 / 23: the same with the executor that writes straight to the output buffer
-        const bool direct = op >= 22;
-        op -= direct ? 2 : 0;  // two-pass LZ4: lane-per-block parse + wavefront-per-block execute (op 21: a tiny arena, so that blocks fall back)
+    if (op >= 20 && op <= 25) {  // two-pass LZ4: lane-per-block parse + wavefront-per-block execute; odd ops: a tiny arena, so that blocks fall back
+        // 20 / 21: the first executor (LDS window that slides); 22 / 23: the executor that writes straight to the output buffer; 24 / 25: the second executor
+        const int execVariant = op >= 24 ? 2 : (op >= 22 ? 0 : 1);
+        const bool tiny = (op & 1) != 0;
         static std::vector<uint8_t> scratch;
-        const int64_t bytes = op == 21 ? 4096 + ((n * 12 + 4095) & ~4095LL) + 3 * 4096 : achip::lz4_twopass_scratch_bytes(n);
+        const int64_t bytes = tiny ? 4096 + ((n * 12 + 4095) & ~4095LL) + 4 * 4096 : achip::lz4_twopass_scratch_bytes(n);
         scratch.assign((size_t)bytes, 0xCD);
         a.ringPad = 16;
-        return achip::launch_lz4_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, direct ? 0 : 1, nullptr);
+        return achip::launch_lz4_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, execVariant, nullptr);
     }
     if (op == 30 || op == 31) {  // two-pass Snappy (31: a tiny arena, so that blocks fall back)
         static std::vector<uint8_t> scratch;
