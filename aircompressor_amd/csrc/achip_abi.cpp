@@ -24,6 +24,8 @@ hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream
 hipError_t launch_lz4_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
 int64_t lz4_twopass_scratch_bytes(int32_t nBlocks);
+int64_t lz4_twopass_scratch_bytes_min(int32_t nBlocks);
+int64_t snappy_twopass_scratch_bytes(int32_t nBlocks);
 hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
 hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
@@ -151,6 +153,17 @@ achip::BatchArgs make_args(const void* srcBase, const int64_t* srcOff, const int
     return a;
 }
 
+int32_t ensure_scratch(achip_ctx* ctx, int64_t bytes);
+// the two-pass decoders' scratch: the full record arena if the device has it, else what it takes to run at all (blocks whose records do
+// not fit are decoded by the ring decoder)
+int32_t ensure_scratch_prefer(achip_ctx* ctx, int64_t want, int64_t atLeast)
+{
+    if (ensure_scratch(ctx, want) == 0) {
+        return 0;
+    }
+    return ensure_scratch(ctx, atLeast);
+}
+
 int32_t ensure_scratch(achip_ctx* ctx, int64_t bytes)
 {
     if (bytes <= ctx->scratchBytes) {
@@ -221,7 +234,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 // sequence lengths, every candidate decoder is launched and the ones not chosen return at once.  Mixed or short-sequence
                 // batches go to the two-pass decoder (parse to records + a wavefront per block), the rest to the rings.
                 // scratch: [probe statistics: the first 4 KiB][two-pass header, meta, arena]
-                int32_t r = ensure_scratch(ctx, 4096 + achip::lz4_twopass_scratch_bytes(a.nBlocks));
+                int32_t r = ensure_scratch_prefer(ctx, 4096 + achip::lz4_twopass_scratch_bytes(a.nBlocks), 4096 + achip::lz4_twopass_scratch_bytes_min(a.nBlocks));
                 if (r < 0) return r;
                 int32_t* stats = (int32_t*)ctx->scratch;
                 ctx->lastLz4dAuto = true;
@@ -237,7 +250,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 break;
             }
             if (ctx->lz4dVariant == 7) {  // two passes: parse to records, a wavefront per block executes them (lz4_decompress_v7.hip)
-                int32_t r = ensure_scratch(ctx, achip::lz4_twopass_scratch_bytes(a.nBlocks));
+                int32_t r = ensure_scratch_prefer(ctx, achip::lz4_twopass_scratch_bytes(a.nBlocks), achip::lz4_twopass_scratch_bytes_min(a.nBlocks));
                 if (r < 0) return r;
                 ctx->lastTwopass = true;
                 e = achip::launch_lz4_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->lz4dGroup, ctx->ringClass, ctx->execVariant, nullptr);
@@ -250,7 +263,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
         case ACHIP_OP_LZ4_COMPRESS: e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint); break;
         case ACHIP_OP_SNAPPY_DECOMPRESS:
             if (ctx->snappydVariant == 5 && a.nBlocks >= ctx->lz4dAutoMinBlocks) {  // auto, as for LZ4
-                int32_t r = ensure_scratch(ctx, 4096 + achip::lz4_twopass_scratch_bytes(a.nBlocks));
+                int32_t r = ensure_scratch_prefer(ctx, 4096 + achip::snappy_twopass_scratch_bytes(a.nBlocks), 4096 + achip::lz4_twopass_scratch_bytes_min(a.nBlocks));
                 if (r < 0) return r;
                 int32_t* stats = (int32_t*)ctx->scratch;
                 ctx->lastLz4dAuto = true;
@@ -266,7 +279,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 break;
             }
             if (ctx->snappydVariant == 7) {  // two passes (snappy_decompress_v5.hip)
-                int32_t r = ensure_scratch(ctx, achip::lz4_twopass_scratch_bytes(a.nBlocks));
+                int32_t r = ensure_scratch_prefer(ctx, achip::snappy_twopass_scratch_bytes(a.nBlocks), achip::lz4_twopass_scratch_bytes_min(a.nBlocks));
                 if (r < 0) return r;
                 ctx->lastTwopass = true;
                 e = achip::launch_snappy_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->snappydGroup, ctx->ringClass, ctx->execVariant, nullptr);

@@ -254,6 +254,15 @@ struct LaneFeed {
     }
 };
 
+// largest multiple of off (1..65535) that is <= x (off <= x <= 65535)
+__device__ __forceinline__ int32_t largest_multiple(int32_t off, int32_t x)
+{
+    int32_t m = (int32_t)((float)x / (float)off);  // within one of the quotient (both below 2^24: exact operands)
+    m -= m * off > x ? 1 : 0;
+    m += (m + 1) * off <= x ? 1 : 0;
+    return m * off;
+}
+
 // ---- lane-private exact copies ------------------------------------------------------------------------------------------------------
 // n bytes (n < 16) of v to dst, nothing else written
 __device__ __forceinline__ void store_exact16(uint8_t* dst, u32x4 v, int32_t n)

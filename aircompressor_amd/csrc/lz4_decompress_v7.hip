@@ -315,15 +315,6 @@ __device__ __forceinline__ bool lz4_parse_general(const uint8_t* __restrict__ in
     return true;
 }
 
-// largest multiple of off (1..65535) that is <= x (off <= x <= 65535)
-__device__ __forceinline__ int32_t largest_multiple(int32_t off, int32_t x)
-{
-    int32_t m = (int32_t)((float)x / (float)off);  // within one of the quotient (both below 2^24: exact operands)
-    m -= m * off > x ? 1 : 0;
-    m += (m + 1) * off <= x ? 1 : 0;
-    return m * off;
-}
-
 template <int DBG>
 __global__ __launch_bounds__(64) void lz4_parse2_kernel(BatchArgs a, sx::ArenaHeader* hdr, sx::BlockMeta* meta, int32_t* only, uint64_t* arena, int32_t maxChunks, const int32_t* stats)
 {
@@ -460,7 +451,7 @@ __global__ __launch_bounds__(64) void lz4_parse2_kernel(BatchArgs a, sx::ArenaHe
         const int32_t pl = sLit < 16 ? sLit : 16;
         const int32_t pm = sLit > 16 ? 0 : (sMl < 16 ? sMl : 16);
         const int32_t xm = 16 * sK + sOff;
-        const int32_t o = sK > 0 ? largest_multiple(sOff > 0 ? sOff : 1, xm < 65535 ? xm : 65535) : sOff;
+        const int32_t o = sK > 0 ? sx::largest_multiple(sOff > 0 ? sOff : 1, xm < 65535 ? xm : 65535) : sOff;
         const int32_t skip = sLitPos - S.litEndPrev;
         const bool fb = do2 && skip > sx::MAX_SKIP;  // (a gap beyond the record field: megabytes of length bytes) the ring decoder takes the block
         const bool ok2 = do2 && !fb;
@@ -583,12 +574,16 @@ __global__ __launch_bounds__(64, WAVES) void seq_execute2_kernel(BatchArgs a, co
 }
 
 // scratch: [header 256 B][meta n x 8][only n x 4][arena, 4 KiB aligned]
-int64_t lz4_twopass_scratch_bytes(int32_t nBlocks)
+// (perBlock: arena bytes per block -- 8 bytes per record.  Pieces of <= 16 + 16 bytes: text-like 64 KiB blocks make 6 000 .. 8 500 LZ4 records and
+// 8 500 .. 11 500 Snappy records, a few percent of them empty ones from trips a lane sat out; blocks that do not fit go to the ring decoder.)
+int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock)
 {
     const int64_t fixed = 4096 + (((int64_t)nBlocks * 12 + 4095) & ~4095LL);
-    int64_t arena = (int64_t)nBlocks * 65536 + (64LL << 20) + 4096;  // (+ the chunk the executor's record loads may run into)
+    int64_t arena = (int64_t)nBlocks * perBlock + (64LL << 20) + 4096;  // (+ the chunk the executor's record loads may run into)
     return fixed + arena;
 }
+int64_t lz4_twopass_scratch_bytes(int32_t nBlocks) { return twopass_scratch_bytes(nBlocks, 98304); }
+int64_t lz4_twopass_scratch_bytes_min(int32_t nBlocks) { return twopass_scratch_bytes(nBlocks, 32768); }
 
 // the execute pass (shared with snappy_decompress_v5.hip): a wavefront per block
 hipError_t launch_seq_execute(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant, const int32_t* stats, int32_t shortLimit)
@@ -636,6 +631,19 @@ hipError_t launch_seq_execute(const BatchArgs& a, hipStream_t stream, const sx::
     return hipGetLastError();
 }
 
+// the second executor (shared with snappy_decompress_v5.hip); execVariant 2 = the product, 121..127 = timing aids and window sizes
+hipError_t launch_seq_execute2(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant, const int32_t* stats, int32_t shortLimit)
+{
+    const dim3 grid((unsigned)a.nBlocks), wg(64);
+    if (execVariant == 121) hipLaunchKernelGGL(seq_execute2_kernel<1>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
+    else if (execVariant == 122) hipLaunchKernelGGL(seq_execute2_kernel<2>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
+    else if (execVariant == 123) hipLaunchKernelGGL(seq_execute2_kernel<3>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
+    else if (execVariant == 124) hipLaunchKernelGGL((seq_execute2_kernel<0, 8192>), grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
+    else if (execVariant == 125) hipLaunchKernelGGL((seq_execute2_kernel<0, 4096, 7>), grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
+    else hipLaunchKernelGGL(seq_execute2_kernel<0>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
+    return hipGetLastError();
+}
+
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 
 hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats)
@@ -664,16 +672,7 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream,
         hipLaunchKernelGGL(lz4_parse2_kernel<0>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
     }
     if (execVariant == 2 || (execVariant >= 120 && execVariant <= 129)) {  // the second executor (the default): needs the pieces of lz4_parse2_kernel
-        const dim3 grid((unsigned)a.nBlocks), wg(64);
-        if (execVariant == 121) hipLaunchKernelGGL(seq_execute2_kernel<1>, grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
-        else if (execVariant == 122) hipLaunchKernelGGL(seq_execute2_kernel<2>, grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
-        else if (execVariant == 124) hipLaunchKernelGGL((seq_execute2_kernel<0, 8192>), grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
-        else if (execVariant == 125) hipLaunchKernelGGL((seq_execute2_kernel<0, 16384>), grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
-        else if (execVariant == 126) hipLaunchKernelGGL((seq_execute2_kernel<0, 4096, 8>), grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
-        else if (execVariant == 127) hipLaunchKernelGGL((seq_execute2_kernel<0, 8192, 8>), grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
-        else if (execVariant == 123) hipLaunchKernelGGL(seq_execute2_kernel<3>, grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
-        else hipLaunchKernelGGL(seq_execute2_kernel<0>, grid, wg, 0, stream, a, (const sx::BlockMeta*)meta, (const uint64_t*)arena, stats, 12);
-        e = hipGetLastError();
+        e = launch_seq_execute2(a, stream, meta, arena, execVariant, stats, 12);
     }
     else {
         e = launch_seq_execute(a, stream, meta, arena, execVariant, stats, 12);

@@ -7,6 +7,8 @@
 // same 16-byte window.  Elements become records {literal run, copy} : a run and the copy behind it share one, a copy behind a copy has
 // an empty run, a run behind a run an empty copy.  The executor counts compressed positions from the block's first byte: the length
 // preamble is part of the first record's `skip`.
+#include <type_traits>
+
 #include "achip_lanecopy.h"
 #include "achip_seqexec.h"
 
@@ -238,11 +240,336 @@ __global__ __launch_bounds__(64) void snappy_parse_kernel(BatchArgs a, sx::Arena
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The parse pass, second version (the default): the structure of lz4_parse2_kernel (lz4_decompress_v7.hip has the reasons) -- the
+// stream through sx::LaneFeed (loads in flight for four trips), exactly one record per lane and trip kept in registers, flags in vector
+// registers and a select-only common path, sequences cut into pieces of at most 16 literal + 16 copy bytes for the second executor.
+// A trip looks at the element at ip and, when that is a literal run of at most 16 bytes, at the element behind it: a run and the copy
+// behind it make one record.  FAST PATH: runs with the length in the tag (<= 60 bytes) and copies with 1- or 2-byte offsets, nothing
+// within the last bytes of either buffer, offset inside the output -- for those every Java check is known to pass.  Anything else is
+// parsed by snappy_parse_general, one element at a time: uncompressAll's loop body (M/snappy/SnappyRawDecompressor.java:84-216)
+// restated check by check, reading the stream directly.
+struct SnappyParseState {
+    int32_t ip, op, st, eo;
+};
+
+// one element, the general way; returns 0 (an error -- S.st set -- or an element of length 0), 1 (a run: rLen bytes at rStart) or 2 (a copy)
+__device__ __forceinline__ int snappy_parse_general(const uint8_t* __restrict__ in, SnappyParseState& S, int32_t inLimit, int32_t outLimit, int32_t& rLen, int32_t& rOff, int32_t& rStart)
+{
+    const int32_t fastOutLimit = outLimit - 8;
+    int32_t ip = S.ip;
+    const int32_t opc = (int32_t)in[ip];
+    ip++;
+#define SN_FAIL2(off)                                                      \
+    {                                                                      \
+        S.st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_MALFORMED); \
+        S.eo = (int32_t)(off);                                             \
+        return 0;                                                          \
+    }
+    const int32_t entry = snappy_op_entry5(opc);
+    const int32_t trailerBytes = entry >> 11;
+    if (!(ip + 4 < inLimit)) {  // :90-92
+        if (ip + trailerBytes > inLimit) SN_FAIL2(ip);
+    }
+    uint32_t t4 = 0;
+    for (int i = 0; i < trailerBytes; i++) {  // (the bytes the masked 4-byte load of :87-106 keeps)
+        t4 |= (uint32_t)in[ip + i] << (8 * i);
+    }
+    const int32_t trailer = (int32_t)t4;
+    if (trailer < 0) SN_FAIL2(ip);
+    ip += trailerBytes;
+    const int32_t length = entry & 0xff;
+    if (length == 0) {
+        S.ip = ip;
+        return 0;
+    }
+    if ((opc & 3) == 0) {  // literal :116-146
+        const int32_t lit = (int32_t)((uint32_t)length + (uint32_t)trailer);
+        if (lit < 0) SN_FAIL2(ip);
+        const int64_t litOutLimit = (int64_t)S.op + lit;
+        if ((litOutLimit > fastOutLimit || (int64_t)ip + lit > inLimit - 8) && (litOutLimit > outLimit || (int64_t)ip + lit > inLimit)) SN_FAIL2(ip);
+        rLen = lit;
+        rStart = ip;
+        S.ip = ip + lit;
+        S.op += lit;
+        return 1;
+    }
+    // copy :147-216
+    const int32_t matchOffset = (int32_t)((uint32_t)(entry & 0x700) + (uint32_t)trailer);
+    if (matchOffset <= 0 || matchOffset > S.op || (int64_t)S.op + length > outLimit) SN_FAIL2(ip);
+#undef SN_FAIL2
+    rLen = length;
+    rOff = matchOffset;
+    rStart = ip;
+    S.ip = ip;
+    S.op += length;
+    return 2;
+}
+
+template <int DBG>
+__global__ __launch_bounds__(64) void snappy_parse2_kernel(BatchArgs a, sx::ArenaHeader* hdr, sx::BlockMeta* meta, int32_t* only, uint64_t* arena, int32_t maxChunks, const int32_t* stats)
+{
+    if (stats != nullptr && snappy_pick(stats, a.nBlocks) != LZ4_PICK_TWOPASS) {  // auto mode: the ring decoder takes this batch
+        return;
+    }
+    constexpr int NS = 4;
+    using Feed = sx::LaneFeed<NS>;
+    __shared__ __attribute__((aligned(16))) uint8_t ldsIn[Feed::STRIDE * 64];
+    const int lane = threadIdx.x;
+    const int64_t block = (int64_t)blockIdx.x * 64 + lane;
+    const bool have = block < batch_count(a);
+    const uint8_t* in0 = have ? a.srcBase + a.srcOff[block] : a.srcBase;
+    const int32_t inLen0 = have ? a.srcLen[block] : 0;
+    const int32_t outLimit = have ? a.dstCap[block] : 0;
+
+    SnappyParseState S;
+    S.ip = 0;
+    S.op = 0;
+    S.st = 0;
+    S.eo = 0;
+    int32_t finished = have ? 0 : 1;
+
+    // readUncompressedLength :277-321 (at most 5 bytes: read straight from the input buffer)
+    uint32_t expected = 0;
+    int32_t nread = 0;
+    if (have) {
+        for (int i = 0; i < 5; i++) {
+            if (nread >= inLen0) {
+                S.st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_TRUNCATED);
+                S.eo = inLen0 - nread;
+                break;
+            }
+            const uint32_t b = in0[nread++];
+            expected |= (b & 0x7f) << (7 * i);
+            if ((b & 0x80) == 0) {
+                break;
+            }
+            if (i == 4) {
+                S.st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_LEN_HIGH_BIT);
+                S.eo = nread;
+            }
+        }
+        if (S.st == 0 && (int32_t)expected < 0) {
+            S.st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_INVALID_LENGTH);
+            S.eo = 0;
+        }
+        if (S.st == 0 && (int64_t)expected > (int64_t)outLimit) {  // :49-50
+            S.st = mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_SNAPPY_OUTPUT_TOO_SMALL);
+            S.eo = 0;
+        }
+        if (S.st != 0) {
+            finished = 1;
+        }
+    }
+
+    // uncompressAll :70-220 ; positions relative to the first byte after the varint
+    const uint8_t* const in = in0 + (finished != 0 ? 0 : nread);
+    const int32_t inLimit = finished != 0 ? 0 : inLen0 - nread;
+    Feed L;
+    {
+        const unsigned long long nonEmpty = __ballot(inLimit > 0);
+        const uint8_t* anywhere = (const uint8_t*)hdr;
+        if (nonEmpty != 0) {  // (uniform) one idle address per wavefront, as an offset from the batch's base (the loads stay global_load)
+            anywhere = a.srcBase + (int64_t)sx::shfl_u64((uint64_t)((in - a.srcBase) - (int64_t)((uintptr_t)in & 31)), __builtin_ctzll(nonEmpty));
+        }
+        L.init(ldsIn, lane, in, inLimit, anywhere);
+    }
+    const int32_t B = L.inBase;
+    const int32_t fastOutLimit = outLimit - 8;
+
+    // ---- state of the sequence under way ----
+    // phase 0: at an element; 1: a short run read (tLit bytes at tStart), at the element behind it (q); 2: its pieces are being emitted
+    int32_t phase = 0;
+    int32_t tLit = 0, tStart = 0, q = 0;
+    int32_t sLit = 0, sLitPos = 0, sMl = 0, sOff = 0, sK = 0;
+    int32_t litEndPrev = 0;  // position (counted from in0) behind the previous record's literals
+    int32_t fallback = 0;
+    uint64_t rec[8];
+    int32_t groupAny = 0;
+    int32_t firstChunk = -1, chunk = -1, fill = sx::CHUNK_RECS, count = 0;
+
+    auto trip = [&](auto tTag) {
+        constexpr int T = decltype(tTag)::value;
+        constexpr int SLOT = T % NS;
+        L.template land<SLOT>();
+        const bool active = finished == 0;
+        // ---- phase 0: the element at ip ----
+        const int32_t v0 = S.ip + B;
+        const uint32_t w = L.rd32(v0);
+        const uint32_t tag = w & 0xFF;
+        const bool do0 = active && phase == 0 && L.resident(v0, 4);
+        const bool isRun = (tag & 3) == 0;
+        const int32_t nLit = (int32_t)(tag >> 2) + 1;          // (a run with its length in the tag)
+        const int32_t nQ = S.ip + 1 + nLit;
+        // a run: fast when the length is in the tag, the four bytes behind the tag are inside the stream (:90), and neither buffer's last
+        // bytes are near (:128 -- the first half of that condition false)
+        const bool runFast = (tag >> 2) < 60 && S.ip + 5 < inLimit && S.op + nLit <= fastOutLimit && nQ <= inLimit - 8;
+        const bool end0 = do0 && S.ip >= inLimit;               // the loop condition :84
+        const bool gen0 = do0 && !end0 && isRun && !runFast;
+        const bool ok0run = do0 && !end0 && isRun && runFast;
+        const bool ok0copy = do0 && !end0 && !isRun;            // a copy at ip: phase 1 looks at it (an empty run before it)
+        tLit = ok0run ? nLit : (ok0copy ? 0 : tLit);
+        tStart = ok0run ? S.ip + 1 : (ok0copy ? S.ip : tStart);
+        q = ok0run ? nQ : (ok0copy ? S.ip : q);
+        // a run of more than 16 bytes is emitted on its own (pieces); a shorter one waits for the element behind it
+        const bool longRun = ok0run && nLit > 16;
+        sLit = longRun ? nLit : sLit;
+        sLitPos = longRun ? nread + S.ip + 1 : sLitPos;
+        sMl = longRun ? 0 : sMl;
+        sOff = longRun ? 0 : sOff;
+        sK = longRun ? 0 : sK;
+        S.op += ok0run ? nLit : 0;
+        S.ip = ok0run ? nQ : S.ip;
+        phase = longRun ? 2 : ((ok0run || ok0copy) ? 1 : phase);
+        finished |= end0 ? 1 : 0;
+        L.restart(nQ + B, ok0run && nQ + B >= L.issueV + 64);
+        // ---- phase 1: the element at q, behind a run of tLit <= 16 bytes (S.ip == q) ----
+        const int32_t v1 = q + B;
+        const uint32_t x = L.rd32(v1);
+        const uint32_t tag2 = x & 0xFF;
+        const bool do1 = finished == 0 && phase == 1 && L.resident(v1, 4);
+        const uint32_t kind = tag2 & 3;
+        const int32_t len1 = (int32_t)((tag2 >> 2) & 7) + 4, off1 = (int32_t)(((tag2 >> 5) << 8) | ((x >> 8) & 0xFF));
+        const int32_t len2 = (int32_t)(tag2 >> 2) + 1, off2 = (int32_t)((x >> 8) & 0xFFFF);
+        const int32_t cLen = kind == 1 ? len1 : len2, cOff = kind == 1 ? off1 : off2;
+        const int32_t cNext = q + (kind == 1 ? 2 : 3);
+        const bool atEnd = q >= inLimit;
+        const bool isCopy = !atEnd && kind != 0;
+        const bool copyFast = (kind == 1 || kind == 2) && q + 5 < inLimit && cOff > 0 && cOff <= S.op && S.op + cLen <= outLimit;
+        const bool ok1copy = do1 && isCopy && copyFast;
+        // not a fast copy behind the run: the run goes alone (tLit > 0), or -- nothing held -- the general path takes the element
+        const bool alone = do1 && !ok1copy && tLit > 0;
+        const bool gen1 = do1 && !ok1copy && tLit == 0 && !atEnd;
+        const bool end1 = do1 && !ok1copy && tLit == 0 && atEnd;
+        const bool seq1 = ok1copy || alone;
+        sLit = seq1 ? tLit : sLit;
+        sLitPos = seq1 ? nread + tStart : sLitPos;
+        sMl = ok1copy ? cLen : (alone ? 0 : sMl);
+        sOff = ok1copy ? cOff : (alone ? 0 : sOff);
+        sK = seq1 ? 0 : sK;
+        S.ip = ok1copy ? cNext : S.ip;
+        S.op += ok1copy ? cLen : 0;
+        phase = seq1 ? 2 : (do1 ? 0 : phase);
+        finished |= end1 ? 1 : 0;
+        if (gen0 || gen1) {  // (rare) one element, reading the stream directly
+            int32_t rLen = 0, rOff = 0, rStart = 0;
+            const int kindG = snappy_parse_general(in, S, inLimit, outLimit, rLen, rOff, rStart);
+            sLit = kindG == 1 ? rLen : 0;
+            sLitPos = nread + rStart;
+            sMl = kindG == 2 ? rLen : 0;
+            sOff = kindG == 2 ? rOff : 0;
+            sK = 0;
+            phase = kindG != 0 ? 2 : 0;
+            finished |= S.st != 0 ? 1 : 0;
+            fallback |= (kindG == 2 && rOff > 0xFFFF) ? 1 : 0;  // an offset beyond the record field: the ring decoder takes the block
+            finished |= fallback;
+            L.restart(S.ip + B, finished == 0 && S.ip + B >= L.issueV + 64);
+        }
+        // ---- phase 2: one piece (see lz4_parse2_kernel) ----
+        const bool do2 = finished == 0 && phase == 2;
+        const int32_t pl = sLit < 16 ? sLit : 16;
+        const int32_t pm = sLit > 16 ? 0 : (sMl < 16 ? sMl : 16);
+        const int32_t xm = 16 * sK + sOff;
+        const int32_t o = sK > 0 ? sx::largest_multiple(sOff > 0 ? sOff : 1, xm < 65535 ? xm : 65535) : sOff;
+        const int32_t skip = pl > 0 ? sLitPos - litEndPrev : 0;
+        const bool fb = do2 && skip > sx::MAX_SKIP;
+        const bool ok2 = do2 && !fb;
+        rec[T] = ok2 ? sx::rec_pack((uint32_t)pl, (uint32_t)pm, pm > 0 ? (uint32_t)o : 0u, (uint32_t)skip) : 0ull;
+        groupAny |= ok2 ? 1 : 0;
+        fallback |= fb ? 1 : 0;
+        litEndPrev = ok2 && pl > 0 ? sLitPos + pl : litEndPrev;
+        sLitPos += ok2 ? pl : 0;
+        sLit -= ok2 ? pl : 0;
+        sMl -= ok2 ? pm : 0;
+        sK += ok2 && pm > 0 ? 1 : 0;
+        phase = (ok2 && sLit == 0 && sMl == 0) ? 0 : phase;
+        finished |= fb ? 1 : 0;
+        L.template issue<SLOT>(S.ip + B, finished == 0);
+    };
+
+    while (__ballot(finished == 0) != 0) {  // (uniform)
+        groupAny = 0;
+        trip(std::integral_constant<int, 0>{});
+        trip(std::integral_constant<int, 1>{});
+        trip(std::integral_constant<int, 2>{});
+        trip(std::integral_constant<int, 3>{});
+        trip(std::integral_constant<int, 4>{});
+        trip(std::integral_constant<int, 5>{});
+        trip(std::integral_constant<int, 6>{});
+        trip(std::integral_constant<int, 7>{});
+        // ---- the group leaves: a chunk for every lane that needs one (one atomic per wavefront), then one 64-byte piece per lane ----
+        const bool flush = groupAny != 0 && fallback == 0;
+        const bool need = flush && fill == sx::CHUNK_RECS;
+        const unsigned long long nm = __ballot(need);
+        if (nm != 0) {  // (uniform)
+            int32_t base = 0;
+            if (lane == __builtin_ctzll(nm)) {
+                base = atomicAdd(&hdr->nextChunk, (int32_t)__popcll(nm));
+            }
+            base = sx::wave_bcast(base, __builtin_ctzll(nm));
+            if (need) {
+                const int32_t c = base + (int32_t)__popcll(nm & ((1ull << lane) - 1));
+                if (c >= maxChunks) {  // the arena is exhausted: the ring decoder takes the block
+                    fallback = 1;
+                    finished = 1;
+                }
+                else {
+                    if (chunk >= 0) {
+                        arena[(int64_t)chunk * sx::CHUNK_SLOTS + sx::CHUNK_RECS] = (uint64_t)(uint32_t)c;  // link
+                    }
+                    else {
+                        firstChunk = c;
+                    }
+                    chunk = c;
+                    fill = 0;
+                }
+            }
+        }
+        if (flush && fallback == 0) {
+            if (DBG != 1) {
+                uint8_t* const dst = (uint8_t*)(arena + (int64_t)chunk * sx::CHUNK_SLOTS + fill);
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    st16(dst + 8 * k, u32x4{(uint32_t)rec[k], (uint32_t)(rec[k] >> 32), (uint32_t)rec[k + 1], (uint32_t)(rec[k + 1] >> 32)});
+                }
+            }
+            fill += 8;
+            count += 8;
+        }
+    }
+    if (!have && block < a.nBlocks) {  // (a batch assembled on the device may hold fewer blocks than the launch was sized for)
+        only[block] = 0;
+        meta[block].firstChunk = 0;
+        meta[block].count = 0;
+    }
+    if (have) {
+        if (fallback != 0) {
+            only[block] = 1;
+            meta[block].firstChunk = 0;
+            meta[block].count = 0;
+            atomicAdd(&hdr->fallbackBlocks, 1);
+        }
+        else {
+            if (S.st == 0 && (int64_t)expected != (int64_t)S.op) {  // :61-65
+                S.st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_LENGTH_MISMATCH);
+                S.eo = 0;
+            }
+            only[block] = 0;
+            meta[block].firstChunk = firstChunk < 0 ? 0 : firstChunk;
+            meta[block].count = S.st == 0 ? count : 0;
+            a.outLen[block] = S.st == 0 ? S.op : 0;
+            a.status[block] = S.st;
+            a.errOffset[block] = (int64_t)S.eo;
+        }
+    }
+}
+
 hipError_t launch_seq_execute(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant, const int32_t* stats, int32_t shortLimit);
-int64_t lz4_twopass_scratch_bytes(int32_t nBlocks);
+hipError_t launch_seq_execute2(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant, const int32_t* stats, int32_t shortLimit);
+int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 
-int64_t snappy_twopass_scratch_bytes(int32_t nBlocks) { return lz4_twopass_scratch_bytes(nBlocks); }
+int64_t snappy_twopass_scratch_bytes(int32_t nBlocks) { return twopass_scratch_bytes(nBlocks, 131072); }
 
 hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats)
 {
@@ -255,17 +582,28 @@ hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stre
     int32_t* only = (int32_t*)(s + 4096 + (int64_t)a.nBlocks * 8);
     const int64_t fixed = 4096 + (((int64_t)a.nBlocks * 12 + 4095) & ~4095LL);
     uint64_t* arena = (uint64_t*)(s + fixed);
-    const int64_t chunks = (scratchBytes - fixed) / (sx::CHUNK_SLOTS * 8);
+    const int64_t chunks = (scratchBytes - fixed) / (sx::CHUNK_SLOTS * 8) - 1;  // (one to spare: the second executor's unconditional record loads)
     const int32_t maxChunks = (int32_t)(chunks > 0x7FFFFFFF ? 0x7FFFFFFF : chunks);
     hipError_t e = hipMemsetAsync(hdr, 0, sizeof(sx::ArenaHeader), stream);
     if (e != hipSuccess) return e;
-    if (execVariant == 201) {
-        hipLaunchKernelGGL(snappy_parse_kernel<1>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+    const dim3 grid((unsigned)((a.nBlocks + 63) / 64)), wg(64);
+    if (execVariant >= 1000) {  // the first parser and executor (kept for comparison: decompress.exec_variant = 1000 + executor variant)
+        hipLaunchKernelGGL(snappy_parse_kernel<0>, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+        e = launch_seq_execute(a, stream, meta, arena, execVariant - 1000, stats, 6);
     }
-    else {
-        hipLaunchKernelGGL(snappy_parse_kernel<0>, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+    else if (execVariant == 2 || (execVariant >= 120 && execVariant <= 129)) {  // the default: pieces + the second executor
+        hipLaunchKernelGGL(snappy_parse2_kernel<0>, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+        e = launch_seq_execute2(a, stream, meta, arena, execVariant, stats, 6);
     }
-    e = launch_seq_execute(a, stream, meta, arena, execVariant, stats, 6);
+    else {  // pieces through the first executor
+        if (execVariant == 201) {
+            hipLaunchKernelGGL(snappy_parse2_kernel<1>, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+        }
+        else {
+            hipLaunchKernelGGL(snappy_parse2_kernel<0>, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+        }
+        e = launch_seq_execute(a, stream, meta, arena, execVariant, stats, 6);
+    }
     if (e != hipSuccess) return e;
     BatchArgs f = a;
     f.only = only;

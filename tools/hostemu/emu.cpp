@@ -24,12 +24,15 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
         a.ringPad = 16;
         return achip::launch_lz4_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, execVariant, nullptr);
     }
-    if (op == 30 || op == 31) {  // two-pass Snappy (31: a tiny arena, so that blocks fall back)
+    if (op >= 30 && op <= 35) {  // two-pass Snappy; odd ops: a tiny arena, so that blocks fall back
+        // 30 / 31: pieces through the first executor; 32 / 33: the first parser and executor; 34 / 35: pieces through the second executor (the default)
+        const int execVariant = op >= 34 ? 2 : (op >= 32 ? 1001 : 1);
+        const bool tiny = (op & 1) != 0;
         static std::vector<uint8_t> scratch;
-        const int64_t bytes = op == 31 ? 4096 + ((n * 12 + 4095) & ~4095LL) + 3 * 4096 : achip::lz4_twopass_scratch_bytes(n);
+        const int64_t bytes = tiny ? 4096 + ((n * 12 + 4095) & ~4095LL) + 4 * 4096 : achip::lz4_twopass_scratch_bytes(n);
         scratch.assign((size_t)bytes, 0xCD);
         a.ringPad = 16;
-        return achip::launch_snappy_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, 1, nullptr);
+        return achip::launch_snappy_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, execVariant, nullptr);
     }
     if (op == 19) return achip::launch_snappy_decompress_lanewindow(a, nullptr, nullptr);
     if (op == 18) return achip::launch_lz4_decompress_lanewindow(a, nullptr, nullptr);  // lane per block + LDS output window: lane-private
