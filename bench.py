@@ -398,6 +398,8 @@ DECODER_NAMES = {0: "rings", 1: "lane-per-block", 2: "lane-per-block with LDS wi
 
 def kernel_symbol(wl, decoder):
     """the dominant kernel of the timed launch as rocprofv3 names it (profiles/*_kernel_stats.csv)"""
+    if wl.endswith("decompress") and decoder.startswith("two-pass"):
+        return "achip::seq_execute2_kernel<0, 4096, 0> (+ achip::%s_parse2_kernel<0>)" % wl.split("_")[0]
     if wl == "lz4_decompress":
         if decoder.endswith("LDS window"):
             return "achip::lz4_decompress_lanewindow_kernel<16, 64>"
