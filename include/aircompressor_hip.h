@@ -125,6 +125,14 @@ enum achip_detail {
     ACHIP_D_SNF_CHECKSUM = 95,            /* :207   "Corrupt input: invalid checksum"                       */
     ACHIP_D_SNF_OUTPUT_TOO_SMALL = 96,    /* this API: the destination cannot hold the stream's plaintext   */
     ACHIP_D_SNF_MAX_OUTPUT = 97,          /* this API (encoder): dstCap < achip_snappyframed_max_compressed_length */
+    /* Hadoop LZ4 / Snappy block streams (M/lz4/Lz4HadoopInputStream.java, M/snappy/SnappyHadoopInputStream.java; IOException / EOFException) */
+    ACHIP_D_HDP_TRUNCATED_INT = 104,      /* Lz4HadoopInputStream.java:153 "Stream is truncated"                                     */
+    ACHIP_D_HDP_EOF_BLOCK_DATA = 105,     /* :136   "encountered EOF while reading block data"                                        */
+    ACHIP_D_HDP_CHUNK_EXCEEDS_BLOCK = 106, /* SnappyHadoopInputStream.java:117 "Chunk uncompressed size is greater than block size"   */
+    ACHIP_D_HDP_LENGTH_MISMATCH = 107,    /* SnappyHadoopInputStream.java:137 "Expected to read N bytes, but data only contained M bytes" */
+    ACHIP_D_HDP_NOT_CONSUMED = 108,       /* T/HadoopCodecDecompressor.java:52 "All input was not consumed": the destination cannot hold the stream */
+    ACHIP_D_HDP_NEGATIVE_LENGTH = 109,    /* this API: a negative chunk length (Java: the block codec's range check throws)           */
+    ACHIP_D_HDP_MAX_OUTPUT = 110,         /* this API (encoder): dstCap < achip_hadoop_max_compressed_length                          */
     /* runtime */
     ACHIP_D_NO_DEVICE = 100,
     ACHIP_D_HIP_ERROR = 101,

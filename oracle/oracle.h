@@ -59,6 +59,12 @@ int64_t orc_snappyframed_decompress(const uint8_t* in, int64_t in_len, uint8_t* 
 uint32_t orc_crc32c(const uint8_t* in, int64_t len);
 uint32_t orc_masked_crc32c(const uint8_t* in, int64_t len);
 
+/* Hadoop LZ4 / Snappy block streams -- M/lz4/Lz4Hadoop{Input,Output}Stream.java, M/snappy/SnappyHadoop{Input,Output}Stream.java
+ * (hadoop_streams.c); codec 0 = LZ4, 1 = Snappy; bufferSize = the streams' buffer size (262144 unless configured) */
+int64_t orc_hadoop_max_compressed_length(int32_t codec, int64_t n, int32_t bufferSize);
+int64_t orc_hadoop_compress(int32_t codec, const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap, int32_t bufferSize);
+int64_t orc_hadoop_decompress(int32_t codec, const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap, int32_t bufferSize, int64_t* err_off);
+
 /* XXH32 -- M/xxhash/XxHash32JavaHasher.java:68-110,343-366 (public xxhash package; LZ4 frame checksums) */
 uint32_t orc_xxh32(const uint8_t* in, int64_t len, uint32_t seed);
 

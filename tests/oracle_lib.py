@@ -47,6 +47,12 @@ class Oracle:
         for name in ("orc_crc32c", "orc_masked_crc32c"):
             getattr(lib, name).restype = ctypes.c_uint32
             getattr(lib, name).argtypes = [u8p, i64]
+        lib.orc_hadoop_max_compressed_length.restype = i64
+        lib.orc_hadoop_max_compressed_length.argtypes = [ctypes.c_int32, i64, ctypes.c_int32]
+        lib.orc_hadoop_compress.restype = i64
+        lib.orc_hadoop_compress.argtypes = [ctypes.c_int32, u8p, i64, u8p, i64, ctypes.c_int32]
+        lib.orc_hadoop_decompress.restype = i64
+        lib.orc_hadoop_decompress.argtypes = [ctypes.c_int32, u8p, i64, u8p, i64, ctypes.c_int32, ctypes.POINTER(i64)]
         lib.orc_random_generator.restype = None
         lib.orc_random_generator.argtypes = [ctypes.c_double, u8p, i64]
         lib.orc_batch.restype = i64
@@ -78,6 +84,29 @@ class Oracle:
         dst = np.zeros(max(cap, 1), dtype=np.uint8)
         eo = ctypes.c_int64(0)
         r = getattr(self.lib, "orc_%s_decompress" % codec)(src.ctypes.data if len(src) else None, len(src), dst.ctypes.data, cap, ctypes.byref(eo))
+        if r < 0:
+            raise OracleError(r, eo.value)
+        return dst[:r].tobytes()
+
+    # Hadoop LZ4 / Snappy block streams (oracle/hadoop_streams.c); codec "lz4" | "snappy"
+    def hadoop_max_compressed_length(self, codec, n, buffer_size=262144):
+        return self.lib.orc_hadoop_max_compressed_length(0 if codec == "lz4" else 1, n, buffer_size)
+
+    def hadoop_compress(self, codec, data, buffer_size=262144, cap=None):
+        src = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+        if cap is None:
+            cap = self.hadoop_max_compressed_length(codec, len(src), buffer_size)
+        dst = np.zeros(max(cap, 1), dtype=np.uint8)
+        r = self.lib.orc_hadoop_compress(0 if codec == "lz4" else 1, src.ctypes.data if len(src) else None, len(src), dst.ctypes.data, cap, buffer_size)
+        if r < 0:
+            raise OracleError(r, 0)
+        return dst[:r].tobytes()
+
+    def hadoop_decompress(self, codec, data, cap, buffer_size=262144):
+        src = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+        dst = np.zeros(max(cap, 1), dtype=np.uint8)
+        eo = ctypes.c_int64(0)
+        r = self.lib.orc_hadoop_decompress(0 if codec == "lz4" else 1, src.ctypes.data if len(src) else None, len(src), dst.ctypes.data, cap, buffer_size, ctypes.byref(eo))
         if r < 0:
             raise OracleError(r, eo.value)
         return dst[:r].tobytes()
