@@ -12,7 +12,7 @@ import numpy as np
 from . import native
 from .native import HipNative
 
-OP_LZ4_DECOMPRESS, OP_LZ4_COMPRESS, OP_SNAPPY_DECOMPRESS, OP_SNAPPY_COMPRESS, OP_ZSTD_DECOMPRESS, OP_ZSTD_COMPRESS, OP_LZ4FRAME_DECOMPRESS, OP_LZ4FRAME_COMPRESS, OP_SNAPPYFRAMED_DECOMPRESS, OP_SNAPPYFRAMED_COMPRESS = range(10)
+OP_LZ4_DECOMPRESS, OP_LZ4_COMPRESS, OP_SNAPPY_DECOMPRESS, OP_SNAPPY_COMPRESS, OP_ZSTD_DECOMPRESS, OP_ZSTD_COMPRESS, OP_LZ4FRAME_DECOMPRESS, OP_LZ4FRAME_COMPRESS, OP_SNAPPYFRAMED_DECOMPRESS, OP_SNAPPYFRAMED_COMPRESS, OP_LZ4HADOOP_DECOMPRESS, OP_LZ4HADOOP_COMPRESS, OP_SNAPPYHADOOP_DECOMPRESS, OP_SNAPPYHADOOP_COMPRESS = range(14)
 _FN = {
     OP_LZ4_DECOMPRESS: "achip_lz4_decompress_batch",
     OP_LZ4_COMPRESS: "achip_lz4_compress_batch",
@@ -24,6 +24,10 @@ _FN = {
     OP_LZ4FRAME_COMPRESS: "achip_lz4frame_compress_batch",
     OP_SNAPPYFRAMED_DECOMPRESS: "achip_snappyframed_decompress_batch",
     OP_SNAPPYFRAMED_COMPRESS: "achip_snappyframed_compress_batch",
+    OP_LZ4HADOOP_DECOMPRESS: "achip_lz4hadoop_decompress_batch",
+    OP_LZ4HADOOP_COMPRESS: "achip_lz4hadoop_compress_batch",
+    OP_SNAPPYHADOOP_DECOMPRESS: "achip_snappyhadoop_decompress_batch",
+    OP_SNAPPYHADOOP_COMPRESS: "achip_snappyhadoop_compress_batch",
 }
 
 

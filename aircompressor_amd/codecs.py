@@ -183,6 +183,63 @@ class SnappyFramedHipDecompressor(_HipDecompressor):
     _codec = "snappyframed"
 
 
+class _HadoopHipCompressor(_HipCompressor):
+    _codec_id = 0
+
+    def __init__(self, device=0, native_ctx=None, buffer_size=262144):
+        super().__init__(device, native_ctx)
+        self.buffer_size = buffer_size
+
+    def max_compressed_length(self, uncompressed_size):
+        r = self._lib.achip_hadoop_max_compressed_length(self._codec_id, uncompressed_size, self.buffer_size)
+        if r < 0:
+            raise IllegalArgumentException("uncompressedSize is negative: %d" % uncompressed_size if uncompressed_size < 0 else
+                                           "Maximum compressed length exceeds Integer.MAX_VALUE for uncompressedSize: %d" % uncompressed_size)
+        return r
+
+    def _compress(self, src, dst):
+        self._native.set_option("hadoop.buffer_size", self.buffer_size)
+        return super()._compress(src, dst)
+
+
+class _HadoopHipDecompressor(_HipDecompressor):
+    def __init__(self, device=0, native_ctx=None, buffer_size=262144):
+        super().__init__(device, native_ctx)
+        self.buffer_size = buffer_size
+
+    def _decompress(self, src, dst):
+        self._native.set_option("hadoop.buffer_size", self.buffer_size)
+        return super()._decompress(src, dst)
+
+
+class Lz4HadoopHipCompressor(_HadoopHipCompressor):
+    """One-shot form of Lz4HadoopOutputStream (M/lz4/Lz4HadoopOutputStream.java:60-118; the stream behind
+    org.apache.hadoop.io.compress.Lz4Codec, M/lz4/Lz4HadoopStreams.java:52-66): what `createOutputStream(out); write(data); close()`
+    leaves in `out` (T/HadoopCodecCompressor.java:57-72) -- per chunk of buffer_size - max(buffer_size / 100, 10) bytes a big-endian
+    plaintext length, a big-endian compressed length and the LZ4 block of the HIP encoder."""
+    _codec = "lz4hadoop"
+    _codec_id = 0
+
+
+class Lz4HadoopHipDecompressor(_HadoopHipDecompressor):
+    """One-shot form of Lz4HadoopInputStream read to the end (M/lz4/Lz4HadoopInputStream.java:47-156, driven as
+    T/HadoopCodecDecompressor.java:40-60 does): blocks of several chunks, empty blocks, the stream's own bufferSize + 8 byte buffer
+    when the destination has less room than a block declares; its IOException / EOFException texts are the ACHIP_D_HDP_* messages."""
+    _codec = "lz4hadoop"
+
+
+class SnappyHadoopHipCompressor(_HadoopHipCompressor):
+    """One-shot form of SnappyHadoopOutputStream (M/snappy/SnappyHadoopOutputStream.java:60-131): chunks of
+    buffer_size - (buffer_size / 6 + 32) plaintext bytes."""
+    _codec = "snappyhadoop"
+    _codec_id = 1
+
+
+class SnappyHadoopHipDecompressor(_HadoopHipDecompressor):
+    """One-shot form of SnappyHadoopInputStream read to the end (M/snappy/SnappyHadoopInputStream.java:44-170)."""
+    _codec = "snappyhadoop"
+
+
 class SnappyHipCompressor(_HipCompressor):
     """Drop-in for SnappyJavaCompressor (M/snappy/SnappyJavaCompressor.java:26-91)."""
     _codec = "snappy"

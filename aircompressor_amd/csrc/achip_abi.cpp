@@ -44,6 +44,10 @@ hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream
 int64_t snappyframed_decompress_scratch_bytes(int32_t nStreams);
 hipError_t launch_snappyframed_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant);
 int64_t snappyframed_compress_scratch_bytes(int32_t nStreams);
+hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize, int variant);
+int64_t hadoop_decompress_scratch_bytes(int32_t nStreams, int32_t bufferSize);
+hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize);
+int64_t hadoop_compress_scratch_bytes(int32_t nStreams);
 hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch);
 hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch);
 int64_t lz4frame_compress_scratch_bytes();
@@ -67,6 +71,8 @@ struct achip_ctx {
     int snappycVariant = 2;  // 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 0;
+    int hadoopBufferSize = 262144;        // Hadoop block streams: the streams' buffer size (Lz4HadoopStreams.java:30; io.compression.codec.*.buffersize)
+    int hadoopDecompressVariant = 1;      // 1 = chunk list through the batched block decoders, the serial kernel behind it (default); 0 = one wavefront per stream
     int snappyFramedCompressVariant = 1;  // framed writer: 1 = block list + two-tier block encoder + compaction (default), 0 = one wavefront per stream
     int snappyFramedVariant = 1;  // framed reader: 1 = chunk list + batched block decoders (default), 0 = one wavefront per stream
     int zstdTile = 65536;    // items per pass of the Zstd decode pipeline (halved automatically when its scratch cannot be allocated)
@@ -329,6 +335,20 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             e = achip::launch_snappyframed_compress(a, ctx->stream, ctx->scratch, ctx->snappyFramedCompressVariant);
             break;
         }
+        case ACHIP_OP_LZ4HADOOP_DECOMPRESS:
+        case ACHIP_OP_SNAPPYHADOOP_DECOMPRESS: {
+            int32_t r = ensure_scratch(ctx, achip::hadoop_decompress_scratch_bytes(a.nBlocks, ctx->hadoopBufferSize));
+            if (r < 0) return r;
+            e = achip::launch_hadoop_decompress(a, ctx->stream, ctx->scratch, op == ACHIP_OP_SNAPPYHADOOP_DECOMPRESS, ctx->hadoopBufferSize, ctx->hadoopDecompressVariant);
+            break;
+        }
+        case ACHIP_OP_LZ4HADOOP_COMPRESS:
+        case ACHIP_OP_SNAPPYHADOOP_COMPRESS: {
+            int32_t r = ensure_scratch(ctx, achip::hadoop_compress_scratch_bytes(a.nBlocks));
+            if (r < 0) return r;
+            e = achip::launch_hadoop_compress(a, ctx->stream, ctx->scratch, op == ACHIP_OP_SNAPPYHADOOP_COMPRESS, ctx->hadoopBufferSize);
+            break;
+        }
         case ACHIP_OP_LZ4FRAME_COMPRESS: {
             int32_t r = ensure_scratch(ctx, achip::lz4frame_compress_scratch_bytes());
             if (r < 0) return r;
@@ -401,6 +421,13 @@ const DetailText kDetailText[] = {
     {ACHIP_D_SNF_CHECKSUM, "Corrupt input: invalid checksum"},
     {ACHIP_D_SNF_OUTPUT_TOO_SMALL, "Output buffer too small for the stream"},
     {ACHIP_D_SNF_MAX_OUTPUT, "Output buffer too small"},
+    {ACHIP_D_HDP_TRUNCATED_INT, "Stream is truncated"},
+    {ACHIP_D_HDP_EOF_BLOCK_DATA, "encountered EOF while reading block data"},
+    {ACHIP_D_HDP_CHUNK_EXCEEDS_BLOCK, "Chunk uncompressed size is greater than block size"},
+    {ACHIP_D_HDP_LENGTH_MISMATCH, "Expected to read the chunk's announced bytes, but data only contained fewer"},
+    {ACHIP_D_HDP_NOT_CONSUMED, "All input was not consumed"},
+    {ACHIP_D_HDP_NEGATIVE_LENGTH, "negative chunk length"},
+    {ACHIP_D_HDP_MAX_OUTPUT, "Output buffer too small"},
     {ACHIP_D_SNAPPY_MALFORMED, "Malformed input"},
     {ACHIP_D_SNAPPY_TRUNCATED, "Input is truncated"},
     {ACHIP_D_SNAPPY_LEN_HIGH_BIT, "last byte of compressed length int has high bit set"},
@@ -488,6 +515,22 @@ int32_t achip_snappyframed_max_compressed_length(int32_t n)
     if (n < 0) return bad_argument("uncompressedSize is negative");
     const int64_t blocks = ((int64_t)n + 65535) / 65536;
     const int64_t maxLength = 10 + 8 * blocks + (int64_t)n;
+    if (maxLength > 0x7FFFFFFF) return bad_argument("Maximum compressed length exceeds Integer.MAX_VALUE");
+    return (int32_t)maxLength;
+}
+int32_t achip_hadoop_max_compressed_length(int32_t codec, int32_t n, int32_t bufferSize)
+{
+    // per chunk of bufferSize - overhead plaintext bytes: two big-endian ints and at most the codec's maxCompressedLength
+    // (M/lz4/Lz4HadoopOutputStream.java:44-46, 107-118, 128-131; M/snappy/SnappyHadoopOutputStream.java likewise)
+    if (n < 0) return bad_argument("uncompressedSize is negative");
+    if (codec != 0 && codec != 1) return bad_argument("codec must be 0 (LZ4) or 1 (Snappy)");
+    const bool snappy = codec == 1;
+    const int64_t overhead = snappy ? bufferSize / 6 + 32 : ((int32_t)(bufferSize * 0.01) > 10 ? (int32_t)(bufferSize * 0.01) : 10);
+    const int64_t chunk = (int64_t)bufferSize - overhead;
+    if (bufferSize <= 0 || chunk <= 0) return bad_argument("bufferSize too small");
+    auto bound = [&](int64_t m) { return snappy ? 32 + m + m / 6 : m + m / 255 + 16; };
+    const int64_t rest = (int64_t)n % chunk;
+    const int64_t maxLength = ((int64_t)n / chunk) * (8 + bound(chunk)) + (rest > 0 ? 8 + bound(rest) : 0);
     if (maxLength > 0x7FFFFFFF) return bad_argument("Maximum compressed length exceeds Integer.MAX_VALUE");
     return (int32_t)maxLength;
 }
@@ -650,6 +693,11 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     else if (k == "snappy.compress.variant") ctx->snappycVariant = (int)value;
     else if (k == "snappyframed.decompress.variant") ctx->snappyFramedVariant = (int)value;
     else if (k == "snappyframed.compress.variant") ctx->snappyFramedCompressVariant = (int)value;
+    else if (k == "hadoop.buffer_size") {
+        if (value < 64 || value > 0x40000000) return bad_argument("hadoop.buffer_size out of range");
+        ctx->hadoopBufferSize = (int)value;
+    }
+    else if (k == "hadoop.decompress.variant") ctx->hadoopDecompressVariant = (int)value;
     else if (k == "decompress.ring_pad") {
         if (value < 0 || value > 256 || (value & 15) != 0) return bad_argument("ring pad must be a multiple of 16 in 0..256");
         ctx->ringPad = (int)value;
@@ -826,6 +874,10 @@ ACHIP_DEFINE_BATCH(achip_lz4frame_decompress_batch, ACHIP_OP_LZ4FRAME_DECOMPRESS
 ACHIP_DEFINE_BATCH(achip_lz4frame_compress_batch, ACHIP_OP_LZ4FRAME_COMPRESS)
 ACHIP_DEFINE_BATCH(achip_snappyframed_decompress_batch, ACHIP_OP_SNAPPYFRAMED_DECOMPRESS)
 ACHIP_DEFINE_BATCH(achip_snappyframed_compress_batch, ACHIP_OP_SNAPPYFRAMED_COMPRESS)
+ACHIP_DEFINE_BATCH(achip_lz4hadoop_decompress_batch, ACHIP_OP_LZ4HADOOP_DECOMPRESS)
+ACHIP_DEFINE_BATCH(achip_lz4hadoop_compress_batch, ACHIP_OP_LZ4HADOOP_COMPRESS)
+ACHIP_DEFINE_BATCH(achip_snappyhadoop_decompress_batch, ACHIP_OP_SNAPPYHADOOP_DECOMPRESS)
+ACHIP_DEFINE_BATCH(achip_snappyhadoop_compress_batch, ACHIP_OP_SNAPPYHADOOP_COMPRESS)
 
 // ---- mixed batch: bucket by codec op, run every op over its slice, un-bucket (BASELINE configs[4]) ----
 namespace {
@@ -844,7 +896,7 @@ int32_t ensure_mix(achip_ctx* ctx, int64_t n)
     ctx->mixItems = want;
     return 0;
 }
-constexpr int kNumOps = 10;
+constexpr int kNumOps = 14;
 }  // namespace
 
 int32_t achip_mixed_batch(achip_ctx* ctx, const int32_t* codecOp, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, void* dstBase,
@@ -1298,6 +1350,22 @@ int32_t achip_snappyframed_compress(achip_ctx* ctx, const void* src, void* dst, 
 int32_t achip_snappyframed_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
 {
     return single_block(ACHIP_OP_SNAPPYFRAMED_DECOMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
+int32_t achip_lz4hadoop_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_LZ4HADOOP_COMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
+int32_t achip_lz4hadoop_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_LZ4HADOOP_DECOMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
+int32_t achip_snappyhadoop_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_SNAPPYHADOOP_COMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
+int32_t achip_snappyhadoop_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_SNAPPYHADOOP_DECOMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
 }
 int32_t achip_lz4frame_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
 {

@@ -13,7 +13,7 @@ template <int GS, int IN_RING, int OUT_RING, int GPL>
 __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
     // auto mode (achip_abi.cpp): both LZ4 decoders are launched, the probe's count of mixed 16-block groups picks one
-    if (mixedGroups != nullptr && lz4_pick(mixedGroups, a.nBlocks) != LZ4_PICK_RINGS) {
+    if (mixedGroups != nullptr && lz4_pick(mixedGroups, batch_count(a)) != LZ4_PICK_RINGS) {
         return;
     }
     ACHIP_DYNAMIC_LDS(smem);
@@ -21,11 +21,11 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a, 
     const int g = threadIdx.x & (GS - 1);
     const int grp = threadIdx.x / GS;
     const int64_t block = (int64_t)blockIdx.x * GROUPS_PER_WG + grp;
-    if (block >= a.nBlocks) {
+    if (block >= batch_count(a)) {  // (a batch assembled on the device may hold fewer blocks than the launch was sized for)
         return;
     }
     if (a.only != nullptr) {  // the blocks a two-pass decode handed over -- if it ran at all (auto mode)
-        if ((a.onlyStats != nullptr && lz4_pick(a.onlyStats, a.nBlocks, a.onlyShortLimit) != LZ4_PICK_TWOPASS) || a.only[block] == 0) {
+        if ((a.onlyStats != nullptr && lz4_pick(a.onlyStats, batch_count(a), a.onlyShortLimit) != LZ4_PICK_TWOPASS) || a.only[block] == 0) {
             return;
         }
     }

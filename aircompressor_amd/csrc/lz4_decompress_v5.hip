@@ -25,14 +25,14 @@ template <int IN_DW, bool NT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void lz4_decompress_lanecopy_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
     using namespace sp;
-    if (mixedGroups != nullptr && lz4_pick(mixedGroups, a.nBlocks) != LZ4_PICK_LANECOPY) {  // auto mode: another decoder takes this batch
+    if (mixedGroups != nullptr && lz4_pick(mixedGroups, batch_count(a)) != LZ4_PICK_LANECOPY) {  // auto mode: another decoder takes this batch
         return;
     }
     __shared__ uint32_t ldsIn[IN_DW * 64];
     __shared__ CopyScratch S;
     const int lane = threadIdx.x;
     const int64_t block = (int64_t)blockIdx.x * 64 + lane;
-    const bool have = block < a.nBlocks;
+    const bool have = block < batch_count(a);
     const uint8_t* in = have ? a.srcBase + a.srcOff[block] : a.srcBase;
     uint8_t* out = have ? a.dstBase + a.dstOff[block] : a.dstBase;
     const int32_t inLimit = have ? a.srcLen[block] : 0;

@@ -40,6 +40,15 @@ SIGNATURES = {
     "achip_snappyframed_compress_batch": (_i32, _BATCH),
     "achip_snappyframed_compress": (_i32, [_vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_i64)]),
     "achip_snappyframed_decompress": (_i32, [_vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_i64)]),
+    "achip_hadoop_max_compressed_length": (_i32, [_i32, _i32, _i32]),
+    "achip_lz4hadoop_decompress_batch": (_i32, _BATCH),
+    "achip_lz4hadoop_compress_batch": (_i32, _BATCH),
+    "achip_snappyhadoop_decompress_batch": (_i32, _BATCH),
+    "achip_snappyhadoop_compress_batch": (_i32, _BATCH),
+    "achip_lz4hadoop_compress": (_i32, [_vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_i64)]),
+    "achip_lz4hadoop_decompress": (_i32, [_vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_i64)]),
+    "achip_snappyhadoop_compress": (_i32, [_vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_i64)]),
+    "achip_snappyhadoop_decompress": (_i32, [_vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_i64)]),
     "achip_lz4frame_max_compressed_length": (_i32, [_i32]),
     "achip_lz4frame_decompress_batch": (_i32, _BATCH),
     "achip_lz4frame_compress_batch": (_i32, _BATCH),

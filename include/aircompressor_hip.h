@@ -278,6 +278,28 @@ int32_t achip_snappyframed_compress_batch(ACHIP_BATCH_ARGS);
 int32_t achip_snappyframed_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
 int32_t achip_snappyframed_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
 
+/* ---- Hadoop LZ4 / Snappy block streams (second half) ----
+ * Replace Lz4HadoopOutputStream / SnappyHadoopOutputStream used as "write everything, close"   M/lz4/Lz4HadoopOutputStream.java:60-118,
+ *     M/snappy/SnappyHadoopOutputStream.java:60-131   (as T/HadoopCodecCompressor.java:57-72 drives them)
+ * and Lz4HadoopInputStream / SnappyHadoopInputStream read to the end   M/lz4/Lz4HadoopInputStream.java:47-156,
+ *     M/snappy/SnappyHadoopInputStream.java:44-170   (as T/HadoopCodecDecompressor.java:40-60 drives them: a destination that cannot hold
+ *     the stream is ACHIP_D_HDP_NOT_CONSUMED)
+ * -- the streams behind org.apache.hadoop.io.compress.Lz4Codec / SnappyCodec (M/lz4/Lz4HadoopStreams.java:52-66) -- with the HIP block
+ * codecs underneath.  [BE int plaintext length][BE int compressed length][block] ...; an item of the batch is a whole stream.  The
+ * streams' buffer size (256 KiB unless configured, M/lz4/Lz4HadoopStreams.java:30) is the context option "hadoop.buffer_size".  Same
+ * batch arguments, result convention and asynchrony as the block codecs; stream-level IOExceptions (details ACHIP_D_HDP_*) report the
+ * position where the failing read began, a block codec error keeps its own detail and offset. */
+int32_t achip_hadoop_max_compressed_length(int32_t codec /* 0 LZ4, 1 Snappy */, int32_t uncompressedSize, int32_t bufferSize);  /* bound this API asks of dstCap */
+int32_t achip_lz4hadoop_decompress_batch(ACHIP_BATCH_ARGS);
+int32_t achip_lz4hadoop_compress_batch(ACHIP_BATCH_ARGS);
+int32_t achip_snappyhadoop_decompress_batch(ACHIP_BATCH_ARGS);
+int32_t achip_snappyhadoop_compress_batch(ACHIP_BATCH_ARGS);
+/* one HOST buffer, staged through the context's pinned buffer */
+int32_t achip_lz4hadoop_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+int32_t achip_lz4hadoop_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+int32_t achip_snappyhadoop_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+int32_t achip_snappyhadoop_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+
 /* ---- xxhash: batched XXH64 / XXH32 of device-resident buffers ----
  * Replace XxHash64Hasher.hash(MemorySegment input, long seed)   M/xxhash/XxHash64Hasher.java:78-86  (-> XxHash64JavaHasher.java:126)
  *     and XxHash32Hasher.hash(MemorySegment input, int seed)    M/xxhash/XxHash32Hasher.java       (-> XxHash32JavaHasher.java:112)
@@ -302,6 +324,10 @@ int32_t achip_xxhash32(achip_ctx* ctx, const void* src, int64_t srcLen, int32_t 
 #define ACHIP_OP_LZ4FRAME_COMPRESS 7
 #define ACHIP_OP_SNAPPYFRAMED_DECOMPRESS 8
 #define ACHIP_OP_SNAPPYFRAMED_COMPRESS 9
+#define ACHIP_OP_LZ4HADOOP_DECOMPRESS 10
+#define ACHIP_OP_LZ4HADOOP_COMPRESS 11
+#define ACHIP_OP_SNAPPYHADOOP_DECOMPRESS 12
+#define ACHIP_OP_SNAPPYHADOOP_COMPRESS 13
 int32_t achip_batch_host(int32_t codecOp, ACHIP_BATCH_ARGS);
 /* (Staging is chunked and double-buffered: while chunk c runs on the GPU, chunk c+1 is gathered into pinned memory and uploaded
  * and chunk c-1 is downloaded and scattered to dstBase by a few host copy threads -- options "host.chunk_bytes",

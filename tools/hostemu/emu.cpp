@@ -9,7 +9,16 @@ extern "C" { long long achip_emu_counters[16]; }  // development counters of ker
 #include "../../aircompressor_amd/csrc/snappy_decompress_v4.hip"
 #include "../../aircompressor_amd/csrc/lz4_decompress_v7.hip"
 #include "../../aircompressor_amd/csrc/snappy_decompress_v5.hip"
+#include "../../aircompressor_amd/csrc/hadoop_streams.hip"
 #include <vector>
+// the decoders the emulator does not build (DPP / cross-lane copy steps) and the probes that would pick them: the probe statistics stay
+// zero, which picks the ring decoders
+namespace achip {
+hipError_t launch_lz4_decompress_lanecopy(const BatchArgs&, hipStream_t, const int32_t*) { return hipSuccess; }
+hipError_t launch_snappy_decompress_lanecopy(const BatchArgs&, hipStream_t, const int32_t*) { return hipSuccess; }
+hipError_t launch_lz4_sequence_sample(const BatchArgs&, hipStream_t, int32_t*, int32_t) { return hipSuccess; }
+hipError_t launch_lz4_mixed_groups(const BatchArgs&, hipStream_t, int32_t*, int32_t) { return hipSuccess; }
+}  // namespace achip
 extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, const int32_t* srcLen, uint8_t* dstBase, const int64_t* dstOff,
                          const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n)
 {
@@ -45,4 +54,15 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
         return achip::launch_snappy_decompress_rings(a, nullptr, 1, op - 12, nullptr);
     }
     return -1;
+}
+
+// Hadoop block streams (hadoop_streams.hip): op 0 = decompress, 1 = compress; the cooperative writer / reader kernels under the fiber emulator
+extern "C" int emu_hadoop(int op, int snappy, int bufferSize, int variant, const uint8_t* srcBase, const int64_t* srcOff, const int32_t* srcLen, uint8_t* dstBase,
+                          const int64_t* dstOff, const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n)
+{
+    achip::BatchArgs a{srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, n, 16};
+    static std::vector<uint8_t> scratch;
+    const int64_t bytes = op == 0 ? achip::hadoop_decompress_scratch_bytes(n, bufferSize) : achip::hadoop_compress_scratch_bytes(n);
+    scratch.assign((size_t)bytes, 0xCD);
+    return op == 0 ? achip::launch_hadoop_decompress(a, nullptr, scratch.data(), snappy != 0, bufferSize, variant) : achip::launch_hadoop_compress(a, nullptr, scratch.data(), snappy != 0, bufferSize);
 }
