@@ -523,14 +523,19 @@ def lz4frame_extra(torch, A, codec, dev, args):
     SURVEY 8f row 2: x-snappy-framed streams of 4 MiB (what SnappyFramedOutputStream writes: 64 KiB chunks with masked CRC-32C)."""
     out = container_extra(torch, A, codec, dev, args, "lz4frame", A.OP_LZ4FRAME_COMPRESS, A.OP_LZ4FRAME_DECOMPRESS)
     out.update(container_extra(torch, A, codec, dev, args, "snappyframed", A.OP_SNAPPYFRAMED_COMPRESS, A.OP_SNAPPYFRAMED_DECOMPRESS))
+    # SURVEY 8f row 2, second half: Hadoop block streams of 4 MiB (what Lz4HadoopOutputStream / SnappyHadoopOutputStream write at the default
+    # 256 KiB buffer: [BE length][BE length][block] per 259523 / 218422 plaintext bytes)
+    out.update(container_extra(torch, A, codec, dev, args, "lz4hadoop", A.OP_LZ4HADOOP_COMPRESS, A.OP_LZ4HADOOP_DECOMPRESS, max_c=codec.lib.achip_hadoop_max_compressed_length(0, 4 << 20, 262144)))
+    out.update(container_extra(torch, A, codec, dev, args, "snappyhadoop", A.OP_SNAPPYHADOOP_COMPRESS, A.OP_SNAPPYHADOOP_DECOMPRESS, max_c=codec.lib.achip_hadoop_max_compressed_length(1, 4 << 20, 262144)))
     return out
 
 
-def container_extra(torch, A, codec, dev, args, name, cop, dop):
+def container_extra(torch, A, codec, dev, args, name, cop, dop, max_c=None):
     out = {}
     fs, n = 4 << 20, 1024
     lib = codec.lib
-    max_c = getattr(lib, "achip_%s_max_compressed_length" % name)(fs)
+    if max_c is None:
+        max_c = getattr(lib, "achip_%s_max_compressed_length" % name)(fs)
     cstride = (max_c + 15) // 16 * 16
     i64 = dict(dtype=torch.int64, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)

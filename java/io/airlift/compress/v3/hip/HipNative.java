@@ -58,6 +58,10 @@ public final class HipNative
     public static final int OP_LZ4FRAME_COMPRESS = 7;    // achip_lz4frame_compress
     public static final int OP_SNAPPYFRAMED_DECOMPRESS = 8;  // achip_snappyframed_decompress (SURVEY 8f row 2)
     public static final int OP_SNAPPYFRAMED_COMPRESS = 9;    // achip_snappyframed_compress
+    public static final int OP_LZ4HADOOP_DECOMPRESS = 10;    // achip_lz4hadoop_decompress (SURVEY 8f row 2: Hadoop block streams)
+    public static final int OP_LZ4HADOOP_COMPRESS = 11;      // achip_lz4hadoop_compress
+    public static final int OP_SNAPPYHADOOP_DECOMPRESS = 12; // achip_snappyhadoop_decompress
+    public static final int OP_SNAPPYHADOOP_COMPRESS = 13;   // achip_snappyhadoop_compress
 
     private record MethodHandles(
             @NativeSignature(name = "achip_device_count", returnType = int.class, argumentTypes = {})
@@ -119,6 +123,28 @@ public final class HipNative
             MethodHandle lz4FrameMaxCompressedLength,
             @NativeSignature(name = "achip_snappyframed_max_compressed_length", returnType = int.class, argumentTypes = int.class)
             MethodHandle snappyFramedMaxCompressedLength,
+            // Hadoop block streams (SURVEY 8f row 2, second half)
+            @NativeSignature(name = "achip_lz4hadoop_compress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle lz4HadoopCompress,
+            @NativeSignature(name = "achip_lz4hadoop_decompress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle lz4HadoopDecompress,
+            @NativeSignature(name = "achip_snappyhadoop_compress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle snappyHadoopCompress,
+            @NativeSignature(name = "achip_snappyhadoop_decompress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle snappyHadoopDecompress,
+            @NativeSignature(name = "achip_hadoop_max_compressed_length", returnType = int.class, argumentTypes = {int.class, int.class, int.class})
+            MethodHandle hadoopMaxCompressedLength,
+            @NativeSignature(name = "achip_ctx_set_option", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, long.class})
+            MethodHandle ctxSetOption,
+            // the public xxhash package on the GPU (SURVEY 8f row 4): (ctx, data, length, seed, out*) and (ctx, base, offsets*, lengths*, seed, hashes*, count)
+            @NativeSignature(name = "achip_xxhash64", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, long.class, long.class, MemorySegment.class})
+            MethodHandle xxhash64,
+            @NativeSignature(name = "achip_xxhash32", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, long.class, int.class, MemorySegment.class})
+            MethodHandle xxhash32,
+            @NativeSignature(name = "achip_xxhash64_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, long.class, MemorySegment.class, int.class})
+            MethodHandle xxhash64Batch,
+            @NativeSignature(name = "achip_xxhash32_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, MemorySegment.class, int.class})
+            MethodHandle xxhash32Batch,
             // batched, device-resident: (op, ctx, srcBase, srcOff*, srcLen*, dstBase, dstOff*, dstCap*, outLen*, status*, errOffset*, nBlocks)
             @NativeSignature(name = "achip_batch_host", returnType = int.class, argumentTypes = {int.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
                     MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
@@ -295,6 +321,53 @@ public final class HipNative
         }
     }
 
+    /** bound the one-shot Hadoop stream writers ask of their destination: codec 0 = LZ4, 1 = Snappy (achip_hadoop_max_compressed_length) */
+    public static int hadoopMaxCompressedLength(int codec, int n, int bufferSize)
+    {
+        try {
+            int result = (int) HANDLES.hadoopMaxCompressedLength().invokeExact(codec, n, bufferSize);
+            if (result < 0) {
+                throw new IllegalArgumentException(n < 0 ? "uncompressedSize is negative: " + n : "Maximum compressed length exceeds Integer.MAX_VALUE for uncompressedSize: " + n);
+            }
+            return result;
+        }
+        catch (RuntimeException e) {
+            throw e;
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
+    // handles of the batched / one-shot hashers (io.airlift.compress.v3.xxhash.XxHashHip)
+    public static MethodHandle xxhash64()
+    {
+        return HANDLES.xxhash64();
+    }
+
+    public static MethodHandle xxhash32()
+    {
+        return HANDLES.xxhash32();
+    }
+
+    public static MethodHandle xxhash64Batch()
+    {
+        return HANDLES.xxhash64Batch();
+    }
+
+    public static MethodHandle xxhash32Batch()
+    {
+        return HANDLES.xxhash32Batch();
+    }
+
+    /** throws what {@link #toException} builds when {@code status} is negative */
+    public static void throwIfError(int status, long errorOffset)
+    {
+        if (status < 0) {
+            throw toException(status, errorOffset);
+        }
+    }
+
     public static int zstdMaxCompressedLength(int n)
     {
         try {
@@ -395,6 +468,21 @@ public final class HipNative
             }
         }
 
+        /** achip_ctx_set_option: a tuning / format option of this context (e.g. "hadoop.buffer_size") */
+        public void setOption(String name, long value)
+        {
+            try (Arena arena = Arena.ofConfined()) {
+                int result = (int) HANDLES.ctxSetOption().invokeExact(handle, arena.allocateFrom(name), value);
+                throwIfError(result, 0);
+            }
+            catch (RuntimeException e) {
+                throw e;
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+        }
+
         /** Single block through host memory: returns bytes written or throws the Java codec's exception. */
         public int singleBlock(int op, MemorySegment input, int inputLength, MemorySegment output, int outputLength)
         {
@@ -411,6 +499,10 @@ public final class HipNative
                     case OP_LZ4FRAME_DECOMPRESS -> HANDLES.lz4FrameDecompress();
                     case OP_SNAPPYFRAMED_COMPRESS -> HANDLES.snappyFramedCompress();
                     case OP_SNAPPYFRAMED_DECOMPRESS -> HANDLES.snappyFramedDecompress();
+                    case OP_LZ4HADOOP_COMPRESS -> HANDLES.lz4HadoopCompress();
+                    case OP_LZ4HADOOP_DECOMPRESS -> HANDLES.lz4HadoopDecompress();
+                    case OP_SNAPPYHADOOP_COMPRESS -> HANDLES.snappyHadoopCompress();
+                    case OP_SNAPPYHADOOP_DECOMPRESS -> HANDLES.snappyHadoopDecompress();
                     default -> throw new IllegalArgumentException("unknown op " + op);
                 };
                 result = (int) method.invokeExact(handle, input, output, inputLength, outputLength, errorOffset);
