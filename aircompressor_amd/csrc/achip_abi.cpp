@@ -85,7 +85,7 @@ struct achip_ctx {
     bool lastTwopass = false;   // the last decode was a two-pass one: its arena header leads the scratch
     bool lastLz4dAuto = false;  // the last LZ4 decode ran in auto mode: its probe count leads the scratch
     int maxSrcLenHint = 0;
-    int execVariant = 2;     // two-pass decoders: 2 = second executor (LZ4; Snappy runs the first), 1 = first executor (LDS window that slides), 0 = straight to the output buffer
+    int execVariant = 2;     // two-pass decoders: 2 = the product; 121..125, 201 = timing aids / window sizes (development)
     // scratch for the zstd pipeline (grown on demand)
     void* scratch = nullptr;
     int64_t scratchBytes = 0;

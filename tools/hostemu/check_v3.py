@@ -74,7 +74,7 @@ def cases_for(codec):
 
 
 def main():
-    for codec, ops in (("lz4", (16, 17, 18, 20, 21, 22, 24, 25)), ("snappy", (12, 13, 19, 30, 31, 32, 34, 35))):
+    for codec, ops in (("lz4", (16, 17, 18, 24, 25)), ("snappy", (12, 13, 19, 34, 35))):
         cases = cases_for(codec)
         for op in ops:
             if emu.emu_batch(op, None, None, None, None, None, None, None, None, None, 0) != 0:

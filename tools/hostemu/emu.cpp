@@ -23,25 +23,14 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
                          const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n)
 {
     achip::BatchArgs a{srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, n, 0};
-    if (op >= 20 && op <= 25) {  // two-pass LZ4: lane-per-block parse + wavefront-per-block execute; odd ops: a tiny arena, so that blocks fall back
-        // 20 / 21: the first executor (LDS window that slides); 22 / 23: the executor that writes straight to the output buffer; 24 / 25: the second executor
-        const int execVariant = op >= 24 ? 2 : (op >= 22 ? 0 : 1);
-        const bool tiny = (op & 1) != 0;
+    if (op == 24 || op == 25 || op == 34 || op == 35) {  // two-pass decoders (24 / 25 LZ4, 34 / 35 Snappy); odd ops: a tiny arena, so that blocks fall back
+        const bool snappy = op >= 34, tiny = (op & 1) != 0;
         static std::vector<uint8_t> scratch;
         const int64_t bytes = tiny ? 4096 + ((n * 12 + 4095) & ~4095LL) + 4 * 4096 : achip::lz4_twopass_scratch_bytes(n);
         scratch.assign((size_t)bytes, 0xCD);
         a.ringPad = 16;
-        return achip::launch_lz4_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, execVariant, nullptr);
-    }
-    if (op >= 30 && op <= 35) {  // two-pass Snappy; odd ops: a tiny arena, so that blocks fall back
-        // 30 / 31: pieces through the first executor; 32 / 33: the first parser and executor; 34 / 35: pieces through the second executor (the default)
-        const int execVariant = op >= 34 ? 2 : (op >= 32 ? 1001 : 1);
-        const bool tiny = (op & 1) != 0;
-        static std::vector<uint8_t> scratch;
-        const int64_t bytes = tiny ? 4096 + ((n * 12 + 4095) & ~4095LL) + 4 * 4096 : achip::lz4_twopass_scratch_bytes(n);
-        scratch.assign((size_t)bytes, 0xCD);
-        a.ringPad = 16;
-        return achip::launch_snappy_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, execVariant, nullptr);
+        return snappy ? achip::launch_snappy_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, 2, nullptr)
+                      : achip::launch_lz4_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, 2, nullptr);
     }
     if (op == 19) return achip::launch_snappy_decompress_lanewindow(a, nullptr, nullptr);
     if (op == 18) return achip::launch_lz4_decompress_lanewindow(a, nullptr, nullptr);  // lane per block + LDS output window: lane-private
