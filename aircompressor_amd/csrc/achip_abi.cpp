@@ -48,6 +48,7 @@ hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void
 int64_t hadoop_decompress_scratch_bytes(int32_t nStreams, int32_t bufferSize);
 hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize);
 int64_t hadoop_compress_scratch_bytes(int32_t nStreams);
+extern int g_zstd_pipe_exec;
 hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch);
 hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch);
 int64_t lz4frame_compress_scratch_bytes();
@@ -698,6 +699,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->hadoopBufferSize = (int)value;
     }
     else if (k == "hadoop.decompress.variant") ctx->hadoopDecompressVariant = (int)value;
+    else if (k == "zstd.decompress.exec") achip::g_zstd_pipe_exec = (int)value;  // (process-wide: a development switch between the two execute stages)
     else if (k == "decompress.ring_pad") {
         if (value < 0 || value > 256 || (value & 15) != 0) return bad_argument("ring pad must be a multiple of 16 in 0..256");
         ctx->ringPad = (int)value;

@@ -174,67 +174,46 @@ __device__ __forceinline__ void exec_block_serial(const uint8_t* __restrict__ in
     }
 }
 
-// Runs `count` records (pieces: at most 16 literal and 16 match bytes each) of one block, starting at slot 0 of chunk `chunk`.
-// in / inLen: the block's compressed bytes (literal source); out: its output.  win: WIN + 16 bytes of LDS owned by this wavefront.
-// The records were validated by the parser: every literal range lies inside the input, every match source inside the output produced
-// so far, the total inside the block's capacity.
-template <int DBG = 0, int WIN = WIN_DEFAULT>
-__device__ __forceinline__ void exec_block(uint8_t* win, const uint8_t* __restrict__ in, int32_t inLen, uint8_t* out, const uint64_t* __restrict__ arena, int32_t chunk,
-                                           int32_t count, int lane)
-{
-    if (inLen < 16) {  // (uniform)
-        exec_block_serial(in, out, arena, chunk, count, lane);
-        return;
-    }
-    constexpr int MASK = WIN - 1;
+// What `prepare` and `compose` share for one block: the window, the output buffer, the literal source, the composing cursor.
+template <int WIN>
+struct Exec {
+    static constexpr int MASK = WIN - 1;
     Window<WIN> io;
-    io.win = win;
-    const int32_t lastLoad = inLen - 16;
+    uint8_t* out;
+    const uint8_t* lit;  // where literal bytes come from (the compressed stream for LZ4 / Snappy, the literal buffer for Zstd)
+    int32_t lastLoad;    // the last position of `lit` a 16-byte load may start at (>= 0: the callers see to that)
+    int lane;
+    int32_t outPos, flushPos;  // (uniform) compose cursor; everything below flushPos is in the output buffer
 
-    // cursor of `prepare`
-    int32_t pChunk = chunk, pSlot = 0, pCount = count, pOut = 0, pSrc = 0;
-    // cursor of `compose`
-    int32_t outPos = 0, flushPos = 0;
+    __device__ __forceinline__ void init(uint8_t* win, uint8_t* out_, const uint8_t* lit_, int32_t litLen, int lane_)
+    {
+        io.win = win;
+        out = out_;
+        lit = lit_;
+        lastLoad = litLen - 16;
+        lane = lane_;
+        outPos = 0;
+        flushPos = 0;
+    }
 
-    auto prepare = [&](uint64_t r, Batch& b) {
-        int32_t nb = CHUNK_RECS - pSlot;
-        nb = nb < 64 ? nb : 64;
-        nb = nb < pCount ? nb : pCount;
-        const bool haveLink = pSlot + nb == CHUNK_RECS && nb < 64;
-        const int32_t linkChunk = haveLink ? (int32_t)(uint32_t)sx::shfl_u64(r, nb) : 0;  // (uniform)
-        if (lane >= nb) {
-            r = 0;
-        }
-        int32_t lit = rec_lit(r), ml = rec_ml(r);
-        const int32_t off = rec_off(r), skip = rec_skip(r);
-        const int32_t tot = lit + ml, adv = skip + lit;
-        const int32_t oEnd = wave_scan_incl(tot, lane), sEnd = wave_scan_incl(adv, lane);
-        int32_t k = (int32_t)__popcll(__ballot(lane < nb && oEnd <= CAP));  // a prefix: oEnd is monotone (>= 1: a piece is <= 32 bytes)
-        k = k < 1 ? 1 : k;
-        if (lane >= k) {
-            lit = 0;
-            ml = 0;
-        }
-        b.k = k;
-        b.total = wave_bcast(oEnd, k - 1);
-        const int32_t sTotal = wave_bcast(sEnd, k - 1);
+    // The second half of `prepare`: b.lit / ml / off / dstLit / k / total are set (this lane's piece; zero lengths beyond k), pOut is the
+    // batch's first output position, srcLit this lane's literal source position.  Issues the batch's two loads -- unconditionally -- and
+    // builds the dependency mask.
+    __device__ __forceinline__ void finish_prepare(Batch& b, int32_t srcLit, int32_t pOut)
+    {
+        const int32_t lit_ = b.lit, ml = b.ml, off = b.off;
         const int32_t pEnd = pOut + b.total;
-        b.lit = lit;
-        b.ml = ml;
-        b.off = off;
-        b.dstLit = pOut + oEnd - tot;
-        // the literal bytes: one 16-byte load, clamped into the stream
-        const int32_t srcLit = pSrc + sEnd - (tot - rec_ml(r));
+        // the literal bytes: one 16-byte load, clamped into the source
         const int32_t at = srcLit < lastLoad ? srcLit : lastLoad;
         b.litShift = srcLit - at;
-        b.litData = ld16(in + at);
+        b.litData = ld16(lit + at);
         // the match source: from the output buffer when it will have left the window by the time this batch is composed (then it was
         // flushed long ago: the window reaches back at least WIN - CAP bytes from the batch's start)
-        const int32_t dstM = b.dstLit + lit;
+        const int32_t dstM = b.dstLit + lit_;
         const int32_t srcM = dstM - off;
         const bool isFar = ml > 0 && srcM < pEnd - WIN;
         b.far = isFar ? 1 : 0;
-        b.farData = ld16(isFar ? out + srcM : in);
+        b.farData = ld16(isFar ? out + srcM : lit);
         // a near match whose source reaches into this batch's own output waits for exactly the lanes a .. bnd-1 that produce it (outputs are
         // contiguous and ordered over the lanes: two binary searches by lane shuffles), as far as their matches are near ones themselves
         const bool isNear = ml > 0 && !isFar;
@@ -258,18 +237,11 @@ __device__ __forceinline__ void exec_block(uint8_t* win, const uint8_t* __restri
             }
         }
         b.dep = dep;
-        pOut = pEnd;
-        pSrc += sTotal;
-        pSlot += k;
-        pCount -= k;
-        if (pSlot == CHUNK_RECS && pCount > 0) {
-            // (a batch of exactly 64 records that ends its chunk had no free lane for the link: read it now)
-            pChunk = haveLink ? linkChunk : (int32_t)(uint32_t)arena[(int64_t)pChunk * CHUNK_SLOTS + CHUNK_RECS];
-            pSlot = 0;
-        }
-    };
+    }
 
-    auto compose = [&](const Batch& b) {
+    template <int DBG>
+    __device__ __forceinline__ void compose(const Batch& b)
+    {
         // (Everything LDS here sits under a branch that only the lanes concerned take -- deliberately: an unaligned LDS access costs by
         // the lanes that take part.  Reading and writing with all lanes and selecting afterwards, flags in vector registers as in the
         // parser, measured 22.8 ms against 17.3.)
@@ -304,12 +276,77 @@ __device__ __forceinline__ void exec_block(uint8_t* win, const uint8_t* __restri
             for (int32_t base = flushPos; base < wholeEnd; base += 1024) {  // (uniform; at most two rounds)
                 const int32_t p = base + lane * 16;
                 if (p < wholeEnd) {
-                    st16(out + p, *(const u32x4*)(win + (p & MASK)));
+                    st16(out + p, *(const u32x4*)(io.win + (p & MASK)));
                 }
             }
         }
         flushPos = wholeEnd;
         wave_sync();  // (the next batch writes the window)
+    }
+
+    __device__ __forceinline__ void finish()
+    {
+        wave_sync();
+        if (flushPos + lane < outPos) {  // the last bytes (fewer than 16)
+            out[flushPos + lane] = io.win[(flushPos + lane) & MASK];
+        }
+    }
+};
+
+// Runs `count` records (pieces: at most 16 literal and 16 match bytes each) of one block, starting at slot 0 of chunk `chunk`.
+// in / inLen: the block's compressed bytes (literal source); out: its output.  win: WIN + 16 bytes of LDS owned by this wavefront.
+// The records were validated by the parser: every literal range lies inside the input, every match source inside the output produced
+// so far, the total inside the block's capacity.
+template <int DBG = 0, int WIN = WIN_DEFAULT>
+__device__ __forceinline__ void exec_block(uint8_t* win, const uint8_t* __restrict__ in, int32_t inLen, uint8_t* out, const uint64_t* __restrict__ arena, int32_t chunk,
+                                           int32_t count, int lane)
+{
+    if (inLen < 16) {  // (uniform)
+        exec_block_serial(in, out, arena, chunk, count, lane);
+        return;
+    }
+    Exec<WIN> X;
+    X.init(win, out, in, inLen, lane);
+
+    // cursor of `prepare`
+    int32_t pChunk = chunk, pSlot = 0, pCount = count, pOut = 0, pSrc = 0;
+
+    auto prepare = [&](uint64_t r, Batch& b) {
+        int32_t nb = CHUNK_RECS - pSlot;
+        nb = nb < 64 ? nb : 64;
+        nb = nb < pCount ? nb : pCount;
+        const bool haveLink = pSlot + nb == CHUNK_RECS && nb < 64;
+        const int32_t linkChunk = haveLink ? (int32_t)(uint32_t)sx::shfl_u64(r, nb) : 0;  // (uniform)
+        if (lane >= nb) {
+            r = 0;
+        }
+        int32_t lit = rec_lit(r), ml = rec_ml(r);
+        const int32_t off = rec_off(r), skip = rec_skip(r);
+        const int32_t tot = lit + ml, adv = skip + lit;
+        const int32_t oEnd = wave_scan_incl(tot, lane), sEnd = wave_scan_incl(adv, lane);
+        int32_t k = (int32_t)__popcll(__ballot(lane < nb && oEnd <= CAP));  // a prefix: oEnd is monotone (>= 1: a piece is <= 32 bytes)
+        k = k < 1 ? 1 : k;
+        if (lane >= k) {
+            lit = 0;
+            ml = 0;
+        }
+        b.k = k;
+        b.total = wave_bcast(oEnd, k - 1);
+        const int32_t sTotal = wave_bcast(sEnd, k - 1);
+        b.lit = lit;
+        b.ml = ml;
+        b.off = off;
+        b.dstLit = pOut + oEnd - tot;
+        X.finish_prepare(b, pSrc + sEnd - (tot - rec_ml(r)), pOut);
+        pOut += b.total;
+        pSrc += sTotal;
+        pSlot += k;
+        pCount -= k;
+        if (pSlot == CHUNK_RECS && pCount > 0) {
+            // (a batch of exactly 64 records that ends its chunk had no free lane for the link: read it now)
+            pChunk = haveLink ? linkChunk : (int32_t)(uint32_t)arena[(int64_t)pChunk * CHUNK_SLOTS + CHUNK_RECS];
+            pSlot = 0;
+        }
     };
 
     Batch A, B;
@@ -323,7 +360,7 @@ __device__ __forceinline__ void exec_block(uint8_t* win, const uint8_t* __restri
             rNext = load_records(arena, pChunk, pSlot, lane);
         }
         left -= A.k;
-        compose(A);
+        X.template compose<DBG>(A);
         if (left <= 0) {
             break;
         }
@@ -332,12 +369,212 @@ __device__ __forceinline__ void exec_block(uint8_t* win, const uint8_t* __restri
             rNext = load_records(arena, pChunk, pSlot, lane);
         }
         left -= B.k;
-        compose(B);
+        X.template compose<DBG>(B);
     }
-    wave_sync();
-    if (flushPos + lane < outPos) {  // the last bytes (fewer than 16)
-        out[flushPos + lane] = win[(flushPos + lane) & MASK];
+    X.finish();
+}
+
+// ---- records of any length: the executor cuts them into pieces itself (zstd_decompress_pipe.hip) ---------------------------------------
+// The Zstd sequence stage produces one record per sequence, {literal length, match length, offset} of up to 128 KiB each, and the literals
+// lie in one buffer in order.  Here a GROUP of 64 records is scanned once (output and literal positions, pieces per record), and every
+// batch takes the next 64 pieces of the group: a lane finds its piece's record by a binary search over the scanned piece counts (lane
+// shuffles), derives the piece -- at most 16 literal bytes and, behind a record's last literal bytes, at most 16 match bytes; later match
+// pieces name the largest multiple of the offset inside the periodic source region, as the LZ4 / Snappy parsers do -- and from there a
+// batch is what it is above.  The records are NOT trusted: a group with a record that runs outside the output capacity or the literal
+// buffer, or whose match starts before the output's first byte (ZstdFrameDecompressor.java:491-496), stops the block with `bad` set;
+// what was executed before it is valid, the caller sends the item to its fallback.
+struct RecordSource {  // one block's records for exec_records: `n` records at `rec`, then the literals left over as one last run
+    const uint64_t* rec;
+    int32_t n;
+    // the record layout of the Zstd sequence stage: bits 0..17 literal length, 18..35 match length, 36.. offset
+    __device__ __forceinline__ static int32_t lit_of(uint64_t r) { return (int32_t)(r & 0x3FFFF); }
+    __device__ __forceinline__ static int32_t ml_of(uint64_t r) { return (int32_t)((r >> 18) & 0x3FFFF); }
+    __device__ __forceinline__ static int32_t off_of(uint64_t r) { return (int32_t)(r >> 36); }
+};
+
+template <int DBG = 0, int WIN = WIN_DEFAULT>
+__device__ __forceinline__ int32_t exec_records(uint8_t* win, const RecordSource& S, const uint8_t* __restrict__ lit, int32_t litSize, uint8_t* out, int32_t outLimit, int lane,
+                                                bool& badOut)
+{
+    badOut = false;
+    // the clamped 16-byte literal loads need 16 readable bytes: a shorter literal buffer is copied to LDS behind the window first
+    __shared__ __attribute__((aligned(16))) uint8_t shortLit[64 * 0 + 16];
+    const uint8_t* litSrc = lit;
+    int32_t litLen = litSize;
+    if (litSize < 16) {  // (uniform)
+        if (lane < 16) {
+            shortLit[lane] = lane < litSize ? lit[lane] : 0;
+        }
+        wave_sync();
+        litSrc = shortLit;
+        litLen = 16;
     }
+    Exec<WIN> X;
+    X.init(win, out, litSrc, litLen, lane);
+
+    // ---- the group under way (per lane: one record of it) ----
+    int32_t gLit = 0, gMl = 0, gOff = 0;
+    int32_t gOutStart = 0, gLitStart = 0;  // where the record's output / literals start
+    int32_t gPieceEnd = 0;                 // pieces of the records up to and including this one (inclusive scan)
+    int32_t gPieces = 0;                   // (uniform) pieces of the group
+    int32_t cursor = 0;                    // (uniform) pieces of the group already handed out
+    int32_t nextRec = 0;                   // (uniform) first record of the next group; S.n = the last literals; S.n + 1 = nothing left
+    int32_t gOut = 0, gSrc = 0;            // (uniform) output / literal position behind the group
+    bool bad = false;                      // (uniform)
+
+    auto load_group = [&](int32_t first) -> uint64_t {  // (unconditional where there are records: indices beyond them read record 0)
+        const int32_t i = first + lane;
+        return S.n > 0 ? S.rec[i < S.n ? i : 0] : 0ull;
+    };
+    // takes the next group: scans it; returns false when nothing is left (or the group is bad)
+    auto next_group = [&](uint64_t r) -> bool {
+        for (;;) {  // (uniform) groups without pieces are skipped
+            if (nextRec > S.n || bad) {
+                return false;
+            }
+            int32_t nb = S.n - nextRec;
+            nb = nb < 64 ? nb : 64;
+            int32_t lit_ = 0, ml = 0, off = 0;
+            if (lane < nb) {
+                lit_ = RecordSource::lit_of(r);
+                ml = RecordSource::ml_of(r);
+                off = RecordSource::off_of(r);
+            }
+            if (nb == 0) {  // behind the last record: the literals left over (copyLastLiteral :518-525)
+                lit_ = lane == 0 ? litSize - gSrc : 0;
+                nb = 1;
+                nextRec = S.n + 1;
+            }
+            else {
+                nextRec += nb;
+            }
+            const int32_t tot = lit_ + ml;
+            const int32_t oEnd = wave_scan_incl(tot, lane), sEnd = wave_scan_incl(lit_, lane);
+            gLit = lit_;
+            gMl = ml;
+            gOff = off;
+            gOutStart = gOut + oEnd - tot;
+            gLitStart = gSrc + sEnd - lit_;
+            // ZstdFrameDecompressor.java:491-496 (and a negative "rest" when the sequences used more literals than there are)
+            const bool wrong = lit_ < 0 || (int64_t)gOutStart + tot > outLimit || gLitStart + lit_ > litSize || (ml > 0 && (off <= 0 || off > gOutStart + lit_));
+            if (__ballot(wrong) != 0) {  // (uniform)
+                bad = true;
+                return false;
+            }
+            // pieces: the literal pieces of 16 that carry no match, the piece with the last literal bytes and the first 16 match bytes,
+            // the remaining match pieces
+            const int32_t litFull = lit_ > 16 ? (lit_ + 15) / 16 - 1 : 0;
+            const int32_t matchRest = ml > 16 ? (ml - 16 + 15) / 16 : 0;
+            const int32_t pieces = tot > 0 ? litFull + 1 + matchRest : 0;
+            gPieceEnd = wave_scan_incl(pieces, lane);
+            gPieces = wave_bcast(gPieceEnd, 63);
+            gOut += wave_bcast(oEnd, 63);
+            gSrc += wave_bcast(sEnd, 63);
+            cursor = 0;
+            if (gPieces > 0) {
+                return true;
+            }
+            r = load_group(nextRec);  // (rare: a group of empty records -- a synchronous load)
+        }
+    };
+
+    // the next batch: up to 64 pieces of the group (fewer where CAP output bytes are reached)
+    auto prepare = [&](Batch& b) {
+        const int32_t q = cursor + lane;
+        const bool valid = q < gPieces;
+        // the record of piece q: the first lane whose inclusive piece count exceeds q
+        int32_t rIdx = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            const int32_t e = __shfl(gPieceEnd, rIdx + step - 1);
+            rIdx += e <= q ? step : 0;
+        }
+        rIdx = rIdx > 63 ? 63 : rIdx;
+        const int32_t rLit = __shfl(gLit, rIdx), rMl = __shfl(gMl, rIdx), rOff = __shfl(gOff, rIdx);
+        const int32_t rOut = __shfl(gOutStart, rIdx), rSrc = __shfl(gLitStart, rIdx);
+        const int32_t rEnd = __shfl(gPieceEnd, rIdx);
+        const int32_t litFull = rLit > 16 ? (rLit + 15) / 16 - 1 : 0;
+        const int32_t matchRest = rMl > 16 ? (rMl - 16 + 15) / 16 : 0;
+        const int32_t kk = q - (rEnd - (litFull + 1 + matchRest));  // piece index within the record
+        int32_t pl, pm, o = rOff, dst, src;
+        if (kk < litFull) {
+            pl = 16;
+            pm = 0;
+            dst = rOut + 16 * kk;
+            src = rSrc + 16 * kk;
+        }
+        else if (kk == litFull) {
+            pl = rLit - 16 * litFull;
+            pm = rMl < 16 ? rMl : 16;
+            dst = rOut + 16 * litFull;
+            src = rSrc + 16 * litFull;
+        }
+        else {
+            const int32_t m = kk - litFull;  // >= 1
+            pl = 0;
+            pm = rMl - 16 * m < 16 ? rMl - 16 * m : 16;
+            dst = rOut + rLit + 16 * m;
+            src = rSrc + rLit;
+            const uint32_t x = 16u * (uint32_t)m + (uint32_t)rOff;  // (< 2^29: lengths <= 2^18, offsets < 2^28)
+            o = rOff > 0 ? (int32_t)((x / (uint32_t)rOff) * (uint32_t)rOff) : 0;  // the largest multiple of the offset inside the periodic source region
+        }
+        if (!valid) {
+            pl = 0;
+            pm = 0;
+        }
+        const int32_t pOut = wave_bcast(dst, 0);  // (lane 0 is always valid)
+        const int32_t endRel = dst + pl + pm - pOut;
+        int32_t k = (int32_t)__popcll(__ballot(valid && endRel <= CAP));  // a prefix: the pieces are contiguous and ordered
+        k = k < 1 ? 1 : k;
+        if (lane >= k) {
+            pl = 0;
+            pm = 0;
+        }
+        b.k = k;
+        b.total = wave_bcast(endRel, k - 1);
+        b.lit = pl;
+        b.ml = pm;
+        b.off = o;
+        b.dstLit = dst;
+        X.finish_prepare(b, src, pOut);
+        cursor += k;
+    };
+
+    Batch A, B;
+    uint64_t rNext = load_group(0);
+    bool haveA = next_group(rNext), haveB = false;
+    rNext = load_group(nextRec);
+    if (haveA) {
+        prepare(A);
+    }
+    while (haveA) {  // (uniform) two batches per trip, as in exec_block
+        // ---- B: the batch behind A ----
+        haveB = true;
+        if (cursor >= gPieces) {
+            haveB = next_group(rNext);
+            rNext = load_group(nextRec);
+        }
+        if (haveB) {
+            prepare(B);
+        }
+        X.template compose<DBG>(A);
+        if (!haveB) {
+            break;
+        }
+        // ---- A: the batch behind B ----
+        haveA = true;
+        if (cursor >= gPieces) {
+            haveA = next_group(rNext);
+            rNext = load_group(nextRec);
+        }
+        if (haveA) {
+            prepare(A);
+        }
+        X.template compose<DBG>(B);
+    }
+    X.finish();
+    badOut = bad;
+    return X.outPos;
 }
 
 }  // namespace sx2

@@ -24,6 +24,7 @@
 // M/zstd/Huffman.java:52-324, M/zstd/FseTableReader.java:27-168, M/zstd/BitInputStream.java:28-206,
 // M/zstd/XxHash64.java:182-291.
 #include "zstd_dec_common.h"
+#include "achip_seqexec2.h"
 #include "zstd_codes.h"
 #include "achip_xxhash.h"
 
@@ -79,6 +80,9 @@ struct Pipe {
     int32_t first;  // first item of this tile
     int32_t count;  // items in this tile
 };
+
+// K4's choice per item: at least 80 output bytes per sequence (capacity as the stand-in for the output size)
+__device__ __forceinline__ bool long_sequences(int32_t capacity, int32_t nSeq) { return (int64_t)capacity >= 80LL * (nSeq > 0 ? nSeq : 1); }
 
 __device__ __forceinline__ void to_fallback(const Pipe& p, int32_t slot, int stage)
 {
@@ -775,7 +779,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
 
 // ---- K4: execute ----
 template <int GS, int IN_RING, int OUT_RING>
-__global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp::Pipe p)
+__global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp::Pipe p, int32_t mode)
 {
     using namespace zp;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -792,6 +796,9 @@ __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp:
         return;
     }
     const int32_t block = p.first + slot;
+    if (mode == 2 && !zp::long_sequences(a.dstCap[block], d.nDecoded)) {
+        return;  // (auto: the record executor takes this item)
+    }
     const uint8_t* src = a.srcBase + a.srcOff[block];
     uint8_t* out = a.dstBase + a.dstOff[block];
     const int32_t outLimit = a.dstCap[block];
@@ -884,6 +891,54 @@ __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp:
         }
     }
     if (g == 0) {
+        if (bad) {
+            to_fallback(p, slot, 4);
+        }
+        else if (d.hasChecksum) {
+            p.desc[slot].outSize = output;
+        }
+        else {
+            a.outLen[block] = output;
+            a.status[block] = 0;
+            a.errOffset[block] = 0;
+        }
+    }
+}
+
+// ---- K4, second version (the default): a WAVEFRONT per item runs the records through the executor of the LZ4 / Snappy two-pass decoders
+// (achip_seqexec2.h exec_records: a 4 KiB circular LDS window, every global load one batch ahead, long sequences cut into pieces of
+// 16 + 16 bytes on the fly).  The records are checked group by group (ZstdFrameDecompressor.java:491-496); an item with a record that
+// runs outside its buffers goes to the fallback list like everything irregular. ----
+// Which of the two runs an item is decided per item (mode 2, the default): the ring version is the faster one on long sequences (measured on
+// 128 KiB frames: fragments data -- 100 bytes per sequence -- 720 against 600 GiB/s; corpus -- 13 bytes per sequence -- 83 against 105), and the
+// item's capacity over its sequence count is what both kernels can see (an upper bound of the bytes per sequence: a caller that hands over far
+// more capacity than the frame needs gets the ring version).
+int g_zstd_pipe_exec = 2;  // context option zstd.decompress.exec: 2 = per item (default), 1 = this kernel, 0 = the ring version above
+
+__global__ __launch_bounds__(64) void zstd_pipe_execute2_kernel(BatchArgs a, zp::Pipe p, int32_t mode)
+{
+    using namespace zp;
+    __shared__ __attribute__((aligned(16))) uint8_t win[sx2::WIN_DEFAULT + 16];
+    const int32_t slot = blockIdx.x;
+    if (slot >= p.count) {
+        return;
+    }
+    const Desc d = p.desc[slot];
+    if (d.state != 1) {
+        return;
+    }
+    const int lane = threadIdx.x;
+    const int32_t block = p.first + slot;
+    if (mode == 2 && zp::long_sequences(a.dstCap[block], d.nDecoded)) {
+        return;  // (auto: the ring version takes this item)
+    }
+    const uint8_t* src = a.srcBase + a.srcOff[block];
+    uint8_t* out = a.dstBase + a.dstOff[block];
+    const uint8_t* lit = d.litMode == 0 ? src + d.litSrc : p.lit + (size_t)d.litBase * 64;
+    sx2::RecordSource S{p.seq + d.seqBase, d.nDecoded};
+    bool bad = false;
+    const int32_t output = sx2::exec_records<0>(win, S, lit, d.litSize, out, a.dstCap[block], lane, bad);
+    if (lane == 0) {
         if (bad) {
             to_fallback(p, slot, 4);
         }
@@ -1010,7 +1065,12 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
         hipLaunchKernelGGL(zstd_pipe_literals_kernel, dim3(w16), dim3(64), 0, stream, a, p);
         hipLaunchKernelGGL(zstd_pipe_sequences_kernel, dim3((unsigned)((p.count + zp::SEQ_ITEMS_PER_WAVE - 1) / zp::SEQ_ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
         constexpr int GS = 4, IN_RING = 128, OUT_RING = 256;
-        hipLaunchKernelGGL((zstd_pipe_execute_kernel<GS, IN_RING, OUT_RING>), dim3((unsigned)((p.count + 256 / GS - 1) / (256 / GS))), dim3(256), (size_t)(256 / GS) * (IN_RING + OUT_RING + a.ringPad), stream, a, p);
+        if (g_zstd_pipe_exec != 0) {
+            hipLaunchKernelGGL(zstd_pipe_execute2_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, (int32_t)g_zstd_pipe_exec);
+        }
+        if (g_zstd_pipe_exec != 1) {
+            hipLaunchKernelGGL((zstd_pipe_execute_kernel<GS, IN_RING, OUT_RING>), dim3((unsigned)((p.count + 256 / GS - 1) / (256 / GS))), dim3(256), (size_t)(256 / GS) * (IN_RING + OUT_RING + a.ringPad), stream, a, p, (int32_t)g_zstd_pipe_exec);
+        }
         hipLaunchKernelGGL(zstd_pipe_checksum_kernel, dim3(w16), dim3(64), 0, stream, a, p);
     }
     e = hipGetLastError();

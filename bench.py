@@ -56,6 +56,7 @@ def parse_args():
     p.add_argument("--no-sweep", action="store_true")
     p.add_argument("--exec-variant", type=int, default=-1, help="DEBUG: decompress.exec_variant (two-pass decoders)")
     p.add_argument("--section", default="all", choices=["all", "zstd", "xxhash", "lz4frame"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
+    p.add_argument("--zstd-exec", type=int, default=-1, help="zstd pipeline execute stage: 2 = chosen per item (default), 1 = wavefront per item through the record executor, 0 = LDS rings")
     p.add_argument("--zstd-variant", type=int, default=-1, help="zstd decoder: 1 = five-stage pipeline (default), 0 = one-kernel decoder")
     return p.parse_args()
 
@@ -586,6 +587,8 @@ def zstd_extra(torch, A, codec, dev, args):
     pool_n, reps = 512, 128   # 65536 frames = 8 GiB of plaintext per launch
     if args.zstd_variant >= 0:
         codec.native.set_option("zstd.decompress.variant", args.zstd_variant)
+    if args.zstd_exec >= 0:
+        codec.native.set_option("zstd.decompress.exec", args.zstd_exec)
     zc = pa.Codec("zstd", compression_level=3)
     for data_kind in ("fragments", "wordmix", "corpus"):
         plain = gen_data(torch, dev, data_kind, pool_n, fs, args.ratio, 4242)

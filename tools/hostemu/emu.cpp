@@ -55,3 +55,23 @@ extern "C" int emu_hadoop(int op, int snappy, int bufferSize, int variant, const
     scratch.assign((size_t)bytes, 0xCD);
     return op == 0 ? achip::launch_hadoop_decompress(a, nullptr, scratch.data(), snappy != 0, bufferSize, variant) : achip::launch_hadoop_compress(a, nullptr, scratch.data(), snappy != 0, bufferSize);
 }
+
+// the executor for records of any length (achip_seqexec2.h exec_records, used by the Zstd pipeline): one block, one wavefront
+namespace {
+void emu_exec_records_kernel(const uint64_t* rec, int32_t n, const uint8_t* lit, int32_t litSize, uint8_t* out, int32_t outLimit, int32_t* result)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t win[achip::sx2::WIN_DEFAULT + 16];
+    achip::sx2::RecordSource S{rec, n};
+    bool bad = false;
+    const int32_t produced = achip::sx2::exec_records<0>(win, S, lit, litSize, out, outLimit, (int)threadIdx.x, bad);
+    if (threadIdx.x == 0) {
+        result[0] = produced;
+        result[1] = bad ? 1 : 0;
+    }
+}
+}  // namespace
+extern "C" int emu_exec_records(const uint64_t* rec, int32_t n, const uint8_t* lit, int32_t litSize, uint8_t* out, int32_t outLimit, int32_t* result)
+{
+    hipLaunchKernelGGL(emu_exec_records_kernel, dim3(1), dim3(64), 0, nullptr, rec, n, lit, litSize, out, outLimit, result);
+    return 0;
+}
