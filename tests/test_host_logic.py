@@ -44,10 +44,10 @@ def test_zstd_code_arithmetic_equals_the_java_tables():
 
 
 def test_lane_private_decoder_kernels_on_the_cpu():
-    """Kernel instantiations without cross-lane traffic -- the lane-per-block LZ4 decoder (v3), and the one-lane-per-block
-    (GS = 1) instantiations of the default LZ4 / Snappy ring decoders (v2) and of the uniform-step LZ4 decoder (v4) -- are
-    compiled from the same .hip sources for the host and run one lane at a time (tools/hostemu): plaintext, status, error
-    offset and guard bands against the oracle, on the cases of the GPU parity suite, without a GPU."""
+    """The kernel sources compiled for the host and run under tools/hostemu (every thread a fiber, cross-lane operations as rendezvous, lanes
+    in a different order from pass to pass): the one-lane-per-block (GS = 1) instantiations of the ring decoders, the lane-per-block decoders
+    with an LDS window, and the cooperative two-pass decoders (parse to records + a wavefront per block; also with an arena so small that blocks
+    fall back) -- plaintext, status, error offset and guard bands against the oracle, on the cases of the GPU parity suite, without a GPU."""
     import shutil
     import sys
     import pytest
@@ -60,6 +60,10 @@ def test_lane_private_decoder_kernels_on_the_cpu():
     out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_v3.py"), "--quick"], check=True, capture_output=True, text=True, cwd=ROOT).stdout
     lines = [l for l in out.splitlines() if "mismatches" in l]
     assert lines and all(l.endswith(" 0 mismatches") for l in lines), out
+    # the executor for records of any length (the Zstd pipeline's execute stage): LZ4 blocks re-expressed as Zstd-style records + one literal
+    # buffer, executed under the emulator and compared with the plaintext; records that run outside their buffers must be refused
+    out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_records.py")], check=True, capture_output=True, text=True, cwd=ROOT).stdout
+    assert out.strip().endswith(" 0 mismatches"), out
 
 
 def test_bench_java_random_generator_equals_the_oracles(oracle):
