@@ -9,7 +9,9 @@
 
 namespace achip {
 
-template <int GS, int IN_RING, int OUT_RING, int GPL>
+// HANDOVER: the launch that decodes only the blocks a two-pass decode handed over (`only` filter) -- its own instantiation, so that kernel
+// statistics keep it apart from the launch that decodes a whole batch
+template <int GS, int IN_RING, int OUT_RING, int GPL, bool HANDOVER = false>
 __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
     // auto mode (achip_abi.cpp): both LZ4 decoders are launched, the probe's count of mixed 16-block groups picks one
@@ -24,7 +26,7 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a, 
     if (block >= batch_count(a)) {  // (a batch assembled on the device may hold fewer blocks than the launch was sized for)
         return;
     }
-    if (a.only != nullptr) {  // the blocks a two-pass decode handed over -- if it ran at all (auto mode)
+    if (HANDOVER) {  // the blocks a two-pass decode handed over -- if it ran at all (auto mode)
         if ((a.onlyStats != nullptr && lz4_pick(a.onlyStats, batch_count(a), a.onlyShortLimit) != LZ4_PICK_TWOPASS) || a.only[block] == 0) {
             return;
         }
@@ -56,7 +58,12 @@ static hipError_t lz4d2_launch(const BatchArgs& a, hipStream_t stream, const int
     constexpr int GROUPS_PER_WG = 256 / GS;
     const unsigned grid = (unsigned)((a.nBlocks + GROUPS_PER_WG - 1) / GROUPS_PER_WG);
     const size_t lds = (size_t)GROUPS_PER_WG * (IN_RING + OUT_RING + a.ringPad);
-    hipLaunchKernelGGL((lz4_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
+    if (a.only != nullptr) {
+        hipLaunchKernelGGL((lz4_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL, true>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
+    }
+    else {
+        hipLaunchKernelGGL((lz4_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL, false>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
+    }
     return hipGetLastError();
 }
 

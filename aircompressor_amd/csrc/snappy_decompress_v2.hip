@@ -7,7 +7,9 @@
 
 namespace achip {
 
-template <int GS, int IN_RING, int OUT_RING, int GPL>
+// HANDOVER: the launch that decodes only the blocks a two-pass decode handed over (`only` filter) -- its own instantiation, so that kernel
+// statistics keep it apart from the launch that decodes a whole batch
+template <int GS, int IN_RING, int OUT_RING, int GPL, bool HANDOVER = false>
 __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
     if (mixedGroups != nullptr && snappy_pick(mixedGroups, batch_count(a)) != LZ4_PICK_RINGS) {  // auto mode (achip_abi.cpp): the lane-per-block decoder takes this batch
@@ -18,7 +20,7 @@ __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs 
     const int g = threadIdx.x & (GS - 1);
     const int grp = threadIdx.x / GS;
     const int64_t block = (int64_t)blockIdx.x * GROUPS_PER_WG + grp;
-    if (a.only != nullptr && ((a.onlyStats != nullptr && lz4_pick(a.onlyStats, a.nBlocks, a.onlyShortLimit) != LZ4_PICK_TWOPASS) || (block < a.nBlocks && a.only[block] == 0))) {
+    if (HANDOVER && ((a.onlyStats != nullptr && lz4_pick(a.onlyStats, a.nBlocks, a.onlyShortLimit) != LZ4_PICK_TWOPASS) || (block < a.nBlocks && a.only[block] == 0))) {
         return;  // (the blocks a two-pass decode handed over -- if it ran at all)
     }
     if (block >= batch_count(a)) {
@@ -49,7 +51,12 @@ static hipError_t snd2_launch(const BatchArgs& a, hipStream_t stream, const int3
     constexpr int GROUPS_PER_WG = 256 / GS;
     const unsigned grid = (unsigned)((a.nBlocks + GROUPS_PER_WG - 1) / GROUPS_PER_WG);
     const size_t lds = (size_t)GROUPS_PER_WG * (IN_RING + OUT_RING + a.ringPad);
-    hipLaunchKernelGGL((snappy_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
+    if (a.only != nullptr) {
+        hipLaunchKernelGGL((snappy_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL, true>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
+    }
+    else {
+        hipLaunchKernelGGL((snappy_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL, false>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
+    }
     return hipGetLastError();
 }
 

@@ -404,11 +404,11 @@ def kernel_symbol(wl, decoder):
     if wl == "lz4_decompress":
         if decoder.endswith("LDS window"):
             return "achip::lz4_decompress_lanewindow_kernel<16, 64>"
-        return "achip::lz4_decompress_lanecopy_kernel<16, false>" if decoder.startswith("lane") else "achip::lz4_decompress_rings_kernel<4, 128, 256, 1>"
+        return "achip::lz4_decompress_lanecopy_kernel<16, false>" if decoder.startswith("lane") else "achip::lz4_decompress_rings_kernel<4, 128, 256, 1, false>"
     if wl == "snappy_decompress":
         if decoder.endswith("LDS window"):
             return "achip::snappy_decompress_lanewindow_kernel<16, 64>"
-        return "achip::snappy_decompress_lanecopy_kernel<16>" if decoder.startswith("lane") else "achip::snappy_decompress_rings_kernel<4, 128, 256, 1>"
+        return "achip::snappy_decompress_lanecopy_kernel<16>" if decoder.startswith("lane") else "achip::snappy_decompress_rings_kernel<4, 128, 256, 1, false>"
     return "achip::lz4_compress_batch_kernel<unsigned short>" if wl == "lz4_compress" else "achip::snappy_compress_tiers_kernel"
 
 
