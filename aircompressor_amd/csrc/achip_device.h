@@ -33,6 +33,9 @@ struct BatchArgs {
                                 // hand over (lz4_decompress_v7.hip)
     const int32_t* onlyStats = nullptr;   // ... and only if these probe statistics picked the two-pass decoder (auto mode; else null)
     int32_t onlyShortLimit = 12;
+    // ring decoders, batches assembled on the device: run only if countLo <= the batch's block count < countHi (the stream readers launch two
+    // lane-group sizes and the count, known on the device only, picks one: few large blocks want more lanes each)
+    int32_t countLo = 0, countHi = 0x7FFFFFFF;
 };
 
 __device__ __forceinline__ int32_t batch_count(const BatchArgs& a) { return a.nBlocksDev != nullptr ? *a.nBlocksDev : a.nBlocks; }

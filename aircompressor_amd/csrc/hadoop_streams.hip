@@ -722,16 +722,22 @@ hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void
     c.only = nullptr;
     c.onlyStats = nullptr;
     int32_t* stats = counters + 16;
+    // LZ4: the ring decoder at two lane-group sizes: 4 lanes per chunk from 32768 chunks on, 16 below (721 -> 814 GiB/s fragments, 56 -> 83 corpus at 16384 chunks) (a stream's chunks are up to 256 KiB: a few
+    // thousand of them at 4 lanes each leave most of the chip idle); the chunk count, known on the device only, picks one
+    BatchArgs big = c, small = c;
+    big.countLo = 32768;
+    small.countHi = 32768;
     e = launch_lz4_mixed_groups(c, stream, stats, 65536);
     if (snappy) {
         if (e == hipSuccess) e = launch_snappy_element_sample(c, stream, stats, 65536);
-        if (e == hipSuccess) e = launch_snappy_decompress_rings(c, stream, 4, 0, stats);
+        if (e == hipSuccess) e = launch_snappy_decompress_rings(c, stream, 4, 0, stats);  // (16 lanes per chunk measured slower for Snappy: 390 against 481 GiB/s)
         if (e == hipSuccess) e = launch_snappy_decompress_lanecopy(c, stream, stats);
         if (e == hipSuccess) e = launch_snappy_decompress_lanewindow(c, stream, stats);
     }
     else {
         if (e == hipSuccess) e = launch_lz4_sequence_sample(c, stream, stats, 65536);
-        if (e == hipSuccess) e = launch_lz4_decompress_rings(c, stream, 4, 0, stats);
+        if (e == hipSuccess) e = launch_lz4_decompress_rings(big, stream, 4, 0, stats);
+        if (e == hipSuccess) e = launch_lz4_decompress_rings(small, stream, 16, 0, stats);
         if (e == hipSuccess) e = launch_lz4_decompress_lanecopy(c, stream, stats);
         if (e == hipSuccess) e = launch_lz4_decompress_lanewindow(c, stream, stats);
     }

@@ -18,6 +18,12 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a, 
     if (mixedGroups != nullptr && lz4_pick(mixedGroups, batch_count(a)) != LZ4_PICK_RINGS) {
         return;
     }
+    {
+        const int32_t n = batch_count(a);
+        if (n < a.countLo || n >= a.countHi) {
+            return;
+        }
+    }
     ACHIP_DYNAMIC_LDS(smem);
     constexpr int GROUPS_PER_WG = 256 / GS;
     const int g = threadIdx.x & (GS - 1);

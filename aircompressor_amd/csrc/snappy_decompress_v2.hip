@@ -15,6 +15,12 @@ __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs 
     if (mixedGroups != nullptr && snappy_pick(mixedGroups, batch_count(a)) != LZ4_PICK_RINGS) {  // auto mode (achip_abi.cpp): the lane-per-block decoder takes this batch
         return;
     }
+    {
+        const int32_t n = batch_count(a);
+        if (n < a.countLo || n >= a.countHi) {
+            return;
+        }
+    }
     ACHIP_DYNAMIC_LDS(smem);
     constexpr int GROUPS_PER_WG = 256 / GS;
     const int g = threadIdx.x & (GS - 1);
