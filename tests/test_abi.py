@@ -67,6 +67,22 @@ def test_size_helpers_match_reference_kats(lib):
             assert got == ctypes.c_int32(o.max_compressed_length(codec, n)).value
 
 
+def test_hadoop_stream_bound_and_messages(lib):
+    # the capacity the one-shot Hadoop stream writers ask for (per chunk of bufferSize - overhead bytes: two big-endian ints + the codec's
+    # bound; M/lz4/Lz4HadoopOutputStream.java:44-46,107-131) against the oracle's, and the stream classes' exception texts
+    o = oracle_lib.load()
+    for codec_id, codec in ((0, "lz4"), (1, "snappy")):
+        for buf in (262144, 70000, 1024, 64):
+            for n in (0, 1, 900, 1014, 1015, 218422, 259523, 259524, 700000, 1 << 22):
+                assert lib.achip_hadoop_max_compressed_length(codec_id, n, buf) == o.hadoop_max_compressed_length(codec, n, buf), (codec, buf, n)
+    assert lib.achip_hadoop_max_compressed_length(0, -1, 262144) < 0 and lib.achip_hadoop_max_compressed_length(2, 10, 262144) < 0
+    assert lib.achip_hadoop_max_compressed_length(1, 10, 36) < 0  # (Snappy's overhead eats the whole buffer)
+    assert lib.achip_detail_message(104) == b"Stream is truncated"
+    assert lib.achip_detail_message(105) == b"encountered EOF while reading block data"
+    assert lib.achip_detail_message(106) == b"Chunk uncompressed size is greater than block size"
+    assert lib.achip_detail_message(108) == b"All input was not consumed"
+
+
 def test_status_helpers(lib):
     st = -(1 + 16 * 5)
     assert lib.achip_status_class(st) == 1 and lib.achip_status_detail(st) == 5
