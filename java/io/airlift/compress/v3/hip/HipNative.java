@@ -164,6 +164,31 @@ public final class HipNative
             @NativeSignature(name = "achip_zstd_decompress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
                     MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
             MethodHandle zstdDecompressBatch,
+            // containers, batched and device-resident: one whole frame / stream per item (same argument list)
+            @NativeSignature(name = "achip_lz4frame_decompress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle lz4FrameDecompressBatch,
+            @NativeSignature(name = "achip_lz4frame_compress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle lz4FrameCompressBatch,
+            @NativeSignature(name = "achip_snappyframed_decompress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle snappyFramedDecompressBatch,
+            @NativeSignature(name = "achip_snappyframed_compress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle snappyFramedCompressBatch,
+            @NativeSignature(name = "achip_lz4hadoop_decompress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle lz4HadoopDecompressBatch,
+            @NativeSignature(name = "achip_lz4hadoop_compress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle lz4HadoopCompressBatch,
+            @NativeSignature(name = "achip_snappyhadoop_decompress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle snappyHadoopDecompressBatch,
+            @NativeSignature(name = "achip_snappyhadoop_compress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle snappyHadoopCompressBatch,
             @NativeSignature(name = "achip_zstd_compress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
                     MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
             MethodHandle zstdCompressBatch) {}
@@ -535,6 +560,14 @@ public final class HipNative
                     case OP_SNAPPY_DECOMPRESS -> HANDLES.snappyDecompressBatch();
                     case OP_ZSTD_COMPRESS -> HANDLES.zstdCompressBatch();
                     case OP_ZSTD_DECOMPRESS -> HANDLES.zstdDecompressBatch();
+                    case OP_LZ4FRAME_COMPRESS -> HANDLES.lz4FrameCompressBatch();
+                    case OP_LZ4FRAME_DECOMPRESS -> HANDLES.lz4FrameDecompressBatch();
+                    case OP_SNAPPYFRAMED_COMPRESS -> HANDLES.snappyFramedCompressBatch();
+                    case OP_SNAPPYFRAMED_DECOMPRESS -> HANDLES.snappyFramedDecompressBatch();
+                    case OP_LZ4HADOOP_COMPRESS -> HANDLES.lz4HadoopCompressBatch();
+                    case OP_LZ4HADOOP_DECOMPRESS -> HANDLES.lz4HadoopDecompressBatch();
+                    case OP_SNAPPYHADOOP_COMPRESS -> HANDLES.snappyHadoopCompressBatch();
+                    case OP_SNAPPYHADOOP_DECOMPRESS -> HANDLES.snappyHadoopDecompressBatch();
                     default -> throw new IllegalArgumentException("unknown op " + op);
                 };
                 result = (int) method.invokeExact(handle, srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, blocks);

@@ -145,3 +145,30 @@ def test_codecs_fail_loudly_without_gpu(lib):
                 A.Lz4FrameHipDecompressor, A.SnappyFramedHipCompressor, A.SnappyFramedHipDecompressor):
         with pytest.raises(A.HipUnavailableError):
             cls()
+
+
+def test_java_sources_are_consistent_with_the_header_and_with_each_other():
+    """No JDK in this image: the Java side cannot be compiled here.  What can be checked without javac is: every
+    @NativeSignature names a symbol the header declares, with as many arguments as the declaration has parameters; every HipNative.member
+    another class uses exists in HipNative.java (the advisor's round-1 finding was exactly such a drift); braces and parentheses balance."""
+    import glob
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "aircompressor_hip.h")).read(), flags=re.S)
+    batch_params = len([p for p in re.search(r"#define ACHIP_BATCH_ARGS\s+((?:.*\\\n)*.*)", header).group(1).replace("\\\n", " ").split(",") if p.strip()])
+    native = open(os.path.join(ROOT, "java", "io", "airlift", "compress", "v3", "hip", "HipNative.java")).read()
+    for name, args in re.findall(r'@NativeSignature\(name = "([a-z0-9_]+)", returnType = [A-Za-z.]+, argumentTypes = ([^)]*)\)', native):
+        m = re.search(r"\b%s\(([^;]*)\);" % name, header)
+        assert m, name
+        decl = m.group(1).strip()
+        n_decl = 0 if decl in ("", "void") else sum(batch_params if part.strip() == "ACHIP_BATCH_ARGS" else 1 for part in decl.split(","))
+        n_java = len(re.findall(r"\b[A-Za-z]+\.class", args))
+        assert n_java == n_decl, (name, n_java, n_decl)
+    declared = set(re.findall(r"\b(?:public|static|final|private|protected)\s+(?:static\s+|final\s+)*[A-Za-z<>\[\].]+\s+([A-Za-z_][A-Za-z0-9_]*)\s*(?:\(|=|;)", native))
+    declared |= set(re.findall(r"\b(?:class|record|enum|interface)\s+([A-Za-z_][A-Za-z0-9_]*)", native))
+    for path in glob.glob(os.path.join(ROOT, "java", "**", "*.java"), recursive=True):
+        text = open(path).read()
+        code = re.sub(r'"(?:\\.|[^"\\])*"', '""', re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", text, flags=re.S)))  # (no comments, no string contents)
+        assert code.count("{") == code.count("}") and code.count("(") == code.count(")"), path
+        if path.endswith("HipNative.java"):
+            continue
+        for member in set(re.findall(r"\bHipNative\.([A-Za-z_][A-Za-z0-9_]*)", code)):
+            assert member in declared, (os.path.basename(path), member)
