@@ -143,6 +143,25 @@ __device__ __forceinline__ void wave_sync()
 #define wave_sync() hostemu::wave_sync(__FILE__, __LINE__)
 #endif
 
+// Kernels that give an item to a QUAD of lanes (the Zstd pipeline's sequence stage): the value of lane K of the caller's quad (a DPP
+// quad_perm broadcast, no LDS traffic), and the ordering point for data that goes between the lanes of a quad through LDS.  Both only
+// need quad-uniform control flow; tools/hostemu makes them rendezvous of the quad.
+#if defined(__HIPCC__)
+template <int K>
+__device__ __forceinline__ int32_t quad_bcast(int32_t v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, false);  // quad_perm:[K,K,K,K]
+}
+__device__ __forceinline__ void quad_sync() { asm volatile("" ::: "memory"); }
+#else
+template <int K>
+inline int32_t quad_bcast(int32_t v)
+{
+    return hostemu::quad_from(v, K, __FILE__, __LINE__);
+}
+#define quad_sync() hostemu::quad_sync(__FILE__, __LINE__)
+#endif
+
 // ---- group copy: n bytes, src and dst ranges do not overlap (or src+n <= dst) ----
 // Lane g of a GS-lane group moves bytes [16g,16g+16) of every GS*16-byte step; the
 // ragged tail (n mod 16) is moved one byte per lane.  Exact: never reads or writes

@@ -256,25 +256,42 @@ __global__ __launch_bounds__(64) void snappy_decompress_lanewindow_kernel(BatchA
     }
 }
 
-// auto mode: how long are the elements?  1024 sampled blocks, the first <= 192 elements of each (a lane per sample; tags only)
+// auto mode: how long are the elements?  1024 sampled blocks, the elements in the first 768 bytes of each (at most 192; a lane per sample;
+// tags only), parsed from an LDS copy of the block's head (lz4_decompress_v5.hip has the reason)
 __global__ __launch_bounds__(64) void snappy_element_sample_kernel(BatchArgs a, int32_t* stats, int32_t minBlocks)
 {
     const int32_t n = batch_count(a);
     if (n < minBlocks) {
         return;
     }
+    constexpr int HEAD = 768, STRIDE = HEAD + 4;
+    __shared__ __attribute__((aligned(16))) uint8_t heads[64 * STRIDE];
     const int32_t t = blockIdx.x * 64 + threadIdx.x;
     const int64_t block = (int64_t)t * n / 1024;
     const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
-    const int32_t inLimit = a.srcLen[block];
+    const int32_t inLen = a.srcLen[block];
+    uint8_t* const h = heads + threadIdx.x * STRIDE;
+    const int32_t inLimit = inLen < HEAD ? inLen : HEAD;
+#pragma unroll 4
+    for (int32_t p = 0; p < inLimit; p += 16) {
+        if (p + 16 <= inLen) {
+            const u32x4 v = ld16(in + p);
+            __builtin_memcpy(h + p, &v, 16);
+        }
+        else {
+            for (int32_t i = p; i < inLimit; i++) {
+                h[i] = in[i];
+            }
+        }
+    }
     int32_t ip = 0, elements = 0;
     int64_t bytes = 0;
-    while (ip < inLimit && ip < 5 && (in[ip] & 0x80) != 0) {  // the length preamble
+    while (ip < inLimit && ip < 5 && (h[ip] & 0x80) != 0) {  // the length preamble
         ip++;
     }
     ip++;
     while (ip < inLimit && elements < 192) {
-        const int32_t opc = in[ip++];
+        const int32_t opc = h[ip++];
         const int32_t entry = snappy_op_entry4(opc);
         const int32_t trailerBytes = entry >> 11;
         if (ip + trailerBytes > inLimit) {
@@ -282,7 +299,7 @@ __global__ __launch_bounds__(64) void snappy_element_sample_kernel(BatchArgs a, 
         }
         uint32_t trailer = 0;
         for (int i = 0; i < trailerBytes; i++) {
-            trailer |= (uint32_t)in[ip + i] << (8 * i);
+            trailer |= (uint32_t)h[ip + i] << (8 * i);
         }
         ip += trailerBytes;
         int64_t length = entry & 0xff;

@@ -457,12 +457,6 @@ __global__ __launch_bounds__(64) void zstd_pipe_parse_kernel(BatchArgs a, zp::Pi
 // conversions and the six bit-field extractions of a sequence run side by side; the fields' bit positions are a
 // prefix over the quad (DPP quad_perm broadcasts, no LDS traffic).  The bit container and the repeat-offset history
 // are replicated in the four lanes.  All 64 lanes of the wavefront work: 16 items per wavefront.
-template <int K>
-__device__ __forceinline__ int32_t quad_bcast(int32_t v)
-{
-    return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, false);  // quad_perm:[K,K,K,K]
-}
-
 struct QuadBits {
     int32_t start, current, consumed, b;
     uint64_t bits, A, B, P;
@@ -749,18 +743,18 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
             }
             nDecoded += over ? 0 : 1;
             if ((nDecoded & (SEQ_STAGE - 1)) == 0 && !over) {
-                wave_mem_order();
+                quad_sync();
                 const u32x4* sv = (const u32x4*)stage + r * (SEQ_STAGE / 8);
                 uint8_t* dst = (uint8_t*)(rec + nDecoded - SEQ_STAGE) + r * (SEQ_STAGE * 2);
 #pragma unroll
                 for (int t2 = 0; t2 < SEQ_STAGE / 8; t2++) {
                     st16(dst + 16 * t2, sv[t2]);
                 }
-                wave_mem_order();
+                quad_sync();
             }
         }
         if (!bad) {
-            wave_mem_order();
+            quad_sync();
             const int32_t rem = nDecoded & (SEQ_STAGE - 1);
             for (int32_t t2 = r; t2 < rem; t2 += 4) {
                 rec[nDecoded - rem + t2] = stage[t2];
@@ -782,7 +776,7 @@ template <int GS, int IN_RING, int OUT_RING>
 __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp::Pipe p, int32_t mode)
 {
     using namespace zp;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    ACHIP_DYNAMIC_LDS(smem);
     static_assert(GS == 4, "the 16-byte far-match prefetch is spread as one dword per lane");
     constexpr int GROUPS_PER_WG = 256 / GS;
     const int g = threadIdx.x & (GS - 1);

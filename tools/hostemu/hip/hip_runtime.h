@@ -19,6 +19,7 @@
 #define __global__
 #define __device__
 #define __host__
+#define __constant__ const
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define __shared__ static
@@ -29,12 +30,15 @@ typedef void* hipStream_t;
 #define hipSuccess 0
 inline hipError_t hipGetLastError() { return 0; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 
 namespace hostemu {
 
 constexpr int MAX_THREADS = 1024;
 constexpr size_t STACK_BYTES = 512 << 10;
-enum Wait { RUNNABLE = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2 };
+enum Wait { RUNNABLE = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, WAIT_QUAD = 3 };
 
 struct Fiber {
     void* sp = nullptr;
@@ -177,6 +181,38 @@ inline void run_workgroup(int nThreads, const std::function<void()>& body)
                 }
             }
         }
+        if (!blockReady) {
+            // quad-level rendezvous (kernels that give an item to four lanes: the Zstd pipeline's sequence stage): the lanes of a quad that
+            // are still running all wait at the same operation
+            for (int q = 0; q < nThreads; q += 4) {
+                bool ready = true, some = false;
+                const char* file = nullptr;
+                int line = 0;
+                for (int t = q; t < q + 4 && t < nThreads; t++) {
+                    Fiber& f = s.f[t];
+                    if (f.done) continue;
+                    if (f.wait != WAIT_QUAD) {
+                        ready = false;
+                        continue;
+                    }
+                    if (!some) {
+                        file = f.file;
+                        line = f.line;
+                        some = true;
+                    }
+                    else if (f.line != line || f.file != file) {
+                        fprintf(stderr, "hostemu: lanes of one quad wait at different cross-lane operations: %s:%d and %s:%d (thread %d)\n", file, line, f.file, f.line, t);
+                        abort();
+                    }
+                }
+                if (ready && some) {
+                    for (int t = q; t < q + 4 && t < nThreads; t++) {
+                        if (!s.f[t].done) s.f[t].wait = RUNNABLE;
+                    }
+                    released = true;
+                }
+            }
+        }
         if (!ran && !released) {
             fprintf(stderr, "hostemu: deadlock -- some lanes wait at a cross-lane operation the others never reach:\n");
             for (int t = 0; t < nThreads; t++) {
@@ -243,6 +279,19 @@ inline T shfl_from(T v, int srcLane, const char* file, int line)
     });
 }
 inline void wave_sync(const char* file, int line) { wait_here(WAIT_WAVE, file, line); }
+inline void quad_sync(const char* file, int line) { wait_here(WAIT_QUAD, file, line); }
+// value of lane k of the caller's quad (DPP quad_perm broadcast); quad-uniform control flow is enough
+template <typename T>
+inline T quad_from(T v, int k, const char* file, int line)
+{
+    State& s = S();
+    s.f[s.cur].post = to_bits(v);
+    wait_here(WAIT_QUAD, file, line);
+    const int t = (s.cur & ~3) + (k & 3);
+    const T r = lane_active(t) ? from_bits<T>(s.f[t].post) : v;
+    wait_here(WAIT_QUAD, file, line);
+    return r;
+}
 inline void block_sync(const char* file, int line) { wait_here(WAIT_BLOCK, file, line); }
 
 }  // namespace hostemu
