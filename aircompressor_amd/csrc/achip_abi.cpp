@@ -36,7 +36,7 @@ hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, 
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
 hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant, void* scratch);
 int64_t snappy_compress_scratch_bytes();
-hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant, int32_t tileMax);
+hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant, int32_t tileMax, const ZstdMbProvider* mbp);
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
 int64_t zstd_decompress_scratch_bytes(int32_t nBlocks, int32_t tileMax);
 int64_t zstd_compress_scratch_bytes(int32_t nBlocks);
@@ -77,6 +77,9 @@ struct achip_ctx {
     int snappyFramedCompressVariant = 1;  // framed writer: 1 = block list + two-tier block encoder + compaction (default), 0 = one wavefront per stream
     int snappyFramedVariant = 1;  // framed reader: 1 = chunk list + batched block decoders (default), 0 = one wavefront per stream
     int zstdTile = 65536;    // items per pass of the Zstd decode pipeline (halved automatically when its scratch cannot be allocated)
+    int zstdStreamBlocks = 65536;  // 128 KiB blocks a pass of the pipeline's multi-block stages has room for (0: multi-block frames take the one-kernel decoder); ~20 GB of scratch, allocated when a batch first holds such frames (halved as often as it takes when the device cannot give that)
+    void* zstdMbScratch = nullptr;
+    int64_t zstdMbScratchBytes = 0;
     int ringPad = 80;        // 64 bytes of far-match staging + 16: consecutive blocks start on different LDS banks
     int scratchPoison = -1;
     int32_t lastZstddBlocks = 0;  // achip_ctx_get_stat
@@ -191,6 +194,30 @@ int32_t ensure_scratch(achip_ctx* ctx, int64_t bytes)
     }
     ctx->scratchBytes = bytes;
     return 0;
+}
+
+// scratch of the Zstd pipeline's multi-block stages (achip::ZstdMbProvider::get; the stream is idle when the stages ask)
+void* zstd_mb_scratch(void* user, int64_t bytes)
+{
+    achip_ctx* ctx = (achip_ctx*)user;
+    if (bytes <= ctx->zstdMbScratchBytes) {
+        return ctx->zstdMbScratch;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        return nullptr;
+    }
+    if (ctx->zstdMbScratch) {
+        (void)hipFree(ctx->zstdMbScratch);
+        ctx->zstdMbScratch = nullptr;
+        ctx->zstdMbScratchBytes = 0;
+    }
+    if (hipMalloc(&ctx->zstdMbScratch, (size_t)bytes) != hipSuccess) {
+        ctx->zstdMbScratch = nullptr;
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    ctx->zstdMbScratchBytes = bytes;
+    return ctx->zstdMbScratch;
 }
 
 int32_t ensure_stage(achip_ctx* ctx, int64_t bytes)
@@ -313,7 +340,8 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 r = ensure_scratch(ctx, achip::zstd_decompress_scratch_bytes(a.nBlocks, ctx->zstdTile));
             }
             if (r < 0) return r;
-            e = achip::launch_zstd_decompress(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->zstddVariant, ctx->zstdTile);
+            const achip::ZstdMbProvider mbp{zstd_mb_scratch, ctx, ctx->zstdStreamBlocks};
+            e = achip::launch_zstd_decompress(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->zstddVariant, ctx->zstdTile, ctx->zstdStreamBlocks >= 16 ? &mbp : nullptr);
             ctx->lastZstddBlocks = a.nBlocks;
             ctx->lastZstddVariant = ctx->zstddVariant;
             break;
@@ -646,6 +674,7 @@ void achip_ctx_destroy(achip_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->zstdMbScratch) (void)hipFree(ctx->zstdMbScratch);
     if (ctx->hostStage) (void)hipHostFree(ctx->hostStage);
     if (ctx->devStage) (void)hipFree(ctx->devStage);
     if (ctx->mixHost) (void)hipHostFree(ctx->mixHost);
@@ -710,6 +739,10 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     }
     else if (k == "debug.scratch_poison") ctx->scratchPoison = (int)value;
     else if (k == "zstd.decompress.variant") ctx->zstddVariant = (int)value;
+    else if (k == "zstd.decompress.stream_blocks") {
+        if (value != 0 && (value < 16 || value > 131072)) return bad_argument("zstd.decompress.stream_blocks must be 0 or 16..131072");
+        ctx->zstdStreamBlocks = (int)value;
+    }
     else if (k == "zstd.compress.variant") ctx->zstdcVariant = (int)value;
     else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;
     else if (k == "decompress.exec_variant") ctx->execVariant = (int)value;
@@ -753,13 +786,22 @@ int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name)
         if (hipMemcpy(v, (const uint8_t*)ctx->scratch + (ctx->lastLz4dAuto ? 4096 : 0), sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
         return v[2];
     }
+    if (k == "zstd.decompress.multiblock_items" || k == "zstd.decompress.multiblock_blocks" || k == "zstd.decompress.multiblock_fast_items") {
+        // the last Zstd decode: items K1 handed to the multi-block stages, their blocks, items those stages finished
+        if (ctx->lastZstddBlocks <= 0 || ctx->scratch == nullptr || ctx->lastZstddVariant == 0) return -1;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+        int32_t v = 0;
+        const int word = k == "zstd.decompress.multiblock_items" ? 40 : (k == "zstd.decompress.multiblock_blocks" ? 41 : 42);
+        if (hipMemcpy(&v, (const int32_t*)ctx->scratch + word, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        return v;
+    }
     const std::string prefix = "zstd.decompress.fallback_";
     if (k.compare(0, prefix.size(), prefix) == 0) {
         // "items": all items handed to the one-kernel decoder; "stage1".."stage5": by the stage that handed them over
         const std::string what = k.substr(prefix.size());
         int word = -1;
         if (what == "items") word = 0;
-        else if (what.size() == 6 && what.compare(0, 5, "stage") == 0 && what[5] >= '1' && what[5] <= '5') word = 32 + (what[5] - '0');
+        else if (what.size() == 6 && what.compare(0, 5, "stage") == 0 && what[5] >= '1' && what[5] <= '6') word = 32 + (what[5] - '0');  // (6: the multi-block stages' walk)
         if (word < 0) return -1;
         if (ctx->lastZstddBlocks <= 0 || ctx->scratch == nullptr) return -1;
         if (ctx->lastZstddVariant == 0) return word == 0 ? ctx->lastZstddBlocks : 0;

@@ -143,6 +143,15 @@ __device__ __forceinline__ void wave_sync()
 #define wave_sync() hostemu::wave_sync(__FILE__, __LINE__)
 #endif
 
+// The Zstd decode pipeline's multi-block stages ask their caller for scratch only when a batch holds multi-block frames (the request
+// comes after a stream synchronisation: `get` may allocate; nullptr = none, the frames then take the slow path).  passBlocks: 128 KiB
+// blocks per pass through the stages.
+struct ZstdMbProvider {
+    void* (*get)(void* user, int64_t bytes);
+    void* user;
+    int32_t passBlocks;
+};
+
 // Kernels that give an item to a QUAD of lanes (the Zstd pipeline's sequence stage): the value of lane K of the caller's quad (a DPP
 // quad_perm broadcast, no LDS traffic), and the ordering point for data that goes between the lanes of a quad through LDS.  Both only
 // need quad-uniform control flow; tools/hostemu makes them rendezvous of the quad.

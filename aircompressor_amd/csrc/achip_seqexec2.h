@@ -383,9 +383,25 @@ __device__ __forceinline__ void exec_block(uint8_t* win, const uint8_t* __restri
 // batch is what it is above.  The records are NOT trusted: a group with a record that runs outside the output capacity or the literal
 // buffer, or whose match starts before the output's first byte (ZstdFrameDecompressor.java:491-496), stops the block with `bad` set;
 // what was executed before it is valid, the caller sends the item to its fallback.
+// An offset field at or above REP_SENTINEL names a repeat offset the producer could not know -- the Zstd sequence stage decodes the blocks
+// of a multi-block frame side by side, and a block's first repeat-offset codes refer to the history the block BEFORE it leaves behind:
+// REP_SENTINEL | k << 16 | m  stands for  max(rep[k] - m, 1), rep[] being the history at the block's start (ZstdFrameDecompressor.java:419-452:
+// every "offset - 1" step clamps at 1).  Real offsets are at most 1 << 24 (the stage rejects larger ones).
+constexpr int32_t REP_SENTINEL = 1 << 25;
+__device__ __forceinline__ int32_t rep_resolve(int32_t v, int32_t rep0, int32_t rep1, int32_t rep2)
+{
+    if (v < REP_SENTINEL) {
+        return v;
+    }
+    const int32_t k = (v >> 16) & 3;
+    const int32_t r = (k == 0 ? rep0 : (k == 1 ? rep1 : rep2)) - (v & 0xFFFF);
+    return r < 1 ? 1 : r;
+}
+
 struct RecordSource {  // one block's records for exec_records: `n` records at `rec`, then the literals left over as one last run
     const uint64_t* rec;
     int32_t n;
+    int32_t rep0, rep1, rep2;  // the repeat-offset history at the block's start (only read where a record holds a sentinel)
     // the record layout of the Zstd sequence stage: bits 0..17 literal length, 18..35 match length, 36.. offset
     __device__ __forceinline__ static int32_t lit_of(uint64_t r) { return (int32_t)(r & 0x3FFFF); }
     __device__ __forceinline__ static int32_t ml_of(uint64_t r) { return (int32_t)((r >> 18) & 0x3FFFF); }
@@ -394,8 +410,11 @@ struct RecordSource {  // one block's records for exec_records: `n` records at `
 
 template <int DBG = 0, int WIN = WIN_DEFAULT>
 __device__ __forceinline__ int32_t exec_records(uint8_t* win, const RecordSource& S, const uint8_t* __restrict__ lit, int32_t litSize, uint8_t* out, int32_t outLimit, int lane,
-                                                bool& badOut)
+                                                bool& badOut, int32_t startPos = 0)
 {
+    // startPos > 0: the block continues an output whose first startPos bytes this wavefront produced by earlier calls with the same
+    // window (the blocks of one Zstd frame): positions, offsets and the capacity are those of the whole output, the window still holds
+    // its last bytes, and everything below startPos is in the output buffer already.
     badOut = false;
     // the clamped 16-byte literal loads need 16 readable bytes: a shorter literal buffer is copied to LDS behind the window first
     __shared__ __attribute__((aligned(16))) uint8_t shortLit[64 * 0 + 16];
@@ -411,6 +430,8 @@ __device__ __forceinline__ int32_t exec_records(uint8_t* win, const RecordSource
     }
     Exec<WIN> X;
     X.init(win, out, litSrc, litLen, lane);
+    X.outPos = startPos;
+    X.flushPos = startPos & ~15;  // (the bytes between were written by the call before, and are written again with the first flush)
 
     // ---- the group under way (per lane: one record of it) ----
     int32_t gLit = 0, gMl = 0, gOff = 0;
@@ -419,7 +440,7 @@ __device__ __forceinline__ int32_t exec_records(uint8_t* win, const RecordSource
     int32_t gPieces = 0;                   // (uniform) pieces of the group
     int32_t cursor = 0;                    // (uniform) pieces of the group already handed out
     int32_t nextRec = 0;                   // (uniform) first record of the next group; S.n = the last literals; S.n + 1 = nothing left
-    int32_t gOut = 0, gSrc = 0;            // (uniform) output / literal position behind the group
+    int32_t gOut = startPos, gSrc = 0;     // (uniform) output / literal position behind the group
     bool bad = false;                      // (uniform)
 
     auto load_group = [&](int32_t first) -> uint64_t {  // (unconditional where there are records: indices beyond them read record 0)
@@ -438,7 +459,7 @@ __device__ __forceinline__ int32_t exec_records(uint8_t* win, const RecordSource
             if (lane < nb) {
                 lit_ = RecordSource::lit_of(r);
                 ml = RecordSource::ml_of(r);
-                off = RecordSource::off_of(r);
+                off = rep_resolve(RecordSource::off_of(r), S.rep0, S.rep1, S.rep2);
             }
             if (nb == 0) {  // behind the last record: the literals left over (copyLastLiteral :518-525)
                 lit_ = lane == 0 ? litSize - gSrc : 0;

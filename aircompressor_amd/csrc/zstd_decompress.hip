@@ -700,7 +700,7 @@ constexpr int ZD_MAX_WAVES = 256 * 8;  // persistent waves: 8 per CU
 int64_t zstd_decompress_general_scratch_bytes() { return 4096 + (int64_t)sizeof(zd::FseTable) * 3 + (int64_t)ZD_MAX_WAVES * zd::LIT_SLAB; }
 
 int64_t zstd_decompress_pipe_scratch_bytes(int32_t nBlocks, int32_t tileMax);
-hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, void* scratch, void* generalScratch, int32_t tileMax);
+hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, void* scratch, void* generalScratch, int32_t tileMax, const ZstdMbProvider* mbp);
 void* zstd_decompress_pipe_general_scratch(void* scratch, int32_t nBlocks, int32_t tileMax);
 
 int64_t zstd_decompress_scratch_bytes(int32_t nBlocks, int32_t tileMax) { return zstd_decompress_pipe_scratch_bytes(nBlocks, tileMax); }
@@ -727,7 +727,7 @@ hipError_t launch_zstd_decompress_list(const BatchArgs& a, hipStream_t stream, v
 }
 
 // variant 1 (default): five-stage pipeline + one-kernel decoder for whatever it hands back; variant 0: one-kernel decoder only
-hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant, int32_t tileMax)
+hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant, int32_t tileMax, const ZstdMbProvider* mbp)
 {
     (void)scratchBytes;
     if (a.nBlocks <= 0) {
@@ -740,7 +740,7 @@ hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* 
         if (e != hipSuccess) return e;
         return launch_zstd_decompress_list(a, stream, general, nullptr, nullptr);
     }
-    return launch_zstd_decompress_pipe(a, stream, scratch, general, tileMax);
+    return launch_zstd_decompress_pipe(a, stream, scratch, general, tileMax, mbp);
 }
 
 }  // namespace achip

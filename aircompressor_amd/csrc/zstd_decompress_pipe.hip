@@ -15,10 +15,14 @@
 //   K5 checksum   16 items per wavefront   XXH64: the four accumulators of an item on 4 lanes
 //
 // Scope: items that hold exactly one frame with exactly one compressed block (what ZstdFrameCompressor and
-// libzstd emit for inputs <= 128 KiB -- BASELINE configs[3]) with a Huffman table log <= 11.  Everything else,
-// and every item in which ANY stage sees ANYTHING irregular, is appended to a fallback list and decoded from
-// scratch by the one-kernel decoder afterwards, which reports the Java-exact status / offset.  The stages
-// therefore only have to DETECT every condition the Java decoder rejects (in any order), never to classify it.
+// libzstd emit for inputs <= 128 KiB -- BASELINE configs[3]) with a Huffman table log <= 11 go through K1..K5 as
+// described.  Items that hold exactly one frame of SEVERAL blocks, or of a raw / RLE block (what ZstdOutputStream,
+// ZstdFrameCompressor and libzstd emit for longer inputs: SURVEY 8f row 3) are collected by K1 and go through the
+// multi-block stages at the end of this file, where the slots of K2 / K3 are BLOCKS and K4 / K5 walk a frame's blocks
+// in order.  Everything else, and every item in which ANY stage sees ANYTHING irregular, is appended to a fallback
+// list and decoded from scratch by the one-kernel decoder afterwards, which reports the Java-exact status / offset.
+// The stages therefore only have to DETECT every condition the Java decoder rejects (in any order), never to
+// classify it.
 //
 // Reference (same functions as zstd_decompress.hip): M/zstd/ZstdFrameDecompressor.java:135-607,708-962,
 // M/zstd/Huffman.java:52-324, M/zstd/FseTableReader.java:27-168, M/zstd/BitInputStream.java:28-206,
@@ -27,6 +31,7 @@
 #include "achip_seqexec2.h"
 #include "zstd_codes.h"
 #include "achip_xxhash.h"
+#include <vector>
 
 namespace achip {
 
@@ -65,6 +70,33 @@ struct Desc {
 };
 static_assert(sizeof(Desc) == 128, "Desc is 128 bytes");
 
+// ---- multi-block frames: one item = one frame; a SLOT of the stages is one of its blocks ----
+struct MbItem {            // per item routed to the multi-block stages (index j in K1's list)
+    int32_t item;          // index in the caller's batch
+    int32_t firstBlock;    // its first block, counted over all listed items (a pass takes a range of items, its slots count from the range's first block)
+    int32_t nBlocks;
+    int32_t state;         // 1 = on the fast path, 0 = handed to the fallback list
+    int32_t hasChecksum;
+    uint32_t checksum;
+    int32_t outSize;       // execute stage: bytes produced
+    uint32_t litUnits;     // what its blocks will take from the literal arena (64-byte units) and from the sequence arena (records), as
+    uint32_t seqs;         // their headers announce it: the host cuts the list into passes that fit the arenas
+    int32_t pad[3];
+};
+static_assert(sizeof(MbItem) == 48, "MbItem is 48 bytes");
+
+struct MbBlock {           // per block slot, written by the walk
+    int32_t itemSlot;      // j
+    int32_t srcPos;        // the block's content (behind its 3-byte header), relative to the item's source
+    int32_t size;          // Block_Size
+    int32_t kind;          // 0 raw, 1 RLE, 2 compressed; < 0: the slot is not in use
+    int32_t hufSlot;       // the slot whose Huffman table the literals use (its own when it defines one; -1: none defined so far)
+    int32_t fseSlot[3];    // the same for the literal-length, offset and match-length tables
+    int32_t repOut[3];     // K3: the repeat-offset history behind the block (real offsets, or sentinels for "what it was before the block")
+    int32_t pad;
+};
+static_assert(sizeof(MbBlock) == 48, "MbBlock is 48 bytes");
+
 struct Pipe {
     Desc* desc;
     uint16_t* huf;
@@ -78,7 +110,16 @@ struct Pipe {
     int32_t* fallbackCount;
     int32_t* fallback;
     int32_t first;  // first item of this tile
-    int32_t count;  // items in this tile
+    int32_t count;  // items in this tile (multi-block stages: block slots of this pass)
+    // multi-block stages (K1 only appends to mbList; nullptr there: multi-block frames go to the fallback list)
+    int32_t* mbList;
+    int32_t* mbCount;     // (= counters + 40; + 41: blocks of all listed items)
+    MbItem* mbItem;
+    MbBlock* mb;
+    int32_t passFirst;    // this pass: the first block of its first item (slot 0) ...
+    int32_t itemFirst, itemEnd;  // ... and its items [itemFirst, itemEnd) of the list
+    int32_t mbSlots;      // what one pass can hold: block slots, literal arena units, sequence records (an item beyond that goes to the fallback list)
+    uint32_t mbLitCap, mbSeqCap;
 };
 
 // K4's choice per item: at least 80 output bytes per sequence (capacity as the stand-in for the output size)
@@ -91,21 +132,50 @@ __device__ __forceinline__ void to_fallback(const Pipe& p, int32_t slot, int sta
     const int32_t k = atomicAdd(p.fallbackCount, 1);
     p.fallback[k] = p.first + slot;
 }
+// multi-block stages: the ITEM leaves the fast path (once: its blocks fail independently of each other)
+__device__ __forceinline__ void mb_to_fallback(const Pipe& p, int32_t j, int stage)
+{
+    if (atomicExch(&p.mbItem[j].state, 0) == 1) {
+        atomicAdd(p.fallbackCount + 32 + stage, 1);
+        const int32_t k = atomicAdd(p.fallbackCount, 1);
+        p.fallback[k] = p.mbItem[j].item;
+    }
+}
+template <bool MB>
+__device__ __forceinline__ void slot_to_fallback(const Pipe& p, int32_t slot, int stage)
+{
+    if (MB) {
+        p.desc[slot].state = 0;
+        mb_to_fallback(p, p.mb[slot].itemSlot, stage);
+    }
+    else {
+        to_fallback(p, slot, stage);
+    }
+}
+// the caller's item behind a slot
+template <bool MB>
+__device__ __forceinline__ int32_t slot_item(const Pipe& p, int32_t slot)
+{
+    return MB ? p.mbItem[p.mb[slot].itemSlot].item : p.first + slot;
+}
 
 // ---- K1 ----
-// returns true when the item is on the fast path and d is complete (wave-uniform)
-__device__ bool parse_item(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot, const FseTable* dflt, Desc& d)
+__device__ bool parse_block(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot, const FseTable* dflt, Desc& d, int32_t input, int32_t blockSize, bool hufBefore, int32_t fseBefore);
+
+// returns 1 when the item is on the fast path and d is complete, 2 when it is a candidate for the multi-block stages, 0 otherwise
+// (wave-uniform)
+__device__ int32_t parse_item(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot, const FseTable* dflt, Desc& d)
 {
     if (c.outCap <= 0) {
-        return false;
+        return 0;
     }
     const int32_t inputLimit = c.inLen;
     if (inputLimit < 4 + 1 + 3 + 3) {
-        return false;
+        return 0;
     }
     int32_t input = 0;
     if ((uint32_t)rd_le(c, input, 4) != 0xFD2FB528u) {
-        return false;
+        return 0;
     }
     input += 4;
     const int32_t headerAddress = input;
@@ -115,33 +185,43 @@ __device__ bool parse_item(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot,
     const int32_t csDesc = fhd >> 6;
     const int32_t headerSize = 1 + (singleSegment ? 0 : 1) + (dictDesc == 0 ? 0 : (1 << (dictDesc - 1))) + (csDesc == 0 ? (singleSegment ? 1 : 0) : (1 << csDesc));
     if (dictDesc != 0 || headerSize > inputLimit - headerAddress) {
-        return false;
+        return 0;
     }
     if (!singleSegment) {
         const int32_t wd = (int32_t)rd_le(c, input++, 1);
         const uint32_t base = 1u << ((10 + (wd >> 3)) & 31);
         const int32_t windowSize = (int32_t)(base + (uint32_t)(((int32_t)base / 8) * (wd & 7)));
         if (windowSize > MAX_WINDOW_SIZE || windowSize < 0) {
-            return false;
+            return 0;
         }
     }
     input = headerAddress + headerSize;
     d.hasChecksum = (fhd & 4) != 0 ? 1 : 0;
     if (input + 3 > inputLimit) {
-        return false;
+        return 0;
     }
     const int32_t header = (int32_t)rd_le(c, input, 3);
     input += 3;
     const int32_t blockSize = (header >> 3) & 0x1FFFFF;
-    if ((header & 1) == 0 || ((header >> 1) & 3) != 2 || blockSize > MAX_BLOCK_SIZE || blockSize < 3) {
-        return false;  // more than one block, or a raw / RLE block
+    if ((header & 1) == 0 || ((header >> 1) & 3) != 2) {
+        return p.mbList != nullptr ? 2 : 0;  // more than one block, or a raw / RLE block: the multi-block stages' walk looks at it
+    }
+    if (blockSize > MAX_BLOCK_SIZE || blockSize < 3) {
+        return 0;
     }
     if ((int64_t)input + blockSize + (d.hasChecksum ? 4 : 0) != inputLimit) {
-        return false;  // truncated, or another frame follows
+        return 0;  // truncated, or another frame follows
     }
-    const int32_t blockStart = input;
+    d.checksum = d.hasChecksum ? (uint32_t)rd_le(c, input + blockSize, 4) : 0u;
+    return parse_block(c, sh, p, slot, dflt, d, input, blockSize, false, 0) ? 1 : 0;
+}
+
+// One compressed block: `input` is its first byte, d receives everything K2 / K3 / K4 need.  hufBefore: an earlier block of the frame
+// left a Huffman table behind (treeless literals may use it: the caller's link says whose); fseBefore bit k: the same for the
+// literal-length / offset / match-length table (repeat mode).  Returns false for everything the stages do not take.
+__device__ bool parse_block(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot, const FseTable* dflt, Desc& d, int32_t input, int32_t blockSize, bool hufBefore, int32_t fseBefore)
+{
     const int32_t blockLimit = input + blockSize;
-    d.checksum = d.hasChecksum ? (uint32_t)rd_le(c, blockLimit, 4) : 0u;
 
     // literals section header (decode*Literals, ZstdFrameDecompressor.java:708-858)
     const int32_t b0 = (int32_t)rd_le(c, input, 1);
@@ -187,8 +267,8 @@ __device__ bool parse_item(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot,
         }
     }
     else {
-        if (literalsBlockType == 3 || blockSize < 5) {
-            return false;  // a first block cannot reuse a table
+        if ((literalsBlockType == 3 && !hufBefore) || blockSize < 5) {
+            return false;  // (nothing to reuse: "Dictionary is corrupted" :292)
         }
         int32_t compressedSize, uncompressedSize, headerBytes;
         bool singleStream = false;
@@ -217,11 +297,13 @@ __device__ bool parse_item(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot,
         input += headerBytes;
         const int32_t streamsLimit = input + compressedSize;
         int32_t tl = 0;
-        const int32_t n = huf_read_table(c, sh, input, compressedSize, &tl);
-        if (n < 0 || tl > FAST_HUF_LOG) {
-            return false;
+        if (literalsBlockType == 2) {
+            const int32_t n = huf_read_table(c, sh, input, compressedSize, &tl);
+            if (n < 0 || tl > FAST_HUF_LOG) {
+                return false;
+            }
+            input += n;
         }
-        input += n;
         d.litMode = 2;
         d.litSize = uncompressedSize;
         d.litSrc = 0;
@@ -254,10 +336,13 @@ __device__ bool parse_item(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot,
                 return false;  // the fourth segment would be negative
             }
         }
-        // publish the table (1 << tl entries; the rest of the slot is never indexed)
-        uint16_t* g = p.huf + (size_t)slot * HUF_SLOT;
-        for (int32_t i = c.lane * 8; i < (1 << tl); i += 64 * 8) {
-            *(u32x4*)(g + i) = *(const u32x4*)(sh.huf + i);
+        // publish the table (1 << tl entries; the rest of the slot is never indexed); treeless literals: the table, and its log, are those
+        // of the slot the block's link names
+        if (literalsBlockType == 2) {
+            uint16_t* g = p.huf + (size_t)slot * HUF_SLOT;
+            for (int32_t i = c.lane * 8; i < (1 << tl); i += 64 * 8) {
+                *(u32x4*)(g + i) = *(const u32x4*)(sh.huf + i);
+            }
         }
         input = streamsLimit;
     }
@@ -318,9 +403,12 @@ __device__ bool parse_item(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot,
             const int16_t* dnorm = k == 0 ? LL_DEFAULT_NORM : (k == 1 ? OF_DEFAULT_NORM : ML_DEFAULT_NORM);
             int32_t tableLog = 0;
             if (mode == 3) {
-                return false;  // nothing to repeat in a first block
+                if (((fseBefore >> k) & 1) == 0) {
+                    return false;  // nothing to repeat
+                }
+                // (the table and its log are those of the slot the block's link names)
             }
-            if (mode == 1) {
+            else if (mode == 1) {
                 if (input >= blockLimit) {
                     return false;
                 }
@@ -394,7 +482,6 @@ __device__ bool parse_item(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot,
     d.seqStart = input;
     d.seqEnd = blockLimit;
     d.outSize = 0;
-    (void)blockStart;
     return true;
 }
 
@@ -439,11 +526,14 @@ __global__ __launch_bounds__(64) void zstd_pipe_parse_kernel(BatchArgs a, zp::Pi
     for (int i = 0; i < 6; i++) {
         d.pad[i] = 0;
     }
-    const bool ok = parse_item(c, sh, p, slot, dflt, d);
-    d.state = ok ? 1 : 0;
+    const int32_t r = parse_item(c, sh, p, slot, dflt, d);
+    d.state = r == 1 ? 1 : 0;
     if (c.lane == 0) {
         p.desc[slot] = d;
-        if (!ok) {
+        if (r == 2) {
+            p.mbList[atomicAdd(p.mbCount, 1)] = block;
+        }
+        else if (r == 0) {
             const int32_t k = atomicAdd(p.fallbackCount, 1);
             p.fallback[k] = block;
             atomicAdd(p.fallbackCount + 32 + 1, 1);
@@ -562,7 +652,9 @@ __device__ __forceinline__ bool huf_decode_stream_win(QuadBits& b, const uint16_
     return b.start == b.current && b.consumed == 64;
 }
 
-// ---- K2: literals ----
+// ---- K2: literals (MB: the slots are the blocks of multi-block frames; a block with treeless literals uses the table of the slot its
+// link names) ----
+template <bool MB>
 __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp::Pipe p)
 {
     using namespace zp;
@@ -571,18 +663,28 @@ __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp:
     const int q = lane >> 2;  // item of this lane
     const int s = lane & 3;   // stream of this lane
     const int32_t slot = blockIdx.x * ITEMS_PER_WAVE + q;
-    const bool valid = slot < p.count;
+    bool valid = slot < p.count;
+    int32_t tableSlot = slot;
+    if (MB && valid) {
+        const MbBlock b = p.mb[slot];
+        valid = b.kind == 2 && p.mbItem[b.itemSlot].state == 1;
+        tableSlot = b.hufSlot;
+    }
     Desc d;
     d.state = 0;
     if (valid) {
         d = p.desc[slot];
     }
     const bool live = valid && d.state == 1;
+    if (MB && live && d.litMode == 2) {
+        d.hufLog = tableSlot >= 0 ? p.desc[tableSlot].hufLog : 0;  // (its own, or that of the block that defined the table)
+    }
     // stage the 16 tables (each copy is done by the whole wavefront)
     for (int k = 0; k < ITEMS_PER_WAVE; k++) {
         const int32_t useHuf = __shfl((live && d.litMode == 2) ? d.hufLog : 0, k * 4);
+        const int32_t from = __shfl(tableSlot, k * 4);
         if (useHuf > 0) {
-            const uint16_t* g = p.huf + (size_t)(blockIdx.x * ITEMS_PER_WAVE + k) * HUF_SLOT;
+            const uint16_t* g = p.huf + (size_t)from * HUF_SLOT;
             for (int32_t i = lane * 8; i < (1 << useHuf); i += 64 * 8) {
                 *(u32x4*)(tables + k * HUF_SLOT + i) = *(const u32x4*)(g + i);
             }
@@ -591,7 +693,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp:
     __syncthreads();
     int32_t bad = 0;
     if (live && d.litMode != 0) {
-        const int32_t block = p.first + slot;
+        const int32_t block = slot_item<MB>(p, slot);
         uint8_t* lit = p.lit + (size_t)d.litBase * 64;
         if (d.litMode == 1) {
             const uint32_t v = (uint32_t)(d.litSrc & 0xFF) * 0x01010101u;
@@ -628,11 +730,15 @@ __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp:
     // any failing stream sends the whole item to the fallback list
     const unsigned long long badMask = __ballot(bad != 0);
     if (live && s == 0 && ((badMask >> (q * 4)) & 0xFull) != 0) {
-        to_fallback(p, slot, 2);
+        slot_to_fallback<MB>(p, slot, 2);
     }
 }
 
-// ---- K3: sequences ----
+// ---- K3: sequences (MB: the slots are the blocks of multi-block frames -- each of a block's three tables may be that of an earlier
+// block (repeat mode), and the repeat-offset history at the block's start is what the block before leaves behind, which is not known
+// here: the history starts as three SENTINELS (achip_seqexec2.h REP_SENTINEL), records may hold sentinels, and the history behind the
+// block goes to MbBlock::repOut for the execute stage, which walks the blocks in order and knows) ----
+template <bool MB>
 __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp::Pipe p)
 {
     using namespace zp;
@@ -650,19 +756,49 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
         codeTab[64 + lane] = (uint32_t)base | ((uint32_t)bits << 24);
     }
     const int32_t slot = blockIdx.x * SEQ_ITEMS_PER_WAVE + q;
-    const bool valid = q < SEQ_ITEMS_PER_WAVE && slot < p.count;
+    bool valid = q < SEQ_ITEMS_PER_WAVE && slot < p.count;
+    int32_t from0 = slot, from1 = slot, from2 = slot;  // the slots the literal-length, offset and match-length tables come from
+    if (MB && valid) {
+        const MbBlock b = p.mb[slot];
+        valid = b.kind == 2 && p.mbItem[b.itemSlot].state == 1;
+        from0 = b.fseSlot[0];
+        from1 = b.fseSlot[1];
+        from2 = b.fseSlot[2];
+    }
     Desc d;
     d.state = 0;
     d.nbSeq = 0;
     if (valid) {
         d = p.desc[slot];
     }
-    const bool live = valid && d.state == 1 && d.nbSeq > 0;
+    const bool live = valid && d.state == 1 && d.nbSeq > 0 && (!MB || (from0 >= 0 && from1 >= 0 && from2 >= 0));
+    if (MB && live) {
+        d.log[0] = p.desc[from0].log[0];
+        d.log[1] = p.desc[from1].log[1];
+        d.log[2] = p.desc[from2].log[2];
+    }
     for (int k = 0; k < SEQ_ITEMS_PER_WAVE; k++) {
         if (__shfl(live ? 1 : 0, k * 4) != 0) {
-            const uint16_t* g = p.fse + (size_t)(blockIdx.x * SEQ_ITEMS_PER_WAVE + k) * FSE_SLOT;
-            for (int32_t i = lane * 8; i < FSE_SLOT; i += 64 * 8) {
-                *(u32x4*)(tables + k * FSE_SLOT + i) = *(const u32x4*)(g + i);
+            if (MB) {
+                const int32_t f0 = __shfl(from0, k * 4), f1 = __shfl(from1, k * 4), f2 = __shfl(from2, k * 4);
+                uint16_t* t = tables + k * FSE_SLOT;
+                // the three state tables (512, 256, 512 entries) and the three count tables (64 entries each), each from its slot
+                *(u32x4*)(t + FSE_LL + lane * 8) = *(const u32x4*)(p.fse + (size_t)f0 * FSE_SLOT + FSE_LL + lane * 8);
+                *(u32x4*)(t + FSE_ML + lane * 8) = *(const u32x4*)(p.fse + (size_t)f2 * FSE_SLOT + FSE_ML + lane * 8);
+                if (lane < 32) {
+                    *(u32x4*)(t + FSE_OF + lane * 8) = *(const u32x4*)(p.fse + (size_t)f1 * FSE_SLOT + FSE_OF + lane * 8);
+                }
+                else if (lane < 56) {
+                    const int part = (lane - 32) >> 3, i = (lane - 32) & 7;
+                    const int32_t f = part == 0 ? f0 : (part == 1 ? f1 : f2);
+                    *(u32x4*)(t + FSE_CNT + 64 * part + i * 8) = *(const u32x4*)(p.fse + (size_t)f * FSE_SLOT + FSE_CNT + 64 * part + i * 8);
+                }
+            }
+            else {
+                const uint16_t* g = p.fse + (size_t)(blockIdx.x * SEQ_ITEMS_PER_WAVE + k) * FSE_SLOT;
+                for (int32_t i = lane * 8; i < FSE_SLOT; i += 64 * 8) {
+                    *(u32x4*)(tables + k * FSE_SLOT + i) = *(const u32x4*)(g + i);
+                }
             }
         }
     }
@@ -670,7 +806,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
     if (!live) {
         return;  // whole quads leave together
     }
-    const int32_t block = p.first + slot;
+    const int32_t block = slot_item<MB>(p, slot);
     const uint8_t* src = a.srcBase + a.srcOff[block];
     // per-lane role: FSE table, state mask, code table
     const uint16_t* tab = tables + q * FSE_SLOT + (r == 0 ? FSE_LL : (r == 1 ? FSE_ML : FSE_OF));
@@ -685,12 +821,13 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
     QuadBits b;
     bool bad = !b.init(src, d.seqStart, d.seqEnd);
     int32_t nDecoded = 0;
+    // the repeat-offset history (replicated in the quad); MB: "what it was before the block", entries 0 .. 2
+    int32_t p0 = MB ? sx2::REP_SENTINEL : 1, p1 = MB ? (sx2::REP_SENTINEL | (1 << 16)) : 4, p2 = MB ? (sx2::REP_SENTINEL | (2 << 16)) : 8;
     if (!bad) {
         // initial states in stream order LL, OF, ML (:378-386)
         const int32_t initOff = r == 0 ? 0 : (r == 1 ? d.log[0] + d.log[1] : d.log[0]);
         int32_t state = (int32_t)peek_bits(b.consumed + initOff, b.bits, myLog) & stateMask;
         b.consumed += d.log[0] + d.log[1] + d.log[2];
-        int32_t p0 = 1, p1 = 4, p2 = 8;
         int32_t sequenceCount = d.nbSeq;
         // ZstdFrameDecompressor.java:388-486.  The body is straight-line (selects, no early exits): an irregular
         // stream sets `bad` and keeps decoding harmless garbage (every index is masked) until the count runs out.
@@ -728,7 +865,8 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
             const int32_t literalsLength = quad_bcast<0>(value), matchLength = quad_bcast<1>(value);
             const int32_t raw = quad_bcast<2>(value) + ((cOF <= 1 && cLL == 0) ? 1 : 0);
             const bool rep = cOF <= 1;
-            int32_t temp = raw == 3 ? p0 - 1 : (raw == 1 ? p1 : p2);
+            // (a sentinel's low bits count the "- 1" steps: at most one per sequence, fewer than 2^16)
+            int32_t temp = raw == 3 ? ((MB && p0 >= sx2::REP_SENTINEL) ? p0 + 1 : p0 - 1) : (raw == 1 ? p1 : p2);
             temp = temp == 0 ? 1 : temp;
             const bool shift2 = rep ? (raw != 0 && raw != 1) : true;   // p2 = p1
             const bool shift1 = rep ? raw != 0 : true;                 // p1 = p0, p0 = new
@@ -736,7 +874,9 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
             p2 = shift2 ? p1 : p2;
             p1 = shift1 ? p0 : p1;
             p0 = shift1 ? offset : p0;
-            bad |= offset <= 0 || offset > (1 << 24);  // cannot be a valid back-reference of a single <= 128 KiB block; keeps the record fields in range
+            // an offset beyond 2^24 cannot be a valid back-reference (the window is at most 2^23); keeps the record fields in range and
+            // the sentinels apart from real offsets
+            bad |= offset <= 0 || (offset > (1 << 24) && !(MB && rep && offset >= sx2::REP_SENTINEL));
             // records are staged in LDS and leave in 256-byte bursts
             if (r == 3 && !over) {
                 stage[nDecoded & (SEQ_STAGE - 1)] = (uint64_t)(uint32_t)literalsLength | ((uint64_t)(uint32_t)matchLength << 18) | ((uint64_t)(uint32_t)(offset & 0xFFFFFFF) << 36);
@@ -763,10 +903,15 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
     }
     if (r == 0) {
         if (bad) {
-            to_fallback(p, slot, 3);
+            slot_to_fallback<MB>(p, slot, 3);
         }
         else {
             p.desc[slot].nDecoded = nDecoded;
+            if (MB) {
+                p.mb[slot].repOut[0] = p0;
+                p.mb[slot].repOut[1] = p1;
+                p.mb[slot].repOut[2] = p2;
+            }
         }
     }
 }
@@ -978,6 +1123,409 @@ __global__ __launch_bounds__(64) void zstd_pipe_checksum_kernel(BatchArgs a, zp:
     }
 }
 
+// ================================================================================================================================
+// Multi-block frames (what ZstdOutputStream.java:154-221 writes -- one frame, a block per 128 KiB, the window, the
+// repeat-offset history and the entropy tables carried from block to block -- and what ZstdFrameCompressor / libzstd write for inputs
+// beyond one block).  K1 lists the items whose first block is not a frame's only compressed block; then
+//
+//   count    a lane per listed item     walks the frame's block headers: one frame that fills the item exactly, block sizes in range
+//   scan     one wavefront              gives every item a range of "virtual" block indices; the host reads the totals (the one
+//                                       synchronisation of the decode call) and runs the blocks through the stages in PASSES of
+//                                       passBlocks virtual blocks (an item belongs to the pass its first block falls into)
+//   fill     a lane per item            walks again: a slot per block with its place, kind and LINKS -- the slot whose Huffman table
+//                                       treeless literals reuse, the slots whose FSE tables repeat mode reuses
+//   parse    a wavefront per block      K1's block part (parse_block); raw blocks become a literal run, RLE blocks one record
+//   K2, K3   16 blocks per wavefront    as above, on block slots, tables fetched through the links; K3 cannot know the repeat-offset
+//                                       history at a block's start and leaves sentinels (achip_seqexec2.h REP_SENTINEL)
+//   execute  a wavefront per item       the blocks in order through exec_records, ONE LDS window and one output position for the frame
+//                                       (matches reach into earlier blocks), the repeat-offset history resolved from block to block
+//   checksum a quad per item            XXH64 of the frame's output
+//
+// Anything irregular in any block sends the ITEM to the fallback list (the one-kernel decoder reports the Java-exact status).
+// ================================================================================================================================
+namespace zp {
+
+struct MbWalk {
+    int32_t n;            // blocks
+    int32_t hasChecksum;
+    uint32_t checksum;
+    uint32_t litUnits;    // literal arena units / sequence records the blocks' headers announce (what parse_block and the RLE blocks will take)
+    uint32_t seqs;
+    bool ok;
+};
+
+// ZstdFrameDecompressor.java:150-214 for an item K1 has looked at (magic, frame header, window size are fine): the block headers up to
+// the last block, the checksum, nothing behind it.  FILL: blocks[0 .. n) receive their place, kind and links (slot numbers count from
+// firstSlot).  Lane-private.
+template <bool FILL>
+__device__ MbWalk mb_walk(const Ctx& c, MbBlock* blocks, int32_t firstSlot, int32_t itemSlot, int32_t maxBlocks)
+{
+    MbWalk w;
+    w.n = 0;
+    w.hasChecksum = 0;
+    w.checksum = 0;
+    w.litUnits = 0;
+    w.seqs = 0;
+    w.ok = false;
+    const int64_t inputLimit = c.inLen;
+    const int32_t fhd = (int32_t)rd_le(c, 4, 1);
+    const bool singleSegment = (fhd & 0x20) != 0;
+    const int32_t csDesc = fhd >> 6;
+    int64_t input = 4 + 1 + (singleSegment ? 0 : 1) + (csDesc == 0 ? (singleSegment ? 1 : 0) : (1 << csDesc));  // (no dictionary id: K1)
+    w.hasChecksum = (fhd & 4) != 0 ? 1 : 0;
+    int32_t lastHuf = -1, lastLL = -1, lastOF = -1, lastML = -1;
+    for (;;) {
+        if (input + 3 > inputLimit || w.n >= maxBlocks) {
+            return w;
+        }
+        const int32_t header = (int32_t)rd_le(c, (int32_t)input, 3);
+        input += 3;
+        const int32_t type = (header >> 1) & 3;
+        const int32_t size = (header >> 3) & 0x1FFFFF;
+        int64_t adv = size;
+        if (type == 1) {
+            adv = 1;
+            if (size > 0x40000) {
+                return w;  // (the record that stands for the block holds size - 1 in 18 bits)
+            }
+        }
+        else if (type == 2) {
+            if (size > MAX_BLOCK_SIZE || size < 3) {
+                return w;
+            }
+        }
+        else if (type == 3) {
+            return w;
+        }
+        if (input + adv > inputLimit) {
+            return w;
+        }
+        {
+            const int32_t slot = firstSlot + w.n;
+            MbBlock b;
+            b.itemSlot = itemSlot;
+            b.srcPos = (int32_t)input;
+            b.size = size;
+            b.kind = type;
+            b.hufSlot = -1;
+            b.fseSlot[0] = b.fseSlot[1] = b.fseSlot[2] = -1;
+            b.repOut[0] = sx2::REP_SENTINEL;
+            b.repOut[1] = sx2::REP_SENTINEL | (1 << 16);
+            b.repOut[2] = sx2::REP_SENTINEL | (2 << 16);
+            b.pad = 0;
+            if (type == 1) {
+                w.seqs += size > 0 ? 1 : 0;  // (the record that stands for the block)
+            }
+            if (type == 2) {
+                // the literals section's header gives its sizes (:708-858), behind it the sequences section's header gives the count and
+                // names the table modes (:328-349); the parse stage checks every field again
+                const int32_t bs = (int32_t)input, bl = (int32_t)input + size;
+                const int32_t b0 = (int32_t)rd_le(c, bs, 1);
+                const int32_t lbt = b0 & 3, sf = (b0 >> 2) & 3;
+                int32_t section, regenerated;
+                if (lbt < 2) {
+                    const int32_t hdr = sf == 1 ? 2 : (sf == 3 ? 3 : 1);
+                    regenerated = sf == 1 ? (int32_t)rd_le(c, bs, 2) >> 4 : (sf == 3 ? (int32_t)(rd_le(c, bs, 3) & 0xFFFFFF) >> 4 : b0 >> 3);
+                    section = hdr + (lbt == 0 ? regenerated : 1);
+                }
+                else {
+                    const int32_t hdr = sf < 2 ? 3 : (sf == 2 ? 4 : 5);
+                    const uint64_t h = rd_le(c, bs, 5);
+                    const int32_t csize = sf < 2 ? (int32_t)((h >> 14) & 0x3FF) : (sf == 2 ? (int32_t)((h >> 18) & 0x3FFF) : (int32_t)((h >> 22) & 0x3FFFF));
+                    regenerated = sf < 2 ? (int32_t)((h >> 4) & 0x3FF) : (sf == 2 ? (int32_t)((h >> 4) & 0x3FFF) : (int32_t)((h >> 4) & 0x3FFFF));
+                    section = hdr + csize;
+                    if (lbt == 2) {
+                        lastHuf = slot;
+                    }
+                    b.hufSlot = lastHuf;
+                }
+                if (lbt != 0 && regenerated <= MAX_BLOCK_SIZE) {
+                    w.litUnits += (uint32_t)(regenerated + 64 + 63) >> 6;  // (parse_block's request)
+                }
+                const int32_t seqPos = bs + section;
+                if (seqPos < bl) {
+                    const int32_t cnt = (int32_t)rd_le(c, seqPos, 1);
+                    const int32_t modesPos = seqPos + 1 + (cnt == 255 ? 2 : (cnt > 127 ? 1 : 0));
+                    if (cnt != 0 && modesPos < bl) {
+                        w.seqs += cnt == 255 ? (uint32_t)rd_le(c, seqPos + 1, 2) + 0x7F00u : (cnt > 127 ? (uint32_t)(((cnt - 128) << 8) + (int32_t)rd_le(c, seqPos + 1, 1)) : (uint32_t)cnt);
+                        const int32_t modes = (int32_t)rd_le(c, modesPos, 1);
+                        lastLL = ((modes >> 6) & 3) != 3 ? slot : lastLL;
+                        lastOF = ((modes >> 4) & 3) != 3 ? slot : lastOF;
+                        lastML = ((modes >> 2) & 3) != 3 ? slot : lastML;
+                        b.fseSlot[0] = lastLL;
+                        b.fseSlot[1] = lastOF;
+                        b.fseSlot[2] = lastML;
+                    }
+                }
+            }
+            if (FILL) {
+                blocks[w.n] = b;
+            }
+        }
+        w.n++;
+        input += adv;
+        if ((header & 1) != 0) {
+            break;
+        }
+    }
+    if (w.hasChecksum) {
+        if (input + 4 > inputLimit) {
+            return w;
+        }
+        w.checksum = (uint32_t)rd_le(c, (int32_t)input, 4);
+        input += 4;
+    }
+    w.ok = input == inputLimit;  // (anything behind the frame -- another frame, garbage -- is the one-kernel decoder's)
+    return w;
+}
+
+__device__ __forceinline__ Ctx mb_source(const BatchArgs& a, int32_t item, int lane)
+{
+    Ctx c;
+    c.in = a.srcBase + a.srcOff[item];
+    c.inLen = a.srcLen[item];
+    c.out = nullptr;
+    c.outCap = 0;
+    c.lit = nullptr;
+    c.R = nullptr;
+    c.lane = lane;
+    c.detail = 0;
+    c.errOff = 0;
+    return c;
+}
+
+__device__ __forceinline__ bool mb_in_pass(const Pipe& p, const MbItem& it, int32_t j) { return it.state == 1 && j >= p.itemFirst && j < p.itemEnd; }
+
+}  // namespace zp
+
+__global__ __launch_bounds__(64) void zstd_mb_count_kernel(BatchArgs a, zp::Pipe p)
+{
+    using namespace zp;
+    const int32_t j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= *p.mbCount) {
+        return;
+    }
+    const int32_t item = p.mbList[j];
+    const Ctx c = mb_source(a, item, threadIdx.x);
+    MbWalk w = mb_walk<false>(c, nullptr, 0, j, p.mbSlots);
+    w.ok = w.ok && w.litUnits <= p.mbLitCap && w.seqs <= p.mbSeqCap;  // (it must fit a pass of its own)
+    MbItem it;
+    it.item = item;
+    it.firstBlock = 0;
+    it.nBlocks = w.ok ? w.n : 0;
+    it.state = w.ok ? 1 : 0;
+    it.hasChecksum = w.hasChecksum;
+    it.checksum = w.checksum;
+    it.outSize = 0;
+    it.litUnits = w.ok ? w.litUnits : 0;
+    it.seqs = w.ok ? w.seqs : 0;
+    it.pad[0] = it.pad[1] = it.pad[2] = 0;
+    p.mbItem[j] = it;
+    if (!w.ok) {
+        atomicAdd(p.fallbackCount + 32 + 6, 1);
+        p.fallback[atomicAdd(p.fallbackCount, 1)] = item;
+    }
+}
+
+// one wavefront: exclusive scan of the items' block counts
+__global__ __launch_bounds__(64) void zstd_mb_scan_kernel(zp::Pipe p)
+{
+    using namespace zp;
+    const int lane = threadIdx.x;
+    const int32_t n = *p.mbCount;
+    int32_t base = 0;
+    for (int32_t j0 = 0; j0 < n; j0 += 64) {  // (uniform)
+        const int32_t j = j0 + lane;
+        const int32_t nb = j < n ? p.mbItem[j].nBlocks : 0;
+        const int32_t incl = sx::wave_scan_incl(nb, lane);
+        if (j < n) {
+            p.mbItem[j].firstBlock = base + incl - nb;
+        }
+        base += sx::wave_bcast(incl, 63);
+    }
+    if (lane == 0) {
+        p.mbCount[1] = base;
+    }
+}
+
+// no scratch for the multi-block stages (or less than the item needs): items [first, end) of the list go to the fallback list
+__global__ __launch_bounds__(64) void zstd_mb_release_kernel(zp::Pipe p, int32_t first, int32_t end)
+{
+    using namespace zp;
+    const int32_t j = first + blockIdx.x * 64 + threadIdx.x;
+    if (j < end && j < *p.mbCount) {
+        mb_to_fallback(p, j, 6);
+    }
+}
+
+__global__ __launch_bounds__(64) void zstd_mb_fill_kernel(BatchArgs a, zp::Pipe p)
+{
+    using namespace zp;
+    const int32_t j = p.itemFirst + blockIdx.x * 64 + threadIdx.x;
+    if (j >= p.itemEnd) {
+        return;
+    }
+    const MbItem it = p.mbItem[j];
+    if (!mb_in_pass(p, it, j)) {
+        return;
+    }
+    const Ctx c = mb_source(a, it.item, threadIdx.x);
+    const int32_t firstSlot = it.firstBlock - p.passFirst;
+    mb_walk<true>(c, p.mb + firstSlot, firstSlot, j, p.mbSlots);
+}
+
+// a wavefront per block slot: the block's Desc (tables to the slot's table space, arena ranges)
+__global__ __launch_bounds__(64) void zstd_mb_parse_kernel(BatchArgs a, zp::Pipe p, const zd::FseTable* __restrict__ dflt)
+{
+    using namespace zp;
+    __shared__ TableShared sh;
+    const int32_t slot = blockIdx.x;
+    const MbBlock b = p.mb[slot];
+    if (b.kind < 0) {
+        return;
+    }
+    const int lane = threadIdx.x;
+    const MbItem it = p.mbItem[b.itemSlot];
+    Ctx c = mb_source(a, it.item, lane);
+    Desc d;
+    d.state = 0;
+    d.litMode = 0;
+    d.litSize = 0;
+    d.litSrc = 0;
+    d.hufLog = 0;
+    d.nStreams = 0;
+    for (int i = 0; i < 4; i++) {
+        d.sStart[i] = 0;
+        d.sEnd[i] = 0;
+    }
+    d.nbSeq = 0;
+    d.seqStart = d.seqEnd = 0;
+    d.log[0] = d.log[1] = d.log[2] = 0;
+    d.seqBase = 0;
+    d.nDecoded = 0;
+    d.hasChecksum = 0;
+    d.checksum = 0;
+    d.outSize = 0;
+    d.litBase = 0;
+    for (int i = 0; i < 6; i++) {
+        d.pad[i] = 0;
+    }
+    bool ok = it.state == 1;
+    if (ok && b.kind == 0) {
+        // decodeRawBlock :211-217: the block is one run of literals that lie in the source
+        d.litSrc = b.srcPos;
+        d.litSize = b.size;
+    }
+    else if (ok && b.kind == 1) {
+        // decodeRleBlock :219-250: one literal (the byte, in the source) and a match of offset 1 over the rest
+        d.litSrc = b.srcPos;
+        d.litSize = b.size > 0 ? 1 : 0;
+        if (b.size > 0) {
+            uint32_t at = 0;
+            if (lane == 0) {
+                at = atomicAdd(p.seqCursor, 1u);
+            }
+            at = __shfl(at, 0);
+            ok = (uint64_t)at + 1 <= p.seqCap;
+            if (ok && lane == 0) {
+                p.seq[at] = 1ull | ((uint64_t)(uint32_t)(b.size - 1) << 18) | (1ull << 36);
+            }
+            d.seqBase = at;
+            d.nDecoded = ok ? 1 : 0;
+        }
+    }
+    else if (ok) {
+        const int32_t fseBefore = ((b.fseSlot[0] >= 0 && b.fseSlot[0] != slot) ? 1 : 0) | ((b.fseSlot[1] >= 0 && b.fseSlot[1] != slot) ? 2 : 0) | ((b.fseSlot[2] >= 0 && b.fseSlot[2] != slot) ? 4 : 0);
+        ok = parse_block(c, sh, p, slot, dflt, d, b.srcPos, b.size, b.hufSlot >= 0 && b.hufSlot != slot, fseBefore);
+    }
+    d.state = ok ? 1 : 0;
+    if (lane == 0) {
+        p.desc[slot] = d;
+        if (!ok) {
+            mb_to_fallback(p, b.itemSlot, 1);
+        }
+    }
+}
+
+// K4 for multi-block frames: a wavefront per item
+__global__ __launch_bounds__(64) void zstd_mb_execute_kernel(BatchArgs a, zp::Pipe p)
+{
+    using namespace zp;
+    __shared__ __attribute__((aligned(16))) uint8_t win[sx2::WIN_DEFAULT + 16];
+    const int32_t j = p.itemFirst + blockIdx.x;
+    const MbItem it = p.mbItem[j];
+    if (!mb_in_pass(p, it, j)) {
+        return;
+    }
+    const int lane = threadIdx.x;
+    const uint8_t* src = a.srcBase + a.srcOff[it.item];
+    uint8_t* out = a.dstBase + a.dstOff[it.item];
+    const int32_t outLimit = a.dstCap[it.item];
+    int32_t rep0 = 1, rep1 = 4, rep2 = 8;  // reset() :199-203
+    int32_t output = 0;
+    bool bad = false;
+    for (int32_t i = 0; i < it.nBlocks && !bad; i++) {  // (uniform)
+        const int32_t slot = it.firstBlock - p.passFirst + i;
+        const Desc d = p.desc[slot];
+        const MbBlock b = p.mb[slot];
+        if (d.state != 1) {
+            bad = true;
+            break;
+        }
+        const uint8_t* lit = d.litMode == 0 ? src + d.litSrc : p.lit + (size_t)d.litBase * 64;
+        sx2::RecordSource S{p.seq + d.seqBase, d.nDecoded, rep0, rep1, rep2};
+        output = sx2::exec_records<0>(win, S, lit, d.litSize, out, outLimit, lane, bad, output);
+        const int32_t n0 = sx2::rep_resolve(b.repOut[0], rep0, rep1, rep2), n1 = sx2::rep_resolve(b.repOut[1], rep0, rep1, rep2), n2 = sx2::rep_resolve(b.repOut[2], rep0, rep1, rep2);
+        rep0 = n0;
+        rep1 = n1;
+        rep2 = n2;
+        wave_sync();  // (the block's last bytes have left the window before the next block writes it)
+    }
+    if (lane == 0) {
+        if (bad) {
+            mb_to_fallback(p, j, 4);
+        }
+        else if (it.hasChecksum) {
+            p.mbItem[j].outSize = output;
+        }
+        else {
+            a.outLen[it.item] = output;
+            a.status[it.item] = 0;
+            a.errOffset[it.item] = 0;
+            atomicAdd(p.mbCount + 2, 1);
+        }
+    }
+}
+
+// K5 for multi-block frames: a quad per item
+__global__ __launch_bounds__(64) void zstd_mb_checksum_kernel(BatchArgs a, zp::Pipe p)
+{
+    using namespace zp;
+    const int lane = threadIdx.x;
+    const int q = lane >> 2;
+    const int s = lane & 3;
+    const int32_t j = p.itemFirst + blockIdx.x * ITEMS_PER_WAVE + q;
+    if (j >= p.itemEnd) {
+        return;
+    }
+    const MbItem it = p.mbItem[j];
+    if (!mb_in_pass(p, it, j) || !it.hasChecksum) {
+        return;
+    }
+    const uint64_t hash = quad_xxh64(a.dstBase + a.dstOff[it.item], it.outSize, 0, s, lane - s);  // :192-204
+    if (s == 0) {
+        if ((uint32_t)hash == it.checksum) {
+            a.outLen[it.item] = it.outSize;
+            a.status[it.item] = 0;
+            a.errOffset[it.item] = 0;
+            atomicAdd(p.mbCount + 2, 1);
+        }
+        else {
+            mb_to_fallback(p, j, 5);
+        }
+    }
+}
+
 // the one-kernel decoder, run over a list of items (zstd_decompress.hip)
 hipError_t launch_zstd_decompress_prepare(hipStream_t stream, void* generalScratch, const zd::FseTable** dflt);
 hipError_t launch_zstd_decompress_list(const BatchArgs& a, hipStream_t stream, void* generalScratch, const int32_t* list, const int32_t* listCount);
@@ -990,7 +1538,7 @@ constexpr uint32_t PIPE_LIT_FLOOR = 16 * (zp::LIT_STRIDE / 64 + 1);  // ... plus
 constexpr uint32_t PIPE_SEQ_PER_ITEM = 20480;     // sequence arena: average records per item (text: 10-16 K per 128 KiB block) ...
 constexpr uint32_t PIPE_SEQ_FLOOR = 16 * 43691;   // ... plus room for 16 blocks of the maximum count (128 KiB / 3), so small batches always fit
 struct PipeLayout {
-    int64_t counters, fallback, desc, huf, fse, lit, seq, general, total;
+    int64_t counters, fallback, mbList, mbItem, desc, huf, fse, lit, seq, general, total;
     int32_t tile;
 };
 PipeLayout pipe_layout(int32_t nBlocks, int32_t tileMax)
@@ -1004,6 +1552,10 @@ PipeLayout pipe_layout(int32_t nBlocks, int32_t tileMax)
     o = up(o + 256);
     L.fallback = o;
     o = up(o + (int64_t)nBlocks * 4);
+    L.mbList = o;
+    o = up(o + (int64_t)nBlocks * 4);
+    L.mbItem = o;
+    o = up(o + (int64_t)nBlocks * sizeof(zp::MbItem));
     L.desc = o;
     o = up(o + (int64_t)L.tile * sizeof(zp::Desc));
     L.huf = o;
@@ -1019,12 +1571,143 @@ PipeLayout pipe_layout(int32_t nBlocks, int32_t tileMax)
     L.total = o;
     return L;
 }
+
+// scratch of the multi-block stages for passes "of passBlocks blocks of 128 KiB": the arenas are sized as the single-block pipeline sizes
+// them for a tile of that many items, the block slots (7 KiB of table space each) for blocks an eighth of that size -- encoders cut
+// blocks short where the statistics change (libzstd on mixed data: ~9 KiB blocks).  The host cuts the list of items into passes whose
+// slots, literals and sequences fit (launch_zstd_mb_stages).  The execute stage is one wavefront per FRAME, whatever the frame's size
+// (its blocks depend on each other through the window), so what a pass takes is about what its longest frame takes: the default
+// (65 536: ~20 GB, asked for when a batch first holds such frames) is meant to hold a batch of some 8 GiB in one pass.
+constexpr uint32_t MB_LIT_FLOOR = 3 * PIPE_LIT_FLOOR, MB_SEQ_FLOOR = 3 * PIPE_SEQ_FLOOR;  // room for 48 blocks of the maximum size / count
+struct MbLayout {
+    int64_t counters, mb, desc, huf, fse, lit, seq, total;
+    int32_t slots;
+};
+MbLayout mb_layout(int32_t passBlocks)
+{
+    MbLayout L;
+    L.slots = 8 * passBlocks;
+    auto up = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
+    int64_t o = 0;
+    L.counters = o;
+    o = up(o + 256);
+    L.mb = o;
+    o = up(o + (int64_t)L.slots * sizeof(zp::MbBlock));
+    L.desc = o;
+    o = up(o + (int64_t)L.slots * sizeof(zp::Desc));
+    L.huf = o;
+    o = up(o + (int64_t)L.slots * zp::HUF_SLOT * 2);
+    L.fse = o;
+    o = up(o + (int64_t)L.slots * zp::FSE_SLOT * 2);
+    L.lit = o;
+    o = up(o + ((int64_t)passBlocks * PIPE_LIT_PER_ITEM + MB_LIT_FLOOR) * 64);
+    L.seq = o;
+    o = up(o + ((int64_t)passBlocks * PIPE_SEQ_PER_ITEM + MB_SEQ_FLOOR) * 8);
+    L.total = o;
+    return L;
+}
 }  // namespace
 
+int64_t zstd_decompress_mb_scratch_bytes(int32_t passBlocks) { return mb_layout(passBlocks < 16 ? 16 : passBlocks).total; }
+
 int64_t zstd_decompress_pipe_scratch_bytes(int32_t nBlocks, int32_t tileMax) { return pipe_layout(nBlocks, tileMax).total; }
+
+namespace {
+// The multi-block stages over the items K1 listed (p: the pipeline's Pipe after its tiles).  The one host synchronisation of a decode
+// call is here: the number of listed items and of their blocks decides whether there is anything to do, how much scratch to ask the
+// caller for, and how many passes to run.
+hipError_t launch_zstd_mb_stages(const BatchArgs& a, hipStream_t stream, zp::Pipe p, const zd::FseTable* dflt, const ZstdMbProvider* mbp)
+{
+    MbLayout M = mb_layout(mbp->passBlocks);
+    uint32_t litCap = (uint32_t)mbp->passBlocks * PIPE_LIT_PER_ITEM + MB_LIT_FLOOR, seqCap = (uint32_t)mbp->passBlocks * PIPE_SEQ_PER_ITEM + MB_SEQ_FLOOR;
+    p.mbSlots = M.slots;
+    p.mbLitCap = litCap;
+    p.mbSeqCap = seqCap;
+    const unsigned perLane = (unsigned)((a.nBlocks + 63) / 64);
+    hipLaunchKernelGGL(zstd_mb_count_kernel, dim3(perLane), dim3(64), 0, stream, a, p);
+    hipLaunchKernelGGL(zstd_mb_scan_kernel, dim3(1), dim3(64), 0, stream, p);
+    int32_t totals[2] = {0, 0};  // listed items, their blocks
+    hipError_t e = hipMemcpyAsync(totals, p.mbCount, sizeof(totals), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    if (totals[0] <= 0) {
+        return hipSuccess;
+    }
+    const unsigned items64 = (unsigned)((totals[0] + 63) / 64);
+    // the scratch: what the option asks for, or -- when the device cannot give that -- half of it, a quarter ... (more passes)
+    uint8_t* mbase = nullptr;
+    for (int32_t pb = mbp->passBlocks; totals[1] > 0 && mbase == nullptr && pb >= 16; pb = pb > 1024 ? pb / 2 : 0) {
+        M = mb_layout(pb);
+        litCap = (uint32_t)pb * PIPE_LIT_PER_ITEM + MB_LIT_FLOOR;
+        seqCap = (uint32_t)pb * PIPE_SEQ_PER_ITEM + MB_SEQ_FLOOR;
+        mbase = (uint8_t*)mbp->get(mbp->user, M.total);
+    }
+    if (mbase == nullptr) {
+        hipLaunchKernelGGL(zstd_mb_release_kernel, dim3(items64), dim3(64), 0, stream, p, 0, totals[0]);  // (no blocks: every listed item failed its walk already)
+        return hipGetLastError();
+    }
+    p.mbSlots = M.slots;
+    // what the items need, for the cut into passes
+    std::vector<zp::MbItem> items((size_t)totals[0]);
+    e = hipMemcpyAsync(items.data(), p.mbItem, items.size() * sizeof(zp::MbItem), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    p.mb = (zp::MbBlock*)(mbase + M.mb);
+    p.desc = (zp::Desc*)(mbase + M.desc);
+    p.huf = (uint16_t*)(mbase + M.huf);
+    p.fse = (uint16_t*)(mbase + M.fse);
+    p.lit = mbase + M.lit;
+    p.seq = (uint64_t*)(mbase + M.seq);
+    p.seqCap = seqCap;
+    p.litCap = litCap;
+    p.seqCursor = (uint32_t*)(mbase + M.counters);
+    p.litCursor = (uint32_t*)(mbase + M.counters + 4);
+    p.first = 0;
+    for (int32_t j0 = 0; j0 < totals[0];) {
+        // the longest run of items whose blocks, literals and sequences fit one pass (every item fits one alone: the count kernel saw to that)
+        int64_t blocks = 0, lit = 0, seq = 0;
+        int32_t j1 = j0;
+        while (j1 < totals[0] && blocks + items[j1].nBlocks <= M.slots && lit + items[j1].litUnits <= litCap && seq + items[j1].seqs <= seqCap) {
+            blocks += items[j1].nBlocks;
+            lit += items[j1].litUnits;
+            seq += items[j1].seqs;
+            j1++;
+        }
+        if (j1 == j0) {
+            // more than a pass holds (the scratch came out smaller than the count kernel assumed): the one-kernel decoder takes the item
+            hipLaunchKernelGGL(zstd_mb_release_kernel, dim3(1), dim3(64), 0, stream, p, j0, j0 + 1);
+            j0++;
+            continue;
+        }
+        p.itemFirst = j0;
+        p.itemEnd = j1;
+        p.passFirst = items[j0].firstBlock;
+        p.count = (int32_t)blocks;
+        j0 = j1;
+        if (blocks == 0) {
+            continue;  // (items that failed their walk)
+        }
+        e = hipMemsetAsync(mbase + M.counters, 0, 256, stream);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(p.mb, 0xFF, (size_t)p.count * sizeof(zp::MbBlock), stream);
+        if (e != hipSuccess) return e;
+        const unsigned nItems = (unsigned)(p.itemEnd - p.itemFirst);
+        const unsigned w16 = (unsigned)((p.count + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE);
+        hipLaunchKernelGGL(zstd_mb_fill_kernel, dim3((nItems + 63) / 64), dim3(64), 0, stream, a, p);
+        hipLaunchKernelGGL(zstd_mb_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
+        hipLaunchKernelGGL(zstd_pipe_literals_kernel<true>, dim3(w16), dim3(64), 0, stream, a, p);
+        hipLaunchKernelGGL(zstd_pipe_sequences_kernel<true>, dim3(w16), dim3(64), 0, stream, a, p);
+        hipLaunchKernelGGL(zstd_mb_execute_kernel, dim3(nItems), dim3(64), 0, stream, a, p);
+        hipLaunchKernelGGL(zstd_mb_checksum_kernel, dim3((nItems + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE), dim3(64), 0, stream, a, p);
+    }
+    return hipGetLastError();
+}
+}  // namespace
 void* zstd_decompress_pipe_general_scratch(void* scratch, int32_t nBlocks, int32_t tileMax) { return (uint8_t*)scratch + pipe_layout(nBlocks, tileMax).general; }
 
-hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, void* scratch, void* generalScratch, int32_t tileMax)
+hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, void* scratch, void* generalScratch, int32_t tileMax, const ZstdMbProvider* mbp)
 {
     const PipeLayout L = pipe_layout(a.nBlocks, tileMax);
     uint8_t* base = (uint8_t*)scratch;
@@ -1045,6 +1728,15 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
     p.litCursor = (uint32_t*)(base + L.counters + 68);
     p.litCap = (uint32_t)L.tile * PIPE_LIT_PER_ITEM + PIPE_LIT_FLOOR;
     p.fallback = (int32_t*)(base + L.fallback);
+    const bool mbOn = mbp != nullptr && mbp->get != nullptr && mbp->passBlocks >= 16;
+    p.mbList = mbOn ? (int32_t*)(base + L.mbList) : nullptr;
+    p.mbCount = (int32_t*)(base + L.counters) + 40;
+    p.mbItem = (zp::MbItem*)(base + L.mbItem);
+    p.mb = nullptr;
+    p.passFirst = 0;
+    p.itemFirst = p.itemEnd = 0;
+    p.mbSlots = 0;
+    p.mbLitCap = p.mbSeqCap = 0;
     hipError_t e = hipMemsetAsync(base + L.counters, 0, 256, stream);
     if (e != hipSuccess) return e;
     for (int32_t first = 0; first < a.nBlocks; first += L.tile) {
@@ -1056,8 +1748,8 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
         }
         const unsigned w16 = (unsigned)((p.count + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE);
         hipLaunchKernelGGL(zstd_pipe_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
-        hipLaunchKernelGGL(zstd_pipe_literals_kernel, dim3(w16), dim3(64), 0, stream, a, p);
-        hipLaunchKernelGGL(zstd_pipe_sequences_kernel, dim3((unsigned)((p.count + zp::SEQ_ITEMS_PER_WAVE - 1) / zp::SEQ_ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
+        hipLaunchKernelGGL(zstd_pipe_literals_kernel<false>, dim3(w16), dim3(64), 0, stream, a, p);
+        hipLaunchKernelGGL(zstd_pipe_sequences_kernel<false>, dim3((unsigned)((p.count + zp::SEQ_ITEMS_PER_WAVE - 1) / zp::SEQ_ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
         constexpr int GS = 4, IN_RING = 128, OUT_RING = 256;
         if (g_zstd_pipe_exec != 0) {
             hipLaunchKernelGGL(zstd_pipe_execute2_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, (int32_t)g_zstd_pipe_exec);
@@ -1069,6 +1761,10 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (mbOn) {
+        e = launch_zstd_mb_stages(a, stream, p, dflt, mbp);
+        if (e != hipSuccess) return e;
+    }
     return launch_zstd_decompress_list(a, stream, generalScratch, p.fallback, p.fallbackCount);
 }
 

@@ -55,7 +55,7 @@ def parse_args():
     p.add_argument("--cpu-leg-seconds", type=float, default=0.6, help="CPU time of each extra entry's CPU leg (per direction)")
     p.add_argument("--no-sweep", action="store_true")
     p.add_argument("--exec-variant", type=int, default=-1, help="DEBUG: decompress.exec_variant (two-pass decoders)")
-    p.add_argument("--section", default="all", choices=["all", "zstd", "xxhash", "lz4frame"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
+    p.add_argument("--section", default="all", choices=["all", "zstd", "zstdstream", "xxhash", "lz4frame"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-exec", type=int, default=-1, help="zstd pipeline execute stage: 2 = chosen per item (default), 1 = wavefront per item through the record executor, 0 = LDS rings")
     p.add_argument("--zstd-variant", type=int, default=-1, help="zstd decoder: 1 = five-stage pipeline (default), 0 = one-kernel decoder")
     return p.parse_args()
@@ -212,6 +212,9 @@ def main():
         return
     if args.section == "zstd":
         print(json.dumps(zstd_extra(torch, A, codec, torch.device("cuda", local_rank), args)), flush=True)
+        return
+    if args.section == "zstdstream":
+        print(json.dumps(zstd_stream_extra(torch, A, codec, torch.device("cuda", local_rank), args)), flush=True)
         return
 
     wl = args.workload
@@ -372,6 +375,10 @@ def main():
         ex.update(lz4frame_extra(torch, A, codec, dev, args))
         try:
             ex.update(zstd_extra(torch, A, codec, dev, args))
+            try:
+                ex.update(zstd_stream_extra(torch, A, codec, dev, args))
+            except Exception as e:  # (a secondary entry must not take the run's line with it; the parity tests are the check)
+                ex["zstdstream_error"] = repr(e)
         except ImportError:
             pass
         result["extra"] = ex
@@ -680,6 +687,73 @@ def zstd_extra(torch, A, codec, dev, args):
             entry.update({"cpu_decompress_GiBps": round(d, 2), "cpu_compress_GiBps": round(c, 2), "cpu_threads": T, "cpu_sample_blocks": pool_n * 8})
         out["zstd_%s" % data_kind] = entry
         del z_dst, back, zplain
+    return out
+
+
+def zstd_stream_extra(torch, A, codec, dev, args):
+    """Zstd frames of SEVERAL blocks (what ZstdOutputStream / ZstdFrameCompressor / libzstd write beyond 128 KiB):
+    1024 frames of 4 MiB (32 blocks each, libzstd level 3 on the host) decoded through the pipeline's multi-block stages, and -- one
+    launch -- through the one-kernel decoder that took such frames before (zstd.decompress.stream_blocks = 0)."""
+    import pyarrow as pa
+    out = {}
+    fs, pool_n, reps = 4 << 20, 16, 64
+    zc = pa.Codec("zstd", compression_level=3)
+    i64 = dict(dtype=torch.int64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    for data_kind in ("fragments", "corpus"):
+        plain = gen_data(torch, dev, data_kind, pool_n * (fs // args.block_size), args.block_size, args.ratio, 515)
+        host = plain.cpu().numpy()
+        frames = [zc.compress(host[i * fs:(i + 1) * fs].tobytes(), asbytes=True) for i in range(pool_n)]
+        lens = np.array([len(f) for f in frames], dtype=np.int64)
+        pad = (lens + 15) // 16 * 16
+        offs = np.cumsum(pad) - pad
+        pack = np.zeros(int(pad.sum()), dtype=np.uint8)
+        for f, o in zip(frames, offs):
+            pack[o:o + len(f)] = np.frombuffer(f, dtype=np.uint8)
+        n = pool_n * reps
+        d_pack = torch.from_numpy(pack).to(dev).repeat(reps)
+        rep_idx = torch.arange(reps, **i64).repeat_interleave(pool_n)
+        src_off = torch.from_numpy(offs).to(dev).repeat(reps) + rep_idx * int(pad.sum())
+        src_len = torch.from_numpy(lens.astype(np.int32)).to(dev).repeat(reps)
+        dst = torch.empty(n * fs + 64, dtype=torch.uint8, device=dev)
+        dst_off = torch.arange(n, **i64) * fs
+        dst_cap = torch.full((n,), fs, **i32)
+        olen = torch.zeros(n, **i32)
+        st = torch.zeros(n, **i32)
+        eo = torch.zeros(n, **i64)
+        torch.cuda.synchronize()
+        launch = lambda: codec.launch(A.OP_ZSTD_DECOMPRESS, d_pack, src_off, src_len, dst, dst_off, dst_cap, olen, st, eo, n)  # noqa: E731
+
+        def check():
+            codec.synchronize()
+            assert int((st != 0).sum()) == 0, "zstd multi-block decode failed"
+            assert bool((dst[:n * fs].view(reps, pool_n * fs) == plain.unsqueeze(0)).all()), "zstd multi-block plaintext mismatch"
+
+        def timed(iters):
+            e0, e1 = codec.event(), codec.event()
+            codec.record(e0)
+            for _ in range(iters):
+                launch()
+            codec.record(e1)
+            return codec.elapsed_ms(e0, e1) / iters * 1e-3
+
+        launch()
+        check()
+        fast = codec.native.get_stat("zstd.decompress.multiblock_fast_items")
+        blocks = codec.native.get_stat("zstd.decompress.multiblock_blocks")
+        t = timed(3)
+        dst.zero_()
+        codec.native.set_option("zstd.decompress.stream_blocks", 0)
+        t1 = timed(1)
+        check()
+        codec.native.set_option("zstd.decompress.stream_blocks", 65536)
+        cbytes = int(lens.sum()) * reps
+        out["zstdstream_%s" % data_kind] = {
+            "ratio": round(n * fs / cbytes, 3), "decompress_GiBps": round(n * fs / t / 2**30, 2), "decompress_hbm_frac": round((n * fs + cbytes) / t / 1e9 / HBM_PEAK_GBS, 4),
+            "one_kernel_decoder_GiBps": round(n * fs / t1 / 2**30, 2), "frames": n, "frame_bytes": fs, "blocks": blocks, "multiblock_fast_items": fast,
+            "encoder": "libzstd level 3 via pyarrow %s" % pa.__version__,
+        }
+        del d_pack, dst, plain
     return out
 
 

@@ -140,6 +140,101 @@ def test_multi_block_frames_and_concatenated_frames(gbd, o):
     assert o.decompress("zstd", cat, len(plain_cat)) == plain_cat
 
 
+def frame_blocks(f):
+    """number of blocks of the (single) frame f"""
+    fhd = f[4]
+    pos = 5 + (0 if fhd & 0x20 else 1) + ((1 if fhd & 0x20 else 0) if fhd >> 6 == 0 else 1 << (fhd >> 6))
+    n = 0
+    while True:
+        h = int.from_bytes(f[pos:pos + 3], "little")
+        pos += 3 + (1 if (h >> 1) & 3 == 1 else h >> 3)
+        n += 1
+        if h & 1:
+            return n
+
+
+def multi_block_plains():
+    """inputs beyond one block: corpus text with cross-block history, noise (raw blocks), long runs (RLE blocks), and data whose blocks look
+    alike, so that the encoders reuse the previous block's Huffman table (treeless literals) and FSE tables (repeat mode)"""
+    whole = b"".join(d for _, d, _ in common.corpus_sample())
+    rng = np.random.default_rng(11)
+    noise = rng.integers(0, 256, 200000, dtype=np.uint8).tobytes()
+    logs = "".join("2026-09-%02d %02d:%02d:%02d host%d GET /api/v1/items/%d?user=%d status=%d bytes=%d\n" % (
+        rng.integers(1, 29), rng.integers(0, 24), rng.integers(0, 60), rng.integers(0, 60), rng.integers(0, 9), rng.integers(0, 100000), rng.integers(0, 5000),
+        [200, 200, 200, 404, 500][rng.integers(0, 5)], rng.integers(100, 99999)) for _ in range(9000)).encode()
+    # (libzstd level 3 cuts this into ~10 KiB blocks, raw ones among them: a frame of ~260 blocks)
+    pool = [rng.integers(0, 256, int(rng.integers(20, 200)), dtype=np.uint8).tobytes() for _ in range(3000)]
+    mixed = bytearray()
+    while len(mixed) < (3 << 20):
+        mixed += pool[int(rng.integers(0, len(pool)))] if rng.random() < 0.5 else rng.integers(0, 256, int(rng.integers(20, 200)), dtype=np.uint8).tobytes()
+    return [whole, whole[:300000], whole[100000:100000 + 131073], whole[:131072] + noise[:140000] + whole[:70000], b"\0" * 400000, b"abc" * 100000 + whole[50000:250000],
+            noise[:5], noise, whole[400000:1000000], b"q" * 131072 + b"r" * 131072 + whole[:10], whole[:262144], logs,
+            (" ".join(str(x) for x in rng.integers(0, 1000, 200000))).encode(), bytes(rng.choice(list(b"ACGT"), 700000).tolist()), bytes(mixed[:3 << 20])]
+
+
+@pytest.mark.parametrize("stream_blocks", [65536, 16])
+def test_multi_block_frames_take_the_multi_block_stages(o, stream_blocks):
+    """frames of several blocks (ZstdOutputStream / ZstdFrameCompressor / libzstd beyond 128 KiB) go through the
+    pipeline's multi-block stages -- window, repeat offsets, Huffman and FSE tables carried from block to block -- and not to the
+    one-kernel decoder; with the smallest passes (room for 16 blocks of 128 KiB, 128 block slots) the batch takes several passes and a
+    frame of more blocks than a pass has slots falls back."""
+    from tests.gpu_harness import GpuBatch
+    g = GpuBatch(0, options={"zstd.decompress.stream_blocks": stream_blocks})
+    plains = multi_block_plains()
+    encoders = [("oracle", lambda b: o.compress("zstd", b))] + [("libzstd-%d" % l, (lambda l: lambda b: zstd_frames([b], l)[0])(l)) for l in (1, 3, 9, 19)]
+    unfit = 0
+    for name, enc in encoders:
+        frames = [enc(b) for b in plains]
+        for pad in (0, 41):
+            outs, status, err = g.run(OP_ZSTD_DECOMPRESS, frames, [len(b) + pad for b in plains], unaligned=(pad == 0))
+            assert all(s == 0 for s in status), (name, status, err)
+            for i, (b, got) in enumerate(zip(plains, outs)):
+                assert got == b, "%s frame %d (len %d)" % (name, i, len(b))
+        fits = sum(1 for f in frames if frame_blocks(f) <= 8 * stream_blocks)
+        assert g.codec.native.get_stat("zstd.decompress.multiblock_items") == len(frames), name
+        assert g.codec.native.get_stat("zstd.decompress.multiblock_fast_items") == fits, name
+        assert g.codec.native.get_stat("zstd.decompress.fallback_items") == len(frames) - fits, name
+        assert g.codec.native.get_stat("zstd.decompress.multiblock_blocks") == sum(frame_blocks(f) for f in frames if frame_blocks(f) <= 8 * stream_blocks), name
+        unfit += len(frames) - fits
+    assert (unfit > 0) == (stream_blocks == 16)  # (libzstd level 3 on the mixed data: ~260 blocks)
+
+
+def test_damaged_multi_block_frames_report_what_the_oracle_reports(gbd, o):
+    """whatever the multi-block stages make of a damaged frame -- decode it (the damage may be harmless, or only change bytes) or hand
+    it to the one-kernel decoder -- the caller sees the oracle's output, status and offset"""
+    rng = np.random.default_rng(23)
+    plains = multi_block_plains()[1:6]
+    cases = []
+    for name, enc in (("oracle", lambda b: o.compress("zstd", b)), ("libzstd-3", lambda b: zstd_frames([b], 3)[0])):
+        for b in plains:
+            f = enc(b)
+            for k in range(18):
+                m = bytearray(f)
+                kind = k % 6
+                if kind == 0:
+                    m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+                elif kind == 1:
+                    m[int(rng.integers(4, min(40, len(m))))] = int(rng.integers(0, 256))
+                elif kind == 2:
+                    m = m[:int(rng.integers(8, max(9, len(m))))]
+                elif kind == 3:
+                    m += bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8).tolist())
+                elif kind == 4:
+                    at = int(rng.integers(0, max(1, len(m) - 16)))
+                    m[at:at + 16] = bytes(min(16, len(m) - at))
+                else:
+                    m[len(m) - 1 - int(rng.integers(0, 6))] ^= 0x10
+                cases.append((bytes(m), len(b) if k % 3 else len(b) - int(rng.integers(1, 5000))))
+    outs, status, err = gbd.run(OP_ZSTD_DECOMPRESS, [c for c, _ in cases], [cap for _, cap in cases])
+    for i, (c, cap) in enumerate(cases):
+        est, eoff, eout = _expect(o, c, cap)
+        assert status[i] == est, "case %d: gpu status %d oracle %d (gpu offset %d, oracle %d)" % (i, status[i], est, err[i], eoff)
+        if est == 0:
+            assert outs[i] == eout, "case %d" % i
+        else:
+            assert err[i] == eoff, "case %d: gpu offset %d oracle %d" % (i, err[i], eoff)
+
+
 def test_pipeline_small_tiles(o):
     """a batch larger than the pipeline's tile goes through it in several passes (here: tiles of 64 items)"""
     from tests.gpu_harness import GpuBatch

@@ -66,6 +66,27 @@ def test_lane_private_decoder_kernels_on_the_cpu():
     assert out.strip().endswith(" 0 mismatches"), out
 
 
+def test_zstd_pipeline_kernels_on_the_cpu():
+    """The Zstd decode pipeline (parse / literals / sequences / execute / checksum and the multi-block stages: walk, per-block parse, tables
+    fetched through links, repeat-offset sentinels, one window per frame) under tools/hostemu with quad-level rendezvous: frames of the
+    oracle's encoder and of libzstd, single-block and multi-block, at two pass sizes, must decode to the plaintext on the fast path; damaged
+    multi-block frames must either leave the fast path or decode to exactly what the oracle's decoder returns."""
+    import shutil
+    import sys
+    import pytest
+    clang = shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("no clang++ for the host build of the kernel source")
+    emu_dir = os.path.join(ROOT, "tools", "hostemu")
+    subprocess.run([clang, "-O1", "-std=c++17", "-fPIC", "-shared", "-I", emu_dir, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "aircompressor_amd", "csrc"),
+                    "-o", os.path.join(emu_dir, "libemu_zstd.so"), os.path.join(emu_dir, "emu_zstd.cpp")], check=True)
+    r = subprocess.run([sys.executable, os.path.join(emu_dir, "check_zstd.py"), "--quick"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if "mismatches" in l]
+    assert len(lines) == 3 and all(" 0 mismatches" in l for l in lines), r.stdout
+    assert "fast 14, fallback list []" in r.stdout and "fast 13, fallback list [13]" in r.stdout, r.stdout  # (the smallest passes: the frame of ~260 short blocks has no room)
+
+
 def test_bench_java_random_generator_equals_the_oracles(oracle):
     """bench.py restates java.util.Random(301) + RandomGenerator in numpy (jump-ahead LCG) for its ratio sweep; the oracle's generator
     (oracle/misc.c, following T/snappy/RandomGenerator.java:25-74) is the checker."""

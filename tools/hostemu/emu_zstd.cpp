@@ -58,9 +58,25 @@ int64_t zstd_decompress_general_scratch_bytes() { return 4096 + (int64_t)sizeof(
 }  // namespace achip
 
 // runs the pipeline over the batch; items it handed to the fallback list get status -1000 and are listed in fallback[0 .. return value)
-extern "C" int emu_zstd_pipe(const uint8_t* srcBase, const int64_t* srcOff, const int32_t* srcLen, uint8_t* dstBase, const int64_t* dstOff, const int32_t* dstCap,
-                             int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n, int32_t tile, int32_t execMode, int32_t* fallback)
+namespace {
+std::vector<uint8_t> g_mbScratch;
+int64_t g_mbMaxBytes = 0;  // > 0: larger requests are refused (the stages then ask for less)
+void* emu_mb_get(void*, int64_t bytes)
 {
+    if (g_mbMaxBytes > 0 && bytes > g_mbMaxBytes) {
+        return nullptr;
+    }
+    g_mbScratch.assign((size_t)bytes, 0xCD);
+    return g_mbScratch.data();
+}
+}  // namespace
+
+// passBlocks: blocks per pass of the multi-block stages (0: multi-block frames go to the fallback list); counters: the pipeline's 64 counter words
+extern "C" int emu_zstd_pipe(const uint8_t* srcBase, const int64_t* srcOff, const int32_t* srcLen, uint8_t* dstBase, const int64_t* dstOff, const int32_t* dstCap,
+                             int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n, int32_t tile, int32_t execMode, int32_t* fallback, int32_t passBlocks,
+                             int32_t* counters, int64_t mbMaxBytes)
+{
+    g_mbMaxBytes = mbMaxBytes;
     achip::BatchArgs a{srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, n, 16};
     static std::vector<uint8_t> scratch;
     const int64_t bytes = achip::zstd_decompress_pipe_scratch_bytes(n, tile);
@@ -70,7 +86,9 @@ extern "C" int emu_zstd_pipe(const uint8_t* srcBase, const int64_t* srcOff, cons
     for (int32_t i = 0; i < n; i++) {
         status[i] = -999;  // "not written"
     }
-    achip::launch_zstd_decompress_pipe(a, nullptr, scratch.data(), achip::zstd_decompress_pipe_general_scratch(scratch.data(), n, tile), tile);
+    achip::ZstdMbProvider mbp{emu_mb_get, nullptr, passBlocks};
+    achip::launch_zstd_decompress_pipe(a, nullptr, scratch.data(), achip::zstd_decompress_pipe_general_scratch(scratch.data(), n, tile), tile, passBlocks > 0 ? &mbp : nullptr);
+    memcpy(counters, scratch.data(), 256);
     for (size_t k = 0; k < achip::g_fallback.size(); k++) {
         fallback[k] = achip::g_fallback[k];
         status[achip::g_fallback[k]] = -1000;

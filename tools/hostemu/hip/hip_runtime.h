@@ -28,6 +28,7 @@ extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 typedef int hipError_t;
 typedef void* hipStream_t;
 #define hipSuccess 0
+#define hipErrorUnknown 999
 inline hipError_t hipGetLastError() { return 0; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
@@ -321,6 +322,7 @@ inline int __ffsll(unsigned long long v) { return v == 0 ? 0 : __builtin_ctzll(v
 // cross-lane builtins that only NOT emulated kernels of a shared header use (they must compile, they never run here)
 inline int __builtin_amdgcn_update_dpp(int old, int src, int, int, int, bool) { (void)old; return src; }
 template <typename T> inline T atomicAdd(T* p, T v) { T old = *p; *p += v; return old; }
+template <typename T> inline T atomicExch(T* p, T v) { T old = *p; *p = v; return old; }
 template <typename T> inline T atomicMax(T* p, T v) { T old = *p; if (v > old) *p = v; return old; }
 
 // dynamic shared memory of the emulated launch: one arena, re-used by every "workgroup"
