@@ -183,7 +183,10 @@ int32_t achip_ctx_synchronize(achip_ctx* ctx);    /* hipStreamSynchronize */
 int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value);
 /* diagnostics of the LAST batched call on this context (synchronizes the stream); -1 = unknown name / nothing recorded.
  * "zstd.decompress.fallback_items": items the five-stage pipeline handed to the one-kernel decoder;
- * "zstd.decompress.fallback_stage1" .. "stage5": the same, by the stage that handed them over;
+ * "zstd.decompress.fallback_stage1" .. "stage6": the same, by the stage that handed them over (6: the multi-block stages' walk);
+ * "zstd.decompress.multiblock_items" / "_blocks" / "_fast_items": items of the last Zstd decode that hold one frame of several blocks
+ *   (ZstdOutputStream's output; ZstdFrameCompressor's and libzstd's beyond 128 KiB), their blocks, and how many of them the pipeline's
+ *   multi-block stages finished (the rest went to the one-kernel decoder); option "zstd.decompress.stream_blocks" sizes those stages;
  * "lz4.decompress.mixed_groups": auto mode's count of mixed 16-block groups of the last LZ4 / Snappy decode (-1: no probe ran);
  * "decompress.choice": the decoder auto mode ran (0 LDS rings, 1 a lane per block with copy steps, 2 a lane per block with an LDS
  *   output window; -1: no probe ran).  DESIGN.md 8b lists every option and statistic. */
@@ -231,7 +234,8 @@ int32_t achip_lz4_compress_batch(ACHIP_BATCH_ARGS);
 int32_t achip_snappy_decompress_batch(ACHIP_BATCH_ARGS);
 /* replaces SnappyRawCompressor.compress     M/snappy/SnappyRawCompressor.java:74-233   (a4) */
 int32_t achip_snappy_compress_batch(ACHIP_BATCH_ARGS);
-/* replaces ZstdFrameDecompressor.decompress M/zstd/ZstdFrameDecompressor.java:135-210  (a5-a10) */
+/* replaces ZstdFrameDecompressor.decompress M/zstd/ZstdFrameDecompressor.java:135-210  (a5-a10); frames of several blocks -- what
+ * ZstdOutputStream (M/zstd/ZstdOutputStream.java:154-221) writes -- take the same fast path (f3, decode half) */
 int32_t achip_zstd_decompress_batch(ACHIP_BATCH_ARGS);
 /* replaces ZstdFrameCompressor.compress(level 3) M/zstd/ZstdFrameCompressor.java:136-150 (a11-a14) */
 int32_t achip_zstd_compress_batch(ACHIP_BATCH_ARGS);
