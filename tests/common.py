@@ -94,3 +94,48 @@ def synthetic_blocks(seed, n_blocks, block_size=65536):
         if n <= block_size:
             out.append(out[len(out) % max(1, n_blocks)][:n] if n_blocks else b"")
     return out
+
+
+def multi_block_plains():
+    """inputs beyond one block: corpus text with cross-block history, noise (raw blocks), long runs (RLE blocks), and data whose blocks look
+    alike, so that the encoders reuse the previous block's Huffman table (treeless literals) and FSE tables (repeat mode)"""
+    whole = b"".join(d for _, d, _ in corpus_sample())
+    rng = np.random.default_rng(11)
+    noise = rng.integers(0, 256, 200000, dtype=np.uint8).tobytes()
+    logs = "".join("2026-09-%02d %02d:%02d:%02d host%d GET /api/v1/items/%d?user=%d status=%d bytes=%d\n" % (
+        rng.integers(1, 29), rng.integers(0, 24), rng.integers(0, 60), rng.integers(0, 60), rng.integers(0, 9), rng.integers(0, 100000), rng.integers(0, 5000),
+        [200, 200, 200, 404, 500][rng.integers(0, 5)], rng.integers(100, 99999)) for _ in range(9000)).encode()
+    # (libzstd level 3 cuts this into ~10 KiB blocks, raw ones among them: a frame of ~260 blocks)
+    pool = [rng.integers(0, 256, int(rng.integers(20, 200)), dtype=np.uint8).tobytes() for _ in range(3000)]
+    mixed = bytearray()
+    while len(mixed) < (3 << 20):
+        mixed += pool[int(rng.integers(0, len(pool)))] if rng.random() < 0.5 else rng.integers(0, 256, int(rng.integers(20, 200)), dtype=np.uint8).tobytes()
+    # sequences of one shape (literal length and match length always the same: libzstd level 19 describes such tables in RLE mode, and
+    # repeats them), and blocks whose literals are one byte value (RLE literals, treeless literals, a block without sequences)
+    prefix = rng.integers(0, 256, 65536, dtype=np.uint8)
+
+    def fixed(n, mlen, lit):
+        out = [prefix.tobytes()]
+        size = len(prefix)
+        while size < n:
+            r = int(rng.integers(0, len(prefix) - mlen))
+            out.append(prefix[r:r + mlen].tobytes())
+            out.append(rng.integers(0, 256, lit, dtype=np.uint8).tobytes())
+            size += mlen + lit
+        return b"".join(out)[:n]
+
+    def one_literal(n):
+        base = bytes(rng.integers(97, 123, 150000, dtype=np.uint8).tolist())
+        out = [base]
+        size = len(base)
+        while size < n:
+            r = int(rng.integers(0, len(base) - 40))
+            k = int(rng.integers(6, 30))
+            out.append(base[r:r + k])
+            out.append(b"z")
+            size += k + 1
+        return b"".join(out)[:n]
+    shaped = [fixed(700000, 8, 1), fixed(700000, 16, 2), one_literal(800000)]
+    return shaped + [whole, whole[:300000], whole[100000:100000 + 131073], whole[:131072] + noise[:140000] + whole[:70000], b"\0" * 400000, b"abc" * 100000 + whole[50000:250000],
+            noise[:5], noise, whole[400000:1000000], b"q" * 131072 + b"r" * 131072 + whole[:10], whole[:262144], logs,
+            (" ".join(str(x) for x in rng.integers(0, 1000, 200000))).encode(), bytes(rng.choice(list(b"ACGT"), 700000).tolist()), bytes(mixed[:3 << 20])]

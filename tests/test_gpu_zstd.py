@@ -153,25 +153,6 @@ def frame_blocks(f):
             return n
 
 
-def multi_block_plains():
-    """inputs beyond one block: corpus text with cross-block history, noise (raw blocks), long runs (RLE blocks), and data whose blocks look
-    alike, so that the encoders reuse the previous block's Huffman table (treeless literals) and FSE tables (repeat mode)"""
-    whole = b"".join(d for _, d, _ in common.corpus_sample())
-    rng = np.random.default_rng(11)
-    noise = rng.integers(0, 256, 200000, dtype=np.uint8).tobytes()
-    logs = "".join("2026-09-%02d %02d:%02d:%02d host%d GET /api/v1/items/%d?user=%d status=%d bytes=%d\n" % (
-        rng.integers(1, 29), rng.integers(0, 24), rng.integers(0, 60), rng.integers(0, 60), rng.integers(0, 9), rng.integers(0, 100000), rng.integers(0, 5000),
-        [200, 200, 200, 404, 500][rng.integers(0, 5)], rng.integers(100, 99999)) for _ in range(9000)).encode()
-    # (libzstd level 3 cuts this into ~10 KiB blocks, raw ones among them: a frame of ~260 blocks)
-    pool = [rng.integers(0, 256, int(rng.integers(20, 200)), dtype=np.uint8).tobytes() for _ in range(3000)]
-    mixed = bytearray()
-    while len(mixed) < (3 << 20):
-        mixed += pool[int(rng.integers(0, len(pool)))] if rng.random() < 0.5 else rng.integers(0, 256, int(rng.integers(20, 200)), dtype=np.uint8).tobytes()
-    return [whole, whole[:300000], whole[100000:100000 + 131073], whole[:131072] + noise[:140000] + whole[:70000], b"\0" * 400000, b"abc" * 100000 + whole[50000:250000],
-            noise[:5], noise, whole[400000:1000000], b"q" * 131072 + b"r" * 131072 + whole[:10], whole[:262144], logs,
-            (" ".join(str(x) for x in rng.integers(0, 1000, 200000))).encode(), bytes(rng.choice(list(b"ACGT"), 700000).tolist()), bytes(mixed[:3 << 20])]
-
-
 @pytest.mark.parametrize("stream_blocks", [65536, 16])
 def test_multi_block_frames_take_the_multi_block_stages(o, stream_blocks):
     """frames of several blocks (ZstdOutputStream / ZstdFrameCompressor / libzstd beyond 128 KiB) go through the
@@ -180,7 +161,7 @@ def test_multi_block_frames_take_the_multi_block_stages(o, stream_blocks):
     frame of more blocks than a pass has slots falls back."""
     from tests.gpu_harness import GpuBatch
     g = GpuBatch(0, options={"zstd.decompress.stream_blocks": stream_blocks})
-    plains = multi_block_plains()
+    plains = common.multi_block_plains()
     encoders = [("oracle", lambda b: o.compress("zstd", b))] + [("libzstd-%d" % l, (lambda l: lambda b: zstd_frames([b], l)[0])(l)) for l in (1, 3, 9, 19)]
     unfit = 0
     for name, enc in encoders:
@@ -203,7 +184,7 @@ def test_damaged_multi_block_frames_report_what_the_oracle_reports(gbd, o):
     """whatever the multi-block stages make of a damaged frame -- decode it (the damage may be harmless, or only change bytes) or hand
     it to the one-kernel decoder -- the caller sees the oracle's output, status and offset"""
     rng = np.random.default_rng(23)
-    plains = multi_block_plains()[1:6]
+    plains = common.multi_block_plains()[1:6]
     cases = []
     for name, enc in (("oracle", lambda b: o.compress("zstd", b)), ("libzstd-3", lambda b: zstd_frames([b], 3)[0])):
         for b in plains:

@@ -65,33 +65,15 @@ def frame_blocks(f):
 
 def multi_block(expect_fast):
     """frames of several blocks (and of raw / RLE blocks) through the multi-block stages, at several pass sizes"""
-    whole = b"".join(d for _, d, _ in common.corpus_sample())
-    rng = np.random.default_rng(11)
-    noise = rng.integers(0, 256, 200000, dtype=np.uint8).tobytes()
-    plains = [whole[:300000], whole[100000:100000 + 131073], whole[:131072] + noise[:140000] + whole[:70000], b"\0" * 400000, b"abc" * 100000 + whole[50000:250000],
-              noise[:5], noise[:200000], whole[400000:1000000], b"q" * 131072 + b"r" * 131072 + whole[:10], whole[:262144]]
-    # data whose blocks look alike: the encoders then reuse the previous block's Huffman table (treeless literals) and FSE tables (repeat mode)
-    def logs(n):
-        out = []
-        for _ in range(n):
-            out.append("2026-09-%02d %02d:%02d:%02d host%d GET /api/v1/items/%d?user=%d status=%d bytes=%d\n" % (
-                rng.integers(1, 29), rng.integers(0, 24), rng.integers(0, 60), rng.integers(0, 60), rng.integers(0, 9), rng.integers(0, 100000), rng.integers(0, 5000),
-                [200, 200, 200, 404, 500][rng.integers(0, 5)], rng.integers(100, 99999)))
-        return "".join(out).encode()
-    plains += [logs(9000), (" ".join(str(x) for x in rng.integers(0, 1000, 200000))).encode(), bytes(rng.choice(list(b"ACGT"), 700000).tolist())]
-    # data that libzstd (level 3) cuts into ~15 KiB blocks: a frame of more blocks than the smallest pass has slots (128) must take the fallback list
-    pool = [rng.integers(0, 256, int(rng.integers(20, 200)), dtype=np.uint8).tobytes() for _ in range(3000)]
-    mixed = bytearray()
-    while len(mixed) < (3 << 20):
-        mixed += pool[int(rng.integers(0, len(pool)))] if rng.random() < 0.5 else rng.integers(0, 256, int(rng.integers(20, 200)), dtype=np.uint8).tobytes()
-    plains.append(bytes(mixed[:3 << 20]))
+    plains = common.multi_block_plains()  # (tests/common.py: also the GPU test's inputs)
+    long_frame = len(plains) - 1
     bad = 0
     encs = [("oracle", lambda p: o.compress("zstd", p))]
     if HAVE_LIBZSTD:
         encs += [("libzstd-%d" % l, (lambda l: lambda p: libzstd(p, l))(l)) for l in ((1, 3, 9, 19) if "--quick" not in sys.argv else (3, 19))]
     for name, enc in encs:
         frames = [bytes(enc(p)) for p in plains]
-        for pass_blocks, pad in (((2048, 0), (16, 11), (64, 0), (8192, 3)) if "--quick" not in sys.argv else ((2048, 0), (16, 11), (8192, 3))[:1 if name == "libzstd-19" else (3 if name == "oracle" else 2)]):
+        for pass_blocks, pad in (((2048, 0), (16, 11), (64, 0), (8192, 3)) if "--quick" not in sys.argv else ((2048, 0), (16, 11)) if name == "oracle" else (((8192, 3), (16, 11)) if name == "libzstd-3" else ((2048, 0),))):
             # (passes for 8192 blocks: the emulator's provider refuses more than 400 MB, the stages ask again for 4096, 2048, 1024)
             outs, status, fb = run(frames, [len(p) + pad for p in plains], pass_blocks=pass_blocks, mb_max_bytes=400 << 20 if pass_blocks == 8192 else 0)
             c = run.counters
