@@ -12,7 +12,7 @@ import numpy as np
 from . import native
 from .native import HipNative
 
-OP_LZ4_DECOMPRESS, OP_LZ4_COMPRESS, OP_SNAPPY_DECOMPRESS, OP_SNAPPY_COMPRESS, OP_ZSTD_DECOMPRESS, OP_ZSTD_COMPRESS, OP_LZ4FRAME_DECOMPRESS, OP_LZ4FRAME_COMPRESS, OP_SNAPPYFRAMED_DECOMPRESS, OP_SNAPPYFRAMED_COMPRESS, OP_LZ4HADOOP_DECOMPRESS, OP_LZ4HADOOP_COMPRESS, OP_SNAPPYHADOOP_DECOMPRESS, OP_SNAPPYHADOOP_COMPRESS = range(14)
+OP_LZ4_DECOMPRESS, OP_LZ4_COMPRESS, OP_SNAPPY_DECOMPRESS, OP_SNAPPY_COMPRESS, OP_ZSTD_DECOMPRESS, OP_ZSTD_COMPRESS, OP_LZ4FRAME_DECOMPRESS, OP_LZ4FRAME_COMPRESS, OP_SNAPPYFRAMED_DECOMPRESS, OP_SNAPPYFRAMED_COMPRESS, OP_LZ4HADOOP_DECOMPRESS, OP_LZ4HADOOP_COMPRESS, OP_SNAPPYHADOOP_DECOMPRESS, OP_SNAPPYHADOOP_COMPRESS, OP_ZSTDSTREAM_COMPRESS = range(15)
 _FN = {
     OP_LZ4_DECOMPRESS: "achip_lz4_decompress_batch",
     OP_LZ4_COMPRESS: "achip_lz4_compress_batch",
@@ -28,6 +28,7 @@ _FN = {
     OP_LZ4HADOOP_COMPRESS: "achip_lz4hadoop_compress_batch",
     OP_SNAPPYHADOOP_DECOMPRESS: "achip_snappyhadoop_decompress_batch",
     OP_SNAPPYHADOOP_COMPRESS: "achip_snappyhadoop_compress_batch",
+    OP_ZSTDSTREAM_COMPRESS: "achip_zstdstream_compress_batch",
 }
 
 

@@ -263,6 +263,49 @@ class ZstdHipCompressor(_HipCompressor):
     _codec = "zstd"
 
 
+class ZstdHipOutputStream:
+    """Drop-in for ZstdOutputStream (M/zstd/ZstdOutputStream.java:30-221) over a binary sink: write() collects, close() hands everything
+    to the stream encoder (achip_zstdstream_compress: the stream's parameters, not the frame compressor's) and writes the frame to the
+    sink.  The Java stream flushes chunks once 4 MiB have been written; that part is not built on the device (include/aircompressor_hip.h):
+    such a stream raises at close()."""
+
+    def __init__(self, sink, device=0, native_ctx=None):
+        self._sink = sink
+        self._codec = _ZstdStreamEncoder(device, native_ctx)
+        self._parts = []
+        self._closed = False
+
+    def write(self, buffer, offset=0, length=None):
+        if self._closed:
+            raise IOError("Stream is closed")  # :72-74
+        view = _ro_view(buffer)
+        length = view.size - offset if length is None else length
+        _verify_range(buffer, offset, length)
+        self._parts.append(bytes(view[offset:offset + length]))
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        data = b"".join(self._parts)
+        self._parts = []
+        out = bytearray(self._codec.max_compressed_length(len(data)))
+        n = self._codec.compress(data, 0, len(data), out, 0, len(out))
+        self._sink.write(bytes(out[:n]))
+        if hasattr(self._sink, "close"):
+            self._sink.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class _ZstdStreamEncoder(_HipCompressor):
+    _codec = "zstdstream"
+
+
 class ZstdHipDecompressor(_HipDecompressor):
     """Drop-in for ZstdJavaDecompressor (M/zstd/ZstdJavaDecompressor.java:29-90)."""
     _codec = "zstd"

@@ -251,6 +251,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
     achip::BatchArgs a = args;
     a.ringPad = ctx->ringPad;
     if (op == ACHIP_OP_ZSTD_COMPRESS) a.ringPad = ctx->zstdcVariant == 100 ? 999 : (ctx->zstdcVariant == 1 ? 1 : 0);  // encoder variant rides in the spare field
+    if (op == ACHIP_OP_ZSTDSTREAM_COMPRESS) a.ringPad = 2;  // (the encoder's stream mode: zstd_compress.hip)
     if (a.nBlocks < 0) {
         return bad_argument("nBlocks < 0");
     }
@@ -384,6 +385,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             e = achip::launch_lz4frame_compress(a, ctx->stream, ctx->scratch);
             break;
         }
+        case ACHIP_OP_ZSTDSTREAM_COMPRESS:
         case ACHIP_OP_ZSTD_COMPRESS: {
             int32_t r = ensure_scratch(ctx, achip::zstd_compress_scratch_bytes(a.nBlocks));
             if (r < 0) return r;
@@ -562,6 +564,13 @@ int32_t achip_hadoop_max_compressed_length(int32_t codec, int32_t n, int32_t buf
     const int64_t maxLength = ((int64_t)n / chunk) * (8 + bound(chunk)) + (rest > 0 ? 8 + bound(rest) : 0);
     if (maxLength > 0x7FFFFFFF) return bad_argument("Maximum compressed length exceeds Integer.MAX_VALUE");
     return (int32_t)maxLength;
+}
+int32_t achip_zstdstream_max_compressed_length(int32_t n)
+{
+    if (n < 0) return bad_argument("uncompressedSize is negative");
+    const int64_t r = (int64_t)achip_zstd_max_compressed_length(n) + 16;
+    if (r > 0x7FFFFFFF) return bad_argument("Maximum compressed length exceeds Integer.MAX_VALUE");
+    return (int32_t)r;
 }
 int32_t achip_zstd_max_compressed_length(int32_t n)
 {
@@ -922,6 +931,7 @@ ACHIP_DEFINE_BATCH(achip_lz4hadoop_decompress_batch, ACHIP_OP_LZ4HADOOP_DECOMPRE
 ACHIP_DEFINE_BATCH(achip_lz4hadoop_compress_batch, ACHIP_OP_LZ4HADOOP_COMPRESS)
 ACHIP_DEFINE_BATCH(achip_snappyhadoop_decompress_batch, ACHIP_OP_SNAPPYHADOOP_DECOMPRESS)
 ACHIP_DEFINE_BATCH(achip_snappyhadoop_compress_batch, ACHIP_OP_SNAPPYHADOOP_COMPRESS)
+ACHIP_DEFINE_BATCH(achip_zstdstream_compress_batch, ACHIP_OP_ZSTDSTREAM_COMPRESS)
 
 // ---- mixed batch: bucket by codec op, run every op over its slice, un-bucket (BASELINE configs[4]) ----
 namespace {
@@ -940,7 +950,7 @@ int32_t ensure_mix(achip_ctx* ctx, int64_t n)
     ctx->mixItems = want;
     return 0;
 }
-constexpr int kNumOps = 14;
+constexpr int kNumOps = 15;
 }  // namespace
 
 int32_t achip_mixed_batch(achip_ctx* ctx, const int32_t* codecOp, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, void* dstBase,
@@ -1410,6 +1420,10 @@ int32_t achip_snappyhadoop_compress(achip_ctx* ctx, const void* src, void* dst, 
 int32_t achip_snappyhadoop_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
 {
     return single_block(ACHIP_OP_SNAPPYHADOOP_DECOMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
+int32_t achip_zstdstream_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
+{
+    return single_block(ACHIP_OP_ZSTDSTREAM_COMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
 }
 int32_t achip_lz4frame_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
 {

@@ -86,6 +86,7 @@ struct Ctx {
     int lane;
     int dbgStage;
     int batchProbe;
+    int streamMode;      // 1: the item is what one write() + close() hand to a ZstdOutputStream (parameters for an unknown size)
     int32_t failStatus;  // 0 = ok
     const int32_t* pre;  // match-finder results of this item (two-kernel path) or null
     // per-wave slab
@@ -1566,8 +1567,20 @@ __device__ int32_t compress_block(Ctx& c, Shared& sh, int32_t inputAddress, int3
 }
 
 // CompressionParameters.compute :256-299 (level 3)
+// ZstdOutputStream.java:48-58 (stream mode): CompressionParameters.compute(3, -1) returns the default row as it stands (:259-261) --
+// window 2^20, chain 2^16, hash 2^17 whatever the input's size.
+constexpr int32_t STREAM_MAX_BUFFER = 4 << 20;  // 4 x window: from here on the stream flushes before close() (not built: see zstd_compress_item)
 __device__ __forceinline__ void compute_parameters(Ctx& c)
 {
+    if (c.streamMode) {
+        c.searchLength = LEVEL3[0][3];
+        c.windowLog = LEVEL3[0][0];
+        c.windowSize = 1 << c.windowLog;
+        c.blockSize = MAX_BLOCK_SIZE;
+        c.chainLog = LEVEL3[0][1];
+        c.hashLog = LEVEL3[0][2];
+        return;
+    }
     const int32_t inputSize = c.inLen;
     const int table = inputSize <= 16 * 1024 ? 3 : (inputSize <= 128 * 1024 ? 2 : (inputSize <= 256 * 1024 ? 1 : 0));
     int32_t windowLog = LEVEL3[table][0], chainLog = LEVEL3[table][1], hashLog = LEVEL3[table][2];
@@ -1605,6 +1618,13 @@ __device__ int32_t zstd_compress_item(Ctx& c, Shared& sh)
     const int32_t inputSize = c.inLen;
     const int32_t outputLimit = c.outCap;
     int32_t output = 0;
+    if (c.streamMode && inputSize >= STREAM_MAX_BUFFER) {
+        // ZstdOutputStream.java:122-131: a write() that fills the 4 MiB buffer is flushed before close() -- a frame header without the
+        // content size, the window slid between chunks (and, the window base staying behind, blocks that find no match: DESIGN 10 row 3).
+        // Below that size close() writes everything as ONE chunk, which is this function with the stream's parameters.
+        c.failStatus = mk_status(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_UNSUPPORTED);
+        return -1;
+    }
     compute_parameters(c);
     ZC_CHECK(c, outputLimit - output >= 4);  // writeMagic :55-61
     st4(c.out + output, 0xFD2FB528u);
@@ -1743,6 +1763,7 @@ __global__ __launch_bounds__(64) void zstd_match_kernel(BatchArgs a, uint8_t* ta
         c.lane = lane;
         c.dbgStage = 0;
         c.batchProbe = batchProbe;
+        c.streamMode = 0;
         c.failStatus = 0;
         c.pre = nullptr;
         if (!split_eligible(c.inLen)) {
@@ -1812,6 +1833,7 @@ __global__ __launch_bounds__(64) void zstd_compress_kernel(BatchArgs a, uint8_t*
         c.lane = lane;
         c.dbgStage = a.ringPad == 999 ? 1 : 0;
         c.batchProbe = a.ringPad == 1 ? 0 : 1;  // variant 1 = serial probing
+        c.streamMode = a.ringPad == 2 ? 1 : 0;  // (launch_zstd_compress: the stream op)
         c.failStatus = 0;
         c.pre = nullptr;
         uint8_t* p = slab;
@@ -1873,11 +1895,15 @@ int64_t zstd_compress_scratch_bytes(int32_t nBlocks)
 
 // variant 0 (default): match-finder kernel + entropy kernel for one-block inputs, one kernel for the rest; 1: the same with
 // serial probing; 2: everything in the one kernel; 100: timing aid (one kernel, stop after the match finder)
+// a.ringPad == 2: the items are ZstdOutputStream inputs (the stream's parameters; the one kernel for every size)
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant)
 {
     (void)scratchBytes;
     if (a.nBlocks <= 0) {
         return hipSuccess;
+    }
+    if (a.ringPad == 2) {
+        variant = 2;
     }
     uint8_t* base = (uint8_t*)scratch;
     int32_t* counter = (int32_t*)base;

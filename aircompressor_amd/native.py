@@ -41,6 +41,9 @@ SIGNATURES = {
     "achip_snappyframed_compress": (_i32, [_vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_i64)]),
     "achip_snappyframed_decompress": (_i32, [_vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_i64)]),
     "achip_hadoop_max_compressed_length": (_i32, [_i32, _i32, _i32]),
+    "achip_zstdstream_max_compressed_length": (_i32, [_i32]),
+    "achip_zstdstream_compress_batch": (_i32, _BATCH),
+    "achip_zstdstream_compress": (_i32, [_vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_i64)]),
     "achip_lz4hadoop_decompress_batch": (_i32, _BATCH),
     "achip_lz4hadoop_compress_batch": (_i32, _BATCH),
     "achip_snappyhadoop_decompress_batch": (_i32, _BATCH),

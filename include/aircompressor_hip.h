@@ -304,6 +304,21 @@ int32_t achip_lz4hadoop_decompress(achip_ctx* ctx, const void* src, void* dst, i
 int32_t achip_snappyhadoop_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
 int32_t achip_snappyhadoop_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
 
+/* ---- Zstd streams ----
+ * READING needs no entry point of its own: what ZstdInputStream (M/zstd/ZstdInputStream.java:26-151, through
+ * ZstdIncrementalFrameDecompressor.java:44-72,216-234) yields for a stream is what ZstdFrameDecompressor yields for its bytes, and
+ * achip_zstd_decompress* take frames of any number of blocks on their fast path (DESIGN 6 "Multi-block frames").
+ * WRITING: item i = everything a caller hands to ONE ZstdOutputStream (M/zstd/ZstdOutputStream.java:30-221) -- write(buffer, 0, n) and
+ * close(), the way the reference's stream harness drives it (T/HadoopCodecCompressor.java:57-72); dst receives what the stream puts on
+ * its sink.  That is NOT achip_zstd_compress' output: the stream's parameters are those for an unknown input size (window 2^20, hash
+ * 2^17, chain 2^16 whatever n is; :48-58).  Built for n < 4 MiB, where close() writes the input as one chunk whose size the frame header
+ * announces; from 4 MiB on the stream flushes chunks before close() (header without content size, window slid between chunks):
+ * INVALID_ARGUMENT / ACHIP_D_UNSUPPORTED for such an item -- the oracle restates that part (oracle/zstd_enc.c), the kernel does not yet.
+ * Byte-identical output wants dstCap >= achip_zstdstream_max_compressed_length(n) (the stream itself never runs out of room). */
+int32_t achip_zstdstream_max_compressed_length(int32_t uncompressedSize);
+int32_t achip_zstdstream_compress_batch(ACHIP_BATCH_ARGS);
+int32_t achip_zstdstream_compress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset);
+
 /* ---- xxhash: batched XXH64 / XXH32 of device-resident buffers ----
  * Replace XxHash64Hasher.hash(MemorySegment input, long seed)   M/xxhash/XxHash64Hasher.java:78-86  (-> XxHash64JavaHasher.java:126)
  *     and XxHash32Hasher.hash(MemorySegment input, int seed)    M/xxhash/XxHash32Hasher.java       (-> XxHash32JavaHasher.java:112)
@@ -332,6 +347,7 @@ int32_t achip_xxhash32(achip_ctx* ctx, const void* src, int64_t srcLen, int32_t 
 #define ACHIP_OP_LZ4HADOOP_COMPRESS 11
 #define ACHIP_OP_SNAPPYHADOOP_DECOMPRESS 12
 #define ACHIP_OP_SNAPPYHADOOP_COMPRESS 13
+#define ACHIP_OP_ZSTDSTREAM_COMPRESS 14
 int32_t achip_batch_host(int32_t codecOp, ACHIP_BATCH_ARGS);
 /* (Staging is chunked and double-buffered: while chunk c runs on the GPU, chunk c+1 is gathered into pinned memory and uploaded
  * and chunk c-1 is downloaded and scattered to dstBase by a few host copy threads -- options "host.chunk_bytes",

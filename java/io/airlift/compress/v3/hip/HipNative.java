@@ -62,6 +62,7 @@ public final class HipNative
     public static final int OP_LZ4HADOOP_COMPRESS = 11;      // achip_lz4hadoop_compress
     public static final int OP_SNAPPYHADOOP_DECOMPRESS = 12; // achip_snappyhadoop_decompress
     public static final int OP_SNAPPYHADOOP_COMPRESS = 13;   // achip_snappyhadoop_compress
+    public static final int OP_ZSTDSTREAM_COMPRESS = 14;     // achip_zstdstream_compress (SURVEY 8f row 3: what a ZstdOutputStream puts on its sink)
 
     private record MethodHandles(
             @NativeSignature(name = "achip_device_count", returnType = int.class, argumentTypes = {})
@@ -134,6 +135,14 @@ public final class HipNative
             MethodHandle snappyHadoopDecompress,
             @NativeSignature(name = "achip_hadoop_max_compressed_length", returnType = int.class, argumentTypes = {int.class, int.class, int.class})
             MethodHandle hadoopMaxCompressedLength,
+            // Zstd streams (SURVEY 8f row 3)
+            @NativeSignature(name = "achip_zstdstream_compress", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle zstdStreamCompress,
+            @NativeSignature(name = "achip_zstdstream_max_compressed_length", returnType = int.class, argumentTypes = int.class)
+            MethodHandle zstdStreamMaxCompressedLength,
+            @NativeSignature(name = "achip_zstdstream_compress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle zstdStreamCompressBatch,
             @NativeSignature(name = "achip_ctx_set_option", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, long.class})
             MethodHandle ctxSetOption,
             // the public xxhash package on the GPU (SURVEY 8f row 4): (ctx, data, length, seed, out*) and (ctx, base, offsets*, lengths*, seed, hashes*, count)
@@ -346,6 +355,24 @@ public final class HipNative
         }
     }
 
+    /** bound of what a ZstdOutputStream writes for n bytes (achip_zstdstream_max_compressed_length) */
+    public static int zstdStreamMaxCompressedLength(int n)
+    {
+        try {
+            int result = (int) HANDLES.zstdStreamMaxCompressedLength().invokeExact(n);
+            if (result < 0) {
+                throw new IllegalArgumentException(n < 0 ? "uncompressedSize is negative: " + n : "Maximum compressed length exceeds Integer.MAX_VALUE for uncompressedSize: " + n);
+            }
+            return result;
+        }
+        catch (RuntimeException e) {
+            throw e;
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
     /** bound the one-shot Hadoop stream writers ask of their destination: codec 0 = LZ4, 1 = Snappy (achip_hadoop_max_compressed_length) */
     public static int hadoopMaxCompressedLength(int codec, int n, int bufferSize)
     {
@@ -527,6 +554,7 @@ public final class HipNative
                     case OP_LZ4HADOOP_COMPRESS -> HANDLES.lz4HadoopCompress();
                     case OP_LZ4HADOOP_DECOMPRESS -> HANDLES.lz4HadoopDecompress();
                     case OP_SNAPPYHADOOP_COMPRESS -> HANDLES.snappyHadoopCompress();
+                    case OP_ZSTDSTREAM_COMPRESS -> HANDLES.zstdStreamCompress();
                     case OP_SNAPPYHADOOP_DECOMPRESS -> HANDLES.snappyHadoopDecompress();
                     default -> throw new IllegalArgumentException("unknown op " + op);
                 };
@@ -567,6 +595,7 @@ public final class HipNative
                     case OP_LZ4HADOOP_COMPRESS -> HANDLES.lz4HadoopCompressBatch();
                     case OP_LZ4HADOOP_DECOMPRESS -> HANDLES.lz4HadoopDecompressBatch();
                     case OP_SNAPPYHADOOP_COMPRESS -> HANDLES.snappyHadoopCompressBatch();
+                    case OP_ZSTDSTREAM_COMPRESS -> HANDLES.zstdStreamCompressBatch();
                     case OP_SNAPPYHADOOP_DECOMPRESS -> HANDLES.snappyHadoopDecompressBatch();
                     default -> throw new IllegalArgumentException("unknown op " + op);
                 };

@@ -39,6 +39,9 @@ int64_t orc_zstd_decompress(const uint8_t* in, int64_t in_len, uint8_t* out, int
 int64_t orc_zstd_decompressed_size(const uint8_t* in, int64_t in_len, int64_t* err_off);
 /* Zstd level-3 encoder -- M/zstd/ZstdFrameCompressor.java and friends */
 int64_t orc_zstd_compress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap);
+/* ZstdOutputStream (M/zstd/ZstdOutputStream.java:30-221): what one write(buffer, 0, n) + close() put on the sink */
+int64_t orc_zstd_stream_compress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap);
+int64_t orc_zstd_stream_max_compressed_length(int64_t n);
 
 /* test hooks for the frame-header KATs of T/zstd/TestCompressor.java:52-98 */
 int32_t orc_zstd_write_frame_header(uint8_t* out14, int32_t inputSize, int32_t windowSize);

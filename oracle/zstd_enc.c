@@ -1643,9 +1643,171 @@ static int64_t zstd_compress(cctx* c, const uint8_t* in, int32_t inputSize, uint
     return output;
 }
 
-static __thread cctx* g_cctx;
+/*
+ * ZstdOutputStream (M/zstd/ZstdOutputStream.java:30-221) for ONE write(buffer, 0, n) followed by close() -- the way the reference's
+ * own stream harness drives it (T/HadoopCodecCompressor.java:57-72) -- restated without the buffer copies: the stream's buffer is a
+ * sliding view of the input (`origin` = the input position of buffer index 0), everything the encoder sees is relative to it.
+ *   :48-58    parameters for an UNKNOWN size (CompressionParameters.compute(3, -1) = the default row as it stands: window 1 MiB, hash 2^17,
+ *             chain 2^16), buffer limit 4 x window = 4 MiB, a fresh CompressionContext
+ *   :107-120  growBufferIfNecessary: the buffer becomes min(2 n, 4 MiB) (at least one block) once per write()
+ *   :122-131  compressIfNecessary: only a FULL buffer of the maximum size is flushed -- so an input below 4 MiB is written by close()
+ *             alone, as one chunk whose size the frame header announces
+ *   :154-221  writeChunk: a flush writes whole blocks and keeps window + one block unprocessed (23 blocks the first time, 15 from then
+ *             on), then slides: table entries move down by the slide (:35-49 of BlockCompressionState, clamped at 0) and the buffer's
+ *             tail moves to its front.  The window base (BlockCompressionState.windowBaseOffset) does NOT move with them -- enforceMaxDistance
+ *             (:61-69) only ever raises it -- so after a slide it lies AHEAD of the next blocks, which therefore find no match at all
+ *             (every candidate fails `matchAddress > windowBaseAddress`, both repeat offsets are put aside) until the position has caught
+ *             up with it: 7 blocks of literals after every slide.  Kept as it is: the bytes are the reference's.
+ * n >= 2^30 is refused (the Java code computes (0 + n) * 2 in int: the buffer would be 128 KiB and write() would never return).
+ */
+static int64_t zstd_stream_compress(cctx* c, const uint8_t* src, int32_t n, uint8_t* out, int64_t outCap)
+{
+    build_defaults();
+    /* :48-58 */
+    c->p.windowLog = LEVEL3[0][0];
+    c->p.windowSize = 1 << c->p.windowLog;
+    c->p.blockSize = c->p.windowSize < MAX_BLOCK_SIZE ? c->p.windowSize : MAX_BLOCK_SIZE;
+    c->p.chainLog = LEVEL3[0][1];
+    c->p.hashLog = LEVEL3[0][2];
+    c->p.searchLog = LEVEL3[0][3];
+    c->p.searchLength = LEVEL3[0][4];
+    c->p.targetLength = LEVEL3[0][5];
+    const int32_t windowSize = c->p.windowSize, blockSizeMax = c->p.blockSize;
+    const int32_t maxBufferSize = windowSize * 4;
+    /* the per-block output buffer of the stream (:55-58): what writeCompressedBlock is told it may use */
+    const int32_t compressedLength = (blockSizeMax + SIZE_OF_BLOCK_HEADER) + ((blockSizeMax + SIZE_OF_BLOCK_HEADER) >> 8) + SIZE_OF_LONG;
+    static __thread uint8_t* compressed;
+    if (!compressed) {
+        compressed = (uint8_t*)malloc((size_t)compressedLength + 64);
+    }
+    c->offset0 = 1;
+    c->offset1 = 4;
+    c->tempOffset0 = c->tempOffset1 = 0;
+    c->windowBaseOffset = 0;
+    memset(c->hashTable, 0, sizeof(int32_t) << c->p.hashLog);
+    memset(c->chainTable, 0, sizeof(int32_t) << c->p.chainLog);
+    memset(&c->huf.tables, 0, sizeof(c->huf.tables));
+    c->huf.previousTable = 0;
+    c->huf.temporaryTable = 1;
+    c->huf.previousCandidate = 0;
+    c->huf.temporaryCandidate = 1;
 
-int64_t orc_zstd_compress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap)
+    int64_t output = 0;
+    int32_t bufferLength = 0;            /* uncompressed.length */
+    int64_t origin = 0;                  /* input position of buffer index 0 */
+    int32_t offset = 0, position = 0;    /* uncompressedOffset, uncompressedPosition */
+    int firstChunk = 1;
+    int32_t length = n;
+    /* growBufferIfNecessary(n) :107-120 */
+    if (!(position + length <= bufferLength || bufferLength >= maxBufferSize)) {
+        int64_t newSize = ((int64_t)bufferLength + length) * 2;
+        newSize = newSize < maxBufferSize ? newSize : maxBufferSize;
+        newSize = newSize > blockSizeMax ? newSize : blockSizeMax;
+        bufferLength = (int32_t)newSize;
+    }
+    for (int closing = 0; closing <= 1; closing++) {
+        for (;;) {
+            int flush;
+            if (!closing) {
+                if (length <= 0) {
+                    break;
+                }
+                /* write :93-104 */
+                int32_t writeSize = length < bufferLength - position ? length : bufferLength - position;
+                position += writeSize;
+                length -= writeSize;
+                /* compressIfNecessary :122-131 */
+                flush = bufferLength >= maxBufferSize && position == bufferLength && bufferLength - windowSize > blockSizeMax;
+                if (!flush) {
+                    continue;
+                }
+            }
+            /* writeChunk(lastChunk = closing) :154-221 */
+            int32_t chunkSize;
+            if (closing) {
+                chunkSize = position - offset;
+            }
+            else {
+                chunkSize = position - offset - windowSize - blockSizeMax;
+                chunkSize = (chunkSize / blockSizeMax) * blockSizeMax; /* (> one block: the buffer is 4 windows) */
+            }
+            if (firstChunk) {
+                firstChunk = 0;
+                uint8_t header[4 + MAX_FRAME_HEADER_SIZE];
+                st32(header, MAGIC_NUMBER);
+                int32_t h = 4 + write_frame_header(header + 4, closing ? chunkSize : -1, windowSize);
+                CHECK_ARGUMENT(outCap - output >= h);
+                memcpy(out + output, header, (size_t)h);
+                output += h;
+            }
+            do {
+                int32_t blockSize = chunkSize < blockSizeMax ? chunkSize : blockSizeMax;
+                int lastBlock = closing && blockSize == chunkSize;
+                const uint8_t* in = src + origin; /* the buffer */
+                int32_t compressedSize = 0;       /* writeCompressedBlock :181-204 into compressed[0 .. compressedLength) */
+                if (blockSize > 0) {
+                    compressedSize = compress_block(c, in, offset, blockSize, compressed, SIZE_OF_BLOCK_HEADER, compressedLength - SIZE_OF_BLOCK_HEADER);
+                }
+                if (compressedSize == 0) {
+                    st24(compressed, (uint32_t)((lastBlock ? 1 : 0) | (RAW_BLOCK << 1) | (blockSize << 3)));
+                    memcpy(compressed + SIZE_OF_BLOCK_HEADER, in + offset, (size_t)blockSize);
+                    compressedSize = SIZE_OF_BLOCK_HEADER + blockSize;
+                }
+                else {
+                    st24(compressed, (uint32_t)((lastBlock ? 1 : 0) | (COMPRESSED_BLOCK << 1) | (compressedSize << 3)));
+                    compressedSize += SIZE_OF_BLOCK_HEADER;
+                }
+                CHECK_ARGUMENT(outCap - output >= compressedSize); /* (the sink: the caller's buffer) */
+                memcpy(out + output, compressed, (size_t)compressedSize);
+                output += compressedSize;
+                offset += blockSize;
+                chunkSize -= blockSize;
+            }
+            while (chunkSize > 0);
+            if (closing) {
+                CHECK_ARGUMENT(outCap - output >= 4);
+                st32(out + output, (uint32_t)orc_xxh64(src, n, 0)); /* (partialHash saw every chunk, in order) */
+                output += 4;
+                break;
+            }
+            /* slide :212-219 */
+            int32_t slide = offset - windowSize;
+            for (int32_t i = 0; i < (1 << c->p.hashLog); i++) {
+                int32_t v = c->hashTable[i] - slide;
+                c->hashTable[i] = v & ~(v >> 31);
+            }
+            for (int32_t i = 0; i < (1 << c->p.chainLog); i++) {
+                int32_t v = c->chainTable[i] - slide;
+                c->chainTable[i] = v & ~(v >> 31);
+            }
+            origin += slide;
+            offset -= slide;
+            position -= slide;
+        }
+    }
+    return output;
+}
+
+static __thread cctx* g_cctx;
+static void ensure_cctx(void);
+
+int64_t orc_zstd_stream_compress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap)
+{
+    if (in_len < 0 || in_len >= (1LL << 30)) {
+        return ACHIP_STATUS(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_UNSUPPORTED);
+    }
+    ensure_cctx();
+    fail_ctx f;
+    f.status = 0;
+    g_fail = &f;
+    if (setjmp(f.jb)) {
+        return f.status;
+    }
+    return zstd_stream_compress(g_cctx, in, (int32_t)in_len, out, out_cap);
+}
+int64_t orc_zstd_stream_max_compressed_length(int64_t n) { return orc_zstd_max_compressed_length(n) + 16; }
+
+static void ensure_cctx(void)
 {
     if (!g_cctx) {
         cctx* c = (cctx*)calloc(1, sizeof(cctx));
@@ -1661,6 +1823,11 @@ int64_t orc_zstd_compress(const uint8_t* in, int64_t in_len, uint8_t* out, int64
         c->ss.offsetCodes = (uint8_t*)malloc(maxSequences);
         g_cctx = c;
     }
+}
+
+int64_t orc_zstd_compress(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_cap)
+{
+    ensure_cctx();
     /* The Java encoder writes with 8-byte stores that may run past the final size but never past the caller's
      * buffer unless it first fails a checkArgument; the restatement works in a scratch copy with slack so that
      * those transient stores cannot touch memory past out_cap, then copies the result back. */

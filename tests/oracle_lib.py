@@ -31,7 +31,9 @@ class Oracle:
         for name in ("orc_lz4_max_compressed_length", "orc_snappy_max_compressed_length", "orc_zstd_max_compressed_length", "orc_lz4frame_max_compressed_length", "orc_snappyframed_max_compressed_length"):
             getattr(lib, name).restype = i64
             getattr(lib, name).argtypes = [i64]
-        for name in ("orc_lz4_compress", "orc_snappy_compress", "orc_zstd_compress", "orc_lz4frame_compress", "orc_snappyframed_compress"):
+        lib.orc_zstd_stream_max_compressed_length.restype = i64
+        lib.orc_zstd_stream_max_compressed_length.argtypes = [i64]
+        for name in ("orc_lz4_compress", "orc_snappy_compress", "orc_zstd_compress", "orc_zstd_stream_compress", "orc_lz4frame_compress", "orc_snappyframed_compress"):
             getattr(lib, name).restype = i64
             getattr(lib, name).argtypes = [u8p, i64, u8p, i64]
         for name in ("orc_lz4_decompress", "orc_snappy_decompress", "orc_zstd_decompress", "orc_lz4frame_decompress", "orc_snappyframed_decompress"):
@@ -75,6 +77,17 @@ class Oracle:
             cap = self.max_compressed_length(codec, len(src))
         dst = np.zeros(max(cap, 1), dtype=np.uint8)
         r = getattr(self.lib, "orc_%s_compress" % codec)(src.ctypes.data if len(src) else None, len(src), dst.ctypes.data, cap)
+        if r < 0:
+            raise OracleError(r, 0)
+        return dst[:r].tobytes()
+
+    def zstd_stream_compress(self, data, cap=None):
+        """what ZstdOutputStream puts on its sink for write(data) + close()"""
+        src = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+        if cap is None:
+            cap = self.lib.orc_zstd_stream_max_compressed_length(len(src))
+        dst = np.zeros(max(cap, 1), dtype=np.uint8)
+        r = self.lib.orc_zstd_stream_compress(src.ctypes.data if len(src) else None, len(src), dst.ctypes.data, cap)
         if r < 0:
             raise OracleError(r, 0)
         return dst[:r].tobytes()
