@@ -1582,11 +1582,23 @@ constexpr uint32_t MB_LIT_FLOOR = 3 * PIPE_LIT_FLOOR, MB_SEQ_FLOOR = 3 * PIPE_SE
 struct MbLayout {
     int64_t counters, mb, desc, huf, fse, lit, seq, total;
     int32_t slots;
+    uint32_t litCap, seqCap;  // literal arena (64-byte units), sequence arena (records)
 };
-MbLayout mb_layout(int32_t passBlocks)
+// what a pass may hold at most with the option at passBlocks
+struct MbCaps {
+    int32_t slots;
+    uint32_t lit, seq;
+};
+MbCaps mb_caps(int32_t passBlocks)
+{
+    return MbCaps{8 * passBlocks, (uint32_t)passBlocks * PIPE_LIT_PER_ITEM + MB_LIT_FLOOR, (uint32_t)passBlocks * PIPE_SEQ_PER_ITEM + MB_SEQ_FLOOR};
+}
+MbLayout mb_layout(const MbCaps& caps)
 {
     MbLayout L;
-    L.slots = 8 * passBlocks;
+    L.slots = caps.slots;
+    L.litCap = caps.lit;
+    L.seqCap = caps.seq;
     auto up = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
     int64_t o = 0;
     L.counters = o;
@@ -1600,15 +1612,15 @@ MbLayout mb_layout(int32_t passBlocks)
     L.fse = o;
     o = up(o + (int64_t)L.slots * zp::FSE_SLOT * 2);
     L.lit = o;
-    o = up(o + ((int64_t)passBlocks * PIPE_LIT_PER_ITEM + MB_LIT_FLOOR) * 64);
+    o = up(o + (int64_t)L.litCap * 64 + 4096);  // (+ a chunk to spare: whole-vector stores behind the last literal)
     L.seq = o;
-    o = up(o + ((int64_t)passBlocks * PIPE_SEQ_PER_ITEM + MB_SEQ_FLOOR) * 8);
+    o = up(o + (int64_t)L.seqCap * 8);
     L.total = o;
     return L;
 }
 }  // namespace
 
-int64_t zstd_decompress_mb_scratch_bytes(int32_t passBlocks) { return mb_layout(passBlocks < 16 ? 16 : passBlocks).total; }
+int64_t zstd_decompress_mb_scratch_bytes(int32_t passBlocks) { return mb_layout(mb_caps(passBlocks < 16 ? 16 : passBlocks)).total; }
 
 int64_t zstd_decompress_pipe_scratch_bytes(int32_t nBlocks, int32_t tileMax) { return pipe_layout(nBlocks, tileMax).total; }
 
@@ -1618,11 +1630,10 @@ namespace {
 // caller for, and how many passes to run.
 hipError_t launch_zstd_mb_stages(const BatchArgs& a, hipStream_t stream, zp::Pipe p, const zd::FseTable* dflt, const ZstdMbProvider* mbp)
 {
-    MbLayout M = mb_layout(mbp->passBlocks);
-    uint32_t litCap = (uint32_t)mbp->passBlocks * PIPE_LIT_PER_ITEM + MB_LIT_FLOOR, seqCap = (uint32_t)mbp->passBlocks * PIPE_SEQ_PER_ITEM + MB_SEQ_FLOOR;
-    p.mbSlots = M.slots;
-    p.mbLitCap = litCap;
-    p.mbSeqCap = seqCap;
+    const MbCaps top = mb_caps(mbp->passBlocks);
+    p.mbSlots = top.slots;
+    p.mbLitCap = top.lit;
+    p.mbSeqCap = top.seq;
     const unsigned perLane = (unsigned)((a.nBlocks + 63) / 64);
     hipLaunchKernelGGL(zstd_mb_count_kernel, dim3(perLane), dim3(64), 0, stream, a, p);
     hipLaunchKernelGGL(zstd_mb_scan_kernel, dim3(1), dim3(64), 0, stream, p);
@@ -1635,25 +1646,36 @@ hipError_t launch_zstd_mb_stages(const BatchArgs& a, hipStream_t stream, zp::Pip
         return hipSuccess;
     }
     const unsigned items64 = (unsigned)((totals[0] + 63) / 64);
-    // the scratch: what the option asks for, or -- when the device cannot give that -- half of it, a quarter ... (more passes)
+    // what the items need: for the size of the scratch and for the cut into passes
+    std::vector<zp::MbItem> items((size_t)totals[0]);
+    e = hipMemcpyAsync(items.data(), p.mbItem, items.size() * sizeof(zp::MbItem), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    int64_t needLit = 0, needSeq = 0;
+    for (const zp::MbItem& it : items) {
+        needLit += it.litUnits;
+        needSeq += it.seqs;
+    }
+    // The scratch: what the batch needs, at most what the option allows -- or, when the device cannot give that, what half the option
+    // allows, a quarter ... (more passes).  A call with one 300 KiB frame asks for a megabyte, not for the 20 GB a full pass takes.
     uint8_t* mbase = nullptr;
-    for (int32_t pb = mbp->passBlocks; totals[1] > 0 && mbase == nullptr && pb >= 16; pb = pb > 1024 ? pb / 2 : 0) {
-        M = mb_layout(pb);
-        litCap = (uint32_t)pb * PIPE_LIT_PER_ITEM + MB_LIT_FLOOR;
-        seqCap = (uint32_t)pb * PIPE_SEQ_PER_ITEM + MB_SEQ_FLOOR;
+    MbLayout M = mb_layout(top);
+    for (int32_t pb = mbp->passBlocks; totals[1] > 0 && mbase == nullptr && pb >= 16; pb = pb >= 32 ? pb / 2 : 0) {
+        const MbCaps c = mb_caps(pb);
+        MbCaps want;
+        want.slots = (int32_t)(totals[1] < c.slots ? (totals[1] < 64 ? 64 : totals[1]) : c.slots);
+        want.lit = (uint32_t)(needLit + 64 < (int64_t)c.lit ? needLit + 64 : (int64_t)c.lit);
+        want.seq = (uint32_t)(needSeq + 64 < (int64_t)c.seq ? needSeq + 64 : (int64_t)c.seq);
+        M = mb_layout(want);
         mbase = (uint8_t*)mbp->get(mbp->user, M.total);
     }
     if (mbase == nullptr) {
         hipLaunchKernelGGL(zstd_mb_release_kernel, dim3(items64), dim3(64), 0, stream, p, 0, totals[0]);  // (no blocks: every listed item failed its walk already)
         return hipGetLastError();
     }
+    const uint32_t litCap = M.litCap, seqCap = M.seqCap;
     p.mbSlots = M.slots;
-    // what the items need, for the cut into passes
-    std::vector<zp::MbItem> items((size_t)totals[0]);
-    e = hipMemcpyAsync(items.data(), p.mbItem, items.size() * sizeof(zp::MbItem), hipMemcpyDeviceToHost, stream);
-    if (e != hipSuccess) return e;
-    e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return e;
     p.mb = (zp::MbBlock*)(mbase + M.mb);
     p.desc = (zp::Desc*)(mbase + M.desc);
     p.huf = (uint16_t*)(mbase + M.huf);

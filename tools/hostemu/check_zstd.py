@@ -74,7 +74,7 @@ def multi_block(expect_fast):
     for name, enc in encs:
         frames = [bytes(enc(p)) for p in plains]
         for pass_blocks, pad in (((2048, 0), (16, 11), (64, 0), (8192, 3)) if "--quick" not in sys.argv else ((2048, 0), (16, 11)) if name == "oracle" else (((8192, 3), (16, 11)) if name == "libzstd-3" else ((2048, 0),))):
-            # (passes for 8192 blocks: the emulator's provider refuses more than 400 MB, the stages ask again for 4096, 2048, 1024)
+            # (the provider refuses more than 400 MB: more than this batch needs -- the stages ask for what the batch needs, not for a full pass)
             outs, status, fb = run(frames, [len(p) + pad for p in plains], pass_blocks=pass_blocks, mb_max_bytes=400 << 20 if pass_blocks == 8192 else 0)
             c = run.counters
             for i, p in enumerate(plains):
@@ -94,6 +94,12 @@ def multi_block(expect_fast):
             if fb != too_long:
                 bad += 1
                 print("MISMATCH %s pass %d: fallback list %s, expected %s" % (name, pass_blocks, fb, too_long))
+    # a provider that gives nothing: every listed frame must come back on the fallback list, none touched
+    frames = [bytes(encs[0][1](p)) for p in plains[:6]]
+    outs, status, fb = run(frames, [len(p) for p in plains[:6]], pass_blocks=2048, mb_max_bytes=1)
+    if fb != list(range(6)):
+        bad += 1
+        print("MISMATCH no scratch: fallback list %s" % fb)
     print("zstd multi-block stages: %d mismatches" % bad)
     return bad
 
