@@ -75,3 +75,16 @@ def test_output_stream_twin(o):
     assert sink.getvalue() == o.zstd_stream_compress(whole[:300000])
     with pytest.raises(IOError):
         s.write(b"x")
+
+
+def test_corpus_files_match_the_stream_manifest(gb, o):
+    """every corpus file below 4 MiB as one stream: the GPU's bytes against tests/golden/oracle_stream_manifest.tsv (the lines a JDK box
+    pins against the real ZstdOutputStream: tools/java/GoldenStreamDump.java)"""
+    import hashlib
+    rows = [r for r in common.read_manifest_tsv("oracle_stream_manifest.tsv") if r[0] != "*" and r[2] < (4 << 20)]
+    corpus = common.corpus_full()
+    inputs = [bytes(corpus[r[0]]) for r in rows]
+    outs, status, err = gb.run(OP_ZSTDSTREAM_COMPRESS, inputs, [o.lib.orc_zstd_stream_max_compressed_length(len(b)) for b in inputs])
+    for r, c, s in zip(rows, outs, status):
+        assert s == 0 and len(c) == r[4] and hashlib.sha256(c).hexdigest() == r[5], r[0]
+

@@ -44,3 +44,29 @@ def test_java_manifest_equals_oracle_manifest():
     assert len(java) == len(orc)
     for j, o in zip(java, orc):
         assert j == o, "Java encoder and oracle differ: %r vs %r" % (j, o)
+
+
+def test_oracle_stream_manifest_is_current(oracle):
+    """tests/golden/oracle_stream_manifest.tsv (tools/make_golden.py): what the oracle's ZstdOutputStream restatement writes for every
+    corpus file and for the whole corpus as one 14 MB stream ("*": chunks flushed before close(), window slides, blind blocks)."""
+    rows = common.read_manifest_tsv("oracle_stream_manifest.tsv")
+    corpus = common.corpus_full()
+    assert len(rows) == len(corpus) + 1
+    import json
+    import os
+    order = [e["file"] for e in json.load(open(os.path.join(common.GOLDEN, "corpus_full.json")))]
+    for file, off, length, codec, clen, sha in rows:
+        data = corpus[file] if file != "*" else b"".join(corpus[f] for f in order)
+        assert off == 0 and length == len(data) and codec == "zstdstream"
+        c = oracle.zstd_stream_compress(data)
+        assert len(c) == clen and hashlib.sha256(c).hexdigest() == sha, file
+        if file == "*":
+            assert oracle.decompress("zstd", c, length) == data
+
+
+def test_java_stream_manifest_equals_oracle_stream_manifest():
+    java = common.read_manifest_tsv("java_stream_manifest.tsv")
+    if java is None:
+        pytest.skip("tests/golden/java_stream_manifest.tsv absent: no JDK >= 22 has run tools/java/run_golden_dump.sh yet (the stream writer's restatement is unpinned)")
+    assert java == common.read_manifest_tsv("oracle_stream_manifest.tsv")
+

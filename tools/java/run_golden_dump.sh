@@ -20,9 +20,18 @@ for f in HadoopStreams HadoopInputStream HadoopOutputStream; do
     echo "$M/hadoop/$f.java" >> "$OUT/sources.txt"
 done
 echo "$HERE/GoldenDump.java" >> "$OUT/sources.txt"
+echo "$HERE/GoldenStreamDump.java" >> "$OUT/sources.txt"
 javac -d "$OUT/classes" @"$OUT/sources.txt"
 java --enable-native-access=ALL-UNNAMED -cp "$OUT/classes" GoldenDump "$REF/testdata" > "$REPO/tests/golden/java_manifest.tsv"
 wc -l "$REPO/tests/golden/java_manifest.tsv"
+# ZstdOutputStream (every file, and the whole corpus as one stream of several chunks) against oracle_stream_manifest.tsv
+java --enable-native-access=ALL-UNNAMED -cp "$OUT/classes" GoldenStreamDump "$REF/testdata" > "$REPO/tests/golden/java_stream_manifest.tsv"
+if diff -q "$REPO/tests/golden/java_stream_manifest.tsv" "$REPO/tests/golden/oracle_stream_manifest.tsv" > /dev/null; then
+    echo "STREAM WRITER PINNED: ZstdOutputStream and the oracle's restatement agree on every line"
+else
+    echo "STREAM WRITER MISMATCH: diff tests/golden/java_stream_manifest.tsv tests/golden/oracle_stream_manifest.tsv"
+    diff "$REPO/tests/golden/java_stream_manifest.tsv" "$REPO/tests/golden/oracle_stream_manifest.tsv" | head -20
+fi
 if diff -q "$REPO/tests/golden/java_manifest.tsv" "$REPO/tests/golden/oracle_manifest.tsv" > /dev/null; then
     echo "PARITY PINNED: the Java encoders and the oracle produce identical streams for every line"
 else

@@ -112,6 +112,18 @@ def full_corpus(o, sha):
                     lines.append("%s\t%d\t%d\t%s\t%d\t%s" % (e["file"], off, len(piece), codec, len(c), sha(c)))
     open(os.path.join(GOLD, "oracle_manifest.tsv"), "w").write("\n".join(lines) + "\n")
     print("golden: full corpus %d files, %d bytes; oracle manifest %d lines" % (len(index), len(blob), len(lines)))
+    stream_manifest(o, sha, [(e["file"], bytes(blob[e["offset"]:e["offset"] + e["length"]])) for e in index])
+
+
+def stream_manifest(o, sha, files):
+    """tests/golden/oracle_stream_manifest.tsv: what the oracle's ZstdOutputStream restatement writes for every corpus file and for the
+    whole corpus as one stream ("*"); tools/java/GoldenStreamDump.java writes the same lines from the real class."""
+    lines = []
+    for name, d in files + [("*", b"".join(d for _, d in files))]:
+        c = o.zstd_stream_compress(d)
+        lines.append("%s\t0\t%d\tzstdstream\t%d\t%s" % (name, len(d), len(c), sha(c)))
+    open(os.path.join(GOLD, "oracle_stream_manifest.tsv"), "w").write("\n".join(lines) + "\n")
+    print("golden: stream manifest %d lines" % len(lines))
 
 
 if __name__ == "__main__":
