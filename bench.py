@@ -390,6 +390,8 @@ def main():
         if "zstd_fragments" in ex:
             result["value_zstd"] = ex["zstd_fragments"]["decompress_GiBps"]      # Zstd level-3 128 KiB frames (BASELINE configs[3]), synthetic
             result["value_zstd_corpus"] = ex["zstd_corpus"]["decompress_GiBps"]  # the same on corpus-tiled data
+        if "zstdstream_corpus" in ex:
+            result["value_zstd_stream_corpus"] = ex["zstdstream_corpus"]["decompress_GiBps"]  # frames of several blocks (4 MiB streams), corpus-tiled
         if not args.no_sweep:
             result["sweep_random301"] = sweep_random301(torch, A, codec, dev, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
