@@ -1128,10 +1128,11 @@ __global__ __launch_bounds__(64) void zstd_pipe_checksum_kernel(BatchArgs a, zp:
 // repeat-offset history and the entropy tables carried from block to block -- and what ZstdFrameCompressor / libzstd write for inputs
 // beyond one block).  K1 lists the items whose first block is not a frame's only compressed block; then
 //
-//   count    a lane per listed item     walks the frame's block headers: one frame that fills the item exactly, block sizes in range
-//   scan     one wavefront              gives every item a range of "virtual" block indices; the host reads the totals (the one
-//                                       synchronisation of the decode call) and runs the blocks through the stages in PASSES of
-//                                       passBlocks virtual blocks (an item belongs to the pass its first block falls into)
+//   count    a lane per listed item     walks the frame's block headers: one frame that fills the item exactly, block sizes in range;
+//                                       adds up what the blocks' headers announce for the literal and the sequence arena
+//   scan     one wavefront              gives every item its range of block indices; the host reads the item records (the one
+//                                       synchronisation of a decode call), asks for scratch by what they need, and cuts the list into
+//                                       PASSES: runs of items whose block slots, literals and sequences fit the scratch
 //   fill     a lane per item            walks again: a slot per block with its place, kind and LINKS -- the slot whose Huffman table
 //                                       treeless literals reuse, the slots whose FSE tables repeat mode reuses
 //   parse    a wavefront per block      K1's block part (parse_block); raw blocks become a literal run, RLE blocks one record
