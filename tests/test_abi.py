@@ -83,6 +83,19 @@ def test_hadoop_stream_bound_and_messages(lib):
     assert lib.achip_detail_message(108) == b"All input was not consumed"
 
 
+def test_zstd_stream_bound(lib):
+    # achip_zstdstream_max_compressed_length against the oracle's, and against what the oracle's stream writer actually needs for
+    # incompressible input (every block stored: 3 bytes per 128 KiB, the longest header, the checksum)
+    o = oracle_lib.load()
+    rng = np.random.default_rng(2)
+    for n in (0, 1, 255, 256, 65791, 65792, 131072, 131073, 1 << 20, (1 << 20) + 1, (4 << 20) - 1, 4 << 20, 9999999):
+        assert lib.achip_zstdstream_max_compressed_length(n) == o.lib.orc_zstd_stream_max_compressed_length(n), n
+    for n in (0, 1, 300, 131072, 131073, 400000, (1 << 20) + 5):
+        noise = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert len(o.zstd_stream_compress(noise)) <= lib.achip_zstdstream_max_compressed_length(n), n
+    assert lib.achip_zstdstream_max_compressed_length(-1) < 0 and lib.achip_zstdstream_max_compressed_length(0x7FFFFFFF) < 0
+
+
 def test_status_helpers(lib):
     st = -(1 + 16 * 5)
     assert lib.achip_status_class(st) == 1 and lib.achip_status_detail(st) == 5

@@ -150,7 +150,61 @@ def mutations(expect_fast):
     return bad
 
 
+def fuzz(n_cases, seed):
+    """--fuzz N [SEED]: N damaged multi-block frames (several mutations each, all encoders) through the stages; whatever is not handed to the
+    fallback list must be exactly what the oracle's decoder returns.  For the record: profiles/r02_zstd_mb_emulator_fuzz.txt"""
+    rng = np.random.default_rng(seed)
+    plains = [p for p in common.multi_block_plains() if 131072 < len(p) <= 800000]
+    encs = [lambda p: o.compress("zstd", p)] + ([lambda p: libzstd(p, 1), lambda p: libzstd(p, 3), lambda p: libzstd(p, 19)] if HAVE_LIBZSTD else [])
+    frames = [(bytes(e(p)), len(p)) for p in plains for e in encs]
+    bad = kept = refused_ok = 0
+    done = 0
+    while done < n_cases:
+        cases = []; caps = []
+        for _ in range(min(48, n_cases - done)):
+            f, n = frames[int(rng.integers(0, len(frames)))]
+            g = bytearray(f)
+            for _ in range(int(rng.integers(1, 4))):
+                kind = int(rng.integers(0, 7))
+                if kind == 0:
+                    g[int(rng.integers(0, len(g)))] ^= 1 << int(rng.integers(0, 8))
+                elif kind == 1:
+                    g[int(rng.integers(4, min(64, len(g))))] = int(rng.integers(0, 256))
+                elif kind == 2 and len(g) > 16:
+                    g = g[:int(rng.integers(8, len(g)))]
+                elif kind == 3:
+                    g += bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8).tolist())
+                elif kind == 4:
+                    at = int(rng.integers(0, max(1, len(g) - 16))); g[at:at + 8] = bytes(rng.integers(0, 256, min(8, len(g) - at), dtype=np.uint8).tolist())
+                elif kind == 5:
+                    g[len(g) - 1 - int(rng.integers(0, min(8, len(g))))] ^= 0x10
+                else:  # a block header: find one by walking, then flip a bit of it
+                    at = int(rng.integers(0, len(g)))
+                    g[at] ^= int(rng.integers(1, 256))
+            cases.append(bytes(g)); caps.append(n if rng.random() < 0.7 else max(1, n - int(rng.integers(1, 70000))))
+        outs, status, fb = run(cases, caps, pass_blocks=2048)
+        for i, (c, cap) in enumerate(zip(cases, caps)):
+            try:
+                want = o.decompress("zstd", c, cap)
+            except oracle_lib.OracleError:
+                want = None
+            if i in fb:
+                refused_ok += 1
+                continue
+            kept += 1
+            if want is None or status[i] != 0 or outs[i] != want:
+                bad += 1
+                print("MISMATCH case %d of batch at %d: oracle %s, stages status %d len %s" % (i, done, "refuses" if want is None else len(want), status[i], None if outs[i] is None else len(outs[i])))
+        done += len(cases)
+    print("zstd multi-block stages, fuzz seed %d: %d damaged frames, %d decoded by the stages (all equal to the oracle's output: %s), %d handed to the fallback list, %d mismatches" % (
+        seed, done, kept, bad == 0, refused_ok, bad))
+    return bad
+
+
 def main():
+    if "--fuzz" in sys.argv:
+        k = sys.argv.index("--fuzz")
+        sys.exit(1 if fuzz(int(sys.argv[k + 1]), int(sys.argv[k + 2]) if len(sys.argv) > k + 2 else 1) else 0)
     expect_fast = "--expect-fast" in sys.argv
     plains = [d for _, d in common.HAND_CASES if len(d) > 0] + [d[:131072] for _, d, _ in common.corpus_sample()[:8]] + common.synthetic_blocks(5, 6)
     plains = [p for p in plains if len(p) <= 131072]
