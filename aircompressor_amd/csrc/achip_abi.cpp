@@ -44,7 +44,7 @@ hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream
 int64_t snappyframed_decompress_scratch_bytes(int32_t nStreams);
 hipError_t launch_snappyframed_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant);
 int64_t snappyframed_compress_scratch_bytes(int32_t nStreams);
-hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize, int variant);
+hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize, int variant, const AuxScratch* aux);
 int64_t hadoop_decompress_scratch_bytes(int32_t nStreams, int32_t bufferSize);
 hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize);
 int64_t hadoop_compress_scratch_bytes(int32_t nStreams);
@@ -73,7 +73,7 @@ struct achip_ctx {
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 0;
     int hadoopBufferSize = 262144;        // Hadoop block streams: the streams' buffer size (Lz4HadoopStreams.java:30; io.compression.codec.*.buffersize)
-    int hadoopDecompressVariant = 1;      // 1 = chunk list through the batched block decoders, the serial kernel behind it (default); 0 = one wavefront per stream
+    int hadoopDecompressVariant = 1;      // 1 = chunk list through the batched block decoders (rings), the serial kernel behind it (default); 2 = the same through the two-pass decoders (unmeasured); 0 = one wavefront per stream
     int snappyFramedCompressVariant = 1;  // framed writer: 1 = block list + two-tier block encoder + compaction (default), 0 = one wavefront per stream
     int snappyFramedVariant = 1;  // framed reader: 1 = chunk list + batched block decoders (default), 0 = one wavefront per stream
     int zstdTile = 65536;    // items per pass of the Zstd decode pipeline (halved automatically when its scratch cannot be allocated)
@@ -369,7 +369,8 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
         case ACHIP_OP_SNAPPYHADOOP_DECOMPRESS: {
             int32_t r = ensure_scratch(ctx, achip::hadoop_decompress_scratch_bytes(a.nBlocks, ctx->hadoopBufferSize));
             if (r < 0) return r;
-            e = achip::launch_hadoop_decompress(a, ctx->stream, ctx->scratch, op == ACHIP_OP_SNAPPYHADOOP_DECOMPRESS, ctx->hadoopBufferSize, ctx->hadoopDecompressVariant);
+            const achip::AuxScratch aux{zstd_mb_scratch, ctx};  // (the context's second, lazily grown buffer: shared with the Zstd multi-block stages)
+            e = achip::launch_hadoop_decompress(a, ctx->stream, ctx->scratch, op == ACHIP_OP_SNAPPYHADOOP_DECOMPRESS, ctx->hadoopBufferSize, ctx->hadoopDecompressVariant, &aux);
             break;
         }
         case ACHIP_OP_LZ4HADOOP_COMPRESS:

@@ -146,6 +146,12 @@ __device__ __forceinline__ void wave_sync()
 // The Zstd decode pipeline's multi-block stages ask their caller for scratch only when a batch holds multi-block frames (the request
 // comes after a stream synchronisation: `get` may allocate; nullptr = none, the frames then take the slow path).  passBlocks: 128 KiB
 // blocks per pass through the stages.
+// The same arrangement for other launchers that learn what they need only on the device (the Hadoop block streams' chunk count): more
+// scratch on request, after a stream synchronisation.
+struct AuxScratch {
+    void* (*get)(void* user, int64_t bytes);
+    void* user;
+};
 struct ZstdMbProvider {
     void* (*get)(void* user, int64_t bytes);
     void* user;

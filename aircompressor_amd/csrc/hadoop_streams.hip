@@ -648,6 +648,9 @@ hipError_t launch_snappy_decompress_lanecopy(const BatchArgs& a, hipStream_t str
 hipError_t launch_snappy_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* stats);
 hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
+hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
+hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
+int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock);
 
 namespace {
 constexpr int HDP_SERIAL_WAVES = 1024;
@@ -665,7 +668,11 @@ int64_t hadoop_decompress_scratch_bytes(int32_t nStreams, int32_t bufferSize)
     return 4096 + n * 16 + 64 + (int64_t)hdp::MAX_CHUNKS * (8 * 3 + 4 * 5) + 4096 + waves * hdp_internal_bytes(bufferSize);
 }
 
-hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize, int variant)
+// variant 1 (default): the chunks through the ring decoders (with the probes' other choices behind them); variant 2 (round 2, written
+// without a GPU at hand: not the default until measured): the chunks through the TWO-PASS decoders -- their record arena is
+// sized by the chunk count, which only the device knows, so the host reads it back (one synchronisation) and asks `aux` for the arena;
+// chunks whose records do not fit, and every chunk when there is no arena, take the ring decoder as in variant 1.
+hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize, int variant, const AuxScratch* aux)
 {
     if (a.nBlocks <= 0) {
         return hipSuccess;
@@ -722,6 +729,33 @@ hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void
     c.only = nullptr;
     c.onlyStats = nullptr;
     int32_t* stats = counters + 16;
+    bool viaTwoPass = false;
+    if (variant == 2 && aux != nullptr && aux->get != nullptr) {
+        int32_t nChunks = 0;
+        e = hipMemcpyAsync(&nChunks, counters + 1, sizeof(nChunks), hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        if (nChunks > 0) {
+            // records per chunk as for 64 KiB blocks (lz4_decompress_v7.hip twopass_scratch_bytes), scaled to the streams' chunk size
+            const int64_t per64k = snappy ? 131072 : 98304;
+            const int64_t perChunk = per64k * (((int64_t)(bufferSize > 65536 ? bufferSize : 65536) + 65535) / 65536);
+            const int64_t bytes = twopass_scratch_bytes(nChunks, perChunk);
+            void* arena = aux->get(aux->user, bytes);
+            if (arena != nullptr) {
+                BatchArgs t = c;
+                t.nBlocks = nChunks;
+                t.nBlocksDev = nullptr;
+                e = snappy ? launch_snappy_decompress_twopass(t, stream, arena, bytes, 4, 0, 2, nullptr) : launch_lz4_decompress_twopass(t, stream, arena, bytes, 16, 0, 2, nullptr);
+                if (e != hipSuccess) return e;
+                viaTwoPass = true;
+            }
+        }
+        else {
+            viaTwoPass = true;  // (nothing listed)
+        }
+    }
+    if (!viaTwoPass) {
     // LZ4: the ring decoder at two lane-group sizes: 4 lanes per chunk from 32768 chunks on, 16 below (721 -> 814 GiB/s fragments, 56 -> 83 corpus at 16384 chunks) (a stream's chunks are up to 256 KiB: a few
     // thousand of them at 4 lanes each leave most of the chip idle); the chunk count, known on the device only, picks one
     BatchArgs big = c, small = c;
@@ -740,6 +774,7 @@ hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void
         if (e == hipSuccess) e = launch_lz4_decompress_rings(small, stream, 16, 0, stats);
         if (e == hipSuccess) e = launch_lz4_decompress_lanecopy(c, stream, stats);
         if (e == hipSuccess) e = launch_lz4_decompress_lanewindow(c, stream, stats);
+    }
     }
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(hdp::hadoop_fold_kernel, dim3(perStream), dim3(64), 0, stream, a, L);

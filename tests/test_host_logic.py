@@ -64,6 +64,11 @@ def test_lane_private_decoder_kernels_on_the_cpu():
     # buffer, executed under the emulator and compared with the plaintext; records that run outside their buffers must be refused
     out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_records.py")], check=True, capture_output=True, text=True, cwd=ROOT).stdout
     assert out.strip().endswith(" 0 mismatches"), out
+    # the Hadoop block-stream reader's variant 2 (walk, chunks through the two-pass decoders with an arena sized after the chunk count is read
+    # back, fold): LZ4 and Snappy streams at three buffer sizes against the plaintext
+    out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_hadoop.py")], check=True, capture_output=True, text=True, cwd=ROOT).stdout
+    lines = [l for l in out.splitlines() if "mismatches" in l]
+    assert len(lines) == 6 and all(l.endswith(" 0 mismatches") for l in lines), out
 
 
 def test_zstd_pipeline_kernels_on_the_cpu():

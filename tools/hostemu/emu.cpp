@@ -53,7 +53,9 @@ extern "C" int emu_hadoop(int op, int snappy, int bufferSize, int variant, const
     static std::vector<uint8_t> scratch;
     const int64_t bytes = op == 0 ? achip::hadoop_decompress_scratch_bytes(n, bufferSize) : achip::hadoop_compress_scratch_bytes(n);
     scratch.assign((size_t)bytes, 0xCD);
-    return op == 0 ? achip::launch_hadoop_decompress(a, nullptr, scratch.data(), snappy != 0, bufferSize, variant) : achip::launch_hadoop_compress(a, nullptr, scratch.data(), snappy != 0, bufferSize);
+    static std::vector<uint8_t> auxBuffer;
+    const achip::AuxScratch aux{[](void*, int64_t bytes) -> void* { auxBuffer.assign((size_t)bytes, 0xCD); return auxBuffer.data(); }, nullptr};
+    return op == 0 ? achip::launch_hadoop_decompress(a, nullptr, scratch.data(), snappy != 0, bufferSize, variant, &aux) : achip::launch_hadoop_compress(a, nullptr, scratch.data(), snappy != 0, bufferSize);
 }
 
 // the executor for records of any length (achip_seqexec2.h exec_records, used by the Zstd pipeline): one block, one wavefront
