@@ -49,7 +49,8 @@ int64_t hadoop_decompress_scratch_bytes(int32_t nStreams, int32_t bufferSize);
 hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize);
 int64_t hadoop_compress_scratch_bytes(int32_t nStreams);
 extern int g_zstd_pipe_exec;
-hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch);
+hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant, const AuxScratch* aux);
+int64_t lz4frame_decompress_scratch_bytes(int32_t nItems, int variant);
 hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch);
 int64_t lz4frame_compress_scratch_bytes();
 hipError_t launch_mix_gather(const int32_t* perm, int32_t n, const BatchArgs& a, int64_t* gSrcOff, int32_t* gSrcLen, int64_t* gDstOff, int32_t* gDstCap, hipStream_t stream);
@@ -73,6 +74,7 @@ struct achip_ctx {
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 0;
     int hadoopBufferSize = 262144;        // Hadoop block streams: the streams' buffer size (Lz4HadoopStreams.java:30; io.compression.codec.*.buffersize)
+    int lz4FrameDecompressVariant = 0;    // 0 = a wavefront per item (default); 1 = the frames' blocks as one batch through the two-pass block decoder (unmeasured)
     int hadoopDecompressVariant = 1;      // 1 = chunk list through the batched block decoders (rings), the serial kernel behind it (default); 2 = the same through the two-pass decoders (unmeasured); 0 = one wavefront per stream
     int snappyFramedCompressVariant = 1;  // framed writer: 1 = block list + two-tier block encoder + compaction (default), 0 = one wavefront per stream
     int snappyFramedVariant = 1;  // framed reader: 1 = chunk list + batched block decoders (default), 0 = one wavefront per stream
@@ -348,9 +350,10 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             break;
         }
         case ACHIP_OP_LZ4FRAME_DECOMPRESS: {
-            int32_t r = ensure_scratch(ctx, 4096);
+            int32_t r = ensure_scratch(ctx, achip::lz4frame_decompress_scratch_bytes(a.nBlocks, ctx->lz4FrameDecompressVariant));
             if (r < 0) return r;
-            e = achip::launch_lz4frame_decompress(a, ctx->stream, ctx->scratch);
+            const achip::AuxScratch aux{zstd_mb_scratch, ctx};
+            e = achip::launch_lz4frame_decompress(a, ctx->stream, ctx->scratch, ctx->lz4FrameDecompressVariant, &aux);
             break;
         }
         case ACHIP_OP_SNAPPYFRAMED_DECOMPRESS: {
@@ -738,6 +741,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->hadoopBufferSize = (int)value;
     }
     else if (k == "hadoop.decompress.variant") ctx->hadoopDecompressVariant = (int)value;
+    else if (k == "lz4frame.decompress.variant") ctx->lz4FrameDecompressVariant = (int)value;
     else if (k == "zstd.decompress.exec") achip::g_zstd_pipe_exec = (int)value;  // (process-wide: a development switch between the two execute stages)
     else if (k == "decompress.ring_pad") {
         if (value < 0 || value > 256 || (value & 15) != 0) return bad_argument("ring pad must be a multiple of 16 in 0..256");

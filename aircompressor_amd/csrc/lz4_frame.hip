@@ -169,7 +169,234 @@ __device__ int32_t decompress_item(const uint8_t* __restrict__ in, int32_t inLen
 
 }  // namespace lz4f
 
-__global__ __launch_bounds__(64) void lz4frame_decompress_kernel(BatchArgs a, int32_t* nextItem)
+// ---- reader variant 1 (round 2; written without a GPU at hand, not the default until measured): the blocks of the regular frames as ONE
+// batch for the two-pass block decoder, as hadoop_streams.hip does it for Hadoop streams.
+//   walk   a lane per item: the item is exactly one frame, its header is in order, no block checksums; every compressed block becomes an
+//          entry of a device-side batch, block k at output position k x blockMaxSize with at most a block's room.  That position is a GUESS
+//          -- a block's length is not in the frame -- which holds for what every writer produces (all blocks but the last are full);
+//   decode the batch through the two-pass decoder; its record arena is sized after the host has read back the number of blocks and their room;
+//   fold   a wavefront per item walks the frame again: compressed blocks must have decoded, all but the last to a full block; stored blocks
+//          are copied now; content checksum and content size are checked; anything else flags the item;
+//   then the kernel above runs the flagged items, and every item of any other shape, from scratch (the Java loop: same status / offset).
+namespace lz4f {
+constexpr int32_t MAX_LIST_BLOCKS = 1 << 20;
+
+struct BlockList {
+    int32_t* counters;   // [0] entries allocated, [1] entries in use (sealed), [2..3] the entries' room (64 bits)
+    int32_t* sFirst;     // per item: first entry, -1 = not on this path
+    int32_t* sSerial;    // per item: 1 = the wavefront-per-item kernel decodes it
+    int64_t* cSrcOff;
+    int64_t* cDstOff;
+    int64_t* cErrOff;
+    int32_t* cSrcLen;
+    int32_t* cDstCap;
+    int32_t* cOutLen;
+    int32_t* cStatus;
+};
+
+struct FrameShape {
+    bool ok;
+    int32_t firstBlock;      // position of the first block header
+    int32_t blockMax;
+    int32_t compressedBlocks;
+    bool contentChecksum;
+    int64_t expectedSize;    // -1: not announced
+};
+
+// the header of an item that holds exactly one frame of the shape the list path takes (decompressFrame :184-240 without its verdicts)
+__device__ __forceinline__ FrameShape frame_shape(const uint8_t* __restrict__ in, int32_t inLen)
+{
+    FrameShape f;
+    f.ok = false;
+    f.firstBlock = 0;
+    f.blockMax = 0;
+    f.compressedBlocks = 0;
+    f.contentChecksum = false;
+    f.expectedSize = -1;
+    if (inLen < HEADER_SIZE + 4 || ld4(in) != MAGIC) {
+        return f;
+    }
+    const int flg = in[4], bd = in[5];
+    if (((flg >> 6) & 3) != 1 || (flg & FLG_RESERVED_MASK) != 0 || (bd & BD_RESERVED_MASK) != 0 || (flg & FLG_BLOCK_INDEPENDENCE) == 0 || (flg & FLG_DICTIONARY_ID) != 0 ||
+        (flg & FLG_BLOCK_CHECKSUM) != 0) {
+        return f;
+    }
+    const int sizeId = (bd >> 4) & 7;
+    if (sizeId < 4) {
+        return f;
+    }
+    f.blockMax = 1 << (8 + 2 * sizeId);
+    f.contentChecksum = (flg & FLG_CONTENT_CHECKSUM) != 0;
+    int32_t p = 6;
+    if ((flg & FLG_CONTENT_SIZE) != 0) {
+        if (p + 8 + 1 > inLen) {
+            return f;
+        }
+        f.expectedSize = (int64_t)ld8(in + p);
+        p += 8;
+    }
+    if (p + 1 > inLen || in[p] != (int)((xxh32_short(in + 4, p - 4) >> 8) & 0xFF)) {
+        return f;
+    }
+    f.firstBlock = p + 1;
+    f.ok = true;
+    return f;
+}
+
+// the blocks of such a frame: FILL = 0 counts the compressed ones and checks that the frame ends the item; FILL = 1 writes their entries
+template <bool FILL>
+__device__ __forceinline__ bool frame_blocks(const BatchArgs& a, int32_t item, FrameShape& f, const BlockList& L, int32_t firstEntry)
+{
+    const uint8_t* __restrict__ in = a.srcBase + a.srcOff[item];
+    const int32_t inLen = a.srcLen[item];
+    const int64_t outCap = a.dstCap[item];
+    int64_t p = f.firstBlock;
+    int64_t o = 0;
+    int32_t n = 0;
+    for (;;) {
+        if (p + 4 > inLen) {
+            return false;
+        }
+        const uint32_t header = ld4(in + p);
+        p += 4;
+        if (header == 0) {
+            break;
+        }
+        const int64_t blockLen = header & 0x7FFFFFFFu;
+        if (blockLen > f.blockMax || p + blockLen > inLen || o >= outCap) {
+            return false;
+        }
+        if ((header & UNCOMPRESSED_FLAG) != 0) {
+            if (o + blockLen > outCap) {
+                return false;
+            }
+            // (a stored block shorter than a full one must be the last: fold sees to that through the positions)
+            o += blockLen < f.blockMax ? blockLen : f.blockMax;
+        }
+        else {
+            if (FILL) {
+                const int32_t e = firstEntry + n;
+                L.cSrcOff[e] = a.srcOff[item] + p;
+                L.cSrcLen[e] = (int32_t)blockLen;
+                L.cDstOff[e] = a.dstOff[item] + o;
+                L.cDstCap[e] = (int32_t)(outCap - o < f.blockMax ? outCap - o : f.blockMax);
+                L.cOutLen[e] = 0;
+                L.cStatus[e] = -1;
+                L.cErrOff[e] = 0;
+            }
+            n++;
+            o += f.blockMax;  // the guess: this block is full (the last one may fall short: nothing follows it)
+        }
+        p += blockLen;
+    }
+    if (f.contentChecksum) {
+        if (p + 4 > inLen) {
+            return false;
+        }
+        p += 4;
+    }
+    f.compressedBlocks = n;
+    return p == inLen;  // (frames or skippable frames behind it: the other kernel's)
+}
+}  // namespace lz4f
+
+__global__ __launch_bounds__(64) void lz4frame_walk_kernel(BatchArgs a, lz4f::BlockList L)
+{
+    using namespace lz4f;
+    const int32_t item = blockIdx.x * 64 + threadIdx.x;
+    if (item >= a.nBlocks) {
+        return;
+    }
+    L.sFirst[item] = -1;
+    L.sSerial[item] = 1;
+    FrameShape f = frame_shape(a.srcBase + a.srcOff[item], a.srcLen[item]);
+    if (!f.ok || a.dstCap[item] <= 0 || !frame_blocks<false>(a, item, f, L, 0)) {
+        return;
+    }
+    const int32_t first = atomicAdd(L.counters, f.compressedBlocks);
+    if ((int64_t)first + f.compressedBlocks > MAX_LIST_BLOCKS) {
+        return;
+    }
+    frame_blocks<true>(a, item, f, L, first);
+    long long room = 0;
+    for (int32_t k = 0; k < f.compressedBlocks; k++) {
+        room += L.cDstCap[first + k];
+    }
+    atomicAdd((unsigned long long*)(L.counters + 2), (unsigned long long)room);
+    L.sFirst[item] = first;
+    L.sSerial[item] = 0;
+}
+
+__global__ void lz4frame_seal_kernel(lz4f::BlockList L)
+{
+    const int32_t allocated = L.counters[0];
+    L.counters[1] = allocated < lz4f::MAX_LIST_BLOCKS ? allocated : lz4f::MAX_LIST_BLOCKS;
+}
+
+// a wavefront per item on the list path
+__global__ __launch_bounds__(64) void lz4frame_fold_kernel(BatchArgs a, lz4f::BlockList L, int32_t decoded)
+{
+    using namespace lz4f;
+    const int32_t item = blockIdx.x;
+    if (L.sSerial[item] != 0) {
+        return;
+    }
+    const int lane = threadIdx.x;
+    const uint8_t* __restrict__ in = a.srcBase + a.srcOff[item];
+    uint8_t* out = a.dstBase + a.dstOff[item];
+    const FrameShape f = frame_shape(in, a.srcLen[item]);  // (the walk's findings again: wave-uniform)
+    bool ok = decoded != 0;
+    int64_t p = f.firstBlock, o = 0;
+    int32_t e = L.sFirst[item];
+    bool shortSeen = false;  // a block that fell short of a full one: nothing may follow it
+    while (ok) {  // (uniform)
+        const uint32_t header = ld4(in + p);
+        p += 4;
+        if (header == 0) {
+            break;
+        }
+        const int64_t blockLen = header & 0x7FFFFFFFu;
+        ok = !shortSeen;
+        if (!ok) {
+            break;
+        }
+        if ((header & UNCOMPRESSED_FLAG) != 0) {
+            wave_sync();
+            group_copy<64>(out + o, in + p, (int32_t)blockLen, lane);
+            wave_sync();
+            shortSeen = blockLen < f.blockMax;
+            o += blockLen;
+        }
+        else {
+            const int32_t got = L.cOutLen[e];
+            ok = L.cStatus[e] == 0;
+            shortSeen = got < f.blockMax;
+            o += got;
+            e++;
+        }
+        p += blockLen;
+    }
+    if (ok && f.contentChecksum) {
+        wave_sync();
+        const uint32_t actual = quad_xxh32(out, (int32_t)o, 0u, lane & 3, lane - (lane & 3));
+        ok = ld4(in + p) == actual;
+    }
+    ok = ok && (f.expectedSize < 0 || o == f.expectedSize);
+    if (lane == 0) {
+        if (ok) {
+            a.outLen[item] = (int32_t)o;
+            a.status[item] = 0;
+            a.errOffset[item] = 0;
+        }
+        else {
+            L.sSerial[item] = 1;  // the Java loop decides what it means
+        }
+    }
+}
+
+// LISTED: only the items `list` flags (the list path's leftovers)
+template <bool LISTED>
+__global__ __launch_bounds__(64) void lz4frame_decompress_kernel(BatchArgs a, int32_t* nextItem, const int32_t* __restrict__ list)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[lz4f::IN_RING + lz4f::OUT_RING];
     __shared__ int32_t item;
@@ -184,6 +411,9 @@ __global__ __launch_bounds__(64) void lz4frame_decompress_kernel(BatchArgs a, in
         if (block >= a.nBlocks) {
             return;
         }
+        if (LISTED && list[block] == 0) {
+            continue;
+        }
         int32_t op = 0;
         int64_t eo = 0;
         const int32_t st = lz4f::decompress_item(a.srcBase + a.srcOff[block], a.srcLen[block], a.dstBase + a.dstOff[block], a.dstCap[block], lds, lane, op, eo);
@@ -195,17 +425,89 @@ __global__ __launch_bounds__(64) void lz4frame_decompress_kernel(BatchArgs a, in
     }
 }
 
-hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch)
+hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
+int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock);
+
+int64_t lz4frame_decompress_scratch_bytes(int32_t nItems, int variant)
+{
+    if (variant != 1) {
+        return 4096;
+    }
+    const int64_t n = nItems < 1 ? 1 : nItems;
+    return 4096 + n * 8 + 64 + (int64_t)lz4f::MAX_LIST_BLOCKS * (8 * 3 + 4 * 4) + 4096;
+}
+
+// variant 0 (default): a wavefront per item; variant 1: the block list (above)
+hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant, const AuxScratch* aux)
 {
     if (a.nBlocks <= 0) {
         return hipSuccess;
     }
-    int32_t* counter = (int32_t*)scratch;
-    hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
+    uint8_t* base = (uint8_t*)scratch;
+    int32_t* counter = (int32_t*)base;
+    hipError_t e = hipMemsetAsync(counter, 0, 4096, stream);
     if (e != hipSuccess) return e;
     const int32_t maxWaves = 256 * 16;
     const unsigned grid = (unsigned)(a.nBlocks < maxWaves ? a.nBlocks : maxWaves);
-    hipLaunchKernelGGL(lz4frame_decompress_kernel, dim3(grid), dim3(64), 0, stream, a, counter);
+    if (variant != 1 || aux == nullptr || aux->get == nullptr) {
+        hipLaunchKernelGGL(lz4frame_decompress_kernel<false>, dim3(grid), dim3(64), 0, stream, a, counter, (const int32_t*)nullptr);
+        return hipGetLastError();
+    }
+    lz4f::BlockList L;
+    uint8_t* p = base + 4096;
+    auto take = [&](int64_t bytes) {
+        uint8_t* r = p;
+        p += (bytes + 15) & ~(int64_t)15;
+        return r;
+    };
+    const int64_t n = a.nBlocks, C = lz4f::MAX_LIST_BLOCKS;
+    L.counters = counter + 16;
+    L.sFirst = (int32_t*)take(4 * n);
+    L.sSerial = (int32_t*)take(4 * n);
+    L.cSrcOff = (int64_t*)take(8 * C);
+    L.cDstOff = (int64_t*)take(8 * C);
+    L.cErrOff = (int64_t*)take(8 * C);
+    L.cSrcLen = (int32_t*)take(4 * C);
+    L.cDstCap = (int32_t*)take(4 * C);
+    L.cOutLen = (int32_t*)take(4 * C);
+    L.cStatus = (int32_t*)take(4 * C);
+    hipLaunchKernelGGL(lz4frame_walk_kernel, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, L);
+    hipLaunchKernelGGL(lz4frame_seal_kernel, dim3(1), dim3(1), 0, stream, L);
+    // the number of listed blocks and their room decide the record arena: the one synchronisation of the call
+    int32_t counts[4] = {0, 0, 0, 0};
+    e = hipMemcpyAsync(counts, L.counters, sizeof(counts), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    const int32_t nListed = counts[1];
+    int32_t decoded = 0;
+    if (nListed > 0) {
+        long long room = 0;
+        __builtin_memcpy(&room, counts + 2, 8);
+        // records per block as for the block codec (96 KiB of arena per 64 KiB of output: lz4_decompress_v7.hip), by the blocks' room
+        const int64_t perBlock = ((room + nListed - 1) / nListed * 3 / 2 + 4095) & ~4095LL;
+        const int64_t bytes = twopass_scratch_bytes(nListed, perBlock < 98304 ? 98304 : perBlock);
+        void* arena = aux->get(aux->user, bytes);
+        if (arena != nullptr) {
+            BatchArgs c = a;
+            c.srcOff = L.cSrcOff;
+            c.srcLen = L.cSrcLen;
+            c.dstOff = L.cDstOff;
+            c.dstCap = L.cDstCap;
+            c.outLen = L.cOutLen;
+            c.status = L.cStatus;
+            c.errOffset = L.cErrOff;
+            c.nBlocks = nListed;
+            c.nBlocksDev = nullptr;
+            c.only = nullptr;
+            c.onlyStats = nullptr;
+            e = launch_lz4_decompress_twopass(c, stream, arena, bytes, 16, 0, 2, nullptr);
+            if (e != hipSuccess) return e;
+            decoded = 1;
+        }
+    }
+    hipLaunchKernelGGL(lz4frame_fold_kernel, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, L, decoded);
+    hipLaunchKernelGGL(lz4frame_decompress_kernel<true>, dim3(grid), dim3(64), 0, stream, a, counter, (const int32_t*)L.sSerial);
     return hipGetLastError();
 }
 

@@ -1,6 +1,8 @@
 """GPU parity tests (through the C ABI) for the LZ4 frame container: the reference's rebuilt test vectors
 (T/lz4/TestLz4FrameDecompressor.java:61-230), byte-identical frames on encode, liblz4 frames on decode, systematic
 corruption with the oracle's status / offset, and a full-size property."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,10 +13,15 @@ pytestmark = pytest.mark.gpu
 OP_DECOMPRESS, OP_COMPRESS = 6, 7
 
 
-@pytest.fixture(scope="module")
-def gb():
+# reader variant 1 (the frames' blocks as one batch through the two-pass block decoder) was written without a GPU at hand and is not the
+# default: it joins these tests when ACHIP_TEST_EXPERIMENTAL is set (tools/hostemu/check_lz4frame.py runs it on the CPU)
+_VARIANTS = [0] + ([1] if os.environ.get("ACHIP_TEST_EXPERIMENTAL") else [])
+
+
+@pytest.fixture(scope="module", params=_VARIANTS, ids=["wave-per-item", "block-list"][:len(_VARIANTS)])
+def gb(request):
     from tests.gpu_harness import GpuBatch
-    return GpuBatch(0)
+    return GpuBatch(0, options={"lz4frame.decompress.variant": request.param})
 
 
 @pytest.fixture(scope="module")

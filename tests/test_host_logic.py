@@ -69,6 +69,10 @@ def test_lane_private_decoder_kernels_on_the_cpu():
     out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_hadoop.py")], check=True, capture_output=True, text=True, cwd=ROOT).stdout
     lines = [l for l in out.splitlines() if "mismatches" in l]
     assert len(lines) == 6 and all(l.endswith(" 0 mismatches") for l in lines), out
+    # the LZ4 frame reader's variant 1 (walk, the frames' blocks as one batch through the two-pass decoder, fold with stored blocks, content size
+    # and content checksum): the Java writer's frames and hand-built ones of 64 / 256 KiB blocks against the plaintext
+    out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_lz4frame.py")], check=True, capture_output=True, text=True, cwd=ROOT).stdout
+    assert out.strip().endswith(" 0 mismatches"), out
 
 
 def test_zstd_pipeline_kernels_on_the_cpu():

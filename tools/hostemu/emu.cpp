@@ -10,6 +10,7 @@ extern "C" { long long achip_emu_counters[16]; }  // development counters of ker
 #include "../../aircompressor_amd/csrc/lz4_decompress_v7.hip"
 #include "../../aircompressor_amd/csrc/snappy_decompress_v5.hip"
 #include "../../aircompressor_amd/csrc/hadoop_streams.hip"
+#include "../../aircompressor_amd/csrc/lz4_frame.hip"
 #include <vector>
 // the decoders the emulator does not build (DPP / cross-lane copy steps) and the probes that would pick them: the probe statistics stay
 // zero, which picks the ring decoders
@@ -76,4 +77,16 @@ extern "C" int emu_exec_records(const uint64_t* rec, int32_t n, const uint8_t* l
 {
     hipLaunchKernelGGL(emu_exec_records_kernel, dim3(1), dim3(64), 0, nullptr, rec, n, lit, litSize, out, outLimit, result);
     return 0;
+}
+
+// LZ4 frames (lz4_frame.hip), reader variant 1: walk, the frames' blocks through the two-pass decoder, fold (the wavefront-per-item kernel
+// behind it moves bytes between lanes in hardware order and is not emulated: irregular items come back with whatever it made of them)
+extern "C" int emu_lz4frame(int variant, const uint8_t* srcBase, const int64_t* srcOff, const int32_t* srcLen, uint8_t* dstBase, const int64_t* dstOff, const int32_t* dstCap,
+                            int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n)
+{
+    achip::BatchArgs a{srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, n, 16};
+    static std::vector<uint8_t> scratch, auxBuffer;
+    scratch.assign((size_t)achip::lz4frame_decompress_scratch_bytes(n, variant), 0xCD);
+    const achip::AuxScratch aux{[](void*, int64_t bytes) -> void* { auxBuffer.assign((size_t)bytes, 0xCD); return auxBuffer.data(); }, nullptr};
+    return achip::launch_lz4frame_decompress(a, nullptr, scratch.data(), variant, &aux);
 }
