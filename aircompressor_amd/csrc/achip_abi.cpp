@@ -40,7 +40,7 @@ hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* 
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
 int64_t zstd_decompress_scratch_bytes(int32_t nBlocks, int32_t tileMax);
 int64_t zstd_compress_scratch_bytes(int32_t nBlocks);
-hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant);
+hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant, const AuxScratch* aux);
 int64_t snappyframed_decompress_scratch_bytes(int32_t nStreams);
 hipError_t launch_snappyframed_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant);
 int64_t snappyframed_compress_scratch_bytes(int32_t nStreams);
@@ -359,7 +359,8 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
         case ACHIP_OP_SNAPPYFRAMED_DECOMPRESS: {
             int32_t r = ensure_scratch(ctx, achip::snappyframed_decompress_scratch_bytes(a.nBlocks));
             if (r < 0) return r;
-            e = achip::launch_snappyframed_decompress(a, ctx->stream, ctx->scratch, ctx->snappyFramedVariant);
+            const achip::AuxScratch aux{zstd_mb_scratch, ctx};
+            e = achip::launch_snappyframed_decompress(a, ctx->stream, ctx->scratch, ctx->snappyFramedVariant, &aux);
             break;
         }
         case ACHIP_OP_SNAPPYFRAMED_COMPRESS: {

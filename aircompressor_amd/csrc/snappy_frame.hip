@@ -707,7 +707,7 @@ __global__ __launch_bounds__(64) void snappyframed_verify_kernel(BatchArgs a, Ch
         int32_t produced;
         if (rawLen >= 0) {
             group_copy<64>(dst, a.srcBase + L.cSrcOff[c], rawLen, lane);
-            wave_mem_order();
+            wave_sync();  // (the checksum below reads what the other lanes copied)
             produced = rawLen;
         }
         else {
@@ -759,7 +759,13 @@ int64_t snappyframed_decompress_scratch_bytes(int32_t nStreams)
     return 4096 + n * (4 * 5 + 8) + (int64_t)snf::MAX_CHUNKS * (8 * 3 + 4 * 7) + 4096;
 }
 
-hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant)
+hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
+int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock);
+
+// variant 1 (default): the chunks through the ring decoders (with the probes' other choices behind them); variant 2 (round 2, written without
+// a GPU at hand: not the default until measured): through the two-pass decoder -- the host reads the chunk count back (one
+// synchronisation) and asks `aux` for the record arena; chunks whose records do not fit take the rings as in variant 1; 0: a wavefront per stream
+hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant, const AuxScratch* aux)
 {
     if (a.nBlocks <= 0) {
         return hipSuccess;
@@ -821,12 +827,35 @@ hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream
     c.only = nullptr;
     c.onlyStats = nullptr;
     int32_t* mixedGroups = counters + 16;
-    e = launch_lz4_mixed_groups(c, stream, mixedGroups, 65536);  // (the lane-per-block decoder wants 64 blocks per wavefront)
-    if (e == hipSuccess) e = launch_snappy_element_sample(c, stream, mixedGroups, 65536);
-    if (e == hipSuccess) e = launch_snappy_decompress_rings(c, stream, 4, 0, mixedGroups);
-    if (e == hipSuccess) e = launch_snappy_decompress_lanecopy(c, stream, mixedGroups);
-    if (e == hipSuccess) e = launch_snappy_decompress_lanewindow(c, stream, mixedGroups);
-    if (e != hipSuccess) return e;
+    bool viaTwoPass = false;
+    if (variant == 2 && aux != nullptr && aux->get != nullptr) {
+        int32_t nChunks = 0;
+        e = hipMemcpyAsync(&nChunks, counters + 1, sizeof(nChunks), hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        viaTwoPass = nChunks == 0;
+        if (nChunks > 0) {
+            const int64_t bytes = twopass_scratch_bytes(nChunks, 131072);  // (chunks hold at most 64 KiB: the block codec's arena per block)
+            void* arena = aux->get(aux->user, bytes);
+            if (arena != nullptr) {
+                BatchArgs t = c;
+                t.nBlocks = nChunks;
+                t.nBlocksDev = nullptr;
+                e = launch_snappy_decompress_twopass(t, stream, arena, bytes, 4, 0, 2, nullptr);
+                if (e != hipSuccess) return e;
+                viaTwoPass = true;
+            }
+        }
+    }
+    if (!viaTwoPass) {
+        e = launch_lz4_mixed_groups(c, stream, mixedGroups, 65536);  // (the lane-per-block decoder wants 64 blocks per wavefront)
+        if (e == hipSuccess) e = launch_snappy_element_sample(c, stream, mixedGroups, 65536);
+        if (e == hipSuccess) e = launch_snappy_decompress_rings(c, stream, 4, 0, mixedGroups);
+        if (e == hipSuccess) e = launch_snappy_decompress_lanecopy(c, stream, mixedGroups);
+        if (e == hipSuccess) e = launch_snappy_decompress_lanewindow(c, stream, mixedGroups);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(snf::snappyframed_verify_kernel, dim3(maxWaves), dim3(64), 0, stream, a, L);
     hipLaunchKernelGGL(snf::snappyframed_fold_kernel, dim3(perStream), dim3(64), 0, stream, a, L);
     // streams that did not fit into the lists

@@ -57,6 +57,7 @@ def parse_args():
     p.add_argument("--exec-variant", type=int, default=-1, help="DEBUG: decompress.exec_variant (two-pass decoders)")
     p.add_argument("--section", default="all", choices=["all", "zstd", "zstdstream", "xxhash", "lz4frame"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-exec", type=int, default=-1, help="zstd pipeline execute stage: 2 = chosen per item (default), 1 = wavefront per item through the record executor, 0 = LDS rings")
+    p.add_argument("--snappyframed-variant", type=int, default=-1, help="x-snappy-framed reader: 1 = chunks through the ring decoders (default), 2 = through the two-pass decoder (unmeasured), 0 = a wavefront per stream")
     p.add_argument("--lz4frame-variant", type=int, default=-1, help="LZ4 frame reader: 0 = a wavefront per item (default), 1 = the frames' blocks as one batch through the two-pass block decoder (unmeasured)")
     p.add_argument("--hadoop-variant", type=int, default=-1, help="Hadoop block-stream reader: 1 = chunks through the ring decoders (default), 2 = through the two-pass decoders (unmeasured), 0 = a wavefront per stream")
     p.add_argument("--zstd-variant", type=int, default=-1, help="zstd decoder: 1 = five-stage pipeline (default), 0 = one-kernel decoder")
@@ -208,6 +209,8 @@ def main():
         codec.native.set_option("decompress.exec_variant", args.exec_variant)
     if args.hadoop_variant >= 0:
         codec.native.set_option("hadoop.decompress.variant", args.hadoop_variant)
+    if args.snappyframed_variant >= 0:
+        codec.native.set_option("snappyframed.decompress.variant", args.snappyframed_variant)
     if args.lz4frame_variant >= 0:
         codec.native.set_option("lz4frame.decompress.variant", args.lz4frame_variant)
     if args.section == "lz4frame":

@@ -3,6 +3,8 @@
 status / offset, chunks beyond 64 KiB, and the wavefront CRC-32C against the oracle at every length class."""
 import struct
 
+import os
+
 import numpy as np
 import pytest
 
@@ -14,12 +16,17 @@ OP_DECOMPRESS, OP_COMPRESS = 8, 9
 HEADER = bytes([0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59])
 
 
-@pytest.fixture(scope="module", params=[1, 0], ids=["block-lists", "wave-per-stream"])
+# reader variant 2 (the chunks through the two-pass Snappy decoder) was written without a GPU at hand and is not the default: it joins these
+# tests when ACHIP_TEST_EXPERIMENTAL is set (tools/hostemu/check_snappyframed.py runs it on the CPU)
+_VARIANTS = [1, 0] + ([2] if os.environ.get("ACHIP_TEST_EXPERIMENTAL") else [])
+
+
+@pytest.fixture(scope="module", params=_VARIANTS, ids=["block-lists", "wave-per-stream", "block-lists-two-pass"][:len(_VARIANTS)])
 def gb(request):
     """reader / writer under test: chunk list + batched block decoders, block list + two-tier block encoder + compaction (defaults);
     one wavefront per stream (their fallback)"""
     from tests.gpu_harness import GpuBatch
-    return GpuBatch(0, options={"snappyframed.decompress.variant": request.param, "snappyframed.compress.variant": request.param})
+    return GpuBatch(0, options={"snappyframed.decompress.variant": request.param, "snappyframed.compress.variant": min(request.param, 1)})
 
 
 @pytest.fixture(scope="module")

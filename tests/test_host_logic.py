@@ -73,6 +73,9 @@ def test_lane_private_decoder_kernels_on_the_cpu():
     # and content checksum): the Java writer's frames and hand-built ones of 64 / 256 KiB blocks against the plaintext
     out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_lz4frame.py")], check=True, capture_output=True, text=True, cwd=ROOT).stdout
     assert out.strip().endswith(" 0 mismatches"), out
+    # the x-snappy-framed reader's variant 2 (walk, chunks through the two-pass Snappy decoder, CRC-32C verification, fold)
+    out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_snappyframed.py")], check=True, capture_output=True, text=True, cwd=ROOT).stdout
+    assert out.strip().endswith(" 0 mismatches"), out
 
 
 def test_zstd_pipeline_kernels_on_the_cpu():

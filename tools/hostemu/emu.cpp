@@ -11,6 +11,7 @@ extern "C" { long long achip_emu_counters[16]; }  // development counters of ker
 #include "../../aircompressor_amd/csrc/snappy_decompress_v5.hip"
 #include "../../aircompressor_amd/csrc/hadoop_streams.hip"
 #include "../../aircompressor_amd/csrc/lz4_frame.hip"
+#include "../../aircompressor_amd/csrc/snappy_frame.hip"
 #include <vector>
 // the decoders the emulator does not build (DPP / cross-lane copy steps) and the probes that would pick them: the probe statistics stay
 // zero, which picks the ring decoders
@@ -89,4 +90,15 @@ extern "C" int emu_lz4frame(int variant, const uint8_t* srcBase, const int64_t* 
     scratch.assign((size_t)achip::lz4frame_decompress_scratch_bytes(n, variant), 0xCD);
     const achip::AuxScratch aux{[](void*, int64_t bytes) -> void* { auxBuffer.assign((size_t)bytes, 0xCD); return auxBuffer.data(); }, nullptr};
     return achip::launch_lz4frame_decompress(a, nullptr, scratch.data(), variant, &aux);
+}
+
+// x-snappy-framed streams (snappy_frame.hip), reader variant 2: walk, the chunks through the two-pass Snappy decoder, CRC verification, fold
+extern "C" int emu_snappyframed(int variant, const uint8_t* srcBase, const int64_t* srcOff, const int32_t* srcLen, uint8_t* dstBase, const int64_t* dstOff, const int32_t* dstCap,
+                                int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n)
+{
+    achip::BatchArgs a{srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, n, 16};
+    static std::vector<uint8_t> scratch, auxBuffer;
+    scratch.assign((size_t)achip::snappyframed_decompress_scratch_bytes(n), 0xCD);
+    const achip::AuxScratch aux{[](void*, int64_t bytes) -> void* { auxBuffer.assign((size_t)bytes, 0xCD); return auxBuffer.data(); }, nullptr};
+    return achip::launch_snappyframed_decompress(a, nullptr, scratch.data(), variant, &aux);
 }
