@@ -654,16 +654,18 @@ __device__ __forceinline__ bool huf_decode_stream_win(QuadBits& b, const uint16_
 
 // ---- K2: literals (MB: the slots are the blocks of multi-block frames; a block with treeless literals uses the table of the slot its
 // link names) ----
-template <bool MB>
+// ITEMS: items per wavefront (16: every quad has one; 8 -- an experiment for the next round -- leaves half the lanes idle and halves the LDS,
+// so that more wavefronts share a CU: the stage waits for memory more than it computes)
+template <bool MB, int ITEMS = zp::ITEMS_PER_WAVE>
 __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp::Pipe p)
 {
     using namespace zp;
-    __shared__ __attribute__((aligned(16))) uint16_t tables[ITEMS_PER_WAVE * HUF_SLOT];  // 64 KiB
+    __shared__ __attribute__((aligned(16))) uint16_t tables[ITEMS * HUF_SLOT];  // 64 KiB at 16 items
     const int lane = threadIdx.x;
     const int q = lane >> 2;  // item of this lane
     const int s = lane & 3;   // stream of this lane
-    const int32_t slot = blockIdx.x * ITEMS_PER_WAVE + q;
-    bool valid = slot < p.count;
+    const int32_t slot = blockIdx.x * ITEMS + q;
+    bool valid = q < ITEMS && slot < p.count;
     int32_t tableSlot = slot;
     if (MB && valid) {
         const MbBlock b = p.mb[slot];
@@ -679,8 +681,8 @@ __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp:
     if (MB && live && d.litMode == 2) {
         d.hufLog = tableSlot >= 0 ? p.desc[tableSlot].hufLog : 0;  // (its own, or that of the block that defined the table)
     }
-    // stage the 16 tables (each copy is done by the whole wavefront)
-    for (int k = 0; k < ITEMS_PER_WAVE; k++) {
+    // stage the tables (each copy is done by the whole wavefront)
+    for (int k = 0; k < ITEMS; k++) {
         const int32_t useHuf = __shfl((live && d.litMode == 2) ? d.hufLog : 0, k * 4);
         const int32_t from = __shfl(tableSlot, k * 4);
         if (useHuf > 0) {
@@ -738,12 +740,12 @@ __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp:
 // block (repeat mode), and the repeat-offset history at the block's start is what the block before leaves behind, which is not known
 // here: the history starts as three SENTINELS (achip_seqexec2.h REP_SENTINEL), records may hold sentinels, and the history behind the
 // block goes to MbBlock::repOut for the execute stage, which walks the blocks in order and knows) ----
-template <bool MB>
+template <bool MB, int ITEMS = zp::SEQ_ITEMS_PER_WAVE>
 __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp::Pipe p)
 {
     using namespace zp;
-    __shared__ __attribute__((aligned(16))) uint16_t tables[SEQ_ITEMS_PER_WAVE * FSE_SLOT];       // 46 KiB: three wavefronts per CU
-    __shared__ __attribute__((aligned(16))) uint64_t staged[SEQ_ITEMS_PER_WAVE * SEQ_STAGE];      // 3.75 KiB: records on their way to HBM
+    __shared__ __attribute__((aligned(16))) uint16_t tables[ITEMS * FSE_SLOT];       // 46 KiB at 16 items: three wavefronts per CU
+    __shared__ __attribute__((aligned(16))) uint64_t staged[ITEMS * SEQ_STAGE];      // 3.75 KiB: records on their way to HBM
     __shared__ uint32_t codeTab[128];  // literal-length codes at 0.., match-length codes at 64..: baseline | extra bits << 24
     const int lane = threadIdx.x;
     const int q = lane >> 2;
@@ -755,8 +757,8 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
         achip_zstd_ml_code(lane < 53 ? lane : 0, &base, &bits);
         codeTab[64 + lane] = (uint32_t)base | ((uint32_t)bits << 24);
     }
-    const int32_t slot = blockIdx.x * SEQ_ITEMS_PER_WAVE + q;
-    bool valid = q < SEQ_ITEMS_PER_WAVE && slot < p.count;
+    const int32_t slot = blockIdx.x * ITEMS + q;
+    bool valid = q < ITEMS && slot < p.count;
     int32_t from0 = slot, from1 = slot, from2 = slot;  // the slots the literal-length, offset and match-length tables come from
     if (MB && valid) {
         const MbBlock b = p.mb[slot];
@@ -777,7 +779,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
         d.log[1] = p.desc[from1].log[1];
         d.log[2] = p.desc[from2].log[2];
     }
-    for (int k = 0; k < SEQ_ITEMS_PER_WAVE; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         if (__shfl(live ? 1 : 0, k * 4) != 0) {
             if (MB) {
                 const int32_t f0 = __shfl(from0, k * 4), f1 = __shfl(from1, k * 4), f2 = __shfl(from2, k * 4);
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
                 }
             }
             else {
-                const uint16_t* g = p.fse + (size_t)(blockIdx.x * SEQ_ITEMS_PER_WAVE + k) * FSE_SLOT;
+                const uint16_t* g = p.fse + (size_t)(blockIdx.x * ITEMS + k) * FSE_SLOT;
                 for (int32_t i = lane * 8; i < FSE_SLOT; i += 64 * 8) {
                     *(u32x4*)(tables + k * FSE_SLOT + i) = *(const u32x4*)(g + i);
                 }
@@ -1053,6 +1055,7 @@ __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp:
 // item's capacity over its sequence count is what both kernels can see (an upper bound of the bytes per sequence: a caller that hands over far
 // more capacity than the frame needs gets the ring version).
 int g_zstd_pipe_exec = 2;  // context option zstd.decompress.exec: 2 = per item (default), 1 = this kernel, 0 = the ring version above
+int g_zstd_pipe_lit_items = 16, g_zstd_pipe_seq_items = 16;  // options zstd.decompress.lit_items / seq_items: 16 (default) or 8 items per wavefront in K2 / K3 (unmeasured)
 
 __global__ __launch_bounds__(64) void zstd_pipe_execute2_kernel(BatchArgs a, zp::Pipe p, int32_t mode)
 {
@@ -1771,8 +1774,18 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
         }
         const unsigned w16 = (unsigned)((p.count + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE);
         hipLaunchKernelGGL(zstd_pipe_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
-        hipLaunchKernelGGL(zstd_pipe_literals_kernel<false>, dim3(w16), dim3(64), 0, stream, a, p);
-        hipLaunchKernelGGL(zstd_pipe_sequences_kernel<false>, dim3((unsigned)((p.count + zp::SEQ_ITEMS_PER_WAVE - 1) / zp::SEQ_ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
+        if (g_zstd_pipe_lit_items == 8) {
+            hipLaunchKernelGGL((zstd_pipe_literals_kernel<false, 8>), dim3((unsigned)((p.count + 7) / 8)), dim3(64), 0, stream, a, p);
+        }
+        else {
+            hipLaunchKernelGGL(zstd_pipe_literals_kernel<false>, dim3(w16), dim3(64), 0, stream, a, p);
+        }
+        if (g_zstd_pipe_seq_items == 8) {
+            hipLaunchKernelGGL((zstd_pipe_sequences_kernel<false, 8>), dim3((unsigned)((p.count + 7) / 8)), dim3(64), 0, stream, a, p);
+        }
+        else {
+            hipLaunchKernelGGL(zstd_pipe_sequences_kernel<false>, dim3((unsigned)((p.count + zp::SEQ_ITEMS_PER_WAVE - 1) / zp::SEQ_ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
+        }
         constexpr int GS = 4, IN_RING = 128, OUT_RING = 256;
         if (g_zstd_pipe_exec != 0) {
             hipLaunchKernelGGL(zstd_pipe_execute2_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, (int32_t)g_zstd_pipe_exec);

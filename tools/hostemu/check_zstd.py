@@ -215,8 +215,9 @@ def main():
         if name.startswith("libzstd") and (not HAVE_LIBZSTD or (quick and name != "libzstd-3")):
             continue
         frames = [bytes(enc(p)) for p in plains]
-        for pad in (0, 37):
-            outs, status, fb = run(frames, [len(p) + pad for p in plains])
+        # (second run: the 8-items-per-wavefront instantiations of the literal and sequence stages -- mode bits 2 and 3)
+        for pad, mode in ((0, 1), (37, 1 | 4 | 8)):
+            outs, status, fb = run(frames, [len(p) + pad for p in plains], exec_mode=mode)
             for i, p in enumerate(plains):
                 total += 1
                 if i in fb:
