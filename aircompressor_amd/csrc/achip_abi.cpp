@@ -38,6 +38,7 @@ hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int va
 int64_t snappy_compress_scratch_bytes();
 hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant, int32_t tileMax, const ZstdMbProvider* mbp);
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
+hipError_t launch_zstd_stream_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int chunked);
 int64_t zstd_decompress_scratch_bytes(int32_t nBlocks, int32_t tileMax);
 int64_t zstd_compress_scratch_bytes(int32_t nBlocks);
 hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant, const AuxScratch* aux);
@@ -80,6 +81,7 @@ struct achip_ctx {
     int snappyFramedCompressVariant = 1;  // framed writer: 1 = block list + two-tier block encoder + compaction (default), 0 = one wavefront per stream
     int snappyFramedVariant = 1;  // framed reader: 1 = chunk list + batched block decoders (default), 0 = one wavefront per stream
     int zstdTile = 65536;    // items per pass of the Zstd decode pipeline (halved automatically when its scratch cannot be allocated)
+    int zstdStreamChunked = 0;     // 1: the stream writer also takes streams from 4 MiB on (unverified: zstd_compress.hip zstd_stream_chunked); 0: it refuses them
     int zstdStreamBlocks = 65536;  // 128 KiB blocks a pass of the pipeline's multi-block stages has room for (0: multi-block frames take the one-kernel decoder); ~20 GB of scratch, allocated when a batch first holds such frames (halved as often as it takes when the device cannot give that)
     void* zstdMbScratch = nullptr;
     int64_t zstdMbScratchBytes = 0;
@@ -254,7 +256,6 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
     achip::BatchArgs a = args;
     a.ringPad = ctx->ringPad;
     if (op == ACHIP_OP_ZSTD_COMPRESS) a.ringPad = ctx->zstdcVariant == 100 ? 999 : (ctx->zstdcVariant == 1 ? 1 : 0);  // encoder variant rides in the spare field
-    if (op == ACHIP_OP_ZSTDSTREAM_COMPRESS) a.ringPad = 2;  // (the encoder's stream mode: zstd_compress.hip)
     if (a.nBlocks < 0) {
         return bad_argument("nBlocks < 0");
     }
@@ -391,7 +392,12 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             e = achip::launch_lz4frame_compress(a, ctx->stream, ctx->scratch);
             break;
         }
-        case ACHIP_OP_ZSTDSTREAM_COMPRESS:
+        case ACHIP_OP_ZSTDSTREAM_COMPRESS: {
+            int32_t r = ensure_scratch(ctx, achip::zstd_compress_scratch_bytes(a.nBlocks));
+            if (r < 0) return r;
+            e = achip::launch_zstd_stream_compress(a, ctx->stream, ctx->scratch, ctx->zstdStreamChunked);
+            break;
+        }
         case ACHIP_OP_ZSTD_COMPRESS: {
             int32_t r = ensure_scratch(ctx, achip::zstd_compress_scratch_bytes(a.nBlocks));
             if (r < 0) return r;
@@ -759,6 +765,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         (k == "zstd.decompress.lit_items" ? achip::g_zstd_pipe_lit_items : achip::g_zstd_pipe_seq_items) = (int)value;
     }
     else if (k == "zstd.decompress.variant") ctx->zstddVariant = (int)value;
+    else if (k == "zstd.stream.chunked") ctx->zstdStreamChunked = value != 0 ? 1 : 0;
     else if (k == "zstd.decompress.stream_blocks") {
         if (value != 0 && (value < 16 || value > 131072)) return bad_argument("zstd.decompress.stream_blocks must be 0 or 16..131072");
         ctx->zstdStreamBlocks = (int)value;

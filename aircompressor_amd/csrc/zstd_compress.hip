@@ -19,1705 +19,9 @@
 // been computed with a wave reduction), the XXH64 stripes.
 // Hash tables (up to 2^17 + 2^16 ints) and the sequence store live in a per-wave slab in HBM (L2-resident while the
 // frame is being encoded); all entropy tables live in LDS.
-#include "achip_device.h"
+#include "zstd_compress_body.h"
 
 namespace achip {
-
-namespace zc {
-constexpr int MAX_BLOCK_SIZE = 128 * 1024;
-constexpr int MAX_SEQUENCES = MAX_BLOCK_SIZE / 4;
-constexpr int HASH_TABLE_INTS = 1 << 17;
-constexpr int CHAIN_TABLE_INTS = 1 << 16;
-constexpr int64_t SLAB_BYTES = (int64_t)4 * HASH_TABLE_INTS + 4 * CHAIN_TABLE_INTS + (MAX_BLOCK_SIZE + 64) + 3 * 4 * MAX_SEQUENCES + 3 * MAX_SEQUENCES + 64;
-
-__constant__ uint8_t LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-__constant__ uint8_t ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                                    1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-__constant__ uint8_t LL_CODE[64] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 16, 17, 17, 18, 18, 19, 19, 20, 20, 20, 20, 21, 21, 21, 21,
-                                    22, 22, 22, 22, 22, 22, 22, 22, 23, 23, 23, 23, 23, 23, 23, 23, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24};
-__constant__ uint8_t ML_CODE[128] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31,
-                                     32, 32, 33, 33, 34, 34, 35, 35, 36, 36, 36, 36, 37, 37, 37, 37, 38, 38, 38, 38, 38, 38, 38, 38, 39, 39, 39, 39, 39, 39, 39, 39,
-                                     40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41,
-                                     42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42};
-__constant__ int16_t LL_DEFAULT_NORM[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
-__constant__ int16_t ML_DEFAULT_NORM[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
-                                            1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
-__constant__ int16_t OF_DEFAULT_NORM[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
-__constant__ int32_t REST_TO_BEAT[8] = {0, 473195, 504333, 520860, 550000, 700000, 750000, 830000};
-// level-3 rows of CompressionParameters.DEFAULT_COMPRESSION_PARAMETERS: {windowLog, chainLog, hashLog, searchLength}
-__constant__ int32_t LEVEL3[4][4] = {{20, 16, 17, 5}, {18, 16, 16, 4}, {17, 15, 16, 5}, {14, 14, 14, 4}};
-
-struct FseCTable {  // FseCompressionTable.java:22-27
-    int16_t nextState[512];
-    int32_t deltaNumberOfBits[56];
-    int32_t deltaFindState[56];
-    int32_t log2Size;
-};
-struct HufCTable {  // HuffmanCompressionTable.java:29-33
-    int16_t values[256];
-    uint8_t numberOfBits[256];
-    int32_t maxSymbol;
-    int32_t maxNumberOfBits;
-};
-struct Shared {
-    FseCTable ll, of, ml, wt;  // SequenceEncodingContext + HuffmanTableWriterWorkspace.fseTable
-    FseCTable dflt[3];         // 0 = literal lengths, 1 = offsets, 2 = match lengths (SequenceEncoder.java:66-68)
-    HufCTable huf[2];
-    int32_t counts[256];
-    int16_t norm[256];
-    int32_t cumulative[258];
-    uint8_t spread[512];
-    // NodeTable (2 * 256 - 1 nodes)
-    int32_t nodeCount[512];
-    int16_t nodeParent[512];
-    int16_t nodeSymbol[512];
-    uint8_t nodeBits[512];
-    int16_t entriesPerRank[16];
-    int16_t valuesPerRank[16];
-    int32_t rankLast[16];
-    uint8_t weights[256];
-};
-
-struct Ctx {
-    const uint8_t* __restrict__ in;
-    int32_t inLen;
-    uint8_t* out;
-    int32_t outCap;
-    int lane;
-    int dbgStage;
-    int batchProbe;
-    int streamMode;      // 1: the item is what one write() + close() hand to a ZstdOutputStream (parameters for an unknown size)
-    int32_t failStatus;  // 0 = ok
-    const int32_t* pre;  // match-finder results of this item (two-kernel path) or null
-    // per-wave slab
-    int32_t* hashTable;
-    int32_t* chainTable;
-    uint8_t* litBuf;
-    int32_t* seqOffset;
-    int32_t* seqLitLen;
-    int32_t* seqMatchLen;
-    uint8_t* codeLL;
-    uint8_t* codeML;
-    uint8_t* codeOF;
-    // parameters
-    int32_t windowLog, windowSize, blockSize, chainLog, hashLog, searchLength;
-    // RepeatedOffsets
-    int32_t offset0, offset1, tempOffset0, tempOffset1;
-    int32_t windowBaseOffset;
-    // SequenceStore
-    int32_t literalsLength, sequenceCount, longLengthField, longLengthPosition;
-    // HuffmanCompressionContext (indices into Shared::huf)
-    int32_t previousTable, temporaryTable, previousCandidate, temporaryCandidate;
-};
-
-#define ZC_FAIL(c)                                                                          \
-    {                                                                                       \
-        (c).failStatus = mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_ZSTD_MAX_OUTPUT);  \
-        return -1;                                                                          \
-    }
-#define ZC_CHECK(c, cond) \
-    if (!(cond)) ZC_FAIL(c)
-#define ZC_PROPAGATE(x) \
-    if ((x) < 0) return -1
-
-__device__ __forceinline__ int32_t highest_bit(uint32_t v) { return 31 - __builtin_clz(v); }
-__device__ __forceinline__ int32_t min_table_log(int32_t inputSize, int32_t maxSymbolValue)  // Util.minTableLog
-{
-    const int32_t a = highest_bit((uint32_t)(inputSize - 1)) + 1;
-    const int32_t b = highest_bit((uint32_t)maxSymbolValue) + 2;
-    return a < b ? a : b;
-}
-__device__ __forceinline__ void st_le(uint8_t* p, uint64_t v, int n)
-{
-    for (int i = 0; i < n; i++) {
-        p[i] = (uint8_t)(v >> (8 * i));
-    }
-}
-
-// ---- BitOutputStream.java: registers + byte-exact stores -------------------------------------------------
-// The Java flush() stores 8 bytes and advances by bitCount/8; only the advanced bytes are final (the rest is
-// overwritten by the next flush / the next section), so storing exactly those bytes yields the same stream.
-struct BitOut {
-    uint8_t* base;
-    int32_t start, limit, current;  // limit = start + size - 8 (:47)
-    uint64_t container;
-    int32_t bitCount;
-};
-__device__ __forceinline__ void bo_init(BitOut& s, uint8_t* base, int32_t start, int32_t size)
-{
-    s.base = base;
-    s.start = start;
-    s.limit = start + size - 8;
-    s.current = start;
-    s.container = 0;
-    s.bitCount = 0;
-}
-__device__ __forceinline__ void bo_add(BitOut& s, int32_t value, int32_t bits)  // addBits :52-56
-{
-    const uint64_t mask = (1ull << bits) - 1ull;  // bits <= 31
-    s.container |= ((uint64_t)(int64_t)value & mask) << (s.bitCount & 63);
-    s.bitCount += bits;
-}
-__device__ __forceinline__ void bo_add_fast(BitOut& s, int32_t value, int32_t bits)  // addBitsFast :61-65
-{
-    s.container |= (uint64_t)(int64_t)value << (s.bitCount & 63);
-    s.bitCount += bits;
-}
-__device__ __forceinline__ void bo_flush(BitOut& s)  // :67-80
-{
-    const int32_t bytes = (int32_t)((uint32_t)s.bitCount >> 3);
-    int32_t n = bytes;
-    if (s.current + n > s.limit + 8) {
-        n = s.limit + 8 - s.current;  // never store past the stream's buffer
-    }
-    if (n == 8) {
-        st8(s.base + s.current, s.container);
-    }
-    else if (n > 0) {
-        st_le(s.base + s.current, s.container, n);
-    }
-    s.current += bytes;
-    if (s.current > s.limit) {
-        s.current = s.limit;
-    }
-    s.bitCount &= 7;
-    s.container >>= ((bytes * 8) & 63);
-}
-__device__ __forceinline__ int32_t bo_close(BitOut& s)  // :82-92
-{
-    bo_add_fast(s, 1, 1);
-    bo_flush(s);
-    if (s.current >= s.limit) {
-        return 0;
-    }
-    if (s.bitCount > 0) {
-        s.base[s.current] = (uint8_t)s.container;  // the partial last byte
-    }
-    return (s.current - s.start) + (s.bitCount > 0 ? 1 : 0);
-}
-
-// ---- FseCompressionTable ----------------------------------------------------------------------------------
-__device__ void fse_init_rle(FseCTable& t, int32_t symbol)  // :46-55
-{
-    t.log2Size = 0;
-    t.nextState[0] = 0;
-    t.nextState[1] = 0;
-    t.deltaFindState[symbol] = 0;
-    t.deltaNumberOfBits[symbol] = 0;
-}
-
-// initialize :57-117 ; norm read through a pointer so the predefined distributions can come from constant memory
-__device__ void fse_initialize(Shared& sh, FseCTable& t, const int16_t* norm, int32_t maxSymbol, int32_t tableLog)
-{
-    const int32_t tableSize = 1 << tableLog;
-    int32_t highThreshold = tableSize - 1;
-    t.log2Size = tableLog;
-    sh.cumulative[0] = 0;
-    for (int32_t i = 1; i <= maxSymbol + 1; i++) {
-        if (norm[i - 1] == -1) {
-            sh.cumulative[i] = sh.cumulative[i - 1] + 1;
-            sh.spread[highThreshold--] = (uint8_t)(i - 1);
-        }
-        else {
-            sh.cumulative[i] = sh.cumulative[i - 1] + norm[i - 1];
-        }
-    }
-    sh.cumulative[maxSymbol + 1] = tableSize + 1;
-    const int32_t mask = tableSize - 1;
-    const int32_t step = (tableSize >> 1) + (tableSize >> 3) + 3;
-    int32_t position = 0;
-    for (int32_t symbol = 0; symbol <= maxSymbol; symbol++) {
-        const int32_t n = norm[symbol];
-        for (int32_t i = 0; i < n; i++) {
-            sh.spread[position] = (uint8_t)symbol;
-            do {
-                position = (position + step) & mask;
-            } while (position > highThreshold);
-        }
-    }
-    for (int32_t i = 0; i < tableSize; i++) {
-        const int32_t symbol = sh.spread[i];
-        const int32_t slot = sh.cumulative[symbol];
-        sh.cumulative[symbol] = slot + 1;
-        t.nextState[slot] = (int16_t)(tableSize + i);
-    }
-    int32_t total = 0;
-    for (int32_t symbol = 0; symbol <= maxSymbol; symbol++) {
-        const int32_t n = norm[symbol];
-        if (n == 0) {
-            t.deltaNumberOfBits[symbol] = ((tableLog + 1) << 16) - tableSize;
-        }
-        else if (n == -1 || n == 1) {
-            t.deltaNumberOfBits[symbol] = (tableLog << 16) - tableSize;
-            t.deltaFindState[symbol] = total - 1;
-            total++;
-        }
-        else {
-            const int32_t maxBitsOut = tableLog - highest_bit((uint32_t)(n - 1));
-            const int32_t minStatePlus = n << maxBitsOut;
-            t.deltaNumberOfBits[symbol] = (maxBitsOut << 16) - minStatePlus;
-            t.deltaFindState[symbol] = total - n;
-            total += n;
-        }
-    }
-}
-__device__ __forceinline__ int32_t fse_begin(const FseCTable& t, int32_t symbol)  // :119-124
-{
-    const int32_t d = t.deltaNumberOfBits[symbol];
-    const int32_t outputBits = (int32_t)((uint32_t)(d + (1 << 15)) >> 16);
-    const int32_t base = (int32_t)((uint32_t)((outputBits << 16) - d) >> (outputBits & 31));
-    return t.nextState[base + t.deltaFindState[symbol]];
-}
-__device__ __forceinline__ int32_t fse_encode(const FseCTable& t, BitOut& s, int32_t state, int32_t symbol)  // :126-131
-{
-    const int32_t outputBits = (int32_t)((uint32_t)(state + t.deltaNumberOfBits[symbol]) >> 16);
-    bo_add(s, state, outputBits);
-    return t.nextState[(int32_t)((uint32_t)state >> (outputBits & 31)) + t.deltaFindState[symbol]];
-}
-__device__ __forceinline__ void fse_finish(const FseCTable& t, BitOut& s, int32_t state)  // :133-137
-{
-    bo_add(s, state, t.log2Size);
-    bo_flush(s);
-}
-
-// ---- FiniteStateEntropy (compression side) ------------------------------------------------------------------
-__device__ int32_t fse_optimal_table_log(int32_t maxTableLog, int32_t inputSize, int32_t maxSymbol)  // :236-255
-{
-    int32_t result = maxTableLog;
-    const int32_t a = highest_bit((uint32_t)(inputSize - 1)) - 2;
-    result = a < result ? a : result;
-    const int32_t b = min_table_log(inputSize, maxSymbol);
-    result = b > result ? b : result;
-    result = result < 5 ? 5 : result;
-    result = result > 12 ? 12 : result;
-    return result;
-}
-
-__device__ void fse_normalize_counts2(int16_t* norm, int32_t tableLog, const int32_t* counts, int32_t total, int32_t maxSymbol)  // :318-405
-{
-    constexpr int16_t UNASSIGNED = -2;
-    int32_t distributed = 0;
-    const int32_t lowThreshold = (int32_t)((uint32_t)total >> tableLog);
-    int32_t lowOne = (int32_t)((uint32_t)(total * 3) >> (tableLog + 1));
-    for (int32_t i = 0; i <= maxSymbol; i++) {
-        const int32_t cnt = counts[i];
-        if (cnt == 0) {
-            norm[i] = 0;
-        }
-        else if (cnt <= lowThreshold) {
-            norm[i] = -1;
-            distributed++;
-            total -= cnt;
-        }
-        else if (cnt <= lowOne) {
-            norm[i] = 1;
-            distributed++;
-            total -= cnt;
-        }
-        else {
-            norm[i] = UNASSIGNED;
-        }
-    }
-    const int32_t normalizationFactor = 1 << tableLog;
-    int32_t toDistribute = normalizationFactor - distributed;
-    if ((total / toDistribute) > lowOne) {
-        lowOne = (total * 3) / (toDistribute * 2);
-        for (int32_t i = 0; i <= maxSymbol; i++) {
-            if (norm[i] == UNASSIGNED && counts[i] <= lowOne) {
-                norm[i] = 1;
-                distributed++;
-                total -= counts[i];
-            }
-        }
-        toDistribute = normalizationFactor - distributed;
-    }
-    if (distributed == maxSymbol + 1) {
-        int32_t maxValue = 0, maxCount = 0;
-        for (int32_t i = 0; i <= maxSymbol; i++) {
-            if (counts[i] > maxCount) {
-                maxValue = i;
-                maxCount = counts[i];
-            }
-        }
-        norm[maxValue] = (int16_t)(norm[maxValue] + (int16_t)toDistribute);
-        return;
-    }
-    if (total == 0) {
-        for (int32_t i = 0; toDistribute > 0; i = (i + 1) % (maxSymbol + 1)) {
-            if (norm[i] > 0) {
-                toDistribute--;
-                norm[i] = (int16_t)(norm[i] + 1);
-            }
-        }
-        return;
-    }
-    const int64_t vStepLog = 62 - tableLog;
-    const int64_t mid = (1LL << (vStepLog - 1)) - 1;
-    const int64_t rStep = (((1LL << vStepLog) * toDistribute) + mid) / total;
-    int64_t tmpTotal = mid;
-    for (int32_t i = 0; i <= maxSymbol; i++) {
-        if (norm[i] == UNASSIGNED) {
-            const int64_t end = tmpTotal + ((int64_t)counts[i] * rStep);
-            const int32_t sStart = (int32_t)((uint64_t)tmpTotal >> vStepLog);
-            const int32_t sEnd = (int32_t)((uint64_t)end >> vStepLog);
-            norm[i] = (int16_t)(sEnd - sStart);
-            tmpTotal = end;
-        }
-    }
-}
-
-__device__ void fse_normalize_counts(int16_t* norm, int32_t tableLog, const int32_t* counts, int32_t total, int32_t maxSymbol)  // :257-316
-{
-    const int64_t scale = 62 - tableLog;
-    const int64_t step = (1LL << 62) / total;
-    const int64_t vstep = 1LL << (scale - 20);
-    int32_t stillToDistribute = 1 << tableLog;
-    int32_t largest = 0;
-    int16_t largestProbability = 0;
-    const int32_t lowThreshold = (int32_t)((uint32_t)total >> tableLog);
-    for (int32_t symbol = 0; symbol <= maxSymbol; symbol++) {
-        const int32_t cnt = counts[symbol];
-        if (cnt == 0) {
-            norm[symbol] = 0;
-            continue;
-        }
-        if (cnt <= lowThreshold) {
-            norm[symbol] = -1;
-            stillToDistribute--;
-        }
-        else {
-            int16_t probability = (int16_t)((uint64_t)((int64_t)cnt * step) >> scale);
-            if (probability < 8) {
-                const int64_t restToBeat = vstep * REST_TO_BEAT[probability];
-                const int64_t delta = (int64_t)cnt * step - (((int64_t)probability) << scale);
-                if (delta > restToBeat) {
-                    probability++;
-                }
-            }
-            if (probability > largestProbability) {
-                largestProbability = probability;
-                largest = symbol;
-            }
-            norm[symbol] = probability;
-            stillToDistribute -= probability;
-        }
-    }
-    if (-stillToDistribute >= (int32_t)((uint32_t)(int32_t)norm[largest] >> 1)) {
-        fse_normalize_counts2(norm, tableLog, counts, total, maxSymbol);
-    }
-    else {
-        norm[largest] = (int16_t)(norm[largest] + (int16_t)stillToDistribute);
-    }
-}
-
-// writeNormalizedCounts :407-521 ; returns bytes written or -1
-__device__ int32_t fse_write_normalized_counts(Ctx& c, uint8_t* base, int32_t outputAddress, int32_t outputSize, const int16_t* norm, int32_t maxSymbol, int32_t tableLog)
-{
-    int32_t output = outputAddress;
-    const int64_t outputLimit = (int64_t)outputAddress + outputSize;
-    const int32_t tableSize = 1 << tableLog;
-    int32_t bitCount = 0;
-    int32_t bitStream = tableLog - 5;
-    bitCount += 4;
-    int32_t remaining = tableSize + 1;
-    int32_t threshold = tableSize;
-    int32_t tableBitCount = tableLog + 1;
-    int32_t symbol = 0;
-    bool previousIs0 = false;
-    while (remaining > 1) {
-        if (previousIs0) {
-            int32_t start = symbol;
-            while (norm[symbol] == 0) {
-                symbol++;
-            }
-            while (symbol >= start + 24) {
-                start += 24;
-                bitStream |= (int32_t)(0xFFFFu << (bitCount & 31));
-                ZC_CHECK(c, (int64_t)output + 2 <= outputLimit);
-                st2(base + output, (uint32_t)bitStream);
-                output += 2;
-                bitStream = (int32_t)((uint32_t)bitStream >> 16);
-            }
-            while (symbol >= start + 3) {
-                start += 3;
-                bitStream |= (int32_t)(3u << (bitCount & 31));
-                bitCount += 2;
-            }
-            bitStream |= (int32_t)((uint32_t)(symbol - start) << (bitCount & 31));
-            bitCount += 2;
-            if (bitCount > 16) {
-                ZC_CHECK(c, (int64_t)output + 2 <= outputLimit);
-                st2(base + output, (uint32_t)bitStream);
-                output += 2;
-                bitStream = (int32_t)((uint32_t)bitStream >> 16);
-                bitCount -= 16;
-            }
-        }
-        int32_t count = norm[symbol++];
-        const int32_t max = (2 * threshold - 1) - remaining;
-        remaining -= count < 0 ? -count : count;
-        count++;
-        if (count >= threshold) {
-            count += max;
-        }
-        bitStream |= (int32_t)((uint32_t)count << (bitCount & 31));
-        bitCount += tableBitCount;
-        bitCount -= (count < max ? 1 : 0);
-        previousIs0 = (count == 1);
-        while (remaining < threshold) {
-            tableBitCount--;
-            threshold >>= 1;
-        }
-        if (bitCount > 16) {
-            ZC_CHECK(c, (int64_t)output + 2 <= outputLimit);
-            st2(base + output, (uint32_t)bitStream);
-            output += 2;
-            bitStream = (int32_t)((uint32_t)bitStream >> 16);
-            bitCount -= 16;
-        }
-    }
-    ZC_CHECK(c, (int64_t)output + 2 <= outputLimit);
-    // the Java code stores 2 bytes and advances by (bitCount + 7) / 8 of them
-    const int32_t adv = (bitCount + 7) / 8;
-    st_le(base + output, (uint32_t)bitStream & 0xFFFFu, adv < 2 ? adv : 2);
-    output += adv;
-    ZC_CHECK(c, symbol <= maxSymbol + 1);
-    return output - outputAddress;
-}
-
-// FiniteStateEntropy.compress :158-234 over the Huffman weights (<= 255 symbols, LDS)
-__device__ int32_t fse_compress_weights(Ctx& c, uint8_t* base, int32_t outputAddress, int32_t outputSize, const uint8_t* in, int32_t inputSize, const FseCTable& table)
-{
-    ZC_CHECK(c, outputSize >= 8);
-    int32_t input = inputSize;
-    if (inputSize <= 2) {
-        return 0;
-    }
-    BitOut s;
-    bo_init(s, base, outputAddress, outputSize);
-    int32_t state1, state2;
-    if ((inputSize & 1) != 0) {
-        input--;
-        state1 = fse_begin(table, in[input]);
-        input--;
-        state2 = fse_begin(table, in[input]);
-        input--;
-        state1 = fse_encode(table, s, state1, in[input]);
-        bo_flush(s);
-    }
-    else {
-        input--;
-        state2 = fse_begin(table, in[input]);
-        input--;
-        state1 = fse_begin(table, in[input]);
-    }
-    inputSize -= 2;
-    if ((inputSize & 2) != 0) {
-        input--;
-        state2 = fse_encode(table, s, state2, in[input]);
-        input--;
-        state1 = fse_encode(table, s, state1, in[input]);
-        bo_flush(s);
-    }
-    while (input > 0) {
-        input--;
-        state2 = fse_encode(table, s, state2, in[input]);
-        input--;
-        state1 = fse_encode(table, s, state1, in[input]);
-        input--;
-        state2 = fse_encode(table, s, state2, in[input]);
-        input--;
-        state1 = fse_encode(table, s, state1, in[input]);
-        bo_flush(s);
-    }
-    fse_finish(table, s, state2);
-    fse_finish(table, s, state1);
-    return bo_close(s);
-}
-
-// ---- histograms: lanes split the input, LDS atomics (Histogram.java:21-65) -----------------------------------
-__device__ void wave_histogram(Shared& sh, const uint8_t* in, int32_t n, int32_t bins, int lane)
-{
-    __syncthreads();
-    for (int32_t i = lane; i < bins; i += 64) {
-        sh.counts[i] = 0;
-    }
-    __syncthreads();
-    for (int32_t i = lane; i < n; i += 64) {
-        atomicAdd(&sh.counts[in[i]], 1);
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ int32_t find_max_symbol(const Shared& sh, int32_t maxSymbol)
-{
-    while (sh.counts[maxSymbol] == 0) {
-        maxSymbol--;
-    }
-    return maxSymbol;
-}
-__device__ __forceinline__ int32_t find_largest_count(const Shared& sh, int32_t maxSymbol)
-{
-    int32_t max = 0;
-    for (int32_t i = 0; i <= maxSymbol; i++) {
-        const int32_t v = sh.counts[i];
-        max = v > max ? v : max;
-    }
-    return max;
-}
-
-// ---- Huffman compression table -------------------------------------------------------------------------------
-__device__ int32_t huf_optimal_number_of_bits(int32_t maxNumberOfBits, int32_t inputSize, int32_t maxSymbol)  // :42-57
-{
-    int32_t result = maxNumberOfBits;
-    const int32_t a = highest_bit((uint32_t)(inputSize - 1)) - 1;
-    result = a < result ? a : result;
-    const int32_t b = min_table_log(inputSize, maxSymbol);
-    result = b > result ? b : result;
-    result = result < 5 ? 5 : result;
-    result = result > 12 ? 12 : result;
-    return result;
-}
-
-__device__ int32_t huf_build_tree(Shared& sh, int32_t maxSymbol)  // buildTree :105-190 (counts in sh.counts)
-{
-    __syncthreads();
-    for (int32_t i = (int32_t)threadIdx.x; i < 512; i += 64) {  // NodeTable.reset(), lanes split the clear
-        sh.nodeCount[i] = 0;
-        sh.nodeParent[i] = 0;
-        sh.nodeSymbol[i] = 0;
-        sh.nodeBits[i] = 0;
-    }
-    __syncthreads();
-    int32_t current = 0;
-    for (int32_t symbol = 0; symbol <= maxSymbol; symbol++) {
-        const int32_t count = sh.counts[symbol];
-        int32_t position = current;
-        while (position > 1 && count > sh.nodeCount[position - 1]) {
-            sh.nodeCount[position] = sh.nodeCount[position - 1];
-            sh.nodeParent[position] = sh.nodeParent[position - 1];
-            sh.nodeSymbol[position] = sh.nodeSymbol[position - 1];
-            sh.nodeBits[position] = sh.nodeBits[position - 1];
-            position--;
-        }
-        sh.nodeCount[position] = count;
-        sh.nodeSymbol[position] = (int16_t)symbol;
-        current++;
-    }
-    int32_t lastNonZero = maxSymbol;
-    while (sh.nodeCount[lastNonZero] == 0) {
-        lastNonZero--;
-    }
-    const int32_t nonLeafStart = 256;
-    current = nonLeafStart;
-    int32_t currentLeaf = lastNonZero;
-    int32_t currentNonLeaf = current;
-    sh.nodeCount[current] = sh.nodeCount[currentLeaf] + sh.nodeCount[currentLeaf - 1];
-    sh.nodeParent[currentLeaf] = (int16_t)current;
-    sh.nodeParent[currentLeaf - 1] = (int16_t)current;
-    current++;
-    currentLeaf -= 2;
-    const int32_t root = 256 + lastNonZero - 1;
-    for (int32_t n = current; n <= root; n++) {
-        sh.nodeCount[n] = 1 << 30;
-    }
-    while (current <= root) {
-        int32_t child1, child2;
-        if (currentLeaf >= 0 && sh.nodeCount[currentLeaf] < sh.nodeCount[currentNonLeaf]) {
-            child1 = currentLeaf--;
-        }
-        else {
-            child1 = currentNonLeaf++;
-        }
-        if (currentLeaf >= 0 && sh.nodeCount[currentLeaf] < sh.nodeCount[currentNonLeaf]) {
-            child2 = currentLeaf--;
-        }
-        else {
-            child2 = currentNonLeaf++;
-        }
-        sh.nodeCount[current] = sh.nodeCount[child1] + sh.nodeCount[child2];
-        sh.nodeParent[child1] = (int16_t)current;
-        sh.nodeParent[child2] = (int16_t)current;
-        current++;
-    }
-    sh.nodeBits[root] = 0;
-    for (int32_t n = root - 1; n >= nonLeafStart; n--) {
-        sh.nodeBits[n] = (uint8_t)(sh.nodeBits[sh.nodeParent[n]] + 1);
-    }
-    for (int32_t n = 0; n <= lastNonZero; n++) {
-        sh.nodeBits[n] = (uint8_t)(sh.nodeBits[sh.nodeParent[n]] + 1);
-    }
-    return lastNonZero;
-}
-
-__device__ int32_t huf_set_max_height(Shared& sh, int32_t lastNonZero, int32_t maxNumberOfBits)  // :294-390
-{
-    const int32_t largestBits = sh.nodeBits[lastNonZero];
-    if (largestBits <= maxNumberOfBits) {
-        return largestBits;
-    }
-    int32_t totalCost = 0;
-    const int32_t baseCost = 1 << (largestBits - maxNumberOfBits);
-    int32_t n = lastNonZero;
-    while (sh.nodeBits[n] > maxNumberOfBits) {
-        totalCost += baseCost - (1 << (largestBits - sh.nodeBits[n]));
-        sh.nodeBits[n] = (uint8_t)maxNumberOfBits;
-        n--;
-    }
-    while (sh.nodeBits[n] == maxNumberOfBits) {
-        n--;
-    }
-    totalCost = (int32_t)((uint32_t)totalCost >> (largestBits - maxNumberOfBits));
-    const int32_t noSymbol = (int32_t)0xF0F0F0F0;
-    for (int i = 0; i < 14; i++) {
-        sh.rankLast[i] = noSymbol;
-    }
-    int32_t currentNbBits = maxNumberOfBits;
-    for (int32_t pos = n; pos >= 0; pos--) {
-        if (sh.nodeBits[pos] >= currentNbBits) {
-            continue;
-        }
-        currentNbBits = sh.nodeBits[pos];
-        sh.rankLast[maxNumberOfBits - currentNbBits] = pos;
-    }
-    while (totalCost > 0) {
-        int32_t dec = highest_bit((uint32_t)totalCost) + 1;
-        for (; dec > 1; dec--) {
-            const int32_t highPosition = sh.rankLast[dec];
-            const int32_t lowPosition = sh.rankLast[dec - 1];
-            if (highPosition == noSymbol) {
-                continue;
-            }
-            if (lowPosition == noSymbol) {
-                break;
-            }
-            const int32_t highTotal = sh.nodeCount[highPosition];
-            const int32_t lowTotal = 2 * sh.nodeCount[lowPosition];
-            if (highTotal <= lowTotal) {
-                break;
-            }
-        }
-        while ((dec <= 12) && (sh.rankLast[dec] == noSymbol)) {
-            dec++;
-        }
-        totalCost -= 1 << (dec - 1);
-        if (sh.rankLast[dec - 1] == noSymbol) {
-            sh.rankLast[dec - 1] = sh.rankLast[dec];
-        }
-        const int32_t at = sh.rankLast[dec];
-        sh.nodeBits[at] = (uint8_t)(sh.nodeBits[at] + 1);
-        if (at == 0) {
-            sh.rankLast[dec] = noSymbol;
-        }
-        else {
-            sh.rankLast[dec] = at - 1;
-            if (sh.nodeBits[at - 1] != maxNumberOfBits - dec) {
-                sh.rankLast[dec] = noSymbol;
-            }
-        }
-    }
-    while (totalCost < 0) {
-        if (sh.rankLast[1] == noSymbol) {
-            while (sh.nodeBits[n] == maxNumberOfBits) {
-                n--;
-            }
-            sh.nodeBits[n + 1] = (uint8_t)(sh.nodeBits[n + 1] - 1);
-            sh.rankLast[1] = n + 1;
-            totalCost++;
-            continue;
-        }
-        const int32_t at = sh.rankLast[1] + 1;
-        sh.nodeBits[at] = (uint8_t)(sh.nodeBits[at] - 1);
-        sh.rankLast[1] = at;
-        totalCost++;
-    }
-    return maxNumberOfBits;
-}
-
-__device__ void huf_table_initialize(Shared& sh, HufCTable& t, int32_t maxSymbol, int32_t maxNumberOfBits)  // initialize :60-103
-{
-    for (int i = 0; i < 13; i++) {  // workspace.reset()
-        sh.entriesPerRank[i] = 0;
-        sh.valuesPerRank[i] = 0;
-    }
-    const int32_t lastNonZero = huf_build_tree(sh, maxSymbol);
-    maxNumberOfBits = huf_set_max_height(sh, lastNonZero, maxNumberOfBits);
-    for (int32_t node = 0; node < maxSymbol + 1; node++) {
-        t.numberOfBits[sh.nodeSymbol[node]] = sh.nodeBits[node];
-    }
-    for (int32_t n = 0; n <= lastNonZero; n++) {
-        const int32_t r = sh.nodeBits[n];
-        sh.entriesPerRank[r] = (int16_t)(sh.entriesPerRank[r] + 1);
-    }
-    int16_t startingValue = 0;
-    for (int32_t rank = maxNumberOfBits; rank > 0; rank--) {
-        sh.valuesPerRank[rank] = startingValue;
-        startingValue = (int16_t)(startingValue + sh.entriesPerRank[rank]);
-        startingValue = (int16_t)((uint32_t)(int32_t)startingValue >> 1);
-    }
-    for (int32_t n = 0; n <= maxSymbol; n++) {
-        const int32_t r = t.numberOfBits[n];
-        const int16_t v = sh.valuesPerRank[r];
-        t.values[n] = v;
-        sh.valuesPerRank[r] = (int16_t)(v + 1);
-    }
-    t.maxSymbol = maxSymbol;
-    t.maxNumberOfBits = maxNumberOfBits;
-}
-
-// compressWeights :392-436 ; returns size, or -1 on failure
-__device__ int32_t huf_compress_weights(Ctx& c, Shared& sh, uint8_t* base, int32_t outputAddress, int32_t outputSize, int32_t weightsLength)
-{
-    if (weightsLength <= 1) {
-        return 0;
-    }
-    // histogram of <= 255 weights: serial, it is tiny (Histogram.count over workspace.counts[13])
-    int32_t wcounts[13];
-#pragma unroll
-    for (int i = 0; i < 13; i++) wcounts[i] = 0;
-    for (int32_t i = 0; i < weightsLength; i++) {
-        const int32_t w = sh.weights[i];
-#pragma unroll
-        for (int k = 0; k < 13; k++) wcounts[k] += (w == k);
-    }
-    int32_t maxSymbol = 12;
-    int32_t maxCount = 0;
-    {
-        bool found = false;
-#pragma unroll
-        for (int k = 12; k >= 0; k--) {
-            if (!found && wcounts[k] != 0) {
-                maxSymbol = k;
-                found = true;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 13; k++) {
-            if (k <= maxSymbol) maxCount = wcounts[k] > maxCount ? wcounts[k] : maxCount;
-        }
-    }
-    if (maxCount == weightsLength) {
-        return 1;
-    }
-    if (maxCount == 1) {
-        return 0;
-    }
-    // the generic FSE routines index their inputs dynamically: park the 13 counts in LDS (rankLast is free once
-    // setMaxHeight is done; the literal histogram in sh.counts must survive for estimateCompressedSize)
-    int32_t* countsLds = &sh.rankLast[0];
-#pragma unroll
-    for (int k = 0; k < 13; k++) countsLds[k] = wcounts[k];
-    int16_t* normLds = &sh.norm[128];  // 13 shorts, disjoint from the sequence normalizedCounts use (index < 53)
-    const int32_t tableLog = fse_optimal_table_log(6, weightsLength, maxSymbol);
-    fse_normalize_counts(normLds, tableLog, countsLds, weightsLength, maxSymbol);
-    int32_t output = outputAddress;
-    const int32_t outputLimit = outputAddress + outputSize;
-    const int32_t headerSize = fse_write_normalized_counts(c, base, output, outputSize, normLds, maxSymbol, tableLog);
-    ZC_PROPAGATE(headerSize);
-    output += headerSize;
-    fse_initialize(sh, sh.wt, normLds, maxSymbol, tableLog);
-    const int32_t compressedSize = fse_compress_weights(c, base, output, outputLimit - output, sh.weights, weightsLength, sh.wt);
-    ZC_PROPAGATE(compressedSize);
-    if (compressedSize == 0) {
-        return 0;
-    }
-    output += compressedSize;
-    return output - outputAddress;
-}
-
-// HuffmanCompressionTable.write :206-268 ; returns size or -1
-__device__ int32_t huf_table_write(Ctx& c, Shared& sh, const HufCTable& t, uint8_t* base, int32_t outputAddress, int32_t outputSize)
-{
-    int32_t output = outputAddress;
-    const int32_t maxNumberOfBits = t.maxNumberOfBits;
-    const int32_t maxSymbol = t.maxSymbol;
-    for (int32_t symbol = 0; symbol < maxSymbol; symbol++) {
-        const int32_t bits = t.numberOfBits[symbol];
-        sh.weights[symbol] = bits == 0 ? (uint8_t)0 : (uint8_t)(maxNumberOfBits + 1 - bits);
-    }
-    int32_t size = huf_compress_weights(c, sh, base, output + 1, outputSize - 1, maxSymbol);
-    ZC_PROPAGATE(size);
-    if (maxSymbol > 127 && size > 127) {  // Java: AssertionError
-        c.failStatus = mk_status(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_UNSUPPORTED);
-        return -1;
-    }
-    if (size != 0 && size != 1 && size < maxSymbol / 2) {
-        base[output] = (uint8_t)size;
-        return size + 1;
-    }
-    const int32_t entryCount = maxSymbol;
-    size = (entryCount + 1) / 2;
-    ZC_CHECK(c, size + 1 <= outputSize);
-    base[output] = (uint8_t)(127 + entryCount);
-    output++;
-    if (maxSymbol >= 255) {  // Java: weights[255] ArrayIndexOutOfBoundsException
-        c.failStatus = mk_status(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_UNSUPPORTED);
-        return -1;
-    }
-    sh.weights[maxSymbol] = 0;
-    for (int32_t i = 0; i < entryCount; i += 2) {
-        base[output] = (uint8_t)((sh.weights[i] << 4) + sh.weights[i + 1]);
-        output++;
-    }
-    return output - outputAddress;
-}
-
-__device__ bool huf_table_is_valid(const Shared& sh, const HufCTable& t, int32_t maxSymbol)  // :273-286
-{
-    if (maxSymbol > t.maxSymbol) {
-        return false;
-    }
-    for (int32_t symbol = 0; symbol <= maxSymbol; ++symbol) {
-        if (sh.counts[symbol] != 0 && t.numberOfBits[symbol] == 0) {
-            return false;
-        }
-    }
-    return true;
-}
-__device__ int32_t huf_estimate_compressed_size(const Shared& sh, const HufCTable& t, int32_t maxSymbol)  // :288-296
-{
-    int32_t bits = 0;
-    const int32_t lim = maxSymbol < t.maxSymbol ? maxSymbol : t.maxSymbol;
-    for (int32_t symbol = 0; symbol <= lim; symbol++) {
-        bits += t.numberOfBits[symbol] * sh.counts[symbol];
-    }
-    return (int32_t)((uint32_t)bits >> 3);
-}
-
-// total code length of in[0..n) under table t: lanes split the input, wave reduction
-__device__ int32_t wave_code_bits(const HufCTable& t, const uint8_t* in, int32_t n, int lane)
-{
-    int32_t bits = 0;
-    for (int32_t i = lane; i < n; i += 64) {
-        bits += t.numberOfBits[in[i]];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        bits += __shfl_xor(bits, off);
-    }
-    return bits;
-}
-
-// HuffmanCompressor.compressSingleStream :88-134 executed by ONE lane (the others idle in this call)
-__device__ int32_t huf_encode_stream(const HufCTable& t, uint8_t* base, int32_t outputAddress, int32_t outputSize, const uint8_t* in, int32_t inputSize)
-{
-    if (outputSize < 8) {
-        return 0;
-    }
-    BitOut bs;
-    bo_init(bs, base, outputAddress, outputSize);
-    int32_t n = inputSize & ~3;
-#define ZC_ENC(sym) bo_add_fast(bs, t.values[(sym)], t.numberOfBits[(sym)])
-    switch (inputSize & 3) {
-        case 3: ZC_ENC(in[n + 2]);  // fallthrough
-        case 2: ZC_ENC(in[n + 1]);  // fallthrough
-        case 1:
-            ZC_ENC(in[n + 0]);
-            bo_flush(bs);  // fallthrough
-        default: break;
-    }
-    for (; n > 0; n -= 4) {
-        const uint32_t w = ld4(in + n - 4);
-        ZC_ENC(w >> 24);
-        ZC_ENC((w >> 16) & 0xFF);
-        ZC_ENC((w >> 8) & 0xFF);
-        ZC_ENC(w & 0xFF);
-        bo_flush(bs);
-    }
-#undef ZC_ENC
-    return bo_close(bs);
-}
-
-// size compressSingleStream would return for a stream of `bits` code bits in a buffer of outputSize bytes
-__device__ __forceinline__ int32_t huf_stream_size(int32_t bits, int32_t outputSize)
-{
-    if (outputSize < 8) {
-        return 0;
-    }
-    const int32_t total = bits + 1;  // end mark
-    if ((total >> 3) >= outputSize - 8) {
-        return 0;  // BitOutputStream.close(): currentAddress >= outputLimit
-    }
-    return (total + 7) >> 3;
-}
-
-// ---- literals section: encodeLiterals :262-378 ---------------------------------------------------------------
-__device__ int32_t raw_literals(Ctx& c, uint8_t* base, int32_t outputAddress, int32_t outputSize, const uint8_t* in, int32_t inputSize)  // :407-431
-{
-    int32_t headerSize = 1;
-    if (inputSize >= 32) headerSize++;
-    if (inputSize >= 4096) headerSize++;
-    ZC_CHECK(c, inputSize + headerSize <= outputSize);
-    if (headerSize == 1) {
-        base[outputAddress] = (uint8_t)(0 | (inputSize << 3));
-    }
-    else if (headerSize == 2) {
-        st2(base + outputAddress, (uint32_t)(0 | (1 << 2) | (inputSize << 4)));
-    }
-    else {
-        st_le(base + outputAddress, (uint32_t)(0 | (3 << 2) | (inputSize << 4)), 3);
-    }
-    ZC_CHECK(c, inputSize + 1 <= outputSize);
-    wave_mem_order();
-    group_copy<64>(base + outputAddress + headerSize, in, inputSize, c.lane);
-    wave_mem_order();
-    return headerSize + inputSize;
-}
-
-__device__ int32_t encode_literals(Ctx& c, Shared& sh, uint8_t* base, int32_t outputAddress, int32_t outputSize, const uint8_t* literals, int32_t literalsSize)
-{
-    if (literalsSize <= 63) {
-        return raw_literals(c, base, outputAddress, outputSize, literals, literalsSize);
-    }
-    const int32_t headerSize = 3 + (literalsSize >= 1024 ? 1 : 0) + (literalsSize >= 16384 ? 1 : 0);
-    ZC_CHECK(c, headerSize + 1 <= outputSize);
-    wave_histogram(sh, literals, literalsSize, 256, c.lane);
-    const int32_t maxSymbol = find_max_symbol(sh, 255);
-    const int32_t largestCount = find_largest_count(sh, maxSymbol);
-    if (largestCount == literalsSize) {  // rleLiterals :380-398
-        const int32_t hs = 1 + (literalsSize > 31 ? 1 : 0) + (literalsSize > 4095 ? 1 : 0);
-        if (hs == 1) {
-            base[outputAddress] = (uint8_t)(1 | (literalsSize << 3));
-        }
-        else if (hs == 2) {
-            st2(base + outputAddress, (uint32_t)(1 | (1 << 2) | (literalsSize << 4)));
-        }
-        else {
-            st_le(base + outputAddress, (uint32_t)(1 | (3 << 2) | (literalsSize << 4)), 3);  // putInt; byte 3 is then overwritten
-        }
-        base[outputAddress + hs] = literals[0];
-        return hs + 1;
-    }
-    else if (largestCount <= (int32_t)((uint32_t)literalsSize >> 7) + 4) {
-        return raw_literals(c, base, outputAddress, outputSize, literals, literalsSize);
-    }
-    HufCTable& previousTable = sh.huf[c.previousTable];
-    const bool canReuse = huf_table_is_valid(sh, previousTable, maxSymbol);
-    const bool preferReuse = literalsSize <= 1024;
-    HufCTable* table;
-    int32_t serializedTableSize;
-    bool reuseTable;
-    if (preferReuse && canReuse) {
-        table = &previousTable;
-        reuseTable = true;
-        serializedTableSize = 0;
-    }
-    else {
-        c.previousCandidate = c.temporaryTable;  // borrowTemporaryTable
-        c.temporaryCandidate = c.previousTable;
-        HufCTable& newTable = sh.huf[c.temporaryTable];
-        huf_table_initialize(sh, newTable, maxSymbol, huf_optimal_number_of_bits(11, literalsSize, maxSymbol));
-        serializedTableSize = huf_table_write(c, sh, newTable, base, outputAddress + headerSize, outputSize - headerSize);
-        ZC_PROPAGATE(serializedTableSize);
-        if (canReuse && huf_estimate_compressed_size(sh, previousTable, maxSymbol) <= serializedTableSize + huf_estimate_compressed_size(sh, newTable, maxSymbol)) {
-            table = &previousTable;
-            reuseTable = true;
-            serializedTableSize = 0;
-            c.previousCandidate = c.previousTable;  // discardTemporaryTable
-            c.temporaryCandidate = c.temporaryTable;
-        }
-        else {
-            table = &newTable;
-            reuseTable = false;
-        }
-    }
-    // ---- HuffmanCompressor: sizes first (wave reduction), then one lane per stream ----
-    const int32_t streamsAddress = outputAddress + headerSize + serializedTableSize;
-    const int32_t streamsSize = outputSize - headerSize - serializedTableSize;
-    const bool singleStream = literalsSize < 256;
-    int32_t compressedSize;
-    wave_mem_order();
-    if (singleStream) {
-        const int32_t bits = wave_code_bits(*table, literals, literalsSize, c.lane);
-        compressedSize = huf_stream_size(bits, streamsSize);
-        if (compressedSize != 0 && c.lane == 0) {
-            huf_encode_stream(*table, base, streamsAddress, streamsSize, literals, literalsSize);
-        }
-    }
-    else {  // compress4streams :26-86
-        const int32_t segmentSize = (literalsSize + 3) / 4;
-        compressedSize = 0;
-        if (!(streamsSize < 6 + 1 + 1 + 1 + 8) && !(literalsSize <= 6 + 1 + 1 + 1)) {
-            int32_t segStart[4], segLen[4], outStart[4], outAvail[4], segBytes[4];
-            int32_t output = streamsAddress + 6;
-            const int32_t outputLimit = streamsAddress + streamsSize;
-            bool ok = true;
-            for (int k = 0; k < 4; k++) {
-                segStart[k] = k * segmentSize;
-                segLen[k] = k < 3 ? segmentSize : literalsSize - 3 * segmentSize;
-                outStart[k] = output;
-                outAvail[k] = outputLimit - output;
-                const int32_t bits = wave_code_bits(*table, literals + segStart[k], segLen[k], c.lane);
-                segBytes[k] = ok ? huf_stream_size(bits, outAvail[k]) : 0;
-                if (segBytes[k] == 0) {
-                    ok = false;
-                }
-                output += segBytes[k];
-            }
-            if (ok) {
-                if (c.lane < 4) {
-                    int32_t mStart = 0, mLen = 0, mOut = 0, mAvail = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (c.lane == k) {
-                            mStart = segStart[k];
-                            mLen = segLen[k];
-                            mOut = outStart[k];
-                            mAvail = outAvail[k];
-                        }
-                    }
-                    huf_encode_stream(*table, base, mOut, mAvail, literals + mStart, mLen);
-                }
-                st2(base + streamsAddress, (uint32_t)segBytes[0]);
-                st2(base + streamsAddress + 2, (uint32_t)segBytes[1]);
-                st2(base + streamsAddress + 4, (uint32_t)segBytes[2]);
-                compressedSize = output - streamsAddress;
-            }
-        }
-    }
-    wave_mem_order();
-    const int32_t totalSize = serializedTableSize + compressedSize;
-    const int32_t minimumGain = (int32_t)((uint32_t)literalsSize >> 6) + 2;
-    if (compressedSize == 0 || totalSize >= literalsSize - minimumGain) {
-        c.previousCandidate = c.previousTable;
-        c.temporaryCandidate = c.temporaryTable;
-        return raw_literals(c, base, outputAddress, outputSize, literals, literalsSize);
-    }
-    const int32_t encodingType = reuseTable ? 3 : 2;
-    if (headerSize == 3) {
-        st_le(base + outputAddress, (uint32_t)(encodingType | ((singleStream ? 0 : 1) << 2) | (literalsSize << 4) | (totalSize << 14)), 3);
-    }
-    else if (headerSize == 4) {
-        st4(base + outputAddress, (uint32_t)(encodingType | (2 << 2) | (literalsSize << 4) | (totalSize << 18)));
-    }
-    else {
-        st4(base + outputAddress, (uint32_t)encodingType | (3u << 2) | ((uint32_t)literalsSize << 4) | ((uint32_t)totalSize << 22));
-        base[outputAddress + 4] = (uint8_t)((uint32_t)totalSize >> 10);
-    }
-    return headerSize + totalSize;
-}
-
-// ---- sequences section: SequenceEncoder.compressSequences :66-209 ---------------------------------------------
-__device__ __forceinline__ int32_t select_encoding_type(int32_t largestCount, int32_t sequenceCount, int32_t defaultLog, bool defaultAllowed)  // :299-341 (DFAST)
-{
-    if (largestCount == sequenceCount) {
-        if (defaultAllowed && sequenceCount <= 2) {
-            return 0;
-        }
-        return 1;
-    }
-    if (defaultAllowed) {
-        const int64_t minNumberOfSequences = ((1LL << defaultLog) * 9) >> 3;
-        if ((sequenceCount < minNumberOfSequences) || (largestCount < (sequenceCount >> (defaultLog - 1)))) {
-            return 0;
-        }
-    }
-    return 2;
-}
-
-// buildCompressionTable :211-226 ; returns bytes written or -1
-__device__ int32_t build_compression_table(Ctx& c, Shared& sh, FseCTable& table, uint8_t* base, int32_t output, int64_t outputLimit, int32_t sequenceCount, int32_t maxTableLog,
-                                           const uint8_t* codes, int32_t maxSymbol)
-{
-    const int32_t tableLog = fse_optimal_table_log(maxTableLog, sequenceCount, maxSymbol);
-    const int32_t lastCode = codes[sequenceCount - 1];
-    if (sh.counts[lastCode] > 1) {
-        sh.counts[lastCode] = sh.counts[lastCode] - 1;
-        sequenceCount--;
-    }
-    fse_normalize_counts(sh.norm, tableLog, sh.counts, sequenceCount, maxSymbol);
-    fse_initialize(sh, table, sh.norm, maxSymbol, tableLog);
-    return fse_write_normalized_counts(c, base, output, (int32_t)(outputLimit - output), sh.norm, maxSymbol, tableLog);
-}
-
-__device__ int32_t compress_sequences(Ctx& c, Shared& sh, uint8_t* base, int32_t outputAddress, int32_t outputSize)
-{
-    int32_t output = outputAddress;
-    const int32_t outputLimit = outputAddress + outputSize;
-    ZC_CHECK(c, outputLimit - output > 3 + 1);
-    const int32_t sequenceCount = c.sequenceCount;
-    if (sequenceCount < 0x7F) {
-        base[output] = (uint8_t)sequenceCount;
-        output++;
-    }
-    else if (sequenceCount < 0x7F00) {
-        base[output] = (uint8_t)((uint32_t)sequenceCount >> 8 | 0x80);
-        base[output + 1] = (uint8_t)sequenceCount;
-        output += 2;
-    }
-    else {
-        base[output] = 0xFF;
-        output++;
-        st2(base + output, (uint32_t)(sequenceCount - 0x7F00));
-        output += 2;
-    }
-    if (sequenceCount == 0) {
-        return output - outputAddress;
-    }
-    const int32_t headerAddress = output++;
-    int32_t maxSymbol, largestCount;
-
-    // literal lengths
-    wave_histogram(sh, c.codeLL, sequenceCount, 53, c.lane);
-    maxSymbol = find_max_symbol(sh, 35);
-    largestCount = find_largest_count(sh, maxSymbol);
-    const int32_t llType = select_encoding_type(largestCount, sequenceCount, 6, true);
-    const FseCTable* llTable;
-    if (llType == 1) {
-        base[output] = c.codeLL[0];
-        output++;
-        fse_init_rle(sh.ll, maxSymbol);
-        llTable = &sh.ll;
-    }
-    else if (llType == 0) {
-        llTable = &sh.dflt[0];
-    }
-    else {
-        const int32_t n = build_compression_table(c, sh, sh.ll, base, output, outputLimit, sequenceCount, 9, c.codeLL, maxSymbol);
-        ZC_PROPAGATE(n);
-        output += n;
-        llTable = &sh.ll;
-    }
-
-    // offsets
-    wave_histogram(sh, c.codeOF, sequenceCount, 53, c.lane);
-    maxSymbol = find_max_symbol(sh, 31);
-    largestCount = find_largest_count(sh, maxSymbol);
-    const int32_t ofType = select_encoding_type(largestCount, sequenceCount, 5, maxSymbol < 28);
-    const FseCTable* ofTable;
-    if (ofType == 1) {
-        base[output] = c.codeOF[0];
-        output++;
-        fse_init_rle(sh.of, maxSymbol);
-        ofTable = &sh.of;
-    }
-    else if (ofType == 0) {
-        ofTable = &sh.dflt[1];
-    }
-    else {  // the Java code passes output + outputSize as the limit here (:155)
-        const int32_t n = build_compression_table(c, sh, sh.of, base, output, (int64_t)output + outputSize, sequenceCount, 8, c.codeOF, maxSymbol);
-        ZC_PROPAGATE(n);
-        output += n;
-        ofTable = &sh.of;
-    }
-
-    // match lengths
-    wave_histogram(sh, c.codeML, sequenceCount, 53, c.lane);
-    maxSymbol = find_max_symbol(sh, 52);
-    largestCount = find_largest_count(sh, maxSymbol);
-    const int32_t mlType = select_encoding_type(largestCount, sequenceCount, 6, true);
-    const FseCTable* mlTable;
-    if (mlType == 1) {
-        base[output] = c.codeML[0];
-        output++;
-        fse_init_rle(sh.ml, maxSymbol);
-        mlTable = &sh.ml;
-    }
-    else if (mlType == 0) {
-        mlTable = &sh.dflt[2];
-    }
-    else {
-        const int32_t n = build_compression_table(c, sh, sh.ml, base, output, outputLimit, sequenceCount, 9, c.codeML, maxSymbol);
-        ZC_PROPAGATE(n);
-        output += n;
-        mlTable = &sh.ml;
-    }
-    base[headerAddress] = (uint8_t)((llType << 6) | (ofType << 4) | (mlType << 2));
-
-    // encodeSequences :228-297 (three interleaved FSE states over one backward bit stream: serial, wave-uniform)
-    BitOut bs;
-    ZC_CHECK(c, outputLimit - output >= 8);
-    bo_init(bs, base, output, outputLimit - output);
-    int32_t n = sequenceCount - 1;
-    int32_t mlState = fse_begin(*mlTable, c.codeML[n]);
-    int32_t ofState = fse_begin(*ofTable, c.codeOF[n]);
-    int32_t llState = fse_begin(*llTable, c.codeLL[n]);
-    bo_add(bs, c.seqLitLen[n], LL_BITS[c.codeLL[n]]);
-    bo_add(bs, c.seqMatchLen[n], ML_BITS[c.codeML[n]]);
-    bo_add(bs, c.seqOffset[n], c.codeOF[n]);
-    bo_flush(bs);
-    for (n = sequenceCount - 2; n >= 0; n--) {
-        const int32_t llCode = c.codeLL[n];
-        const int32_t ofCode = c.codeOF[n];
-        const int32_t mlCode = c.codeML[n];
-        const int32_t llBits = LL_BITS[llCode];
-        const int32_t ofBits = ofCode;
-        const int32_t mlBits = ML_BITS[mlCode];
-        ofState = fse_encode(*ofTable, bs, ofState, ofCode);
-        mlState = fse_encode(*mlTable, bs, mlState, mlCode);
-        llState = fse_encode(*llTable, bs, llState, llCode);
-        if (ofBits + mlBits + llBits >= 64 - 7 - (9 + 9 + 8)) {
-            bo_flush(bs);
-        }
-        bo_add(bs, c.seqLitLen[n], llBits);
-        if (llBits + mlBits > 24) {
-            bo_flush(bs);
-        }
-        bo_add(bs, c.seqMatchLen[n], mlBits);
-        if (ofBits + mlBits + llBits > 56) {
-            bo_flush(bs);
-        }
-        bo_add(bs, c.seqOffset[n], ofBits);
-        bo_flush(bs);
-    }
-    fse_finish(*mlTable, bs, mlState);
-    fse_finish(*ofTable, bs, ofState);
-    fse_finish(*llTable, bs, llState);
-    const int32_t streamSize = bo_close(bs);
-    ZC_CHECK(c, streamSize > 0);
-    output += streamSize;
-    return output - outputAddress;
-}
-
-// ---- match finder: DoubleFastBlockCompressor.compressBlock :28-180 ---------------------------------------------
-__device__ __forceinline__ int32_t hash4(uint32_t v, int32_t bits) { return (int32_t)((v * 0x9E3779B1u) >> (32 - bits)); }
-__device__ __forceinline__ int32_t hash5(uint64_t v, int32_t bits) { return (int32_t)(((v << 24) * 0xCF1BBCDCBBULL) >> (64 - bits)); }
-__device__ __forceinline__ int32_t hash8(uint64_t v, int32_t bits) { return (int32_t)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - bits)); }
-__device__ __forceinline__ int32_t hash_short(const Ctx& c, int32_t address)  // hash(...) :213-222 ; level 3 only uses search lengths 4 and 5
-{
-    return c.searchLength == 5 ? hash5(ld8(c.in + address), c.chainLog) : hash4(ld4(c.in + address), c.chainLog);
-}
-
-__device__ __forceinline__ void store_sequence(Ctx& c, int32_t literalAddress, int32_t literalLength, int32_t offsetCode, int32_t matchLengthBase)  // SequenceStore.storeSequence :83-111
-{
-    wave_mem_order();
-    group_copy<64>(c.litBuf + c.literalsLength, c.in + literalAddress, literalLength, c.lane);
-    c.literalsLength += literalLength;
-    const int32_t i = c.sequenceCount;
-    if (literalLength > 65535) {
-        c.longLengthField = 1;
-        c.longLengthPosition = i;
-    }
-    c.seqLitLen[i] = literalLength;
-    c.seqOffset[i] = offsetCode + 1;
-    if (matchLengthBase > 65535) {
-        c.longLengthField = 2;
-        c.longLengthPosition = i;
-    }
-    c.seqMatchLen[i] = matchLengthBase;
-    c.sequenceCount = i + 1;
-}
-
-// for every lane, the mask of lanes whose `key` (low `bits` bits) equals its own
-__device__ __forceinline__ unsigned long long zc_match_any(uint32_t key, int bits, unsigned long long active)
-{
-    unsigned long long eq = active;
-    for (int b = 0; b < bits; b++) {
-        const bool bit = (key >> b) & 1u;
-        const unsigned long long m = __ballot(bit);
-        eq &= bit ? m : ~m;
-    }
-    return eq;
-}
-
-__device__ int32_t dfast_compress_block(Ctx& c, int32_t inputAddress, int32_t inputSize)
-{
-    const uint8_t* __restrict__ in = c.in;
-    const int32_t windowBase = c.windowBaseOffset;
-    int32_t* longTable = c.hashTable;
-    int32_t* shortTable = c.chainTable;
-    const int32_t longBits = c.hashLog;
-    const int32_t inputEnd = inputAddress + inputSize;
-    const int32_t inputLimit = inputEnd - 8;
-    int32_t input = inputAddress;
-    int32_t anchor = inputAddress;
-    int32_t offset1 = c.offset0;
-    int32_t offset2 = c.offset1;
-    int32_t savedOffset = 0;
-    if (input - windowBase == 0) {
-        input++;
-    }
-    const int32_t maxRep = input - windowBase;
-    if (offset2 > maxRep) {
-        savedOffset = offset2;
-        offset2 = 0;
-    }
-    if (offset1 > maxRep) {
-        savedOffset = offset1;
-        offset1 = 0;
-    }
-    int32_t width = 8;  // lanes of the next batch probe: narrow right after a match (text finds the next one within a few positions), 64 once a batch found nothing
-    while (input < inputLimit) {
-        uint64_t here = 0;
-        int32_t shortHash = 0, longHash = 0, shortMatch = 0, longMatch = 0;
-        bool repHit = false, longHit = false, shortHit = false;
-        bool probed = false;
-        if (c.batchProbe && input - anchor < 256 - 64) {
-            // Batch probe: while nothing matches the serial loop visits input, input + 1, ... (its step is
-            // ((input - anchor) >> 8) + 1 = 1 here) and changes nothing but the two tables, so the lanes test the next
-            // `width` positions at once -- three dependent HBM round trips per batch instead of per position.  A lane
-            // sees the tables as the serial loop would: the latest earlier lane with the same hash, else the stored
-            // entry.  Lanes before the first candidate match commit their inserts (latest position per slot); the
-            // first candidate's position continues below with what its lane has already loaded.
-            const int lane = c.lane;
-            const int32_t p = input + lane;
-            const bool act = lane < width && p < inputLimit;
-            const unsigned long long actMask = __ballot(act);
-            const uint64_t hereB = act ? ld8(in + p) : 0ull;
-            const int32_t sh = c.searchLength == 5 ? hash5(hereB, c.chainLog) : hash4((uint32_t)hereB, c.chainLog);
-            const int32_t lh = hash8(hereB, longBits);
-            int32_t sm = act ? shortTable[sh] : 0;
-            int32_t lm = act ? longTable[lh] : 0;
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const unsigned long long sameS = zc_match_any((uint32_t)sh, c.chainLog, actMask);
-            const unsigned long long sameL = zc_match_any((uint32_t)lh, longBits, actMask);
-            if (act && (sameS & below) != 0) {
-                sm = input + (63 - __builtin_clzll(sameS & below));
-            }
-            if (act && (sameL & below) != 0) {
-                lm = input + (63 - __builtin_clzll(sameL & below));
-            }
-            bool r = false, l = false, sHit = false;
-            if (act) {
-                r = offset1 > 0 && ld4(in + p + 1 - offset1) == (uint32_t)(hereB >> 8);
-                l = lm > windowBase && ld8(in + lm) == hereB;
-                sHit = sm > windowBase && ld4(in + sm) == (uint32_t)hereB;
-            }
-            const unsigned long long hitMask = __ballot(r || l || sHit);
-            const unsigned long long stop = hitMask | ~actMask;
-            const int first = stop != 0 ? __builtin_ctzll(stop) : 64;
-            const unsigned long long upTo = first >= 64 ? ~0ull : ((1ull << first) - 1ull);  // lanes that found nothing
-            const unsigned long long above = lane >= 63 ? 0ull : ~((2ull << lane) - 1ull);
-            if (lane < first) {
-                if ((sameL & upTo & above) == 0) {
-                    longTable[lh] = p;
-                }
-                if ((sameS & upTo & above) == 0) {
-                    shortTable[sh] = p;
-                }
-            }
-            wave_mem_order();
-            input += first;
-            if (first >= 64 || ((hitMask >> first) & 1ull) == 0) {
-                width = 64;  // nothing in this batch (or the end of the block): keep going, wide
-                continue;
-            }
-            here = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(hereB >> 32), first) << 32) | (uint32_t)__shfl((int)(uint32_t)hereB, first);
-            shortHash = __shfl(sh, first);
-            longHash = __shfl(lh, first);
-            shortMatch = __shfl(sm, first);
-            longMatch = __shfl(lm, first);
-            repHit = __shfl(r ? 1 : 0, first) != 0;
-            longHit = __shfl(l ? 1 : 0, first) != 0;
-            shortHit = __shfl(sHit ? 1 : 0, first) != 0;
-            probed = true;
-        }
-        if (!probed) {
-            here = ld8(in + input);
-            shortHash = c.searchLength == 5 ? hash5(here, c.chainLog) : hash4((uint32_t)here, c.chainLog);
-            shortMatch = shortTable[shortHash];
-            longHash = hash8(here, longBits);
-            longMatch = longTable[longHash];
-            repHit = offset1 > 0 && ld4(in + input + 1 - offset1) == ld4(in + input + 1);
-            if (!repHit) {
-                longHit = longMatch > windowBase && ld8(in + longMatch) == here;
-                if (!longHit) {
-                    shortHit = shortMatch > windowBase && ld4(in + shortMatch) == (uint32_t)here;
-                }
-            }
-        }
-        const int32_t current = input;
-        longTable[longHash] = current;
-        shortTable[shortHash] = current;
-        int32_t matchLength;
-        int32_t offset;
-        if (repHit) {
-            matchLength = wave_count(in, input + 1 + 4, input + 1 + 4 - offset1, inputEnd, c.lane) + 4;
-            input++;
-            store_sequence(c, anchor, input - anchor, 0, matchLength - 3);
-        }
-        else {
-            if (longHit) {
-                matchLength = wave_count(in, input + 8, longMatch + 8, inputEnd, c.lane) + 8;
-                offset = input - longMatch;
-                while (input > anchor && longMatch > windowBase && in[input - 1] == in[longMatch - 1]) {
-                    input--;
-                    longMatch--;
-                    matchLength++;
-                }
-            }
-            else if (shortHit) {
-                const uint64_t next = ld8(in + input + 1);
-                const int32_t nextHash = hash8(next, longBits);
-                int32_t nextMatch = longTable[nextHash];
-                longTable[nextHash] = current + 1;
-                if (nextMatch > windowBase && ld8(in + nextMatch) == next) {
-                    matchLength = wave_count(in, input + 1 + 8, nextMatch + 8, inputEnd, c.lane) + 8;
-                    input++;
-                    offset = input - nextMatch;
-                    while (input > anchor && nextMatch > windowBase && in[input - 1] == in[nextMatch - 1]) {
-                        input--;
-                        nextMatch--;
-                        matchLength++;
-                    }
-                }
-                else {
-                    matchLength = wave_count(in, input + 4, shortMatch + 4, inputEnd, c.lane) + 4;
-                    offset = input - shortMatch;
-                    while (input > anchor && shortMatch > windowBase && in[input - 1] == in[shortMatch - 1]) {
-                        input--;
-                        shortMatch--;
-                        matchLength++;
-                    }
-                }
-            }
-            else {
-                input += ((input - anchor) >> 8) + 1;
-                continue;
-            }
-            offset2 = offset1;
-            offset1 = offset;
-            store_sequence(c, anchor, input - anchor, offset + 2, matchLength - 3);
-        }
-        width = input - anchor >= 24 ? 64 : 8;  // the literal run just closed predicts the next one: wide batches for long runs, narrow for text
-        input += matchLength;
-        anchor = input;
-        if (input <= inputLimit) {
-            const uint64_t a = ld8(in + current + 2);
-            longTable[hash8(a, longBits)] = current + 2;
-            shortTable[c.searchLength == 5 ? hash5(a, c.chainLog) : hash4((uint32_t)a, c.chainLog)] = current + 2;
-            const uint64_t b = ld8(in + input - 2);
-            longTable[hash8(b, longBits)] = input - 2;
-            shortTable[c.searchLength == 5 ? hash5(b, c.chainLog) : hash4((uint32_t)b, c.chainLog)] = input - 2;
-            while (input <= inputLimit && offset2 > 0 && ld4(in + input) == ld4(in + input - offset2)) {
-                const int32_t repetitionLength = wave_count(in, input + 4, input + 4 - offset2, inputEnd, c.lane) + 4;
-                const int32_t temp = offset2;
-                offset2 = offset1;
-                offset1 = temp;
-                const uint64_t r = ld8(in + input);
-                shortTable[c.searchLength == 5 ? hash5(r, c.chainLog) : hash4((uint32_t)r, c.chainLog)] = input;
-                longTable[hash8(r, longBits)] = input;
-                store_sequence(c, anchor, 0, 0, repetitionLength - 3);
-                input += repetitionLength;
-                anchor = input;
-            }
-        }
-    }
-    c.tempOffset0 = offset1 != 0 ? offset1 : savedOffset;
-    c.tempOffset1 = offset2 != 0 ? offset2 : savedOffset;
-    return inputEnd - anchor;
-}
-
-// ---- blocks and frame: ZstdFrameCompressor :136-260 --------------------------------------------------------------
-__device__ int32_t compress_block(Ctx& c, Shared& sh, int32_t inputAddress, int32_t inputSize, int32_t outputAddress, int32_t outputSize)
-{
-    if (inputSize < 3 + 3 + 1) {
-        return 0;
-    }
-    const int32_t newOffset = (inputAddress + inputSize) - c.windowSize;  // enforceMaxDistance
-    if (c.windowBaseOffset < newOffset) {
-        c.windowBaseOffset = newOffset;
-    }
-    c.literalsLength = 0;
-    c.sequenceCount = 0;
-    c.longLengthField = 0;
-    if (c.pre != nullptr) {
-        c.sequenceCount = c.pre[1];
-        c.literalsLength = c.pre[2];
-        c.longLengthField = c.pre[3];
-        c.longLengthPosition = c.pre[4];
-        c.tempOffset0 = c.pre[5];
-        c.tempOffset1 = c.pre[6];
-    }
-    else {
-        const int32_t lastLiteralsSize = dfast_compress_block(c, inputAddress, inputSize);
-        if (c.dbgStage == 1) {
-            return 0;  // DEBUG (timing split only): stop after the match finder
-        }
-        wave_mem_order();
-        group_copy<64>(c.litBuf + c.literalsLength, c.in + inputAddress + inputSize - lastLiteralsSize, lastLiteralsSize, c.lane);
-        c.literalsLength += lastLiteralsSize;
-    }
-    wave_mem_order();
-    // generateCodes :121-135 : one sequence per lane per step
-    for (int32_t i = c.lane; i < c.sequenceCount; i += 64) {
-        const int32_t ll = c.seqLitLen[i];
-        c.codeLL[i] = (uint8_t)(ll >= 64 ? highest_bit((uint32_t)ll) + 19 : LL_CODE[ll]);
-        c.codeOF[i] = (uint8_t)highest_bit((uint32_t)c.seqOffset[i]);
-        const int32_t ml = c.seqMatchLen[i];
-        c.codeML[i] = (uint8_t)(ml >= 128 ? highest_bit((uint32_t)ml) + 36 : ML_CODE[ml]);
-    }
-    wave_mem_order();
-    if (c.longLengthField == 1) {
-        c.codeLL[c.longLengthPosition] = 35;
-    }
-    if (c.longLengthField == 2) {
-        c.codeML[c.longLengthPosition] = 52;
-    }
-    wave_mem_order();
-    const int32_t outputLimit = outputAddress + outputSize;
-    int32_t output = outputAddress;
-    const int32_t compressedLiteralsSize = encode_literals(c, sh, c.out, output, outputLimit - output, c.litBuf, c.literalsLength);
-    ZC_PROPAGATE(compressedLiteralsSize);
-    output += compressedLiteralsSize;
-    const int32_t compressedSequencesSize = compress_sequences(c, sh, c.out, output, outputLimit - output);
-    ZC_PROPAGATE(compressedSequencesSize);
-    const int32_t compressedSize = compressedLiteralsSize + compressedSequencesSize;
-    if (compressedSize == 0) {
-        return 0;
-    }
-    const int32_t maxCompressedSize = inputSize - ((int32_t)((uint32_t)inputSize >> 6) + 2);
-    if (compressedSize > maxCompressedSize) {
-        return 0;
-    }
-    c.offset0 = c.tempOffset0;  // context.commit()
-    c.offset1 = c.tempOffset1;
-    c.temporaryTable = c.temporaryCandidate;
-    c.previousTable = c.previousCandidate;
-    return compressedSize;
-}
-
-// CompressionParameters.compute :256-299 (level 3)
-// ZstdOutputStream.java:48-58 (stream mode): CompressionParameters.compute(3, -1) returns the default row as it stands (:259-261) --
-// window 2^20, chain 2^16, hash 2^17 whatever the input's size.
-constexpr int32_t STREAM_MAX_BUFFER = 4 << 20;  // 4 x window: from here on the stream flushes before close() (not built: see zstd_compress_item)
-__device__ __forceinline__ void compute_parameters(Ctx& c)
-{
-    if (c.streamMode) {
-        c.searchLength = LEVEL3[0][3];
-        c.windowLog = LEVEL3[0][0];
-        c.windowSize = 1 << c.windowLog;
-        c.blockSize = MAX_BLOCK_SIZE;
-        c.chainLog = LEVEL3[0][1];
-        c.hashLog = LEVEL3[0][2];
-        return;
-    }
-    const int32_t inputSize = c.inLen;
-    const int table = inputSize <= 16 * 1024 ? 3 : (inputSize <= 128 * 1024 ? 2 : (inputSize <= 256 * 1024 ? 1 : 0));
-    int32_t windowLog = LEVEL3[table][0], chainLog = LEVEL3[table][1], hashLog = LEVEL3[table][2];
-    c.searchLength = LEVEL3[table][3];
-    const int32_t inputSizeLog = inputSize < 64 ? 6 : highest_bit((uint32_t)(inputSize - 1)) + 1;
-    if (windowLog > inputSizeLog) {
-        windowLog = inputSizeLog;
-    }
-    if (hashLog > windowLog + 1) {
-        hashLog = windowLog + 1;
-    }
-    if (chainLog > windowLog) {
-        chainLog -= (chainLog - windowLog);
-    }
-    if (windowLog < 10) {
-        windowLog = 10;
-    }
-    c.windowLog = windowLog;
-    c.windowSize = 1 << windowLog;
-    c.blockSize = c.windowSize < MAX_BLOCK_SIZE ? c.windowSize : MAX_BLOCK_SIZE;
-    c.chainLog = chainLog;
-    c.hashLog = hashLog;
-}
-
-// Two-kernel path (inputs of one block, 7..128 KiB -- BASELINE configs[3] / [4]): the match finder is 84-98 % of the
-// encoder's time and needs neither the entropy stage's LDS nor most of its registers, so it runs as its own kernel with
-// more wavefronts per CU; its results (sequence store, literals, the two candidate repeat offsets) wait in the item's
-// scratch for the entropy kernel.  Larger inputs stay in the one kernel: whether block k's repeat offsets are committed
-// depends on block k's entropy outcome (ZstdFrameCompressor.java:246-258), so their match finding cannot run ahead.
-// the match kernel's record (first 256 bytes of an item's scratch): valid, sequenceCount, literalsLength, longLengthField, longLengthPosition, tempOffset0, tempOffset1
-__device__ __forceinline__ bool split_eligible(int32_t inLen) { return inLen >= 7 && inLen <= MAX_BLOCK_SIZE; }
-
-__device__ int32_t zstd_compress_item(Ctx& c, Shared& sh)
-{
-    const int32_t inputSize = c.inLen;
-    const int32_t outputLimit = c.outCap;
-    int32_t output = 0;
-    if (c.streamMode && inputSize >= STREAM_MAX_BUFFER) {
-        // ZstdOutputStream.java:122-131: a write() that fills the 4 MiB buffer is flushed before close() -- a frame header without the
-        // content size, the window slid between chunks (and, the window base staying behind, blocks that find no match: DESIGN 10 row 3).
-        // Below that size close() writes everything as ONE chunk, which is this function with the stream's parameters.
-        c.failStatus = mk_status(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_UNSUPPORTED);
-        return -1;
-    }
-    compute_parameters(c);
-    ZC_CHECK(c, outputLimit - output >= 4);  // writeMagic :55-61
-    st4(c.out + output, 0xFD2FB528u);
-    output += 4;
-    ZC_CHECK(c, outputLimit - output >= 14);  // writeFrameHeader :64-121
-    {
-        const int32_t contentSizeDescriptor = (inputSize >= 256 ? 1 : 0) + (inputSize >= 65536 + 256 ? 1 : 0);
-        int32_t fhd = (contentSizeDescriptor << 6) | 0x04;
-        const bool singleSegment = c.windowSize >= inputSize;
-        if (singleSegment) {
-            fhd |= 0x20;
-        }
-        c.out[output++] = (uint8_t)fhd;
-        if (!singleSegment) {
-            c.out[output++] = (uint8_t)((c.windowLog - 10) << 3);  // window sizes here are powers of two: mantissa 0
-        }
-        if (contentSizeDescriptor == 0) {
-            if (singleSegment) {
-                c.out[output++] = (uint8_t)inputSize;
-            }
-        }
-        else if (contentSizeDescriptor == 1) {
-            st2(c.out + output, (uint32_t)(inputSize - 256));
-            output += 2;
-        }
-        else {
-            st4(c.out + output, (uint32_t)inputSize);
-            output += 4;
-        }
-    }
-    // compressFrame :152-179 with a fresh CompressionContext
-    {
-        c.offset0 = 1;
-        c.offset1 = 4;
-        c.tempOffset0 = c.tempOffset1 = 0;
-        c.windowBaseOffset = 0;
-        if (c.pre == nullptr) {  // (with a precomputed record the match finder -- and its tables -- already ran elsewhere)
-            wave_fill((uint8_t*)c.hashTable, 0, 4 << c.hashLog, c.lane);
-            wave_fill((uint8_t*)c.chainTable, 0, 4 << c.chainLog, c.lane);
-        }
-        for (int i = c.lane; i < 256; i += 64) {
-            sh.huf[0].numberOfBits[i] = 0;
-            sh.huf[1].numberOfBits[i] = 0;
-        }
-        sh.huf[0].maxSymbol = 0;
-        sh.huf[0].maxNumberOfBits = 0;
-        sh.huf[1].maxSymbol = 0;
-        sh.huf[1].maxNumberOfBits = 0;
-        c.previousTable = 0;
-        c.temporaryTable = 1;
-        c.previousCandidate = 0;
-        c.temporaryCandidate = 1;
-        __syncthreads();
-        wave_mem_order();
-        int32_t blockSize = c.blockSize;
-        int32_t outputSize = outputLimit - output;
-        int32_t remaining = inputSize;
-        int32_t input = 0;
-        do {
-            ZC_CHECK(c, outputSize >= 3 + 3);
-            const bool lastBlock = blockSize >= remaining;
-            blockSize = blockSize < remaining ? blockSize : remaining;
-            int32_t compressedSize = 0;  // writeCompressedBlock :181-204
-            if (blockSize > 0) {
-                compressedSize = compress_block(c, sh, input, blockSize, output + 3, outputSize - 3);
-                ZC_PROPAGATE(compressedSize);
-            }
-            if (compressedSize == 0) {
-                ZC_CHECK(c, blockSize + 3 <= outputSize);
-                st_le(c.out + output, (uint32_t)((lastBlock ? 1 : 0) | (0 << 1) | (blockSize << 3)), 3);
-                wave_mem_order();
-                group_copy<64>(c.out + output + 3, c.in + input, blockSize, c.lane);
-                wave_mem_order();
-                compressedSize = 3 + blockSize;
-            }
-            else {
-                st_le(c.out + output, (uint32_t)((lastBlock ? 1 : 0) | (2 << 1) | (compressedSize << 3)), 3);
-                compressedSize += 3;
-            }
-            input += blockSize;
-            remaining -= blockSize;
-            output += compressedSize;
-            outputSize -= compressedSize;
-        } while (remaining > 0);
-    }
-    ZC_CHECK(c, outputLimit - output >= 4);  // writeChecksum :123-134
-    const uint64_t hash = wave_xxh64(c.in, inputSize, c.lane);
-    st4(c.out + output, (uint32_t)hash);
-    output += 4;
-    return output;
-}
-
-}  // namespace zc
 
 namespace zc {
 // per-item scratch of the two-kernel path: [record | seqOffset | seqLitLen | seqMatchLen | literals]
@@ -1763,7 +67,6 @@ __global__ __launch_bounds__(64) void zstd_match_kernel(BatchArgs a, uint8_t* ta
         c.lane = lane;
         c.dbgStage = 0;
         c.batchProbe = batchProbe;
-        c.streamMode = 0;
         c.failStatus = 0;
         c.pre = nullptr;
         if (!split_eligible(c.inLen)) {
@@ -1833,7 +136,6 @@ __global__ __launch_bounds__(64) void zstd_compress_kernel(BatchArgs a, uint8_t*
         c.lane = lane;
         c.dbgStage = a.ringPad == 999 ? 1 : 0;
         c.batchProbe = a.ringPad == 1 ? 0 : 1;  // variant 1 = serial probing
-        c.streamMode = a.ringPad == 2 ? 1 : 0;  // (launch_zstd_compress: the stream op)
         c.failStatus = 0;
         c.pre = nullptr;
         uint8_t* p = slab;
@@ -1895,15 +197,11 @@ int64_t zstd_compress_scratch_bytes(int32_t nBlocks)
 
 // variant 0 (default): match-finder kernel + entropy kernel for one-block inputs, one kernel for the rest; 1: the same with
 // serial probing; 2: everything in the one kernel; 100: timing aid (one kernel, stop after the match finder)
-// a.ringPad == 2: the items are ZstdOutputStream inputs (the stream's parameters; the one kernel for every size)
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant)
 {
     (void)scratchBytes;
     if (a.nBlocks <= 0) {
         return hipSuccess;
-    }
-    if (a.ringPad == 2) {
-        variant = 2;
     }
     uint8_t* base = (uint8_t*)scratch;
     int32_t* counter = (int32_t*)base;
