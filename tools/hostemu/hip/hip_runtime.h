@@ -34,6 +34,15 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+// streams and events do not exist here: everything runs in launch order
+typedef void* hipEvent_t;
+#define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
+inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 
 namespace hostemu {
 
