@@ -373,13 +373,7 @@ hipError_t launch_seq_execute2(const BatchArgs& a, hipStream_t stream, const sx:
 
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 
-namespace {
-// two helper streams per host thread and device, for the split below
-struct SplitStreams {
-    int device = -1;
-    hipStream_t s[2] = {nullptr, nullptr};
-    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
-};
+// two helper streams per host thread and device, for the split below (also used by snappy_decompress_v5.hip)
 SplitStreams* split_streams()
 {
     static thread_local SplitStreams st;
@@ -400,7 +394,6 @@ SplitStreams* split_streams()
     }
     return &st;
 }
-}  // namespace
 
 // execVariant 302 .. 308 (an experiment for the next round -- written without a GPU at hand, functionally checked on the CPU emulator, where
 // streams do not exist): the product's two passes over the batch cut into 2 .. 8 parts that alternate between two helper streams, so that

@@ -31,8 +31,8 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
         const int64_t bytes = tiny ? 4096 + ((n * 12 + 4095) & ~4095LL) + 4 * 4096 : achip::lz4_twopass_scratch_bytes(n);
         scratch.assign((size_t)bytes, 0xCD);
         a.ringPad = 16;
-        // (op 24 with more than 192 blocks: the split of execVariant 303 -- three parts -- is exercised too)
-        return snappy ? achip::launch_snappy_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, 2, nullptr)
+        // (ops 24 / 34 with more than 192 blocks: the split of execVariant 303 -- three parts -- is exercised too)
+        return snappy ? achip::launch_snappy_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, op == 34 && n >= 192 ? 303 : 2, nullptr)
                       : achip::launch_lz4_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, op == 24 && n >= 192 ? 303 : 2, nullptr);
     }
     if (op == 19) return achip::launch_snappy_decompress_lanewindow(a, nullptr, nullptr);
