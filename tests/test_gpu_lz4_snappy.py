@@ -2,6 +2,7 @@
 bit-exact plaintext on decode, bit-exact compressed streams on encode, identical status/offset on the
 reference's error vectors.  Mirrors T/AbstractTestCompression.java's conformance cases."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -255,6 +256,30 @@ def test_large_inputs_single_block(gb, o, codec):
     assert outs[1] == o.compress(codec, big[:70000])
     plain, status, _ = gb.run(CODECS[codec]["d"], outs, [len(big), 70000])
     assert status == [0, 0] and plain[0] == big and plain[1] == big[:70000]
+
+
+@pytest.mark.skipif(not os.environ.get("ACHIP_TEST_EXPERIMENTAL"), reason="experiment for the next round (two-pass decode cut into parts over two helper streams): set ACHIP_TEST_EXPERIMENTAL=1")
+@pytest.mark.parametrize("codec", ["lz4", "snappy"])
+@pytest.mark.parametrize("parts", [2, 3, 8])
+def test_two_pass_decode_in_parts_over_two_streams(o, codec, parts):
+    """exec variants 302 .. 308 (lz4_decompress_v7.hip): same plaintext, status and offsets as the oracle, damaged blocks included"""
+    from tests.gpu_harness import GpuBatch
+    g = GpuBatch(0, options={"%s.decompress.variant" % codec: 7, "decompress.exec_variant": 300 + parts})
+    rng = np.random.default_rng(parts)
+    blocks = [d for _, d, _ in common.corpus_sample()] * 40 + common.synthetic_blocks(9, 40)   # ~800 blocks: every part holds whole wavefronts of the parser
+    comp = [o.compress(codec, b) for b in blocks]
+    for k in range(0, len(comp), 37):  # damage some
+        m = bytearray(comp[k])
+        m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+        comp[k] = bytes(m)
+    outs, status, err = g.run(CODECS[codec]["d"], comp, [len(b) for b in blocks])
+    for i, (c, b) in enumerate(zip(comp, blocks)):
+        try:
+            want = o.decompress(codec, c, len(b)); est, eoff = 0, 0
+        except oracle_lib.OracleError as e:
+            want, est, eoff = None, e.status, e.offset
+        assert status[i] == est, (i, status[i], est)
+        assert (outs[i] == want) if est == 0 else (err[i] == eoff), i
 
 
 def test_single_block_host_api_mirrors_reference_interface(o):
