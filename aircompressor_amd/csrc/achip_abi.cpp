@@ -50,7 +50,7 @@ int64_t hadoop_decompress_scratch_bytes(int32_t nStreams, int32_t bufferSize);
 hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize);
 int64_t hadoop_compress_scratch_bytes(int32_t nStreams);
 extern int g_zstd_pipe_exec;
-extern int g_zstd_pipe_lit_items, g_zstd_pipe_seq_items;
+extern int g_zstd_pipe_lit_items, g_zstd_pipe_seq_items, g_zstd_pipe_exec_window;
 hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant, const AuxScratch* aux);
 int64_t lz4frame_decompress_scratch_bytes(int32_t nItems, int variant);
 hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch);
@@ -760,6 +760,10 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->zstdTile = (int)value;
     }
     else if (k == "debug.scratch_poison") ctx->scratchPoison = (int)value;
+    else if (k == "zstd.decompress.exec_window") {  // (process-wide development switch)
+        if (value != 4096 && value != 8192) return bad_argument("the record executor's window: 4096 or 8192");
+        achip::g_zstd_pipe_exec_window = (int)value;
+    }
     else if (k == "zstd.decompress.lit_items" || k == "zstd.decompress.seq_items") {  // (process-wide development switches, like zstd.decompress.exec)
         if (value != 8 && value != 16) return bad_argument("items per wavefront: 8 or 16");
         (k == "zstd.decompress.lit_items" ? achip::g_zstd_pipe_lit_items : achip::g_zstd_pipe_seq_items) = (int)value;

@@ -38,7 +38,12 @@ using sx::wave_bcast;
 using sx::wave_scan_incl;
 
 constexpr int WIN_DEFAULT = 4096;
-constexpr int CAP = 1024;  // output bytes of one batch (a record is at most 32: a batch always takes at least 32 records)
+constexpr int CAP = 1024;  // output bytes of one batch at the default window (a record is at most 32: a batch always takes at least 32 records)
+// a batch may hold a quarter of the window (the far-match rule below wants everything older than WIN - CAP bytes flushed two batches ago);
+// at 8 KiB 64 pieces of 32 bytes always fit a batch
+template <int WIN>
+constexpr int cap_of() { return WIN / 4; }
+static_assert(cap_of<WIN_DEFAULT>() == CAP, "the default window's batch");
 
 struct Batch {
     int32_t lit, ml, off;
@@ -324,7 +329,7 @@ __device__ __forceinline__ void exec_block(uint8_t* win, const uint8_t* __restri
         const int32_t off = rec_off(r), skip = rec_skip(r);
         const int32_t tot = lit + ml, adv = skip + lit;
         const int32_t oEnd = wave_scan_incl(tot, lane), sEnd = wave_scan_incl(adv, lane);
-        int32_t k = (int32_t)__popcll(__ballot(lane < nb && oEnd <= CAP));  // a prefix: oEnd is monotone (>= 1: a piece is <= 32 bytes)
+        int32_t k = (int32_t)__popcll(__ballot(lane < nb && oEnd <= cap_of<WIN>()));  // a prefix: oEnd is monotone (>= 1: a piece is <= 32 bytes)
         k = k < 1 ? 1 : k;
         if (lane >= k) {
             lit = 0;
@@ -545,7 +550,7 @@ __device__ __forceinline__ int32_t exec_records(uint8_t* win, const RecordSource
         }
         const int32_t pOut = wave_bcast(dst, 0);  // (lane 0 is always valid)
         const int32_t endRel = dst + pl + pm - pOut;
-        int32_t k = (int32_t)__popcll(__ballot(valid && endRel <= CAP));  // a prefix: the pieces are contiguous and ordered
+        int32_t k = (int32_t)__popcll(__ballot(valid && endRel <= cap_of<WIN>()));  // a prefix: the pieces are contiguous and ordered
         k = k < 1 ? 1 : k;
         if (lane >= k) {
             pl = 0;

@@ -1055,12 +1055,14 @@ __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp:
 // item's capacity over its sequence count is what both kernels can see (an upper bound of the bytes per sequence: a caller that hands over far
 // more capacity than the frame needs gets the ring version).
 int g_zstd_pipe_exec = 2;  // context option zstd.decompress.exec: 2 = per item (default), 1 = this kernel, 0 = the ring version above
+int g_zstd_pipe_exec_window = 4096;  // option zstd.decompress.exec_window: 4096 (default) or 8192 -- the record executor's LDS window, and with it batches of up to 2 KiB (unmeasured)
 int g_zstd_pipe_lit_items = 16, g_zstd_pipe_seq_items = 16;  // options zstd.decompress.lit_items / seq_items: 16 (default) or 8 items per wavefront in K2 / K3 (unmeasured)
 
+template <int WIN = sx2::WIN_DEFAULT>
 __global__ __launch_bounds__(64) void zstd_pipe_execute2_kernel(BatchArgs a, zp::Pipe p, int32_t mode)
 {
     using namespace zp;
-    __shared__ __attribute__((aligned(16))) uint8_t win[sx2::WIN_DEFAULT + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t win[WIN + 16];
     const int32_t slot = blockIdx.x;
     if (slot >= p.count) {
         return;
@@ -1079,7 +1081,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_execute2_kernel(BatchArgs a, zp:
     const uint8_t* lit = d.litMode == 0 ? src + d.litSrc : p.lit + (size_t)d.litBase * 64;
     sx2::RecordSource S{p.seq + d.seqBase, d.nDecoded};
     bool bad = false;
-    const int32_t output = sx2::exec_records<0>(win, S, lit, d.litSize, out, a.dstCap[block], lane, bad);
+    const int32_t output = sx2::exec_records<0, WIN>(win, S, lit, d.litSize, out, a.dstCap[block], lane, bad);
     if (lane == 0) {
         if (bad) {
             to_fallback(p, slot, 4);
@@ -1452,10 +1454,11 @@ __global__ __launch_bounds__(64) void zstd_mb_parse_kernel(BatchArgs a, zp::Pipe
 }
 
 // K4 for multi-block frames: a wavefront per item
+template <int WIN = sx2::WIN_DEFAULT>
 __global__ __launch_bounds__(64) void zstd_mb_execute_kernel(BatchArgs a, zp::Pipe p)
 {
     using namespace zp;
-    __shared__ __attribute__((aligned(16))) uint8_t win[sx2::WIN_DEFAULT + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t win[WIN + 16];
     const int32_t j = p.itemFirst + blockIdx.x;
     const MbItem it = p.mbItem[j];
     if (!mb_in_pass(p, it, j)) {
@@ -1478,7 +1481,7 @@ __global__ __launch_bounds__(64) void zstd_mb_execute_kernel(BatchArgs a, zp::Pi
         }
         const uint8_t* lit = d.litMode == 0 ? src + d.litSrc : p.lit + (size_t)d.litBase * 64;
         sx2::RecordSource S{p.seq + d.seqBase, d.nDecoded, rep0, rep1, rep2};
-        output = sx2::exec_records<0>(win, S, lit, d.litSize, out, outLimit, lane, bad, output);
+        output = sx2::exec_records<0, WIN>(win, S, lit, d.litSize, out, outLimit, lane, bad, output);
         const int32_t n0 = sx2::rep_resolve(b.repOut[0], rep0, rep1, rep2), n1 = sx2::rep_resolve(b.repOut[1], rep0, rep1, rep2), n2 = sx2::rep_resolve(b.repOut[2], rep0, rep1, rep2);
         rep0 = n0;
         rep1 = n1;
@@ -1725,7 +1728,12 @@ hipError_t launch_zstd_mb_stages(const BatchArgs& a, hipStream_t stream, zp::Pip
         hipLaunchKernelGGL(zstd_mb_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
         hipLaunchKernelGGL(zstd_pipe_literals_kernel<true>, dim3(w16), dim3(64), 0, stream, a, p);
         hipLaunchKernelGGL(zstd_pipe_sequences_kernel<true>, dim3(w16), dim3(64), 0, stream, a, p);
-        hipLaunchKernelGGL(zstd_mb_execute_kernel, dim3(nItems), dim3(64), 0, stream, a, p);
+        if (g_zstd_pipe_exec_window == 8192) {
+            hipLaunchKernelGGL(zstd_mb_execute_kernel<8192>, dim3(nItems), dim3(64), 0, stream, a, p);
+        }
+        else {
+            hipLaunchKernelGGL(zstd_mb_execute_kernel<>, dim3(nItems), dim3(64), 0, stream, a, p);
+        }
         hipLaunchKernelGGL(zstd_mb_checksum_kernel, dim3((nItems + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE), dim3(64), 0, stream, a, p);
     }
     return hipGetLastError();
@@ -1788,7 +1796,12 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
         }
         constexpr int GS = 4, IN_RING = 128, OUT_RING = 256;
         if (g_zstd_pipe_exec != 0) {
-            hipLaunchKernelGGL(zstd_pipe_execute2_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, (int32_t)g_zstd_pipe_exec);
+            if (g_zstd_pipe_exec_window == 8192) {
+                hipLaunchKernelGGL(zstd_pipe_execute2_kernel<8192>, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, (int32_t)g_zstd_pipe_exec);
+            }
+            else {
+                hipLaunchKernelGGL(zstd_pipe_execute2_kernel<>, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, (int32_t)g_zstd_pipe_exec);
+            }
         }
         if (g_zstd_pipe_exec != 1) {
             hipLaunchKernelGGL((zstd_pipe_execute_kernel<GS, IN_RING, OUT_RING>), dim3((unsigned)((p.count + 256 / GS - 1) / (256 / GS))), dim3(256), (size_t)(256 / GS) * (IN_RING + OUT_RING + a.ringPad), stream, a, p, (int32_t)g_zstd_pipe_exec);

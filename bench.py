@@ -60,6 +60,7 @@ def parse_args():
     p.add_argument("--snappyframed-variant", type=int, default=-1, help="x-snappy-framed reader: 1 = chunks through the ring decoders (default), 2 = through the two-pass decoder (unmeasured), 0 = a wavefront per stream")
     p.add_argument("--lz4frame-variant", type=int, default=-1, help="LZ4 frame reader: 0 = a wavefront per item (default), 1 = the frames' blocks as one batch through the two-pass block decoder (unmeasured)")
     p.add_argument("--hadoop-variant", type=int, default=-1, help="Hadoop block-stream reader: 1 = chunks through the ring decoders (default), 2 = through the two-pass decoders (unmeasured), 0 = a wavefront per stream")
+    p.add_argument("--zstd-exec-window", type=int, default=-1, help="zstd record executor: LDS window 4096 (default) or 8192 with batches of up to 2 KiB (unmeasured experiment)")
     p.add_argument("--zstd-lit-items", type=int, default=-1, help="zstd pipeline literal stage: items per wavefront, 16 (default) or 8 (unmeasured experiment)")
     p.add_argument("--zstd-seq-items", type=int, default=-1, help="zstd pipeline sequence stage: items per wavefront, 16 (default) or 8 (unmeasured experiment)")
     p.add_argument("--zstd-variant", type=int, default=-1, help="zstd decoder: 1 = five-stage pipeline (default), 0 = one-kernel decoder")
@@ -609,6 +610,8 @@ def zstd_extra(torch, A, codec, dev, args):
         codec.native.set_option("zstd.decompress.variant", args.zstd_variant)
     if args.zstd_exec >= 0:
         codec.native.set_option("zstd.decompress.exec", args.zstd_exec)
+    if args.zstd_exec_window >= 0:
+        codec.native.set_option("zstd.decompress.exec_window", args.zstd_exec_window)
     if args.zstd_lit_items >= 0:
         codec.native.set_option("zstd.decompress.lit_items", args.zstd_lit_items)
     if args.zstd_seq_items >= 0:

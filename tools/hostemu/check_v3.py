@@ -74,7 +74,8 @@ def cases_for(codec):
 
 
 def main():
-    for codec, ops in (("lz4", (16, 17, 18, 24, 25)), ("snappy", (12, 13, 19, 34, 35))):
+    # (26 / 36: the two-pass decoders with the executor's 8 KiB window and 2 KiB batches -- exec variant 124, an experiment)
+    for codec, ops in (("lz4", (16, 17, 18, 24, 25, 26)), ("snappy", (12, 13, 19, 34, 35, 36))):
         cases = cases_for(codec)
         for op in ops:
             if emu.emu_batch(op, None, None, None, None, None, None, None, None, None, 0) != 0:
