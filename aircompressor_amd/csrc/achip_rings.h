@@ -43,6 +43,18 @@ struct Rings {
     // for every path any of its blocks takes: on text that was ~785 wave instructions per 16 sequences.
     static constexpr bool UNIFIED = GS == 4 && GPL == 1;
 
+    // The lanes of a group hand bytes to each other through the rings.  On the device they run in lockstep and a wavefront's memory
+    // operations are performed in order: order() only has to keep the compiler from moving loads over stores, enter() is nothing.
+    // tools/hostemu runs lanes as fibers: with HOSTEMU_RINGS_LOCKSTEP both become a rendezvous of the GROUP, which restores what the
+    // code relies on -- nobody reads before everybody has written (order), nobody writes before everybody has read (enter).
+#if !defined(__HIPCC__) && defined(HOSTEMU_RINGS_LOCKSTEP)
+    __device__ __forceinline__ void order() const { if (GS > 1) hostemu::group_sync(GS, __FILE__, __LINE__); }
+    __device__ __forceinline__ void enter() const { if (GS > 1) hostemu::group_sync(GS, __FILE__, __LINE__); }
+#else
+    __device__ __forceinline__ void order() const { wave_mem_order(); }
+    __device__ __forceinline__ void enter() const {}
+#endif
+
     __device__ __forceinline__ void init(uint8_t* ldsIn, uint8_t* ldsOut, const uint8_t* in, int32_t inLimit, uint8_t* out, int lane, uint8_t* ldsStage = nullptr)
     {
         inRing = ldsIn;
@@ -65,11 +77,12 @@ struct Rings {
     // switch the input ring to a new source stream (Zstd: literals of the next block, a raw block, ...)
     __device__ __forceinline__ void reset_input(const uint8_t* in, int32_t inLimit)
     {
+        enter();
         inBase = (int32_t)((uintptr_t)in & 15);
         inAligned = in - inBase;
         inEndV = inLimit + inBase;
         inLoadedV = 0;
-        wave_mem_order();
+        order();
 #pragma unroll
         for (int q = 0; q < GPL; q++) {
             pending[q] = fetch_granule(16 * (g + GS * q));
@@ -111,11 +124,12 @@ struct Rings {
     // make input bytes [pos, pos+need) readable from the ring (need <= CHUNK); bytes past the input end read as 0
     __device__ __forceinline__ void ensure_input(int32_t pos, int32_t need)
     {
+        enter();
         const int32_t want = pos + inBase + need;
         while (want > inLoadedV && inLoadedV < inEndV) {
             refill();
         }
-        wave_mem_order();
+        order();
     }
     __device__ __forceinline__ uint32_t in_u8(int32_t pos) const { return inRing[(pos + inBase) & (IN_RING - 1)]; }
 
@@ -154,6 +168,7 @@ struct Rings {
     __device__ __forceinline__ void copy_small(const uint8_t* src, int32_t sV, int32_t dV, int32_t n)
     {
         const uint32_t w = ring_ld4<SRC_RING>(src, sV + 4 * g);
+        enter();
         put4(dV + 4 * g, w, n - 4 * g);
     }
 
@@ -183,6 +198,7 @@ struct Rings {
                 hb[k] = src[(sV + k) & mask];
             }
         }
+        enter();  // (every lane has read before any lane writes: on the device the loads above are issued before the stores below)
 #pragma unroll
         for (int q = 0; q < ITER; q++) {
             *(uint32_t*)(outRing + ((dV + head + 4 * (g + GS * q)) & (OUT_RING - 1))) = w[q];
@@ -202,8 +218,9 @@ struct Rings {
     // flush every complete CHUNK below position `op` (absolute)
     __device__ __forceinline__ void flush_complete(int32_t op)
     {
+        enter();
         const int32_t opV = op + outBase;
-        wave_mem_order();
+        order();
         while (flushedV + CHUNK <= opV) {
 #pragma unroll
             for (int q = 0; q < GPL; q++) {
@@ -219,7 +236,7 @@ struct Rings {
             }
             flushedV += CHUNK;
         }
-        wave_mem_order();
+        order();
     }
     // flush everything up to `op` (end of block)
     __device__ __forceinline__ void flush_all(int32_t op)
@@ -243,12 +260,13 @@ struct Rings {
             }
         }
         flushedV = opV & ~15;  // stays granule-aligned: a later flush re-stores the partial granule from the ring, whole
-        wave_mem_order();
+        order();
     }
 
     // n copies of one byte (Zstd RLE blocks)
     __device__ __forceinline__ void fill(int32_t op, uint32_t value, int32_t n)
     {
+        enter();
         while (n > 0) {
             const int32_t c = n < CHUNK ? n : CHUNK;
             for (int32_t k = g; k < c; k += GS) {
@@ -263,6 +281,7 @@ struct Rings {
     // literals: n input bytes at ip -> output at op (n arbitrary; input ring refilled, output flushed as we go)
     __device__ __forceinline__ void copy_literals(int32_t ip, int32_t op, int32_t n)
     {
+        enter();
         if (UNIFIED && n > 4 * GS) {
             while (n > 0) {
                 const int32_t c = n < CHUNK ? n : CHUNK;
@@ -305,6 +324,7 @@ struct Rings {
     // offsets the period is folded so all sources lie BEFORE the chunk (no intra-chunk dependency).
     __device__ __forceinline__ void copy_match(int32_t op, int32_t offset, int32_t n)
     {
+        enter();
         if (UNIFIED && !(n <= 4 * GS && offset >= n)) {
             if (stage != nullptr) {
                 // A trip never reads what it writes (c <= dist); a distance shorter than a chunk doubles once a whole
@@ -313,7 +333,7 @@ struct Rings {
                 while (n > 0) {
                     int32_t c = n < CHUNK ? n : CHUNK;
                     c = c < dist ? c : dist;
-                    wave_mem_order();
+                    order();
                     if (dist <= LDS_REACH) {
                         copy_dwords<OUT_RING>(outRing, op + outBase - dist, op + outBase, c);
                     }
@@ -321,7 +341,7 @@ struct Rings {
                         // flushed long ago (dist > LDS_REACH >= 2 * CHUNK): 64 source bytes land in the staging area,
                         // then the same move as every other copy.  Reading past c stays inside this block's output.
                         *(u32x4*)(stage + 16 * g) = ld16(outAligned + outBase + (op - dist) + 16 * g);
-                        wave_mem_order();
+                        order();
                         copy_dwords<CHUNK>(stage, 0, op + outBase, c);
                     }
                     op += c;
@@ -335,7 +355,7 @@ struct Rings {
             }
         }
         if (n <= 4 * GS && offset >= n) {
-            wave_mem_order();
+            order();
             if (offset <= LDS_REACH) {
                 copy_small<OUT_RING>(outRing, op + outBase - offset, op + outBase, n);
             }
@@ -348,7 +368,7 @@ struct Rings {
         int32_t c0 = op;
         while (n > 0) {
             const int32_t c = n < CHUNK ? n : CHUNK;
-            wave_mem_order();
+            order();
             if (offset <= LDS_REACH) {
                 if (offset >= c && c <= (GS > 4 ? GS : 4)) {
                     for (int32_t j = g; j < c; j += GS) {

@@ -45,7 +45,8 @@ def test_zstd_code_arithmetic_equals_the_java_tables():
 
 def test_lane_private_decoder_kernels_on_the_cpu():
     """The kernel sources compiled for the host and run under tools/hostemu (every thread a fiber, cross-lane operations as rendezvous, lanes
-    in a different order from pass to pass): the one-lane-per-block (GS = 1) instantiations of the ring decoders, the lane-per-block decoders
+    in a different order from pass to pass): the ring decoders with one lane per block and -- the product's default, the headline's kernel --
+    with FOUR lanes per block (the lanes of a group meet at the emulator-only lockstep points of achip_rings.h), the lane-per-block decoders
     with an LDS window, and the cooperative two-pass decoders (parse to records + a wavefront per block; also with an arena so small that blocks
     fall back) -- plaintext, status, error offset and guard bands against the oracle, on the cases of the GPU parity suite, without a GPU."""
     import shutil

@@ -1,5 +1,6 @@
 // tools/hostemu/emu.cpp -- runs the lane-private decoder kernels on the CPU (sequential lanes are exact when a kernel
 // uses no cross-lane operation: the GS=1 instantiations of the ring decoders and the lane-per-block decoders with an LDS window).
+#define HOSTEMU_RINGS_LOCKSTEP 1  // achip_rings.h: the lanes of a group meet where the device's lockstep makes them meet
 #include "hip/hip_runtime.h"
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 extern "C" { long long achip_emu_counters[16]; }  // development counters of kernels under emulation (ACHIP_EMU_COUNT)
@@ -44,6 +45,13 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
     if (op == 12 || op == 13) {
         a.ringPad = 16;
         return achip::launch_snappy_decompress_rings(a, nullptr, 1, op - 12, nullptr);
+    }
+    // the ring decoders with a lane GROUP per block (the product's shape: 4 lanes; 16 and 64 for large blocks): 44 / 46 / 48 LZ4, 54 / 56 / 58
+    // Snappy; the product's ring padding (80 bytes: the staging area of far matches included)
+    if (op == 44 || op == 46 || op == 48 || op == 54 || op == 56 || op == 58) {
+        a.ringPad = 80;
+        const int gs = (op % 10) == 4 ? 4 : ((op % 10) == 6 ? 16 : 64);
+        return op < 50 ? achip::launch_lz4_decompress_rings(a, nullptr, gs, 0, nullptr) : achip::launch_snappy_decompress_rings(a, nullptr, gs, 0, nullptr);
     }
     return -1;
 }

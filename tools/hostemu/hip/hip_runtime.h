@@ -9,6 +9,10 @@
 // barrier: a wavefront's memory operations are performed in program order; here it is a rendezvous).  A cross-lane operation reached
 // by only some lanes of a wave (at different source lines) is reported and aborts: such code would depend on EXEC-mask semantics that
 // this shim does not model.  Lane-private kernels (no cross-lane operation at all) simply run one lane after the other.
+// Kernels that give an item to an aligned GROUP of lanes (a quad: the Zstd sequence stage; 4 / 16 / 64 lanes: the ring decoders) have
+// rendezvous of the group: quad_bcast / quad_sync, and group_sync, which achip_rings.h places -- for this shim only, the device code is
+// untouched -- where the hardware's lockstep makes the lanes of a group meet: before anybody writes what somebody may still read, and
+// before anybody reads what somebody may still write (within one copy step too: all loads, then all stores).
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -48,7 +52,7 @@ namespace hostemu {
 
 constexpr int MAX_THREADS = 1024;
 constexpr size_t STACK_BYTES = 512 << 10;
-enum Wait { RUNNABLE = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, WAIT_QUAD = 3 };
+enum Wait { RUNNABLE = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, WAIT_QUAD = 3 };  // (WAIT_QUAD: an aligned group of Fiber::gsize lanes, 4 by default)
 
 struct Fiber {
     void* sp = nullptr;
@@ -58,6 +62,7 @@ struct Fiber {
     const char* file = nullptr;
     int line = 0;
     uint64_t post = 0;
+    int gsize = 4;  // group size of a WAIT_QUAD rendezvous
 };
 
 struct State {
@@ -137,7 +142,9 @@ inline void run_workgroup(int nThreads, const std::function<void()>& body)
         for (int t0 = 0; t0 < nThreads; t0++) {
             // lanes run in a different order from pass to pass (ascending, descending, interleaved): code that works only because a lower
             // lane happens to run first between two rendezvous is a race on the hardware and should fail here too
-            const int t = (pass & 3) == 0 ? t0 : ((pass & 3) == 1 ? nThreads - 1 - t0 : ((pass & 3) == 2 ? (t0 ^ 1) < nThreads ? (t0 ^ 1) : t0 : (t0 * 37 + 11) % nThreads));
+            static const int fixedOrder = getenv("HOSTEMU_ORDER") ? atoi(getenv("HOSTEMU_ORDER")) : -1;  // (diagnosis: one lane order for every pass)
+            const unsigned ord = fixedOrder >= 0 ? (unsigned)fixedOrder : (pass & 3);
+            const int t = ord == 0 ? t0 : (ord == 1 ? nThreads - 1 - t0 : (ord == 2 ? (t0 ^ 1) < nThreads ? (t0 ^ 1) : t0 : (t0 * 37 + 11) % nThreads));
             Fiber& f = s.f[t];
             if (f.done) continue;
             any = true;
@@ -194,11 +201,21 @@ inline void run_workgroup(int nThreads, const std::function<void()>& body)
         if (!blockReady) {
             // quad-level rendezvous (kernels that give an item to four lanes: the Zstd pipeline's sequence stage): the lanes of a quad that
             // are still running all wait at the same operation
-            for (int q = 0; q < nThreads; q += 4) {
+            for (int q = 0; q < nThreads;) {
+                // the group of the first lane at or behind q that waits at a group rendezvous decides the stride (groups are aligned)
+                int gs = 4;
+                for (int t = q; t < nThreads && t < q + 64; t++) {
+                    if (!s.f[t].done && s.f[t].wait == WAIT_QUAD) {
+                        gs = s.f[t].gsize;
+                        break;
+                    }
+                }
+                q &= ~(gs - 1);
+                const int qEnd = q + gs;
                 bool ready = true, some = false;
                 const char* file = nullptr;
                 int line = 0;
-                for (int t = q; t < q + 4 && t < nThreads; t++) {
+                for (int t = q; t < qEnd && t < nThreads; t++) {
                     Fiber& f = s.f[t];
                     if (f.done) continue;
                     if (f.wait != WAIT_QUAD) {
@@ -216,11 +233,12 @@ inline void run_workgroup(int nThreads, const std::function<void()>& body)
                     }
                 }
                 if (ready && some) {
-                    for (int t = q; t < q + 4 && t < nThreads; t++) {
+                    for (int t = q; t < qEnd && t < nThreads; t++) {
                         if (!s.f[t].done) s.f[t].wait = RUNNABLE;
                     }
                     released = true;
                 }
+                q = qEnd;
             }
         }
         if (!ran && !released) {
@@ -289,13 +307,16 @@ inline T shfl_from(T v, int srcLane, const char* file, int line)
     });
 }
 inline void wave_sync(const char* file, int line) { wait_here(WAIT_WAVE, file, line); }
-inline void quad_sync(const char* file, int line) { wait_here(WAIT_QUAD, file, line); }
+inline void quad_sync(const char* file, int line) { S().f[S().cur].gsize = 4; wait_here(WAIT_QUAD, file, line); }
+// rendezvous of the caller's aligned group of gs lanes (gs a power of two, at most 64): kernels that give a block to a lane group
+inline void group_sync(int gs, const char* file, int line) { S().f[S().cur].gsize = gs; wait_here(WAIT_QUAD, file, line); }
 // value of lane k of the caller's quad (DPP quad_perm broadcast); quad-uniform control flow is enough
 template <typename T>
 inline T quad_from(T v, int k, const char* file, int line)
 {
     State& s = S();
     s.f[s.cur].post = to_bits(v);
+    s.f[s.cur].gsize = 4;
     wait_here(WAIT_QUAD, file, line);
     const int t = (s.cur & ~3) + (k & 3);
     const T r = lane_active(t) ? from_bits<T>(s.f[t].post) : v;
