@@ -58,25 +58,31 @@ def test_lane_private_decoder_kernels_on_the_cpu():
     emu_dir = os.path.join(ROOT, "tools", "hostemu")
     subprocess.run([clang, "-O1", "-std=c++17", "-fPIC", "-shared", "-I", emu_dir, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "aircompressor_amd", "csrc"),
                     "-o", os.path.join(emu_dir, "libemu.so"), os.path.join(emu_dir, "emu.cpp")], check=True)
-    out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_v3.py"), "--quick"], check=True, capture_output=True, text=True, cwd=ROOT).stdout
-    lines = [l for l in out.splitlines() if "mismatches" in l]
-    assert lines and all(l.endswith(" 0 mismatches") for l in lines), out
-    # the executor for records of any length (the Zstd pipeline's execute stage): LZ4 blocks re-expressed as Zstd-style records + one literal
-    # buffer, executed under the emulator and compared with the plaintext; records that run outside their buffers must be refused
-    out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_records.py")], check=True, capture_output=True, text=True, cwd=ROOT).stdout
-    assert out.strip().endswith(" 0 mismatches"), out
-    # the Hadoop block-stream reader's variant 2 (walk, chunks through the two-pass decoders with an arena sized after the chunk count is read
-    # back, fold): LZ4 and Snappy streams at three buffer sizes against the plaintext
-    out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_hadoop.py")], check=True, capture_output=True, text=True, cwd=ROOT).stdout
-    lines = [l for l in out.splitlines() if "mismatches" in l]
-    assert len(lines) == 6 and all(l.endswith(" 0 mismatches") for l in lines), out
-    # the LZ4 frame reader's variant 1 (walk, the frames' blocks as one batch through the two-pass decoder, fold with stored blocks, content size
-    # and content checksum): the Java writer's frames and hand-built ones of 64 / 256 KiB blocks against the plaintext
-    out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_lz4frame.py")], check=True, capture_output=True, text=True, cwd=ROOT).stdout
-    assert out.strip().endswith(" 0 mismatches"), out
-    # the x-snappy-framed reader's variant 2 (walk, chunks through the two-pass Snappy decoder, CRC-32C verification, fold)
-    out = subprocess.run([sys.executable, os.path.join(emu_dir, "check_snappyframed.py")], check=True, capture_output=True, text=True, cwd=ROOT).stdout
-    assert out.strip().endswith(" 0 mismatches"), out
+    # the checks run side by side (separate processes; the library is read-only): check_v3.py in three parts by decoder family
+    def start(script, *args):
+        return subprocess.Popen([sys.executable, os.path.join(emu_dir, script), *args], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT)
+    jobs = {
+        "rings-1-lane": start("check_v3.py", "--quick", "--ops", "16,17,18,12,13,19"),
+        "two-pass": start("check_v3.py", "--quick", "--ops", "24,25,26,34,35,36"),
+        "rings-4-lanes": start("check_v3.py", "--quick", "--ops", "44,54"),
+        # the executor for records of any length (the Zstd pipeline's execute stage): LZ4 blocks re-expressed as Zstd-style records + one
+        # literal buffer, executed and compared with the plaintext; records that run outside their buffers must be refused
+        "records": start("check_records.py"),
+        # the Hadoop block-stream reader's variant 2 (walk, chunks through the two-pass decoders with an arena sized after the chunk count is
+        # read back, fold): LZ4 and Snappy streams at three buffer sizes against the plaintext
+        "hadoop": start("check_hadoop.py"),
+        # the LZ4 frame reader's variant 1 (walk, the frames' blocks as one batch through the two-pass decoder, fold with stored blocks,
+        # content size and content checksum): the Java writer's frames and hand-built ones of 64 / 256 KiB blocks against the plaintext
+        "lz4frame": start("check_lz4frame.py"),
+        # the x-snappy-framed reader's variant 2 (walk, chunks through the two-pass Snappy decoder, CRC-32C verification, fold)
+        "snappyframed": start("check_snappyframed.py"),
+    }
+    expected = {"rings-1-lane": 6, "two-pass": 6, "rings-4-lanes": 2, "records": 1, "hadoop": 6, "lz4frame": 1, "snappyframed": 1}
+    for name, job in jobs.items():
+        out = job.communicate()[0]
+        assert job.returncode == 0, (name, out)
+        lines = [l for l in out.splitlines() if "mismatches" in l]
+        assert len(lines) == expected[name] and all(l.endswith(" 0 mismatches") for l in lines), (name, out)
 
 
 def test_zstd_pipeline_kernels_on_the_cpu():
@@ -93,11 +99,14 @@ def test_zstd_pipeline_kernels_on_the_cpu():
     emu_dir = os.path.join(ROOT, "tools", "hostemu")
     subprocess.run([clang, "-O1", "-std=c++17", "-fPIC", "-shared", "-I", emu_dir, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "aircompressor_amd", "csrc"),
                     "-o", os.path.join(emu_dir, "libemu_zstd.so"), os.path.join(emu_dir, "emu_zstd.cpp")], check=True)
-    r = subprocess.run([sys.executable, os.path.join(emu_dir, "check_zstd.py"), "--quick"], capture_output=True, text=True, cwd=ROOT)
-    assert r.returncode == 0, r.stdout + r.stderr
-    lines = [l for l in r.stdout.splitlines() if "mismatches" in l]
-    assert len(lines) == 4 and all(" 0 mismatches" in l for l in lines), r.stdout
-    assert "fast 18, fallback list []" in r.stdout and "fast 17, fallback list [17]" in r.stdout, r.stdout  # (the smallest passes: the frame of ~260 short blocks has no room)
+    jobs = [subprocess.Popen([sys.executable, os.path.join(emu_dir, "check_zstd.py"), "--quick", "--part", part], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT)
+            for part in ("single", "multi", "damaged")]  # (side by side)
+    outs = [j.communicate()[0] for j in jobs]
+    assert all(j.returncode == 0 for j in jobs), "\n".join(outs)
+    out = "\n".join(outs)
+    lines = [l for l in out.splitlines() if "mismatches" in l]
+    assert len(lines) == 4 and all(" 0 mismatches" in l for l in lines), out
+    assert "fast 18, fallback list []" in out and "fast 17, fallback list [17]" in out, out  # (the smallest passes: the frame of ~260 short blocks has no room)
 
 
 def test_bench_java_random_generator_equals_the_oracles(oracle):

@@ -212,6 +212,11 @@ def main():
         k = sys.argv.index("--fuzz")
         sys.exit(1 if fuzz(int(sys.argv[k + 1]), int(sys.argv[k + 2]) if len(sys.argv) > k + 2 else 1) else 0)
     expect_fast = "--expect-fast" in sys.argv
+    part = sys.argv[sys.argv.index("--part") + 1] if "--part" in sys.argv else "all"  # single | multi | damaged | all
+    if part == "multi":
+        sys.exit(1 if multi_block(expect_fast) else 0)
+    if part == "damaged":
+        sys.exit(1 if mutations(expect_fast) else 0)
     plains = [d for _, d in common.HAND_CASES if len(d) > 0] + [d[:131072] for _, d, _ in common.corpus_sample()[:8]] + common.synthetic_blocks(5, 6)
     plains = [p for p in plains if len(p) <= 131072]
     bad = 0; slow = 0; total = 0
@@ -234,8 +239,9 @@ def main():
                     print("MISMATCH %s item %d (len %d): status %d" % (name, i, len(p), status[i]))
         print("%s: %d frames, fallback list %s" % (name, len(frames), fb))
     print("zstd pipeline: %d cases, %d mismatches, %d on the fallback list" % (total, bad, slow))
-    bad += multi_block(expect_fast)
-    bad += mutations(expect_fast)
+    if part == "all":
+        bad += multi_block(expect_fast)
+        bad += mutations(expect_fast)
     if bad or (expect_fast and slow):
         sys.exit(1)
 
