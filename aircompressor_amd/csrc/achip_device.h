@@ -127,7 +127,13 @@ __device__ __forceinline__ uint32_t alignbyte_u32(uint32_t hi, uint32_t lo, uint
 // may be produced by OTHER lanes of the same wave.  The hardware issues a wave's vector
 // memory instructions to the CU's L1/TA in program order, so keeping the compiler from
 // reordering across this point is sufficient inside one wave.
+#if !defined(__HIPCC__) && defined(HOSTEMU_ORDER_IS_RENDEZVOUS)
+// (tools/hostemu, translation units that hold only kernels running one item per WAVEFRONT in wave-uniform control flow -- the
+// wavefront-per-item readers of the containers, the one-kernel Zstd decoder: the hand-over point is a rendezvous of the wave there)
+#define wave_mem_order() hostemu::order_point(__FILE__, __LINE__)
+#else
 __device__ __forceinline__ void wave_mem_order() { asm volatile("" ::: "memory"); }
+#endif
 
 // The same ordering point for kernels whose lanes COOPERATE on one block: everything the lanes of this wave stored before it (LDS or
 // global) is visible to every lane after it.  On the device a compiler barrier is all it takes (a wavefront's memory operations are

@@ -109,6 +109,27 @@ def test_zstd_pipeline_kernels_on_the_cpu():
     assert "fast 18, fallback list []" in out and "fast 17, fallback list [17]" in out, out  # (the smallest passes: the frame of ~260 short blocks has no room)
 
 
+def test_wavefront_per_item_kernels_on_the_cpu():
+    """The wavefront-per-item kernels -- the LZ4 frame reader, the wavefront-per-stream readers of x-snappy-framed and Hadoop block streams,
+    the one-kernel Zstd decoder (what every irregular item falls back to) -- under tools/hostemu (libemu_serial.so: wave_mem_order() and the
+    rings' lockstep points are rendezvous there), driven by the GPU PARITY TESTS THEMSELVES through an emulator-backed harness
+    (tools/hostemu/emu_harness.py): the reference's LZ4 frame vectors, every branch of the Hadoop readers, the framed format's error cases,
+    the Zstd fixtures and corruptions -- output, status and error offset as the oracle has them.  (tools/hostemu/check_serial.py without
+    --quick runs the long tests too: liblz4 / libzstd frames, random corruption of every container.)"""
+    import shutil
+    import sys
+    import pytest
+    clang = shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("no clang++ for the host build of the kernel source")
+    emu_dir = os.path.join(ROOT, "tools", "hostemu")
+    subprocess.run([clang, "-O1", "-std=c++17", "-fPIC", "-shared", "-I", emu_dir, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "aircompressor_amd", "csrc"),
+                    "-o", os.path.join(emu_dir, "libemu_serial.so"), os.path.join(emu_dir, "emu_serial.cpp")], check=True)
+    r = subprocess.run([sys.executable, os.path.join(emu_dir, "check_serial.py"), "--quick"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "FAILED" not in r.stdout and r.stdout.strip().endswith("8 tests passed, 0 mismatches"), r.stdout
+
+
 def test_bench_java_random_generator_equals_the_oracles(oracle):
     """bench.py restates java.util.Random(301) + RandomGenerator in numpy (jump-ahead LCG) for its ratio sweep; the oracle's generator
     (oracle/misc.c, following T/snappy/RandomGenerator.java:25-74) is the checker."""

@@ -307,6 +307,7 @@ inline T shfl_from(T v, int srcLane, const char* file, int line)
     });
 }
 inline void wave_sync(const char* file, int line) { wait_here(WAIT_WAVE, file, line); }
+inline void order_point(const char* file, int line) { wait_here(WAIT_WAVE, file, line); }  // (wave_mem_order under HOSTEMU_ORDER_IS_RENDEZVOUS)
 inline void quad_sync(const char* file, int line) { S().f[S().cur].gsize = 4; wait_here(WAIT_QUAD, file, line); }
 // rendezvous of the caller's aligned group of gs lanes (gs a power of two, at most 64): kernels that give a block to a lane group
 inline void group_sync(int gs, const char* file, int line) { S().f[S().cur].gsize = gs; wait_here(WAIT_QUAD, file, line); }
