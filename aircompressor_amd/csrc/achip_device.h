@@ -131,6 +131,10 @@ __device__ __forceinline__ uint32_t alignbyte_u32(uint32_t hi, uint32_t lo, uint
 // (tools/hostemu, translation units that hold only kernels running one item per WAVEFRONT in wave-uniform control flow -- the
 // wavefront-per-item readers of the containers, the one-kernel Zstd decoder: the hand-over point is a rendezvous of the wave there)
 #define wave_mem_order() hostemu::order_point(__FILE__, __LINE__)
+#elif !defined(__HIPCC__) && defined(HOSTEMU_ORDER_IS_SOFT)
+// (tools/hostemu, any mix of kernels: the hand-over point is a pause until no lane of the wave can run further -- a barrier for code in
+// wave-uniform control flow, harmless for lanes that go their own ways)
+#define wave_mem_order() hostemu::soft_order_point(__FILE__, __LINE__)
 #else
 __device__ __forceinline__ void wave_mem_order() { asm volatile("" ::: "memory"); }
 #endif
@@ -181,6 +185,14 @@ inline int32_t quad_bcast(int32_t v)
     return hostemu::quad_from(v, K, __FILE__, __LINE__);
 }
 #define quad_sync() hostemu::quad_sync(__FILE__, __LINE__)
+#endif
+
+// the value lane k of the caller's GS-lane group holds (laneBase: the group's first lane within the wavefront).  A macro, so that the device
+// code is the plain __shfl expression; tools/hostemu makes it a rendezvous of the group only
+#if defined(__HIPCC__)
+#define ACHIP_GROUP_SHFL(GS, v, laneBase, k) __shfl((v), (laneBase) + (k))
+#else
+#define ACHIP_GROUP_SHFL(GS, v, laneBase, k) hostemu::group_from((v), (GS), (k), __FILE__, __LINE__)
 #endif
 
 // ---- group copy: n bytes, src and dst ranges do not overlap (or src+n <= dst) ----

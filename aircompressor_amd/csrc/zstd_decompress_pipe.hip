@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp:
         int32_t before = 0;
 #pragma unroll
         for (int k = 0; k < GS - 1; k++) {
-            const int32_t t = __shfl(myLL + myML, laneBase + k);
+            const int32_t t = ACHIP_GROUP_SHFL(GS, myLL + myML, laneBase, k);
             before += k < g ? t : 0;
         }
         const int32_t myMatchPos = output + before + myLL;
@@ -982,10 +982,10 @@ __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp:
             far = ld16(out + (myMatchPos - myOF));
         }
         for (int k = 0; k < n; k++) {
-            const int32_t ll = __shfl(myLL, laneBase + k);
-            const int32_t ml = __shfl(myML, laneBase + k);
-            const int32_t of = __shfl(myOF, laneBase + k);
-            const int32_t hasFar = __shfl(pre ? 1 : 0, laneBase + k);
+            const int32_t ll = ACHIP_GROUP_SHFL(GS, myLL, laneBase, k);
+            const int32_t ml = ACHIP_GROUP_SHFL(GS, myML, laneBase, k);
+            const int32_t of = ACHIP_GROUP_SHFL(GS, myOF, laneBase, k);
+            const int32_t hasFar = ACHIP_GROUP_SHFL(GS, pre ? 1 : 0, laneBase, k);
             // ZstdFrameDecompressor.java:491-496
             if ((int64_t)output + ll + ml > outLimit || literalsInput + ll > litSize || of > output + ll) {
                 bad = true;
@@ -999,7 +999,7 @@ __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp:
                 uint32_t mineW = 0;
 #pragma unroll
                 for (int q = 0; q < GS; q++) {
-                    const uint32_t t = (uint32_t)__shfl((int)(q == 0 ? far.x : (q == 1 ? far.y : (q == 2 ? far.z : far.w))), laneBase + k);
+                    const uint32_t t = (uint32_t)ACHIP_GROUP_SHFL(GS, (int)(q == 0 ? far.x : (q == 1 ? far.y : (q == 2 ? far.z : far.w))), laneBase, k);
                     mineW = g == q ? t : mineW;
                 }
                 const int32_t head = ml < 16 ? ml : 16;

@@ -130,6 +130,26 @@ def test_wavefront_per_item_kernels_on_the_cpu():
     assert "FAILED" not in r.stdout and r.stdout.strip().endswith("8 tests passed, 0 mismatches"), r.stdout
 
 
+def test_whole_decode_paths_on_the_cpu():
+    """Every decode kernel in ONE emulator library (tools/hostemu/libemu_all.so: the ring decoders, the two-pass decoders, the container
+    readers, the one-kernel Zstd decoder and the Zstd pipeline with its multi-block stages; wave_mem_order() is a soft order point there), so
+    that the product's own launch functions -- launch_hadoop_decompress, launch_lz4frame_decompress, launch_snappyframed_decompress,
+    launch_zstd_decompress with every reader variant, the experimental ones included -- run start to end on the CPU, driven by the GPU
+    parity tests themselves.  (tools/hostemu/check_serial.py --all without --quick runs the long tests too.)"""
+    import shutil
+    import sys
+    import pytest
+    clang = shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("no clang++ for the host build of the kernel source")
+    emu_dir = os.path.join(ROOT, "tools", "hostemu")
+    subprocess.run([clang, "-O1", "-std=c++17", "-fPIC", "-shared", "-I", emu_dir, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "aircompressor_amd", "csrc"),
+                    "-o", os.path.join(emu_dir, "libemu_all.so"), os.path.join(emu_dir, "emu_all.cpp")], check=True)
+    r = subprocess.run([sys.executable, os.path.join(emu_dir, "check_serial.py"), "--all", "--quick"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "FAILED" not in r.stdout and r.stdout.strip().endswith("19 tests passed, 0 mismatches"), r.stdout
+
+
 def test_bench_java_random_generator_equals_the_oracles(oracle):
     """bench.py restates java.util.Random(301) + RandomGenerator in numpy (jump-ahead LCG) for its ratio sweep; the oracle's generator
     (oracle/misc.c, following T/snappy/RandomGenerator.java:25-74) is the checker."""

@@ -1,11 +1,12 @@
-"""Runs GPU parity tests of tests/test_gpu_*.py on the CPU: their `gb` is an emulator-backed harness (tools/hostemu/emu_harness.py) whose
+"""Runs GPU parity tests of tests/test_gpu_*.py on the CPU (--all: over libemu_all.so -- whole product paths, the default and the experimental
+reader variants; otherwise over libemu_serial.so -- the wavefront-per-item kernels): their `gb` is an emulator-backed harness (tools/hostemu/emu_harness.py) whose
 run() drives the wavefront-per-item kernels of libemu_serial.so -- the LZ4 frame reader, the wavefront-per-stream readers of x-snappy-framed
 and Hadoop block streams, the one-kernel Zstd decoder.  Only tests that decode (and whose expectations come from the oracle) are run."""
 import os, sys, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from emu_harness import EmuBatch
+from emu_harness import EmuBatch, EmuAllBatch
 from tests import oracle_lib
 
 o = oracle_lib.load()
@@ -16,6 +17,10 @@ def main():
     import tests.test_gpu_hadoop as hd
     import tests.test_gpu_zstd as zs
     import tests.test_gpu_snappy_framed as sf
+    whole = "--all" in sys.argv
+    # (--all: one run per reader variant, as the test modules' fixtures parametrise them -- the experimental ones included)
+    variants = {"lz4 frame": [{"lz4frame.decompress.variant": v} for v in (0, 1)], "hadoop streams": [{"hadoop.decompress.variant": v} for v in (1, 0, 2)],
+                "snappy framed": [{"snappyframed.decompress.variant": v} for v in (1, 0, 2)], "zstd": [{"zstd.decompress.variant": v} for v in (1, 0)]} if whole else {}
     plan = [("lz4 frame", lf, [n for n in dir(lf) if n.startswith("test_")]),
             ("hadoop streams", hd, [n for n in dir(hd) if n.startswith("test_")]),
             ("snappy framed", sf, [n for n in dir(sf) if n.startswith("test_")]),
@@ -40,11 +45,14 @@ def main():
                 if mark.name == "parametrize":
                     key, values = mark.args[0], mark.args[1]
                     params = [dict(p, **{key: v}) for p in params for v in values]
+            params = [dict(p, _options=opt) for p in params for opt in variants.get(title, [None])]
             for p in params:
+                options = p.pop("_options")
                 kwargs = dict(p)
+                p = dict(p, **(options or {}))
                 for a in argnames:
                     if a in ("gb", "gbd"):
-                        kwargs[a] = EmuBatch()
+                        kwargs[a] = EmuAllBatch(options) if whole else EmuBatch()
                     elif a == "o":
                         kwargs[a] = o
                 if any(a not in kwargs for a in argnames):

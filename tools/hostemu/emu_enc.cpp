@@ -1,0 +1,47 @@
+// tools/hostemu/emu_enc.cpp -- the ENCODERS on the CPU.  They run the same serial code on all 64 lanes of a wavefront and change shared
+// state in place (hash tables, sequence stores), which is exact only under the device's lockstep: this unit is built with
+//   clang++ -fsanitize-coverage=inline-8bit-counters,trace-loads,trace-stores
+// and HOSTEMU_ACCESS_LOCKSTEP, so that every memory access of the kernel source is a soft order point (hip/hip_runtime.h).  Slow (a fiber
+// switch per access and lane): inputs of a few KiB take seconds, a 128 KiB Zstd block about a minute.
+#define HOSTEMU_ACCESS_LOCKSTEP 1
+#define HOSTEMU_ORDER_IS_RENDEZVOUS 1  // wave_mem_order(): where the source says "every lane's accesses so far come before every lane's accesses from here on" all lanes meet
+#include "emu.cpp"  // (the decoders and the container readers / writers: hadoop_streams.hip, lz4_frame.hip, snappy_frame.hip)
+#include "../../aircompressor_amd/csrc/lz4_compress.hip"
+#include "../../aircompressor_amd/csrc/snappy_compress.hip"
+#include "../../aircompressor_amd/csrc/zstd_compress.hip"
+#include "../../aircompressor_amd/csrc/zstd_stream.hip"
+
+// op: the C ABI's operation numbers -- 1 LZ4, 3 Snappy, 5 Zstd compress; 7 LZ4 frame, 9 x-snappy-framed, 11 / 13 Hadoop LZ4 / Snappy stream writers;
+// 14 the Zstd stream writer (option: 1 = chunked streams from 4 MiB on)
+extern "C" int emu_encode(int op, const uint8_t* srcBase, const int64_t* srcOff, const int32_t* srcLen, uint8_t* dstBase, const int64_t* dstOff, const int32_t* dstCap,
+                          int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n, int32_t option, int32_t bufferSize)
+{
+    achip::BatchArgs a{srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, n, 0};
+    static std::vector<uint8_t> scratch;
+    if (op == 1) {
+        int maxLen = 0;
+        for (int i = 0; i < n; i++) maxLen = srcLen[i] > maxLen ? srcLen[i] : maxLen;
+        return achip::launch_lz4_compress(a, nullptr, option, maxLen);
+    }
+    if (op == 3) {
+        scratch.assign((size_t)achip::snappy_compress_scratch_bytes(), 0xCD);
+        return achip::launch_snappy_compress(a, nullptr, option, scratch.data());
+    }
+    if (op == 5 || op == 14) {
+        scratch.assign((size_t)achip::zstd_compress_scratch_bytes(n), 0xCD);
+        return op == 5 ? achip::launch_zstd_compress(a, nullptr, scratch.data(), (int64_t)scratch.size(), option) : achip::launch_zstd_stream_compress(a, nullptr, scratch.data(), option);
+    }
+    if (op == 7) {
+        scratch.assign((size_t)achip::lz4frame_compress_scratch_bytes(), 0xCD);
+        return achip::launch_lz4frame_compress(a, nullptr, scratch.data());
+    }
+    if (op == 9) {
+        scratch.assign((size_t)achip::snappyframed_compress_scratch_bytes(n), 0xCD);
+        return achip::launch_snappyframed_compress(a, nullptr, scratch.data(), option);
+    }
+    if (op == 11 || op == 13) {
+        scratch.assign((size_t)achip::hadoop_compress_scratch_bytes(n), 0xCD);
+        return achip::launch_hadoop_compress(a, nullptr, scratch.data(), op == 13, bufferSize);
+    }
+    return -1;
+}

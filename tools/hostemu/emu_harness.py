@@ -40,6 +40,9 @@ class EmuBatch:
     def set_option(self, k, v):
         self.options[k] = v
 
+    def _call(self, op, src, src_off, src_len, dst, dst_off, caps, out_len, status, err, n):
+        return self.lib.emu_serial(op, int(self.options.get("hadoop.buffer_size", 262144)), P(src), P(src_off), P(src_len), P(dst), P(dst_off), P(caps), P(out_len), P(status), P(err), n)
+
     def run(self, op, blocks, caps, fill=0xA5, unaligned=False):
         n = len(blocks)
         caps = np.asarray(caps, dtype=np.int32)
@@ -59,7 +62,7 @@ class EmuBatch:
         if n:
             if isinstance(op, (list, tuple, np.ndarray)):
                 raise NotEmulated("mixed batch")
-            r = self.lib.emu_serial(int(op), int(self.options.get("hadoop.buffer_size", 262144)), P(src), P(src_off), P(src_len), P(dst), P(dst_off), P(caps), P(out_len), P(status), P(err), n)
+            r = self._call(int(op), src, src_off, src_len, dst, dst_off, caps, out_len, status, err, n)
             if r != 0:
                 raise NotEmulated("op %d" % op)
         ends = np.append(dst_off[1:], pos) if n else np.array([], dtype=np.int64)
@@ -67,3 +70,42 @@ class EmuBatch:
             assert (dst[dst_off[i] + caps[i]:ends[i]] == fill).all(), "block %d wrote past its capacity" % i
         assert (dst[:64] == fill).all() and (dst[pos:] == fill).all(), "wrote outside the destination buffer"
         return [dst[dst_off[i]:dst_off[i] + max(int(out_len[i]), 0)].tobytes() for i in range(n)], status.tolist(), err.tolist()
+
+
+class EmuAllBatch(EmuBatch):
+    """The same over libemu_all.so (every decode kernel, soft order points): whole product paths -- the default variants and the experimental
+    ones, chosen by the same context options the GPU tests set."""
+
+    def __init__(self, options=None):
+        self.lib = ctypes.CDLL(os.path.join(ROOT, "tools", "hostemu", "libemu_all.so"))
+        self.options = dict(options or {})
+        self.codec = _Codec(self)
+        self.variant = self.options.get("zstd.decompress.variant", 1)
+        self.counters = np.zeros(64, dtype=np.int32)
+        self.codec.native.get_stat = self.get_stat
+
+    def get_stat(self, name):
+        words = {"zstd.decompress.fallback_items": 0, "zstd.decompress.multiblock_items": 40, "zstd.decompress.multiblock_blocks": 41, "zstd.decompress.multiblock_fast_items": 42}
+        if name in words:
+            return int(self.counters[words[name]])
+        if name.startswith("zstd.decompress.fallback_stage"):
+            return int(self.counters[32 + int(name[-1])])
+        return -1
+
+    def _call(self, op, src, src_off, src_len, dst, dst_off, caps, out_len, status, err, n):
+        a = (P(src), P(src_off), P(src_len), P(dst), P(dst_off), P(caps), P(out_len), P(status), P(err), n)
+        o = self.options
+        if op == 0:
+            return self.lib.emu_batch({1: 44, 7: 24, 6: 18}.get(o.get("lz4.decompress.variant", 1), 44), *a)
+        if op == 2:
+            return self.lib.emu_batch({1: 54, 7: 34, 6: 19}.get(o.get("snappy.decompress.variant", 1), 54), *a)
+        if op == 4:
+            self.variant = o.get("zstd.decompress.variant", 1)
+            return self.lib.emu_zstd_full(*a, int(self.variant), int(o.get("zstd.decompress.stream_blocks", 65536)), P(self.counters))
+        if op == 6:
+            return self.lib.emu_lz4frame(int(o.get("lz4frame.decompress.variant", 0)), *a)
+        if op == 8:
+            return self.lib.emu_snappyframed(int(o.get("snappyframed.decompress.variant", 1)), *a)
+        if op in (10, 12):
+            return self.lib.emu_hadoop(0, 1 if op == 12 else 0, int(o.get("hadoop.buffer_size", 262144)), int(o.get("hadoop.decompress.variant", 1)), *a)
+        return -1

@@ -13,12 +13,24 @@
 // rendezvous of the group: quad_bcast / quad_sync, and group_sync, which achip_rings.h places -- for this shim only, the device code is
 // untouched -- where the hardware's lockstep makes the lanes of a group meet: before anybody writes what somebody may still read, and
 // before anybody reads what somebody may still write (within one copy step too: all loads, then all stores).
+//
+// HOSTEMU_ACCESS_LOCKSTEP (tools/hostemu/emu_enc.cpp: the encoders): the unit is built with clang's -fsanitize-coverage=trace-loads,trace-stores,
+// whose callbacks make EVERY load and store of the kernel source a soft order point (below): a lane pauses before each memory access until
+// no lane of its wave can run further, so all lanes perform access k before any performs access k+1 -- the lockstep of a wavefront at
+// the granularity of memory operations.  That is what kernels need that run the same serial code on every lane and change shared state in
+// place (table[h] read and then overwritten by all 64 lanes: every lane must see the old entry).  Accesses to a fiber's own stack do not
+// pause; the shim's own functions are not instrumented (and not inlined into code that is).
 #pragma once
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#if defined(HOSTEMU_ACCESS_LOCKSTEP)
+// (noinline: inlined into an instrumented kernel function the shim's own accesses would be instrumented with it -- and a pause between
+// "me.wait = WAIT_BLOCK" and the switch would turn the barrier into nothing)
+#pragma clang attribute push(__attribute__((no_sanitize("coverage"), noinline)), apply_to = function)
+#endif
 
 #define __global__
 #define __device__
@@ -52,7 +64,7 @@ namespace hostemu {
 
 constexpr int MAX_THREADS = 1024;
 constexpr size_t STACK_BYTES = 512 << 10;
-enum Wait { RUNNABLE = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, WAIT_QUAD = 3 };  // (WAIT_QUAD: an aligned group of Fiber::gsize lanes, 4 by default)
+enum Wait { RUNNABLE = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, WAIT_QUAD = 3, WAIT_SOFT = 4 };  // (WAIT_QUAD: an aligned group of Fiber::gsize lanes, 4 by default)
 
 struct Fiber {
     void* sp = nullptr;
@@ -63,12 +75,15 @@ struct Fiber {
     int line = 0;
     uint64_t post = 0;
     int gsize = 4;  // group size of a WAIT_QUAD rendezvous
+    long waits[5] = {0, 0, 0, 0, 0};  // (diagnosis: rendezvous of each kind this lane has been to)
+    int recent[64] = {0};              // (diagnosis: source lines of its latest rendezvous)
 };
 
 struct State {
     Fiber f[MAX_THREADS];
     int n = 0;
     int cur = -1;
+    bool inFiber = false;  // a kernel lane is running (not the scheduler, not host code)
     void* schedSp = nullptr;
     std::function<void()> body;
 };
@@ -109,6 +124,8 @@ inline void wait_here(int kind, const char* file, int line)
     me.wait = kind;
     me.file = file;
     me.line = line;
+    me.waits[kind]++;
+    if (kind == WAIT_WAVE) me.recent[me.waits[kind] & 63] = line;
     hostemu_switch(&me.sp, s.schedSp);
 }
 
@@ -134,6 +151,7 @@ inline void run_workgroup(int nThreads, const std::function<void()>& body)
         f.sp = (void*)p;
         f.done = false;
         f.wait = RUNNABLE;
+        f.waits[WAIT_WAVE] = 0;
     }
     for (;;) {
         bool any = false, ran = false;
@@ -151,7 +169,9 @@ inline void run_workgroup(int nThreads, const std::function<void()>& body)
             if (f.wait != RUNNABLE) continue;
             s.cur = t;
             threadIdx = dim3((unsigned)t);
+            s.inFiber = true;
             hostemu_switch(&s.schedSp, f.sp);
+            s.inFiber = false;
             ran = true;
         }
         if (!any) break;
@@ -187,6 +207,14 @@ inline void run_workgroup(int nThreads, const std::function<void()>& body)
                     }
                     else if (f.line != line || f.file != file) {
                         fprintf(stderr, "hostemu: lanes of one wave wait at different cross-lane operations: %s:%d and %s:%d (thread %d)\n", file, line, f.file, f.line, t);
+                        if (getenv("HOSTEMU_VERBOSE")) {
+                            for (int u = w; u < e; u++) {
+                                fprintf(stderr, "  thread %d: %s at %s:%d  (wave rendezvous so far: %ld)\n", u, s.f[u].done ? "done" : (s.f[u].wait == RUNNABLE ? "runnable" : "waits"), s.f[u].file ? s.f[u].file : "?", s.f[u].line, s.f[u].waits[WAIT_WAVE]);
+                                fprintf(stderr, "      latest:");
+                                for (int k = 63; k >= 0; k--) fprintf(stderr, " %d", s.f[u].recent[(s.f[u].waits[WAIT_WAVE] - k) & 63]);
+                                fprintf(stderr, "\n");
+                            }
+                        }
                         abort();
                     }
                 }
@@ -239,6 +267,24 @@ inline void run_workgroup(int nThreads, const std::function<void()>& body)
                     released = true;
                 }
                 q = qEnd;
+            }
+        }
+        // soft order points (wave_mem_order under HOSTEMU_ORDER_IS_SOFT): a lane that reaches one pauses until no lane of its wave can run any
+        // further -- every other lane is at an order point of its own, at a rendezvous, or done.  For code that runs a wavefront in uniform
+        // control flow that is a barrier (what the device's lockstep gives it); for lanes that go their own ways it is only a pause.
+        for (int w = 0; w < nThreads; w += 64) {
+            const int e = w + 64 < nThreads ? w + 64 : nThreads;
+            bool anyRunnable = false, anySoft = false;
+            for (int t = w; t < e; t++) {
+                if (s.f[t].done) continue;
+                anyRunnable = anyRunnable || s.f[t].wait == RUNNABLE;
+                anySoft = anySoft || s.f[t].wait == WAIT_SOFT;
+            }
+            if (anySoft && !anyRunnable) {
+                for (int t = w; t < e; t++) {
+                    if (!s.f[t].done && s.f[t].wait == WAIT_SOFT) s.f[t].wait = RUNNABLE;
+                }
+                released = true;
             }
         }
         if (!ran && !released) {
@@ -307,7 +353,22 @@ inline T shfl_from(T v, int srcLane, const char* file, int line)
     });
 }
 inline void wave_sync(const char* file, int line) { wait_here(WAIT_WAVE, file, line); }
+// value of lane k of the caller's aligned group of gs lanes (a shuffle whose source lies in the caller's own lane group: group-uniform control flow is enough)
+template <typename T>
+inline T group_from(T v, int gs, int k, const char* file, int line)
+{
+    State& s = S();
+    s.f[s.cur].post = to_bits(v);
+    s.f[s.cur].gsize = gs;
+    wait_here(WAIT_QUAD, file, line);
+    const int t = (s.cur & ~(gs - 1)) + (k & (gs - 1));
+    const T r = lane_active(t) ? from_bits<T>(s.f[t].post) : v;
+    s.f[s.cur].gsize = gs;
+    wait_here(WAIT_QUAD, file, line);
+    return r;
+}
 inline void order_point(const char* file, int line) { wait_here(WAIT_WAVE, file, line); }  // (wave_mem_order under HOSTEMU_ORDER_IS_RENDEZVOUS)
+inline void soft_order_point(const char* file, int line) { wait_here(WAIT_SOFT, file, line); }  // (wave_mem_order under HOSTEMU_ORDER_IS_SOFT)
 inline void quad_sync(const char* file, int line) { S().f[S().cur].gsize = 4; wait_here(WAIT_QUAD, file, line); }
 // rendezvous of the caller's aligned group of gs lanes (gs a power of two, at most 64): kernels that give a block to a lane group
 inline void group_sync(int gs, const char* file, int line) { S().f[S().cur].gsize = gs; wait_here(WAIT_QUAD, file, line); }
@@ -359,3 +420,34 @@ template <typename T> inline T atomicMax(T* p, T v) { T old = *p; if (v > old) *
 // dynamic shared memory of the emulated launch: one arena, re-used by every "workgroup"
 static uint8_t hostemu_dynamic_lds[1 << 20] __attribute__((aligned(64)));
 inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+#if defined(HOSTEMU_ACCESS_LOCKSTEP)
+namespace hostemu {
+inline void access_point(const void* p)
+{
+    State& s = S();
+    if (!s.inFiber) return;  // host code of the same unit
+    Fiber& me = s.f[s.cur];
+    if ((uintptr_t)p - (uintptr_t)me.stack < STACK_BYTES) return;  // the lane's own stack: private
+    me.wait = WAIT_SOFT;
+    me.file = "memory access";
+    me.line = 0;
+    hostemu_switch(&me.sp, s.schedSp);
+}
+}  // namespace hostemu
+extern "C" {
+void __sanitizer_cov_load1(uint8_t* p) { hostemu::access_point(p); }
+void __sanitizer_cov_load2(uint16_t* p) { hostemu::access_point(p); }
+void __sanitizer_cov_load4(uint32_t* p) { hostemu::access_point(p); }
+void __sanitizer_cov_load8(uint64_t* p) { hostemu::access_point(p); }
+void __sanitizer_cov_load16(__int128* p) { hostemu::access_point(p); }
+void __sanitizer_cov_store1(uint8_t* p) { hostemu::access_point(p); }
+void __sanitizer_cov_store2(uint16_t* p) { hostemu::access_point(p); }
+void __sanitizer_cov_store4(uint32_t* p) { hostemu::access_point(p); }
+void __sanitizer_cov_store8(uint64_t* p) { hostemu::access_point(p); }
+void __sanitizer_cov_store16(__int128* p) { hostemu::access_point(p); }
+void __sanitizer_cov_8bit_counters_init(char*, char*) {}
+void __sanitizer_cov_pcs_init(const uintptr_t*, const uintptr_t*) {}
+}
+#pragma clang attribute pop
+#endif
