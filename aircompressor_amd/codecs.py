@@ -266,8 +266,8 @@ class ZstdHipCompressor(_HipCompressor):
 class ZstdHipOutputStream:
     """Drop-in for ZstdOutputStream (M/zstd/ZstdOutputStream.java:30-221) over a binary sink: write() collects, close() hands everything
     to the stream encoder (achip_zstdstream_compress: the stream's parameters, not the frame compressor's) and writes the frame to the
-    sink.  The Java stream flushes chunks once 4 MiB have been written; that part is not built on the device (include/aircompressor_hip.h):
-    such a stream raises at close()."""
+    sink.  The Java stream flushes chunks once 4 MiB have been written and slides its window; the device writer produces those bytes too
+    (include/aircompressor_hip.h: the chunked form), only that they reach the sink at close() in one piece."""
 
     def __init__(self, sink, device=0, native_ctx=None):
         self._sink = sink

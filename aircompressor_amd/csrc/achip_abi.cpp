@@ -81,7 +81,8 @@ struct achip_ctx {
     int snappyFramedCompressVariant = 1;  // framed writer: 1 = block list + two-tier block encoder + compaction (default), 0 = one wavefront per stream
     int snappyFramedVariant = 1;  // framed reader: 1 = chunk list + batched block decoders (default), 0 = one wavefront per stream
     int zstdTile = 65536;    // items per pass of the Zstd decode pipeline (halved automatically when its scratch cannot be allocated)
-    int zstdStreamChunked = 0;     // 1: the stream writer also takes streams from 4 MiB on (unverified: zstd_compress.hip zstd_stream_chunked); 0: it refuses them
+    int zstdStreamChunked = 1;     // 1: the stream writer takes streams from 4 MiB on as well (chunks flushed before close(), window slides: zstd_stream.hip; byte-identical with
+                                   // the test suite's CPU restatement under tools/hostemu, not yet run on a GPU); 0: it refuses them (INVALID_ARGUMENT / ACHIP_D_UNSUPPORTED)
     int zstdStreamBlocks = 65536;  // 128 KiB blocks a pass of the pipeline's multi-block stages has room for (0: multi-block frames take the one-kernel decoder); ~20 GB of scratch, allocated when a batch first holds such frames (halved as often as it takes when the device cannot give that)
     void* zstdMbScratch = nullptr;
     int64_t zstdMbScratchBytes = 0;

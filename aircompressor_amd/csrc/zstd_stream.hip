@@ -11,8 +11,9 @@
 //   :154-221  from 4 MiB on: a header without the content size; a flush writes whole blocks and keeps window + one block; then the tables and
 //             the buffer slide (BlockCompressionState.java:35-49) -- here c.in moves and every position is relative to it -- while
 //             c.windowBaseOffset stays where enforceMaxDistance put it, as in the reference (the blocks behind a slide find no match until
-//             the position has caught up with it).  That part was written without a GPU at hand, and this encoder does not run on the CPU
-//             emulator: it is NOT verified, and `chunked` == 0 (the default; context option zstd.stream.chunked) refuses such streams.
+//             the position has caught up with it).  That part was written without a GPU at hand; it is byte-identical with the CPU
+//             restatement of the Java writer (the test suite's checker) under tools/hostemu's access-granular lockstep (check_enc.py --chunked: 4.5 MB and 6.4 MB streams, one and two
+//             slides).  `chunked` == 0 (context option zstd.stream.chunked) refuses such streams instead.
 #include "zstd_compress_body.h"
 
 namespace achip {

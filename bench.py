@@ -388,7 +388,8 @@ def main():
         try:
             ex.update(zstd_extra(torch, A, codec, dev, args))
             try:
-                ex.update(zstd_stream_extra(torch, A, codec, dev, args))
+                torch.cuda.empty_cache()
+                ex.update(zstd_stream_extra_isolated())
             except Exception as e:  # (a secondary entry must not take the run's line with it; the parity tests are the check)
                 ex["zstdstream_error"] = repr(e)
         except ImportError:
@@ -708,6 +709,18 @@ def zstd_extra(torch, A, codec, dev, args):
         out["zstd_%s" % data_kind] = entry
         del z_dst, back, zplain
     return out
+
+
+def zstd_stream_extra_isolated():
+    """zstd_stream_extra in a process of its own (this command line + --section zstdstream): the defaults of the multi-block stages were
+    last touched after the round's GPU minutes were spent (CPU-emulator-verified only), and a device fault there must not take the run's
+    line with it -- an exception can be caught, an aborted process cannot."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--section", "zstdstream"], capture_output=True, text=True, timeout=1200)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("exit %d: %s" % (r.returncode, r.stderr[-400:]))
+    return json.loads(lines[-1])
 
 
 def zstd_stream_extra(torch, A, codec, dev, args):

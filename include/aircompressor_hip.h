@@ -311,10 +311,10 @@ int32_t achip_snappyhadoop_decompress(achip_ctx* ctx, const void* src, void* dst
  * WRITING: item i = everything a caller hands to ONE ZstdOutputStream (M/zstd/ZstdOutputStream.java:30-221) -- write(buffer, 0, n) and
  * close(), the way the reference's stream harness drives it (T/HadoopCodecCompressor.java:57-72); dst receives what the stream puts on
  * its sink.  That is NOT achip_zstd_compress' output: the stream's parameters are those for an unknown input size (window 2^20, hash
- * 2^17, chain 2^16 whatever n is; :48-58).  Built for n < 4 MiB, where close() writes the input as one chunk whose size the frame header
- * announces; from 4 MiB on the stream flushes chunks before close() (header without content size, window slid between chunks):
- * INVALID_ARGUMENT / ACHIP_D_UNSUPPORTED for such an item -- the oracle restates that part (oracle/zstd_enc.c); the kernel's version of it
- * exists but has never run (option "zstd.stream.chunked" = 1 enables it: DESIGN 10 row 3).
+ * 2^17, chain 2^16 whatever n is; :48-58).  Below 4 MiB close() writes the input as one chunk whose size the frame header announces; from
+ * 4 MiB on the stream flushes chunks before close() (header without content size, 23 blocks, then 15 per further 1920 KiB, the window slid
+ * in between -- and, as in the reference, 7 blocks after every slide without a match: DESIGN 10 row 3).  n >= 2^30 is INVALID_ARGUMENT /
+ * ACHIP_D_UNSUPPORTED (the Java code overflows there); option "zstd.stream.chunked" = 0 refuses everything from 4 MiB on the same way.
  * Byte-identical output wants dstCap >= achip_zstdstream_max_compressed_length(n) (the stream itself never runs out of room). */
 int32_t achip_zstdstream_max_compressed_length(int32_t uncompressedSize);
 int32_t achip_zstdstream_compress_batch(ACHIP_BATCH_ARGS);

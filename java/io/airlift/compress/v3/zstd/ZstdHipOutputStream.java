@@ -29,8 +29,8 @@ import static java.util.Objects.requireNonNull;
  * {@code ZstdHipCompressor}'s -- and that frame goes to the sink.
  * <p>
  * {@code ZstdOutputStream} starts flushing chunks once 4 MiB have been written (a frame header without the content size, the window
- * slid between chunks); that part is not built on the device: a longer stream fails at {@code close()} with the library's
- * "unsupported" error.  To write many streams at once use {@link io.airlift.compress.v3.hip.HipBatchCodec} with
+ * slid between chunks); the library writes those bytes too -- they only reach the sink in one piece at {@code close()} -- up to
+ * 2^30 bytes per stream.  To write many streams at once use {@link io.airlift.compress.v3.hip.HipBatchCodec} with
  * {@link HipNative#OP_ZSTDSTREAM_COMPRESS}: one item per stream.
  * <p>
  * Reading needs no class of its own: {@code ZstdHipDecompressor} (and the batch form) take frames of any number of blocks.

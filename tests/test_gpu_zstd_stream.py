@@ -1,11 +1,11 @@
 """GPU parity (through the C ABI) of the Zstd STREAM writer: achip_zstdstream_compress* must produce what
 ZstdOutputStream (M/zstd/ZstdOutputStream.java:30-221) puts on its sink for write(buffer, 0, n) + close() -- here: what the oracle's
-restatement produces (tests/test_oracle_zstd_stream.py pins that one against the Java source's implications).  Built for streams below
-4 MiB (one chunk); longer ones are refused, not approximated.
+restatement produces (tests/test_oracle_zstd_stream.py pins that one against the Java source's implications): one chunk below 4 MiB, chunks
+flushed before close() with window slides from there on (the last test).
 
-Added at the very end of round 2, after the round's GPU minutes were spent: the kernel change is a parameter switch in an encoder whose
-code paths were all GPU-verified before (the stream's parameters are the frame compressor's for inputs beyond 512 KiB), but these tests
-themselves first run on the driver's box."""
+Added at the very end of round 2, after the round's GPU minutes were spent: the kernel is the frame compressor's device code with the
+stream's parameters (GPU-verified paths) plus the chunk loop; both forms are byte-identical with the oracle on the CPU emulator
+(tools/hostemu/check_enc.py, access-granular lockstep), but these tests themselves first run on the driver's box."""
 import io
 
 import numpy as np
@@ -53,13 +53,16 @@ def test_stream_writer_is_bit_exact_with_the_oracle(gb, o):
     assert [bytes(p) for p in back] == inputs
 
 
-def test_a_stream_that_would_flush_before_close_is_refused(gb, o):
+def test_a_stream_that_would_flush_before_close_can_be_refused(gb, o):
     whole = b"".join(d for _, d, _ in common.corpus_sample())
     big = (whole * 5)[:4 << 20]
-    outs, status, err = gb.run(OP_ZSTDSTREAM_COMPRESS, [big[:-1], big, whole], [o.lib.orc_zstd_stream_max_compressed_length(len(big))] * 3)
+    gb.set_option("zstd.stream.chunked", 0)
+    try:
+        outs, status, err = gb.run(OP_ZSTDSTREAM_COMPRESS, [big[:-1], big, whole], [o.lib.orc_zstd_stream_max_compressed_length(len(big))] * 3)
+    finally:
+        gb.set_option("zstd.stream.chunked", 1)
     assert status[0] == 0 and status[2] == 0 and outs[2] == o.zstd_stream_compress(whole)
     assert oracle_lib.status_class(status[1]) == 3 and oracle_lib.status_detail(status[1]) == 103  # INVALID_ARGUMENT / ACHIP_D_UNSUPPORTED
-    assert len(o.zstd_stream_compress(big)) > 0  # (the oracle restates the chunked form: tests/test_oracle_zstd_stream.py)
 
 
 def test_output_stream_twin(o):
@@ -88,3 +91,34 @@ def test_corpus_files_match_the_stream_manifest(gb, o):
     for r, c, s in zip(rows, outs, status):
         assert s == 0 and len(c) == r[4] and hashlib.sha256(c).hexdigest() == r[5], r[0]
 
+
+
+def test_streams_from_4_mib_on_are_written_in_chunks(gb, o):
+    """(last in the file: the chunked writer -- 23 blocks flushed at 4 MiB, the window slid by 1920 KiB, 15 blocks per further 1920 KiB, and as
+    in the reference 7 blocks after every slide without a match -- was verified on the CPU emulator only before its first GPU run:
+    tools/hostemu/check_enc.py --chunked)  The oracle's bytes for streams with no, one, two and six slides; the GPU decoder reads them back;
+    the whole corpus as one 14 MB stream against the manifest line a JDK box pins (tools/java/GoldenStreamDump.java)."""
+    import hashlib
+    whole = b"".join(d for _, d, _ in common.corpus_sample())
+    rng = np.random.default_rng(43)
+    tiled = whole * 16
+    inputs = [tiled[:4 << 20], tiled[:(4 << 20) + 1], tiled[:4 * (1 << 20) + 1920 * 1024], tiled[100:6400100],
+              tiled[:3000000] + rng.integers(0, 256, 700000, dtype=np.uint8).tobytes() + tiled[:2500000], tiled[:15 << 20]]
+    caps = [o.lib.orc_zstd_stream_max_compressed_length(len(b)) for b in inputs]
+    outs, status, err = gb.run(OP_ZSTDSTREAM_COMPRESS, inputs, caps)
+    for i, b in enumerate(inputs):
+        assert status[i] == 0, (i, len(b), status[i])
+        assert outs[i] == o.zstd_stream_compress(b), "input %d (len %d)" % (i, len(b))
+    back, status, err = gb.run(OP_ZSTD_DECOMPRESS, outs, [len(b) for b in inputs])
+    assert all(s == 0 for s in status), status
+    assert [bytes(p) for p in back] == inputs
+    star = [r for r in common.read_manifest_tsv("oracle_stream_manifest.tsv") if r[0] == "*"]
+    assert len(star) == 1
+    import json
+    import os
+    corpus = common.corpus_full()
+    order = [e["file"] for e in json.load(open(os.path.join(common.GOLDEN, "corpus_full.json")))]
+    everything = b"".join(bytes(corpus[f]) for f in order)
+    assert len(everything) == star[0][2]
+    outs, status, err = gb.run(OP_ZSTDSTREAM_COMPRESS, [everything], [o.lib.orc_zstd_stream_max_compressed_length(len(everything))])
+    assert status[0] == 0 and len(outs[0]) == star[0][4] and hashlib.sha256(outs[0]).hexdigest() == star[0][5]

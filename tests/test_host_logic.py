@@ -150,6 +150,30 @@ def test_whole_decode_paths_on_the_cpu():
     assert "FAILED" not in r.stdout and r.stdout.strip().endswith("19 tests passed, 0 mismatches"), r.stdout
 
 
+def test_encoders_and_writers_on_the_cpu():
+    """The encoders -- LZ4, Snappy (one and two tiers), Zstd (match finder + entropy stage), the ZstdOutputStream writer, the LZ4 frame,
+    x-snappy-framed and Hadoop block stream writers -- under tools/hostemu's access-granular lockstep (libemu_enc.so, built with clang's
+    load / store tracing: every memory access of the kernel source is a soft order point, which is what replicated serial code with tables
+    updated in place needs): bytes, lengths and statuses (capacities below the bound included) against the oracle's restatement of the Java
+    encoders.  (tools/hostemu/check_enc.py without --quick: blocks beyond 64 / 128 / 256 KiB, every Zstd variant, the Hadoop buffer sizes;
+    --chunked N: a ZstdOutputStream of N >= 4 MiB bytes through the chunked writer.)"""
+    import shutil
+    import sys
+    import pytest
+    clang = shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("no clang++ for the host build of the kernel source")
+    emu_dir = os.path.join(ROOT, "tools", "hostemu")
+    subprocess.run([clang, "-O2", "-std=c++17", "-fPIC", "-shared", "-fsanitize-coverage=inline-8bit-counters,trace-loads,trace-stores", "-I", emu_dir,
+                    "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "aircompressor_amd", "csrc"),
+                    "-o", os.path.join(emu_dir, "libemu_enc.so"), os.path.join(emu_dir, "emu_enc.cpp")], check=True)
+    jobs = [subprocess.Popen([sys.executable, os.path.join(emu_dir, "check_enc.py"), "--quick", "--part", part], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT)
+            for part in ("block", "zstd", "stream", "containers")]  # (side by side)
+    outs = [j.communicate()[0] for j in jobs]
+    assert all(j.returncode == 0 for j in jobs), "\n".join(outs)
+    assert all(o.strip().endswith("encoders under the emulator: 0 mismatches") for o in outs) and "MISMATCH" not in "".join(outs), "\n".join(outs)
+
+
 def test_bench_java_random_generator_equals_the_oracles(oracle):
     """bench.py restates java.util.Random(301) + RandomGenerator in numpy (jump-ahead LCG) for its ratio sweep; the oracle's generator
     (oracle/misc.c, following T/snappy/RandomGenerator.java:25-74) is the checker."""
