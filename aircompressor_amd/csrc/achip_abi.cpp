@@ -34,7 +34,9 @@ hipError_t launch_snappy_decompress_lanecopy(const BatchArgs& a, hipStream_t str
 hipError_t launch_snappy_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* stats);
 hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
+hipError_t launch_lz4_compress_window(const BatchArgs& a, hipStream_t stream, int maxSrcLenHint);
 hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant, void* scratch);
+hipError_t launch_snappy_compress_window(const BatchArgs& a, hipStream_t stream, void* scratch);
 int64_t snappy_compress_scratch_bytes();
 hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant, int32_t tileMax, const ZstdMbProvider* mbp);
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
@@ -71,8 +73,8 @@ struct achip_ctx {
     int lz4dVariant = 5;     // 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 4 = a lane per block, copies straight between the global buffers (lz4_decompress_v5.hip), 6 = a lane per block with an LDS output window (lz4_decompress_v6.hip), 5 = auto
     int snappydVariant = 5;  // 1 rings (snappy_decompress_v2.hip), 4 / 6 a lane per block (snappy_decompress_v3.hip / _v4.hip), 5 auto as for LZ4
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
-    int lz4cVariant = 1;     // 0 = serial probes, 1 = 64 probes per step (batch)
-    int snappycVariant = 2;  // 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory
+    int lz4cVariant = 1;     // 0 = serial probes, 1 = 64 probes per step (batch), 3 = the same with an LDS input window and one round of loads per batch (lz4_compress_v3.hip: experiment)
+    int snappycVariant = 2;  // 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory, 3 = 2 with an LDS input window (snappy_compress_v3.hip: experiment)
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 0;
     int hadoopBufferSize = 262144;        // Hadoop block streams: the streams' buffer size (Lz4HadoopStreams.java:30; io.compression.codec.*.buffersize)
@@ -300,7 +302,9 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 : ctx->lz4dVariant == 6 ? achip::launch_lz4_decompress_lanewindow(a, ctx->stream, nullptr)
                                         : achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, nullptr);
             break;
-        case ACHIP_OP_LZ4_COMPRESS: e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint); break;
+        case ACHIP_OP_LZ4_COMPRESS:
+            e = ctx->lz4cVariant == 3 ? achip::launch_lz4_compress_window(a, ctx->stream, ctx->maxSrcLenHint) : achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint);
+            break;
         case ACHIP_OP_SNAPPY_DECOMPRESS:
             if (ctx->snappydVariant == 5 && a.nBlocks >= ctx->lz4dAutoMinBlocks) {  // auto, as for LZ4
                 int32_t r = ensure_scratch_prefer(ctx, 4096 + achip::snappy_twopass_scratch_bytes(a.nBlocks), 4096 + achip::lz4_twopass_scratch_bytes_min(a.nBlocks));
@@ -330,11 +334,11 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                                            : achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, nullptr);
             break;
         case ACHIP_OP_SNAPPY_COMPRESS: {
-            if (ctx->snappycVariant == 2) {
+            if (ctx->snappycVariant >= 2) {
                 int32_t r = ensure_scratch(ctx, achip::snappy_compress_scratch_bytes());
                 if (r < 0) return r;
             }
-            e = achip::launch_snappy_compress(a, ctx->stream, ctx->snappycVariant, ctx->scratch);
+            e = ctx->snappycVariant == 3 ? achip::launch_snappy_compress_window(a, ctx->stream, ctx->scratch) : achip::launch_snappy_compress(a, ctx->stream, ctx->snappycVariant, ctx->scratch);
             break;
         }
         case ACHIP_OP_ZSTD_DECOMPRESS: {

@@ -203,7 +203,7 @@ def main():
         codec.native.set_option("decompress.ring_class", args.ring_class)
     if args.compress_variant >= 0:
         codec.native.set_option("lz4.compress.variant", args.compress_variant)
-        if args.compress_variant <= 1:
+        if args.compress_variant <= 1 or args.compress_variant == 3:  # (3: the LDS-window experiments of both codecs)
             codec.native.set_option("snappy.compress.variant", args.compress_variant)
     if args.ring_pad >= 0:
         codec.native.set_option("decompress.ring_pad", args.ring_pad)

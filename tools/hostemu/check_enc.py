@@ -70,7 +70,7 @@ def part_block():
         blocks.append(b"".join(d for _, d, _ in common.corpus_sample()[:2])[:100000])  # beyond 64 KiB: the i32 table (LZ4), a second sub-block (Snappy)
     # (not the serial-probe variants 0: after `if (lane == 0) { emit }` in the middle of replicated serial code the hardware has the other
     # lanes wait at the join; the shim lets them run on to their next access -- it does not model reconvergence)
-    for codec, op, variants in (("lz4", 1, (1,)), ("snappy", 3, (2, 1))):
+    for codec, op, variants in (("lz4", 1, (1, 3)), ("snappy", 3, (2, 1, 3))):  # (variants 3: the LDS-window experiments, lz4_compress_v3.hip / snappy_compress_v3.hip)
         caps = [o.max_compressed_length(codec, len(b)) for b in blocks]
         for v in variants:
             bad += compare("%s compress, variant %d" % (codec, v), op, v, blocks, caps, lambda b, c, codec=codec: o.compress(codec, b, c))
