@@ -164,7 +164,7 @@ def test_encoders_and_writers_on_the_cpu():
     if not os.path.exists(clang):
         pytest.skip("no clang++ for the host build of the kernel source")
     emu_dir = os.path.join(ROOT, "tools", "hostemu")
-    subprocess.run([clang, "-O2", "-std=c++17", "-fPIC", "-shared", "-fsanitize-coverage=inline-8bit-counters,trace-loads,trace-stores", "-I", emu_dir,
+    subprocess.run([clang, "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-omit-frame-pointer", "-fsanitize-coverage=inline-8bit-counters,trace-loads,trace-stores", "-I", emu_dir,
                     "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "aircompressor_amd", "csrc"),
                     "-o", os.path.join(emu_dir, "libemu_enc.so"), os.path.join(emu_dir, "emu_enc.cpp")], check=True)
     jobs = [subprocess.Popen([sys.executable, os.path.join(emu_dir, "check_enc.py"), "--quick", "--part", part], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT)

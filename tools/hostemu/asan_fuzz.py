@@ -4,7 +4,7 @@ its first and last byte lie in (an aligned piece that holds one byte of the item
 can), destination exactly its capacity -- so that every read or write a kernel makes outside what the ABI hands it is reported, for valid
 streams, truncated streams, bit flips and garbage.  Run through tools/hostemu/run_asan_fuzz.sh (LD_PRELOAD of the ASan runtime).
 
-  asan_fuzz.py <seed> <rounds> [lz4|snappy|zstd|containers ...]"""
+  asan_fuzz.py <seed> <rounds> [lz4|snappy|zstd|zstdmb|containers ...]     (zstdmb: frames of several blocks)"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -114,6 +114,36 @@ def containers():
             yield "hadoop-" + codec, "Hadoop %s reader %d" % (codec, v), (lambda *a, sn=sn, v=v: lib.emu_hadoop(0, sn, 1024, v, *a)), (lambda b, codec=codec: o.hadoop_compress(codec, b, 1024))
 
 
+def zstd_multi_block(rng, rounds):
+    """frames of SEVERAL blocks (the pipeline's multi-block stages: walk with links, per-block parse, one wavefront per frame executes): the
+    shared multi-block inputs (tests/common.py: shaped data -- RLE-mode tables, treeless literals, raw / RLE blocks) up to 800 KB, as the
+    oracle's encoder and as libzstd (pyarrow: many short blocks) write them, valid and damaged"""
+    import pyarrow as pa
+    frames = []
+    for p in common.multi_block_plains():
+        if len(p) <= 800000:
+            frames.append((len(p), o.compress("zstd", p)))
+            frames.append((len(p), pa.Codec("zstd", compression_level=3).compress(p, asbytes=True)))
+    calls = 0
+    decoders = family("zstd")[1]
+    for _ in range(rounds):
+        for n, good in frames:
+            title, call = decoders[int(rng.integers(0, len(decoders)))]
+            c = bytearray(good)
+            kind = int(rng.integers(0, 4))
+            if kind == 1:
+                c = c[:int(rng.integers(0, len(c)))]
+            elif kind == 2:
+                for _ in range(int(rng.integers(1, 4))):
+                    c[int(rng.integers(0, len(c)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 3:  # damage near a block header: the walk's territory
+                i = int(rng.integers(0, min(len(c), 400)))
+                c[i] = int(rng.integers(0, 256))
+            run1(call, bytes(c), n if rng.integers(0, 3) else int(rng.integers(0, n)), int(rng.integers(0, 32)))
+            calls += 1
+    return calls
+
+
 def main():
     seed, rounds = int(sys.argv[1]), int(sys.argv[2])
     names = sys.argv[3:] or ["lz4", "snappy", "zstd", "containers"]
@@ -123,6 +153,9 @@ def main():
     for _ in range(rounds):
         ps = plains(rng)
         for name in names:
+            if name == "zstdmb":
+                calls += zstd_multi_block(rng, 1)
+                continue
             if name == "containers":
                 for _, title, call, enc in containers():
                     for b in ps[::3]:

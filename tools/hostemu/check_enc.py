@@ -68,9 +68,9 @@ def part_block():
     if not quick:
         blocks.append(common.corpus_sample()[1][1])  # a whole 64 KiB block: Snappy re-zeroes its table per 64 KiB, LZ4 uses the u16 table up to there
         blocks.append(b"".join(d for _, d, _ in common.corpus_sample()[:2])[:100000])  # beyond 64 KiB: the i32 table (LZ4), a second sub-block (Snappy)
-    # (not the serial-probe variants 0: after `if (lane == 0) { emit }` in the middle of replicated serial code the hardware has the other
-    # lanes wait at the join; the shim lets them run on to their next access -- it does not model reconvergence)
-    for codec, op, variants in (("lz4", 1, (1, 3)), ("snappy", 3, (2, 1, 3))):  # (variants 3: the LDS-window experiments, lz4_compress_v3.hip / snappy_compress_v3.hip)
+    # (the serial-probe variants 0 run `if (lane == 0) { emit }` in the middle of replicated serial code and have the other lanes wait at the
+    # join: what the shim's earliest-in-the-program-first release of paused lanes is for)
+    for codec, op, variants in (("lz4", 1, (1, 3, 0)), ("snappy", 3, (2, 1, 3, 0))):  # (variants 3: the LDS-window experiments, lz4_compress_v3.hip / snappy_compress_v3.hip)
         caps = [o.max_compressed_length(codec, len(b)) for b in blocks]
         for v in variants:
             bad += compare("%s compress, variant %d" % (codec, v), op, v, blocks, caps, lambda b, c, codec=codec: o.compress(codec, b, c))
@@ -90,7 +90,7 @@ def part_zstd():
         blocks.append((sample[0] + sample[1] + sample[2])[:140000])  # two blocks: tables, repeat offsets, Huffman reuse carried over
         blocks.append(b"".join(sample[:5])[:270000])                  # beyond 256 KiB: the default parameter row
     caps = [o.max_compressed_length("zstd", len(b)) for b in blocks]
-    for v in ((0,) if quick else (0, 2)):  # (0: match kernel + entropy kernel, the default; 2: one kernel.  Not 1, the serial-probe baseline: see part_block)
+    for v in ((0, 1) if quick else (0, 1, 2)):  # (0: match kernel + entropy kernel, the default; 1: the same with serial probes; 2: one kernel)
         bad += compare("zstd compress, variant %d" % v, 5, v, blocks, caps, lambda b, c: o.compress("zstd", b, c))
     some = blocks[2:8]
     tight = [max(len(o.compress("zstd", b)) - 3 * k, 0) for k, b in enumerate(some)]

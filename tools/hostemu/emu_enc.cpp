@@ -1,6 +1,6 @@
 // tools/hostemu/emu_enc.cpp -- the ENCODERS on the CPU.  They run the same serial code on all 64 lanes of a wavefront and change shared
 // state in place (hash tables, sequence stores), which is exact only under the device's lockstep: this unit is built with
-//   clang++ -fsanitize-coverage=inline-8bit-counters,trace-loads,trace-stores
+//   clang++ -fno-omit-frame-pointer -fsanitize-coverage=inline-8bit-counters,trace-loads,trace-stores
 // and HOSTEMU_ACCESS_LOCKSTEP, so that every memory access of the kernel source is a soft order point (hip/hip_runtime.h).  Slow (a fiber
 // switch per access and lane): inputs of a few KiB take seconds, a 128 KiB Zstd block about a minute.
 #define HOSTEMU_ACCESS_LOCKSTEP 1

@@ -76,6 +76,8 @@ struct Fiber {
     uint64_t post = 0;
     int gsize = 4;  // group size of a WAIT_QUAD rendezvous
     long waits[5] = {0, 0, 0, 0, 0};  // (diagnosis: rendezvous of each kind this lane has been to)
+    uintptr_t key[24];                 // (HOSTEMU_ACCESS_LOCKSTEP: where the lane pauses -- return addresses, outermost frame first)
+    int keyLen = 0;
     int recent[64] = {0};              // (diagnosis: source lines of its latest rendezvous)
 };
 
@@ -107,6 +109,15 @@ __asm__(
     "  ret\n"
     ".size hostemu_switch,.-hostemu_switch\n");
 
+inline bool key_less(const Fiber& a, const Fiber& b)
+{
+    const int n = a.keyLen < b.keyLen ? a.keyLen : b.keyLen;
+    for (int i = 0; i < n; i++) {
+        if (a.key[i] != b.key[i]) return a.key[i] < b.key[i];
+    }
+    return false;  // (equal as far as both go: together)
+}
+
 inline void fiber_entry()
 {
     State& s = S();
@@ -124,6 +135,7 @@ inline void wait_here(int kind, const char* file, int line)
     me.wait = kind;
     me.file = file;
     me.line = line;
+    me.keyLen = 0;
     me.waits[kind]++;
     if (kind == WAIT_WAVE) me.recent[me.waits[kind] & 63] = line;
     hostemu_switch(&me.sp, s.schedSp);
@@ -281,8 +293,18 @@ inline void run_workgroup(int nThreads, const std::function<void()>& body)
                 anySoft = anySoft || s.f[t].wait == WAIT_SOFT;
             }
             if (anySoft && !anyRunnable) {
+                // Of the lanes that pause before a memory access, those EARLIEST IN THE PROGRAM go first -- the call stacks' return addresses
+                // compared from the outermost frame inwards, smallest first: a lane inside an `if (lane == 0) { ... }` or still in a loop runs
+                // until it has caught up with the lanes that wait behind the join.  That is the reconvergence a wavefront has by
+                // construction (the other lanes are masked off, not ahead); code laid out in source order is what makes addresses a fair
+                // stand-in for it.  (Lanes with equal stacks -- uniform code -- go together; pauses without a stack, keyLen 0, likewise.)
+                int best = -1;
                 for (int t = w; t < e; t++) {
-                    if (!s.f[t].done && s.f[t].wait == WAIT_SOFT) s.f[t].wait = RUNNABLE;
+                    if (s.f[t].done || s.f[t].wait != WAIT_SOFT) continue;
+                    if (best < 0 || key_less(s.f[t], s.f[best])) best = t;
+                }
+                for (int t = w; t < e; t++) {
+                    if (!s.f[t].done && s.f[t].wait == WAIT_SOFT && !key_less(s.f[best], s.f[t])) s.f[t].wait = RUNNABLE;
                 }
                 released = true;
             }
@@ -423,7 +445,7 @@ inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)
 
 #if defined(HOSTEMU_ACCESS_LOCKSTEP)
 namespace hostemu {
-inline void access_point(const void* p)
+inline void access_point(const void* p, void* pc, void** callerFrame)  // pc: the access in the kernel source; callerFrame: that function's frame
 {
     State& s = S();
     if (!s.inFiber) return;  // host code of the same unit
@@ -432,20 +454,37 @@ inline void access_point(const void* p)
     me.wait = WAIT_SOFT;
     me.file = "memory access";
     me.line = 0;
+    {   // the call stack (units built with -fno-omit-frame-pointer): [saved frame pointer][return address] per frame, up to fiber_entry's null
+        uintptr_t ra[24];
+        int n = 0;
+        ra[n++] = (uintptr_t)pc;
+        void** fp = callerFrame;
+        while (fp != nullptr && n < 24) {
+            const uintptr_t r = (uintptr_t)fp[1];
+            if (r == 0) break;
+            ra[n++] = r;
+            void** up = (void**)fp[0];
+            if (up <= fp || (uintptr_t)up - (uintptr_t)me.stack >= STACK_BYTES) break;
+            fp = up;
+        }
+        me.keyLen = 0;
+        for (int i = n - 1; i >= 0; i--) me.key[me.keyLen++] = ra[i];
+    }
     hostemu_switch(&me.sp, s.schedSp);
 }
 }  // namespace hostemu
+#define HOSTEMU_TRACE_CALLBACK __attribute__((disable_tail_calls))  // (a frame of its own: its return address is the access, its saved frame pointer the kernel function's)
 extern "C" {
-void __sanitizer_cov_load1(uint8_t* p) { hostemu::access_point(p); }
-void __sanitizer_cov_load2(uint16_t* p) { hostemu::access_point(p); }
-void __sanitizer_cov_load4(uint32_t* p) { hostemu::access_point(p); }
-void __sanitizer_cov_load8(uint64_t* p) { hostemu::access_point(p); }
-void __sanitizer_cov_load16(__int128* p) { hostemu::access_point(p); }
-void __sanitizer_cov_store1(uint8_t* p) { hostemu::access_point(p); }
-void __sanitizer_cov_store2(uint16_t* p) { hostemu::access_point(p); }
-void __sanitizer_cov_store4(uint32_t* p) { hostemu::access_point(p); }
-void __sanitizer_cov_store8(uint64_t* p) { hostemu::access_point(p); }
-void __sanitizer_cov_store16(__int128* p) { hostemu::access_point(p); }
+HOSTEMU_TRACE_CALLBACK void __sanitizer_cov_load1(uint8_t* p) { hostemu::access_point(p, __builtin_return_address(0), (void**)*(void**)__builtin_frame_address(0)); }
+HOSTEMU_TRACE_CALLBACK void __sanitizer_cov_load2(uint16_t* p) { hostemu::access_point(p, __builtin_return_address(0), (void**)*(void**)__builtin_frame_address(0)); }
+HOSTEMU_TRACE_CALLBACK void __sanitizer_cov_load4(uint32_t* p) { hostemu::access_point(p, __builtin_return_address(0), (void**)*(void**)__builtin_frame_address(0)); }
+HOSTEMU_TRACE_CALLBACK void __sanitizer_cov_load8(uint64_t* p) { hostemu::access_point(p, __builtin_return_address(0), (void**)*(void**)__builtin_frame_address(0)); }
+HOSTEMU_TRACE_CALLBACK void __sanitizer_cov_load16(__int128* p) { hostemu::access_point(p, __builtin_return_address(0), (void**)*(void**)__builtin_frame_address(0)); }
+HOSTEMU_TRACE_CALLBACK void __sanitizer_cov_store1(uint8_t* p) { hostemu::access_point(p, __builtin_return_address(0), (void**)*(void**)__builtin_frame_address(0)); }
+HOSTEMU_TRACE_CALLBACK void __sanitizer_cov_store2(uint16_t* p) { hostemu::access_point(p, __builtin_return_address(0), (void**)*(void**)__builtin_frame_address(0)); }
+HOSTEMU_TRACE_CALLBACK void __sanitizer_cov_store4(uint32_t* p) { hostemu::access_point(p, __builtin_return_address(0), (void**)*(void**)__builtin_frame_address(0)); }
+HOSTEMU_TRACE_CALLBACK void __sanitizer_cov_store8(uint64_t* p) { hostemu::access_point(p, __builtin_return_address(0), (void**)*(void**)__builtin_frame_address(0)); }
+HOSTEMU_TRACE_CALLBACK void __sanitizer_cov_store16(__int128* p) { hostemu::access_point(p, __builtin_return_address(0), (void**)*(void**)__builtin_frame_address(0)); }
 void __sanitizer_cov_8bit_counters_init(char*, char*) {}
 void __sanitizer_cov_pcs_init(const uintptr_t*, const uintptr_t*) {}
 }
