@@ -8,7 +8,7 @@ RT=$($CLANG -print-file-name=libclang_rt.asan-x86_64.so)
 if [ "$1" = "--enc" ]; then
     shift
     if [ ! -f tools/hostemu/libemu_enc_asan.so ] || [ tools/hostemu/emu_enc.cpp -nt tools/hostemu/libemu_enc_asan.so ] || [ -n "$(find aircompressor_amd/csrc tools/hostemu/hip -newer tools/hostemu/libemu_enc_asan.so -name '*.h*' | head -1)" ]; then
-        $CLANG -O2 -g -std=c++17 -fPIC -shared -fsanitize=address -shared-libasan -fno-omit-frame-pointer -fsanitize-coverage=inline-8bit-counters,trace-loads,trace-stores \
+        $CLANG -O2 -g -std=c++17 -fPIC -shared -Wl,-Bsymbolic-functions -fsanitize=address -shared-libasan -fno-omit-frame-pointer -fsanitize-coverage=inline-8bit-counters,trace-loads,trace-stores \
             -I tools/hostemu -I include -I aircompressor_amd/csrc -o tools/hostemu/libemu_enc_asan.so tools/hostemu/emu_enc.cpp || exit 1
     fi
     LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:verify_asan_link_order=0 exec python tools/hostemu/asan_enc.py "$@"
