@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 from tests import common, oracle_lib
 from tests.oracle_lib import OracleError
 
-emu = ctypes.CDLL(os.path.join(ROOT, "tools", "hostemu", "libemu.so"))
+emu = ctypes.CDLL(os.path.join(ROOT, "tools", "hostemu", os.environ.get("HOSTEMU_LIB", "libemu.so")))  # (HOSTEMU_LIB=libemu_lockstep.so: emu_lockstep.cpp)
 o = oracle_lib.load()
 
 

@@ -1,6 +1,8 @@
 // tools/hostemu/emu.cpp -- runs the lane-private decoder kernels on the CPU (sequential lanes are exact when a kernel
 // uses no cross-lane operation: the GS=1 instantiations of the ring decoders and the lane-per-block decoders with an LDS window).
+#if !defined(HOSTEMU_NO_RINGS_LOCKSTEP)
 #define HOSTEMU_RINGS_LOCKSTEP 1  // achip_rings.h: the lanes of a group meet where the device's lockstep makes them meet
+#endif
 #include "hip/hip_runtime.h"
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 extern "C" { long long achip_emu_counters[16]; }  // development counters of kernels under emulation (ACHIP_EMU_COUNT)
