@@ -4,8 +4,12 @@
 // and the way to run a changed ring kernel before anybody has thought about where its lanes meet.
 // STATUS (end of round 2): the lane-private decoders (ops 16, 18) and the two-pass decoders (op 24) agree with the oracle under this model as
 // they do under the hand-placed points; the ring decoders with more than one lane per block (ops 44 / 46 / 48) do NOT yet (337-374 of 423
-// cases differ, also with a whole wavefront per block, i.e. in uniform control flow) -- something they rely on is not an access the
-// tracing sees.  Until that is found, libemu.so with achip_rings.h's own points is what checks the ring decoders (0 mismatches).
+// cases differ, also with a whole wavefront per block).  Probable cause: LOOP BACK-EDGES.  "Earliest in the program first" compares
+// addresses, so a lane that has already jumped back to the head of the sequence loop (low address) is preferred over lanes still in the
+// previous trip's tail (high address) -- the opposite of what a wavefront does, whose lanes meet at the loop's end before any goes round
+// again; the ring decoders' trips differ in length from lane to lane and hand bytes from trip to trip through the rings, the encoders' and
+// two-pass decoders' loops have a cross-lane operation in every trip.  Until the shim knows about trips, libemu.so with achip_rings.h's own
+// points is what checks the ring decoders (0 mismatches).
 //   clang++ -O2 -fno-omit-frame-pointer -fsanitize-coverage=inline-8bit-counters,trace-loads,trace-stores ... -o libemu_lockstep.so emu_lockstep.cpp
 //   HOSTEMU_LIB=libemu_lockstep.so python tools/hostemu/check_v3.py --ops 44,54
 #define HOSTEMU_ACCESS_LOCKSTEP 1
