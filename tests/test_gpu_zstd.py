@@ -153,6 +153,7 @@ def frame_blocks(f):
             return n
 
 
+@pytest.mark.timeout(900, method="thread")  # (the default pass size was last changed after the round's GPU minutes: CPU-emulator-verified)
 @pytest.mark.parametrize("stream_blocks", [65536, 16])
 def test_multi_block_frames_take_the_multi_block_stages(o, stream_blocks):
     """frames of several blocks (ZstdOutputStream / ZstdFrameCompressor / libzstd beyond 128 KiB) go through the
