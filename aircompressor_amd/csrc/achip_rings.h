@@ -50,6 +50,10 @@ struct Rings {
 #if !defined(__HIPCC__) && defined(HOSTEMU_RINGS_LOCKSTEP)
     __device__ __forceinline__ void order() const { if (GS > 1) hostemu::group_sync(GS, __FILE__, __LINE__); }
     __device__ __forceinline__ void enter() const { if (GS > 1) hostemu::group_sync(GS, __FILE__, __LINE__); }
+#elif !defined(__HIPCC__) && defined(HOSTEMU_RINGS_ORDER_ONLY)
+    // (tools/hostemu/emu_lockstep.cpp: under access-granular lockstep the group only has to meet where the device has its compiler barrier)
+    __device__ __forceinline__ void order() const { if (GS > 1) hostemu::group_sync(GS, __FILE__, __LINE__); }
+    __device__ __forceinline__ void enter() const {}
 #else
     __device__ __forceinline__ void order() const { wave_mem_order(); }
     __device__ __forceinline__ void enter() const {}

@@ -299,8 +299,8 @@ inline void run_workgroup(int nThreads, const std::function<void()>& body)
                 // construction (the other lanes are masked off, not ahead); code laid out in source order is what makes addresses a fair
                 // stand-in for it.  (Lanes with equal stacks -- uniform code -- go together; pauses without a stack, keyLen 0, likewise.)
                 // Not modelled: loop trips.  A lane back at a loop's head compares EARLIER than lanes in the previous trip's tail; kernels
-                // whose lanes fall out of step inside a trip and have no cross-lane operation per trip (the ring decoders) need their own
-                // rendezvous points (achip_rings.h) -- tools/hostemu/emu_lockstep.cpp.
+                // whose lanes fall out of step inside a trip and have no cross-lane operation per trip (the ring decoders) need a rendezvous
+                // of their own now and then -- where their device code has its wave_mem_order() is enough: tools/hostemu/emu_lockstep.cpp.
                 int best = -1;
                 for (int t = w; t < e; t++) {
                     if (s.f[t].done || s.f[t].wait != WAIT_SOFT) continue;
