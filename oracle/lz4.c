@@ -80,7 +80,9 @@ static int64_t encode_run_length(uint8_t* out, int64_t o, int64_t length)
 static int64_t emit_last_literal(uint8_t* out, int64_t o, const uint8_t* in, int64_t from, int64_t length)
 {
     o = encode_run_length(out, o, length);
-    memcpy(out + o, in + from, (size_t)length);
+    if (length > 0) {  /* (an empty input has a null `in`) */
+        memcpy(out + o, in + from, (size_t)length);
+    }
     return o + length;
 }
 

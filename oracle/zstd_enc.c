@@ -1267,7 +1267,7 @@ static int32_t encode_literals(cctx* c, uint8_t* base, int64_t outputAddress, in
             break;
         }
         case 4: {
-            uint32_t header = (uint32_t)(encodingType | (2 << 2) | (literalsSize << 4) | (totalSize << 18));
+            uint32_t header = (uint32_t)encodingType | (2u << 2) | ((uint32_t)literalsSize << 4) | ((uint32_t)totalSize << 18);  /* (Java's int arithmetic wraps: unsigned here) */
             st32(base + outputAddress, header);
             break;
         }
@@ -1620,7 +1620,9 @@ static int64_t zstd_compress(cctx* c, const uint8_t* in, int32_t inputSize, uint
                 CHECK_ARGUMENT(blockSize + SIZE_OF_BLOCK_HEADER <= outputSize);
                 int32_t blockHeader = (lastBlock ? 1 : 0) | (RAW_BLOCK << 1) | (blockSize << 3);
                 st24(out + output, (uint32_t)blockHeader);
-                memcpy(out + output + SIZE_OF_BLOCK_HEADER, in + input, (size_t)blockSize);
+                if (blockSize > 0) {
+                    memcpy(out + output + SIZE_OF_BLOCK_HEADER, in + input, (size_t)blockSize);
+                }
                 compressedSize = SIZE_OF_BLOCK_HEADER + blockSize;
             }
             else {
@@ -1750,7 +1752,9 @@ static int64_t zstd_stream_compress(cctx* c, const uint8_t* src, int32_t n, uint
                 }
                 if (compressedSize == 0) {
                     st24(compressed, (uint32_t)((lastBlock ? 1 : 0) | (RAW_BLOCK << 1) | (blockSize << 3)));
-                    memcpy(compressed + SIZE_OF_BLOCK_HEADER, in + offset, (size_t)blockSize);
+                    if (blockSize > 0) {
+                        memcpy(compressed + SIZE_OF_BLOCK_HEADER, in + offset, (size_t)blockSize);
+                    }
                     compressedSize = SIZE_OF_BLOCK_HEADER + blockSize;
                 }
                 else {

@@ -175,5 +175,7 @@ def load():
         srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
         if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
             build()
+        if os.environ.get("ORACLE_LIB"):  # (e.g. liboracle_asan.so -- `make -C oracle asan`, run with the sanitizer runtime preloaded)
+            path = os.path.join(ORACLE_DIR, os.environ["ORACLE_LIB"])
         _cached = Oracle(ctypes.CDLL(path))
     return _cached
