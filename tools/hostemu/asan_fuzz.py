@@ -12,7 +12,7 @@ import numpy as np
 from tests import common, oracle_lib
 
 o = oracle_lib.load()
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "hostemu", "libemu_all_asan.so"))
+lib = ctypes.CDLL(os.path.join(ROOT, "tools", "hostemu", os.environ.get("HOSTEMU_LIB", "libemu_all_asan.so")))  # (HOSTEMU_LIB=libemu_all_ubsan.so: the same fuzz under UBSan)
 P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
 counters = np.zeros(64, dtype=np.int32)
 
