@@ -23,9 +23,11 @@ hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, i
 hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
-int64_t lz4_twopass_scratch_bytes(int32_t nBlocks);
-int64_t lz4_twopass_scratch_bytes_min(int32_t nBlocks);
-int64_t snappy_twopass_scratch_bytes(int32_t nBlocks);
+int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock);
+// record arena per block of the two-pass decoders (8 bytes per record; lz4_decompress_v7.hip: text-like 64 KiB blocks make 6 000 .. 8 500 LZ4
+// records, 8 500 .. 11 500 Snappy records), and the least it is worth running them with (blocks that do not fit go to the ring decoder)
+constexpr int64_t LZ4_RECORD_BYTES_PER_BLOCK = 98304, LZ4_RECORD_BYTES_PER_BLOCK_MIN = 32768;
+constexpr int64_t SNAPPY_RECORD_BYTES_PER_BLOCK = 131072, SNAPPY_RECORD_BYTES_PER_BLOCK_MIN = 49152;
 hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
 hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
@@ -172,14 +174,40 @@ achip::BatchArgs make_args(const void* srcBase, const int64_t* srcOff, const int
 }
 
 int32_t ensure_scratch(achip_ctx* ctx, int64_t bytes);
-// the two-pass decoders' scratch: the full record arena if the device has it, else what it takes to run at all (blocks whose records do
-// not fit are decoded by the ring decoder)
-int32_t ensure_scratch_prefer(achip_ctx* ctx, int64_t want, int64_t atLeast)
+// The two-pass decoders' scratch (lead bytes of probe statistics + header, meta and record arena): the full arena (`perBlock` bytes of
+// records per block) if the device has it to spare -- never more than half of what is free right now beyond what the context already
+// holds, so that one large batch does not take the device from its other users --, else what is there down to `perBlockMin` (blocks whose
+// records do not fit are decoded by the ring decoder: the parse kernels hand them over per block).  Returns 1 with the scratch in
+// place, 0 when not even the minimum could be had -- the caller then runs the ring decoder alone, which needs no scratch: a batch that
+// decoded before the two-pass decoders existed still decodes on a busy device -- and < 0 for an error that is not about memory.
+int32_t ensure_twopass_scratch(achip_ctx* ctx, int64_t lead, int32_t nBlocks, int64_t perBlock, int64_t perBlockMin)
 {
-    if (ensure_scratch(ctx, want) == 0) {
-        return 0;
+    const int64_t want = lead + achip::twopass_scratch_bytes(nBlocks, perBlock);
+    if (want <= ctx->scratchBytes) {
+        return 1;
     }
-    return ensure_scratch(ctx, atLeast);
+    const int64_t atLeast = lead + achip::twopass_scratch_bytes(nBlocks, perBlockMin);
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t freeB = 0, totalB = 0;
+    int64_t ask = want;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+        const int64_t room = ctx->scratchBytes + (int64_t)(freeB / 2);
+        ask = std::min(want, std::max(room, atLeast));
+    }
+    else {
+        (void)hipGetLastError();
+    }
+    if (ask <= ctx->scratchBytes) {
+        return ctx->scratchBytes >= atLeast ? 1 : 0;
+    }
+    if (ensure_scratch(ctx, ask) == 0) {
+        return 1;
+    }
+    if (ask > atLeast && ensure_scratch(ctx, atLeast) == 0) {
+        return 1;
+    }
+    g_lastError.clear();
+    return 0;
 }
 
 int32_t ensure_scratch(achip_ctx* ctx, int64_t bytes)
@@ -258,7 +286,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
     }
     achip::BatchArgs a = args;
     a.ringPad = ctx->ringPad;
-    if (op == ACHIP_OP_ZSTD_COMPRESS) a.ringPad = ctx->zstdcVariant == 100 ? 999 : (ctx->zstdcVariant == 1 ? 1 : 0);  // encoder variant rides in the spare field
+    if (op == ACHIP_OP_ZSTD_COMPRESS) a.ringPad = ctx->zstdcVariant == 100 ? 999 : (ctx->zstdcVariant == 1 ? 1 : 0);  // (100: -DACHIP_DEV builds only)  // encoder variant rides in the spare field
     if (a.nBlocks < 0) {
         return bad_argument("nBlocks < 0");
     }
@@ -276,8 +304,12 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 // sequence lengths, every candidate decoder is launched and the ones not chosen return at once.  Mixed or short-sequence
                 // batches go to the two-pass decoder (parse to records + a wavefront per block), the rest to the rings.
                 // scratch: [probe statistics: the first 4 KiB][two-pass header, meta, arena]
-                int32_t r = ensure_scratch_prefer(ctx, 4096 + achip::lz4_twopass_scratch_bytes(a.nBlocks), 4096 + achip::lz4_twopass_scratch_bytes_min(a.nBlocks));
+                const int32_t r = ensure_twopass_scratch(ctx, 4096, a.nBlocks, achip::LZ4_RECORD_BYTES_PER_BLOCK, achip::LZ4_RECORD_BYTES_PER_BLOCK_MIN);
                 if (r < 0) return r;
+                if (r == 0) {  // no room for records on this device right now: the rings alone
+                    e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, nullptr);
+                    break;
+                }
                 int32_t* stats = (int32_t*)ctx->scratch;
                 ctx->lastLz4dAuto = true;
                 ctx->lastAutoBlocks = a.nBlocks;
@@ -292,8 +324,12 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 break;
             }
             if (ctx->lz4dVariant == 7) {  // two passes: parse to records, a wavefront per block executes them (lz4_decompress_v7.hip)
-                int32_t r = ensure_scratch_prefer(ctx, achip::lz4_twopass_scratch_bytes(a.nBlocks), achip::lz4_twopass_scratch_bytes_min(a.nBlocks));
+                const int32_t r = ensure_twopass_scratch(ctx, 0, a.nBlocks, achip::LZ4_RECORD_BYTES_PER_BLOCK, achip::LZ4_RECORD_BYTES_PER_BLOCK_MIN);
                 if (r < 0) return r;
+                if (r == 0) {
+                    e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, nullptr);
+                    break;
+                }
                 ctx->lastTwopass = true;
                 e = achip::launch_lz4_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->lz4dGroup, ctx->ringClass, ctx->execVariant, nullptr);
                 break;
@@ -307,8 +343,12 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             break;
         case ACHIP_OP_SNAPPY_DECOMPRESS:
             if (ctx->snappydVariant == 5 && a.nBlocks >= ctx->lz4dAutoMinBlocks) {  // auto, as for LZ4
-                int32_t r = ensure_scratch_prefer(ctx, 4096 + achip::snappy_twopass_scratch_bytes(a.nBlocks), 4096 + achip::lz4_twopass_scratch_bytes_min(a.nBlocks));
+                const int32_t r = ensure_twopass_scratch(ctx, 4096, a.nBlocks, achip::SNAPPY_RECORD_BYTES_PER_BLOCK, achip::SNAPPY_RECORD_BYTES_PER_BLOCK_MIN);
                 if (r < 0) return r;
+                if (r == 0) {
+                    e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, nullptr);
+                    break;
+                }
                 int32_t* stats = (int32_t*)ctx->scratch;
                 ctx->lastLz4dAuto = true;
                 ctx->lastAutoBlocks = a.nBlocks;
@@ -323,8 +363,12 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 break;
             }
             if (ctx->snappydVariant == 7) {  // two passes (snappy_decompress_v5.hip)
-                int32_t r = ensure_scratch_prefer(ctx, achip::snappy_twopass_scratch_bytes(a.nBlocks), achip::lz4_twopass_scratch_bytes_min(a.nBlocks));
+                const int32_t r = ensure_twopass_scratch(ctx, 0, a.nBlocks, achip::SNAPPY_RECORD_BYTES_PER_BLOCK, achip::SNAPPY_RECORD_BYTES_PER_BLOCK_MIN);
                 if (r < 0) return r;
+                if (r == 0) {
+                    e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, nullptr);
+                    break;
+                }
                 ctx->lastTwopass = true;
                 e = achip::launch_snappy_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->snappydGroup, ctx->ringClass, ctx->execVariant, nullptr);
                 break;
@@ -739,23 +783,50 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         if (value != 1 && value != 4 && value != 5 && value != 6 && value != 7) return bad_argument("lz4.decompress.variant: 1 rings, 4 / 6 a lane per block, 7 two passes, 5 auto");
         ctx->lz4dVariant = (int)value;
     }
-    else if (k == "lz4.decompress.auto_min_blocks") ctx->lz4dAutoMinBlocks = (int)value;
+    else if (k == "lz4.decompress.auto_min_blocks") {
+        if (value < 16 || value > 0x7FFFFFFF) return bad_argument("lz4.decompress.auto_min_blocks must be at least 16");
+        ctx->lz4dAutoMinBlocks = (int)value;
+    }
     else if (k == "snappy.decompress.variant") {
         if (value != 1 && value != 4 && value != 5 && value != 6 && value != 7) return bad_argument("snappy.decompress.variant: 1 rings, 4 / 6 a lane per block, 7 two passes, 5 auto");
         ctx->snappydVariant = (int)value;
     }
-    else if (k == "decompress.ring_class") ctx->ringClass = (int)value;
-    else if (k == "lz4.compress.variant") ctx->lz4cVariant = (int)value;
-    else if (k == "snappy.compress.variant") ctx->snappycVariant = (int)value;
-    else if (k == "snappyframed.decompress.variant") ctx->snappyFramedVariant = (int)value;
-    else if (k == "snappyframed.compress.variant") ctx->snappyFramedCompressVariant = (int)value;
+    else if (k == "decompress.ring_class") {
+        if (value != 0 && value != 1) return bad_argument("decompress.ring_class: 0 compact, 1 large");
+        ctx->ringClass = (int)value;
+    }
+    else if (k == "lz4.compress.variant") {
+        if (value != 0 && value != 1 && value != 3) return bad_argument("lz4.compress.variant: 0 serial probes, 1 batch probes, 3 batch probes over an LDS input window");
+        ctx->lz4cVariant = (int)value;
+    }
+    else if (k == "snappy.compress.variant") {
+        if (value < 0 || value > 3) return bad_argument("snappy.compress.variant: 0 serial probes, 1 batch probes, 2 two tiers, 3 two tiers over LDS input windows");
+        ctx->snappycVariant = (int)value;
+    }
+    else if (k == "snappyframed.decompress.variant") {
+        if (value < 0 || value > 2) return bad_argument("snappyframed.decompress.variant: 0 a wavefront per stream, 1 chunk list through the ring decoders, 2 through the two-pass decoder");
+        ctx->snappyFramedVariant = (int)value;
+    }
+    else if (k == "snappyframed.compress.variant") {
+        if (value != 0 && value != 1) return bad_argument("snappyframed.compress.variant: 0 a wavefront per stream, 1 block list");
+        ctx->snappyFramedCompressVariant = (int)value;
+    }
     else if (k == "hadoop.buffer_size") {
         if (value < 64 || value > 0x40000000) return bad_argument("hadoop.buffer_size out of range");
         ctx->hadoopBufferSize = (int)value;
     }
-    else if (k == "hadoop.decompress.variant") ctx->hadoopDecompressVariant = (int)value;
-    else if (k == "lz4frame.decompress.variant") ctx->lz4FrameDecompressVariant = (int)value;
-    else if (k == "zstd.decompress.exec") achip::g_zstd_pipe_exec = (int)value;  // (process-wide: a development switch between the two execute stages)
+    else if (k == "hadoop.decompress.variant") {
+        if (value < 0 || value > 2) return bad_argument("hadoop.decompress.variant: 0 a wavefront per stream, 1 chunk list through the ring decoders, 2 through the two-pass decoders");
+        ctx->hadoopDecompressVariant = (int)value;
+    }
+    else if (k == "lz4frame.decompress.variant") {
+        if (value != 0 && value != 1) return bad_argument("lz4frame.decompress.variant: 0 a wavefront per item, 1 block list through the two-pass decoder");
+        ctx->lz4FrameDecompressVariant = (int)value;
+    }
+    else if (k == "zstd.decompress.exec") {
+        if (value < 0 || value > 2) return bad_argument("zstd.decompress.exec: 0 rings, 1 record executor, 2 chosen per item");
+        achip::g_zstd_pipe_exec = (int)value;
+    }  // (process-wide: a development switch between the two execute stages)
     else if (k == "decompress.ring_pad") {
         if (value < 0 || value > 256 || (value & 15) != 0) return bad_argument("ring pad must be a multiple of 16 in 0..256");
         ctx->ringPad = (int)value;
@@ -773,15 +844,35 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         if (value != 8 && value != 16) return bad_argument("items per wavefront: 8 or 16");
         (k == "zstd.decompress.lit_items" ? achip::g_zstd_pipe_lit_items : achip::g_zstd_pipe_seq_items) = (int)value;
     }
-    else if (k == "zstd.decompress.variant") ctx->zstddVariant = (int)value;
+    else if (k == "zstd.decompress.variant") {
+        if (value != 0 && value != 1) return bad_argument("zstd.decompress.variant: 1 pipeline, 0 one-kernel decoder");
+        ctx->zstddVariant = (int)value;
+    }
     else if (k == "zstd.stream.chunked") ctx->zstdStreamChunked = value != 0 ? 1 : 0;
     else if (k == "zstd.decompress.stream_blocks") {
         if (value != 0 && (value < 16 || value > 131072)) return bad_argument("zstd.decompress.stream_blocks must be 0 or 16..131072");
         ctx->zstdStreamBlocks = (int)value;
     }
-    else if (k == "zstd.compress.variant") ctx->zstdcVariant = (int)value;
+    else if (k == "zstd.compress.variant") {
+        // (100, a timing aid whose output is not valid, exists in -DACHIP_DEV builds only: a shipped library has no option that returns wrong data)
+        bool ok = value >= 0 && value <= 2;
+#ifdef ACHIP_DEV
+        ok = ok || value == 100;
+#endif
+        if (!ok) return bad_argument("zstd.compress.variant: 0 match-finder kernel + entropy kernel, 1 the same with serial probes, 2 one kernel");
+        ctx->zstdcVariant = (int)value;
+    }
     else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;
-    else if (k == "decompress.exec_variant") ctx->execVariant = (int)value;
+    else if (k == "decompress.exec_variant") {
+        // 2 the product; 124 / 125 an 8 KiB window / registers capped (valid results); 302 .. 308 the batch in parts over two helper
+        // streams (valid results).  121 .. 123 and 201 skip work (results NOT valid): -DACHIP_DEV builds only.
+        bool ok = value == 2 || value == 124 || value == 125 || (value >= 302 && value <= 308);
+#ifdef ACHIP_DEV
+        ok = ok || (value >= 121 && value <= 123) || value == 201;
+#endif
+        if (!ok) return bad_argument("decompress.exec_variant: 2, 124, 125 or 302..308");
+        ctx->execVariant = (int)value;
+    }
     else if (k == "host.chunk_bytes") {
         if (value < (1 << 16) || value > (1LL << 32)) return bad_argument("host.chunk_bytes must be in 64 KiB .. 4 GiB");
         ctx->hostChunkBytes = value;

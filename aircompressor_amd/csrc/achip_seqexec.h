@@ -124,7 +124,9 @@ struct LaneFeed {
     {
         ring = lds + lane * STRIDE;
         inBase = (int32_t)((uintptr_t)in & (GRAN - 1));
-        inAligned = in - inBase;
+        // (an empty payload has no byte of its own to anchor the granule loads at: `in` may be the first byte BEHIND the item, and on a
+        // 32-byte boundary the piece at `in` then lies outside everything the caller handed over -- such a stream reads `anywhere`)
+        inAligned = inLimit > 0 ? in - inBase : (const uint8_t*)anywhere;
         lastV = inLimit > 0 ? ((inLimit + inBase - 1) & ~15) : 0;
         safe = (const uint8_t*)anywhere;
         loadedV = 0;

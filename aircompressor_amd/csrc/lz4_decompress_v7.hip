@@ -356,16 +356,18 @@ int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock)
     return fixed + arena;
 }
 int64_t lz4_twopass_scratch_bytes(int32_t nBlocks) { return twopass_scratch_bytes(nBlocks, 98304); }
-int64_t lz4_twopass_scratch_bytes_min(int32_t nBlocks) { return twopass_scratch_bytes(nBlocks, 32768); }
 
 // the execute pass (shared with snappy_decompress_v5.hip); execVariant 2 = the product, 121..125 = timing aids and window sizes (results not valid / slower)
 hipError_t launch_seq_execute2(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant, const int32_t* stats, int32_t shortLimit)
 {
     const dim3 grid((unsigned)a.nBlocks), wg(64);
+#ifdef ACHIP_DEV  // timing aids (no matches / no literals / no flush: results NOT valid) -- never in a shipped library
     if (execVariant == 121) hipLaunchKernelGGL(seq_execute2_kernel<1>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
     else if (execVariant == 122) hipLaunchKernelGGL(seq_execute2_kernel<2>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
     else if (execVariant == 123) hipLaunchKernelGGL(seq_execute2_kernel<3>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
-    else if (execVariant == 124) hipLaunchKernelGGL((seq_execute2_kernel<0, 8192>), grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
+    else
+#endif
+    if (execVariant == 124) hipLaunchKernelGGL((seq_execute2_kernel<0, 8192>), grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
     else if (execVariant == 125) hipLaunchKernelGGL((seq_execute2_kernel<0, 4096, 7>), grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
     else hipLaunchKernelGGL(seq_execute2_kernel<0>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
     return hipGetLastError();
@@ -453,10 +455,13 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream,
         if (e != hipSuccess) return e;
     }
     else {
-    if (execVariant == 201) {  // (timing aid: no record stores)
+#ifdef ACHIP_DEV
+    if (execVariant == 201) {  // (timing aid: no record stores -- results NOT valid)
         hipLaunchKernelGGL(lz4_parse2_kernel<1>, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
     }
-    else {
+    else
+#endif
+    {
         hipLaunchKernelGGL(lz4_parse2_kernel<0>, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
     }
     e = launch_seq_execute2(a, stream, meta, arena, execVariant, stats, 12);

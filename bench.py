@@ -44,7 +44,7 @@ def parse_args():
     p.add_argument("--workload", default="lz4_decompress", choices=["lz4_decompress", "snappy_decompress", "lz4_compress", "snappy_compress"])
     p.add_argument("--data", default="fragments", choices=["fragments", "wordmix", "corpus"])
     p.add_argument("--group", type=int, default=0, help="decoder lanes per block (0 = library default)")
-    p.add_argument("--variant", type=int, default=-1, help="decoder variant: 1 = LDS rings (default), 0 = direct-to-HBM groups")
+    p.add_argument("--variant", type=int, default=-1, help="decoder variant: 5 = chosen on the device (default), 1 = LDS rings, 7 = two passes, 4 / 6 = a lane per block")
     p.add_argument("--ring-class", type=int, default=-1, help="0 = compact LDS rings, 1 = large")
     p.add_argument("--compress-variant", type=int, default=-1, help="LZ4 / Snappy encoder variant (see lz4.compress.variant)")
     p.add_argument("--ring-pad", type=int, default=-1, help="LDS bytes between the ring pairs of consecutive blocks (multiple of 16)")
@@ -181,6 +181,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo")
+    if os.environ.get("ACHIP_BENCH_SHARE_DEVICE") == "1":
+        # PATH CHECK ONLY (never a scaling number): every rank uses device 0, so that the N > 1 path -- rendezvous, shard_for_rank, barrier,
+        # max-over-ranks, one JSON line from rank 0, verification on every rank -- can be executed end to end on a box with one GPU
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -358,7 +362,7 @@ def main():
             "workload": "%s, %d x %d B %s blocks per GPU (BASELINE configs[1]), %s data%s, LZ4 ratio %.3f, batched C-ABI launch, HBM-resident" % (
                 wl, n_local, bs, name.upper(), args.data, (" ratio=%.2f" % args.ratio) if args.data == "fragments" else "", plain_bytes_local / comp_bytes_local),
             "blocks_per_gpu": n_local, "block_bytes": bs, "distinct_blocks": pool_n, "compression_ratio": round(plain_bytes_local / comp_bytes_local, 4),
-            "parallelism": "block-sharded x%d, no collective" % world,
+            "parallelism": "block-sharded x%d, no collective" % world + (" -- ALL RANKS ON ONE DEVICE (ACHIP_BENCH_SHARE_DEVICE=1): a path check, not a scaling number" if world > 1 and os.environ.get("ACHIP_BENCH_SHARE_DEVICE") == "1" else ""),
             "decoder": decoder + (" (chosen on the device: %d of %d 16-block groups mixed)" % (mixed_groups, (n_local + 15) // 16) if mixed_groups >= 0 else ""),
             "twopass_fallback_blocks": twopass_fallback,
         },

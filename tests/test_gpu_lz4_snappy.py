@@ -239,6 +239,74 @@ def test_malformed_inputs_report_the_reference_errors(gb, o, codec, cfg):
     configure(gb, codec, DECODERS[0])
 
 
+@pytest.mark.parametrize("variant", [7, 1, 4, 6], ids=["two-pass", "rings", "copy-steps", "lds-window"])
+def test_snappy_prefix_only_item_at_the_end_of_an_allocation(o, variant):
+    """Round 2's ASan finding (achip_seqexec.h LaneFeed::init): a Snappy item that is its length prefix only and ends on a 32-byte
+    boundary had the 32 bytes BEHIND it read by the two-pass parser.  Here such items end exactly where a hipMalloc'ed source buffer of a
+    whole number of 2 MiB pages ends (nothing of the caller's lies behind them), beside ordinary blocks; status, offset and length must be
+    the oracle's.  (tools/hostemu/asan_fuzz.py runs the same streams under AddressSanitizer, which is what can SEE the read.)"""
+    import ctypes
+    import aircompressor_amd as A
+    from aircompressor_amd import native
+    nat = A.HipNative(0)
+    lib = nat.lib
+    nat.set_option("snappy.decompress.variant", variant)
+    text = common.corpus_sample()[0][1][:3000]
+    items = [(o.compress("snappy", text), len(text))]
+    for n in (0, 1, 300, 65536):  # prefix-only streams: "truncated" unless the announced length is 0
+        c = bytearray()
+        v = n
+        while v >= 0x80:
+            c.append((v & 0x7F) | 0x80)
+            v >>= 7
+        c.append(v)
+        items.append((bytes(c), n))
+    total = 2 << 20
+    src = np.zeros(total, dtype=np.uint8)
+    offs, lens, caps = [], [], []
+    # the ordinary block first, the prefix-only items packed against the END of the buffer: the last one ends at `total`, the others
+    # on 32-byte boundaries before it
+    src[:len(items[0][0])] = np.frombuffer(items[0][0], dtype=np.uint8)
+    offs.append(0); lens.append(len(items[0][0])); caps.append(items[0][1])
+    end = total
+    for c, n in reversed(items[1:]):
+        src[end - len(c):end] = np.frombuffer(c, dtype=np.uint8)
+        offs.append(end - len(c)); lens.append(len(c)); caps.append(max(n, 1))
+        end -= 32
+    n = len(offs)
+    dst_off = np.cumsum([0] + [(c + 15) // 16 * 16 for c in caps[:-1]]).astype(np.int64)
+    dbytes = int(dst_off[-1]) + caps[-1] + 64
+    meta_h = [np.asarray(offs, dtype=np.int64), np.asarray(lens, dtype=np.int32), dst_off, np.asarray(caps, dtype=np.int32)]
+    d_src = lib.achip_device_alloc(nat.ctx, total)
+    d_dst = lib.achip_device_alloc(nat.ctx, dbytes)
+    d_meta = [lib.achip_device_alloc(nat.ctx, m.nbytes) for m in meta_h]
+    d_res = [lib.achip_device_alloc(nat.ctx, n * 4), lib.achip_device_alloc(nat.ctx, n * 4), lib.achip_device_alloc(nat.ctx, n * 8)]
+    try:
+        assert d_src and d_dst and all(d_meta) and all(d_res)
+        assert lib.achip_memcpy_h2d(nat.ctx, d_src, src.ctypes.data, total) == 0
+        for d, m in zip(d_meta, meta_h):
+            assert lib.achip_memcpy_h2d(nat.ctx, d, m.ctypes.data, m.nbytes) == 0
+        nat.synchronize()
+        r = lib.achip_snappy_decompress_batch(nat.ctx, d_src, d_meta[0], d_meta[1], d_dst, d_meta[2], d_meta[3], d_res[0], d_res[1], d_res[2], n)
+        assert r == 0, r
+        out_len = np.zeros(n, dtype=np.int32); status = np.zeros(n, dtype=np.int32); err = np.zeros(n, dtype=np.int64)
+        out = np.zeros(dbytes, dtype=np.uint8)
+        for d, h in zip(d_res + [d_dst], (out_len, status, err, out)):
+            assert lib.achip_memcpy_d2h(nat.ctx, h.ctypes.data, d, h.nbytes) == 0
+        nat.synchronize()
+        for i in range(n):
+            comp = bytes(src[offs[i]:offs[i] + lens[i]])
+            es, eo, eout = _oracle_status(o, "snappy", comp, caps[i])
+            assert (int(status[i]), int(err[i]) if es else 0) == (es, eo if es else 0), "item %d" % i
+            if es == 0:
+                assert bytes(out[dst_off[i]:dst_off[i] + out_len[i]]) == eout
+    finally:
+        for d in [d_src, d_dst] + d_meta + d_res:
+            if d:
+                lib.achip_device_free(nat.ctx, d)
+        nat.close()
+
+
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
 def test_compress_rejects_small_output(gb, o, codec):
     b = common.corpus_sample()[0][1]

@@ -34,11 +34,10 @@ def envelope(size):
     raise RuntimeError("no allocation with the wanted alignment")
 
 
-def run1(call, data, cap, lead, slack=0):
-    """one item: source at offset `lead` (0..31) of a granule-aligned allocation that ends with the granule of the item's last byte
-    (+ `slack` bytes: KNOWN_FINDINGS below)"""
+def run1(call, data, cap, lead):
+    """one item: source at offset `lead` (0..31) of a granule-aligned allocation that ends with the granule of the item's last byte"""
     n = len(data)
-    raw, src = envelope(max((lead + n + GRANULE - 1) // GRANULE * GRANULE, GRANULE) + slack)
+    raw, src = envelope(max((lead + n + GRANULE - 1) // GRANULE * GRANULE, GRANULE))
     if n:
         src[lead:lead + n] = np.frombuffer(bytes(data), dtype=np.uint8)
     dst = np.full(max(cap, 1), 0xA5, dtype=np.uint8)
@@ -50,13 +49,18 @@ def run1(call, data, cap, lead, slack=0):
     return int(ol[0]), int(st[0]), dst
 
 
-# KNOWN_FINDINGS (round 2, found by this fuzz; fix prepared for round 3 where it can be verified on a GPU -- profiles/r02_notes.md):
-#   the two-pass parsers' input feed (achip_seqexec.h LaneFeed::init) anchors an EMPTY payload at `in` itself: a Snappy stream that is its
-#   length prefix only (plaintext of 0 bytes, or truncated behind the prefix) and ends exactly on a 32-byte boundary has the 32 bytes
-#   BEHIND it read (never used).  Harmless inside a batch buffer; at the very end of a mapped region it could fault.  Such streams get
-#   one granule of slack here so that the fuzz goes on looking for anything else.
-def prefix_only(codec, c):
-    return codec == "snappy" and 0 < len(c) <= 5 and all(b & 0x80 for b in c[:-1]) and not (c[-1] & 0x80)
+# Round 2's finding (the two-pass parsers' input feed anchored an EMPTY payload at `in` itself, so a Snappy stream that is its length prefix
+# only and ends on a 32-byte boundary had the 32 bytes BEHIND it read) is fixed in achip_seqexec.h LaneFeed::init; such streams are part of
+# the fuzz with no slack (prefix_only_cases below runs every one of them at the lead that puts their end on a granule boundary).
+def prefix_only_cases():
+    for n in (0, 1, 127, 128, 300, 65536, 1 << 21, (1 << 31) - 1):
+        c = bytearray()
+        v = n
+        while v >= 0x80:
+            c.append((v & 0x7F) | 0x80)
+            v >>= 7
+        c.append(v)
+        yield bytes(c)
 
 
 def mutate(rng, c):
@@ -164,12 +168,19 @@ def main():
                         calls += 1
                 continue
             codec, decoders = family(name)
+            if codec == "snappy":  # the prefix-only streams, their end on a granule boundary (and one byte off it)
+                for c in prefix_only_cases():
+                    for title, call in decoders:
+                        for lead in ((-len(c)) % GRANULE, (-len(c) - 1) % GRANULE):
+                            for cap in (0, 1, 64):
+                                run1(call, c, cap, lead)
+                                calls += 1
             for b in ps:
                 good = o.compress(codec, b)
                 for title, call in decoders:
                     c = mutate(rng, good)
                     cap = max(len(b) + int(rng.integers(-3, 40)), 0) if rng.integers(0, 4) else int(rng.integers(0, len(b) + 2))
-                    run1(call, c, cap, int(rng.integers(0, 32)), GRANULE if prefix_only(codec, c) else 0)
+                    run1(call, c, cap, int(rng.integers(0, 32)))
                     calls += 1
     print("asan fuzz seed %d: %d calls over %s, no report (%.0f s)" % (seed, calls, ", ".join(names), time.time() - t))
 
