@@ -25,8 +25,10 @@
 // the codec's bound, so chunk k is compressed at its WORST-CASE position k * (8 + maxCompressedLength(chunk)) by persistent wavefronts
 // drawing chunks from one list; a wavefront per stream then writes the length fields and moves the chunks left into place, in order.
 //
-// What the one-shot form adds: the offset of the stream-level IOExceptions (the position where the failing read began); a negative
-// chunk length is ACHIP_D_HDP_NEGATIVE_LENGTH (Java: the block codec's range check throws); a Snappy chunk that ends inside its length
+// What the one-shot form adds: the offset of the stream-level IOExceptions (the position where the failing read began); for the
+// Snappy reader a negative chunk length other than -1 is ACHIP_D_HDP_NEGATIVE_LENGTH (Java goes on with whatever its buffer holds from the
+// chunk before: an exception whose kind depends on stale state; the LZ4 reader takes any negative length for the end of the stream, as
+// Java does); a Snappy chunk that ends inside its length
 // preamble is ACHIP_D_SNAPPY_TRUNCATED (Java reads stale buffer bytes); a Snappy chunk that announces more than the destination has
 // left AND more than the wavefront's buffer holds (max(bufferSize, 256 KiB) + 8) is not decoded to look for errors in it
 // (ACHIP_D_HDP_NOT_CONSUMED, what Java reports for a well-formed one).
@@ -104,6 +106,7 @@ struct Reader {
     int64_t eo;
     uint8_t* lds;
     int lane;
+    bool snappy;
 };
 
 // readBigEndianInt :142-156
@@ -146,6 +149,9 @@ __device__ __forceinline__ int32_t next_chunk(Reader& r)
         return e;
     }
     if (clen < 0) {
+        if (!r.snappy) {  // Lz4HadoopInputStream.java:51-54,65-68: `compressedChunkLength < 0` -- any negative value ends the stream for this read
+            return STREAM_EOF;
+        }
         r.eo = r.pos - 4;
         return mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_HDP_NEGATIVE_LENGTH);
     }
@@ -306,6 +312,7 @@ __device__ int32_t decompress_item(const uint8_t* in, int32_t inLen, uint8_t* ou
     r.eo = 0;
     r.lds = lds;
     r.lane = lane;
+    r.snappy = SNAPPY;
     int32_t done = 0;
     int32_t result = 0;
     while (done < outCap) {

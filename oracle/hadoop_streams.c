@@ -19,13 +19,18 @@
  *
  * What the one-shot form adds (no Java counterpart): the offset reported with the stream-level IOExceptions, which carry none -- the
  * position in the stream where the read that failed began; a block codec exception keeps its own offset (relative to the chunk).
- * Deviations, both for inputs no writer produces: a negative chunk length is ACHIP_D_HDP_NEGATIVE_LENGTH (Java: the block codec's
- * range check throws); SnappyHadoopInputStream asks getUncompressedLength of its whole buffer, so a chunk that ends inside its length
- * preamble makes it read stale bytes -- here the preamble ends with the chunk (ACHIP_D_SNAPPY_TRUNCATED), as in snappy_framed.c.
+ * Deviations, both for inputs no writer produces and both in the Snappy reader only: a negative chunk length other than -1 is
+ * ACHIP_D_HDP_NEGATIVE_LENGTH (SnappyHadoopInputStream.java:110-133 goes on to ask getUncompressedLength of whatever its buffer still holds from
+ * the chunk before, then fails in the block codec's range check: an exception whose kind depends on stale state); and, because that
+ * method is asked of the whole buffer, a chunk that ends inside its length preamble makes Java read stale bytes -- here the preamble
+ * ends with the chunk (ACHIP_D_SNAPPY_TRUNCATED), as in snappy_framed.c.  (The LZ4 reader takes any negative chunk length for the end
+ * of the stream, as Java does.)
  *
  * Pinning: the format has no golden vectors in the reference (its tests round-trip through org.apache.hadoop's codecs, absent here);
  * tests/test_oracle_hadoop.py checks the writer against a byte-level description of the format, the reader against hand-built streams
- * covering every branch above, and both against each other over the corpus.
+ * covering every branch above, and both against each other over the corpus.  Since round 3 the reference's OWN stream classes execute
+ * here (oracle/_ref: transliterated by tools/j2c.py) and tests/test_ref_pin.py compares this file with them: the writers byte for byte,
+ * the readers on every one of those hand-built streams and on random damage.
  */
 #include "oracle.h"
 #include "../include/aircompressor_hip.h"
@@ -139,8 +144,14 @@ static int64_t next_chunk(Reader* r)
         return e;
     }
     if (clen < 0) {
+        if (r->codec == 0) {
+            /* Lz4HadoopInputStream: bufferCompressedData :113-126 allocates nothing and reads nothing for a negative length and returns it; both
+             * callers test `compressedChunkLength < 0` (:51-54, :65-68), so ANY negative value ends the stream for the read that sees it --
+             * pinned by the reference's own classes executing (tests/test_ref_pin.py) */
+            return STREAM_EOF;
+        }
         r->eo = r->pos - 4;
-        return MALFORMED(ACHIP_D_HDP_NEGATIVE_LENGTH);
+        return MALFORMED(ACHIP_D_HDP_NEGATIVE_LENGTH);  /* Snappy: only -1 ends the stream (:105-108); see the header for the rest */
     }
     if (r->pos + clen > r->n) {  /* readInput :129-140 */
         r->eo = r->pos;

@@ -124,10 +124,28 @@ inline jstring operator+(T a, const jstring& b)
     return jstring((std::is_same<T, bool>::value ? std::string(a ? "true" : "false") : std::to_string(a)) + b.s);
 }
 struct String {
-    template <class... A>
-    static jstring format(const jstring& f, A...)
+    static void fmt1(std::string& out, const std::string& f, size_t& pos) { out += f.substr(pos); pos = f.size(); }
+    template <class T, class... A>
+    static void fmt1(std::string& out, const std::string& f, size_t& pos, const T& v, const A&... rest)
     {
-        return f;  // (messages only: nothing on the compress path looks at them)
+        // the next %s / %d takes v (the only conversions the reference's messages use)
+        while (pos < f.size()) {
+            if (f[pos] == '%' && pos + 1 < f.size() && (f[pos + 1] == 's' || f[pos + 1] == 'd')) {
+                out += (jstring("") + v).s;
+                pos += 2;
+                fmt1(out, f, pos, rest...);
+                return;
+            }
+            out += f[pos++];
+        }
+    }
+    template <class... A>
+    static jstring format(const jstring& f, const A&... a)
+    {
+        std::string out;
+        size_t pos = 0;
+        fmt1(out, f.s, pos, a...);
+        return jstring(out);
     }
     template <class T>
     static jstring valueOf(T v)
@@ -167,6 +185,9 @@ struct ArrayIndexOutOfBoundsException : IndexOutOfBoundsException {
 struct NullPointerException : RuntimeException {
     using RuntimeException::RuntimeException;
 };
+struct NegativeArraySizeException : RuntimeException {
+    using RuntimeException::RuntimeException;
+};
 struct ArithmeticException : RuntimeException {
     using RuntimeException::RuntimeException;
 };
@@ -182,8 +203,8 @@ struct EOFException : IOException {
 // io.airlift.compress.v3.MalformedInputException (M/MalformedInputException.java:16-38): (offset) / (offset, reason)
 struct MalformedInputException : RuntimeException {
     jlong offset = 0;
-    MalformedInputException(jlong o) : RuntimeException(jstring("Malformed input")), offset(o) {}
-    MalformedInputException(jlong o, const jstring& reason) : RuntimeException(reason), offset(o) {}
+    MalformedInputException(jlong o) : MalformedInputException(o, jstring("Malformed input")) {}
+    MalformedInputException(jlong o, const jstring& reason) : RuntimeException(reason + ": offset=" + o), offset(o) {}
     jlong getOffset() { return offset; }
 };
 
@@ -206,7 +227,7 @@ struct jarray {
     static jarray make(jlong n)
     {
         if (n < 0) {
-            jrt::die("NegativeArraySizeException");
+            throw new NegativeArraySizeException(jstring("") + n);
         }
         jarray a;
         a.length = (jint)n;
@@ -218,9 +239,8 @@ struct jarray {
         if (data == nullptr) {
             jrt::die("NullPointerException (array)");
         }
-        if (i < 0 || i >= length) {
-            fprintf(stderr, "jrt: ArrayIndexOutOfBoundsException: index %lld, length %d\n", (long long)i, length);
-            abort();
+        if (i < 0 || i >= length) {  // (as the JVM: an exception the caller sees, not memory corruption)
+            throw new ArrayIndexOutOfBoundsException(jstring("Index ") + i + " out of bounds for length " + length);
         }
         return data[i];
     }
@@ -293,33 +313,50 @@ struct Unsafe {
     void setMemory(const jobject& b, jlong a, jlong n, jbyte v) const { memset(at(b, a), (uint8_t)v, (size_t)n); }
     void setMemory(jlong a, jlong n, jbyte v) const { memset(at(nullptr, a), (uint8_t)v, (size_t)n); }
 };
-static const Unsafe UNSAFE_INSTANCE;
-#define ARRAY_BYTE_BASE_OFFSET_VALUE 16
+static const Unsafe UNSAFE{};
+#define JASSERT(...) ((void)0)  /* the JVM runs with assertions disabled unless started with -ea */
+
+// enums: instances with ordinal() / name(), as in Java
+struct jenum_base : jobject_base {
+    jint ordinal_ = 0;
+    const char* name_ = "";
+    jint ordinal() { return ordinal_; }
+    jstring name() { return jstring(name_); }
+};
+template <class E>
+inline E* jenum_make(E* e, jint ordinal, const char* name)
+{
+    e->ordinal_ = ordinal;
+    e->name_ = name;
+    return e;
+}
 
 // ---- shifts with Java's promotion and count masking -------------------------------------------------------------------------------
 struct JUshrTag {};
 struct JShrTag {};
 struct JShlTag {};
-static const JUshrTag JUSHR;
-static const JShrTag JSHR;
-static const JShlTag JSHL;
+static constexpr JUshrTag JUSHR{};
+static constexpr JShrTag JSHR{};
+static constexpr JShlTag JSHL{};
 template <class T, class Tag>
 struct JShiftLhs {
     T v;
 };
-// left operand: anything narrower than long promotes to int
-inline JShiftLhs<jlong, JUshrTag> operator>>(jlong v, JUshrTag) { return {v}; }
-inline JShiftLhs<jint, JUshrTag> operator>>(jint v, JUshrTag) { return {v}; }
-inline JShiftLhs<jlong, JShrTag> operator>>(jlong v, JShrTag) { return {v}; }
-inline JShiftLhs<jint, JShrTag> operator>>(jint v, JShrTag) { return {v}; }
-inline JShiftLhs<jlong, JShlTag> operator<<(jlong v, JShlTag) { return {v}; }
-inline JShiftLhs<jint, JShlTag> operator<<(jint v, JShlTag) { return {v}; }
-inline jint operator>>(JShiftLhs<jint, JUshrTag> l, jlong n) { return (jint)((uint32_t)l.v >> (n & 31)); }
-inline jlong operator>>(JShiftLhs<jlong, JUshrTag> l, jlong n) { return (jlong)((uint64_t)l.v >> (n & 63)); }
-inline jint operator>>(JShiftLhs<jint, JShrTag> l, jlong n) { return l.v >> (n & 31); }
-inline jlong operator>>(JShiftLhs<jlong, JShrTag> l, jlong n) { return l.v >> (n & 63); }
-inline jint operator<<(JShiftLhs<jint, JShlTag> l, jlong n) { return (jint)((uint32_t)l.v << (n & 31)); }
-inline jlong operator<<(JShiftLhs<jlong, JShlTag> l, jlong n) { return (jlong)((uint64_t)l.v << (n & 63)); }
+// left operand: anything narrower than long promotes to int (Java's binary numeric promotion for shifts looks at the left operand only)
+template <class T>
+using jpromoted = typename std::conditional<sizeof(T) == 8, jlong, jint>::type;
+template <class T, class = typename std::enable_if<std::is_integral<T>::value>::type>
+constexpr JShiftLhs<jpromoted<T>, JUshrTag> operator>>(T v, JUshrTag) { return {(jpromoted<T>)v}; }
+template <class T, class = typename std::enable_if<std::is_integral<T>::value>::type>
+constexpr JShiftLhs<jpromoted<T>, JShrTag> operator>>(T v, JShrTag) { return {(jpromoted<T>)v}; }
+template <class T, class = typename std::enable_if<std::is_integral<T>::value>::type>
+constexpr JShiftLhs<jpromoted<T>, JShlTag> operator<<(T v, JShlTag) { return {(jpromoted<T>)v}; }
+constexpr jint operator>>(JShiftLhs<jint, JUshrTag> l, jlong n) { return (jint)((uint32_t)l.v >> (n & 31)); }
+constexpr jlong operator>>(JShiftLhs<jlong, JUshrTag> l, jlong n) { return (jlong)((uint64_t)l.v >> (n & 63)); }
+constexpr jint operator>>(JShiftLhs<jint, JShrTag> l, jlong n) { return l.v >> (n & 31); }
+constexpr jlong operator>>(JShiftLhs<jlong, JShrTag> l, jlong n) { return l.v >> (n & 63); }
+constexpr jint operator<<(JShiftLhs<jint, JShlTag> l, jlong n) { return (jint)((uint32_t)l.v << (n & 31)); }
+constexpr jlong operator<<(JShiftLhs<jlong, JShlTag> l, jlong n) { return (jlong)((uint64_t)l.v << (n & 63)); }
 
 // ---- java.lang.Math / Integer / Long / Short / Byte, java.util.Arrays / Objects, System ----------------------------------------------
 struct Math {
@@ -496,4 +533,102 @@ struct Objects {
         }
         return from;
     }
+};
+
+// ---- java.io.OutputStream / InputStream as the translated stream classes use them ----------------------------------------------------
+struct OutputStream : jobject_base {
+    virtual void write(jint b)
+    {
+        jarray<jbyte> one = jarray<jbyte>::make(1);
+        one[0] = (jbyte)b;
+        write(one, 0, 1);
+    }
+    virtual void write(jarray<jbyte> b) { write(b, 0, b.length); }
+    virtual void write(jarray<jbyte> b, jint off, jint len)
+    {
+        for (jint i = 0; i < len; i++) {
+            write((jint)b[off + i]);
+        }
+    }
+    virtual void flush() {}
+    virtual void close() {}
+};
+struct InputStream : jobject_base {
+    virtual jint read() = 0;
+    virtual jint read(jarray<jbyte> b) { return read(b, 0, b.length); }
+    virtual jint read(jarray<jbyte> b, jint off, jint len)
+    {
+        if (len == 0) {
+            return 0;
+        }
+        jint n = 0;
+        while (n < len) {
+            const jint c = read();
+            if (c < 0) {
+                break;
+            }
+            b[off + n++] = (jbyte)c;
+        }
+        return n == 0 ? -1 : n;
+    }
+    virtual jlong skip(jlong n)
+    {
+        jlong k = 0;
+        while (k < n && read() >= 0) {
+            k++;
+        }
+        return k;
+    }
+    virtual jint available() { return 0; }
+    virtual void close() {}
+};
+// a sink that collects what a translated OutputStream writes (the shims' stand-in for the caller's stream)
+struct ByteSink : OutputStream {
+    std::string bytes;
+    using OutputStream::write;
+    void write(jint b) override { bytes.push_back((char)b); }
+    void write(jarray<jbyte> b, jint off, jint len) override
+    {
+        if (off < 0 || len < 0 || off > b.length - len) {
+            throw new IndexOutOfBoundsException(jstring("write out of bounds"));
+        }
+        bytes.append((const char*)b.data + off, (size_t)len);
+    }
+};
+// java.io.ByteArrayInputStream(buf, offset, length) as the reference's test harness uses it (T/HadoopCodecDecompressor.java:40)
+struct ByteSource : InputStream {
+    const uint8_t* p;
+    jlong n, pos = 0;
+    ByteSource(const uint8_t* data, jlong len) : p(data), n(len) {}
+    using InputStream::read;
+    jint read() override { return pos < n ? (jint)p[pos++] : -1; }
+    jint read(jarray<jbyte> b, jint off, jint len) override
+    {
+        if (off < 0 || len < 0 || len > b.length - off) {
+            throw new IndexOutOfBoundsException(jstring("read out of bounds"));
+        }
+        if (pos >= n) {
+            return -1;
+        }
+        const jlong avail = n - pos;
+        if (len > avail) {
+            len = (jint)avail;
+        }
+        if (len <= 0) {
+            return 0;
+        }
+        memcpy(b.data + off, p + pos, (size_t)len);
+        pos += len;
+        return len;
+    }
+    jlong skip(jlong k) override
+    {
+        jlong s = n - pos < k ? n - pos : k;
+        if (s < 0) {
+            s = 0;
+        }
+        pos += s;
+        return s;
+    }
+    jint available() override { return (jint)(n - pos); }
 };
