@@ -286,14 +286,18 @@ class ZstdHipOutputStream:
     def close(self):
         if self._closed:
             return
-        self._closed = True
-        data = b"".join(self._parts)
-        self._parts = []
-        out = bytearray(self._codec.max_compressed_length(len(data)))
-        n = self._codec.compress(data, 0, len(data), out, 0, len(out))
-        self._sink.write(bytes(out[:n]))
-        if hasattr(self._sink, "close"):
-            self._sink.close()
+        # (ZstdOutputStream.close :193-205 sets `closed` only behind writeChunk(true); a failing encode leaves the stream open and the data in
+        # place -- and the sink is closed either way, as its try / finally does)
+        try:
+            data = b"".join(self._parts)
+            out = bytearray(self._codec.max_compressed_length(len(data)))
+            n = self._codec.compress(data, 0, len(data), out, 0, len(out))
+            self._sink.write(bytes(out[:n]))
+            self._parts = []
+            self._closed = True
+        finally:
+            if hasattr(self._sink, "close"):
+                self._sink.close()
 
     def __enter__(self):
         return self
@@ -304,6 +308,72 @@ class ZstdHipOutputStream:
 
 class _ZstdStreamEncoder(_HipCompressor):
     _codec = "zstdstream"
+
+
+class ZstdHipInputStream:
+    """Drop-in for ZstdInputStream (M/zstd/ZstdInputStream.java:28-151 over ZstdIncrementalFrameDecompressor.java:44-386) over a binary source,
+    in whole-buffer form like the other stream twins: the first read takes everything the source holds, asks the library for the bound of
+    what the frames decode to (achip_zstd_decompress_bound: frame and block headers only -- frames need NOT carry a content size, which
+    ZstdOutputStream's do not from 4 MiB on), decodes all frames in one call of the batched decoder and hands the plaintext out as asked.
+    What differs from the Java stream: a damaged stream fails at the first read, not at the read that reaches the damage."""
+
+    def __init__(self, source, device=0, native_ctx=None):
+        self._source = source
+        self._codec = ZstdHipDecompressor(device, native_ctx)
+        self._plain = None
+        self._pos = 0
+        self._closed = False
+
+    def _fill(self):
+        if self._plain is not None:
+            return
+        data = self._source.read()
+        if len(data) == 0:
+            # the incremental decoder wants a frame magic before it will call the stream ended (ZstdInputStream.java:79-85: not at a stopping point)
+            raise IOError("Not enough input bytes")
+        src = _ro_view(data)
+        eo = ctypes.c_int64(0)
+        bound = self._codec._lib.achip_zstd_decompress_bound(src.ctypes.data, int(src.size), ctypes.byref(eo))
+        if bound < 0:
+            native.raise_for_status(int(bound), eo.value)
+        out = bytearray(max(int(bound), 1))
+        n = self._codec.decompress(data, 0, len(data), out, 0, int(bound)) if bound > 0 else 0
+        self._plain = bytes(out[:n])
+
+    def read(self, n=-1):
+        """io-style: up to n bytes (all that is left for n < 0), b"" at the end"""
+        if self._closed:
+            raise IOError("Stream is closed")  # :66-68
+        self._fill()
+        end = len(self._plain) if n is None or n < 0 else min(len(self._plain), self._pos + n)
+        piece = self._plain[self._pos:end]
+        self._pos = end
+        return piece
+
+    def read_into(self, output_buffer, output_offset, output_length):
+        """ZstdInputStream.read(byte[], int, int) :63-105: the number of bytes delivered, -1 at the end of the stream"""
+        if self._closed:
+            raise IOError("Stream is closed")
+        _verify_range(output_buffer, output_offset, output_length)
+        if output_length == 0:
+            return 0
+        piece = self.read(output_length)
+        if not piece:
+            return -1
+        _rw_view(output_buffer)[output_offset:output_offset + len(piece)] = _ro_view(piece)
+        return len(piece)
+
+    def close(self):
+        if not self._closed:
+            self._closed = True
+            if hasattr(self._source, "close"):
+                self._source.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 class ZstdHipDecompressor(_HipDecompressor):

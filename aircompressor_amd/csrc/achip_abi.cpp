@@ -36,7 +36,6 @@ hipError_t launch_snappy_decompress_lanecopy(const BatchArgs& a, hipStream_t str
 hipError_t launch_snappy_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* stats);
 hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
-hipError_t launch_lz4_compress_window(const BatchArgs& a, hipStream_t stream, int maxSrcLenHint);
 hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant, void* scratch);
 hipError_t launch_snappy_compress_window(const BatchArgs& a, hipStream_t stream, void* scratch);
 int64_t snappy_compress_scratch_bytes();
@@ -54,7 +53,6 @@ int64_t hadoop_decompress_scratch_bytes(int32_t nStreams, int32_t bufferSize);
 hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize);
 int64_t hadoop_compress_scratch_bytes(int32_t nStreams);
 extern int g_zstd_pipe_exec;
-extern int g_zstd_pipe_lit_items, g_zstd_pipe_seq_items, g_zstd_pipe_exec_window;
 hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant, const AuxScratch* aux);
 int64_t lz4frame_decompress_scratch_bytes(int32_t nItems, int variant);
 hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch);
@@ -75,15 +73,15 @@ struct achip_ctx {
     int lz4dVariant = 5;     // 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 4 = a lane per block, copies straight between the global buffers (lz4_decompress_v5.hip), 6 = a lane per block with an LDS output window (lz4_decompress_v6.hip), 5 = auto
     int snappydVariant = 5;  // 1 rings (snappy_decompress_v2.hip), 4 / 6 a lane per block (snappy_decompress_v3.hip / _v4.hip), 5 auto as for LZ4
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
-    int lz4cVariant = 1;     // 0 = serial probes, 1 = 64 probes per step (batch), 3 = the same with an LDS input window and one round of loads per batch (lz4_compress_v3.hip: experiment)
-    int snappycVariant = 2;  // 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory, 3 = 2 with an LDS input window (snappy_compress_v3.hip: experiment)
+    int lz4cVariant = 1;     // 0 = serial probes, 1 = 64 probes per step (batch).  (3, the batch over an LDS input window, measured 17.2 against 18.2 GiB/s on corpus in round 3: removed)
+    int snappycVariant = 3;  // 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory, 3 = 2 with an LDS input window (snappy_compress_v3.hip; the default since round 3: 8.3 against 7.6 GiB/s on corpus, 75.4 against 74.1 on fragments)
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 0;
     int hadoopBufferSize = 262144;        // Hadoop block streams: the streams' buffer size (Lz4HadoopStreams.java:30; io.compression.codec.*.buffersize)
-    int lz4FrameDecompressVariant = 0;    // 0 = a wavefront per item (default); 1 = the frames' blocks as one batch through the two-pass block decoder (unmeasured)
-    int hadoopDecompressVariant = 1;      // 1 = chunk list through the batched block decoders (rings), the serial kernel behind it (default); 2 = the same through the two-pass decoders (unmeasured); 0 = one wavefront per stream
+    int lz4FrameDecompressVariant = 2;    // 2 = chosen per call by a probe of the sequence lengths (default: 75 / 13.4 GiB/s on fragments / corpus frames); 0 = a wavefront per item (75 / 7.8); 1 = the frames' blocks as one batch through the two-pass block decoder (22 / 13.4)
+    int hadoopDecompressVariant = 3;      // 3 = chunk list, the block decoder chosen per call by a probe of the sequence lengths (default); 1 = always the rings; 2 = always the two-pass decoders; 0 = one wavefront per stream (profiles/r03_notes.md)
     int snappyFramedCompressVariant = 1;  // framed writer: 1 = block list + two-tier block encoder + compaction (default), 0 = one wavefront per stream
-    int snappyFramedVariant = 1;  // framed reader: 1 = chunk list + batched block decoders (default), 0 = one wavefront per stream
+    int snappyFramedVariant = 3;  // framed reader: 3 = chunk list, the block decoder chosen per call by a probe of the element lengths (default); 1 = always the rings; 2 = always the two-pass decoder; 0 = one wavefront per stream
     int zstdTile = 65536;    // items per pass of the Zstd decode pipeline (halved automatically when its scratch cannot be allocated)
     int zstdStreamChunked = 1;     // 1: the stream writer takes streams from 4 MiB on as well (chunks flushed before close(), window slides: zstd_stream.hip; byte-identical with
                                    // the test suite's CPU restatement under tools/hostemu, not yet run on a GPU); 0: it refuses them (INVALID_ARGUMENT / ACHIP_D_UNSUPPORTED)
@@ -99,7 +97,7 @@ struct achip_ctx {
     bool lastTwopass = false;   // the last decode was a two-pass one: its arena header leads the scratch
     bool lastLz4dAuto = false;  // the last LZ4 decode ran in auto mode: its probe count leads the scratch
     int maxSrcLenHint = 0;
-    int execVariant = 2;     // two-pass decoders: 2 = the product; 121..125, 201 = timing aids / window sizes (development)
+    int execVariant = 2;     // two-pass decoders: 2 = the product; 121..123, 201 = timing aids of -DACHIP_DEV builds
     // scratch for the zstd pipeline (grown on demand)
     void* scratch = nullptr;
     int64_t scratchBytes = 0;
@@ -339,7 +337,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                                         : achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, nullptr);
             break;
         case ACHIP_OP_LZ4_COMPRESS:
-            e = ctx->lz4cVariant == 3 ? achip::launch_lz4_compress_window(a, ctx->stream, ctx->maxSrcLenHint) : achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint);
+            e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint);
             break;
         case ACHIP_OP_SNAPPY_DECOMPRESS:
             if (ctx->snappydVariant == 5 && a.nBlocks >= ctx->lz4dAutoMinBlocks) {  // auto, as for LZ4
@@ -670,6 +668,57 @@ int64_t achip_snappy_uncompressed_length(const void* src, int64_t srcLen, int64_
     return (int64_t)result;
 }
 
+// An upper bound of what the frames in [src, src + srcLen) decode to -- what a one-shot decoder needs before it can read a stream
+// whose frames carry NO content size (ZstdOutputStream writes such frames from 4 MiB on, M/zstd/ZstdOutputStream.java:193-221; the
+// reference reads them through a growing window, M/zstd/ZstdIncrementalFrameDecompressor.java:99-234,305-352, never knowing the size).
+// Walks the frame headers (readFrameHeader, M/zstd/ZstdFrameDecompressor.java:865-947) and the block headers (:156-181): a raw or RLE
+// block decodes to its size field, a compressed block to at most MAX_BLOCK_SIZE = 128 KiB (:278), a frame to at most its content
+// size when it has one.  Host code, no device.  Negative = status (the bytes do not parse as frames; *errOffset set).
+int64_t achip_zstd_decompress_bound(const void* src, int64_t srcLen, int64_t* errOffset)
+{
+    const uint8_t* in = (const uint8_t*)src;
+    auto fail = [&](int detail, int64_t off) -> int64_t {
+        if (errOffset) *errOffset = off;
+        return ACHIP_STATUS(ACHIP_CLASS_MALFORMED, detail);
+    };
+    if (errOffset) *errOffset = 0;
+    if (srcLen < 0 || (srcLen > 0 && in == nullptr)) return bad_argument("src");
+    int64_t input = 0, total = 0;
+    while (input < srcLen) {
+        int64_t eo = 0;
+        const int64_t fcs = achip_zstd_decompressed_size(in + input, srcLen - input, &eo);
+        if (fcs < -1) {
+            if (errOffset) *errOffset = input + eo;
+            return fcs;
+        }
+        const int32_t fhd = in[input + 4];
+        const bool singleSegment = (fhd & 0x20) != 0, hasChecksum = (fhd & 0x04) != 0;
+        const int32_t csDesc = fhd >> 6;
+        input += 4 + 1 + (singleSegment ? 0 : 1) + (csDesc == 0 ? (singleSegment ? 1 : 0) : (1 << csDesc));
+        int64_t blocks = 0;
+        for (;;) {
+            if (srcLen - input < 3) return fail(ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, input);
+            const int32_t h = in[input] | (in[input + 1] << 8) | (in[input + 2] << 16);
+            input += 3;
+            const int32_t type = (h >> 1) & 3, size = h >> 3;
+            if (type == 3) return fail(ACHIP_D_ZSTD_INVALID_BLOCK_TYPE, input);
+            const int64_t stored = type == 1 ? 1 : size;  // an RLE block stores one byte
+            if (stored > srcLen - input) return fail(ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, input);
+            input += stored;
+            blocks += type == 2 ? 131072 : size;
+            if (h & 1) {
+                break;
+            }
+        }
+        if (hasChecksum) {
+            if (srcLen - input < 4) return fail(ACHIP_D_ZSTD_NOT_ENOUGH_INPUT, input);
+            input += 4;
+        }
+        total += fcs >= 0 && fcs < blocks ? fcs : blocks;
+    }
+    return total;
+}
+
 int64_t achip_zstd_decompressed_size(const void* src, int64_t srcLen, int64_t* errOffset)
 {
     // ZstdFrameDecompressor.getDecompressedSize = verifyMagic + readFrameHeader
@@ -796,7 +845,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->ringClass = (int)value;
     }
     else if (k == "lz4.compress.variant") {
-        if (value != 0 && value != 1 && value != 3) return bad_argument("lz4.compress.variant: 0 serial probes, 1 batch probes, 3 batch probes over an LDS input window");
+        if (value != 0 && value != 1) return bad_argument("lz4.compress.variant: 0 serial probes, 1 batch probes");
         ctx->lz4cVariant = (int)value;
     }
     else if (k == "snappy.compress.variant") {
@@ -804,7 +853,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->snappycVariant = (int)value;
     }
     else if (k == "snappyframed.decompress.variant") {
-        if (value < 0 || value > 2) return bad_argument("snappyframed.decompress.variant: 0 a wavefront per stream, 1 chunk list through the ring decoders, 2 through the two-pass decoder");
+        if (value < 0 || value > 3) return bad_argument("snappyframed.decompress.variant: 0 a wavefront per stream, 1 chunk list through the ring decoders, 2 through the two-pass decoder, 3 chosen by a probe");
         ctx->snappyFramedVariant = (int)value;
     }
     else if (k == "snappyframed.compress.variant") {
@@ -816,11 +865,11 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->hadoopBufferSize = (int)value;
     }
     else if (k == "hadoop.decompress.variant") {
-        if (value < 0 || value > 2) return bad_argument("hadoop.decompress.variant: 0 a wavefront per stream, 1 chunk list through the ring decoders, 2 through the two-pass decoders");
+        if (value < 0 || value > 3) return bad_argument("hadoop.decompress.variant: 0 a wavefront per stream, 1 chunk list through the ring decoders, 2 through the two-pass decoders, 3 chosen by a probe");
         ctx->hadoopDecompressVariant = (int)value;
     }
     else if (k == "lz4frame.decompress.variant") {
-        if (value != 0 && value != 1) return bad_argument("lz4frame.decompress.variant: 0 a wavefront per item, 1 block list through the two-pass decoder");
+        if (value < 0 || value > 2) return bad_argument("lz4frame.decompress.variant: 0 a wavefront per item, 1 block list through the two-pass decoder, 2 chosen by a probe");
         ctx->lz4FrameDecompressVariant = (int)value;
     }
     else if (k == "zstd.decompress.exec") {
@@ -836,14 +885,6 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->zstdTile = (int)value;
     }
     else if (k == "debug.scratch_poison") ctx->scratchPoison = (int)value;
-    else if (k == "zstd.decompress.exec_window") {  // (process-wide development switch)
-        if (value != 4096 && value != 8192) return bad_argument("the record executor's window: 4096 or 8192");
-        achip::g_zstd_pipe_exec_window = (int)value;
-    }
-    else if (k == "zstd.decompress.lit_items" || k == "zstd.decompress.seq_items") {  // (process-wide development switches, like zstd.decompress.exec)
-        if (value != 8 && value != 16) return bad_argument("items per wavefront: 8 or 16");
-        (k == "zstd.decompress.lit_items" ? achip::g_zstd_pipe_lit_items : achip::g_zstd_pipe_seq_items) = (int)value;
-    }
     else if (k == "zstd.decompress.variant") {
         if (value != 0 && value != 1) return bad_argument("zstd.decompress.variant: 1 pipeline, 0 one-kernel decoder");
         ctx->zstddVariant = (int)value;
@@ -864,13 +905,13 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     }
     else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;
     else if (k == "decompress.exec_variant") {
-        // 2 the product; 124 / 125 an 8 KiB window / registers capped (valid results); 302 .. 308 the batch in parts over two helper
-        // streams (valid results).  121 .. 123 and 201 skip work (results NOT valid): -DACHIP_DEV builds only.
-        bool ok = value == 2 || value == 124 || value == 125 || (value >= 302 && value <= 308);
+        // 2 the product -- the only value a shipped library takes.  121 .. 123 and 201 skip work (results NOT valid): -DACHIP_DEV builds only.
+        // (Round 2's experiments 124 / 125 / 302 .. 308 were measured in round 3 and removed: profiles/r03_notes.md.)
+        bool ok = value == 2;
 #ifdef ACHIP_DEV
         ok = ok || (value >= 121 && value <= 123) || value == 201;
 #endif
-        if (!ok) return bad_argument("decompress.exec_variant: 2, 124, 125 or 302..308");
+        if (!ok) return bad_argument("decompress.exec_variant: 2");
         ctx->execVariant = (int)value;
     }
     else if (k == "host.chunk_bytes") {

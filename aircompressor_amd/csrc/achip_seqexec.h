@@ -15,14 +15,6 @@
 
 namespace achip {
 
-// host side: two helper streams per host thread and device for the two-pass launchers' split experiment (lz4_decompress_v7.hip)
-struct SplitStreams {
-    int device = -1;
-    hipStream_t s[2] = {nullptr, nullptr};
-    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
-};
-SplitStreams* split_streams();
-
 namespace sx {
 
 // ---- records --------------------------------------------------------------------------------------------------------------------

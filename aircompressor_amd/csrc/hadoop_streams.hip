@@ -737,13 +737,35 @@ hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void
     c.onlyStats = nullptr;
     int32_t* stats = counters + 16;
     bool viaTwoPass = false;
-    if (variant == 2 && aux != nullptr && aux->get != nullptr) {
-        int32_t nChunks = 0;
-        e = hipMemcpyAsync(&nChunks, counters + 1, sizeof(nChunks), hipMemcpyDeviceToHost, stream);
+    int32_t nChunksHost = -1;  // the chunk count once the host has read it (variants 2 and 3)
+    if ((variant == 2 || variant == 3) && aux != nullptr && aux->get != nullptr) {
+        // variant 3 (the default since round 3): the probes of the batched block API's auto mode (lz4_pick: mixed 16-chunk groups,
+        // bytes per sampled sequence / element) run on the chunk list BEFORE the one synchronisation that reads the chunk count back, and
+        // their verdict comes back with it -- text-like chunks (short sequences) go through the two-pass decoders, long copies
+        // through the rings: measured (profiles/r03_notes.md, 1024 streams x 4 MiB) LZ4 818 / 83 GiB/s on fragments / corpus with the
+        // rings, 271 / 158 with the two-pass decoders; Snappy 474 / 39 against 230 / 107
+        int32_t head[20] = {0};
+        if (variant == 3) {
+            e = hipMemsetAsync(stats, 0, 4 * sizeof(int32_t), stream);
+            if (e == hipSuccess) e = snappy ? launch_snappy_element_sample(c, stream, stats, 0) : launch_lz4_sequence_sample(c, stream, stats, 0);
+            if (e != hipSuccess) return e;
+        }
+        e = hipMemcpyAsync(head, counters, sizeof(head), hipMemcpyDeviceToHost, stream);
         if (e != hipSuccess) return e;
         e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return e;
-        if (nChunks > 0) {
+        const int32_t nChunks = head[1];
+        nChunksHost = nChunks;
+        bool wantTwoPass = true;
+        if (variant == 3) {
+            // (only the sampled sequence lengths count here: a stream's last chunk is a short one, so "compressed sizes within a 16-chunk
+            // group differ by 2x" -- the block API's sign of a mixed batch -- holds for every group of a batch of streams)
+            const int32_t* v = head + 16;
+            wantTwoPass = v[1] > 0 && (int64_t)v[2] < (int64_t)(snappy ? 6 : 12) * (int64_t)v[1];
+        }
+        if (!wantTwoPass) {
+        }
+        else if (nChunks > 0) {
             // records per chunk as for 64 KiB blocks (lz4_decompress_v7.hip twopass_scratch_bytes), scaled to the streams' chunk size
             const int64_t per64k = snappy ? 131072 : 98304;
             const int64_t perChunk = per64k * (((int64_t)(bufferSize > 65536 ? bufferSize : 65536) + 65535) / 65536);
@@ -762,7 +784,16 @@ hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void
             viaTwoPass = true;  // (nothing listed)
         }
     }
-    if (!viaTwoPass) {
+    if (!viaTwoPass && nChunksHost >= 0) {
+        // the host knows the chunk count (variant 3 chose the rings): one launch of the size that fits, no probes
+        BatchArgs t = c;
+        t.nBlocks = nChunksHost;
+        t.nBlocksDev = nullptr;
+        if (nChunksHost > 0) {
+            e = snappy ? launch_snappy_decompress_rings(t, stream, 4, 0, nullptr) : launch_lz4_decompress_rings(t, stream, nChunksHost >= 32768 ? 4 : 16, 0, nullptr);
+        }
+    }
+    else if (!viaTwoPass) {
     // LZ4: the ring decoder at two lane-group sizes: 4 lanes per chunk from 32768 chunks on, 16 below (721 -> 814 GiB/s fragments, 56 -> 83 corpus at 16384 chunks) (a stream's chunks are up to 256 KiB: a few
     // thousand of them at 4 lanes each leave most of the chip idle); the chunk count, known on the device only, picks one
     BatchArgs big = c, small = c;

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 __global__ __launch_bounds__(256) void lz4_mixed_groups_kernel(BatchArgs a, int32_t* mixedGroups, int32_t minBlocks)
 {
     const int32_t n = batch_count(a);
-    if (n < minBlocks) {
+    if (n < minBlocks || n <= 0) {
         return;  // too few blocks for the lane-per-block decoder: the count stays 0
     }
     const int64_t group = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -286,7 +286,7 @@ __device__ __forceinline__ int32_t sample_stage_head(uint8_t* h, const uint8_t* 
 __global__ __launch_bounds__(64) void lz4_sequence_sample_kernel(BatchArgs a, int32_t* stats, int32_t minBlocks)
 {
     const int32_t n = batch_count(a);
-    if (n < minBlocks) {
+    if (n < minBlocks || n <= 0) {
         return;
     }
     __shared__ __attribute__((aligned(16))) uint8_t heads[64 * SAMPLE_STRIDE];

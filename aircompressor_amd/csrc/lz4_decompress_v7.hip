@@ -357,7 +357,7 @@ int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock)
 }
 int64_t lz4_twopass_scratch_bytes(int32_t nBlocks) { return twopass_scratch_bytes(nBlocks, 98304); }
 
-// the execute pass (shared with snappy_decompress_v5.hip); execVariant 2 = the product, 121..125 = timing aids and window sizes (results not valid / slower)
+// the execute pass (shared with snappy_decompress_v5.hip); execVariant 2 = the product; 121..123 timing aids in -DACHIP_DEV builds (results not valid)
 hipError_t launch_seq_execute2(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant, const int32_t* stats, int32_t shortLimit)
 {
     const dim3 grid((unsigned)a.nBlocks), wg(64);
@@ -367,49 +367,20 @@ hipError_t launch_seq_execute2(const BatchArgs& a, hipStream_t stream, const sx:
     else if (execVariant == 123) hipLaunchKernelGGL(seq_execute2_kernel<3>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
     else
 #endif
-    if (execVariant == 124) hipLaunchKernelGGL((seq_execute2_kernel<0, 8192>), grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
-    else if (execVariant == 125) hipLaunchKernelGGL((seq_execute2_kernel<0, 4096, 7>), grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
-    else hipLaunchKernelGGL(seq_execute2_kernel<0>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
+    hipLaunchKernelGGL(seq_execute2_kernel<0>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
     return hipGetLastError();
 }
 
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 
-// two helper streams per host thread and device, for the split below (also used by snappy_decompress_v5.hip)
-SplitStreams* split_streams()
-{
-    static thread_local SplitStreams st;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) {
-        return nullptr;
-    }
-    if (st.device != dev) {
-        for (int j = 0; j < 2; j++) {
-            if (hipStreamCreateWithFlags(&st.s[j], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&st.join[j], hipEventDisableTiming) != hipSuccess) {
-                return nullptr;
-            }
-        }
-        if (hipEventCreateWithFlags(&st.fork, hipEventDisableTiming) != hipSuccess) {
-            return nullptr;
-        }
-        st.device = dev;
-    }
-    return &st;
-}
-
-// execVariant 302 .. 308 (an experiment for the next round -- written without a GPU at hand, functionally checked on the CPU emulator, where
-// streams do not exist): the product's two passes over the batch cut into 2 .. 8 parts that alternate between two helper streams, so that
-// one part's parse (instruction-bound, a lane per block) can share the chip with another part's execute (LDS-bound, a wavefront per
-// block).  Only for forced two-pass decoding (stats == nullptr: the probes' verdict is about the whole batch).
+// The two passes of a batch on the caller's stream.  (Round 2 left an experiment here -- the batch cut into 2 .. 8 parts alternating between two
+// helper streams, so that one part's parse could share the chip with another part's execute; measured in round 3 on the corpus batch
+// (profiles/r03_notes.md): 2 parts 520 GiB/s against 517, 4 parts 456, 8 parts 363: the two kernels compete for the same issue slots.
+// Removed, with the 8 KiB-window executor (489) and the register-capped one.)
 hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats)
 {
     if (a.nBlocks <= 0) {
         return hipSuccess;
-    }
-    int parts = 1;
-    if (execVariant >= 302 && execVariant <= 308) {
-        parts = stats == nullptr && a.nBlocksDev == nullptr && a.nBlocks >= 64 * (execVariant - 300) ? execVariant - 300 : 1;
-        execVariant = 2;
     }
     uint8_t* s = (uint8_t*)scratch;
     sx::ArenaHeader* hdr = (sx::ArenaHeader*)s;
@@ -422,39 +393,7 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream,
     hipError_t e = hipMemsetAsync(hdr, 0, sizeof(sx::ArenaHeader), stream);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((a.nBlocks + 63) / 64)), wg(64);
-    SplitStreams* ss = parts > 1 ? split_streams() : nullptr;
-    if (ss != nullptr) {
-        // fork: the helper streams start behind everything queued on the caller's stream (the arena header among it)
-        e = hipEventRecord(ss->fork, stream);
-        for (int j = 0; j < 2 && e == hipSuccess; j++) {
-            e = hipStreamWaitEvent(ss->s[j], ss->fork, 0);
-        }
-        if (e != hipSuccess) return e;
-        const int32_t per = ((a.nBlocks + parts - 1) / parts + 63) & ~63;  // (whole wavefronts of the parse kernel)
-        int k = 0;
-        for (int32_t first = 0; first < a.nBlocks; first += per, k++) {
-            BatchArgs t = a;
-            t.srcOff = a.srcOff + first;
-            t.srcLen = a.srcLen + first;
-            t.dstOff = a.dstOff + first;
-            t.dstCap = a.dstCap + first;
-            t.outLen = a.outLen + first;
-            t.status = a.status + first;
-            t.errOffset = a.errOffset + first;
-            t.nBlocks = a.nBlocks - first < per ? a.nBlocks - first : per;
-            hipStream_t st = ss->s[k & 1];
-            hipLaunchKernelGGL(lz4_parse2_kernel<0>, dim3((unsigned)((t.nBlocks + 63) / 64)), wg, 0, st, t, hdr, meta + first, only + first, arena, maxChunks, stats);
-            e = launch_seq_execute2(t, st, meta + first, arena, execVariant, stats, 12);
-            if (e != hipSuccess) return e;
-        }
-        // join: the caller's stream continues behind both
-        for (int j = 0; j < 2 && e == hipSuccess; j++) {
-            e = hipEventRecord(ss->join[j], ss->s[j]);
-            if (e == hipSuccess) e = hipStreamWaitEvent(stream, ss->join[j], 0);
-        }
-        if (e != hipSuccess) return e;
-    }
-    else {
+    {
 #ifdef ACHIP_DEV
     if (execVariant == 201) {  // (timing aid: no record stores -- results NOT valid)
         hipLaunchKernelGGL(lz4_parse2_kernel<1>, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);

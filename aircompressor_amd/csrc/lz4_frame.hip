@@ -425,12 +425,13 @@ __global__ __launch_bounds__(64) void lz4frame_decompress_kernel(BatchArgs a, in
     }
 }
 
+hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
 int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock);
 
 int64_t lz4frame_decompress_scratch_bytes(int32_t nItems, int variant)
 {
-    if (variant != 1) {
+    if (variant != 1 && variant != 2) {
         return 4096;
     }
     const int64_t n = nItems < 1 ? 1 : nItems;
@@ -449,7 +450,7 @@ hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, vo
     if (e != hipSuccess) return e;
     const int32_t maxWaves = 256 * 16;
     const unsigned grid = (unsigned)(a.nBlocks < maxWaves ? a.nBlocks : maxWaves);
-    if (variant != 1 || aux == nullptr || aux->get == nullptr) {
+    if ((variant != 1 && variant != 2) || aux == nullptr || aux->get == nullptr) {
         hipLaunchKernelGGL(lz4frame_decompress_kernel<false>, dim3(grid), dim3(64), 0, stream, a, counter, (const int32_t*)nullptr);
         return hipGetLastError();
     }
@@ -473,15 +474,29 @@ hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, vo
     L.cStatus = (int32_t*)take(4 * C);
     hipLaunchKernelGGL(lz4frame_walk_kernel, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, stream, a, L);
     hipLaunchKernelGGL(lz4frame_seal_kernel, dim3(1), dim3(1), 0, stream, L);
+    // variant 2 (the default since round 3): the sequence-length probe of the block API's auto mode runs on the listed blocks before the
+    // synchronisation; long sequences (a lane walking them pays per sequence, the wavefront-per-item kernel moves 64 bytes per step: 75
+    // against 22 GiB/s on the fragments frames) leave every item to the wavefront-per-item kernel, short ones (text: 7.8 -> 13.4 GiB/s) take the list
+    int32_t* stats = counter + 24;
+    if (variant == 2) {
+        BatchArgs c = a;
+        c.srcOff = L.cSrcOff;
+        c.srcLen = L.cSrcLen;
+        c.nBlocks = (int32_t)C;
+        c.nBlocksDev = L.counters + 1;
+        e = launch_lz4_sequence_sample(c, stream, stats, 0);
+        if (e != hipSuccess) return e;
+    }
     // the number of listed blocks and their room decide the record arena: the one synchronisation of the call
-    int32_t counts[4] = {0, 0, 0, 0};
+    int32_t counts[12] = {0};
     e = hipMemcpyAsync(counts, L.counters, sizeof(counts), hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return e;
     e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return e;
     const int32_t nListed = counts[1];
+    const bool isShort = counts[8 + 1] > 0 && (int64_t)counts[8 + 2] < 12LL * (int64_t)counts[8 + 1];
     int32_t decoded = 0;
-    if (nListed > 0) {
+    if (nListed > 0 && (variant == 1 || isShort)) {
         long long room = 0;
         __builtin_memcpy(&room, counts + 2, 8);
         // records per block as for the block codec (96 KiB of arena per 64 KiB of output: lz4_decompress_v7.hip), by the blocks' room

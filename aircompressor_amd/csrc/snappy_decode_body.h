@@ -72,42 +72,67 @@ __device__ __forceinline__ void snappy_buffer_decode(uint8_t* ldsIn, uint8_t* ld
         eo = (int32_t)(off);                                             \
         break;                                                           \
     }
-        while (ip < inLimit) {
-            R.ensure_input(ip, 5);
-            const int32_t opc = (int32_t)R.in_u8(ip++);
-            const int32_t entry = snappy_op_entry2(opc);
+        // One trip of the loop = [a literal element, if one is next] then [a copy element, if one is next] -- the shape of an LZ4 sequence.
+        // The lane groups of a wavefront run in lockstep and a wavefront pays for every path any of its groups takes: with one element
+        // of either kind per trip, groups at a literal and groups at a copy made every trip cost both paths for one element each; in
+        // this order the groups stay in step on literal / copy / literal / copy streams and a trip moves two elements.  The elements
+        // are still taken strictly in stream order with the checks of :83-216 in their order: status and offset are what they were.
+        // element header :84-110 at ip (tag already peeked): false = malformed at eo
+        auto header = [&](int32_t opc, int32_t& entry, int32_t& trailer) -> bool {
+            ip++;
+            entry = snappy_op_entry2(opc);
             const int32_t trailerBytes = entry >> 11;
             if (!(ip + 4 < inLimit)) {  // :90-92
-                if (ip + trailerBytes > inLimit) SN_FAIL(ip);
+                if (ip + trailerBytes > inLimit) {
+                    eo = ip;
+                    return false;
+                }
             }
             // little-endian trailer: one unaligned 4-byte ring read, masked to trailerBytes (bytes past the input end are never selected)
             const uint32_t t = trailerBytes == 0 ? 0u : (R.template ring_ld4<IN_RING>(R.inRing, ip + R.inBase) & (0xFFFFFFFFu >> (32 - 8 * trailerBytes)));
-            const int32_t trailer = (int32_t)t;
-            if (trailer < 0) SN_FAIL(ip);
+            trailer = (int32_t)t;
+            if (trailer < 0) {
+                eo = ip;
+                return false;
+            }
             ip += trailerBytes;
-
-            const int32_t length = entry & 0xff;
-            if (length == 0) {
-                continue;
-            }
-
+            return true;
+        };
+        while (ip < inLimit) {
+            R.ensure_input(ip, 5);
+            int32_t opc = (int32_t)R.in_u8(ip);
             if ((opc & 3) == 0) {  // literal :116-146
-                const int32_t lit = (int32_t)((uint32_t)length + (uint32_t)trailer);
-                if (lit < 0) SN_FAIL(ip);
-                const int64_t litOutLimit = (int64_t)op + lit;
-                if (litOutLimit > fastOutLimit || (int64_t)ip + lit > inLimit - 8) {
-                    if (litOutLimit > outLimit || (int64_t)ip + lit > inLimit) SN_FAIL(ip);
+                int32_t entry, trailer;
+                if (!header(opc, entry, trailer)) SN_FAIL(eo);
+                const int32_t length = entry & 0xff;
+                if (length != 0) {
+                    const int32_t lit = (int32_t)((uint32_t)length + (uint32_t)trailer);
+                    if (lit < 0) SN_FAIL(ip);
+                    const int64_t litOutLimit = (int64_t)op + lit;
+                    if (litOutLimit > fastOutLimit || (int64_t)ip + lit > inLimit - 8) {
+                        if (litOutLimit > outLimit || (int64_t)ip + lit > inLimit) SN_FAIL(ip);
+                    }
+                    R.copy_literals(ip, op, lit);
+                    ip += lit;
+                    op += lit;
                 }
-                R.copy_literals(ip, op, lit);
-                ip += lit;
-                op += lit;
+                if (!(ip < inLimit)) {
+                    break;
+                }
+                R.ensure_input(ip, 5);
+                opc = (int32_t)R.in_u8(ip);  // what follows the literal: a copy goes in this trip, another literal in the next
             }
-            else {  // copy :147-216
-                const int32_t matchOffset = (int32_t)((uint32_t)(entry & 0x700) + (uint32_t)trailer);
-                if (matchOffset <= 0) SN_FAIL(ip);
-                if (matchOffset > op || (int64_t)op + length > outLimit) SN_FAIL(ip);
-                R.copy_match(op, matchOffset, length);
-                op += length;
+            if ((opc & 3) != 0) {  // copy :147-216
+                int32_t entry, trailer;
+                if (!header(opc, entry, trailer)) SN_FAIL(eo);
+                const int32_t length = entry & 0xff;
+                if (length != 0) {
+                    const int32_t matchOffset = (int32_t)((uint32_t)(entry & 0x700) + (uint32_t)trailer);
+                    if (matchOffset <= 0) SN_FAIL(ip);
+                    if (matchOffset > op || (int64_t)op + length > outLimit) SN_FAIL(ip);
+                    R.copy_match(op, matchOffset, length);
+                    op += length;
+                }
             }
         }
 #undef SN_FAIL

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64) void snappy_decompress_lanewindow_kernel(BatchA
 __global__ __launch_bounds__(64) void snappy_element_sample_kernel(BatchArgs a, int32_t* stats, int32_t minBlocks)
 {
     const int32_t n = batch_count(a);
-    if (n < minBlocks) {
+    if (n < minBlocks || n <= 0) {
         return;
     }
     constexpr int HEAD = 768, STRIDE = HEAD + 4;

@@ -356,16 +356,10 @@ hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream
 
 int64_t snappy_twopass_scratch_bytes(int32_t nBlocks) { return twopass_scratch_bytes(nBlocks, 131072); }
 
-// execVariant 302 .. 308: the batch in 2 .. 8 parts over two helper streams (lz4_decompress_v7.hip has the description)
 hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats)
 {
     if (a.nBlocks <= 0) {
         return hipSuccess;
-    }
-    int parts = 1;
-    if (execVariant >= 302 && execVariant <= 308) {
-        parts = stats == nullptr && a.nBlocksDev == nullptr && a.nBlocks >= 64 * (execVariant - 300) ? execVariant - 300 : 1;
-        execVariant = 2;
     }
     uint8_t* s = (uint8_t*)scratch;
     sx::ArenaHeader* hdr = (sx::ArenaHeader*)s;
@@ -378,37 +372,7 @@ hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stre
     hipError_t e = hipMemsetAsync(hdr, 0, sizeof(sx::ArenaHeader), stream);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((a.nBlocks + 63) / 64)), wg(64);
-    SplitStreams* ss = parts > 1 ? split_streams() : nullptr;
-    if (ss != nullptr) {
-        e = hipEventRecord(ss->fork, stream);
-        for (int j = 0; j < 2 && e == hipSuccess; j++) {
-            e = hipStreamWaitEvent(ss->s[j], ss->fork, 0);
-        }
-        if (e != hipSuccess) return e;
-        const int32_t per = ((a.nBlocks + parts - 1) / parts + 63) & ~63;
-        int k = 0;
-        for (int32_t first = 0; first < a.nBlocks; first += per, k++) {
-            BatchArgs t = a;
-            t.srcOff = a.srcOff + first;
-            t.srcLen = a.srcLen + first;
-            t.dstOff = a.dstOff + first;
-            t.dstCap = a.dstCap + first;
-            t.outLen = a.outLen + first;
-            t.status = a.status + first;
-            t.errOffset = a.errOffset + first;
-            t.nBlocks = a.nBlocks - first < per ? a.nBlocks - first : per;
-            hipStream_t st = ss->s[k & 1];
-            hipLaunchKernelGGL(snappy_parse2_kernel<0>, dim3((unsigned)((t.nBlocks + 63) / 64)), wg, 0, st, t, hdr, meta + first, only + first, arena, maxChunks, stats);
-            e = launch_seq_execute2(t, st, meta + first, arena, execVariant, stats, 6);
-            if (e != hipSuccess) return e;
-        }
-        for (int j = 0; j < 2 && e == hipSuccess; j++) {
-            e = hipEventRecord(ss->join[j], ss->s[j]);
-            if (e == hipSuccess) e = hipStreamWaitEvent(stream, ss->join[j], 0);
-        }
-        if (e != hipSuccess) return e;
-    }
-    else {
+    {
         hipLaunchKernelGGL(snappy_parse2_kernel<0>, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
         e = launch_seq_execute2(a, stream, meta, arena, execVariant, stats, 6);
         if (e != hipSuccess) return e;

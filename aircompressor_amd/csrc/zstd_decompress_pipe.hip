@@ -1055,8 +1055,6 @@ __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp:
 // item's capacity over its sequence count is what both kernels can see (an upper bound of the bytes per sequence: a caller that hands over far
 // more capacity than the frame needs gets the ring version).
 int g_zstd_pipe_exec = 2;  // context option zstd.decompress.exec: 2 = per item (default), 1 = this kernel, 0 = the ring version above
-int g_zstd_pipe_exec_window = 4096;  // option zstd.decompress.exec_window: 4096 (default) or 8192 -- the record executor's LDS window, and with it batches of up to 2 KiB (unmeasured)
-int g_zstd_pipe_lit_items = 16, g_zstd_pipe_seq_items = 16;  // options zstd.decompress.lit_items / seq_items: 16 (default) or 8 items per wavefront in K2 / K3 (unmeasured)
 
 template <int WIN = sx2::WIN_DEFAULT>
 __global__ __launch_bounds__(64) void zstd_pipe_execute2_kernel(BatchArgs a, zp::Pipe p, int32_t mode)
@@ -1728,12 +1726,7 @@ hipError_t launch_zstd_mb_stages(const BatchArgs& a, hipStream_t stream, zp::Pip
         hipLaunchKernelGGL(zstd_mb_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
         hipLaunchKernelGGL(zstd_pipe_literals_kernel<true>, dim3(w16), dim3(64), 0, stream, a, p);
         hipLaunchKernelGGL(zstd_pipe_sequences_kernel<true>, dim3(w16), dim3(64), 0, stream, a, p);
-        if (g_zstd_pipe_exec_window == 8192) {
-            hipLaunchKernelGGL(zstd_mb_execute_kernel<8192>, dim3(nItems), dim3(64), 0, stream, a, p);
-        }
-        else {
-            hipLaunchKernelGGL(zstd_mb_execute_kernel<>, dim3(nItems), dim3(64), 0, stream, a, p);
-        }
+        hipLaunchKernelGGL(zstd_mb_execute_kernel<>, dim3(nItems), dim3(64), 0, stream, a, p);
         hipLaunchKernelGGL(zstd_mb_checksum_kernel, dim3((nItems + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE), dim3(64), 0, stream, a, p);
     }
     return hipGetLastError();
@@ -1782,26 +1775,13 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
         }
         const unsigned w16 = (unsigned)((p.count + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE);
         hipLaunchKernelGGL(zstd_pipe_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
-        if (g_zstd_pipe_lit_items == 8) {
-            hipLaunchKernelGGL((zstd_pipe_literals_kernel<false, 8>), dim3((unsigned)((p.count + 7) / 8)), dim3(64), 0, stream, a, p);
-        }
-        else {
-            hipLaunchKernelGGL(zstd_pipe_literals_kernel<false>, dim3(w16), dim3(64), 0, stream, a, p);
-        }
-        if (g_zstd_pipe_seq_items == 8) {
-            hipLaunchKernelGGL((zstd_pipe_sequences_kernel<false, 8>), dim3((unsigned)((p.count + 7) / 8)), dim3(64), 0, stream, a, p);
-        }
-        else {
-            hipLaunchKernelGGL(zstd_pipe_sequences_kernel<false>, dim3((unsigned)((p.count + zp::SEQ_ITEMS_PER_WAVE - 1) / zp::SEQ_ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
-        }
+        // (items per wavefront in K2 / K3 of 8 instead of 16, and an 8 KiB window for the record executor, were round-2 experiments: measured in
+        // round 3 within noise of the defaults on all three data sets -- profiles/r03_notes.md -- and removed)
+        hipLaunchKernelGGL(zstd_pipe_literals_kernel<false>, dim3(w16), dim3(64), 0, stream, a, p);
+        hipLaunchKernelGGL(zstd_pipe_sequences_kernel<false>, dim3((unsigned)((p.count + zp::SEQ_ITEMS_PER_WAVE - 1) / zp::SEQ_ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
         constexpr int GS = 4, IN_RING = 128, OUT_RING = 256;
         if (g_zstd_pipe_exec != 0) {
-            if (g_zstd_pipe_exec_window == 8192) {
-                hipLaunchKernelGGL(zstd_pipe_execute2_kernel<8192>, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, (int32_t)g_zstd_pipe_exec);
-            }
-            else {
-                hipLaunchKernelGGL(zstd_pipe_execute2_kernel<>, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, (int32_t)g_zstd_pipe_exec);
-            }
+            hipLaunchKernelGGL(zstd_pipe_execute2_kernel<>, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, (int32_t)g_zstd_pipe_exec);
         }
         if (g_zstd_pipe_exec != 1) {
             hipLaunchKernelGGL((zstd_pipe_execute_kernel<GS, IN_RING, OUT_RING>), dim3((unsigned)((p.count + 256 / GS - 1) / (256 / GS))), dim3(256), (size_t)(256 / GS) * (IN_RING + OUT_RING + a.ringPad), stream, a, p, (int32_t)g_zstd_pipe_exec);

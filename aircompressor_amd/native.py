@@ -28,6 +28,7 @@ SIGNATURES = {
     "achip_zstd_max_compressed_length": (_i32, [_i32]),
     "achip_snappy_uncompressed_length": (_i64, [_vp, _i64, ctypes.POINTER(_i64)]),
     "achip_zstd_decompressed_size": (_i64, [_vp, _i64, ctypes.POINTER(_i64)]),
+    "achip_zstd_decompress_bound": (_i64, [_vp, _i64, ctypes.POINTER(_i64)]),
     "achip_ctx_create": (_vp, [_i32]),
     "achip_ctx_destroy": (None, [_vp]),
     "achip_ctx_device": (_i32, [_vp]),

@@ -57,12 +57,9 @@ def parse_args():
     p.add_argument("--exec-variant", type=int, default=-1, help="DEBUG: decompress.exec_variant (two-pass decoders)")
     p.add_argument("--section", default="all", choices=["all", "zstd", "zstdstream", "xxhash", "lz4frame"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-exec", type=int, default=-1, help="zstd pipeline execute stage: 2 = chosen per item (default), 1 = wavefront per item through the record executor, 0 = LDS rings")
-    p.add_argument("--snappyframed-variant", type=int, default=-1, help="x-snappy-framed reader: 1 = chunks through the ring decoders (default), 2 = through the two-pass decoder (unmeasured), 0 = a wavefront per stream")
-    p.add_argument("--lz4frame-variant", type=int, default=-1, help="LZ4 frame reader: 0 = a wavefront per item (default), 1 = the frames' blocks as one batch through the two-pass block decoder (unmeasured)")
-    p.add_argument("--hadoop-variant", type=int, default=-1, help="Hadoop block-stream reader: 1 = chunks through the ring decoders (default), 2 = through the two-pass decoders (unmeasured), 0 = a wavefront per stream")
-    p.add_argument("--zstd-exec-window", type=int, default=-1, help="zstd record executor: LDS window 4096 (default) or 8192 with batches of up to 2 KiB (unmeasured experiment)")
-    p.add_argument("--zstd-lit-items", type=int, default=-1, help="zstd pipeline literal stage: items per wavefront, 16 (default) or 8 (unmeasured experiment)")
-    p.add_argument("--zstd-seq-items", type=int, default=-1, help="zstd pipeline sequence stage: items per wavefront, 16 (default) or 8 (unmeasured experiment)")
+    p.add_argument("--snappyframed-variant", type=int, default=-1, help="x-snappy-framed reader: 3 = ring or two-pass decoder by a probe (default), 1 = chunks through the ring decoders, 2 = through the two-pass decoder, 0 = a wavefront per stream")
+    p.add_argument("--lz4frame-variant", type=int, default=-1, help="LZ4 frame reader: 2 = by a probe (default), 0 = a wavefront per item, 1 = the frames' blocks as one batch through the two-pass block decoder")
+    p.add_argument("--hadoop-variant", type=int, default=-1, help="Hadoop block-stream reader: 3 = ring or two-pass decoders by a probe (default), 1 = chunks through the ring decoders, 2 = through the two-pass decoders, 0 = a wavefront per stream")
     p.add_argument("--zstd-variant", type=int, default=-1, help="zstd decoder: 1 = five-stage pipeline (default), 0 = one-kernel decoder")
     return p.parse_args()
 
@@ -206,9 +203,9 @@ def main():
     if args.ring_class >= 0:
         codec.native.set_option("decompress.ring_class", args.ring_class)
     if args.compress_variant >= 0:
-        codec.native.set_option("lz4.compress.variant", args.compress_variant)
-        if args.compress_variant <= 1 or args.compress_variant == 3:  # (3: the LDS-window experiments of both codecs)
-            codec.native.set_option("snappy.compress.variant", args.compress_variant)
+        if args.compress_variant <= 1:
+            codec.native.set_option("lz4.compress.variant", args.compress_variant)
+        codec.native.set_option("snappy.compress.variant", args.compress_variant)
     if args.ring_pad >= 0:
         codec.native.set_option("decompress.ring_pad", args.ring_pad)
     codec.native.set_option("max_src_len_hint", bs)
@@ -615,12 +612,6 @@ def zstd_extra(torch, A, codec, dev, args):
         codec.native.set_option("zstd.decompress.variant", args.zstd_variant)
     if args.zstd_exec >= 0:
         codec.native.set_option("zstd.decompress.exec", args.zstd_exec)
-    if args.zstd_exec_window >= 0:
-        codec.native.set_option("zstd.decompress.exec_window", args.zstd_exec_window)
-    if args.zstd_lit_items >= 0:
-        codec.native.set_option("zstd.decompress.lit_items", args.zstd_lit_items)
-    if args.zstd_seq_items >= 0:
-        codec.native.set_option("zstd.decompress.seq_items", args.zstd_seq_items)
     zc = pa.Codec("zstd", compression_level=3)
     for data_kind in ("fragments", "wordmix", "corpus"):
         plain = gen_data(torch, dev, data_kind, pool_n, fs, args.ratio, 4242)

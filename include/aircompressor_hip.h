@@ -166,6 +166,11 @@ int32_t achip_zstd_max_compressed_length(int32_t uncompressedSize);
 int64_t achip_snappy_uncompressed_length(const void* src, int64_t srcLen, int64_t* errOffset);
 /* replaces ZstdFrameDecompressor.getDecompressedSize    M/zstd/ZstdFrameDecompressor.java:942-947; -1 = unknown, < -1 = status */
 int64_t achip_zstd_decompressed_size(const void* src, int64_t srcLen, int64_t* errOffset);
+/* what the reading side of the stream classes needs in one-shot form (M/zstd/ZstdInputStream.java:63-105 over
+ * M/zstd/ZstdIncrementalFrameDecompressor.java:99-352 reads frames WITHOUT a content size -- ZstdOutputStream's from 4 MiB on -- through a
+ * growing window): an upper bound of the decoded size of all frames in the buffer, from the frame and block headers alone (host code);
+ * >= 0 bound, negative = status, *errOffset set */
+int64_t achip_zstd_decompress_bound(const void* src, int64_t srcLen, int64_t* errOffset);
 
 /* ------------------------------------------------------------------------- */
 /* Context: one HIP stream + device scratch on one GPU.                       */

@@ -81,6 +81,8 @@ public final class HipNative
             MethodHandle snappyUncompressedLength,
             @NativeSignature(name = "achip_zstd_decompressed_size", returnType = long.class, argumentTypes = {MemorySegment.class, long.class, MemorySegment.class})
             MethodHandle zstdDecompressedSize,
+            @NativeSignature(name = "achip_zstd_decompress_bound", returnType = long.class, argumentTypes = {MemorySegment.class, long.class, MemorySegment.class})
+            MethodHandle zstdDecompressBound,
             @NativeSignature(name = "achip_ctx_create", returnType = MemorySegment.class, argumentTypes = int.class)
             MethodHandle ctxCreate,
             @NativeSignature(name = "achip_ctx_destroy", returnType = void.class, argumentTypes = MemorySegment.class)
@@ -448,6 +450,25 @@ public final class HipNative
         }
     }
 
+    /** An upper bound of what all frames in {@code compressed} decode to, from their frame and block headers (frames need no content size). */
+    public static long zstdDecompressBound(MemorySegment compressed)
+    {
+        try (Arena arena = Arena.ofConfined()) {
+            MemorySegment errorOffset = arena.allocate(JAVA_LONG);
+            long result = (long) HANDLES.zstdDecompressBound().invokeExact(compressed, compressed.byteSize(), errorOffset);
+            if (result < 0) {
+                throw toException((int) result, errorOffset.get(JAVA_LONG, 0));
+            }
+            return result;
+        }
+        catch (RuntimeException e) {
+            throw e;
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
     public static long zstdDecompressedSize(MemorySegment compressed)
     {
         try (Arena arena = Arena.ofConfined()) {
@@ -476,6 +497,7 @@ public final class HipNative
     {
         private final MemorySegment handle;
         private final MemorySegment errorOffset = Arena.ofAuto().allocate(JAVA_LONG);
+        private final java.lang.ref.Cleaner.Cleanable cleanable;
 
         public Context(int device)
         {
@@ -492,13 +514,22 @@ public final class HipNative
             }
             handle = created;
             MethodHandle destroy = HANDLES.ctxDestroy();
-            CLEANER.register(this, () -> {
-                try {
-                    destroy.invokeExact(created);
-                }
-                catch (Throwable ignored) {
+            java.util.concurrent.atomic.AtomicBoolean destroyed = new java.util.concurrent.atomic.AtomicBoolean();
+            this.cleanable = CLEANER.register(this, () -> {
+                if (destroyed.compareAndSet(false, true)) {
+                    try {
+                        destroy.invokeExact(created);
+                    }
+                    catch (Throwable ignored) {
+                    }
                 }
             });
+        }
+
+        /** Frees the native context (HIP stream, device scratch) now; the cleaner is only the backstop for contexts nobody closed. */
+        public void close()
+        {
+            cleanable.clean();
         }
 
         MemorySegment handle()

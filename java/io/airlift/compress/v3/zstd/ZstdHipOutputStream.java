@@ -33,7 +33,7 @@ import static java.util.Objects.requireNonNull;
  * 2^30 bytes per stream.  To write many streams at once use {@link io.airlift.compress.v3.hip.HipBatchCodec} with
  * {@link HipNative#OP_ZSTDSTREAM_COMPRESS}: one item per stream.
  * <p>
- * Reading needs no class of its own: {@code ZstdHipDecompressor} (and the batch form) take frames of any number of blocks.
+ * Reading: {@link ZstdHipInputStream}.
  */
 public final class ZstdHipOutputStream
         extends OutputStream
@@ -82,11 +82,17 @@ public final class ZstdHipOutputStream
         if (closed) {
             return;
         }
-        closed = true;
-        byte[] input = pending.toByteArray();
-        byte[] output = new byte[HipNative.zstdStreamMaxCompressedLength(input.length)];
-        int size = context.singleBlock(HipNative.OP_ZSTDSTREAM_COMPRESS, MemorySegment.ofArray(input), input.length, MemorySegment.ofArray(output), output.length);
-        outputStream.write(output, 0, size);
-        outputStream.close();
+        // (ZstdOutputStream.close sets `closed` only behind writeChunk(true) and closes its sink in a finally block: M/zstd/ZstdOutputStream.java:193-205)
+        try {
+            byte[] input = pending.toByteArray();
+            byte[] output = new byte[HipNative.zstdStreamMaxCompressedLength(input.length)];
+            int size = context.singleBlock(HipNative.OP_ZSTDSTREAM_COMPRESS, MemorySegment.ofArray(input), input.length, MemorySegment.ofArray(output), output.length);
+            outputStream.write(output, 0, size);
+            closed = true;
+            context.close();  // (the native context -- a HIP stream and scratch -- goes with the stream, not with the garbage collector)
+        }
+        finally {
+            outputStream.close();
+        }
     }
 }

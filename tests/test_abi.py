@@ -132,6 +132,40 @@ def test_zstd_decompressed_size(lib):
     assert lib.achip_status_detail(r) == 35
 
 
+def test_zstd_decompress_bound(lib):
+    """achip_zstd_decompress_bound (host code): an upper bound of what the frames of a buffer decode to from frame and block headers alone --
+    what the one-shot reader of streams WITHOUT a content size needs (ZstdOutputStream's from 4 MiB on).  Against the oracle's decoder: never
+    below the decoded size, exact where the content size is known, less than one block above it for the writer's chunked streams; the
+    reference's fixtures (two frames) and truncations."""
+    o = oracle_lib.load()
+    eo = ctypes.c_int64()
+
+    def bound(z):
+        a = np.frombuffer(bytes(z), dtype=np.uint8)
+        return lib.achip_zstd_decompress_bound(a.ctypes.data if len(a) else None, len(a), ctypes.byref(eo))
+
+    text = b"".join(d for _, d, _ in common.corpus_sample())
+    for n in (0, 1, 1000, 131072, 131073, 300000, 700001):
+        data = text[:n]
+        for z in (o.compress("zstd", data), o.zstd_stream_compress(data)):
+            assert bound(z) == n, n  # single-segment / content size present: exact
+    tiled = (text * 16)[:(4 << 20) + 12345]
+    z = o.zstd_stream_compress(tiled)
+    assert lib.achip_zstd_decompressed_size(np.frombuffer(z, dtype=np.uint8).ctypes.data, len(z), ctypes.byref(eo)) == -1  # no content size
+    b = bound(z)
+    assert len(tiled) <= b < len(tiled) + 131072
+    assert o.decompress("zstd", z, b) == tiled
+    assert bound(z + o.compress("zstd", text[:5000])) == b + 5000  # frames add up
+    for name, want, frames in (("with-checksum.zst", 11359, 1), ("multiple-frames.zst", 22718, 2)):  # (no content size in these: a block of 128 KiB per frame)
+        assert bound(common.golden_zstd(name)) == 131072 * frames >= want
+    assert bound(b"") == 0
+    for cut in (3, 5, 9, len(z) // 2, len(z) - 1):
+        r = bound(z[:cut])
+        assert r < 0 and lib.achip_status_class(r) == 1 and lib.achip_status_detail(r) == 32, cut  # "Not enough input bytes"
+    r = bound(b"\x00\x01\x02\x03\x04\x05")
+    assert lib.achip_status_detail(r) == 35
+
+
 def test_partition_blocks():
     import aircompressor_amd as A
     w = np.full(1000, 65536 + 30000, dtype=np.int64)

@@ -16,12 +16,12 @@ OPS = {"lz4": (10, 11), "snappy": (12, 13)}  # (decompress, compress)
 BUF = 262144
 
 
-# reader variant 2 (the chunks through the two-pass decoders) was written without a GPU at hand and is not the default: it joins these tests
-# when ACHIP_TEST_EXPERIMENTAL is set (tools/hostemu/check_hadoop.py runs it on the CPU)
-_VARIANTS = [1, 0] + ([2] if os.environ.get("ACHIP_TEST_EXPERIMENTAL") else [])
+# every reader variant runs: 3 the default (chunk list, the block decoder chosen by a probe of the sequence lengths: rings for long copies, the
+# two-pass decoders for text), 1 / 2 the chunk list always through the rings / the two-pass decoders, 0 a wavefront per stream (the fallback of all)
+_VARIANTS = [3, 1, 2, 0]
 
 
-@pytest.fixture(scope="module", params=_VARIANTS, ids=["chunk-list", "wave-per-stream", "chunk-list-two-pass"][:len(_VARIANTS)])
+@pytest.fixture(scope="module", params=_VARIANTS, ids=["chunk-list-auto", "chunk-list-rings", "chunk-list-two-pass", "wave-per-stream"])
 def gb(request):
     from tests.gpu_harness import GpuBatch
     return GpuBatch(0, options={"hadoop.decompress.variant": request.param})

@@ -13,12 +13,12 @@ pytestmark = pytest.mark.gpu
 OP_DECOMPRESS, OP_COMPRESS = 6, 7
 
 
-# reader variant 1 (the frames' blocks as one batch through the two-pass block decoder) was written without a GPU at hand and is not the
-# default: it joins these tests when ACHIP_TEST_EXPERIMENTAL is set (tools/hostemu/check_lz4frame.py runs it on the CPU)
-_VARIANTS = [0] + ([1] if os.environ.get("ACHIP_TEST_EXPERIMENTAL") else [])
+# every reader variant runs: 2 the default (the block list when a probe finds short sequences, else a wavefront per item), 0 always a wavefront
+# per item, 1 always the block list through the two-pass block decoder
+_VARIANTS = [2, 0, 1]
 
 
-@pytest.fixture(scope="module", params=_VARIANTS, ids=["wave-per-item", "block-list"][:len(_VARIANTS)])
+@pytest.fixture(scope="module", params=_VARIANTS, ids=["auto", "wave-per-item", "block-list"])
 def gb(request):
     from tests.gpu_harness import GpuBatch
     return GpuBatch(0, options={"lz4frame.decompress.variant": request.param})

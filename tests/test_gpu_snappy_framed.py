@@ -16,12 +16,12 @@ OP_DECOMPRESS, OP_COMPRESS = 8, 9
 HEADER = bytes([0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59])
 
 
-# reader variant 2 (the chunks through the two-pass Snappy decoder) was written without a GPU at hand and is not the default: it joins these
-# tests when ACHIP_TEST_EXPERIMENTAL is set (tools/hostemu/check_snappyframed.py runs it on the CPU)
-_VARIANTS = [1, 0] + ([2] if os.environ.get("ACHIP_TEST_EXPERIMENTAL") else [])
+# every reader variant runs: 3 the default (chunk list, rings or two-pass decoder by a probe of the element lengths), 1 / 2 always the rings /
+# the two-pass decoder, 0 a wavefront per stream
+_VARIANTS = [3, 1, 2, 0]
 
 
-@pytest.fixture(scope="module", params=_VARIANTS, ids=["block-lists", "wave-per-stream", "block-lists-two-pass"][:len(_VARIANTS)])
+@pytest.fixture(scope="module", params=_VARIANTS, ids=["block-lists-auto", "block-lists-rings", "block-lists-two-pass", "wave-per-stream"])
 def gb(request):
     """reader / writer under test: chunk list + batched block decoders, block list + two-tier block encoder + compaction (defaults);
     one wavefront per stream (their fallback)"""

@@ -124,3 +124,35 @@ def test_streams_from_4_mib_on_are_written_in_chunks(gb, o):
     assert len(everything) == star[0][2]
     outs, status, err = gb.run(OP_ZSTDSTREAM_COMPRESS, [everything], [o.lib.orc_zstd_stream_max_compressed_length(len(everything))])
     assert status[0] == 0 and len(outs[0]) == star[0][4] and hashlib.sha256(outs[0]).hexdigest() == star[0][5]
+
+
+def test_input_stream_twin_reads_streams_without_a_content_size(o):
+    """ZstdHipInputStream (aircompressor_amd/codecs.py; Java: ZstdHipInputStream.java) = ZstdInputStream read to the end: the repo's own
+    chunked streams (>= 4 MiB: no content size in the frame header), several frames back to back, small frames -- with NO size hint: the
+    capacity comes from achip_zstd_decompress_bound.  The transliterated reference stream (oracle/_ref, where present) reads the same."""
+    import aircompressor_amd as A
+    whole = b"".join(d for _, d, _ in common.corpus_sample())
+    tiled = whole * 16
+    plains = [tiled[:(4 << 20) + 1], tiled[100:6400100], whole[:70000], b"x", b""]
+    streams = [o.zstd_stream_compress(p) for p in plains]
+    streams.append(streams[2] + streams[0] + o.compress("zstd", whole[:300]))  # three frames, the middle one without a content size
+    plains.append(plains[2] + plains[0] + whole[:300])
+    for z, p in zip(streams, plains):
+        with A.ZstdHipInputStream(io.BytesIO(z)) as s:
+            got = b""
+            buf = bytearray(1 << 20)
+            while True:
+                n = s.read_into(buf, 0, len(buf))
+                if n < 0:
+                    break
+                got += bytes(buf[:n])
+            assert got == p, (len(z), len(p), len(got))
+        assert A.ZstdHipInputStream(io.BytesIO(z)).read() == p
+    with pytest.raises(IOError):
+        A.ZstdHipInputStream(io.BytesIO(b"")).read()
+    with pytest.raises(Exception):
+        A.ZstdHipInputStream(io.BytesIO(streams[0][:len(streams[0]) // 2])).read()
+    s = A.ZstdHipInputStream(io.BytesIO(streams[3]))
+    s.close()
+    with pytest.raises(IOError):
+        s.read()

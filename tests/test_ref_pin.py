@@ -51,6 +51,7 @@ class Ref:
             f = getattr(lib, "ref_%s_max_compressed_length" % c)
             f.restype, f.argtypes = i64, [i64]
         lib.ref_zstd_stream_compress.restype, lib.ref_zstd_stream_compress.argtypes = i64, [vp, i64, vp, i64]
+        lib.ref_zstd_stream_decompress.restype, lib.ref_zstd_stream_decompress.argtypes = i64, [vp, i64, vp, i64, ctypes.POINTER(i64)]
         lib.ref_hadoop_compress.restype, lib.ref_hadoop_compress.argtypes = i64, [ctypes.c_int32, vp, i64, vp, i64, ctypes.c_int32]
         lib.ref_hadoop_decompress.restype, lib.ref_hadoop_decompress.argtypes = i64, [ctypes.c_int32, vp, i64, vp, i64, ctypes.c_int32, ctypes.POINTER(i64)]
         lib.ref_xxh64.restype, lib.ref_xxh64.argtypes = ctypes.c_uint64, [vp, i64, ctypes.c_uint64]
@@ -329,3 +330,26 @@ def test_xxh64_and_size_probes(ref, oracle):
         assert ref.lib.ref_snappy_uncompressed_length(c, len(c), ctypes.byref(eo)) == n
         z = oracle.compress("zstd", text[:n])
         assert ref.lib.ref_zstd_decompressed_size(z, len(z), ctypes.byref(eo)) == n
+
+
+def test_input_stream_reads_what_the_one_shot_decoder_reads(ref, oracle):
+    """f3 reader: the reference's ZstdInputStream (over ZstdIncrementalFrameDecompressor: input in pieces, a window buffer, frames without a
+    content size) read to the end delivers what the oracle's one-shot decoder -- the GPU decoders' checker -- delivers for the same bytes,
+    given the capacity achip_zstd_decompress_bound computes: the writer's streams below and beyond 4 MiB, libzstd-shaped multi-block
+    frames, concatenated frames"""
+    from aircompressor_amd import native
+    lib = native.load_library()
+    text = b"".join(d for _, d, _ in common.corpus_sample())
+    tiled = text * 16
+    plains = [b"", b"q", text[:1000], text[:300000], tiled[:(4 << 20) + 5], tiled[7:6400007]] + [p for p in common.multi_block_plains() if len(p) <= 1 << 20][:6]
+    streams = [oracle.zstd_stream_compress(p) for p in plains] + [oracle.compress("zstd", p) for p in plains[1:4]]
+    streams.append(streams[3] + streams[4] + streams[2])
+    for z in streams:
+        eo = i64(0)
+        a = np.frombuffer(z, dtype=np.uint8)
+        bound = lib.achip_zstd_decompress_bound(a.ctypes.data, len(a), ctypes.byref(eo))
+        assert bound >= 0
+        want = oracle.decompress("zstd", z, bound)
+        out = ctypes.create_string_buffer(max(bound, 1))
+        r = ref.lib.ref_zstd_stream_decompress(z, len(z), out, bound, ctypes.byref(eo))
+        assert r == len(want) and out.raw[:r] == want, (len(z), r, len(want), ref.lib.ref_zstd_last_error())

@@ -74,11 +74,10 @@ def cases_for(codec):
 
 
 def main():
-    # (26 / 36: the two-pass decoders with the executor's 8 KiB window and 2 KiB batches -- exec variant 124, an experiment)
     # (44 / 46 / 48, 54 / 56 / 58: the ring decoders with 4 / 16 / 64 lanes per block -- the product's default is 4 --: the lanes of a group meet
     #  at the emulator-only lockstep points of achip_rings.h)
     only = [int(x) for x in sys.argv[sys.argv.index("--ops") + 1].split(",")] if "--ops" in sys.argv else None
-    for codec, ops in (("lz4", (16, 17, 18, 24, 25, 26, 44, 46, 48)), ("snappy", (12, 13, 19, 34, 35, 36, 54, 56, 58))):
+    for codec, ops in (("lz4", (16, 17, 18, 24, 25, 44, 46, 48)), ("snappy", (12, 13, 19, 34, 35, 54, 56, 58))):
         if only is not None:
             ops = tuple(op for op in ops if op in only)
         elif "--quick" in sys.argv:

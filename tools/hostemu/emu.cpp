@@ -28,15 +28,14 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
                          const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n)
 {
     achip::BatchArgs a{srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, n, 0};
-    if (op == 24 || op == 25 || op == 34 || op == 35 || op == 26 || op == 36) {  // (26 / 36: exec variant 124)  // two-pass decoders (24 / 25 LZ4, 34 / 35 Snappy); odd ops: a tiny arena, so that blocks fall back
-        const bool snappy = op >= 34, tiny = (op & 1) != 0, wide = op == 26 || op == 36;
+    if (op == 24 || op == 25 || op == 34 || op == 35) {  // two-pass decoders (24 / 25 LZ4, 34 / 35 Snappy); odd ops: a tiny arena, so that blocks fall back
+        const bool snappy = op >= 34, tiny = (op & 1) != 0;
         static std::vector<uint8_t> scratch;
         const int64_t bytes = tiny ? 4096 + ((n * 12 + 4095) & ~4095LL) + 4 * 4096 : achip::lz4_twopass_scratch_bytes(n);
         scratch.assign((size_t)bytes, 0xCD);
         a.ringPad = 16;
-        // (ops 24 / 34 with more than 192 blocks: the split of execVariant 303 -- three parts -- is exercised too)
-        return snappy ? achip::launch_snappy_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, wide ? 124 : (op == 34 && n >= 192 ? 303 : 2), nullptr)
-                      : achip::launch_lz4_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, wide ? 124 : (op == 24 && n >= 192 ? 303 : 2), nullptr);
+        return snappy ? achip::launch_snappy_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, 2, nullptr)
+                      : achip::launch_lz4_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, 2, nullptr);
     }
     if (op == 19) return achip::launch_snappy_decompress_lanewindow(a, nullptr, nullptr);
     if (op == 18) return achip::launch_lz4_decompress_lanewindow(a, nullptr, nullptr);  // lane per block + LDS output window: lane-private

@@ -7,7 +7,6 @@
 #define HOSTEMU_ORDER_IS_RENDEZVOUS 1  // wave_mem_order(): where the source says "every lane's accesses so far come before every lane's accesses from here on" all lanes meet
 #include "emu.cpp"  // (the decoders and the container readers / writers: hadoop_streams.hip, lz4_frame.hip, snappy_frame.hip)
 #include "../../aircompressor_amd/csrc/lz4_compress.hip"
-#include "../../aircompressor_amd/csrc/lz4_compress_v3.hip"
 #include "../../aircompressor_amd/csrc/snappy_compress.hip"
 #include "../../aircompressor_amd/csrc/snappy_compress_v3.hip"
 #include "../../aircompressor_amd/csrc/zstd_compress.hip"
@@ -23,7 +22,7 @@ extern "C" int emu_encode(int op, const uint8_t* srcBase, const int64_t* srcOff,
     if (op == 1) {
         int maxLen = 0;
         for (int i = 0; i < n; i++) maxLen = srcLen[i] > maxLen ? srcLen[i] : maxLen;
-        return option == 3 ? achip::launch_lz4_compress_window(a, nullptr, maxLen) : achip::launch_lz4_compress(a, nullptr, option, maxLen);
+        return achip::launch_lz4_compress(a, nullptr, option, maxLen);
     }
     if (op == 3) {
         scratch.assign((size_t)achip::snappy_compress_scratch_bytes(), 0xCD);

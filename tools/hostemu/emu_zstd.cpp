@@ -82,9 +82,6 @@ extern "C" int emu_zstd_pipe(const uint8_t* srcBase, const int64_t* srcOff, cons
     const int64_t bytes = achip::zstd_decompress_pipe_scratch_bytes(n, tile);
     scratch.assign((size_t)bytes, 0xCD);
     achip::g_zstd_pipe_exec = execMode & 3;
-    achip::g_zstd_pipe_lit_items = (execMode & 4) ? 8 : 16;  // (bits 2 / 3 of the mode: the 8-items-per-wavefront instantiations of K2 / K3)
-    achip::g_zstd_pipe_seq_items = (execMode & 8) ? 8 : 16;
-    achip::g_zstd_pipe_exec_window = (execMode & 16) ? 8192 : 4096;  // (bit 4: the record executor with an 8 KiB window and 2 KiB batches)
     achip::g_fallback.clear();
     for (int32_t i = 0; i < n; i++) {
         status[i] = -999;  // "not written"

@@ -117,6 +117,21 @@ class Project:
         """a Java type string naming a reference to an instance of a translated / runtime class (not an array, string, primitive)"""
         return t is not None and not t.endswith("[]") and (t in self.classes or t in RUNTIME_OBJECTS)
 
+    def method_cxx_name(self, cname, mname):
+        """Java keeps fields and methods in separate namespaces; a class that has both under one name gets its METHOD renamed (name_m)"""
+        seen = set()
+        stack = [cname]
+        while stack:
+            c = stack.pop()
+            if c in seen or c not in self.classes:
+                continue
+            seen.add(c)
+            ci = self.classes[c]
+            if mname in ci.methods and mname in ci.fields:
+                return mname + "_m"
+            stack.extend(ci.bases)
+        return mname
+
     def find_field(self, cname, fname):
         seen = set()
         while cname in self.classes and cname not in seen:
@@ -230,6 +245,7 @@ def cxx_type(jt, proj):
 def collect(proj, rel, toks):
     stack = []  # (ClassInfo or None, brace depth at which its body opened)
     depth = 0
+    parens = 0  # parenthesis depth: method parameters are not members
     i = 0
     n = len(toks)
     pending = None  # ClassInfo whose `{` is awaited
@@ -296,8 +312,12 @@ def collect(proj, rel, toks):
             depth -= 1
             i += 1
             continue
+        if t.kind == "op" and t.text in "()":
+            parens += 1 if t.text == "(" else -1
+            i += 1
+            continue
         # a member declaration: at class-body depth, [modifiers] Type name followed by ( or = ; ,
-        if stack and stack[-1][1] == depth and t.kind == "id":
+        if stack and stack[-1][1] == depth and parens == 0 and t.kind == "id":
             ci = stack[-1][0]
             # gather modifiers
             j = i
@@ -667,7 +687,7 @@ class Rewriter:
                             static_kw = self.take_back_static()
                             virt = "virtual " if (ci.kind == "interface" or (not static_kw)) and ci.kind != "enum" or (ci.kind == "enum" and not static_kw) else ""
                             emit(("static " if static_kw else virt) + cxx_type(jt, proj))
-                            emit("".join(x.text for x in toks[j:k]) + self.safe_name(vname))
+                            emit("".join(x.text for x in toks[j:k]) + self.safe_name(proj.method_cxx_name(ci.name, vname)))
                             self.method_pending = (ci, k2)
                             self.scopes.append({})
                             self.method_scope_depth = depth
@@ -722,7 +742,7 @@ class Rewriter:
                     if nxt == "(":
                         m = proj.find_method(owner, w, count_args(toks, nx)) if owner else None
                         brk.append(("call", m[0] if m else None))
-                        emit(name)
+                        emit(self.safe_name(proj.method_cxx_name(owner, w)) if owner else name)
                         emit("".join(x.text for x in toks[i + 1:nx]) + "(")
                         paren_depth += 1
                         i = nx + 1
@@ -753,12 +773,12 @@ class Rewriter:
                     em = self.enclosing_method(w, count_args(toks, nx))
                     if em:
                         ci, (ret, is_static) = em
-                        emit((ci.qualified() + "::" if is_static else "this->") + name)
+                        emit((ci.qualified() + "::" if is_static else "this->") + self.safe_name(proj.method_cxx_name(ci.name, w)))
                     elif w in self.static_imports:
                         owner = self.static_imports[w]
                         m = proj.find_method(owner, w, count_args(toks, nx))
                         ret = m[0] if m else None
-                        emit((proj.classes[owner].qualified() if owner in proj.classes else owner) + "::" + name)
+                        emit((proj.classes[owner].qualified() if owner in proj.classes else owner) + "::" + self.safe_name(proj.method_cxx_name(owner, w)))
                     else:
                         emit(name)
                     brk.append(("call", ret))
