@@ -19,8 +19,8 @@ def main():
     import tests.test_gpu_snappy_framed as sf
     whole = "--all" in sys.argv
     # (--all: one run per reader variant, as the test modules' fixtures parametrise them -- the experimental ones included)
-    variants = {"lz4 frame": [{"lz4frame.decompress.variant": v} for v in (0, 1)], "hadoop streams": [{"hadoop.decompress.variant": v} for v in (1, 0, 2)],
-                "snappy framed": [{"snappyframed.decompress.variant": v} for v in (1, 0, 2)], "zstd": [{"zstd.decompress.variant": v} for v in (1, 0)]} if whole else {}
+    variants = {"lz4 frame": [{"lz4frame.decompress.variant": v} for v in (2, 0, 1)], "hadoop streams": [{"hadoop.decompress.variant": v} for v in (3, 1, 0, 2)],
+                "snappy framed": [{"snappyframed.decompress.variant": v} for v in (3, 1, 0, 2)], "zstd": [{"zstd.decompress.variant": v} for v in (1, 0)]} if whole else {}
     plan = [("lz4 frame", lf, [n for n in dir(lf) if n.startswith("test_")]),
             ("hadoop streams", hd, [n for n in dir(hd) if n.startswith("test_")]),
             ("snappy framed", sf, [n for n in dir(sf) if n.startswith("test_")]),

@@ -103,9 +103,9 @@ class EmuAllBatch(EmuBatch):
             self.variant = o.get("zstd.decompress.variant", 1)
             return self.lib.emu_zstd_full(*a, int(self.variant), int(o.get("zstd.decompress.stream_blocks", 65536)), P(self.counters))
         if op == 6:
-            return self.lib.emu_lz4frame(int(o.get("lz4frame.decompress.variant", 0)), *a)
+            return self.lib.emu_lz4frame(int(o.get("lz4frame.decompress.variant", 2)), *a)
         if op == 8:
-            return self.lib.emu_snappyframed(int(o.get("snappyframed.decompress.variant", 1)), *a)
+            return self.lib.emu_snappyframed(int(o.get("snappyframed.decompress.variant", 3)), *a)
         if op in (10, 12):
-            return self.lib.emu_hadoop(0, 1 if op == 12 else 0, int(o.get("hadoop.buffer_size", 262144)), int(o.get("hadoop.decompress.variant", 1)), *a)
+            return self.lib.emu_hadoop(0, 1 if op == 12 else 0, int(o.get("hadoop.buffer_size", 262144)), int(o.get("hadoop.decompress.variant", 3)), *a)
         return -1
