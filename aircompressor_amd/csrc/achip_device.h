@@ -79,6 +79,17 @@ __device__ __forceinline__ u32x4 ld16(const uint8_t* p)
     __builtin_memcpy(&v, p, 16);
     return v;
 }
+// 16 aligned bytes of GLOBAL memory: the address-space cast keeps the load a global_load where the compiler cannot prove the pointer's
+// provenance (a flat_load also counts against the LDS counter: every wait for an LDS read would wait for it)
+__device__ __forceinline__ u32x4 ld16_global(const uint8_t* p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const u32x4 __attribute__((address_space(1))) * GlobalPtr;
+    return *(GlobalPtr)(p);
+#else
+    return *(const u32x4*)p;
+#endif
+}
 __device__ __forceinline__ void st16(uint8_t* p, u32x4 v) { __builtin_memcpy(p, &v, 16); }
 __device__ __forceinline__ uint64_t ld8(const uint8_t* p)
 {

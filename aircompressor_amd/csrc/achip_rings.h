@@ -19,12 +19,20 @@ namespace achip {
 // 384 B = 96-dword slot the 16 blocks of a wavefront start on only two distinct LDS banks; 400 B = 100 dwords
 // spreads them over all banks (context option "decompress.ring_pad").
 
-template <int GS, int IN_RING, int OUT_RING, int GPL = 1>
+// PHASED (round 3): ONE place per sequence where this group's vector memory operations are issued -- memory_phase(): the input chunk
+// requested a sequence ago enters the ring, completed output chunks leave, the next input chunk is requested -- instead of refills and
+// flushes wherever a copy happens to need them.  Why: a wavefront waits for its vector memory operations by COUNT, and with loads and
+// stores under data-dependent branches the compiler can only wait for all of them (`s_waitcnt vmcnt(0)`, 49 of the 52 vmcnt waits of the
+// round-2 kernel): every refill waited for the stores of the flush just before it to be acknowledged (SQ_WAIT_ANY 57 % of the
+// wave-cycles, profiles/r03_notes.md).  With all of a sequence's memory operations in one place, whatever a wait covers is a whole
+// sequence old.  The copies then only flush inside loops (long runs), the input ring is kept two chunks ahead (IN_RING >= 4 chunks).
+template <int GS, int IN_RING, int OUT_RING, int GPL = 1, bool PHASED = false>
 struct Rings {
     static constexpr int CHUNK = GS * 16 * GPL;                // bytes per refill / flush / copy step (GPL 16-byte granules per lane)
     static constexpr int LDS_REACH = OUT_RING - CHUNK - 16;    // farthest back-reference served from the ring
     static_assert((IN_RING & (IN_RING - 1)) == 0 && (OUT_RING & (OUT_RING - 1)) == 0, "rings are powers of two");
     static_assert(IN_RING >= 2 * CHUNK && OUT_RING >= 4 * CHUNK, "ring too small for the chunk size");
+    static_assert(!PHASED || (IN_RING >= 4 * CHUNK && GS == 4 && GPL == 1), "the phased form keeps two chunks of input ahead");
 
     uint8_t* inRing;
     uint8_t* outRing;
@@ -98,7 +106,7 @@ struct Rings {
     {
         u32x4 d = {0, 0, 0, 0};
         if (v >= inBase && v + 16 <= inEndV) {
-            d = *(const u32x4*)(inAligned + v);  // aligned, fully inside the input: one coalesced CHUNK per group
+            d = ld16_global(inAligned + v);  // aligned, fully inside the input: one coalesced CHUNK per group (a GLOBAL load: a flat one also counts as an LDS operation, and every LDS wait then waits for memory)
         }
         else if (v + 16 > inBase && v < inEndV) {  // first / last granule of the stream: byte-guarded, kept small (cold)
             uint32_t w[4] = {0, 0, 0, 0};
@@ -136,6 +144,20 @@ struct Rings {
         order();
     }
     __device__ __forceinline__ uint32_t in_u8(int32_t pos) const { return inRing[(pos + inBase) & (IN_RING - 1)]; }
+
+    // PHASED: the one place per sequence (the decode loops call it at the top of a trip; ip / op = bytes consumed / produced so far)
+    __device__ __forceinline__ void memory_phase(int32_t ip, int32_t op)
+    {
+        if (PHASED) {
+            enter();
+            // the chunk requested one phase ago enters the ring as soon as what it overwrites is consumed, and the next one is requested
+            if (inLoadedV - (ip + inBase) <= IN_RING - CHUNK && inLoadedV < inEndV) {
+                refill();
+            }
+            order();
+            flush_complete(op);
+        }
+    }
 
     // 4 bytes at an arbitrary virtual position of a ring: two aligned LDS dword reads + v_alignbyte
     template <int RING>
@@ -294,14 +316,18 @@ struct Rings {
                 ip += c;
                 op += c;
                 n -= c;
-                flush_complete(op);
+                if (!PHASED || n > 0) {  // (PHASED: a run of one chunk leaves its flush to the next memory phase)
+                    flush_complete(op);
+                }
             }
             return;
         }
         if (n <= 4 * GS) {
             ensure_input(ip, n);
             copy_small<IN_RING>(inRing, ip + inBase, op + outBase, n);
-            flush_complete(op + n);
+            if (!PHASED) {
+                flush_complete(op + n);
+            }
             return;
         }
         while (n > 0) {
@@ -344,6 +370,10 @@ struct Rings {
                     else {
                         // flushed long ago (dist > LDS_REACH >= 2 * CHUNK): 64 source bytes land in the staging area,
                         // then the same move as every other copy.  Reading past c stays inside this block's output.
+                        if (PHASED && op + outBase - dist + CHUNK > flushedV) {  // (deferred flushes: what is read back must have left)
+                            flush_complete(op);
+                            order();
+                        }
                         *(u32x4*)(stage + 16 * g) = ld16(outAligned + outBase + (op - dist) + 16 * g);
                         order();
                         copy_dwords<CHUNK>(stage, 0, op + outBase, c);
@@ -353,7 +383,9 @@ struct Rings {
                     if (dist < CHUNK) {
                         dist += dist;
                     }
-                    flush_complete(op);
+                    if (!PHASED || n > 0) {
+                        flush_complete(op);
+                    }
                 }
                 return;
             }
@@ -364,9 +396,15 @@ struct Rings {
                 copy_small<OUT_RING>(outRing, op + outBase - offset, op + outBase, n);
             }
             else {
+                if (PHASED && op + outBase - offset + 4 * GS > flushedV) {
+                    flush_complete(op);
+                    order();
+                }
                 put4(op + outBase + 4 * g, ld4(outAligned + outBase + (op - offset) + 4 * g), n - 4 * g);  // flushed long ago (see below)
             }
-            flush_complete(op + n);
+            if (!PHASED) {
+                flush_complete(op + n);
+            }
             return;
         }
         int32_t c0 = op;

@@ -8,8 +8,8 @@ namespace achip {
 
 // `R` is initialised on (in, inLimit, out); on return st / eo hold the status and error offset, op the bytes produced
 // (the output is flushed).  All lanes of the group return the same values.
-template <int GS, int IN_RING, int OUT_RING, int GPL>
-__device__ __forceinline__ void lz4_block_decode(Rings<GS, IN_RING, OUT_RING, GPL>& R, const uint8_t* __restrict__ in, int32_t inLimit, int32_t outLimit, int32_t& stOut,
+template <int GS, int IN_RING, int OUT_RING, int GPL, bool PHASED = false>
+__device__ __forceinline__ void lz4_block_decode(Rings<GS, IN_RING, OUT_RING, GPL, PHASED>& R, const uint8_t* __restrict__ in, int32_t inLimit, int32_t outLimit, int32_t& stOut,
                                                  int32_t& eoOut, int32_t& opOut)
 {
     int32_t st = 0;
@@ -40,6 +40,7 @@ __device__ __forceinline__ void lz4_block_decode(Rings<GS, IN_RING, OUT_RING, GP
         R.ensure_input(ip, 4);
         uint32_t t4 = R.template ring_ld4<IN_RING>(R.inRing, ip + R.inBase);  // token and the 3 bytes after it
         while (ip < inLimit) {
+            R.memory_phase(ip, op);  // (PHASED rings: this sequence's refill and flushes, all in one place)
             const int32_t token = (int32_t)(t4 & 0xFF);
             ip++;
 
@@ -68,7 +69,7 @@ __device__ __forceinline__ void lz4_block_decode(Rings<GS, IN_RING, OUT_RING, GP
             }
 
             uint32_t o4 = 0;
-            const bool early = lit + 3 <= Rings<GS, IN_RING, OUT_RING, GPL>::CHUNK;
+            const bool early = lit + 3 <= Rings<GS, IN_RING, OUT_RING, GPL, PHASED>::CHUNK;
             if (early) {
                 R.ensure_input(ip, lit + 3);
                 o4 = R.template ring_ld4<IN_RING>(R.inRing, (int32_t)litEnd + R.inBase);

@@ -11,7 +11,7 @@ namespace achip {
 
 // HANDOVER: the launch that decodes only the blocks a two-pass decode handed over (`only` filter) -- its own instantiation, so that kernel
 // statistics keep it apart from the launch that decodes a whole batch
-template <int GS, int IN_RING, int OUT_RING, int GPL, bool HANDOVER = false>
+template <int GS, int IN_RING, int OUT_RING, int GPL, bool HANDOVER = false, bool PHASED = false>
 __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
     // auto mode (achip_abi.cpp): both LZ4 decoders are launched, the probe's count of mixed 16-block groups picks one
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a, 
     const int32_t inLimit = a.srcLen[block];
     const int32_t outLimit = a.dstCap[block];
 
-    Rings<GS, IN_RING, OUT_RING, GPL> R;
+    Rings<GS, IN_RING, OUT_RING, GPL, PHASED> R;
     R.init(smem + grp * (IN_RING + OUT_RING + a.ringPad), smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING, in, inLimit, out, g,
            a.ringPad >= 16 * GS * GPL ? smem + grp * (IN_RING + OUT_RING + a.ringPad) + IN_RING + OUT_RING : nullptr);
 
@@ -58,17 +58,17 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a, 
     }
 }
 
-template <int GS, int IN_RING, int OUT_RING, int GPL = 1>
+template <int GS, int IN_RING, int OUT_RING, int GPL = 1, bool PHASED = false>
 static hipError_t lz4d2_launch(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups)
 {
     constexpr int GROUPS_PER_WG = 256 / GS;
     const unsigned grid = (unsigned)((a.nBlocks + GROUPS_PER_WG - 1) / GROUPS_PER_WG);
     const size_t lds = (size_t)GROUPS_PER_WG * (IN_RING + OUT_RING + a.ringPad);
     if (a.only != nullptr) {
-        hipLaunchKernelGGL((lz4_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL, true>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
+        hipLaunchKernelGGL((lz4_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL, true, PHASED>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
     }
     else {
-        hipLaunchKernelGGL((lz4_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL, false>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
+        hipLaunchKernelGGL((lz4_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL, false, PHASED>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
     }
     return hipGetLastError();
 }
@@ -79,7 +79,9 @@ hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, i
     switch (groupSize) {
         case 1: return ringClass ? lz4d2_launch<1, 128, 256, 4>(a, stream, mixedGroups) : lz4d2_launch<1, 64, 128, 2>(a, stream, mixedGroups);
         case 2: return ringClass ? lz4d2_launch<2, 128, 256, 2>(a, stream, mixedGroups) : lz4d2_launch<2, 64, 128, 1>(a, stream, mixedGroups);
-        case 4: return ringClass ? lz4d2_launch<4, 256, 512>(a, stream, mixedGroups) : lz4d2_launch<4, 128, 256>(a, stream, mixedGroups);
+        case 4:
+            // ring class 0 (the default): the phased form, with an input ring of four chunks (achip_rings.h); class 2: round 2's compact rings (kept for the comparison in profiles/r03_notes.md)
+            return ringClass == 1 ? lz4d2_launch<4, 256, 512>(a, stream, mixedGroups) : (ringClass == 2 ? lz4d2_launch<4, 128, 256>(a, stream, mixedGroups) : lz4d2_launch<4, 256, 256, 1, true>(a, stream, mixedGroups));
         case 8: return ringClass ? lz4d2_launch<8, 512, 1024>(a, stream, mixedGroups) : lz4d2_launch<8, 256, 512>(a, stream, mixedGroups);
         case 32: return ringClass ? lz4d2_launch<32, 2048, 4096>(a, stream, mixedGroups) : lz4d2_launch<32, 1024, 2048>(a, stream, mixedGroups);
         case 64: return ringClass ? lz4d2_launch<64, 4096, 8192>(a, stream, mixedGroups) : lz4d2_launch<64, 2048, 4096>(a, stream, mixedGroups);

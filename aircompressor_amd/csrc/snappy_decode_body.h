@@ -21,7 +21,7 @@ __device__ __forceinline__ int32_t snappy_op_entry2(int32_t op)  // opLookupTabl
 
 // `ldsIn` / `ldsOut` / `ldsStage` (may be null): the group's rings.  On return st / eo hold the status and error offset, op the
 // bytes produced (flushed).  All lanes of the group return the same values.
-template <int GS, int IN_RING, int OUT_RING, int GPL>
+template <int GS, int IN_RING, int OUT_RING, int GPL, bool PHASED = false>
 __device__ __forceinline__ void snappy_buffer_decode(uint8_t* ldsIn, uint8_t* ldsOut, uint8_t* ldsStage, const uint8_t* __restrict__ in0, int32_t inLen0, uint8_t* out,
                                                      int32_t outLimit, int g, int32_t& stOut, int32_t& eoOut, int32_t& opOut)
 {
@@ -63,7 +63,7 @@ __device__ __forceinline__ void snappy_buffer_decode(uint8_t* ldsIn, uint8_t* ld
         const int32_t inLimit = inLen0 - nread;
         const int32_t fastOutLimit = outLimit - 8;
         int32_t ip = 0;
-        Rings<GS, IN_RING, OUT_RING, GPL> R;
+        Rings<GS, IN_RING, OUT_RING, GPL, PHASED> R;
         R.init(ldsIn, ldsOut, in, inLimit, out, g, ldsStage);
 
 #define SN_FAIL(off)                                                     \
@@ -99,6 +99,7 @@ __device__ __forceinline__ void snappy_buffer_decode(uint8_t* ldsIn, uint8_t* ld
             return true;
         };
         while (ip < inLimit) {
+            R.memory_phase(ip, op);  // (PHASED rings: this trip's refill and flushes, all in one place)
             R.ensure_input(ip, 5);
             int32_t opc = (int32_t)R.in_u8(ip);
             if ((opc & 3) == 0) {  // literal :116-146

@@ -9,7 +9,7 @@ namespace achip {
 
 // HANDOVER: the launch that decodes only the blocks a two-pass decode handed over (`only` filter) -- its own instantiation, so that kernel
 // statistics keep it apart from the launch that decodes a whole batch
-template <int GS, int IN_RING, int OUT_RING, int GPL, bool HANDOVER = false>
+template <int GS, int IN_RING, int OUT_RING, int GPL, bool HANDOVER = false, bool PHASED = false>
 __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
     if (mixedGroups != nullptr && snappy_pick(mixedGroups, batch_count(a)) != LZ4_PICK_RINGS) {  // auto mode (achip_abi.cpp): the lane-per-block decoder takes this batch
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs 
     int32_t eo = 0;
     int32_t op = 0;
     uint8_t* const slot = smem + grp * (IN_RING + OUT_RING + a.ringPad);
-    snappy_buffer_decode<GS, IN_RING, OUT_RING, GPL>(slot, slot + IN_RING, a.ringPad >= 16 * GS * GPL ? slot + IN_RING + OUT_RING : nullptr, in0, inLen0, out, outLimit, g, st,
+    snappy_buffer_decode<GS, IN_RING, OUT_RING, GPL, PHASED>(slot, slot + IN_RING, a.ringPad >= 16 * GS * GPL ? slot + IN_RING + OUT_RING : nullptr, in0, inLen0, out, outLimit, g, st,
                                                       eo, op);
 
     if (g == 0) {
@@ -51,17 +51,17 @@ __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs 
     }
 }
 
-template <int GS, int IN_RING, int OUT_RING, int GPL = 1>
+template <int GS, int IN_RING, int OUT_RING, int GPL = 1, bool PHASED = false>
 static hipError_t snd2_launch(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups)
 {
     constexpr int GROUPS_PER_WG = 256 / GS;
     const unsigned grid = (unsigned)((a.nBlocks + GROUPS_PER_WG - 1) / GROUPS_PER_WG);
     const size_t lds = (size_t)GROUPS_PER_WG * (IN_RING + OUT_RING + a.ringPad);
     if (a.only != nullptr) {
-        hipLaunchKernelGGL((snappy_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL, true>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
+        hipLaunchKernelGGL((snappy_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL, true, PHASED>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
     }
     else {
-        hipLaunchKernelGGL((snappy_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL, false>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
+        hipLaunchKernelGGL((snappy_decompress_rings_kernel<GS, IN_RING, OUT_RING, GPL, false, PHASED>), dim3(grid), dim3(256), lds, stream, a, mixedGroups);
     }
     return hipGetLastError();
 }
@@ -71,7 +71,8 @@ hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream
     switch (groupSize) {
         case 1: return ringClass ? snd2_launch<1, 128, 256, 4>(a, stream, mixedGroups) : snd2_launch<1, 64, 128, 2>(a, stream, mixedGroups);
         case 2: return ringClass ? snd2_launch<2, 128, 256, 2>(a, stream, mixedGroups) : snd2_launch<2, 64, 128, 1>(a, stream, mixedGroups);
-        case 4: return ringClass ? snd2_launch<4, 256, 512>(a, stream, mixedGroups) : snd2_launch<4, 128, 256>(a, stream, mixedGroups);
+        case 4:  // ring class 0 (default): the phased form (achip_rings.h); 2: round 2's compact rings
+            return ringClass == 1 ? snd2_launch<4, 256, 512>(a, stream, mixedGroups) : (ringClass == 2 ? snd2_launch<4, 128, 256>(a, stream, mixedGroups) : snd2_launch<4, 256, 256, 1, true>(a, stream, mixedGroups));
         case 8: return ringClass ? snd2_launch<8, 512, 1024>(a, stream, mixedGroups) : snd2_launch<8, 256, 512>(a, stream, mixedGroups);
         case 32: return ringClass ? snd2_launch<32, 2048, 4096>(a, stream, mixedGroups) : snd2_launch<32, 1024, 2048>(a, stream, mixedGroups);
         case 64: return ringClass ? snd2_launch<64, 4096, 8192>(a, stream, mixedGroups) : snd2_launch<64, 2048, 4096>(a, stream, mixedGroups);
