@@ -80,11 +80,23 @@ struct Rings {
         inLoadedV = 0;
         flushedV = 0;
         g = lane;
+        if (PHASED) {
+            request_pending(16 * g);
+        }
+        else {
 #pragma unroll
-        for (int q = 0; q < GPL; q++) {
-            pending[q] = fetch_granule(16 * (g + GS * q));
+            for (int q = 0; q < GPL; q++) {
+                pending[q] = fetch_granule(16 * (g + GS * q));
+            }
         }
     }
+
+    // (Round 3 tried to hide the prefetch from the compiler -- the load issued through inline assembly, waited for by hand -- so that none
+    // of its conservative waits would cover it.  tools/check_hidden_loads.py, a data-flow check of the generated code, showed why not: the
+    // compiler lands the asm's result in temporaries and copies it home, reading registers with the load in flight.  What works instead is
+    // to keep every wait the compiler places out of the common path: see ensure_input.)
+    __device__ __forceinline__ void request_pending(int32_t v) { pending[0] = fetch_granule(v); }
+    __device__ __forceinline__ u32x4 take_pending(int32_t) { return pending[0]; }
 
     // switch the input ring to a new source stream (Zstd: literals of the next block, a raw block, ...)
     __device__ __forceinline__ void reset_input(const uint8_t* in, int32_t inLimit)
@@ -125,6 +137,13 @@ struct Rings {
     // ---- input side ----
     __device__ __forceinline__ void refill()
     {
+        if (PHASED) {
+            const int32_t v = inLoadedV + 16 * g;
+            *(u32x4*)(inRing + (v & (IN_RING - 1))) = take_pending(v);  // requested during the previous refill
+            request_pending(v + CHUNK);
+            inLoadedV += CHUNK;
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < GPL; q++) {
             const int32_t v = inLoadedV + 16 * (g + GS * q);
@@ -138,8 +157,13 @@ struct Rings {
     {
         enter();
         const int32_t want = pos + inBase + need;
-        while (want > inLoadedV && inLoadedV < inEndV) {
-            refill();
+        // (an `if` around the loop, not a bare `while`: the compiler flushes the memory counters in the PREHEADER of a loop that uses a
+        // register with a load in flight -- `s_waitcnt vmcnt(0)` on every pass through here, refill or not, i.e. a wait for the chunk
+        // requested a moment ago at each of a sequence's four calls -- whereas a wait inside a branch is only paid when it is taken)
+        if (want > inLoadedV && inLoadedV < inEndV) {
+            do {
+                refill();
+            } while (want > inLoadedV && inLoadedV < inEndV);
         }
         order();
     }
@@ -150,7 +174,8 @@ struct Rings {
     {
         if (PHASED) {
             enter();
-            // the chunk requested one phase ago enters the ring as soon as what it overwrites is consumed, and the next one is requested
+            // the chunk requested one phase ago enters the ring as soon as what it overwrites is consumed (the only wait: everything in
+            // flight is a sequence old), the next one is requested, completed output chunks leave
             if (inLoadedV - (ip + inBase) <= IN_RING - CHUNK && inLoadedV < inEndV) {
                 refill();
             }
