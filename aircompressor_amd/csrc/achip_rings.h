@@ -180,19 +180,7 @@ struct Rings {
                 refill();
             }
             order();
-            // (straight-line for the two chunks a sequence of the common kind completes: a loop's preheader is where the compiler parks
-            // a wait for everything in flight -- the chunk requested three lines up included)
-            const int32_t opV = op + outBase;
-            if (flushedV + CHUNK <= opV) {
-                flush_chunk();
-                if (flushedV + CHUNK <= opV) {
-                    flush_chunk();
-                    if (flushedV + CHUNK <= opV) {
-                        flush_complete(op);
-                    }
-                }
-            }
-            order();
+            flush_complete(op);
         }
     }
 
@@ -278,20 +266,6 @@ struct Rings {
     __device__ __forceinline__ void out_put(int32_t pos, uint32_t byte) { outRing[(pos + outBase) & (OUT_RING - 1)] = (uint8_t)byte; }
     __device__ __forceinline__ uint32_t out_get(int32_t pos) const { return outRing[(pos + outBase) & (OUT_RING - 1)]; }
 
-    // one complete chunk (not the one straddling the start of the output buffer: flush_complete takes that) leaves
-    __device__ __forceinline__ void flush_chunk()
-    {
-        const int32_t v = flushedV + 16 * g;
-        if (v >= outBase) {
-            *(u32x4*)(outAligned + v) = *(const u32x4*)(outRing + (v & (OUT_RING - 1)));
-        }
-        else if (v + 16 > outBase) {
-            for (int32_t p = outBase; p < v + 16; p++) {
-                outAligned[p] = outRing[p & (OUT_RING - 1)];
-            }
-        }
-        flushedV += CHUNK;
-    }
     // flush every complete CHUNK below position `op` (absolute)
     __device__ __forceinline__ void flush_complete(int32_t op)
     {
@@ -360,18 +334,6 @@ struct Rings {
     {
         enter();
         if (UNIFIED && n > 4 * GS) {
-            if (PHASED) {  // the first chunk straight-line (no loop preheader in the common path), its flush left to the next memory phase
-                const int32_t c = n < CHUNK ? n : CHUNK;
-                ensure_input(ip, c);
-                copy_dwords<IN_RING>(inRing, ip + inBase, op + outBase, c);
-                ip += c;
-                op += c;
-                n -= c;
-                if (n <= 0) {
-                    return;
-                }
-                flush_complete(op);
-            }
             while (n > 0) {
                 const int32_t c = n < CHUNK ? n : CHUNK;
                 ensure_input(ip, c);
@@ -379,7 +341,9 @@ struct Rings {
                 ip += c;
                 op += c;
                 n -= c;
-                flush_complete(op);
+                if (!PHASED || n > 0) {  // (PHASED: a run of one chunk leaves its flush to the next memory phase)
+                    flush_complete(op);
+                }
             }
             return;
         }
@@ -421,7 +385,7 @@ struct Rings {
                 // A trip never reads what it writes (c <= dist); a distance shorter than a chunk doubles once a whole
                 // period has been written -- the data is periodic, so out[x] = out[x - 2 * dist] as well.
                 int32_t dist = offset;
-                auto step = [&]() {
+                while (n > 0) {
                     int32_t c = n < CHUNK ? n : CHUNK;
                     c = c < dist ? c : dist;
                     order();
@@ -444,17 +408,9 @@ struct Rings {
                     if (dist < CHUNK) {
                         dist += dist;
                     }
-                };
-                if (PHASED) {  // the first chunk straight-line, its flush left to the next memory phase
-                    step();
-                    if (n <= 0) {
-                        return;
+                    if (!PHASED || n > 0) {
+                        flush_complete(op);
                     }
-                    flush_complete(op);
-                }
-                while (n > 0) {
-                    step();
-                    flush_complete(op);
                 }
                 return;
             }
