@@ -26,13 +26,14 @@ namespace achip {
 // round-2 kernel): every refill waited for the stores of the flush just before it to be acknowledged (SQ_WAIT_ANY 57 % of the
 // wave-cycles, profiles/r03_notes.md).  With all of a sequence's memory operations in one place, whatever a wait covers is a whole
 // sequence old.  The copies then only flush inside loops (long runs), the input ring is kept two chunks ahead (IN_RING >= 4 chunks).
-template <int GS, int IN_RING, int OUT_RING, int GPL = 1, bool PHASED = false>
+template <int GS, int IN_RING, int OUT_RING, int GPL = 1, int PHASED = 0>  // PHASED bits: 1 = the memory phase tops the input ring up, 2 = it takes the flushes
 struct Rings {
     static constexpr int CHUNK = GS * 16 * GPL;                // bytes per refill / flush / copy step (GPL 16-byte granules per lane)
     static constexpr int LDS_REACH = OUT_RING - CHUNK - 16;    // farthest back-reference served from the ring
     static_assert((IN_RING & (IN_RING - 1)) == 0 && (OUT_RING & (OUT_RING - 1)) == 0, "rings are powers of two");
     static_assert(IN_RING >= 2 * CHUNK && OUT_RING >= 4 * CHUNK, "ring too small for the chunk size");
     static_assert(!PHASED || (IN_RING >= 4 * CHUNK && GS == 4 && GPL == 1), "the phased form keeps two chunks of input ahead");
+    static constexpr bool PH_REFILL = (PHASED & 1) != 0, PH_FLUSH = (PHASED & 2) != 0;
 
     uint8_t* inRing;
     uint8_t* outRing;
@@ -176,11 +177,13 @@ struct Rings {
             enter();
             // the chunk requested one phase ago enters the ring as soon as what it overwrites is consumed (the only wait: everything in
             // flight is a sequence old), the next one is requested, completed output chunks leave
-            if (inLoadedV - (ip + inBase) <= IN_RING - CHUNK && inLoadedV < inEndV) {
+            if (PH_REFILL && inLoadedV - (ip + inBase) <= IN_RING - CHUNK && inLoadedV < inEndV) {
                 refill();
             }
             order();
-            flush_complete(op);
+            if (PH_FLUSH) {
+                flush_complete(op);
+            }
         }
     }
 
@@ -341,7 +344,7 @@ struct Rings {
                 ip += c;
                 op += c;
                 n -= c;
-                if (!PHASED || n > 0) {  // (PHASED: a run of one chunk leaves its flush to the next memory phase)
+                if (!PH_FLUSH || n > 0) {  // (deferred flushes: a run of one chunk leaves its flush to the next memory phase)
                     flush_complete(op);
                 }
             }
@@ -350,7 +353,7 @@ struct Rings {
         if (n <= 4 * GS) {
             ensure_input(ip, n);
             copy_small<IN_RING>(inRing, ip + inBase, op + outBase, n);
-            if (!PHASED) {
+            if (!PH_FLUSH) {
                 flush_complete(op + n);
             }
             return;
@@ -395,7 +398,7 @@ struct Rings {
                     else {
                         // flushed long ago (dist > LDS_REACH >= 2 * CHUNK): 64 source bytes land in the staging area,
                         // then the same move as every other copy.  Reading past c stays inside this block's output.
-                        if (PHASED && op + outBase - dist + CHUNK > flushedV) {  // (deferred flushes: what is read back must have left)
+                        if (PH_FLUSH && op + outBase - dist + CHUNK > flushedV) {  // (deferred flushes: what is read back must have left)
                             flush_complete(op);
                             order();
                         }
@@ -408,7 +411,7 @@ struct Rings {
                     if (dist < CHUNK) {
                         dist += dist;
                     }
-                    if (!PHASED || n > 0) {
+                    if (!PH_FLUSH || n > 0) {
                         flush_complete(op);
                     }
                 }
@@ -421,13 +424,13 @@ struct Rings {
                 copy_small<OUT_RING>(outRing, op + outBase - offset, op + outBase, n);
             }
             else {
-                if (PHASED && op + outBase - offset + 4 * GS > flushedV) {
+                if (PH_FLUSH && op + outBase - offset + 4 * GS > flushedV) {
                     flush_complete(op);
                     order();
                 }
                 put4(op + outBase + 4 * g, ld4(outAligned + outBase + (op - offset) + 4 * g), n - 4 * g);  // flushed long ago (see below)
             }
-            if (!PHASED) {
+            if (!PH_FLUSH) {
                 flush_complete(op + n);
             }
             return;

@@ -8,7 +8,7 @@ namespace achip {
 
 // `R` is initialised on (in, inLimit, out); on return st / eo hold the status and error offset, op the bytes produced
 // (the output is flushed).  All lanes of the group return the same values.
-template <int GS, int IN_RING, int OUT_RING, int GPL, bool PHASED = false>
+template <int GS, int IN_RING, int OUT_RING, int GPL, int PHASED = 0>
 __device__ __forceinline__ void lz4_block_decode(Rings<GS, IN_RING, OUT_RING, GPL, PHASED>& R, const uint8_t* __restrict__ in, int32_t inLimit, int32_t outLimit, int32_t& stOut,
                                                  int32_t& eoOut, int32_t& opOut)
 {

@@ -11,7 +11,7 @@ namespace achip {
 
 // HANDOVER: the launch that decodes only the blocks a two-pass decode handed over (`only` filter) -- its own instantiation, so that kernel
 // statistics keep it apart from the launch that decodes a whole batch
-template <int GS, int IN_RING, int OUT_RING, int GPL, bool HANDOVER = false, bool PHASED = false>
+template <int GS, int IN_RING, int OUT_RING, int GPL, bool HANDOVER = false, int PHASED = 0>
 __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
     // auto mode (achip_abi.cpp): both LZ4 decoders are launched, the probe's count of mixed 16-block groups picks one
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void lz4_decompress_rings_kernel(BatchArgs a, 
     }
 }
 
-template <int GS, int IN_RING, int OUT_RING, int GPL = 1, bool PHASED = false>
+template <int GS, int IN_RING, int OUT_RING, int GPL = 1, int PHASED = 0>
 static hipError_t lz4d2_launch(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups)
 {
     constexpr int GROUPS_PER_WG = 256 / GS;
@@ -81,7 +81,14 @@ hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, i
         case 2: return ringClass ? lz4d2_launch<2, 128, 256, 2>(a, stream, mixedGroups) : lz4d2_launch<2, 64, 128, 1>(a, stream, mixedGroups);
         case 4:
             // ring class 0 (the default): the phased form, with an input ring of four chunks (achip_rings.h); class 2: round 2's compact rings (kept for the comparison in profiles/r03_notes.md)
-            return ringClass == 1 ? lz4d2_launch<4, 256, 512>(a, stream, mixedGroups) : (ringClass == 2 ? lz4d2_launch<4, 128, 256>(a, stream, mixedGroups) : lz4d2_launch<4, 256, 256, 1, true>(a, stream, mixedGroups));
+            switch (ringClass) {
+                case 1: return lz4d2_launch<4, 256, 512>(a, stream, mixedGroups);
+                case 2: return lz4d2_launch<4, 128, 256>(a, stream, mixedGroups);
+                case 3: return lz4d2_launch<4, 256, 256, 1, 1>(a, stream, mixedGroups);
+                case 4: return lz4d2_launch<4, 256, 256, 1, 2>(a, stream, mixedGroups);
+                case 5: return lz4d2_launch<4, 256, 256, 1, 0>(a, stream, mixedGroups);
+                default: return lz4d2_launch<4, 256, 256, 1, 3>(a, stream, mixedGroups);
+            }
         case 8: return ringClass ? lz4d2_launch<8, 512, 1024>(a, stream, mixedGroups) : lz4d2_launch<8, 256, 512>(a, stream, mixedGroups);
         case 32: return ringClass ? lz4d2_launch<32, 2048, 4096>(a, stream, mixedGroups) : lz4d2_launch<32, 1024, 2048>(a, stream, mixedGroups);
         case 64: return ringClass ? lz4d2_launch<64, 4096, 8192>(a, stream, mixedGroups) : lz4d2_launch<64, 2048, 4096>(a, stream, mixedGroups);

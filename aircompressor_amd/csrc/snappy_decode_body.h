@@ -21,7 +21,7 @@ __device__ __forceinline__ int32_t snappy_op_entry2(int32_t op)  // opLookupTabl
 
 // `ldsIn` / `ldsOut` / `ldsStage` (may be null): the group's rings.  On return st / eo hold the status and error offset, op the
 // bytes produced (flushed).  All lanes of the group return the same values.
-template <int GS, int IN_RING, int OUT_RING, int GPL, bool PHASED = false>
+template <int GS, int IN_RING, int OUT_RING, int GPL, int PHASED = 0>
 __device__ __forceinline__ void snappy_buffer_decode(uint8_t* ldsIn, uint8_t* ldsOut, uint8_t* ldsStage, const uint8_t* __restrict__ in0, int32_t inLen0, uint8_t* out,
                                                      int32_t outLimit, int g, int32_t& stOut, int32_t& eoOut, int32_t& opOut)
 {

@@ -9,7 +9,7 @@ namespace achip {
 
 // HANDOVER: the launch that decodes only the blocks a two-pass decode handed over (`only` filter) -- its own instantiation, so that kernel
 // statistics keep it apart from the launch that decodes a whole batch
-template <int GS, int IN_RING, int OUT_RING, int GPL, bool HANDOVER = false, bool PHASED = false>
+template <int GS, int IN_RING, int OUT_RING, int GPL, bool HANDOVER = false, int PHASED = 0>
 __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs a, const int32_t* mixedGroups)
 {
     if (mixedGroups != nullptr && snappy_pick(mixedGroups, batch_count(a)) != LZ4_PICK_RINGS) {  // auto mode (achip_abi.cpp): the lane-per-block decoder takes this batch
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void snappy_decompress_rings_kernel(BatchArgs 
     }
 }
 
-template <int GS, int IN_RING, int OUT_RING, int GPL = 1, bool PHASED = false>
+template <int GS, int IN_RING, int OUT_RING, int GPL = 1, int PHASED = 0>
 static hipError_t snd2_launch(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups)
 {
     constexpr int GROUPS_PER_WG = 256 / GS;
@@ -72,7 +72,14 @@ hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream
         case 1: return ringClass ? snd2_launch<1, 128, 256, 4>(a, stream, mixedGroups) : snd2_launch<1, 64, 128, 2>(a, stream, mixedGroups);
         case 2: return ringClass ? snd2_launch<2, 128, 256, 2>(a, stream, mixedGroups) : snd2_launch<2, 64, 128, 1>(a, stream, mixedGroups);
         case 4:  // ring class 0 (default): the phased form (achip_rings.h); 2: round 2's compact rings
-            return ringClass == 1 ? snd2_launch<4, 256, 512>(a, stream, mixedGroups) : (ringClass == 2 ? snd2_launch<4, 128, 256>(a, stream, mixedGroups) : snd2_launch<4, 256, 256, 1, true>(a, stream, mixedGroups));
+            switch (ringClass) {
+                case 1: return snd2_launch<4, 256, 512>(a, stream, mixedGroups);
+                case 2: return snd2_launch<4, 128, 256>(a, stream, mixedGroups);
+                case 3: return snd2_launch<4, 256, 256, 1, 1>(a, stream, mixedGroups);
+                case 4: return snd2_launch<4, 256, 256, 1, 2>(a, stream, mixedGroups);
+                case 5: return snd2_launch<4, 256, 256, 1, 0>(a, stream, mixedGroups);
+                default: return snd2_launch<4, 256, 256, 1, 3>(a, stream, mixedGroups);
+            }
         case 8: return ringClass ? snd2_launch<8, 512, 1024>(a, stream, mixedGroups) : snd2_launch<8, 256, 512>(a, stream, mixedGroups);
         case 32: return ringClass ? snd2_launch<32, 2048, 4096>(a, stream, mixedGroups) : snd2_launch<32, 1024, 2048>(a, stream, mixedGroups);
         case 64: return ringClass ? snd2_launch<64, 4096, 8192>(a, stream, mixedGroups) : snd2_launch<64, 2048, 4096>(a, stream, mixedGroups);

@@ -8,8 +8,8 @@ line() { grep '^{' | python -c "import sys,json; r=json.loads(sys.stdin.read());
 timeout 500 python -m pytest tests/test_gpu_lz4_snappy.py tests/test_gpu_corpus.py tests/test_gpu_fuzz.py tests/test_gpu_snappy_framed.py tests/test_gpu_hadoop.py -m gpu -x -q > $O/pytest.log 2>&1
 tail -3 $O/pytest.log
 for w in lz4_decompress snappy_decompress; do
-  for rc in 0 2; do
-    for d in fragments wordmix corpus; do
+  for rc in 0 2 3 4 5; do
+    for d in fragments; do
       echo "## $w ring_class $rc $d" >> $O/ab.txt
       timeout 150 $B --workload $w --data $d --variant 1 --ring-class $rc --steps 5 --warmup 2 2>&1 | line >> $O/ab.txt 2>&1
     done
