@@ -841,7 +841,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->snappydVariant = (int)value;
     }
     else if (k == "decompress.ring_class") {
-        if (value < 0 || value > 5) return bad_argument("decompress.ring_class: 0 compact (4 lanes per block: phased), 1 large, 2 round-2 compact rings (4 lanes per block)");
+        if (value < 0 || value > 4) return bad_argument("decompress.ring_class: 0 compact (4 lanes per block: phased), 1 large, 2 round-2 compact rings (4 lanes per block)");
         ctx->ringClass = (int)value;
     }
     else if (k == "lz4.compress.variant") {

@@ -26,14 +26,14 @@ namespace achip {
 // round-2 kernel): every refill waited for the stores of the flush just before it to be acknowledged (SQ_WAIT_ANY 57 % of the
 // wave-cycles, profiles/r03_notes.md).  With all of a sequence's memory operations in one place, whatever a wait covers is a whole
 // sequence old.  The copies then only flush inside loops (long runs), the input ring is kept two chunks ahead (IN_RING >= 4 chunks).
-template <int GS, int IN_RING, int OUT_RING, int GPL = 1, int PHASED = 0>  // PHASED bits: 1 = the memory phase tops the input ring up, 2 = it takes the flushes
+template <int GS, int IN_RING, int OUT_RING, int GPL = 1, int PHASED = 0>  // PHASED != 0: the decode loops top the input ring up once per trip (memory_phase)
 struct Rings {
     static constexpr int CHUNK = GS * 16 * GPL;                // bytes per refill / flush / copy step (GPL 16-byte granules per lane)
     static constexpr int LDS_REACH = OUT_RING - CHUNK - 16;    // farthest back-reference served from the ring
     static_assert((IN_RING & (IN_RING - 1)) == 0 && (OUT_RING & (OUT_RING - 1)) == 0, "rings are powers of two");
     static_assert(IN_RING >= 2 * CHUNK && OUT_RING >= 4 * CHUNK, "ring too small for the chunk size");
     static_assert(!PHASED || (IN_RING >= 4 * CHUNK && GS == 4 && GPL == 1), "the phased form keeps two chunks of input ahead");
-    static constexpr bool PH_REFILL = (PHASED & 1) != 0, PH_FLUSH = (PHASED & 2) != 0;
+    static constexpr bool PH_REFILL = PHASED != 0, PH_FLUSH = false;  // (PH_FLUSH: the flushes deferred to the phase as well -- measured 3 .. 11 % slower, profiles/r03_notes.md; the code paths stay for the record of what was measured)
 
     uint8_t* inRing;
     uint8_t* outRing;
