@@ -845,7 +845,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->ringClass = (int)value;
     }
     else if (k == "lz4.compress.variant") {
-        if (value != 0 && value != 1) return bad_argument("lz4.compress.variant: 0 serial probes, 1 batch probes");
+        if (value != 0 && value != 1 && value != 4) return bad_argument("lz4.compress.variant: 0 serial probes, 1 batch probes, 4 many matches per window");
         ctx->lz4cVariant = (int)value;
     }
     else if (k == "snappy.compress.variant") {

@@ -15,6 +15,7 @@
 // skip-accelerated search loop (:113-138) in parallel, resolving same-hash collisions
 // inside the batch so the table evolves exactly as in program order.
 #include "lz4_compress_body.h"
+#include "lz4_compress_mw.h"
 
 namespace achip {
 
@@ -218,6 +219,35 @@ __global__ __launch_bounds__(64) void lz4_compress_batch_kernel(BatchArgs a, int
     }
 }
 
+// "Many matches per window" variant (lz4_compress_mw.h): the same parse, replayed over 64 consecutive positions held in registers.
+template <typename TableT>
+__global__ __launch_bounds__(64) void lz4_compress_mw_kernel(BatchArgs a, int32_t bothWidths)
+{
+    using namespace lz4c;
+    __shared__ TableT table[MAX_TABLE_SIZE];
+    const int lane = threadIdx.x;
+    const int64_t block = blockIdx.x;
+    const int32_t inLen = a.srcLen[block];
+    constexpr bool WIDE = sizeof(TableT) == 4;
+    if (WIDE ? (inLen <= 65536) : (inLen > 65536)) {
+        if (!bothWidths && lane == 0) {
+            a.outLen[block] = 0;
+            a.status[block] = mk_status(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_BAD_ARGUMENT);
+            a.errOffset[block] = 0;
+        }
+        return;
+    }
+    const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
+    uint8_t* __restrict__ out = a.dstBase + a.dstOff[block];
+    int32_t st = 0;
+    const int32_t output = lz4_compress_block_mw<TableT>(in, inLen, out, a.dstCap[block], table, lane, st);
+    if (lane == 0) {
+        a.outLen[block] = st == 0 ? output : 0;
+        a.status[block] = st;
+        a.errOffset[block] = 0;
+    }
+}
+
 // ---- LZ4 frame container, encoder -------------------------------------------------------------
 // Replaces Lz4FrameCompression.compress (M/lz4/Lz4FrameCompression.java:96-140): header (magic, FLG = version 01 +
 // independent blocks, BD = 4 MiB, xxHash32 header checksum byte), 4 MiB blocks each through the block encoder above into a
@@ -329,6 +359,13 @@ hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int varia
     // maxSrcLenHint: 0 = unknown, else the caller's promise about the largest srcLen in the batch: when it is <= 64 KiB the launch of
     // the wide-table kernel is skipped (a block that breaks the promise gets an INVALID_ARGUMENT status, not silence)
     const int32_t both = maxSrcLenHint == 0 || maxSrcLenHint > 65536;
+    if (variant == 4) {
+        hipLaunchKernelGGL(lz4_compress_mw_kernel<uint16_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, both);
+        if (both) {
+            hipLaunchKernelGGL(lz4_compress_mw_kernel<int32_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, both);
+        }
+        return hipGetLastError();
+    }
     if (variant == 0) {
         hipLaunchKernelGGL(lz4_compress_kernel<uint16_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, both);
     }

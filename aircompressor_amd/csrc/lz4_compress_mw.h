@@ -1,0 +1,422 @@
+// lz4_compress_mw.h -- the LZ4 block encoder of one wavefront, "many matches per window" form (round 3; lz4_compress.hip has the
+// design notes of the family, lz4_compress_body.h the batch-probe encoder this one grew out of and still uses for long searches).
+//
+// Bit-exactness with M/lz4/Lz4RawCompressor.java:69-192 makes the parse one serial chain per block, and round 2's profile said what a
+// link of that chain costs on a wavefront: ~3.2 us per sequence on text -- five DEPENDENT memory round trips (the probes' bytes, the
+// candidates' bytes, the catch-up bytes, the bytes of `count`, the literal copy's loads), each waited for in turn, for 12 bytes of
+// progress.  The batch-probe encoder evaluates 64 probe positions at once but throws the batch away at its first match, which on
+// text is lane 3 .. 6.
+//
+// Here a WINDOW of 64 consecutive positions is loaded once -- lane l holds the 8 bytes at base + l, their hash, the table entry of
+// that hash as it was when the window began, and 16 bytes around that entry's position ([entry - 4, entry + 12): the candidate's own 4
+// bytes, 4 before it for the catch-up, 8 behind it for `count`) -- and then the Java loop is REPLAYED over the window with wave-uniform
+// control and no memory access at all in the common case:
+//   * what the table would say at a lane is known without touching the table: the latest lane of the window with the same hash that
+//     the replay has inserted so far (a 64-bit mask per lane from wave_match_any, intersected with the mask of inserted lanes), else
+//     the entry read at the window's start; a candidate inside the window is another lane's register;
+//   * search (:113-138): every remaining lane evaluates its hit test at once, the first hit is the match; the lanes before it are
+//     marked inserted, the lanes inside the match never are;
+//   * catch-up (:141-144), count (:240-267) on the first 8 bytes, the re-probe behind the match (:157-184) with its `input - 2`
+//     insert: lane reads (readlane) of registers; only a match longer than 12 bytes or a catch-up beyond 4 goes to memory;
+//   * literals are stored straight from the lanes' registers (a literal byte of the window is the low byte of its lane's 8), the
+//     token / offset / length bytes by lane 0: stores only, nothing to wait for;
+//   * at the end of the window the table takes the latest inserted lane of every hash.
+// A window therefore costs two memory round trips (its own bytes, the candidates' surroundings) plus one LDS round trip, whatever the
+// number of sequences in it -- about five on text.  A search that runs through a whole window without a match (incompressible data:
+// the skip schedule takes over after 64 probes) is handed to the batch-probe loop below, which comes back here after its match.
+#pragma once
+#include "lz4_compress_body.h"
+
+namespace achip {
+
+namespace lz4mw {
+__device__ __forceinline__ uint32_t rl32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int src) { return ((uint64_t)rl32((uint32_t)(v >> 32), src) << 32) | rl32((uint32_t)v, src); }
+// bits [lo, hi) of a 64-bit mask (0 <= lo, hi <= 64)
+__device__ __forceinline__ uint64_t bits(int lo, int hi)
+{
+    const uint64_t upTo = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+    const uint64_t below = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
+    return upTo & ~below;
+}
+// 8 bytes starting at byte `off` (0 .. 8) of the 16 bytes (lo, hi)
+__device__ __forceinline__ uint64_t ext64(uint64_t lo, uint64_t hi, int off)
+{
+    return off == 0 ? lo : (off >= 8 ? hi : ((lo >> (8 * off)) | (hi << (64 - 8 * off))));
+}
+}  // namespace lz4mw
+
+template <typename TableT>
+__device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t inLen, uint8_t* __restrict__ out, int32_t outCap, TableT* table, int lane, int32_t& stOut)
+{
+    using namespace lz4c;
+    using namespace lz4mw;
+    int32_t st = 0;
+    int32_t output = 0;
+    const int64_t bound = (int64_t)inLen + inLen / 255 + 16;
+    if ((uint32_t)inLen > 0x7E000000u) {
+        st = mk_status(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_LZ4_MAX_INPUT);
+    }
+    else if ((int64_t)outCap < bound) {
+        st = mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_LZ4_MAX_OUTPUT);
+    }
+    else {
+        int32_t tableSize = inLen <= 1 ? 0 : (int32_t)((0x80000000u >> __builtin_clz((uint32_t)(inLen - 1))) << 1);
+        tableSize = tableSize < MIN_TABLE_SIZE ? MIN_TABLE_SIZE : (tableSize > MAX_TABLE_SIZE ? MAX_TABLE_SIZE : tableSize);
+        for (int i = lane; i < tableSize; i += 64) {
+            table[i] = 0;
+        }
+        __syncthreads();
+        const int32_t mask = tableSize - 1;
+        const int hashBits = 32 - __builtin_clz((uint32_t)mask | 1u);
+        const int32_t inputLimit = inLen;
+        const int32_t matchFindLimit = inputLimit - MATCH_FIND_LIMIT;
+        const int32_t matchLimit = inputLimit - LAST_LITERAL_SIZE;
+        int32_t anchor = 0;
+
+        // emitMatch :209-235 behind a literal run already in place; returns the new output position
+        auto emit_match = [&](int32_t tokenPos, int32_t literalLength, int32_t offset, int32_t matchLength) {
+            if (lane == 0) {
+                lz4_write_run_length(out, tokenPos, literalLength, matchLength >= ML_MASK ? ML_MASK : (uint32_t)matchLength);
+                out[output] = (uint8_t)offset;
+                out[output + 1] = (uint8_t)((uint32_t)offset >> 8);
+                if (matchLength >= ML_MASK) {
+                    int32_t o = output + 2;
+                    int32_t remaining = matchLength - ML_MASK;
+                    while (remaining >= 510) {
+                        out[o++] = 255;
+                        out[o++] = 255;
+                        remaining -= 510;
+                    }
+                    if (remaining >= 255) {
+                        out[o++] = 255;
+                        remaining -= 255;
+                    }
+                    out[o++] = (uint8_t)remaining;
+                }
+            }
+            output += 2;
+            if (matchLength >= ML_MASK) {
+                output += 1 + (matchLength - ML_MASK) / 255;
+            }
+        };
+
+        if (inLen >= MIN_LENGTH) {
+            // mode 0: block start (position 0 is inserted, the search starts at 1); mode 1: after a match that ended at `input`;
+            // mode 2: a search that has run through a window goes on (probe k0 of the search that began at scanStart comes next)
+            int mode = 0;
+            int32_t input = 0;
+            int32_t scanStart = 1;
+            int32_t k0 = 0;
+            for (;;) {
+                if (mode == 2) {
+                    // ---- the batch-probe step of lz4_compress_body.h for a search in progress: 64 probes at the positions of the skip schedule ----
+                    const int32_t k = k0 + lane;
+                    const int32_t pos = scanStart + lz4_scan_offset(k);
+                    const bool valid = pos + lz4_scan_advance(k) <= matchFindLimit;
+                    const unsigned long long invalidMask = __ballot(!valid);
+                    const int firstInvalid = invalidMask ? __builtin_ctzll(invalidMask) : 64;
+                    const bool active = lane < firstInvalid;
+                    const unsigned long long activeMask = __ballot(active);
+                    uint64_t x = 0;
+                    int32_t h = 0;
+                    int32_t cand = 0;
+                    if (active) {
+                        x = ld8(in + pos);
+                        h = lz4_hash(x, mask);
+                        cand = (int32_t)table[h];
+                    }
+                    const unsigned long long same = wave_match_any((uint32_t)h, hashBits, activeMask);
+                    const unsigned long long earlier = same & ((1ull << lane) - 1ull);
+                    {
+                        const bool fromBatch = active && earlier != 0;
+                        const int32_t latest = __shfl(pos, fromBatch ? 63 - __builtin_clzll(earlier) : lane);
+                        if (fromBatch) {
+                            cand = latest;
+                        }
+                    }
+                    bool hit = false;
+                    if (active) {
+                        hit = ld4(in + cand) == (uint32_t)x && cand + MAX_DISTANCE >= pos;
+                    }
+                    const unsigned long long hitMask = __ballot(hit);
+                    const int winner = hitMask ? __builtin_ctzll(hitMask) : -1;
+                    const int lastWriter = winner >= 0 ? winner : firstInvalid - 1;
+                    {
+                        const unsigned long long upTo = lastWriter >= 63 ? ~0ull : ((1ull << (lastWriter + 1)) - 1ull);
+                        const unsigned long long later = same & upTo & ~((2ull << lane) - 1ull);
+                        if (active && lane <= lastWriter && later == 0) {
+                            table[h] = (TableT)pos;
+                        }
+                    }
+                    __syncthreads();
+                    if (winner < 0) {
+                        if (firstInvalid < 64) {
+                            break;  // the search ran off the end: last literals from anchor
+                        }
+                        k0 += 64;
+                        continue;
+                    }
+                    input = __shfl(pos, winner);
+                    int32_t matchIndex = __shfl(cand, winner);
+                    int32_t room = input - anchor < matchIndex ? input - anchor : matchIndex;  // catch up :141-144
+                    while (room > 0) {
+                        const bool eq = lane < room && in[input - 1 - lane] == in[matchIndex - 1 - lane];
+                        const unsigned long long ne = ~__ballot(eq);
+                        const int run = ne ? __builtin_ctzll(ne) : 64;
+                        input -= run;
+                        matchIndex -= run;
+                        room -= run;
+                        if (run < 64) {
+                            break;
+                        }
+                    }
+                    const int32_t literalLength = input - anchor;
+                    const int32_t tokenPos = output;
+                    const int32_t litPos = tokenPos + lz4_run_length_size(literalLength);
+                    group_copy<64>(out + litPos, in + anchor, literalLength, lane);
+                    output = litPos + literalLength;
+                    const int32_t matchLength = wave_count(in, input + MIN_MATCH, matchIndex + MIN_MATCH, matchLimit, lane);
+                    emit_match(tokenPos, literalLength, input - matchIndex, matchLength);
+                    input += matchLength + MIN_MATCH;
+                    anchor = input;
+                    if (input > matchFindLimit) {
+                        break;
+                    }
+                    mode = 1;
+                    continue;
+                }
+
+                // ---- a window: 64 consecutive positions from `base`; lane 0 (position 0, or input - 2) is inserted, never probed ----
+                const int32_t base = mode == 0 ? 0 : input - 2;
+                const int32_t pos = base + lane;
+                const bool canLoad = pos + 8 <= inLen;
+                const bool canProbe = pos + 1 <= matchFindLimit;  // a search probe needs its successor inside the limit (:127-129)
+                uint64_t x = 0;
+                int32_t h = 0;
+                int32_t tc = 0;
+                if (canLoad) {
+                    x = ld8(in + pos);
+                    h = lz4_hash(x, mask);
+                    tc = (int32_t)table[h];
+                }
+                const uint32_t x4 = (uint32_t)x;
+                const unsigned long long loadMask = __ballot(canLoad);
+                const unsigned long long same = wave_match_any((uint32_t)h, hashBits, loadMask) & loadMask;
+                // the 16 bytes around the table entry: [tc - 4, tc + 12) where there is room for them, else only the entry's own 4 bytes
+                // (fast == false: such a lane's match, if it wins, is measured from memory like the batch-probe encoder does)
+                const int32_t tcLo = tc >= 4 ? tc - 4 : 0;
+                const int shift = tc - tcLo;
+                const bool fast = canLoad && tcLo + 16 <= inLen;
+                uint64_t rLo = 0, rHi = 0;
+                uint32_t c4 = 0;
+                if (fast) {
+                    const u32x4 a = ld16(in + tcLo);
+                    rLo = (uint64_t)a.x | ((uint64_t)a.y << 32);
+                    rHi = (uint64_t)a.z | ((uint64_t)a.w << 32);
+                    c4 = (uint32_t)ext64(rLo, rHi, shift);
+                }
+                else if (canLoad) {
+                    c4 = ld4(in + tc);
+                }
+
+                unsigned long long M = 1ull;     // inserted lanes
+                int c = mode == 0 ? 1 : 3;      // first lane of the search that follows
+                int r = mode == 0 ? -1 : 2;     // lane of a pending re-probe (the position right behind a match), -1: none
+                bool blockDone = false;          // the search ran off the end, or a match ended beyond matchFindLimit
+                bool searchGoesOn = false;       // the window is used up in the middle of a search
+                for (;;) {
+                    int wl = -1;                 // lane where the match starts
+                    int32_t cand = 0;            // its candidate's position
+                    int jl = -1;                 // ... as a lane of this window (-1: the table's entry)
+                    bool zeroLit = false;
+                    if (r >= 0) {
+                        // the immediate re-probe :171-176 at lane r: the table as the replay has left it
+                        const unsigned long long elig = rl64(same, r) & M & bits(0, r);
+                        jl = elig != 0 ? 63 - __builtin_clzll(elig) : -1;
+                        const uint32_t xr = rl32(x4, r);
+                        const uint32_t cr = jl >= 0 ? rl32(x4, jl) : rl32(c4, r);
+                        cand = jl >= 0 ? base + jl : (int32_t)rl32((uint32_t)tc, r);
+                        const bool hit = cr == xr && (jl >= 0 || cand + MAX_DISTANCE >= base + r);
+                        M |= 1ull << r;
+                        if (hit) {
+                            wl = r;
+                            zeroLit = true;
+                        }
+                        else {
+                            c = r + 1;
+                        }
+                        r = -1;
+                    }
+                    if (wl < 0) {
+                        // the search :113-138 over lanes c .. 63 at once: a lane sees the inserts of the replay so far and of the search lanes before it
+                        const unsigned long long elig = same & (M | bits(c, lane)) & bits(0, lane);
+                        const int j = elig != 0 ? 63 - __builtin_clzll(elig) : -1;
+                        const uint32_t cv = __shfl(x4, j >= 0 ? j : lane);
+                        const uint32_t cmp = j >= 0 ? cv : c4;
+                        const int32_t cp = j >= 0 ? base + j : tc;
+                        const bool probing = lane >= c;
+                        const bool hit = probing && canProbe && cmp == x4 && (j >= 0 || cp + MAX_DISTANCE >= pos);
+                        const unsigned long long hm = __ballot(hit);
+                        const unsigned long long im = __ballot(probing && !canProbe);
+                        const unsigned long long first = hm | im;
+                        if (first == 0) {
+                            M |= bits(c, 64);
+                            searchGoesOn = true;
+                            break;
+                        }
+                        const int w = __builtin_ctzll(first);
+                        if (((im >> w) & 1ull) != 0) {  // the probe at lane w would step beyond matchFindLimit: the block ends in literals
+                            M |= bits(c, w);
+                            blockDone = true;
+                            break;
+                        }
+                        M |= bits(c, w + 1);
+                        wl = w;
+                        cand = (int32_t)rl32((uint32_t)cp, w);
+                        jl = (int)rl32((uint32_t)j, w);
+                    }
+                    // ---- a match starts at lane wl against `cand` (lane jl of the window, or the table's entry of lane wl) ----
+                    input = base + wl;
+                    const bool winFast = jl >= 0 || rl32((uint32_t)fast, wl) != 0;
+                    const int shiftW = (int)rl32((uint32_t)shift, wl);
+                    const uint64_t rLoW = rl64(rLo, wl), rHiW = rl64(rHi, wl);
+                    int32_t back = 0;
+                    if (!zeroLit) {  // catch up :141-144
+                        int32_t room = input - anchor < cand ? input - anchor : cand;
+                        bool slow = !winFast;
+                        if (room > 0 && !slow) {
+                            // the 4 bytes before either position, last byte in the top bits
+                            uint32_t bi = 0, bc = 0;
+                            if (wl >= 4) {
+                                bi = rl32(x4, wl - 4);
+                            }
+                            else {
+                                slow = true;
+                            }
+                            if (jl >= 4) {
+                                bc = rl32(x4, jl - 4);
+                            }
+                            else if (jl >= 0) {
+                                slow = true;
+                            }
+                            else {
+                                bc = shiftW == 4 ? (uint32_t)rLoW : (uint32_t)((uint32_t)rLoW << (8 * (4 - shiftW)));  // (only `shift` = cand bytes exist before a candidate below 4: room stops there)
+                            }
+                            if (!slow) {
+                                const uint32_t d = bi ^ bc;
+                                const int32_t t = d == 0 ? 4 : (int32_t)(__builtin_clz(d) >> 3);
+                                back = t < room ? t : room;
+                                if (back == 4 && room > 4) {
+                                    slow = true;  // more than 4 bytes match backwards: the rest from memory
+                                }
+                            }
+                        }
+                        if (slow && room > 0) {
+                            int32_t i2 = input - back, m2 = cand - back, room2 = room - back;
+                            while (room2 > 0) {
+                                const bool eq = lane < room2 && in[i2 - 1 - lane] == in[m2 - 1 - lane];
+                                const unsigned long long ne = ~__ballot(eq);
+                                const int run = ne ? __builtin_ctzll(ne) : 64;
+                                i2 -= run;
+                                m2 -= run;
+                                room2 -= run;
+                                if (run < 64) {
+                                    break;
+                                }
+                            }
+                            back = input - i2;
+                        }
+                        input -= back;
+                        cand -= back;
+                    }
+                    // literals [anchor, input): bytes of this window (anchor >= base here), stored from the lanes' registers; token byte behind the match length
+                    int32_t literalLength = 0;
+                    int32_t tokenPos;
+                    if (zeroLit) {
+                        tokenPos = output++;  // zero-literal token :181-183
+                    }
+                    else {
+                        literalLength = input - anchor;
+                        tokenPos = output;
+                        const int32_t litPos = tokenPos + lz4_run_length_size(literalLength);
+                        if (pos >= anchor && pos < input) {
+                            out[litPos + (pos - anchor)] = (uint8_t)x4;
+                        }
+                        output = litPos + literalLength;
+                    }
+                    // count :240-267 from input + 4 against cand + 4: the first 8 bytes from registers
+                    int32_t matchLength;
+                    {
+                        const int32_t a0 = input + MIN_MATCH, b0 = cand + MIN_MATCH;
+                        const int32_t limitLen = matchLimit - a0;  // (>= 4: input <= matchFindLimit - 1)
+                        const int la = a0 - base;
+                        const int lb = b0 - base;
+                        // (a catch-up that went to memory may have moved both positions out of what the registers hold)
+                        const bool okA = la >= 0 && la < 64 && a0 + 8 <= inLen;
+                        const bool okB = jl >= 0 ? (lb >= 0 && lb < 64 && b0 + 8 <= inLen) : (winFast && back <= shiftW + 4);
+                        if (okA && okB) {
+                            const uint64_t a8 = rl64(x, la);
+                            const uint64_t b8 = jl >= 0 ? rl64(x, lb) : ext64(rLoW, rHiW, shiftW + 4 - back);
+                            const uint64_t d = a8 ^ b8;
+                            int32_t eq = d == 0 ? 8 : (int32_t)(__builtin_ctzll(d) >> 3);
+                            eq = eq < limitLen ? eq : limitLen;
+                            matchLength = eq;
+                            if (eq == 8 && limitLen > 8) {
+                                matchLength = 8 + wave_count(in, a0 + 8, b0 + 8, matchLimit, lane);
+                            }
+                        }
+                        else {
+                            matchLength = wave_count(in, a0, b0, matchLimit, lane);
+                        }
+                    }
+                    emit_match(tokenPos, literalLength, input - cand, matchLength);
+                    input += matchLength + MIN_MATCH;
+                    anchor = input;
+                    if (input > matchFindLimit) {  // :152-155
+                        blockDone = true;
+                        break;
+                    }
+                    const int rr = input - base;
+                    if (rr < 64) {
+                        M |= 1ull << (rr - 2);  // :157-159 the `input - 2` insert
+                        r = rr;
+                        continue;
+                    }
+                    break;  // the match ends beyond the window: the next one starts at input - 2
+                }
+                // the table takes the latest inserted lane of every hash
+                {
+                    const unsigned long long later = same & M & ~((2ull << lane) - 1ull);
+                    if (canLoad && ((M >> lane) & 1ull) != 0 && later == 0) {
+                        table[h] = (TableT)pos;
+                    }
+                }
+                __syncthreads();
+                if (blockDone) {
+                    break;
+                }
+                if (searchGoesOn) {
+                    mode = 2;
+                    scanStart = base + c;
+                    k0 = 64 - c;
+                    continue;
+                }
+                mode = 1;
+            }
+        }
+        {  // emitLastLiteral :269-280
+            const int32_t length = inputLimit - anchor;
+            if (lane == 0) {
+                lz4_write_run_length(out, output, length, 0);
+            }
+            output += lz4_run_length_size(length);
+            group_copy<64>(out + output, in + anchor, length, lane);
+            output += length;
+        }
+    }
+    stOut = st;
+    return output;
+}
+
+}  // namespace achip
