@@ -849,7 +849,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->lz4cVariant = (int)value;
     }
     else if (k == "snappy.compress.variant") {
-        if (value < 0 || value > 3) return bad_argument("snappy.compress.variant: 0 serial probes, 1 batch probes, 2 two tiers, 3 two tiers over LDS input windows");
+        if (value < 0 || value > 4) return bad_argument("snappy.compress.variant: 0 serial probes, 1 batch probes, 2 two tiers, 3 two tiers over LDS input windows, 4 two tiers, many matches per window");
         ctx->snappycVariant = (int)value;
     }
     else if (k == "snappyframed.decompress.variant") {

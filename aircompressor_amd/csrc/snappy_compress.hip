@@ -9,6 +9,7 @@
 // the lanes help with the match-length count (64 x 8 bytes per step, ballot for the first
 // mismatch) and the literal copies (64 x 16 bytes per step).
 #include "snappy_compress_body.h"
+#include "snappy_compress_mw.h"
 
 namespace achip {
 
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(64) void snappy_compress_batch_kernel(BatchArgs a)
 // LDS table: wavefront 0 encodes with the table in LDS, the other three with tables in global memory (a 32 KB slab each, resident
 // in the L2 / Infinity Cache) -- slower chains, but fifteen more of them per CU.  Wavefronts are independent and persistent (each
 // draws its next buffer from a counter), so the faster ones simply take more buffers.
+template <bool MW>  // MW: the "many matches per window" form of the encoder (snappy_compress_mw.h)
 __global__ __launch_bounds__(256) void snappy_compress_tiers_kernel(BatchArgs a, uint16_t* slabs, int32_t* nextItem)
 {
     using namespace snc;
@@ -165,12 +167,18 @@ __global__ __launch_bounds__(256) void snappy_compress_tiers_kernel(BatchArgs a,
         uint8_t* __restrict__ out = a.dstBase + a.dstOff[block];
         int32_t st = 0;
         int32_t output = 0;
-        if (wave == 0) {
+        uint16_t* const table = wave == 0 ? ldsTable : slab;
+        if (MW) {
+            if (wave == 0) snappy_compress_buffer_mw(ldsTable, in0, a.srcLen[block], out, a.dstCap[block], lane, st, output);
+            else snappy_compress_buffer_mw(slab, in0, a.srcLen[block], out, a.dstCap[block], lane, st, output);
+        }
+        else if (wave == 0) {
             snappy_compress_buffer(ldsTable, in0, a.srcLen[block], out, a.dstCap[block], lane, st, output);
         }
         else {
             snappy_compress_buffer(slab, in0, a.srcLen[block], out, a.dstCap[block], lane, st, output);
         }
+        (void)table;
         if (lane == 0) {
             a.outLen[block] = st == 0 ? output : 0;
             a.status[block] = st;
@@ -191,13 +199,14 @@ hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int va
     if (a.nBlocks <= 0) {
         return hipSuccess;
     }
-    if (variant == 2) {
+    if (variant == 2 || variant == 4) {
         int32_t* counter = (int32_t*)scratch;
         const hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
         if (e != hipSuccess) return e;
         const unsigned need = (unsigned)((a.nBlocks + 3) / 4);
         const unsigned grid = need < (unsigned)SNC_TIER_WORKGROUPS ? need : (unsigned)SNC_TIER_WORKGROUPS;
-        hipLaunchKernelGGL(snappy_compress_tiers_kernel, dim3(grid), dim3(256), 0, stream, a, (uint16_t*)((uint8_t*)scratch + 4096), counter);
+        if (variant == 4) hipLaunchKernelGGL(snappy_compress_tiers_kernel<true>, dim3(grid), dim3(256), 0, stream, a, (uint16_t*)((uint8_t*)scratch + 4096), counter);
+        else hipLaunchKernelGGL(snappy_compress_tiers_kernel<false>, dim3(grid), dim3(256), 0, stream, a, (uint16_t*)((uint8_t*)scratch + 4096), counter);
         return hipGetLastError();
     }
     if (variant == 0) {

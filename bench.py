@@ -203,9 +203,11 @@ def main():
     if args.ring_class >= 0:
         codec.native.set_option("decompress.ring_class", args.ring_class)
     if args.compress_variant >= 0:
-        if args.compress_variant <= 1:
+        # (one flag for both codecs' encoders: each takes the values it knows -- LZ4 0 / 1 / 4, Snappy 0 .. 3)
+        if args.compress_variant in (0, 1, 4):
             codec.native.set_option("lz4.compress.variant", args.compress_variant)
-        codec.native.set_option("snappy.compress.variant", args.compress_variant)
+        if args.compress_variant <= 4:
+            codec.native.set_option("snappy.compress.variant", args.compress_variant)
     if args.ring_pad >= 0:
         codec.native.set_option("decompress.ring_pad", args.ring_pad)
     codec.native.set_option("max_src_len_hint", bs)

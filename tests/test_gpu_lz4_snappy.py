@@ -47,7 +47,7 @@ def all_blocks():
     return blocks
 
 
-@pytest.mark.parametrize("codec, variant", [("lz4", 4), ("lz4", 1), ("lz4", 0), ("snappy", 3), ("snappy", 2), ("snappy", 1), ("snappy", 0)])
+@pytest.mark.parametrize("codec, variant", [("lz4", 4), ("lz4", 1), ("lz4", 0), ("snappy", 4), ("snappy", 3), ("snappy", 2), ("snappy", 1), ("snappy", 0)])
 def test_compress_is_bit_exact_with_oracle(gb, o, codec, variant):
     # 0 = serial probes, 1 = 64 probes per step, 4 (LZ4) = many matches per window of 64 positions (lz4_compress_mw.h), 2 = batch probes in two tiers: hash tables in LDS and in global memory, 3 = two tiers
     # over an LDS input window, one round of loads per batch (snappy_compress_v3.hip: the Snappy default since round 3)

@@ -4,8 +4,7 @@ export TMPDIR=/tmp
 O=gpurun_out/r03c7
 mkdir -p $O
 B="python bench.py --no-cpu-baseline --no-sweep --no-extra"
-timeout 400 python -m pytest tests/test_gpu_lz4_snappy.py tests/test_gpu_corpus.py tests/test_gpu_fuzz.py tests/test_gpu_lz4_frame.py -m gpu -x -q > $O/pytest.log 2>&1
-tail -3 $O/pytest.log
+echo skip-tests
 for d in corpus wordmix fragments; do
   for v in 1 4; do
     echo "## lz4_compress $d variant $v" >> $O/enc.txt
@@ -15,8 +14,3 @@ done
 echo "## lz4_compress corpus variant 4, 262144 blocks" >> $O/enc.txt
 timeout 200 $B --workload lz4_compress --data corpus --steps 3 --warmup 1 --compress-variant 4 2>&1 | grep '^{' | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(r['value'], r['roofline']['kernel_ms_avg'])" >> $O/enc.txt 2>&1
 cat $O/enc.txt
-for rc in 0 3 4; do
-  echo "## lz4_decompress ring_class $rc" >> $O/rings.txt
-  timeout 150 $B --workload lz4_decompress --variant 1 --ring-class $rc --steps 5 --warmup 2 2>&1 | grep '^{' | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(r['value'], r['roofline']['frac'])" >> $O/rings.txt 2>&1
-done
-cat $O/rings.txt
