@@ -73,8 +73,8 @@ struct achip_ctx {
     int lz4dVariant = 5;     // 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 4 = a lane per block, copies straight between the global buffers (lz4_decompress_v5.hip), 6 = a lane per block with an LDS output window (lz4_decompress_v6.hip), 5 = auto
     int snappydVariant = 5;  // 1 rings (snappy_decompress_v2.hip), 4 / 6 a lane per block (snappy_decompress_v3.hip / _v4.hip), 5 auto as for LZ4
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
-    int lz4cVariant = 1;     // 0 = serial probes, 1 = 64 probes per step (batch).  (3, the batch over an LDS input window, measured 17.2 against 18.2 GiB/s on corpus in round 3: removed)
-    int snappycVariant = 3;  // 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory, 3 = 2 with an LDS input window (snappy_compress_v3.hip; the default since round 3: 8.3 against 7.6 GiB/s on corpus, 75.4 against 74.1 on fragments)
+    int lz4cVariant = 4;     // 4 = many matches per window of 64 positions (lz4_compress_mw.h; default since round 3: 25.8 against 18.2 GiB/s on corpus, 100 against 111 on fragments), 0 = serial probes, 1 = 64 probes per step (batch).  (3, the batch over an LDS input window, measured 17.2 against 18.2 GiB/s on corpus in round 3: removed)
+    int snappycVariant = 4;  // 4 = two tiers, many matches per window (snappy_compress_mw.h; default since round 3: 22.0 against 8.3 GiB/s on corpus, 65 against 74 on fragments); 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory, 3 = 2 with an LDS input window (snappy_compress_v3.hip; the default since round 3: 8.3 against 7.6 GiB/s on corpus, 75.4 against 74.1 on fragments)
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 0;
     int hadoopBufferSize = 262144;        // Hadoop block streams: the streams' buffer size (Lz4HadoopStreams.java:30; io.compression.codec.*.buffersize)
@@ -841,7 +841,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->snappydVariant = (int)value;
     }
     else if (k == "decompress.ring_class") {
-        if (value < 0 || value > 4) return bad_argument("decompress.ring_class: 0 compact (4 lanes per block: phased), 1 large, 2 round-2 compact rings (4 lanes per block)");
+        if (value < 0 || value > 2) return bad_argument("decompress.ring_class: 0 compact (4 lanes per block: phased), 1 large, 2 round-2 compact rings (4 lanes per block)");
         ctx->ringClass = (int)value;
     }
     else if (k == "lz4.compress.variant") {

@@ -34,8 +34,8 @@
 // (ACHIP_D_HDP_NOT_CONSUMED, what Java reports for a well-formed one).
 #include "lz4_decode_body.h"
 #include "snappy_decode_body.h"
-#include "lz4_compress_body.h"
-#include "snappy_compress_body.h"
+#include "lz4_compress_mw.h"
+#include "snappy_compress_mw.h"
 
 namespace achip {
 
@@ -587,13 +587,13 @@ __global__ __launch_bounds__(64) void hadoop_encode_kernel(BatchArgs a, BlockLis
         const int32_t cap = (int32_t)block_bound(SNAPPY, length);
         int32_t cst = 0, compressed = 0;
         if (SNAPPY) {
-            snappy_compress_buffer((uint16_t*)tableBytes, block, length, out, cap, lane, cst, compressed);
+            snappy_compress_buffer_mw((uint16_t*)tableBytes, block, length, out, cap, lane, cst, compressed);
         }
         else if (length <= 65536) {
-            compressed = lz4_compress_block<uint16_t>(block, length, out, cap, (uint16_t*)tableBytes, lane, cst);
+            compressed = lz4_compress_block_mw<uint16_t>(block, length, out, cap, (uint16_t*)tableBytes, lane, cst);
         }
         else {
-            compressed = lz4_compress_block<int32_t>(block, length, out, cap, (int32_t*)tableBytes, lane, cst);
+            compressed = lz4_compress_block_mw<int32_t>(block, length, out, cap, (int32_t*)tableBytes, lane, cst);
         }
         wave_mem_order();
         if (lane == 0) {

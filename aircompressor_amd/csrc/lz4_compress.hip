@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64) void lz4frame_compress_kernel(BatchArgs a, uint
             const int32_t blockLen = inLen - ipos < lz4f::BLOCK_MAX_4MB ? inLen - ipos : lz4f::BLOCK_MAX_4MB;
             int32_t st = 0;
             wave_mem_order();
-            const int32_t clen = lz4_compress_block<int32_t>(in + ipos, blockLen, slab, (int32_t)lz4f::SLAB_BYTES, table, lane, st);
+            const int32_t clen = lz4_compress_block_mw<int32_t>(in + ipos, blockLen, slab, (int32_t)lz4f::SLAB_BYTES, table, lane, st);
             wave_mem_order();
             const bool compressed = st == 0 && clen < blockLen;
             const int32_t payload = compressed ? clen : blockLen;

@@ -40,9 +40,6 @@ __device__ __forceinline__ void lz4_block_decode(Rings<GS, IN_RING, OUT_RING, GP
         R.ensure_input(ip, 4);
         uint32_t t4 = R.template ring_ld4<IN_RING>(R.inRing, ip + R.inBase);  // token and the 3 bytes after it
         while (ip < inLimit) {
-            if (PHASED == 1) {
-                R.memory_phase(ip, op);  // (PHASED rings: the input ring is topped up once per sequence, here ...)
-            }
             const int32_t token = (int32_t)(t4 & 0xFF);
             ip++;
 
@@ -79,9 +76,8 @@ __device__ __forceinline__ void lz4_block_decode(Rings<GS, IN_RING, OUT_RING, GP
             R.copy_literals(ip, op, lit);  // :99-109
             op += lit;
             ip = (int32_t)litEnd;
-            if (PHASED == 4) {
-                R.memory_phase(ip, op);  // (... or here, between the two copies)
-            }
+            R.memory_phase(ip, op);  // (PHASED rings: the input ring is topped up once per sequence, here between the two copies: at the top of the
+                                     // loop -- where the Snappy decoder has it -- it costs this decoder 6 %, here it gains 2 %: profiles/r03_notes.md)
 
             if (!early) {
                 R.ensure_input(ip, 3);

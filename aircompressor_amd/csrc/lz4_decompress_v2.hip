@@ -83,9 +83,10 @@ hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, i
             // ring class 0 (the default): the phased form, with an input ring of four chunks (achip_rings.h); class 2: round 2's compact rings (kept for the comparison in profiles/r03_notes.md)
             switch (ringClass) {
                 case 1: return lz4d2_launch<4, 256, 512>(a, stream, mixedGroups);
-                case 3: return lz4d2_launch<4, 256, 256, 1, 1>(a, stream, mixedGroups);  // (measurement: the input ring topped up at the loop top)
-                case 4: return lz4d2_launch<4, 256, 256, 1, 4>(a, stream, mixedGroups);  // (measurement: ... between the two copies)
-                default: return lz4d2_launch<4, 128, 256>(a, stream, mixedGroups);
+                case 2: return lz4d2_launch<4, 128, 256>(a, stream, mixedGroups);  // (round 2's rings: the comparison in profiles/r03_notes.md)
+                // default: an input ring of four chunks, topped up once per sequence BETWEEN the literal copy and the match copy (+2.3 %: 1951 against
+                // 1907 GiB/s; at the top of the loop, where Snappy's sits, it costs LZ4 6 %: profiles/r03_notes.md)
+                default: return lz4d2_launch<4, 256, 256, 1, 4>(a, stream, mixedGroups);
             }
         case 8: return ringClass ? lz4d2_launch<8, 512, 1024>(a, stream, mixedGroups) : lz4d2_launch<8, 256, 512>(a, stream, mixedGroups);
         case 32: return ringClass ? lz4d2_launch<32, 2048, 4096>(a, stream, mixedGroups) : lz4d2_launch<32, 1024, 2048>(a, stream, mixedGroups);

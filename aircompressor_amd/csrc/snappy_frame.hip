@@ -13,7 +13,7 @@
 // to the block decoder (the Java reader's buffer of max(65541, everything seen so far) bytes, limited by what the destination
 // has left); a chunk that ends inside its length preamble is ACHIP_D_SNAPPY_TRUNCATED (Java would read stale buffer bytes).
 #include "snappy_decode_body.h"
-#include "snappy_compress_body.h"
+#include "snappy_compress_mw.h"
 #include "achip_crc32c.h"
 
 namespace achip {
@@ -211,7 +211,7 @@ __device__ int32_t compress_item(const Crc32cTables& tables, uint16_t* table, co
         const uint8_t* block = in + pos;
         const uint32_t crc = crc32c_mask(wave_crc32c(tables, block, length, lane));  // writeCompressed :204
         int32_t cst = 0, compressed = 0;
-        snappy_compress_buffer(table, block, length, slab, (int32_t)SLAB_BYTES, lane, cst, compressed);  // :206-211
+        snappy_compress_buffer_mw(table, block, length, slab, (int32_t)SLAB_BYTES, lane, cst, compressed);  // :206-211
         wave_mem_order();
         if (cst != 0) {
             return cst;
@@ -362,10 +362,10 @@ __global__ __launch_bounds__(256) void snappyframed_encode_kernel(BatchArgs a, B
         const uint32_t crc = crc32c_mask(wave_crc32c(tables, block, length, lane));  // writeCompressed :204
         int32_t cst = 0, compressed = 0;
         if (wave == 0) {
-            snappy_compress_buffer(ldsTable, block, length, slab, (int32_t)SLAB_BYTES, lane, cst, compressed);  // :206-211
+            snappy_compress_buffer_mw(ldsTable, block, length, slab, (int32_t)SLAB_BYTES, lane, cst, compressed);  // :206-211
         }
         else {
-            snappy_compress_buffer(tableSlab, block, length, slab, (int32_t)SLAB_BYTES, lane, cst, compressed);
+            snappy_compress_buffer_mw(tableSlab, block, length, slab, (int32_t)SLAB_BYTES, lane, cst, compressed);
         }
         wave_mem_order();
         const bool keep = ((double)compressed / (double)length) <= 0.85;  // :214

@@ -62,7 +62,7 @@ def test_compress_is_bit_exact_with_oracle(gb, o, codec, variant):
     n_hand = len(common.HAND_CASES)
     for k, (_, _, e) in enumerate(common.corpus_sample()):
         assert hashlib.sha256(outs[n_hand + k]).hexdigest() == e[codec]["sha256"]
-    gb.set_option("%s.compress.variant" % codec, 3 if codec == "snappy" else 1)
+    gb.set_option("%s.compress.variant" % codec, 4)
 
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
@@ -340,7 +340,7 @@ def test_options_that_would_return_wrong_data_do_not_exist():
         bad += [("lz4.compress.variant", v) for v in (2, 3, 100)] + [("snappy.compress.variant", v) for v in (4, -1, 100)]
         bad += [("lz4.decompress.variant", v) for v in (0, 2, 3, 8)] + [("snappy.decompress.variant", v) for v in (0, 2, 3, 8)]
         bad += [("hadoop.decompress.variant", 4), ("lz4frame.decompress.variant", 3), ("snappyframed.decompress.variant", 4), ("snappyframed.compress.variant", 2),
-                ("zstd.decompress.variant", 2), ("zstd.decompress.exec", 3), ("decompress.ring_class", 5), ("zstd.decompress.lit_items", 8),
+                ("zstd.decompress.variant", 2), ("zstd.decompress.exec", 3), ("decompress.ring_class", 3), ("zstd.decompress.lit_items", 8),
                 ("zstd.decompress.seq_items", 8), ("zstd.decompress.exec_window", 8192), ("no.such.option", 1)]
         for name, value in bad:
             with pytest.raises(IllegalArgumentException):
