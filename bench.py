@@ -371,13 +371,18 @@ def main():
             "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
         },
     }
+    # roofline.traffic: HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 passes: tools/make_traffic_json.py
+    # writes profiles/traffic.json with the hash of the kernel sources it measured).  Counters cannot be collected inside this process, so
+    # the figure is the committed measurement -- and only if it was taken on THESE kernel sources and this batch size; otherwise null.
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath)).get(wl)
-            if t and t.get("blocks") == n_local:
+            if t and t.get("blocks") == n_local and t.get("kernel_sources_sha256") == kernel_sources_hash():
                 result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                 result["roofline"]["traffic_source"] = t.get("source")
+            elif t:
+                result["roofline"]["traffic_source"] = "profiles/traffic.json is for other kernel sources or another batch size: not reported"
         except Exception:
             pass
 
@@ -417,6 +422,18 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_sources_hash():
+    """sha256 over the kernel sources (aircompressor_amd/csrc/*.hip, *.h, *.cpp): what profiles/traffic.json's measurement is tied to"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "aircompressor_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()
 
 
 DECODER_NAMES = {0: "rings", 1: "lane-per-block", 2: "lane-per-block with LDS window", 3: "two-pass (parse to records, a wavefront per block executes)"}
@@ -860,14 +877,20 @@ def cpu_baseline(torch, pool_pack, pool_pack_off, pool_clen, pool_plain, bs, op,
         src_len = np.full(n * reps, bs, dtype=np.int32)
         from tests import oracle_lib
         cap = int(oracle_lib.load().max_compressed_length(codec, bs))
-    r1, p1 = cpu_rate(op, src, src_off[:max(64, n // 16)], src_len[:max(64, n // 16)], cap, 1, seconds * 0.3)
-    rN, pN = cpu_rate(op, src, src_off, src_len, cap, T, seconds * 0.7)
+    r1, p1 = cpu_rate(op, src, src_off[:max(64, n // 16)], src_len[:max(64, n // 16)], cap, 1, seconds * 0.2)
+    # ONE number for north_star's ">= 4x aggregate over the CPU baseline at 8 GPUs": the 4096-block sample (256 MiB of plaintext per pass: 16
+    # blocks per thread on 256 threads, cache-resident -- the CPU at its best, the conservative bar; it is also the sample of every
+    # `extra` entry's CPU leg).  The >= 1 GiB sample, which on this host is bound by its memory system, is reported beside it.
+    k = min(4096, n * reps)
+    rC, pC = cpu_rate(op, src, src_off[:k], src_len[:k], cap, T, seconds * 0.4)
+    rN, pN = cpu_rate(op, src, src_off, src_len, cap, T, seconds * 0.4)
     return {
-        "value": round(rN, 3), "unit": "GiB/s", "cores": T, "kind": "port",
-        "value_1_thread": round(r1, 3),
-        "sample": "%d blocks of %d bytes per pass (the same %d distinct %s blocks, %s), %.1f passes per thread on %d pthreads for %.1f s; oracle/liboracle.so = "
-                  "C restatement of the Java codec (no JVM on the box), one codec state per thread, disjoint block ranges" % (
-                      n * reps, bs, n, codec.upper(), wl, pN, T, seconds * 0.7),
+        "value": round(rC, 3), "unit": "GiB/s", "cores": T, "kind": "port",
+        "value_1_thread": round(r1, 3), "value_1GiB_sample": round(rN, 3),
+        "criterion": "north_star's >= 4x at 8 GPUs is evaluated against `value` (the cache-resident 4096-block sample: the higher of the two CPU figures)",
+        "sample": "%d blocks of %d bytes per pass (%d distinct %s blocks, %s), %.1f passes per thread on %d pthreads for %.1f s; value_1GiB_sample: %d blocks per pass, %.1f passes; "
+                  "oracle/liboracle.so = C restatement of the Java codec (no JVM on the box; pinned against the transliterated reference sources, tests/test_ref_pin.py), "
+                  "one codec state per thread, disjoint block ranges" % (k, bs, n, codec.upper(), wl, pC, T, seconds * 0.4, n * reps, pN),
     }
 
 

@@ -147,7 +147,7 @@ def test_whole_decode_paths_on_the_cpu():
                     "-o", os.path.join(emu_dir, "libemu_all.so"), os.path.join(emu_dir, "emu_all.cpp")], check=True)
     r = subprocess.run([sys.executable, os.path.join(emu_dir, "check_serial.py"), "--all", "--quick"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "FAILED" not in r.stdout and r.stdout.strip().endswith("19 tests passed, 0 mismatches"), r.stdout
+    assert "FAILED" not in r.stdout and r.stdout.strip().endswith("23 tests passed, 0 mismatches"), r.stdout
 
 
 def test_encoders_and_writers_on_the_cpu():

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""make_traffic_json.py -- runs the two PMC passes of the headline workload (rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE: separate passes,
+with --kernel-trace only, as MI355X_MICROARCH.md prescribes) and writes profiles/traffic.json: HBM bytes per launch of the dominant kernel =
+FETCH_SIZE x 1024 x 2 (gfx950 counts half the bytes of wide coalesced reads: calibrated in profiles/r03_notes.md on a 4 GiB device copy, which
+also confirmed WRITE_SIZE x 1024 as exact) + WRITE_SIZE x 1024, together with the sha256 of the kernel sources it was taken on --
+bench.py only reports `roofline.traffic` when that hash is the tree's.  Run on the GPU box: python tools/make_traffic_json.py [out.json]"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "traffic.json")
+result = {}
+for wl in ("lz4_decompress",):
+    vals = {}
+    line = None
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(ROOT, "gpurun_out", "traffic_" + ctr)
+        shutil.rmtree(d, ignore_errors=True)
+        env = dict(os.environ, TMPDIR="/tmp")
+        p = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "--pmc", ctr, "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                            "--no-cpu-baseline", "--no-extra", "--steps", "3", "--warmup", "1", "--workload", wl], capture_output=True, text=True, cwd=ROOT, env=env)
+        for l in p.stdout.splitlines():
+            if l.startswith("{"):
+                line = json.loads(l)
+        acc = collections.defaultdict(list)
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") == ctr and "rings_kernel" in r["Kernel_Name"] and "true" not in r["Kernel_Name"].split("<")[1]:
+                    acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        best = max(acc.items(), key=lambda kv: sum(kv[1]))  # the decoder that ran (the others return at once)
+        v = best[1][1:] if len(best[1]) > 1 else best[1]
+        vals[ctr] = sum(v) / len(v) * 1024
+        vals["kernel"] = best[0][:90]
+        shutil.rmtree(d, ignore_errors=True)
+    fetch, write = vals["FETCH_SIZE"] * 2, vals["WRITE_SIZE"]
+    result[wl] = {
+        "blocks": line["config"]["blocks_per_gpu"], "hbm_bytes_per_launch": int(fetch + write), "fetch_bytes_x2": int(fetch), "write_bytes": int(write),
+        "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"], "kernel": vals["kernel"],
+        "kernel_sources_sha256": bench.kernel_sources_hash(),
+        "source": "tools/make_traffic_json.py: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --no-extra --steps 3`; FETCH_SIZE doubled (gfx950, "
+                  "calibrated: profiles/r03_notes.md), WRITE_SIZE as counted (calibrated exact)",
+    }
+json.dump(result, open(out, "w"), indent=1)
+print(json.dumps(result))
