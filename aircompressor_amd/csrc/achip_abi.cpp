@@ -284,7 +284,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
     }
     achip::BatchArgs a = args;
     a.ringPad = ctx->ringPad;
-    if (op == ACHIP_OP_ZSTD_COMPRESS) a.ringPad = ctx->zstdcVariant == 100 ? 999 : (ctx->zstdcVariant == 1 ? 1 : 0);  // (100: -DACHIP_DEV builds only)  // encoder variant rides in the spare field
+    if (op == ACHIP_OP_ZSTD_COMPRESS) a.ringPad = ctx->zstdcVariant == 100 ? 999 : (ctx->zstdcVariant == 1 ? 1 : (ctx->zstdcVariant == 3 ? 3 : 0));  // (100: -DACHIP_DEV builds only)  // encoder variant rides in the spare field
     if (a.nBlocks < 0) {
         return bad_argument("nBlocks < 0");
     }
@@ -896,11 +896,11 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     }
     else if (k == "zstd.compress.variant") {
         // (100, a timing aid whose output is not valid, exists in -DACHIP_DEV builds only: a shipped library has no option that returns wrong data)
-        bool ok = value >= 0 && value <= 2;
+        bool ok = value >= 0 && value <= 3;
 #ifdef ACHIP_DEV
         ok = ok || value == 100;
 #endif
-        if (!ok) return bad_argument("zstd.compress.variant: 0 match-finder kernel + entropy kernel, 1 the same with serial probes, 2 one kernel");
+        if (!ok) return bad_argument("zstd.compress.variant: 0 match-finder kernel + entropy kernel, 1 the same with serial probes, 3 with the window match finder, 2 one kernel");
         ctx->zstdcVariant = (int)value;
     }
     else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void zstd_match_kernel(BatchArgs a, uint8_t* ta
         c.sequenceCount = 0;
         c.longLengthField = 0;
         c.longLengthPosition = 0;
-        const int32_t lastLiteralsSize = dfast_compress_block(c, 0, c.inLen);
+        const int32_t lastLiteralsSize = match_finder(c, 0, c.inLen);
         wave_mem_order();
         group_copy<64>(c.litBuf + c.literalsLength, c.in + c.inLen - lastLiteralsSize, lastLiteralsSize, lane);
         c.literalsLength += lastLiteralsSize;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64) void zstd_compress_kernel(BatchArgs a, uint8_t*
         c.outCap = a.dstCap[block];
         c.lane = lane;
         c.dbgStage = a.ringPad == 999 ? 1 : 0;
-        c.batchProbe = a.ringPad == 1 ? 0 : 1;  // variant 1 = serial probing
+        c.batchProbe = a.ringPad == 1 ? 0 : (a.ringPad == 3 ? 2 : 1);  // variant 1 = serial probing, 3 = many matches per window
         c.failStatus = 0;
         c.pre = nullptr;
         uint8_t* p = slab;
@@ -196,7 +196,7 @@ int64_t zstd_compress_scratch_bytes(int32_t nBlocks)
 }
 
 // variant 0 (default): match-finder kernel + entropy kernel for one-block inputs, one kernel for the rest; 1: the same with
-// serial probing; 2: everything in the one kernel; 100: timing aid (one kernel, stop after the match finder)
+// serial probing; 3: the same with the window match finder (zstd_dfast_mw.h); 2: everything in the one kernel; 100: timing aid (one kernel, stop after the match finder)
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant)
 {
     (void)scratchBytes;
@@ -208,7 +208,7 @@ hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* sc
     uint8_t* slabs = base + 4096;
     uint8_t* tableSlabs = slabs + (int64_t)(a.nBlocks < ZC_MAX_WAVES ? a.nBlocks : ZC_MAX_WAVES) * zc::SLAB_BYTES;
     uint8_t* itemScratch = tableSlabs + (int64_t)(a.nBlocks < ZM_MAX_WAVES ? a.nBlocks : ZM_MAX_WAVES) * ZM_TABLE_BYTES;
-    const bool split = variant == 0 || variant == 1;
+    const bool split = variant == 0 || variant == 1 || variant == 3;
     const int32_t tile = split ? ZC_TILE : a.nBlocks;
     for (int32_t first = 0; first < a.nBlocks; first += tile) {
         const int32_t count = a.nBlocks - first < tile ? a.nBlocks - first : tile;
@@ -216,7 +216,7 @@ hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* sc
         if (e != hipSuccess) return e;
         if (split) {
             const unsigned mgrid = (unsigned)(count < ZM_MAX_WAVES ? count : ZM_MAX_WAVES);
-            hipLaunchKernelGGL(zstd_match_kernel, dim3(mgrid), dim3(64), 0, stream, a, tableSlabs, itemScratch, first, count, counter, variant == 1 ? 0 : 1);
+            hipLaunchKernelGGL(zstd_match_kernel, dim3(mgrid), dim3(64), 0, stream, a, tableSlabs, itemScratch, first, count, counter, variant == 1 ? 0 : (variant == 3 ? 2 : 1));
         }
         const unsigned grid = (unsigned)(count < ZC_MAX_WAVES ? count : ZC_MAX_WAVES);
         hipLaunchKernelGGL(zstd_compress_kernel, dim3(grid), dim3(64), 0, stream, a, slabs, counter + 8, split ? itemScratch : (uint8_t*)nullptr, first, count);

@@ -1480,6 +1480,13 @@ __device__ int32_t dfast_compress_block(Ctx& c, int32_t inputAddress, int32_t in
     return inputEnd - anchor;
 }
 
+#include "zstd_dfast_mw.h"  // dfast_compress_block_mw (c.batchProbe == 2)
+
+__device__ __forceinline__ int32_t match_finder(Ctx& c, int32_t inputAddress, int32_t inputSize)
+{
+    return c.batchProbe == 2 ? dfast_compress_block_mw(c, inputAddress, inputSize) : dfast_compress_block(c, inputAddress, inputSize);
+}
+
 // ---- blocks and frame: ZstdFrameCompressor :136-260 --------------------------------------------------------------
 __device__ int32_t compress_block(Ctx& c, Shared& sh, int32_t inputAddress, int32_t inputSize, int32_t outputAddress, int32_t outputSize)
 {
@@ -1502,7 +1509,7 @@ __device__ int32_t compress_block(Ctx& c, Shared& sh, int32_t inputAddress, int3
         c.tempOffset1 = c.pre[6];
     }
     else {
-        const int32_t lastLiteralsSize = dfast_compress_block(c, inputAddress, inputSize);
+        const int32_t lastLiteralsSize = match_finder(c, inputAddress, inputSize);
         if (c.dbgStage == 1) {
             return 0;  // DEBUG (timing split only): stop after the match finder
         }

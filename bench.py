@@ -60,6 +60,7 @@ def parse_args():
     p.add_argument("--snappyframed-variant", type=int, default=-1, help="x-snappy-framed reader: 3 = ring or two-pass decoder by a probe (default), 1 = chunks through the ring decoders, 2 = through the two-pass decoder, 0 = a wavefront per stream")
     p.add_argument("--lz4frame-variant", type=int, default=-1, help="LZ4 frame reader: 2 = by a probe (default), 0 = a wavefront per item, 1 = the frames' blocks as one batch through the two-pass block decoder")
     p.add_argument("--hadoop-variant", type=int, default=-1, help="Hadoop block-stream reader: 3 = ring or two-pass decoders by a probe (default), 1 = chunks through the ring decoders, 2 = through the two-pass decoders, 0 = a wavefront per stream")
+    p.add_argument("--zstd-compress-variant", type=int, default=-1, help="zstd encoder: 0 match kernel (batch probes) + entropy kernel, 3 match kernel (many matches per window) + entropy kernel, 1 serial probes, 2 one kernel")
     p.add_argument("--zstd-variant", type=int, default=-1, help="zstd decoder: 1 = five-stage pipeline (default), 0 = one-kernel decoder")
     return p.parse_args()
 
@@ -446,12 +447,12 @@ def kernel_symbol(wl, decoder):
     if wl == "lz4_decompress":
         if decoder.endswith("LDS window"):
             return "achip::lz4_decompress_lanewindow_kernel<16, 64>"
-        return "achip::lz4_decompress_lanecopy_kernel<16, false>" if decoder.startswith("lane") else "achip::lz4_decompress_rings_kernel<4, 128, 256, 1, false>"
+        return "achip::lz4_decompress_lanecopy_kernel<16, false>" if decoder.startswith("lane") else "achip::lz4_decompress_rings_kernel<4, 256, 256, 1, false, 4>"
     if wl == "snappy_decompress":
         if decoder.endswith("LDS window"):
             return "achip::snappy_decompress_lanewindow_kernel<16, 64>"
-        return "achip::snappy_decompress_lanecopy_kernel<16>" if decoder.startswith("lane") else "achip::snappy_decompress_rings_kernel<4, 128, 256, 1, false>"
-    return "achip::lz4_compress_batch_kernel<unsigned short>" if wl == "lz4_compress" else "achip::snappy_compress_tiers_kernel"
+        return "achip::snappy_decompress_lanecopy_kernel<16>" if decoder.startswith("lane") else "achip::snappy_decompress_rings_kernel<4, 256, 256, 1, false, 1>"
+    return "achip::lz4_compress_mw_kernel<unsigned short>" if wl == "lz4_compress" else "achip::snappy_compress_tiers_kernel<true>"
 
 
 def run_pair(torch, codec, args, name, cop, dop, plain, n, bs, cpu_seconds):
@@ -631,6 +632,8 @@ def zstd_extra(torch, A, codec, dev, args):
         codec.native.set_option("zstd.decompress.variant", args.zstd_variant)
     if args.zstd_exec >= 0:
         codec.native.set_option("zstd.decompress.exec", args.zstd_exec)
+    if args.zstd_compress_variant >= 0:
+        codec.native.set_option("zstd.compress.variant", args.zstd_compress_variant)
     zc = pa.Codec("zstd", compression_level=3)
     for data_kind in ("fragments", "wordmix", "corpus"):
         plain = gen_data(torch, dev, data_kind, pool_n, fs, args.ratio, 4242)

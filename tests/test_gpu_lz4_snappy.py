@@ -336,8 +336,8 @@ def test_options_that_would_return_wrong_data_do_not_exist():
     nat = A.HipNative(0)
     try:
         bad = [("decompress.exec_variant", v) for v in (121, 122, 123, 124, 125, 201, 302, 304, 308, 0, 1, 3)]
-        bad += [("zstd.compress.variant", v) for v in (100, 3, -1)]
-        bad += [("lz4.compress.variant", v) for v in (2, 3, 100)] + [("snappy.compress.variant", v) for v in (4, -1, 100)]
+        bad += [("zstd.compress.variant", v) for v in (100, 4, -1)]
+        bad += [("lz4.compress.variant", v) for v in (2, 3, 100)] + [("snappy.compress.variant", v) for v in (5, -1, 100)]
         bad += [("lz4.decompress.variant", v) for v in (0, 2, 3, 8)] + [("snappy.decompress.variant", v) for v in (0, 2, 3, 8)]
         bad += [("hadoop.decompress.variant", 4), ("lz4frame.decompress.variant", 3), ("snappyframed.decompress.variant", 4), ("snappyframed.compress.variant", 2),
                 ("zstd.decompress.variant", 2), ("zstd.decompress.exec", 3), ("decompress.ring_class", 3), ("zstd.decompress.lit_items", 8),

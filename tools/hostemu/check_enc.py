@@ -90,7 +90,7 @@ def part_zstd():
         blocks.append((sample[0] + sample[1] + sample[2])[:140000])  # two blocks: tables, repeat offsets, Huffman reuse carried over
         blocks.append(b"".join(sample[:5])[:270000])                  # beyond 256 KiB: the default parameter row
     caps = [o.max_compressed_length("zstd", len(b)) for b in blocks]
-    for v in ((0, 1) if quick else (0, 1, 2)):  # (0: match kernel + entropy kernel, the default; 1: the same with serial probes; 2: one kernel)
+    for v in ((3, 0, 1) if quick else (3, 0, 1, 2)):  # (3: match kernel with the window match finder + entropy kernel; 0: batch probes; 1: serial probes; 2: one kernel)
         bad += compare("zstd compress, variant %d" % v, 5, v, blocks, caps, lambda b, c: o.compress("zstd", b, c))
     some = blocks[2:8]
     tight = [max(len(o.compress("zstd", b)) - 3 * k, 0) for k, b in enumerate(some)]

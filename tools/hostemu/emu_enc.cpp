@@ -29,6 +29,7 @@ extern "C" int emu_encode(int op, const uint8_t* srcBase, const int64_t* srcOff,
         return option == 3 ? achip::launch_snappy_compress_window(a, nullptr, scratch.data()) : achip::launch_snappy_compress(a, nullptr, option, scratch.data());
     }
     if (op == 5 || op == 14) {
+        if (op == 5) a.ringPad = option == 1 ? 1 : (option == 3 ? 3 : 0);  // (what achip_abi.cpp does: the one-kernel path reads the variant from the spare field)
         scratch.assign((size_t)achip::zstd_compress_scratch_bytes(n), 0xCD);
         return op == 5 ? achip::launch_zstd_compress(a, nullptr, scratch.data(), (int64_t)scratch.size(), option) : achip::launch_zstd_stream_compress(a, nullptr, scratch.data(), option);
     }

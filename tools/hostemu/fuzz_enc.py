@@ -1,4 +1,4 @@
-"""Differential fuzz of an ENCODER variant on the CPU emulator (libemu_enc.so) against the oracle:  fuzz_enc.py <seed> <count> [lz4|snappy] [variant]
+"""Differential fuzz of an ENCODER variant on the CPU emulator (libemu_enc.so) against the oracle:  fuzz_enc.py <seed> <count> [lz4|snappy|zstd] [variant]
 Structured inputs -- short and long incompressible stretches (the skip schedule grows, batches leave the LDS window and come back), near and
 far copies of 4..1500 bytes, byte runs, small alphabets -- of 13 bytes to 40 KB, plus, for seed 0, the sizes around the window's chunk
 boundaries and around 64 KiB (Snappy sub-blocks, LZ4's wide table)."""
@@ -14,7 +14,7 @@ class EncBatch(EmuBatch):
     def __init__(self, option): self.lib = lib; self.options = {}; self.option = option
     def _call(self, op, src, src_off, src_len, dst, dst_off, caps, out_len, status, err, n):
         return self.lib.emu_encode(op, P(src), P(src_off), P(src_len), P(dst), P(dst_off), P(caps), P(out_len), P(status), P(err), n, self.option, 262144)
-seed = int(sys.argv[1]); count = int(sys.argv[2]); codec = sys.argv[3] if len(sys.argv) > 3 else "lz4"; opnum = 1 if codec == "lz4" else 3; variant = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+seed = int(sys.argv[1]); count = int(sys.argv[2]); codec = sys.argv[3] if len(sys.argv) > 3 else "lz4"; opnum = {"lz4": 1, "snappy": 3, "zstd": 5}[codec]; variant = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 rng = np.random.default_rng(seed)
 def gen(n):
     out = bytearray()
