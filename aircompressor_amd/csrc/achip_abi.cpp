@@ -76,7 +76,7 @@ struct achip_ctx {
     int lz4cVariant = 4;     // 4 = many matches per window of 64 positions (lz4_compress_mw.h; default since round 3: 25.8 against 18.2 GiB/s on corpus, 100 against 111 on fragments), 0 = serial probes, 1 = 64 probes per step (batch).  (3, the batch over an LDS input window, measured 17.2 against 18.2 GiB/s on corpus in round 3: removed)
     int snappycVariant = 4;  // 4 = two tiers, many matches per window (snappy_compress_mw.h; default since round 3: 22.0 against 8.3 GiB/s on corpus, 65 against 74 on fragments); 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory, 3 = 2 with an LDS input window (snappy_compress_v3.hip; the default since round 3: 8.3 against 7.6 GiB/s on corpus, 75.4 against 74.1 on fragments)
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
-    int zstdcVariant = 0;
+    int zstdcVariant = 3;  // match kernel in window form (zstd_dfast_mw.h) + entropy kernel
     int hadoopBufferSize = 262144;        // Hadoop block streams: the streams' buffer size (Lz4HadoopStreams.java:30; io.compression.codec.*.buffersize)
     int lz4FrameDecompressVariant = 2;    // 2 = chosen per call by a probe of the sequence lengths (default: 75 / 13.4 GiB/s on fragments / corpus frames); 0 = a wavefront per item (75 / 7.8); 1 = the frames' blocks as one batch through the two-pass block decoder (22 / 13.4)
     int hadoopDecompressVariant = 3;      // 3 = chunk list, the block decoder chosen per call by a probe of the sequence lengths (default); 1 = always the rings; 2 = always the two-pass decoders; 0 = one wavefront per stream (profiles/r03_notes.md)
@@ -900,7 +900,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
 #ifdef ACHIP_DEV
         ok = ok || value == 100;
 #endif
-        if (!ok) return bad_argument("zstd.compress.variant: 0 match-finder kernel + entropy kernel, 1 the same with serial probes, 3 with the window match finder, 2 one kernel");
+        if (!ok) return bad_argument("zstd.compress.variant: 3 match-finder kernel (many matches per window) + entropy kernel, 0 the same with batch probes, 1 with serial probes, 2 one kernel");
         ctx->zstdcVariant = (int)value;
     }
     else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;

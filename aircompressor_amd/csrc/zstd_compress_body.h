@@ -166,6 +166,30 @@ __device__ __forceinline__ void bo_flush(BitOut& s)  // :67-80
     s.bitCount &= 7;
     s.container >>= ((bytes * 8) & 63);
 }
+// flush() as the Java code does it -- 8 bytes, of which bitCount / 8 are final -- for a stream whose buffer this wavefront (or lane) owns up
+// to `safeEnd`: what lies behind the final bytes is this stream's own and is rewritten by its next flush.  Close to safeEnd: exact bytes.
+__device__ __forceinline__ void bo_flush_wide(BitOut& s, int32_t safeEnd)
+{
+    const int32_t bytes = (int32_t)((uint32_t)s.bitCount >> 3);
+    if (s.current + 8 <= safeEnd && s.current <= s.limit) {
+        st8(s.base + s.current, s.container);
+    }
+    else {
+        int32_t n = bytes;
+        if (s.current + n > s.limit + 8) {
+            n = s.limit + 8 - s.current;
+        }
+        if (n > 0) {
+            st_le(s.base + s.current, s.container, n);
+        }
+    }
+    s.current += bytes;
+    if (s.current > s.limit) {
+        s.current = s.limit;
+    }
+    s.bitCount &= 7;
+    s.container >>= ((bytes * 8) & 63);
+}
 __device__ __forceinline__ int32_t bo_close(BitOut& s)  // :82-92
 {
     bo_add_fast(s, 1, 1);
@@ -880,32 +904,53 @@ __device__ int32_t wave_code_bits(const HufCTable& t, const uint8_t* in, int32_t
     return bits;
 }
 
-// HuffmanCompressor.compressSingleStream :88-134 executed by ONE lane (the others idle in this call)
-__device__ int32_t huf_encode_stream(const HufCTable& t, uint8_t* base, int32_t outputAddress, int32_t outputSize, const uint8_t* in, int32_t inputSize)
+// HuffmanCompressor.compressSingleStream :88-134 executed by ONE lane (the others idle in this call).  The literals come 16 bytes per load,
+// the next load requested before the current 16 symbols are encoded (one lane encoding from memory 4 bytes at a time waited a memory
+// latency per 4 symbols: ~3 ms per 128 KiB frame); the flushes store 8 bytes where that stays inside this stream (`streamBytes`, its exact
+// size, computed beforehand: the next stream begins right behind it and is written by another lane at the same time).
+__device__ int32_t huf_encode_stream(const HufCTable& t, uint8_t* base, int32_t outputAddress, int32_t outputSize, const uint8_t* in, int32_t inputSize, int32_t streamBytes)
 {
     if (outputSize < 8) {
         return 0;
     }
     BitOut bs;
     bo_init(bs, base, outputAddress, outputSize);
+    const int32_t safeEnd = outputAddress + streamBytes;
     int32_t n = inputSize & ~3;
 #define ZC_ENC(sym) bo_add_fast(bs, t.values[(sym)], t.numberOfBits[(sym)])
+#define ZC_ENC4(w)            \
+    ZC_ENC((w) >> 24);          \
+    ZC_ENC(((w) >> 16) & 0xFF); \
+    ZC_ENC(((w) >> 8) & 0xFF);  \
+    ZC_ENC((w) & 0xFF);         \
+    bo_flush_wide(bs, safeEnd);
     switch (inputSize & 3) {
         case 3: ZC_ENC(in[n + 2]);  // fallthrough
         case 2: ZC_ENC(in[n + 1]);  // fallthrough
         case 1:
             ZC_ENC(in[n + 0]);
-            bo_flush(bs);  // fallthrough
+            bo_flush_wide(bs, safeEnd);  // fallthrough
         default: break;
+    }
+    if (n >= 16) {
+        u32x4 next = ld16(in + n - 16);
+        while (n >= 16) {
+            const u32x4 w = next;
+            n -= 16;
+            if (n >= 16) {
+                next = ld16(in + n - 16);
+            }
+            ZC_ENC4(w.w);
+            ZC_ENC4(w.z);
+            ZC_ENC4(w.y);
+            ZC_ENC4(w.x);
+        }
     }
     for (; n > 0; n -= 4) {
         const uint32_t w = ld4(in + n - 4);
-        ZC_ENC(w >> 24);
-        ZC_ENC((w >> 16) & 0xFF);
-        ZC_ENC((w >> 8) & 0xFF);
-        ZC_ENC(w & 0xFF);
-        bo_flush(bs);
+        ZC_ENC4(w);
     }
+#undef ZC_ENC4
 #undef ZC_ENC
     return bo_close(bs);
 }
@@ -1013,7 +1058,7 @@ __device__ int32_t encode_literals(Ctx& c, Shared& sh, uint8_t* base, int32_t ou
         const int32_t bits = wave_code_bits(*table, literals, literalsSize, c.lane);
         compressedSize = huf_stream_size(bits, streamsSize);
         if (compressedSize != 0 && c.lane == 0) {
-            huf_encode_stream(*table, base, streamsAddress, streamsSize, literals, literalsSize);
+            huf_encode_stream(*table, base, streamsAddress, streamsSize, literals, literalsSize, compressedSize);
         }
     }
     else {  // compress4streams :26-86
@@ -1038,7 +1083,7 @@ __device__ int32_t encode_literals(Ctx& c, Shared& sh, uint8_t* base, int32_t ou
             }
             if (ok) {
                 if (c.lane < 4) {
-                    int32_t mStart = 0, mLen = 0, mOut = 0, mAvail = 0;
+                    int32_t mStart = 0, mLen = 0, mOut = 0, mAvail = 0, mBytes = 0;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         if (c.lane == k) {
@@ -1046,9 +1091,10 @@ __device__ int32_t encode_literals(Ctx& c, Shared& sh, uint8_t* base, int32_t ou
                             mLen = segLen[k];
                             mOut = outStart[k];
                             mAvail = outAvail[k];
+                            mBytes = segBytes[k];
                         }
                     }
-                    huf_encode_stream(*table, base, mOut, mAvail, literals + mStart, mLen);
+                    huf_encode_stream(*table, base, mOut, mAvail, literals + mStart, mLen, mBytes);
                 }
                 st2(base + streamsAddress, (uint32_t)segBytes[0]);
                 st2(base + streamsAddress + 2, (uint32_t)segBytes[1]);
@@ -1218,29 +1264,62 @@ __device__ int32_t compress_sequences(Ctx& c, Shared& sh, uint8_t* base, int32_t
     bo_add(bs, c.seqMatchLen[n], ML_BITS[c.codeML[n]]);
     bo_add(bs, c.seqOffset[n], c.codeOF[n]);
     bo_flush(bs);
-    for (n = sequenceCount - 2; n >= 0; n--) {
-        const int32_t llCode = c.codeLL[n];
-        const int32_t ofCode = c.codeOF[n];
-        const int32_t mlCode = c.codeML[n];
-        const int32_t llBits = LL_BITS[llCode];
-        const int32_t ofBits = ofCode;
-        const int32_t mlBits = ML_BITS[mlCode];
-        ofState = fse_encode(*ofTable, bs, ofState, ofCode);
-        mlState = fse_encode(*mlTable, bs, mlState, mlCode);
-        llState = fse_encode(*llTable, bs, llState, llCode);
-        if (ofBits + mlBits + llBits >= 64 - 7 - (9 + 9 + 8)) {
-            bo_flush(bs);
+    // The sequences 64 at a time: lane l fetches sequence top - l -- its codes, its three values, the bit counts of its codes and, from the
+    // three tables, the two per-symbol deltas of each code (none of which depends on the states) -- and the serial loop reads lanes.  With
+    // its loads inside, the loop waited a memory latency per sequence: two thirds of the entropy kernel's time on text.
+    const int32_t seqEnd = outputLimit;  // (the stream's buffer reaches to the end of the block's room: wide flushes stay inside it)
+    for (int32_t top = sequenceCount - 2; top >= 0; top -= 64) {
+        const int32_t mine = top - c.lane;
+        int32_t vLL = 0, vML = 0, vOF = 0, bLL = 0, bML = 0, bOF = 0, nLL = 0, fLL = 0, nML = 0, fML = 0, nOF = 0, fOF = 0;
+        if (mine >= 0) {
+            const int32_t llCode = c.codeLL[mine];
+            const int32_t ofCode = c.codeOF[mine];
+            const int32_t mlCode = c.codeML[mine];
+            vLL = c.seqLitLen[mine];
+            vML = c.seqMatchLen[mine];
+            vOF = c.seqOffset[mine];
+            bLL = LL_BITS[llCode];
+            bML = ML_BITS[mlCode];
+            bOF = ofCode;
+            nLL = llTable->deltaNumberOfBits[llCode];
+            fLL = llTable->deltaFindState[llCode];
+            nML = mlTable->deltaNumberOfBits[mlCode];
+            fML = mlTable->deltaFindState[mlCode];
+            nOF = ofTable->deltaNumberOfBits[ofCode];
+            fOF = ofTable->deltaFindState[ofCode];
         }
-        bo_add(bs, c.seqLitLen[n], llBits);
-        if (llBits + mlBits > 24) {
-            bo_flush(bs);
+        const int count = top + 1 < 64 ? top + 1 : 64;
+        for (int k = 0; k < count; k++) {
+#define ZC_RL(v) __builtin_amdgcn_readlane((v), k)
+            const int32_t llBits = ZC_RL(bLL);
+            const int32_t ofBits = ZC_RL(bOF);
+            const int32_t mlBits = ZC_RL(bML);
+            {  // fse_encode :126-131 x 3
+                const int32_t ob = (int32_t)((uint32_t)(ofState + ZC_RL(nOF)) >> 16);
+                bo_add(bs, ofState, ob);
+                ofState = ofTable->nextState[(int32_t)((uint32_t)ofState >> (ob & 31)) + ZC_RL(fOF)];
+                const int32_t mb = (int32_t)((uint32_t)(mlState + ZC_RL(nML)) >> 16);
+                bo_add(bs, mlState, mb);
+                mlState = mlTable->nextState[(int32_t)((uint32_t)mlState >> (mb & 31)) + ZC_RL(fML)];
+                const int32_t lb = (int32_t)((uint32_t)(llState + ZC_RL(nLL)) >> 16);
+                bo_add(bs, llState, lb);
+                llState = llTable->nextState[(int32_t)((uint32_t)llState >> (lb & 31)) + ZC_RL(fLL)];
+            }
+            if (ofBits + mlBits + llBits >= 64 - 7 - (9 + 9 + 8)) {
+                bo_flush_wide(bs, seqEnd);
+            }
+            bo_add(bs, ZC_RL(vLL), llBits);
+            if (llBits + mlBits > 24) {
+                bo_flush_wide(bs, seqEnd);
+            }
+            bo_add(bs, ZC_RL(vML), mlBits);
+            if (ofBits + mlBits + llBits > 56) {
+                bo_flush_wide(bs, seqEnd);
+            }
+            bo_add(bs, ZC_RL(vOF), ofBits);
+            bo_flush_wide(bs, seqEnd);
+#undef ZC_RL
         }
-        bo_add(bs, c.seqMatchLen[n], mlBits);
-        if (ofBits + mlBits + llBits > 56) {
-            bo_flush(bs);
-        }
-        bo_add(bs, c.seqOffset[n], ofBits);
-        bo_flush(bs);
     }
     fse_finish(*mlTable, bs, mlState);
     fse_finish(*ofTable, bs, ofState);

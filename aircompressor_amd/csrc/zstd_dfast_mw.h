@@ -23,6 +23,16 @@
 // :150); longer literal runs (incompressible data) take the serial step below, which is the Java loop as it stands.
 #pragma once
 
+#ifdef ACHIP_HOST_STATS  // (CPU emulator only: how often each part of the replay runs -- tools/hostemu/zc_stats.py)
+extern "C" long long g_zc_stats[32];
+// (out of line and not instrumented: under the emulator's access-granular lockstep every traced access is an order point of ALL lanes)
+static __attribute__((noinline, no_sanitize("coverage"))) void zc_stat_add(int i, long long n) { g_zc_stats[i] += n; }
+#define ZC_STAT(i, n) \
+    if (lane == 0) zc_stat_add((i), (n))
+#else
+#define ZC_STAT(i, n)
+#endif
+
 namespace dmw {
 __device__ __forceinline__ uint32_t rl32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 __device__ __forceinline__ uint64_t rl64(uint64_t v, int src) { return ((uint64_t)rl32((uint32_t)(v >> 32), src) << 32) | rl32((uint32_t)v, src); }
@@ -132,13 +142,13 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
                 input += repetitionLength;
                 anchor = input;
             }
-            wave_mem_order();
         }
         litStored = anchor;
     };
 
     while (input < inputLimit) {
         if (input - anchor >= 192) {
+            ZC_STAT(14, 1);
             // ---- the serial step: the Java loop as it stands (long literal runs: the probes skip ahead) ----
             const uint64_t here = ld8(in + input);
             const int32_t shortHash = hash_s(here);
@@ -199,7 +209,6 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
                     }
                 }
                 else {
-                    wave_mem_order();
                     input += ((input - anchor) >> 8) + 1;
                     continue;
                 }
@@ -209,11 +218,11 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
             }
             input += matchLength;
             anchor = input;
-            wave_mem_order();
             after_match_serial(current, true);
             continue;
         }
 
+        ZC_STAT(0, 1);
         // ---- a window: the 64 positions from `input`; lanes 0 .. nact - 1 may be probed, lane 63 only lends its bytes ----
         const int32_t base = input;
         if (litStored < base) {  // (only at the start of a block, whose first position is never probed: :52-54)
@@ -301,6 +310,7 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
                 eq += n;
             }
             if (!mismatch) {
+                ZC_STAT(11, 1);
                 eq += wave_count(in, aPos + eq, bPos + eq, inputEnd, lane);
             }
             return eq;
@@ -311,6 +321,7 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
             const unsigned long long Eo = __ballot(ld && lane >= o && ((prev ^ x4) & 0xFFu) == 0);
             int32_t eq = run_from(Eo, k, nld);
             if (k + eq >= nld) {
+                ZC_STAT(12, 1);
                 eq += wave_count(in, base + k + eq, base + k + eq - o, inputEnd, lane);
             }
             return eq;
@@ -320,12 +331,14 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
             const unsigned long long E = __ballot((d & 0xFFu) == 0);
             int32_t eq = run_from(E, k, nld);
             if (k + eq >= nld) {
+                ZC_STAT(13, 1);
                 eq += wave_count(in, base + k + eq + 1, base + k + eq + 1 - offset, inputEnd, lane);
             }
             return eq;
         };
 
         while (cs < nact) {
+            ZC_STAT(1, 1);
             // ---- the search :57-150 over lanes cs .. nact - 1 at once: a lane sees the replay's inserts and those of the search lanes before it ----
             const unsigned long long below = bits(0, lane);
             const unsigned long long assumed = bits(cs, lane);
@@ -343,6 +356,7 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
             const bool probing = lane >= cs && lane < nact;
             const unsigned long long hm = __ballot(probing && (repH || longH || shortH));
             if (hm == 0) {
+                ZC_STAT(15, 1);
                 ML |= bits(cs, nact);
                 MS |= bits(cs, nact);
                 cs = nact;
@@ -357,7 +371,9 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
             const int32_t current = base + w;
             int32_t matchLength;
             int32_t offset = 0;
+            ZC_STAT(2, 1);
             if ((fw & 1u) != 0) {
+                ZC_STAT(3, 1);
                 // repeat offset at current + 1 :71-80
                 matchLength = 4 + count_repeat(d1, offset1, w + 4);
                 input = current + 1;
@@ -385,7 +401,9 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
                 const int minLen = isLong ? 8 : 4;
                 uint64_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
                 int shW = 0;
+                ZC_STAT(isLong ? 4 : 5, 1);
                 if (jc >= 0) {
+                    ZC_STAT(6, 1);
                     matchLength = minLen + count_window(m - jc, m + minLen);
                 }
                 else if (isLong) {
@@ -434,7 +452,9 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
                     }
                     back++;
                 }
+                ZC_STAT(7, back);
                 if (fromMemory) {
+                    ZC_STAT(8, 1);
                     while (input - back > anchor && cand - back > windowBase && in[input - back - 1] == in[cand - back - 1]) {
                         back++;
                     }
@@ -460,6 +480,7 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
             litStored = anchor;
             if (input <= inputLimit) {
                 if (input - base > 62) {
+                    ZC_STAT(9, 1);
                     post = 1;
                     postCurrent = current;
                     break;
@@ -473,6 +494,7 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
                     if (rl32(d2, q) != 0) {
                         break;
                     }
+                    ZC_STAT(10, 1);
                     const int32_t repetitionLength = 4 + count_repeat(d2, offset2, q + 4);
                     const int32_t to = offset2;
                     offset2 = offset1;

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64) void zstd_stream_kernel(BatchArgs a, uint8_t* s
         c.outCap = a.dstCap[block];
         c.lane = lane;
         c.dbgStage = 0;
-        c.batchProbe = 1;
+        c.batchProbe = 2;  // the window match finder (zstd_dfast_mw.h)
         c.failStatus = 0;
         c.pre = nullptr;
         uint8_t* p = slab;

@@ -309,7 +309,7 @@ def encoder_inputs():
     return blocks
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2], ids=["two-kernel", "two-kernel-serial-probe", "one-kernel"])
+@pytest.mark.parametrize("variant", [3, 0, 1, 2], ids=["two-kernel-window-match-finder", "two-kernel-batch-probe", "two-kernel-serial-probe", "one-kernel"])
 def test_zstd_compress_is_bit_exact_with_oracle(gb, o, variant):
     blocks = encoder_inputs()
     blocks += [b for b in common.synthetic_blocks(77, 12)]   # RandomGenerator-style data: long literal runs, many same-hash positions per batch
@@ -318,7 +318,7 @@ def test_zstd_compress_is_bit_exact_with_oracle(gb, o, variant):
     try:
         outs, status, _ = gb.run(OP_ZSTD_COMPRESS, blocks, caps)
     finally:
-        gb.set_option("zstd.compress.variant", 0)
+        gb.set_option("zstd.compress.variant", 3)
     assert all(s == 0 for s in status), status
     for i, (b, z) in enumerate(zip(blocks, outs)):
         assert z == o.compress("zstd", b, caps[i]), "block %d (len %d): gpu %d bytes" % (i, len(b), len(z))

@@ -9,6 +9,9 @@
 #include "../../aircompressor_amd/csrc/lz4_compress.hip"
 #include "../../aircompressor_amd/csrc/snappy_compress.hip"
 #include "../../aircompressor_amd/csrc/snappy_compress_v3.hip"
+#ifdef ACHIP_HOST_STATS
+extern "C" { long long g_zc_stats[32]; }  // tools/hostemu/zc_stats.py
+#endif
 #include "../../aircompressor_amd/csrc/zstd_compress.hip"
 #include "../../aircompressor_amd/csrc/zstd_stream.hip"
 

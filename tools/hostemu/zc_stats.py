@@ -1,0 +1,28 @@
+"""How often each part of the Zstd window match finder (zstd_dfast_mw.h) runs, per 128 KiB of input: the kernel source on the CPU emulator,
+built with -DACHIP_HOST_STATS (libemu_enc_stats.so).  zc_stats.py [corpus file index ...]"""
+import sys, os, ctypes, subprocess
+ROOT_ = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT_); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from emu_harness import EmuBatch, P, ROOT
+from tests import oracle_lib, common
+so = os.path.join(ROOT, "tools", "hostemu", "libemu_enc_stats.so")
+src = os.path.join(ROOT, "tools", "hostemu", "emu_enc.cpp")
+subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-omit-frame-pointer", "-DACHIP_HOST_STATS", "-fsanitize-coverage=inline-8bit-counters,trace-loads,trace-stores",
+                "-I", os.path.join(ROOT, "tools", "hostemu"), "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "aircompressor_amd", "csrc"), "-o", so, src], check=True)
+lib = ctypes.CDLL(so)
+stats = (ctypes.c_longlong * 32).in_dll(lib, "g_zc_stats")
+o = oracle_lib.load()
+class EncBatch(EmuBatch):
+    def __init__(self, option): self.lib = lib; self.options = {}; self.option = option
+    def _call(self, op, src, src_off, src_len, dst, dst_off, caps, out_len, status, err, n):
+        return self.lib.emu_encode(op, P(src), P(src_off), P(src_len), P(dst), P(dst_off), P(caps), P(out_len), P(status), P(err), n, self.option, 262144)
+names = ["windows", "searches", "matches", "repeat at +1", "long", "short", "candidate inside the window", "backward bytes", "backward from memory", "match ends beyond the window",
+         "repeat loop hits", "count_table to memory", "count_window to memory", "count_repeat to memory", "serial steps", "searches without a hit"]
+files = common.corpus_files() if hasattr(common, "corpus_files") else None
+sample = [d for _, d, _ in common.corpus_sample()]
+for idx in [int(a) for a in sys.argv[1:]] or [0, 1, 2]:
+    data = (sample[idx] * 3)[:131072] if len(sample[idx]) < 131072 else sample[idx][:131072]
+    for i in range(32): stats[i] = 0
+    outs, status, _ = EncBatch(3).run(5, [data], [o.max_compressed_length("zstd", len(data))])
+    assert status[0] == 0 and outs[0] == o.compress("zstd", data)
+    print("sample %d (%d bytes -> %d):" % (idx, len(data), len(outs[0])), ", ".join("%s %d" % (n, stats[i]) for i, n in enumerate(names)))
