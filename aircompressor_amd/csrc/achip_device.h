@@ -8,6 +8,9 @@
 // group step touches GS*16 contiguous bytes of HBM.  Groups of one wave diverge only
 // on rare paths (length escapes, tails, overlapping matches).
 #pragma once
+#ifndef ACHIP_WAVES_PER_EU  // cap a kernel's registers for at least `lo` wavefronts per SIMD (the CPU emulator's shim defines it away)
+#define ACHIP_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -312,7 +315,7 @@ __device__ __forceinline__ int32_t wave_count(const uint8_t* __restrict__ in, in
         const unsigned long long m = __ballot(stop);
         if (m != 0) {
             const int first = __builtin_ctzll(m);
-            const int32_t e = __shfl(eq, first);
+            const int32_t e = __builtin_amdgcn_readlane(eq, first);  // (a scalar: the callers' positions stay wave-uniform for the compiler, too)
             return total + first * 8 + e;
         }
         total += 512;

@@ -40,7 +40,7 @@ __device__ __forceinline__ void point_item_scratch(Ctx& c, uint8_t* itemScratch)
 }  // namespace zc
 
 // K_m: the match finder alone (DoubleFastBlockCompressor.compressBlock) for the eligible items [first, first + count)
-__global__ __launch_bounds__(64) void zstd_match_kernel(BatchArgs a, uint8_t* tableSlabs, uint8_t* itemScratch, int32_t first, int32_t count, int32_t* nextItem, int32_t batchProbe)
+__global__ __launch_bounds__(64) ACHIP_WAVES_PER_EU(4, 8) void zstd_match_kernel(BatchArgs a, uint8_t* tableSlabs, uint8_t* itemScratch, int32_t first, int32_t count, int32_t* nextItem, int32_t batchProbe)
 {
     using namespace zc;
     __shared__ int32_t item;

@@ -40,6 +40,12 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 {
     return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src);
 }
+// "this value is the same in every lane": the replay's state is wave-uniform by construction, but what was loaded from memory or came through a
+// shuffle is a vector register to the compiler, and one such value in a position (input, anchor, an offset) turns every branch and every
+// mask operation behind it into vector code under exec masks -- the first GPU build of this file ran 244 s_and_saveexec for 19 scalar branches
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
 // bits [lo, hi) of a 64-bit mask (0 <= lo, hi <= 64; empty when hi <= lo)
 __device__ __forceinline__ uint64_t bits(int lo, int hi)
 {
@@ -65,27 +71,48 @@ __device__ __forceinline__ int run_from(uint64_t E, int k, int nv)
     const int r = inv != 0 ? __builtin_ctzll(inv) : 64;
     return r < nv - k ? r : nv - k;
 }
+// zc_match_any with fewer ballots: classes by the low 9 bits of the key, then one check that every class is pure (all of its lanes have the full
+// key of its first lane) -- which it is unless two different hashes of a window share their low bits: then the full loop
+__device__ __forceinline__ unsigned long long match_any_fast(uint32_t key, int keyBits, unsigned long long active, bool isActive)
+{
+    if (keyBits <= 9) {
+        return zc_match_any(key, keyBits, active);
+    }
+    const unsigned long long eq = zc_match_any(key, 9, active);
+    const int leader = eq != 0 ? __builtin_ctzll(eq) : 0;
+    const uint32_t leaderKey = (uint32_t)__shfl((int)key, leader);
+    if (__ballot(isActive && leaderKey != key) != 0) {
+        return zc_match_any(key, keyBits, active);
+    }
+    return eq;
+}
 }  // namespace dmw
 
 __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t inputSize)
 {
     using namespace dmw;
+    inputAddress = uni(inputAddress);  // (what the kernel loaded from the batch arrays is wave-uniform, which the compiler cannot know)
+    inputSize = uni(inputSize);
     if (inputSize < 96) {
         return dfast_compress_block(c, inputAddress, inputSize);  // (the candidates' 32 bytes are taken from inside [0, inputEnd))
     }
     const uint8_t* __restrict__ in = c.in;
     const int lane = c.lane;
-    const int32_t windowBase = c.windowBaseOffset;
+    const int32_t windowBase = uni(c.windowBaseOffset);
     int32_t* longTable = c.hashTable;
     int32_t* shortTable = c.chainTable;
-    const int32_t longBits = c.hashLog;
-    const int32_t shortBits = c.chainLog;
+    const int32_t longBits = uni(c.hashLog);
+    const int32_t shortBits = uni(c.chainLog);
+    const bool fiveByteHash = uni(c.searchLength) == 5;
     const int32_t inputEnd = inputAddress + inputSize;
     const int32_t inputLimit = inputEnd - 8;
     int32_t input = inputAddress;
     int32_t anchor = inputAddress;
-    int32_t offset1 = c.offset0;
-    int32_t offset2 = c.offset1;
+    int32_t offset1 = uni(c.offset0);
+    int32_t offset2 = uni(c.offset1);
+    c.literalsLength = uni(c.literalsLength);
+    c.sequenceCount = uni(c.sequenceCount);
+    c.longLengthField = uni(c.longLengthField);
     int32_t savedOffset = 0;
     if (input - windowBase == 0) {
         input++;
@@ -100,8 +127,9 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
         offset1 = 0;
     }
     int32_t litStored = anchor;  // the literal bytes [anchor, litStored) are in litBuf already (stored from registers as the windows went by)
+    const unsigned long long below = bits(0, lane);  // the lanes before this one
 
-    auto hash_s = [&](uint64_t v) { return c.searchLength == 5 ? hash5(v, shortBits) : hash4((uint32_t)v, shortBits); };
+    auto hash_s = [&](uint64_t v) { return fiveByteHash ? hash5(v, shortBits) : hash4((uint32_t)v, shortBits); };
     // SequenceStore.storeSequence :83-111 without the literal copy
     auto seq = [&](int32_t literalLength, int32_t offsetCode, int32_t matchLengthBase) {
         c.literalsLength += literalLength;
@@ -123,19 +151,19 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
     auto after_match_serial = [&](int32_t current, bool inserts) {
         if (input <= inputLimit) {
             if (inserts) {
-                const uint64_t a = ld8(in + current + 2);
+                const uint64_t a = uni(ld8(in + current + 2));
                 longTable[hash8(a, longBits)] = current + 2;
                 shortTable[hash_s(a)] = current + 2;
-                const uint64_t b = ld8(in + input - 2);
+                const uint64_t b = uni(ld8(in + input - 2));
                 longTable[hash8(b, longBits)] = input - 2;
                 shortTable[hash_s(b)] = input - 2;
             }
-            while (input <= inputLimit && offset2 > 0 && ld4(in + input) == ld4(in + input - offset2)) {
+            while (input <= inputLimit && offset2 > 0 && uni(ld4(in + input)) == uni(ld4(in + input - offset2))) {
                 const int32_t repetitionLength = wave_count(in, input + 4, input + 4 - offset2, inputEnd, lane) + 4;
                 const int32_t temp = offset2;
                 offset2 = offset1;
                 offset1 = temp;
-                const uint64_t r = ld8(in + input);
+                const uint64_t r = uni(ld8(in + input));
                 shortTable[hash_s(r)] = input;
                 longTable[hash8(r, longBits)] = input;
                 seq(0, 0, repetitionLength - 3);
@@ -150,17 +178,17 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
         if (input - anchor >= 192) {
             ZC_STAT(14, 1);
             // ---- the serial step: the Java loop as it stands (long literal runs: the probes skip ahead) ----
-            const uint64_t here = ld8(in + input);
+            const uint64_t here = uni(ld8(in + input));
             const int32_t shortHash = hash_s(here);
-            int32_t shortMatch = shortTable[shortHash];
+            int32_t shortMatch = uni(shortTable[shortHash]);
             const int32_t longHash = hash8(here, longBits);
-            int32_t longMatch = longTable[longHash];
-            const bool repHit = offset1 > 0 && ld4(in + input + 1 - offset1) == ld4(in + input + 1);
+            int32_t longMatch = uni(longTable[longHash]);
+            const bool repHit = offset1 > 0 && uni(ld4(in + input + 1 - offset1)) == (uint32_t)(here >> 8);
             bool longHit = false, shortHit = false;
             if (!repHit) {
-                longHit = longMatch > windowBase && ld8(in + longMatch) == here;
+                longHit = longMatch > windowBase && uni(ld8(in + longMatch)) == here;
                 if (!longHit) {
-                    shortHit = shortMatch > windowBase && ld4(in + shortMatch) == (uint32_t)here;
+                    shortHit = shortMatch > windowBase && uni(ld4(in + shortMatch)) == (uint32_t)here;
                 }
             }
             const int32_t current = input;
@@ -177,22 +205,22 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
                 if (longHit) {
                     matchLength = wave_count(in, input + 8, longMatch + 8, inputEnd, lane) + 8;
                     offset = input - longMatch;
-                    while (input > anchor && longMatch > windowBase && in[input - 1] == in[longMatch - 1]) {
+                    while (input > anchor && longMatch > windowBase && uni((uint32_t)in[input - 1]) == uni((uint32_t)in[longMatch - 1])) {
                         input--;
                         longMatch--;
                         matchLength++;
                     }
                 }
                 else if (shortHit) {
-                    const uint64_t next = ld8(in + input + 1);
+                    const uint64_t next = uni(ld8(in + input + 1));
                     const int32_t nextHash = hash8(next, longBits);
-                    int32_t nextMatch = longTable[nextHash];
+                    int32_t nextMatch = uni(longTable[nextHash]);
                     longTable[nextHash] = current + 1;
-                    if (nextMatch > windowBase && ld8(in + nextMatch) == next) {
+                    if (nextMatch > windowBase && uni(ld8(in + nextMatch)) == next) {
                         matchLength = wave_count(in, input + 1 + 8, nextMatch + 8, inputEnd, lane) + 8;
                         input++;
                         offset = input - nextMatch;
-                        while (input > anchor && nextMatch > windowBase && in[input - 1] == in[nextMatch - 1]) {
+                        while (input > anchor && nextMatch > windowBase && uni((uint32_t)in[input - 1]) == uni((uint32_t)in[nextMatch - 1])) {
                             input--;
                             nextMatch--;
                             matchLength++;
@@ -201,7 +229,7 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
                     else {
                         matchLength = wave_count(in, input + 4, shortMatch + 4, inputEnd, lane) + 4;
                         offset = input - shortMatch;
-                        while (input > anchor && shortMatch > windowBase && in[input - 1] == in[shortMatch - 1]) {
+                        while (input > anchor && shortMatch > windowBase && uni((uint32_t)in[input - 1]) == uni((uint32_t)in[shortMatch - 1])) {
                             input--;
                             shortMatch--;
                             matchLength++;
@@ -252,8 +280,8 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
         }
         const uint32_t x4 = (uint32_t)x;
         const unsigned long long ldMask = __ballot(ld);
-        const unsigned long long sameS = zc_match_any((uint32_t)sHash, shortBits, ldMask) & ldMask;
-        const unsigned long long sameL = zc_match_any((uint32_t)lHash, longBits, ldMask) & ldMask;
+        const unsigned long long sameS = match_any_fast((uint32_t)sHash, shortBits, ldMask, ld) & ldMask;
+        const unsigned long long sameL = match_any_fast((uint32_t)lHash, longBits, ldMask, ld) & ldMask;
         // the candidates' surroundings
         uint64_t L0 = 0, L1 = 0, L2 = 0, L3 = 0, S0 = 0, S1 = 0;
         int shL = 0, shS = 0;
@@ -285,36 +313,87 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
             cS4 = (uint32_t)ext32(S0, S1, 0ull, 0ull, shS);
         }
 
+        // What a match against the TABLE's candidate would be, for every lane at once (the replay then reads one packed word per match instead
+        // of walking the candidate's bytes): equal bytes behind the first 8 / 4 as far as the fetched bytes and the window's lanes go, equal
+        // bytes before both positions (up to 4), each with a flag "everything known was equal: the rest is in memory".
+        uint32_t packed = 0;
+        {
+            const uint64_t x8 = shfl64(x, lane + 8 < 64 ? lane + 8 : lane);     // the bytes at p + 8 (valid: lane + 8 < nld)
+            const uint64_t x16 = shfl64(x, lane + 16 < 64 ? lane + 16 : lane);  // ... at p + 16
+            const bool v8 = lane + 8 < nld, v16 = lane + 16 < nld;
+            // the 4 bytes before p, the last one in the top byte; lanes 1 .. 3 know 1 .. 3 of them
+            const uint32_t prev = (uint32_t)__shfl((int)x4, lane >= 4 ? lane - 4 : 0);
+            const uint32_t xm4 = lane >= 4 ? prev : (lane == 0 ? 0u : prev << (8 * (4 - lane)));
+            const int knownBack = lane < 4 ? lane : 4;
+            if (okL) {
+                const int k0 = shL + 8, nAvail = 24 - shL;
+                const uint64_t d0 = x8 ^ ext32(L0, L1, L2, L3, k0);
+                const uint64_t dn = x16 ^ ext32(L0, L1, L2, L3, k0 + 8);
+                const int e0 = d0 == 0 ? 8 : (__builtin_ctzll(d0) >> 3);
+                const int e1 = dn == 0 ? 8 : (__builtin_ctzll(dn) >> 3);
+                const int cnt = e0 == 8 ? 8 + e1 : e0;
+                const int usable = !v8 ? 0 : (nAvail < 8 ? nAvail : (!v16 ? 8 : (nAvail < 16 ? nAvail : 16)));
+                const int f = cnt < usable ? cnt : usable;
+                const int kb = shL < 4 ? shL : 4;
+                const uint32_t before = shL >= 4 ? (uint32_t)ext32(L0, L1, L2, L3, shL - 4) : (shL == 0 ? 0u : (uint32_t)L0 << (8 * (4 - shL)));
+                const uint32_t db = xm4 ^ before;
+                const int eb = db == 0 ? 4 : (__builtin_clz(db) >> 3);
+                const int ub = kb < knownBack ? kb : knownBack;
+                const int b = eb < ub ? eb : ub;
+                packed |= (uint32_t)f | (f == usable ? 32u : 0u) | ((uint32_t)b << 6) | (b == ub ? 512u : 0u);
+            }
+            if (okS) {
+                const int k0 = shS + 4, nAvail = 12 - shS;
+                const uint64_t a = (x >> 32) | (x8 << 32);
+                const uint64_t d0 = a ^ ext32(S0, S1, 0ull, 0ull, k0);
+                const int cnt = d0 == 0 ? 8 : (__builtin_ctzll(d0) >> 3);
+                int usable = v8 ? 8 : 4;
+                usable = nAvail < usable ? nAvail : usable;
+                const int f = cnt < usable ? cnt : usable;
+                const int kb = shS < 4 ? shS : 4;
+                const uint32_t before = shS >= 4 ? (uint32_t)ext32(S0, S1, 0ull, 0ull, shS - 4) : (shS == 0 ? 0u : (uint32_t)S0 << (8 * (4 - shS)));
+                const uint32_t db = xm4 ^ before;
+                const int eb = db == 0 ? 4 : (__builtin_clz(db) >> 3);
+                const int ub = kb < knownBack ? kb : knownBack;
+                const int b = eb < ub ? eb : ub;
+                packed |= ((uint32_t)f << 10) | (f == usable ? (1u << 14) : 0u) | ((uint32_t)b << 15) | (b == ub ? (1u << 18) : 0u);
+            }
+        }
+        // hits against the tables' own entries do not change during the replay; lanes of the window with equal hashes (rare) make a lane's view of a
+        // table depend on what the replay has inserted: only windows that have such lanes evaluate that
+        const bool tableLongH = okL && cL8 == x;
+        const bool tableShortH = okS && cS4 == x4;
+        const unsigned long long sameLb = sameL & below, sameSb = sameS & below;
+        const bool anySame = __ballot(sameLb != 0 || sameSb != 0) != 0;
+        ZC_STAT(16, anySame ? 1 : 0);
+        uint8_t* const litLane = c.litBuf + p;  // (a literal byte of lane q goes to litLane[literalsLength - anchor])
+        // the window's sequences are kept by the lanes (sequence k by lane k) and stored together at its end
+        int32_t qLL = 0, qOF = 0, qML = 0;
+        int nq = 0;
+        const int32_t seqBase = c.sequenceCount;
+        auto seq_w = [&](int32_t literalLength, int32_t offsetCode, int32_t matchLengthBase) {
+            c.literalsLength += literalLength;
+            if (literalLength > 65535) {
+                c.longLengthField = 1;
+                c.longLengthPosition = seqBase + nq;
+            }
+            if (matchLengthBase > 65535) {
+                c.longLengthField = 2;
+                c.longLengthPosition = seqBase + nq;
+            }
+            if (lane == nq) {
+                qLL = literalLength;
+                qOF = offsetCode + 1;
+                qML = matchLengthBase;
+            }
+            nq++;
+        };
+
         unsigned long long ML = 0, MS = 0;  // lanes the replay has inserted into the long / short table
         int cs = 0;                         // first lane of the search that comes next
         int post = 0;                       // the match ended beyond the window: 1 = its inserts and the repeat loop, 2 = the rest of the repeat loop, from memory
         int32_t postCurrent = 0;
 
-        // equal bytes of in[aPos ...] (held by the lanes from la0 on) and bytes k0 ... of the nbytes (r0 .. r3) read around a table candidate (bPos), then memory
-        auto count_table = [&](uint64_t r0, uint64_t r1, uint64_t r2, uint64_t r3, int nbytes, int k0, int la0, int32_t aPos, int32_t bPos) -> int32_t {
-            int32_t eq = 0;
-            bool mismatch = false;
-            for (;;) {
-                const int la = la0 + eq, k = k0 + eq;
-                if (la >= nld || k >= nbytes) {
-                    break;
-                }
-                const int n = nbytes - k > 8 ? 8 : nbytes - k;
-                const uint64_t dd = rl64(x, la) ^ ext32(r0, r1, r2, r3, k);
-                const int e = dd == 0 ? 8 : (__builtin_ctzll(dd) >> 3);
-                if (e < n) {
-                    eq += e;
-                    mismatch = true;
-                    break;
-                }
-                eq += n;
-            }
-            if (!mismatch) {
-                ZC_STAT(11, 1);
-                eq += wave_count(in, aPos + eq, bPos + eq, inputEnd, lane);
-            }
-            return eq;
-        };
         // equal bytes of in[base + k ...] and in[base + k - o ...] for a distance o inside the window, then memory
         auto count_window = [&](int o, int k) -> int32_t {
             const uint32_t prev = (uint32_t)__shfl((int)x4, lane >= o ? lane - o : lane);
@@ -340,18 +419,23 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
         while (cs < nact) {
             ZC_STAT(1, 1);
             // ---- the search :57-150 over lanes cs .. nact - 1 at once: a lane sees the replay's inserts and those of the search lanes before it ----
-            const unsigned long long below = bits(0, lane);
-            const unsigned long long assumed = bits(cs, lane);
-            const unsigned long long eL = sameL & (ML | assumed) & below;
-            const int jL = eL != 0 ? 63 - __builtin_clzll(eL) : -1;
-            const unsigned long long eS = sameS & (MS | assumed) & below;
-            const int jS = eS != 0 ? 63 - __builtin_clzll(eS) : -1;
-            const uint64_t xjL = shfl64(x, jL >= 0 ? jL : lane);
-            const uint32_t xjS = (uint32_t)__shfl((int)x4, jS >= 0 ? jS : lane);
-            const int32_t pL = jL >= 0 ? base + jL : tL;
-            const int32_t pS = jS >= 0 ? base + jS : tS;
-            const bool longH = pL > windowBase && (jL >= 0 ? xjL == x : (okL && cL8 == x));
-            const bool shortH = pS > windowBase && (jS >= 0 ? xjS == x4 : (okS && cS4 == x4));
+            int jL = -1, jS = -1;
+            bool longH = tableLongH, shortH = tableShortH;
+            if (anySame) {
+                const unsigned long long seen = ~bits(0, cs);  // (with `below`: the search lanes before this one)
+                const unsigned long long eL = sameLb & (ML | seen);
+                jL = eL != 0 ? 63 - __builtin_clzll(eL) : -1;
+                const unsigned long long eS = sameSb & (MS | seen);
+                jS = eS != 0 ? 63 - __builtin_clzll(eS) : -1;
+                const uint64_t xjL = shfl64(x, jL >= 0 ? jL : lane);
+                const uint32_t xjS = (uint32_t)__shfl((int)x4, jS >= 0 ? jS : lane);
+                if (jL >= 0) {
+                    longH = base + jL > windowBase && xjL == x;
+                }
+                if (jS >= 0) {
+                    shortH = base + jS > windowBase && xjS == x4;
+                }
+            }
             const bool repH = offset1 > 0 && d1 == 0;
             const bool probing = lane >= cs && lane < nact;
             const unsigned long long hm = __ballot(probing && (repH || longH || shortH));
@@ -378,9 +462,9 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
                 matchLength = 4 + count_repeat(d1, offset1, w + 4);
                 input = current + 1;
                 if (p >= litStored && p < input) {
-                    c.litBuf[c.literalsLength + (p - anchor)] = (uint8_t)x4;
+                    litLane[c.literalsLength - anchor] = (uint8_t)x4;
                 }
-                seq(input - anchor, 0, matchLength - 3);
+                seq_w(input - anchor, 0, matchLength - 3);
             }
             else {
                 int m = w;        // lane where the match starts
@@ -399,64 +483,53 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
                 int32_t cand = jc >= 0 ? base + jc : (int32_t)rl32((uint32_t)(isLong ? tL : tS), m);
                 input = base + m;
                 const int minLen = isLong ? 8 : 4;
-                uint64_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-                int shW = 0;
                 ZC_STAT(isLong ? 4 : 5, 1);
-                if (jc >= 0) {
-                    ZC_STAT(6, 1);
-                    matchLength = minLen + count_window(m - jc, m + minLen);
-                }
-                else if (isLong) {
-                    r0 = rl64(L0, m);
-                    r1 = rl64(L1, m);
-                    r2 = rl64(L2, m);
-                    r3 = rl64(L3, m);
-                    shW = (int)rl32((uint32_t)shL, m);
-                    matchLength = 8 + count_table(r0, r1, r2, r3, 32, shW + 8, m + 8, input + 8, cand + 8);
+                int32_t back = 0;
+                if (jc < 0) {
+                    // the table's candidate: what its lane has measured
+                    const uint32_t pk = rl32(packed, m) >> (isLong ? 0 : 10);
+                    const int f = (int)(pk & (isLong ? 31u : 15u));
+                    const bool fAll = ((pk >> (isLong ? 5 : 4)) & 1u) != 0;
+                    const int b = (int)((pk >> (isLong ? 6 : 5)) & 7u);
+                    const bool bAll = ((pk >> (isLong ? 9 : 8)) & 1u) != 0;
+                    matchLength = minLen + f;
+                    if (fAll) {
+                        ZC_STAT(11, 1);
+                        matchLength += wave_count(in, input + minLen + f, cand + minLen + f, inputEnd, lane);
+                    }
+                    // backward :136-142 (and its twins :93-99, :117-123)
+                    const int32_t roomA = input - anchor, roomB = cand - windowBase;
+                    const int32_t room = roomA < roomB ? roomA : roomB;
+                    back = b < room ? b : room;
+                    if (bAll && back < room) {
+                        ZC_STAT(8, 1);
+                        while (input - back > anchor && cand - back > windowBase && uni((uint32_t)in[input - back - 1]) == uni((uint32_t)in[cand - back - 1])) {
+                            back++;
+                        }
+                    }
+                    ZC_STAT(7, back);
                 }
                 else {
-                    r0 = rl64(S0, m);
-                    r1 = rl64(S1, m);
-                    shW = (int)rl32((uint32_t)shS, m);
-                    matchLength = 4 + count_table(r0, r1, 0ull, 0ull, 16, shW + 4, m + 4, input + 4, cand + 4);
-                }
-                // backward :136-142 (and its twins :93-99, :117-123): registers first
-                int32_t back = 0;
-                bool fromMemory = false;
-                while (input - back > anchor && cand - back > windowBase) {
-                    const int li = input - back - 1 - base;
-                    if (li < 0) {
-                        fromMemory = true;
-                        break;
-                    }
-                    const uint32_t bi = rl32(x4, li) & 0xFFu;
-                    uint32_t bc;
-                    if (jc >= 0) {
+                    // a candidate inside the window (rare): the other lanes' registers
+                    ZC_STAT(6, 1);
+                    matchLength = minLen + count_window(m - jc, m + minLen);
+                    bool fromMemory = false;
+                    while (input - back > anchor && cand - back > windowBase) {
+                        const int li = input - back - 1 - base;
                         const int lc = jc - back - 1;
-                        if (lc < 0) {
+                        if (li < 0 || lc < 0) {
                             fromMemory = true;
                             break;
                         }
-                        bc = rl32(x4, lc) & 0xFFu;
-                    }
-                    else {
-                        const int kb = shW - back - 1;
-                        if (kb < 0) {
-                            fromMemory = true;
+                        if ((rl32(x4, li) & 0xFFu) != (rl32(x4, lc) & 0xFFu)) {
                             break;
                         }
-                        bc = (uint32_t)ext32(r0, r1, r2, r3, kb) & 0xFFu;
-                    }
-                    if (bi != bc) {
-                        break;
-                    }
-                    back++;
-                }
-                ZC_STAT(7, back);
-                if (fromMemory) {
-                    ZC_STAT(8, 1);
-                    while (input - back > anchor && cand - back > windowBase && in[input - back - 1] == in[cand - back - 1]) {
                         back++;
+                    }
+                    if (fromMemory) {
+                        while (input - back > anchor && cand - back > windowBase && uni((uint32_t)in[input - back - 1]) == uni((uint32_t)in[cand - back - 1])) {
+                            back++;
+                        }
                     }
                 }
                 input -= back;
@@ -464,14 +537,14 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
                 matchLength += back;
                 offset = input - cand;
                 if (p >= litStored && p < input) {
-                    c.litBuf[c.literalsLength + (p - anchor)] = (uint8_t)x4;
+                    litLane[c.literalsLength - anchor] = (uint8_t)x4;
                 }
-                seq(input - anchor, offset + 2, matchLength - 3);
+                seq_w(input - anchor, offset + 2, matchLength - 3);
                 offset2 = offset1;
                 offset1 = offset;
                 d2 = d1;
                 d1 = 0xFFFFFFFFu;
-                if (ld && p + 1 >= offset) {
+                if (ld && p + 1 >= offset && input + matchLength - base <= 62) {  // (a match that ends beyond the window ends the window)
                     d1 = ld4(in + p + 1 - offset) ^ (uint32_t)(x >> 8);
                 }
             }
@@ -504,7 +577,7 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
                     d1 = td;
                     ML |= 1ull << (q + 1);
                     MS |= 1ull << (q + 1);
-                    seq(0, 0, repetitionLength - 3);
+                    seq_w(0, 0, repetitionLength - 3);
                     input += repetitionLength;
                     anchor = input;
                     litStored = anchor;
@@ -521,8 +594,14 @@ __device__ int32_t dfast_compress_block_mw(Ctx& c, int32_t inputAddress, int32_t
         }
         // literal bytes of this window behind the last match: stored now, from registers (the next window's first sequence, or the block's end, owns them)
         if (post == 0 && p >= litStored && p < input) {
-            c.litBuf[c.literalsLength + (p - anchor)] = (uint8_t)x4;
+            litLane[c.literalsLength - anchor] = (uint8_t)x4;
         }
+        if (lane < nq) {
+            c.seqLitLen[seqBase + lane] = qLL;
+            c.seqOffset[seqBase + lane] = qOF;
+            c.seqMatchLen[seqBase + lane] = qML;
+        }
+        c.sequenceCount = seqBase + nq;
         if (post == 0 && input > litStored) {
             litStored = input;
         }

@@ -38,6 +38,7 @@
 #define __constant__ const
 #define __forceinline__ inline
 #define __launch_bounds__(...)
+#define ACHIP_WAVES_PER_EU(lo, hi)  // (a register cap of the device compiler: achip_device.h)
 #define __shared__ static
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
