@@ -289,6 +289,13 @@ __device__ __forceinline__ void group_match_copy(uint8_t* out, int32_t pos, int3
     }
 }
 
+// "this value is the same in every lane."  State that is wave-uniform by construction (a position, a length, a count) but was loaded from memory
+// or came through a shuffle is a vector register to the compiler, and one such value in a position turns every branch and every mask operation
+// behind it into vector code under exec masks.  uni() hands the compiler the scalar.
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
+
 // ---- wave-wide match-length count (one wavefront per block) ----
 // Number of equal bytes of in[a..] vs in[b..] with a < limit, b < a: the `count` routines of the Java
 // encoders (M/lz4/Lz4RawCompressor.java:240-267, M/snappy/SnappyRawCompressor.java:235-266) both return

@@ -51,6 +51,8 @@ __device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t
 {
     using namespace lz4c;
     using namespace lz4mw;
+    inLen = uni(inLen);  // (loaded from the batch arrays: wave-uniform, which the compiler cannot know -- achip_device.h, uni())
+    outCap = uni(outCap);
     int32_t st = 0;
     int32_t output = 0;
     const int64_t bound = (int64_t)inLen + inLen / 255 + 16;
@@ -157,8 +159,8 @@ __device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t
                         k0 += 64;
                         continue;
                     }
-                    input = __shfl(pos, winner);
-                    int32_t matchIndex = __shfl(cand, winner);
+                    input = (int32_t)rl32((uint32_t)pos, winner);
+                    int32_t matchIndex = (int32_t)rl32((uint32_t)cand, winner);
                     int32_t room = input - anchor < matchIndex ? input - anchor : matchIndex;  // catch up :141-144
                     while (room > 0) {
                         const bool eq = lane < room && in[input - 1 - lane] == in[matchIndex - 1 - lane];

@@ -38,6 +38,8 @@ __device__ __forceinline__ void snappy_compress_buffer_mw(uint16_t* table, const
 {
     using namespace snc;
     using namespace snmw;
+    inLen = uni(inLen);  // (loaded from the batch arrays: wave-uniform, which the compiler cannot know -- achip_device.h, uni())
+    outCap = uni(outCap);
     int32_t st = 0;
     int32_t output = 0;
     const int64_t bound = 32 + (int64_t)inLen + inLen / 6;
@@ -124,8 +126,8 @@ __device__ __forceinline__ void snappy_compress_buffer_mw(uint16_t* table, const
                             k0 += 64;
                             continue;
                         }
-                        input = __shfl(pos, winner);
-                        const int32_t candidate = __shfl(cand, winner);
+                        input = uni(__shfl(pos, winner));
+                        const int32_t candidate = uni(__shfl(cand, winner));
                         const int32_t literalLength = input - nextEmit;  // :169-175
                         output += snappy_literal_header(out, output, literalLength, lane);
                         group_copy<64>(out + output, in + nextEmit, literalLength, lane);

@@ -40,12 +40,6 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 {
     return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src);
 }
-// "this value is the same in every lane": the replay's state is wave-uniform by construction, but what was loaded from memory or came through a
-// shuffle is a vector register to the compiler, and one such value in a position (input, anchor, an offset) turns every branch and every
-// mask operation behind it into vector code under exec masks -- the first GPU build of this file ran 244 s_and_saveexec for 19 scalar branches
-__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ uint64_t uni(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
 // bits [lo, hi) of a 64-bit mask (0 <= lo, hi <= 64; empty when hi <= lo)
 __device__ __forceinline__ uint64_t bits(int lo, int hi)
 {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 3, call 14: LZ4 / Snappy encoders after wave_count() returns a scalar (uniform positions for the compiler) -- corpus, wordmix, fragments
 export TMPDIR=/tmp
-O=gpurun_out/r03c14
+O=gpurun_out/r03c15
 rm -rf $O; mkdir -p $O
 B="python bench.py --no-cpu-baseline --no-sweep --no-extra --blocks 65536 --steps 5 --warmup 2"
 for w in lz4_compress snappy_compress; do
