@@ -20,8 +20,11 @@ namespace achip {
 
 namespace zc {
 constexpr int32_t STREAM_MAX_BUFFER = 4 << 20;
+// a wavefront's block buffer lives where the frame compressor's match kernel keeps a wavefront's tables (zstd_compress_scratch_bytes: at least as many of
+// those as slabs); its stride is theirs
+constexpr int64_t STREAM_BLOCK_BUFFER_BYTES = (int64_t)4 * (HASH_TABLE_INTS + CHAIN_TABLE_INTS);
 
-__device__ int32_t zstd_stream_item(Ctx& c, Shared& sh, int chunked)
+__device__ int32_t zstd_stream_item(Ctx& c, Shared& sh, int chunked, uint8_t* blockBuf)
 {
     const int32_t n = c.inLen;
     const int32_t outputLimit = c.outCap;
@@ -87,11 +90,12 @@ __device__ int32_t zstd_stream_item(Ctx& c, Shared& sh, int chunked)
             }
             if (first) {  // writeFrameHeader(inputSize = closing ? chunk : -1, windowSize) (ZstdFrameCompressor.java:64-121)
                 first = false;
-                ZC_CHECK(c, outputLimit - output >= 14);
                 const int32_t inputSize = closing ? chunk : -1;
                 const int32_t contentSizeDescriptor = inputSize == -1 ? 0 : (inputSize >= 256 ? 1 : 0) + (inputSize >= 65536 + 256 ? 1 : 0);
                 int32_t fhd = (contentSizeDescriptor << 6) | 0x04;
                 const bool singleSegment = inputSize != -1 && windowSize >= inputSize;
+                // (the stream composes the header in its own buffer and hands the sink exactly these bytes: the sink's room is checked against them)
+                ZC_CHECK(c, outputLimit - output >= 1 + (singleSegment ? 0 : 1) + (contentSizeDescriptor == 0 ? (singleSegment ? 1 : 0) : (contentSizeDescriptor == 1 ? 2 : 4)));
                 if (singleSegment) {
                     fhd |= 0x20;
                 }
@@ -115,12 +119,19 @@ __device__ int32_t zstd_stream_item(Ctx& c, Shared& sh, int chunked)
                 outputSize = outputLimit - output;
             }
             do {  // :186-204
-                ZC_CHECK(c, outputSize >= 3 + 3);
                 const int32_t blockSize = chunk < blockMax ? chunk : blockMax;
                 const bool lastBlock = closing != 0 && blockSize == chunk;
-                int32_t compressedSize = 0;  // writeCompressedBlock (ZstdFrameCompressor.java:181-204)
+                // writeCompressedBlock (ZstdFrameCompressor.java:181-204) works in the STREAM's own buffer of a fixed length (ZstdOutputStream.java:55-58),
+                // whatever the sink's room is: the block is compressed into this wavefront's block buffer with exactly that room, and the sink --
+                // the caller's buffer -- is checked against the bytes it is then handed (with the caller's remaining capacity as the
+                // room, capacities below the bound failed where the Java stream succeeds)
+                const int32_t privateLength = (blockMax + 3) + ((blockMax + 3) >> 8) + 8;
+                int32_t compressedSize = 0;
                 if (blockSize > 0) {
-                    compressedSize = compress_block(c, sh, offset, blockSize, output + 3, outputSize - 3);
+                    uint8_t* const sink = c.out;
+                    c.out = blockBuf;
+                    compressedSize = compress_block(c, sh, offset, blockSize, 3, privateLength - 3);
+                    c.out = sink;
                     ZC_PROPAGATE(compressedSize);
                 }
                 if (compressedSize == 0) {
@@ -132,6 +143,10 @@ __device__ int32_t zstd_stream_item(Ctx& c, Shared& sh, int chunked)
                     compressedSize = 3 + blockSize;
                 }
                 else {
+                    ZC_CHECK(c, compressedSize + 3 <= outputSize);
+                    wave_mem_order();
+                    group_copy<64>(c.out + output + 3, blockBuf + 3, compressedSize, c.lane);
+                    wave_mem_order();
                     st_le(c.out + output, (uint32_t)((lastBlock ? 1 : 0) | (2 << 1) | (compressedSize << 3)), 3);
                     compressedSize += 3;
                 }
@@ -170,7 +185,7 @@ __device__ int32_t zstd_stream_item(Ctx& c, Shared& sh, int chunked)
 }  // namespace zc
 
 // the same persistent loop and per-wavefront slab as zstd_compress_kernel (zstd_compress.hip)
-__global__ __launch_bounds__(64) void zstd_stream_kernel(BatchArgs a, uint8_t* slabs, int32_t* nextItem, int32_t count, int32_t chunked)
+__global__ __launch_bounds__(64) void zstd_stream_kernel(BatchArgs a, uint8_t* slabs, uint8_t* blockBufs, int32_t* nextItem, int32_t count, int32_t chunked)
 {
     using namespace zc;
     __shared__ Shared sh;
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(64) void zstd_stream_kernel(BatchArgs a, uint8_t* s
             c.failStatus = mk_status(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_BAD_ARGUMENT);
         }
         else {
-            r = zstd_stream_item(c, sh, chunked);
+            r = zstd_stream_item(c, sh, chunked, blockBufs + (size_t)blockIdx.x * STREAM_BLOCK_BUFFER_BYTES);
         }
         if (lane == 0) {
             a.outLen[block] = r >= 0 ? r : 0;
@@ -246,7 +261,8 @@ hipError_t launch_zstd_stream_compress(const BatchArgs& a, hipStream_t stream, v
     hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
     if (e != hipSuccess) return e;
     const unsigned grid = (unsigned)(a.nBlocks < 256 * 8 ? a.nBlocks : 256 * 8);  // (ZC_MAX_WAVES of zstd_compress.hip: what the scratch holds slabs for)
-    hipLaunchKernelGGL(zstd_stream_kernel, dim3(grid), dim3(64), 0, stream, a, base + 4096, counter + 8, a.nBlocks, chunked);
+    uint8_t* const blockBufs = base + 4096 + (int64_t)grid * zc::SLAB_BYTES;    // (the match kernel's table slabs in zstd_compress_scratch_bytes' layout)
+    hipLaunchKernelGGL(zstd_stream_kernel, dim3(grid), dim3(64), 0, stream, a, base + 4096, blockBufs, counter + 8, a.nBlocks, chunked);
     return hipGetLastError();
 }
 

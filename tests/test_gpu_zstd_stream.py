@@ -55,6 +55,23 @@ def test_stream_writer_is_bit_exact_with_the_oracle(gb, o):
     assert [bytes(p) for p in back] == inputs
 
 
+def test_the_sink_only_has_to_hold_the_stream(gb, o):
+    """ZstdOutputStream compresses every block in its OWN buffer (ZstdOutputStream.java:55-58) and hands the sink the result: a caller's buffer of
+    exactly the stream's size -- far below the advertised bound -- is enough, one byte less is "output too small" (round 2 passed the caller's
+    remaining room to the block compressor and failed here: ADVICE)."""
+    inputs = stream_inputs()[:14] + stream_inputs()[-3:]
+    want = [o.zstd_stream_compress(b) for b in inputs]
+    for extra in (0, 1, 20):
+        outs, status, _ = gb.run(OP_ZSTDSTREAM_COMPRESS, inputs, [len(w) + extra for w in want])
+        assert all(s == 0 for s in status), (extra, status)
+        assert outs == want, extra
+    outs, status, _ = gb.run(OP_ZSTDSTREAM_COMPRESS, inputs, [len(w) - 1 for w in want])
+    for b, s, w in zip(inputs, status, want):
+        with pytest.raises(oracle_lib.OracleError) as e:
+            o.zstd_stream_compress(b, len(w) - 1)
+        assert s == e.value.status, (len(b), s, e.value.status)
+
+
 def test_a_stream_that_would_flush_before_close_can_be_refused(gb, o):
     whole = b"".join(d for _, d, _ in common.corpus_sample())
     big = (whole * 5)[:4 << 20]

@@ -109,6 +109,10 @@ def part_stream():
     some = inputs[3:7]
     tight = [max(len(o.zstd_stream_compress(b)) - 1 - 5 * k, 0) for k, b in enumerate(some)]
     bad += compare("ZstdOutputStream, tight capacities", 14, 0, some, tight, lambda b, c: o.zstd_stream_compress(b, c))
+    # capacities between the stream's size and the advertised bound: the Java stream succeeds (its blocks are compressed in its own buffer, the sink
+    # only has to hold the result) -- every input at exactly its size, at one byte more, at 20 bytes more
+    exact = [len(o.zstd_stream_compress(b)) + d for b in inputs for d in (0, 1, 20)]
+    bad += compare("ZstdOutputStream, capacities of exactly the stream's size and a little more", 14, 0, [b for b in inputs for _ in range(3)], exact, lambda b, c: o.zstd_stream_compress(b, c))
     return bad
 
 
