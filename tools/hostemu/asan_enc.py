@@ -1,7 +1,7 @@
 """Memory-safety check of the ENCODERS and writers on the CPU: libemu_enc_asan.so (access-granular lockstep + AddressSanitizer), one item per
 call, source exactly its length and destination exactly its capacity in allocations of their own: every byte an encoder reads outside
 [src, src + n) or touches outside [dst, dst + capacity) is reported.  Run through tools/hostemu/run_asan_fuzz.sh --enc.
-Every encoder and writer: LZ4 and Snappy (the default kernels and the LDS-window experiments), Zstd (two-kernel, one-kernel, the stream
+Every encoder and writer: LZ4 and Snappy (the window encoders -- the defaults -- and the batch-probe ones), Zstd (window match finder, batch probes, one-kernel, the stream
 writer), the LZ4 frame, x-snappy-framed and Hadoop writers; the bytes are compared with the oracle's as well.  (The library binds its
 tracing callbacks to itself, -Bsymbolic-functions: the preloaded ASan runtime has no-op callbacks of the same names, and with those
 taking the calls there is no lockstep.)"""
@@ -41,11 +41,13 @@ def main():
         ps += [bytes(int(rng.integers(1, 2000))), rng.integers(0, 256, int(rng.integers(1, 1500)), dtype=np.uint8).tobytes(), b"abc" * int(rng.integers(1, 600)), b""]
         for b in ps:
             for title, op, option, bound, ref in (
-                    ("lz4", 1, 1, lambda n: o.max_compressed_length("lz4", n), lambda b: o.compress("lz4", b)),
-                    ("lz4 window", 1, 3, lambda n: o.max_compressed_length("lz4", n), lambda b: o.compress("lz4", b)),
-                    ("snappy", 3, 2, lambda n: o.max_compressed_length("snappy", n), lambda b: o.compress("snappy", b)),
-                    ("snappy window", 3, 3, lambda n: o.max_compressed_length("snappy", n), lambda b: o.compress("snappy", b)),
-                    ("zstd", 5, 0, lambda n: o.max_compressed_length("zstd", n), lambda b: o.compress("zstd", b)),
+                    ("lz4 (many matches per window)", 1, 4, lambda n: o.max_compressed_length("lz4", n), lambda b: o.compress("lz4", b)),
+                    ("lz4 batch probes", 1, 1, lambda n: o.max_compressed_length("lz4", n), lambda b: o.compress("lz4", b)),
+                    ("snappy (many matches per window)", 3, 4, lambda n: o.max_compressed_length("snappy", n), lambda b: o.compress("snappy", b)),
+                    ("snappy batch probes", 3, 2, lambda n: o.max_compressed_length("snappy", n), lambda b: o.compress("snappy", b)),
+                    ("snappy LDS input window", 3, 3, lambda n: o.max_compressed_length("snappy", n), lambda b: o.compress("snappy", b)),
+                    ("zstd (window match finder)", 5, 3, lambda n: o.max_compressed_length("zstd", n), lambda b: o.compress("zstd", b)),
+                    ("zstd batch probes", 5, 0, lambda n: o.max_compressed_length("zstd", n), lambda b: o.compress("zstd", b)),
                     ("zstd one kernel", 5, 2, lambda n: o.max_compressed_length("zstd", n), lambda b: o.compress("zstd", b)),
                     ("zstd stream", 14, 1, lambda n: o.lib.orc_zstd_stream_max_compressed_length(n), lambda b: o.zstd_stream_compress(b)),
                     ("lz4 frame", 7, 0, lambda n: o.max_compressed_length("lz4frame", n), lambda b: o.compress("lz4frame", b)),
