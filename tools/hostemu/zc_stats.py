@@ -17,7 +17,7 @@ class EncBatch(EmuBatch):
     def _call(self, op, src, src_off, src_len, dst, dst_off, caps, out_len, status, err, n):
         return self.lib.emu_encode(op, P(src), P(src_off), P(src_len), P(dst), P(dst_off), P(caps), P(out_len), P(status), P(err), n, self.option, 262144)
 names = ["windows", "searches", "matches", "repeat at +1", "long", "short", "candidate inside the window", "backward bytes", "backward from memory", "match ends beyond the window",
-         "repeat loop hits", "count_table to memory", "count_window to memory", "count_repeat to memory", "serial steps", "searches without a hit"]
+         "repeat loop hits", "count_table to memory", "count_window to memory", "count_repeat to memory", "serial steps", "searches without a hit", "windows with equal hashes"]
 files = common.corpus_files() if hasattr(common, "corpus_files") else None
 sample = [d for _, d, _ in common.corpus_sample()]
 for idx in [int(a) for a in sys.argv[1:]] or [0, 1, 2]:

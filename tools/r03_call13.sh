@@ -1,14 +1,15 @@
 #!/bin/bash
-# Round 3, call 13: issue profile of the Zstd match kernel (window form, v2).  -> gpurun_out/r03c13/
+# Round 3: instruction-cache, scalar-cache and memory-level counters of the Zstd match kernel (window form).  -> gpurun_out/r03c13/
 export TMPDIR=/tmp
 O=gpurun_out/r03c13
 rm -rf $O; mkdir -p $O
-for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH" \
-           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_VMEM_RD" \
-           "SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SALU SQ_IFETCH SQ_INSTS_FLAT SQ_WAVES_EQ_64 SQ_INSTS_EXP_GDS"; do
+for set in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_ICACHE_BUSY_CYCLES SQC_TC_INST_REQ SQC_TC_STALL SQ_IFETCH" \
+           "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_LEVEL_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+           "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum"; do
   D=$O/pmc_tmp; rm -rf $D
   timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $set -d $D -o pmc -- python bench.py --section zstd --no-cpu-baseline > /dev/null 2>&1
-  python - $D "$set" <<'PY' >> $O/match_profile.txt
+  python - $D <<'PY' >> $O/match_profile.txt
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
