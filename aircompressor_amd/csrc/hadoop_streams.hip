@@ -556,12 +556,17 @@ __global__ void hadoop_seal_blocks_kernel(BlockList L)
     L.counters[1] = allocated < MAX_CHUNKS ? allocated : MAX_CHUNKS;
 }
 
+// LZ4: a wavefront per workgroup around its table in LDS.  Snappy (round 3): the two tiers of the block encoder (snappy_compress.hip) -- a 32 KB
+// table allows five workgroups per CU, so a workgroup is four independent persistent wavefronts: wavefront 0 with the table in LDS, the others with a
+// table slab each in memory, all drawing chunks from the one counter.
 template <bool SNAPPY>
-__global__ __launch_bounds__(64) void hadoop_encode_kernel(BatchArgs a, BlockList L, int32_t bufferSize)
+__global__ __launch_bounds__(SNAPPY ? 256 : 64) void hadoop_encode_kernel(BatchArgs a, BlockList L, int32_t bufferSize, uint16_t* slabs)
 {
     // the codec's hash table: Snappy 16384 x u16; LZ4 4096 entries, u16 for chunks <= 64 KiB, i32 beyond
     __shared__ __attribute__((aligned(16))) uint8_t tableBytes[SNAPPY ? snc::MAX_HASH_TABLE_SIZE * 2 : lz4c::MAX_TABLE_SIZE * 4];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint16_t* const snappyTable = !SNAPPY || wave == 0 ? (uint16_t*)tableBytes : slabs + ((size_t)blockIdx.x * 3 + (wave - 1)) * snc::MAX_HASH_TABLE_SIZE;
     const int32_t total = L.counters[1];
     const int32_t chunk = input_max_size(SNAPPY, bufferSize);
     const int64_t worst = 8 + block_bound(SNAPPY, chunk);
@@ -587,7 +592,12 @@ __global__ __launch_bounds__(64) void hadoop_encode_kernel(BatchArgs a, BlockLis
         const int32_t cap = (int32_t)block_bound(SNAPPY, length);
         int32_t cst = 0, compressed = 0;
         if (SNAPPY) {
-            snappy_compress_buffer_mw((uint16_t*)tableBytes, block, length, out, cap, lane, cst, compressed);
+            if (wave == 0) {  // (two calls: the table's address space is part of the code)
+                snappy_compress_buffer_mw((uint16_t*)tableBytes, block, length, out, cap, lane, cst, compressed);
+            }
+            else {
+                snappy_compress_buffer_mw(snappyTable, block, length, out, cap, lane, cst, compressed);
+            }
         }
         else if (length <= 65536) {
             compressed = lz4_compress_block_mw<uint16_t>(block, length, out, cap, (uint16_t*)tableBytes, lane, cst);
@@ -822,10 +832,15 @@ hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void
     return hipGetLastError();
 }
 
+namespace {
+constexpr int HADOOP_SNAPPY_WORKGROUPS = 256 * 5;  // five 32 KB LDS tables per CU, four wavefronts around each
+constexpr int64_t HADOOP_SNAPPY_SLAB_BYTES = (int64_t)HADOOP_SNAPPY_WORKGROUPS * 3 * snc::MAX_HASH_TABLE_SIZE * 2 + 64;
+}
+
 int64_t hadoop_compress_scratch_bytes(int32_t nStreams)
 {
     const int64_t n = nStreams < 1 ? 1 : nStreams;
-    return 4096 + n * 12 + 64 + (int64_t)hdp::MAX_CHUNKS * 12 + 4096;
+    return 4096 + n * 12 + 64 + (int64_t)hdp::MAX_CHUNKS * 12 + 4096 + HADOOP_SNAPPY_SLAB_BYTES;
 }
 
 hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize)
@@ -852,19 +867,20 @@ hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* 
     L.bStream = (int32_t*)take(4 * (int64_t)hdp::MAX_CHUNKS);
     L.bIndex = (int32_t*)take(4 * (int64_t)hdp::MAX_CHUNKS);
     L.bSize = (int32_t*)take(4 * (int64_t)hdp::MAX_CHUNKS);
+    uint16_t* const slabs = (uint16_t*)take(HADOOP_SNAPPY_SLAB_BYTES - 64);
     const unsigned perStream = (unsigned)((a.nBlocks + 63) / 64);
-    const unsigned encodeGrid = 256 * (snappy ? 4 : 8);
+    const unsigned encodeGrid = snappy ? HADOOP_SNAPPY_WORKGROUPS : 256 * 10;  // (LZ4: chunks beyond 64 KiB take the 16 KB table: ten wavefronts per CU)
     const unsigned compactGrid = (unsigned)a.nBlocks;
     if (snappy) {
         hipLaunchKernelGGL(hdp::hadoop_plan_kernel<true>, dim3(perStream), dim3(64), 0, stream, a, L, bufferSize);
         hipLaunchKernelGGL(hdp::hadoop_seal_blocks_kernel, dim3(1), dim3(1), 0, stream, L);
-        hipLaunchKernelGGL(hdp::hadoop_encode_kernel<true>, dim3(encodeGrid), dim3(64), 0, stream, a, L, bufferSize);
+        hipLaunchKernelGGL(hdp::hadoop_encode_kernel<true>, dim3(encodeGrid), dim3(256), 0, stream, a, L, bufferSize, slabs);
         hipLaunchKernelGGL(hdp::hadoop_compact_kernel<true>, dim3(compactGrid), dim3(64), 0, stream, a, L, bufferSize);
     }
     else {
         hipLaunchKernelGGL(hdp::hadoop_plan_kernel<false>, dim3(perStream), dim3(64), 0, stream, a, L, bufferSize);
         hipLaunchKernelGGL(hdp::hadoop_seal_blocks_kernel, dim3(1), dim3(1), 0, stream, L);
-        hipLaunchKernelGGL(hdp::hadoop_encode_kernel<false>, dim3(encodeGrid), dim3(64), 0, stream, a, L, bufferSize);
+        hipLaunchKernelGGL(hdp::hadoop_encode_kernel<false>, dim3(encodeGrid), dim3(64), 0, stream, a, L, bufferSize, slabs);
         hipLaunchKernelGGL(hdp::hadoop_compact_kernel<false>, dim3(compactGrid), dim3(64), 0, stream, a, L, bufferSize);
     }
     return hipGetLastError();
