@@ -53,6 +53,7 @@ int64_t hadoop_decompress_scratch_bytes(int32_t nStreams, int32_t bufferSize);
 hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize);
 int64_t hadoop_compress_scratch_bytes(int32_t nStreams);
 extern int g_zstd_pipe_exec;
+extern int g_zstd_pipe_seq;
 hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant, const AuxScratch* aux);
 int64_t lz4frame_decompress_scratch_bytes(int32_t nItems, int variant);
 hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch);
@@ -871,6 +872,10 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     else if (k == "lz4frame.decompress.variant") {
         if (value < 0 || value > 2) return bad_argument("lz4frame.decompress.variant: 0 a wavefront per item, 1 block list through the two-pass decoder, 2 chosen by a probe");
         ctx->lz4FrameDecompressVariant = (int)value;
+    }
+    else if (k == "zstd.decompress.seq") {
+        if (value < 0 || value > 1) return bad_argument("zstd.decompress.seq: 1 a lane per item, 0 a quad per item");
+        achip::g_zstd_pipe_seq = (int)value;
     }
     else if (k == "zstd.decompress.exec") {
         if (value < 0 || value > 2) return bad_argument("zstd.decompress.exec: 0 rings, 1 record executor, 2 chosen per item");

@@ -918,6 +918,173 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp
     }
 }
 
+// ---- K3, a lane per item (round 4) ----
+// The quad version above spreads one item over four lanes: 16 items and ~216 instructions per step and wavefront.  What bounds the stage
+// is the LDS: 2.5 KB of state tables per item, ~55 items per CU whatever the launch shape, each a serial chain -- so the rate is (items per
+// CU) / (time of one step), and a step of a wavefront costs its instruction count whether 16 or 60 of its lanes hold an item.  Here a LANE
+// owns an item: its three states, its bit container, its repeat-offset history; the three table lookups of a step are independent loads of
+// one lane, nothing is broadcast, the record goes straight to the arena (8 bytes per lane and step: the L2 merges a line's pieces).  60 items
+// per wavefront, one wavefront per CU (60 x 2576 B of LDS).  The tables are staged in the form  symbol | nextState << 6  (K1 publishes
+// symbol | rank << 6 and a count per symbol: nextState = count + rank is added here, once per entry, instead of a second dependent lookup
+// per step).
+namespace zp {
+constexpr int SEQL_ITEMS = 60;
+constexpr int SEQL_STRIDE = 1280 + 8;  // u16 per item in LDS (+ 16 bytes: consecutive items start on different banks)
+}
+template <bool MB>
+__global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs a, zp::Pipe p)
+{
+    using namespace zp;
+    __shared__ __attribute__((aligned(16))) uint16_t tables[SEQL_ITEMS * SEQL_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint16_t cntTmp[192];
+    __shared__ uint32_t codeTab[128];  // literal-length codes at 0.., match-length codes at 64..: baseline | extra bits << 24
+    const int lane = threadIdx.x;
+    {
+        int32_t base = 0, bits = 0;
+        achip_zstd_ll_code(lane < 36 ? lane : 0, &base, &bits);
+        codeTab[lane] = (uint32_t)base | ((uint32_t)bits << 24);
+        achip_zstd_ml_code(lane < 53 ? lane : 0, &base, &bits);
+        codeTab[64 + lane] = (uint32_t)base | ((uint32_t)bits << 24);
+    }
+    const int32_t slot = blockIdx.x * SEQL_ITEMS + lane;
+    bool valid = lane < SEQL_ITEMS && slot < p.count;
+    int32_t from0 = slot, from1 = slot, from2 = slot;  // the slots the literal-length, offset and match-length tables come from
+    if (MB && valid) {
+        const MbBlock b = p.mb[slot];
+        valid = b.kind == 2 && p.mbItem[b.itemSlot].state == 1;
+        from0 = b.fseSlot[0];
+        from1 = b.fseSlot[1];
+        from2 = b.fseSlot[2];
+    }
+    Desc d;
+    d.state = 0;
+    d.nbSeq = 0;
+    if (valid) {
+        d = p.desc[slot];
+    }
+    const bool live = valid && d.state == 1 && d.nbSeq > 0 && (!MB || (from0 >= 0 && from1 >= 0 && from2 >= 0));
+    if (MB && live) {
+        d.log[0] = p.desc[from0].log[0];
+        d.log[1] = p.desc[from1].log[1];
+        d.log[2] = p.desc[from2].log[2];
+    }
+    // stage the tables, item by item (each copy is done by the whole wavefront)
+    for (int k = 0; k < SEQL_ITEMS; k++) {  // (uniform)
+        if (__shfl(live ? 1 : 0, k) == 0) {
+            continue;
+        }
+        const int32_t f0 = __shfl(from0, k), f1 = __shfl(from1, k), f2 = __shfl(from2, k);
+        const uint16_t* gLL = p.fse + (size_t)f0 * FSE_SLOT;
+        const uint16_t* gOF = p.fse + (size_t)f1 * FSE_SLOT;
+        const uint16_t* gML = p.fse + (size_t)f2 * FSE_SLOT;
+        if (lane < 24) {  // the three count tables (64 entries each: 8 lanes x 16 bytes)
+            const int part = lane >> 3, i = lane & 7;
+            const uint16_t* g = part == 0 ? gLL : (part == 1 ? gOF : gML);
+            *(u32x4*)(cntTmp + 64 * part + 8 * i) = *(const u32x4*)(g + FSE_CNT + 64 * part + 8 * i);
+        }
+        __syncthreads();
+        for (int32_t piece = lane; piece < 160; piece += 64) {  // 1280 states, 8 per piece: LL 0..511, OF 512..767, ML 768..1279
+            const int32_t i = piece * 8;
+            const int part = i < FSE_OF ? 0 : (i < FSE_ML ? 1 : 2);
+            const uint16_t* g = part == 0 ? gLL : (part == 1 ? gOF : gML);
+            const u32x4 v = *(const u32x4*)(g + i);
+            const uint16_t* cnt = cntTmp + 64 * part;
+            auto conv = [&](uint32_t w) -> uint32_t {
+                const uint32_t e0 = w & 0xFFFF, e1 = w >> 16;
+                const uint32_t n0 = (uint32_t)cnt[e0 & 63] + (e0 >> 6), n1 = (uint32_t)cnt[e1 & 63] + (e1 >> 6);
+                return ((e0 & 63) | ((n0 & 1023) << 6)) | (((e1 & 63) | ((n1 & 1023) << 6)) << 16);
+            };
+            *(u32x4*)(tables + k * SEQL_STRIDE + i) = u32x4{conv(v.x), conv(v.y), conv(v.z), conv(v.w)};
+        }
+        __syncthreads();
+    }
+    if (!live) {
+        return;
+    }
+    const int32_t block = slot_item<MB>(p, slot);
+    const uint8_t* src = a.srcBase + a.srcOff[block];
+    const uint16_t* tLL = tables + lane * SEQL_STRIDE + FSE_LL;
+    const uint16_t* tOF = tables + lane * SEQL_STRIDE + FSE_OF;
+    const uint16_t* tML = tables + lane * SEQL_STRIDE + FSE_ML;
+    const int32_t logLL = d.log[0], logOF = d.log[1], logML = d.log[2];
+    uint64_t* rec = p.seq + d.seqBase;
+
+    QuadBits b;
+    bool bad = !b.init(src, d.seqStart, d.seqEnd);
+    int32_t nDecoded = 0;
+    // the repeat-offset history; MB: "what it was before the block", entries 0 .. 2 (see the quad version)
+    int32_t p0 = MB ? sx2::REP_SENTINEL : 1, p1 = MB ? (sx2::REP_SENTINEL | (1 << 16)) : 4, p2 = MB ? (sx2::REP_SENTINEL | (2 << 16)) : 8;
+    if (!bad) {
+        // initial states in stream order LL, OF, ML (:378-386)
+        int32_t sLL = (int32_t)peek_bits(b.consumed, b.bits, logLL) & 511;
+        int32_t sOF = (int32_t)peek_bits(b.consumed + logLL, b.bits, logOF) & 255;
+        int32_t sML = (int32_t)peek_bits(b.consumed + logLL + logOF, b.bits, logML) & 511;
+        b.consumed += logLL + logOF + logML;
+        int32_t sequenceCount = d.nbSeq;
+        // ZstdFrameDecompressor.java:388-486, straight-line as in the quad version: an irregular stream sets `bad` and keeps decoding
+        // harmless garbage (every index is masked) until the count runs out
+        while (sequenceCount > 0) {
+            sequenceCount--;
+            const bool over = b.load();
+            bad |= over && sequenceCount != 0;  // "Not all sequences were consumed"
+            sequenceCount = over ? 0 : sequenceCount;
+            const uint32_t eLL = tLL[sLL], eML = tML[sML], eOF = tOF[sOF];
+            const int32_t cLL = (int32_t)(eLL & 63), cML = (int32_t)(eML & 63), cOF = (int32_t)(eOF & 63);
+            const uint32_t tl = codeTab[cLL], tm = codeTab[64 + cML];
+            const int32_t xLL = (int32_t)(tl >> 24), xML = (int32_t)(tm >> 24), xOF = cOF & 31;
+            bad |= cLL > 35 || cML > 52 || cOF > 28;  // only reachable through a table the Java reader would also have rejected or mis-indexed
+            // extra bits are read in the order offset, match length, literal length
+            const int32_t vOF = (cOF < 2 ? cOF : (1 << xOF) - 3) + b.peek(b.consumed, xOF);
+            const int32_t matchLength = (int32_t)(tm & 0xFFFFFF) + b.peek(b.consumed + xOF, xML);
+            const int32_t literalsLength = (int32_t)(tl & 0xFFFFFF) + b.peek(b.consumed + xOF + xML, xLL);
+            const int32_t xsum = xLL + xML + xOF;
+            b.consumed += xsum;
+            if (xsum > 64 - 7 - (9 + 9 + 8)) {
+                b.load();
+            }
+            // state updates in the order LL, ML, OF
+            const int32_t nLL = (int32_t)(eLL >> 6), nML = (int32_t)(eML >> 6), nOF = (int32_t)(eOF >> 6);
+            const int32_t nbLL = (logLL - (31 - __builtin_clz((uint32_t)nLL | 1u))) & 15;
+            const int32_t nbML = (logML - (31 - __builtin_clz((uint32_t)nML | 1u))) & 15;
+            const int32_t nbOF = (logOF - (31 - __builtin_clz((uint32_t)nOF | 1u))) & 15;
+            sLL = ((nLL << nbLL) - (1 << logLL) + b.peek(b.consumed, nbLL)) & 511;
+            sML = ((nML << nbML) - (1 << logML) + b.peek(b.consumed + nbLL, nbML)) & 511;
+            sOF = ((nOF << nbOF) - (1 << logOF) + b.peek(b.consumed + nbLL + nbML, nbOF)) & 255;
+            b.consumed += nbLL + nbML + nbOF;
+            // repeat-offset history, :419-452
+            const int32_t raw = vOF + ((cOF <= 1 && cLL == 0) ? 1 : 0);
+            const bool rep = cOF <= 1;
+            // (a sentinel's low bits count the "- 1" steps: at most one per sequence, fewer than 2^16)
+            int32_t temp = raw == 3 ? ((MB && p0 >= sx2::REP_SENTINEL) ? p0 + 1 : p0 - 1) : (raw == 1 ? p1 : p2);
+            temp = temp == 0 ? 1 : temp;
+            const bool shift2 = rep ? (raw != 0 && raw != 1) : true;   // p2 = p1
+            const bool shift1 = rep ? raw != 0 : true;                 // p1 = p0, p0 = new
+            const int32_t offset = rep ? (raw != 0 ? temp : p0) : raw;
+            p2 = shift2 ? p1 : p2;
+            p1 = shift1 ? p0 : p1;
+            p0 = shift1 ? offset : p0;
+            // an offset beyond 2^24 cannot be a valid back-reference (the window is at most 2^23); keeps the record fields in range and
+            // the sentinels apart from real offsets
+            bad |= offset <= 0 || (offset > (1 << 24) && !(MB && rep && offset >= sx2::REP_SENTINEL));
+            if (!over) {
+                rec[nDecoded] = (uint64_t)(uint32_t)literalsLength | ((uint64_t)(uint32_t)matchLength << 18) | ((uint64_t)(uint32_t)(offset & 0xFFFFFFF) << 36);
+            }
+            nDecoded += over ? 0 : 1;
+        }
+    }
+    if (bad) {
+        slot_to_fallback<MB>(p, slot, 3);
+    }
+    else {
+        p.desc[slot].nDecoded = nDecoded;
+        if (MB) {
+            p.mb[slot].repOut[0] = p0;
+            p.mb[slot].repOut[1] = p1;
+            p.mb[slot].repOut[2] = p2;
+        }
+    }
+}
+
 // ---- K4: execute ----
 template <int GS, int IN_RING, int OUT_RING>
 __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp::Pipe p, int32_t mode)
@@ -1054,6 +1221,7 @@ __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp:
 // 128 KiB frames: fragments data -- 100 bytes per sequence -- 720 against 600 GiB/s; corpus -- 13 bytes per sequence -- 83 against 105), and the
 // item's capacity over its sequence count is what both kernels can see (an upper bound of the bytes per sequence: a caller that hands over far
 // more capacity than the frame needs gets the ring version).
+int g_zstd_pipe_seq = 1;   // context option zstd.decompress.seq: 1 = the sequence stage with a lane per item (default), 0 = a quad per item
 int g_zstd_pipe_exec = 2;  // context option zstd.decompress.exec: 2 = per item (default), 1 = this kernel, 0 = the ring version above
 
 template <int WIN = sx2::WIN_DEFAULT>
@@ -1725,7 +1893,12 @@ hipError_t launch_zstd_mb_stages(const BatchArgs& a, hipStream_t stream, zp::Pip
         hipLaunchKernelGGL(zstd_mb_fill_kernel, dim3((nItems + 63) / 64), dim3(64), 0, stream, a, p);
         hipLaunchKernelGGL(zstd_mb_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
         hipLaunchKernelGGL(zstd_pipe_literals_kernel<true>, dim3(w16), dim3(64), 0, stream, a, p);
-        hipLaunchKernelGGL(zstd_pipe_sequences_kernel<true>, dim3(w16), dim3(64), 0, stream, a, p);
+        if (g_zstd_pipe_seq != 0) {
+            hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<true>, dim3((unsigned)((p.count + zp::SEQL_ITEMS - 1) / zp::SEQL_ITEMS)), dim3(64), 0, stream, a, p);
+        }
+        else {
+            hipLaunchKernelGGL(zstd_pipe_sequences_kernel<true>, dim3(w16), dim3(64), 0, stream, a, p);
+        }
         hipLaunchKernelGGL(zstd_mb_execute_kernel<>, dim3(nItems), dim3(64), 0, stream, a, p);
         hipLaunchKernelGGL(zstd_mb_checksum_kernel, dim3((nItems + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE), dim3(64), 0, stream, a, p);
     }
@@ -1778,7 +1951,12 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
         // (items per wavefront in K2 / K3 of 8 instead of 16, and an 8 KiB window for the record executor, were round-2 experiments: measured in
         // round 3 within noise of the defaults on all three data sets -- profiles/r03_notes.md -- and removed)
         hipLaunchKernelGGL(zstd_pipe_literals_kernel<false>, dim3(w16), dim3(64), 0, stream, a, p);
-        hipLaunchKernelGGL(zstd_pipe_sequences_kernel<false>, dim3((unsigned)((p.count + zp::SEQ_ITEMS_PER_WAVE - 1) / zp::SEQ_ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
+        if (g_zstd_pipe_seq != 0) {
+            hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<false>, dim3((unsigned)((p.count + zp::SEQL_ITEMS - 1) / zp::SEQL_ITEMS)), dim3(64), 0, stream, a, p);
+        }
+        else {
+            hipLaunchKernelGGL(zstd_pipe_sequences_kernel<false>, dim3((unsigned)((p.count + zp::SEQ_ITEMS_PER_WAVE - 1) / zp::SEQ_ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
+        }
         constexpr int GS = 4, IN_RING = 128, OUT_RING = 256;
         if (g_zstd_pipe_exec != 0) {
             hipLaunchKernelGGL(zstd_pipe_execute2_kernel<>, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, (int32_t)g_zstd_pipe_exec);

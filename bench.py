@@ -57,6 +57,7 @@ def parse_args():
     p.add_argument("--exec-variant", type=int, default=-1, help="DEBUG: decompress.exec_variant (two-pass decoders)")
     p.add_argument("--section", default="all", choices=["all", "zstd", "zstdstream", "xxhash", "lz4frame"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-exec", type=int, default=-1, help="zstd pipeline execute stage: 2 = chosen per item (default), 1 = wavefront per item through the record executor, 0 = LDS rings")
+    p.add_argument("--zstd-seq", type=int, default=-1, help="zstd pipeline sequence stage: 1 = a lane per item (default), 0 = a quad per item")
     p.add_argument("--snappyframed-variant", type=int, default=-1, help="x-snappy-framed reader: 3 = ring or two-pass decoder by a probe (default), 1 = chunks through the ring decoders, 2 = through the two-pass decoder, 0 = a wavefront per stream")
     p.add_argument("--lz4frame-variant", type=int, default=-1, help="LZ4 frame reader: 2 = by a probe (default), 0 = a wavefront per item, 1 = the frames' blocks as one batch through the two-pass block decoder")
     p.add_argument("--hadoop-variant", type=int, default=-1, help="Hadoop block-stream reader: 3 = ring or two-pass decoders by a probe (default), 1 = chunks through the ring decoders, 2 = through the two-pass decoders, 0 = a wavefront per stream")
@@ -165,26 +166,112 @@ def gen_wordmix(torch, dev, n_blocks, block_size, seed):
     return torch.cat(out)[:total].contiguous()
 
 
+def relaunch_with_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command under torch.distributed.run (one process per GPU,
+    rank r on cuda:r) and hand its exit code on.  The driver's own `python -m torch.distributed.run ... bench.py --gpus N` form sets WORLD_SIZE
+    and never comes here."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:  # a free port for the rendezvous
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def stub_main(args, rank, world, dist):
+    """ACHIP_BENCH_STUB_DEVICE=1: the control plane of an N-rank run WITHOUT a device -- launch, rendezvous, shard_for_rank, barrier, timed steps,
+    MAX over ranks, per-rank gather, ONE line from rank 0 -- with a host memcpy standing in for the kernel.  tests/test_bench_launch.py runs it on
+    the CPU; the line says "stub" and is never a result."""
+    from aircompressor_amd.sharding import shard_for_rank
+    bs = args.block_size
+    n_global = args.blocks * world
+    lo, hi = shard_for_rank(np.full(n_global, bs, dtype=np.int64), world, rank)
+    n_local = hi - lo
+    a = np.zeros(min(n_local, 256) * bs, dtype=np.uint8)
+    b = np.empty_like(a)
+    for _ in range(args.warmup):
+        np.copyto(b, a)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        np.copyto(b, a)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    per_rank = [elapsed_local]
+    if world > 1:
+        import torch
+        dist.barrier()
+        t = torch.tensor([elapsed_local], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, elapsed_local)
+    if rank == 0:
+        print(json.dumps({"metric": "GiB/s decompressed throughput (Zstd+LZ4) at 1/2/4/8 GPUs; % of HBM3E roofline", "value": 0.0, "unit": "GiB/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "stub (ACHIP_BENCH_STUB_DEVICE=1: no device, control plane only -- not a result)",
+                          "stub": True, "config": {"workload": "stub", "blocks_per_gpu": n_local, "shard": [lo, hi], "per_rank_seconds": per_rank}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     args = parse_args()
-    import torch
-    import aircompressor_amd as A
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return relaunch_with_ranks(args.gpus)  # --gpus N means N ranks: started here when no launcher did
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # the line's n_gpus must be what was asked for: a launcher that started another number of ranks is an error, not a silent N
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report one under the other's name" % (args.gpus, world), file=sys.stderr)
+        return 2
+    dist = None
     if world > 1:
         # control plane only (barrier + MAX of the elapsed time, on CPU tensors): gloo -- the data path has no collective and needs no
         # RCCL (north_star: "per-GPU batch split, no RCCL needed")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo")
-    if os.environ.get("ACHIP_BENCH_SHARE_DEVICE") == "1":
+    if os.environ.get("ACHIP_BENCH_STUB_DEVICE") == "1":
+        return stub_main(args, rank, world, dist)
+    import torch
+    import aircompressor_amd as A
+
+    share = os.environ.get("ACHIP_BENCH_SHARE_DEVICE") == "1"
+    if share:
         # PATH CHECK ONLY (never a scaling number): every rank uses device 0, so that the N > 1 path -- rendezvous, shard_for_rank, barrier,
         # max-over-ranks, one JSON line from rank 0, verification on every rank -- can be executed end to end on a box with one GPU
         local_rank = 0
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:
+        print("bench.py: rank %d wants cuda:%d but the node has %d device(s) (ACHIP_BENCH_SHARE_DEVICE=1 runs every rank on cuda:0 as a path check)" % (rank, local_rank, n_dev), file=sys.stderr)
+        return 3
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        # N ranks must sit on N distinct devices
+        props = torch.cuda.get_device_properties(local_rank)
+        ident = "%s/%s" % (getattr(props, "uuid", ""), getattr(props, "pci_bus_id", local_rank))
+        idents = [None] * world
+        dist.all_gather_object(idents, (local_rank, ident))
+        if not share and len(set(idents)) != world:
+            if rank == 0:
+                print("bench.py: %d ranks on %d distinct devices %r" % (world, len(set(idents)), idents), file=sys.stderr)
+            return 3
 
     bs = args.block_size
     n_local_target = args.blocks
@@ -317,6 +404,7 @@ def main():
     codec.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if world > 1:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -372,6 +460,14 @@ def main():
             "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
         },
     }
+    # per rank: its own GiB/s and its kernel's fraction of the roofline (`value` is the whole job: all ranks' bytes over the slowest rank's time)
+    mine = {"rank": rank, "device": local_rank, "GiBps": round(plain_bytes_local * args.steps / elapsed_local / 2**30, 2), "kernel_ms_avg": round(kavg * 1e3, 4),
+            "roofline_frac": round(achieved / HBM_PEAK_GBS, 4)}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    result["per_rank"] = per_rank
     # roofline.traffic: HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 passes: tools/make_traffic_json.py
     # writes profiles/traffic.json with the hash of the kernel sources it measured).  Counters cannot be collected inside this process, so
     # the figure is the committed measurement -- and only if it was taken on THESE kernel sources and this batch size; otherwise null.
@@ -423,6 +519,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 def kernel_sources_hash():
@@ -632,6 +729,8 @@ def zstd_extra(torch, A, codec, dev, args):
         codec.native.set_option("zstd.decompress.variant", args.zstd_variant)
     if args.zstd_exec >= 0:
         codec.native.set_option("zstd.decompress.exec", args.zstd_exec)
+    if args.zstd_seq >= 0:
+        codec.native.set_option("zstd.decompress.seq", args.zstd_seq)
     if args.zstd_compress_variant >= 0:
         codec.native.set_option("zstd.compress.variant", args.zstd_compress_variant)
     zc = pa.Codec("zstd", compression_level=3)
@@ -898,4 +997,4 @@ def cpu_baseline(torch, pool_pack, pool_pack_off, pool_clen, pool_plain, bs, op,
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)
