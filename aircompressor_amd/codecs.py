@@ -315,10 +315,19 @@ class ZstdHipInputStream:
     in whole-buffer form like the other stream twins: the first read takes everything the source holds, asks the library for the bound of
     what the frames decode to (achip_zstd_decompress_bound: frame and block headers only -- frames need NOT carry a content size, which
     ZstdOutputStream's do not from 4 MiB on), decodes all frames in one call of the batched decoder and hands the plaintext out as asked.
-    What differs from the Java stream: a damaged stream fails at the first read, not at the read that reaches the damage."""
+    What differs from the Java stream: a damaged stream fails at the first read, not at the read that reaches the damage; and the whole
+    plaintext is held at once, where ZstdInputStream needs a window.  The bound of a few bytes of input can be huge (every 4-byte RLE block
+    header announces up to 128 KiB; 4 KB of such headers: 2 GiB), so the one-shot allocation is capped: a stream whose bound exceeds
+    `max_decoded_bytes` (DEFAULT_MAX_DECODED_BYTES = 1 GiB unless the caller says otherwise; None = no cap) is refused with an IOError
+    before anything is allocated.  INTEGRATION.md section 6 states the limit for the Java twin as well."""
 
-    def __init__(self, source, device=0, native_ctx=None):
+    DEFAULT_MAX_DECODED_BYTES = 1 << 30
+
+    def __init__(self, source, device=0, native_ctx=None, max_decoded_bytes=DEFAULT_MAX_DECODED_BYTES):
+        if max_decoded_bytes is not None and max_decoded_bytes < 0:
+            raise ValueError("max_decoded_bytes must be >= 0 or None")
         self._source = source
+        self._max_decoded = max_decoded_bytes
         self._codec = ZstdHipDecompressor(device, native_ctx)
         self._plain = None
         self._pos = 0
@@ -336,6 +345,9 @@ class ZstdHipInputStream:
         bound = self._codec._lib.achip_zstd_decompress_bound(src.ctypes.data, int(src.size), ctypes.byref(eo))
         if bound < 0:
             native.raise_for_status(int(bound), eo.value)
+        if self._max_decoded is not None and bound > self._max_decoded:
+            # (memory amplification, not corruption: the frames may well be legal -- ADVICE round 3)
+            raise IOError("Decoded size bound %d exceeds max_decoded_bytes %d" % (int(bound), int(self._max_decoded)))
         out = bytearray(max(int(bound), 1))
         n = self._codec.decompress(data, 0, len(data), out, 0, int(bound)) if bound > 0 else 0
         self._plain = bytes(out[:n])

@@ -75,7 +75,7 @@ struct achip_ctx {
     int snappydVariant = 5;  // 1 rings (snappy_decompress_v2.hip), 4 / 6 a lane per block (snappy_decompress_v3.hip / _v4.hip), 5 auto as for LZ4
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
     int lz4cVariant = 4;     // 4 = many matches per window of 64 positions (lz4_compress_mw.h; default since round 3: 25.8 against 18.2 GiB/s on corpus, 100 against 111 on fragments), 0 = serial probes, 1 = 64 probes per step (batch).  (3, the batch over an LDS input window, measured 17.2 against 18.2 GiB/s on corpus in round 3: removed)
-    int snappycVariant = 4;  // 4 = two tiers, many matches per window (snappy_compress_mw.h; default since round 3: 22.0 against 8.3 GiB/s on corpus, 65 against 74 on fragments); 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory, 3 = 2 with an LDS input window (snappy_compress_v3.hip; the default since round 3: 8.3 against 7.6 GiB/s on corpus, 75.4 against 74.1 on fragments)
+    int snappycVariant = 4;  // THE DEFAULT IS 4 = two tiers, many matches per window (snappy_compress_mw.h; since round 3: 22.0 against 8.3 GiB/s on corpus, 65 against 74 on fragments); tested non-default variants: 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory, 3 = 2 with an LDS input window (snappy_compress_v3.hip: 8.3 against 7.6 GiB/s on corpus for 2)
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 3;  // match kernel in window form (zstd_dfast_mw.h) + entropy kernel
     int hadoopBufferSize = 262144;        // Hadoop block streams: the streams' buffer size (Lz4HadoopStreams.java:30; io.compression.codec.*.buffersize)
@@ -173,6 +173,7 @@ achip::BatchArgs make_args(const void* srcBase, const int64_t* srcOff, const int
 }
 
 int32_t ensure_scratch(achip_ctx* ctx, int64_t bytes);
+int32_t grow_scratch_keeping_old(achip_ctx* ctx, int64_t bytes);
 // The two-pass decoders' scratch (lead bytes of probe statistics + header, meta and record arena): the full arena (`perBlock` bytes of
 // records per block) if the device has it to spare -- never more than half of what is free right now beyond what the context already
 // holds, so that one large batch does not take the device from its other users --, else what is there down to `perBlockMin` (blocks whose
@@ -199,10 +200,20 @@ int32_t ensure_twopass_scratch(achip_ctx* ctx, int64_t lead, int32_t nBlocks, in
     if (ask <= ctx->scratchBytes) {
         return ctx->scratchBytes >= atLeast ? 1 : 0;
     }
-    if (ensure_scratch(ctx, ask) == 0) {
+    // Grow WITHOUT giving up what is there: the new buffer is allocated first and the old one freed only when that worked, so a
+    // context never loses a working scratch to a failed request.  Only a context whose scratch is below the minimum anyway lets it go and
+    // asks again (the device may have room for one of the two, not both).
+    if (grow_scratch_keeping_old(ctx, ask) == 0) {
         return 1;
     }
-    if (ask > atLeast && ensure_scratch(ctx, atLeast) == 0) {
+    if (ask > atLeast && ctx->scratchBytes < atLeast && grow_scratch_keeping_old(ctx, atLeast) == 0) {
+        return 1;
+    }
+    if (ctx->scratchBytes >= atLeast) {
+        g_lastError.clear();
+        return 1;  // what is there serves (fewer records per block: more blocks go to the ring decoder -- decompress.twopass_fallback_blocks)
+    }
+    if (ensure_scratch(ctx, atLeast) == 0) {  // (frees the old scratch first)
         return 1;
     }
     g_lastError.clear();
@@ -227,6 +238,33 @@ int32_t ensure_scratch(achip_ctx* ctx, int64_t bytes)
         (void)hipGetLastError();  // not sticky: the caller may retry with a smaller request
         return device_failure("hipMalloc(scratch)", e);
     }
+    ctx->scratchBytes = bytes;
+    return 0;
+}
+
+// bytes > what is there: allocates the larger buffer, then -- only then -- frees the old one.  Non-zero (and nothing changed) when the device
+// cannot hold both.
+int32_t grow_scratch_keeping_old(achip_ctx* ctx, int64_t bytes)
+{
+    if (bytes <= ctx->scratchBytes) {
+        return 0;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    void* fresh = nullptr;
+    const hipError_t e = hipMalloc(&fresh, (size_t)bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    if (ctx->scratch) {
+        const hipError_t s = hipStreamSynchronize(ctx->stream);
+        if (s != hipSuccess) {
+            (void)hipFree(fresh);
+            return device_failure("hipStreamSynchronize", s);
+        }
+        (void)hipFree(ctx->scratch);
+    }
+    ctx->scratch = fresh;
     ctx->scratchBytes = bytes;
     return 0;
 }
@@ -951,6 +989,9 @@ int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name)
         const bool mixed = (int64_t)v[0] * 4 > (ctx->lastAutoBlocks + 15) / 16;
         const bool isShort = v[1] > 0 && (int64_t)v[2] < (ctx->lastAutoIsLz4 ? 12 : 6) * (int64_t)v[1];
         return (mixed || isShort) ? 3 : 0;
+    }
+    if (k == "decompress.scratch_bytes") {  // the context's decode scratch as granted (the two-pass decoders' record arena is what lies behind its fixed part): a smaller grant than a batch asked for shows here and in decompress.twopass_fallback_blocks
+        return ctx->scratchBytes;
     }
     if (k == "decompress.twopass_fallback_blocks") {  // blocks the last two-pass LZ4 / Snappy decode handed to the ring decoder (-1: none ran)
         if (!ctx->lastTwopass || ctx->scratch == nullptr) return -1;

@@ -46,7 +46,7 @@ def parse_args():
     p.add_argument("--group", type=int, default=0, help="decoder lanes per block (0 = library default)")
     p.add_argument("--variant", type=int, default=-1, help="decoder variant: 5 = chosen on the device (default), 1 = LDS rings, 7 = two passes, 4 / 6 = a lane per block")
     p.add_argument("--ring-class", type=int, default=-1, help="0 = compact LDS rings, 1 = large")
-    p.add_argument("--compress-variant", type=int, default=-1, help="LZ4 / Snappy encoder variant (see lz4.compress.variant)")
+    p.add_argument("--compress-variant", type=int, default=-1, help="LZ4 / Snappy encoder variant: 4 = many matches per window (the default of both); LZ4 also 0 / 1, Snappy 0 .. 3 (see lz4.compress.variant / snappy.compress.variant)")
     p.add_argument("--ring-pad", type=int, default=-1, help="LDS bytes between the ring pairs of consecutive blocks (multiple of 16)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true")
@@ -257,8 +257,11 @@ def main():
         # max-over-ranks, one JSON line from rank 0, verification on every rank -- can be executed end to end on a box with one GPU
         local_rank = 0
     n_dev = torch.cuda.device_count()
-    if local_rank >= n_dev:
-        print("bench.py: rank %d wants cuda:%d but the node has %d device(s) (ACHIP_BENCH_SHARE_DEVICE=1 runs every rank on cuda:0 as a path check)" % (rank, local_rank, n_dev), file=sys.stderr)
+    if (not share and world > n_dev) or local_rank >= n_dev:  # (every rank sees the same counts: all of them leave, nobody waits in a collective)
+        if rank == 0:
+            print("bench.py: %d ranks but the node has %d device(s) (ACHIP_BENCH_SHARE_DEVICE=1 runs every rank on cuda:0 as a path check)" % (world, n_dev), file=sys.stderr)
+        if world > 1:
+            dist.destroy_process_group()
         return 3
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -291,7 +294,7 @@ def main():
     if args.ring_class >= 0:
         codec.native.set_option("decompress.ring_class", args.ring_class)
     if args.compress_variant >= 0:
-        # (one flag for both codecs' encoders: each takes the values it knows -- LZ4 0 / 1 / 4, Snappy 0 .. 3)
+        # (one flag for both codecs' encoders: each takes the values it knows -- LZ4 0 / 1 / 4, Snappy 0 .. 4; 4 is the default of both)
         if args.compress_variant in (0, 1, 4):
             codec.native.set_option("lz4.compress.variant", args.compress_variant)
         if args.compress_variant <= 4:
@@ -663,6 +666,9 @@ def lz4frame_extra(torch, A, codec, dev, args):
     GPU encode (byte-identical to the Java frame encoder), then GPU decode, verified against the plaintext.
     SURVEY 8f row 2: x-snappy-framed streams of 4 MiB (what SnappyFramedOutputStream writes: 64 KiB chunks with masked CRC-32C)."""
     out = container_extra(torch, A, codec, dev, args, "lz4frame", A.OP_LZ4FRAME_COMPRESS, A.OP_LZ4FRAME_DECOMPRESS)
+    # the same container in a batch that can fill the chip (1024 frames of one 4 MiB block each are 1024 units of work for 1024 SIMDs): 16384
+    # frames of 256 KiB -- still one block per frame (the writer's block size is 4 MiB: Lz4FrameCompression.java:93-133)
+    out.update(container_extra(torch, A, codec, dev, args, "lz4frame", A.OP_LZ4FRAME_COMPRESS, A.OP_LZ4FRAME_DECOMPRESS, fs=256 << 10, n=16384, suffix="256k"))
     out.update(container_extra(torch, A, codec, dev, args, "snappyframed", A.OP_SNAPPYFRAMED_COMPRESS, A.OP_SNAPPYFRAMED_DECOMPRESS))
     # SURVEY 8f row 2, second half: Hadoop block streams of 4 MiB (what Lz4HadoopOutputStream / SnappyHadoopOutputStream write at the default
     # 256 KiB buffer: [BE length][BE length][block] per 259523 / 218422 plaintext bytes)
@@ -671,9 +677,8 @@ def lz4frame_extra(torch, A, codec, dev, args):
     return out
 
 
-def container_extra(torch, A, codec, dev, args, name, cop, dop, max_c=None):
+def container_extra(torch, A, codec, dev, args, name, cop, dop, max_c=None, fs=4 << 20, n=1024, suffix=""):
     out = {}
-    fs, n = 4 << 20, 1024
     lib = codec.lib
     if max_c is None:
         max_c = getattr(lib, "achip_%s_max_compressed_length" % name)(fs)
@@ -709,10 +714,15 @@ def container_extra(torch, A, codec, dev, args, name, cop, dop, max_c=None):
         cbytes = int(clen.to(torch.int64).sum())
         td = timed(lambda: codec.launch(dop, comp, c_off, clen, back, p_off, p_len, blen, st, eo, n), 2)
         assert int((st != 0).sum()) == 0 and bool((back[:n * fs] == plain).all())
-        out["%s_%s" % (name, data_kind)] = {
+        entry = {
             "ratio": round(n * fs / cbytes, 3), "compress_GiBps": round(n * fs / tc / 2**30, 2), "decompress_GiBps": round(n * fs / td / 2**30, 2),
             "decompress_hbm_frac": round((n * fs + cbytes) / td / 1e9 / HBM_PEAK_GBS, 4), "frames": n, "frame_bytes": fs,
         }
+        if not args.no_cpu_baseline:
+            # the CPU leg beside it: the oracle's writer / reader of the same container over the first streams of this
+            # very batch (256 MiB of plaintext), all host threads, one stream per call
+            entry.update(cpu_pair(torch, dop, cop, plain, comp, c_off, clen, min(n, max(host_threads(), (256 << 20) // fs)), fs, int(max_c), args.cpu_leg_seconds))
+        out["%s%s_%s" % (name, suffix, data_kind)] = entry
         del comp, back, plain
     return out
 
@@ -897,11 +907,18 @@ def zstd_stream_extra(torch, A, codec, dev, args):
         check()
         codec.native.set_option("zstd.decompress.stream_blocks", 65536)
         cbytes = int(lens.sum()) * reps
-        out["zstdstream_%s" % data_kind] = {
+        entry = {
             "ratio": round(n * fs / cbytes, 3), "decompress_GiBps": round(n * fs / t / 2**30, 2), "decompress_hbm_frac": round((n * fs + cbytes) / t / 1e9 / HBM_PEAK_GBS, 4),
             "one_kernel_decoder_GiBps": round(n * fs / t1 / 2**30, 2), "frames": n, "frame_bytes": fs, "blocks": blocks, "multiblock_fast_items": fast,
             "encoder": "libzstd level 3 via pyarrow %s" % pa.__version__,
         }
+        if not args.no_cpu_baseline and args.cpu_leg_seconds > 0:
+            # CPU leg: the oracle's decoder (the Java frame decoder restated) over the same frames, one frame per call, all host threads
+            T = host_threads()
+            tile = max(1, (T + pool_n - 1) // pool_n)
+            d, _ = cpu_rate(A.OP_ZSTD_DECOMPRESS, pack, np.tile(offs, tile), np.tile(lens.astype(np.int32), tile), fs, T, args.cpu_leg_seconds)
+            entry.update({"cpu_decompress_GiBps": round(d, 2), "cpu_threads": min(T, pool_n * tile), "cpu_sample_blocks": pool_n * tile})
+        out["zstdstream_%s" % data_kind] = entry
         del d_pack, dst, plain
     return out
 
@@ -958,7 +975,7 @@ def cpu_pair(torch, dop, cop, plain, comp, c_off, clen, n_sample, bs, max_c, sec
     h_comp = comp[:end].cpu().numpy()
     d, _ = cpu_rate(dop, h_comp, offs, lens, bs, T, seconds)
     c, _ = cpu_rate(cop, h_plain, np.arange(k, dtype=np.int64) * bs, np.full(k, bs, dtype=np.int32), max_c, T, seconds)
-    return {"cpu_decompress_GiBps": round(d, 2), "cpu_compress_GiBps": round(c, 2), "cpu_threads": T, "cpu_sample_blocks": k}
+    return {"cpu_decompress_GiBps": round(d, 2), "cpu_compress_GiBps": round(c, 2), "cpu_threads": min(T, k), "cpu_sample_blocks": k}
 
 
 def cpu_baseline(torch, pool_pack, pool_pack_off, pool_clen, pool_plain, bs, op, wl, seconds):

@@ -494,8 +494,10 @@ public final class HipNative
      * distinct contexts may be used from distinct threads.  Freed by a Cleaner.
      */
     public static final class Context
+            implements AutoCloseable
     {
         private final MemorySegment handle;
+        private final java.util.concurrent.atomic.AtomicBoolean destroyed = new java.util.concurrent.atomic.AtomicBoolean();
         private final MemorySegment errorOffset = Arena.ofAuto().allocate(JAVA_LONG);
         private final java.lang.ref.Cleaner.Cleanable cleanable;
 
@@ -514,7 +516,7 @@ public final class HipNative
             }
             handle = created;
             MethodHandle destroy = HANDLES.ctxDestroy();
-            java.util.concurrent.atomic.AtomicBoolean destroyed = new java.util.concurrent.atomic.AtomicBoolean();
+            java.util.concurrent.atomic.AtomicBoolean destroyed = this.destroyed;  // (the cleaner's action must not capture `this`)
             this.cleanable = CLEANER.register(this, () -> {
                 if (destroyed.compareAndSet(false, true)) {
                     try {
@@ -526,14 +528,27 @@ public final class HipNative
             });
         }
 
-        /** Frees the native context (HIP stream, device scratch) now; the cleaner is only the backstop for contexts nobody closed. */
+        /**
+         * Frees the native context (HIP stream, device scratch) now; the cleaner is only the backstop for contexts nobody closed.
+         * Every entry point of a closed context throws {@link IllegalStateException}: the native pointer is never handed out again.
+         */
+        @Override
         public void close()
         {
             cleanable.clean();
         }
 
+        public boolean isClosed()
+        {
+            return destroyed.get();
+        }
+
+        /** the native context; throws once {@link #close()} has run (a freed pointer must not reach a downcall) */
         MemorySegment handle()
         {
+            if (destroyed.get()) {
+                throw new IllegalStateException("HipNative.Context is closed");
+            }
             return handle;
         }
 
@@ -541,7 +556,7 @@ public final class HipNative
         {
             int status;
             try {
-                status = (int) HANDLES.ctxSynchronize().invokeExact(handle);
+                status = (int) HANDLES.ctxSynchronize().invokeExact(handle());
             }
             catch (Throwable e) {
                 throw new AssertionError("should not reach here", e);
@@ -555,7 +570,7 @@ public final class HipNative
         public void setOption(String name, long value)
         {
             try (Arena arena = Arena.ofConfined()) {
-                int result = (int) HANDLES.ctxSetOption().invokeExact(handle, arena.allocateFrom(name), value);
+                int result = (int) HANDLES.ctxSetOption().invokeExact(handle(), arena.allocateFrom(name), value);
                 throwIfError(result, 0);
             }
             catch (RuntimeException e) {
@@ -589,7 +604,7 @@ public final class HipNative
                     case OP_SNAPPYHADOOP_DECOMPRESS -> HANDLES.snappyHadoopDecompress();
                     default -> throw new IllegalArgumentException("unknown op " + op);
                 };
-                result = (int) method.invokeExact(handle, input, output, inputLength, outputLength, errorOffset);
+                result = (int) method.invokeExact(handle(), input, output, inputLength, outputLength, errorOffset);
             }
             catch (RuntimeException e) {
                 throw e;
@@ -630,7 +645,7 @@ public final class HipNative
                     case OP_SNAPPYHADOOP_DECOMPRESS -> HANDLES.snappyHadoopDecompressBatch();
                     default -> throw new IllegalArgumentException("unknown op " + op);
                 };
-                result = (int) method.invokeExact(handle, srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, blocks);
+                result = (int) method.invokeExact(handle(), srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, blocks);
             }
             catch (RuntimeException e) {
                 throw e;
@@ -649,7 +664,7 @@ public final class HipNative
         {
             int result;
             try {
-                result = (int) HANDLES.batchHost().invokeExact(op, handle, srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, blocks);
+                result = (int) HANDLES.batchHost().invokeExact(op, handle(), srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, blocks);
             }
             catch (Throwable e) {
                 throw new AssertionError("should not reach here", e);
@@ -662,7 +677,7 @@ public final class HipNative
         public MemorySegment allocateDevice(long bytes)
         {
             try {
-                MemorySegment segment = (MemorySegment) HANDLES.deviceAlloc().invokeExact(handle, bytes);
+                MemorySegment segment = (MemorySegment) HANDLES.deviceAlloc().invokeExact(handle(), bytes);
                 if (segment.address() == 0) {
                     throw new OutOfMemoryError("achip_device_alloc(" + bytes + ") failed: " + lastError());
                 }
@@ -679,7 +694,7 @@ public final class HipNative
         public void freeDevice(MemorySegment segment)
         {
             try {
-                int ignored = (int) HANDLES.deviceFree().invokeExact(handle, segment);
+                int ignored = (int) HANDLES.deviceFree().invokeExact(handle(), segment);
             }
             catch (Throwable e) {
                 throw new AssertionError("should not reach here", e);
@@ -689,7 +704,7 @@ public final class HipNative
         public void copyToDevice(MemorySegment device, MemorySegment host, long bytes)
         {
             try {
-                int status = (int) HANDLES.memcpyHostToDevice().invokeExact(handle, device, host, bytes);
+                int status = (int) HANDLES.memcpyHostToDevice().invokeExact(handle(), device, host, bytes);
                 if (status < 0) {
                     throw toException(status, 0);
                 }
@@ -705,7 +720,7 @@ public final class HipNative
         public void copyToHost(MemorySegment host, MemorySegment device, long bytes)
         {
             try {
-                int status = (int) HANDLES.memcpyDeviceToHost().invokeExact(handle, host, device, bytes);
+                int status = (int) HANDLES.memcpyDeviceToHost().invokeExact(handle(), host, device, bytes);
                 if (status < 0) {
                     throw toException(status, 0);
                 }

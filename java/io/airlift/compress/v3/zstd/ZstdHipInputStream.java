@@ -27,14 +27,20 @@ import static java.util.Objects.requireNonNull;
  * the first read takes everything the underlying stream holds, asks {@code achip_zstd_decompress_bound} what the frames can decode to
  * (from their frame and block headers: the frames need NOT carry a content size -- {@code ZstdOutputStream}'s do not from 4 MiB on), decodes
  * all frames in one call and hands the plaintext out as asked.  A damaged stream fails at that first read, not at the read that reaches
- * the damage.  To read many streams at once use {@link io.airlift.compress.v3.hip.HipBatchCodec} with
+ * the damage.  The whole plaintext is held at once, and the bound of a few bytes of input can be huge (every 4-byte RLE block header
+ * announces up to 128 KiB): a stream whose bound exceeds {@code maxDecodedBytes} (default {@link #DEFAULT_MAX_DECODED_BYTES}, 1 GiB) is refused
+ * with an {@link IOException} before anything is allocated -- {@code ZstdInputStream} decodes the same stream in a window's worth of memory.
+ * To read many streams at once use {@link io.airlift.compress.v3.hip.HipBatchCodec} with
  * {@link HipNative#OP_ZSTD_DECOMPRESS}: one item per stream, capacities from {@link HipNative#zstdDecompressBound}.
  */
 public final class ZstdHipInputStream
         extends InputStream
 {
+    public static final long DEFAULT_MAX_DECODED_BYTES = 1L << 30;
+
     private final InputStream inputStream;
     private final int device;
+    private final long maxDecodedBytes;
     private byte[] plain;
     private int position;
     private boolean closed;
@@ -46,9 +52,18 @@ public final class ZstdHipInputStream
 
     public ZstdHipInputStream(InputStream inputStream, int device)
     {
+        this(inputStream, device, DEFAULT_MAX_DECODED_BYTES);
+    }
+
+    public ZstdHipInputStream(InputStream inputStream, int device, long maxDecodedBytes)
+    {
         this.inputStream = requireNonNull(inputStream, "inputStream is null");
+        if (maxDecodedBytes < 0) {
+            throw new IllegalArgumentException("maxDecodedBytes is negative");
+        }
         HipNative.verifyEnabled();
         this.device = device;
+        this.maxDecodedBytes = maxDecodedBytes;
     }
 
     private void fill()
@@ -63,18 +78,18 @@ public final class ZstdHipInputStream
             throw new IOException("Not enough input bytes");
         }
         long bound = HipNative.zstdDecompressBound(MemorySegment.ofArray(input));
+        if (bound > maxDecodedBytes) {
+            // (memory amplification, not corruption: the frames may well be legal)
+            throw new IOException("Decoded size bound " + bound + " exceeds maxDecodedBytes " + maxDecodedBytes);
+        }
         if (bound > Integer.MAX_VALUE - 8) {
             throw new IOException("Stream decodes to more than a byte[] holds: " + bound);
         }
         byte[] output = new byte[(int) Math.max(bound, 1)];
         int size = 0;
         if (bound > 0) {
-            HipNative.Context context = new HipNative.Context(device);
-            try {
+            try (HipNative.Context context = new HipNative.Context(device)) {
                 size = context.singleBlock(HipNative.OP_ZSTD_DECOMPRESS, MemorySegment.ofArray(input), input.length, MemorySegment.ofArray(output), (int) bound);
-            }
-            finally {
-                context.close();
             }
         }
         plain = size == output.length ? output : java.util.Arrays.copyOf(output, size);

@@ -55,6 +55,16 @@ int64_t orc_batch(int32_t op, const uint8_t* src_base, const int64_t* src_off, c
             case ACHIP_OP_SNAPPY_COMPRESS: r = orc_snappy_compress(s, src_len[i], d, dst_cap[i]); break;
             case ACHIP_OP_ZSTD_DECOMPRESS: r = orc_zstd_decompress(s, src_len[i], d, dst_cap[i], &eo); break;
             case ACHIP_OP_ZSTD_COMPRESS: r = orc_zstd_compress(s, src_len[i], d, dst_cap[i]); break;
+            /* the containers, at the Hadoop streams' default buffer size: bench.py's CPU legs beside the container extras */
+            case ACHIP_OP_LZ4FRAME_DECOMPRESS: r = orc_lz4frame_decompress(s, src_len[i], d, dst_cap[i], &eo); break;
+            case ACHIP_OP_LZ4FRAME_COMPRESS: r = orc_lz4frame_compress(s, src_len[i], d, dst_cap[i]); break;
+            case ACHIP_OP_SNAPPYFRAMED_DECOMPRESS: r = orc_snappyframed_decompress(s, src_len[i], d, dst_cap[i], &eo); break;
+            case ACHIP_OP_SNAPPYFRAMED_COMPRESS: r = orc_snappyframed_compress(s, src_len[i], d, dst_cap[i]); break;
+            case ACHIP_OP_LZ4HADOOP_DECOMPRESS: r = orc_hadoop_decompress(0, s, src_len[i], d, dst_cap[i], 262144, &eo); break;
+            case ACHIP_OP_LZ4HADOOP_COMPRESS: r = orc_hadoop_compress(0, s, src_len[i], d, dst_cap[i], 262144); break;
+            case ACHIP_OP_SNAPPYHADOOP_DECOMPRESS: r = orc_hadoop_decompress(1, s, src_len[i], d, dst_cap[i], 262144, &eo); break;
+            case ACHIP_OP_SNAPPYHADOOP_COMPRESS: r = orc_hadoop_compress(1, s, src_len[i], d, dst_cap[i], 262144); break;
+            case ACHIP_OP_ZSTDSTREAM_COMPRESS: r = orc_zstd_stream_compress(s, src_len[i], d, dst_cap[i]); break;
             default: r = ACHIP_STATUS(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_BAD_ARGUMENT); break;
         }
         if (r >= 0) {
@@ -108,7 +118,7 @@ static double now_s(void)
 static void* orc_bench_thread(void* arg)
 {
     orc_bench_task* t = (orc_bench_task*)arg;
-    const int compress = t->op & 1;
+    const int compress = (t->op & 1) || t->op == ACHIP_OP_ZSTDSTREAM_COMPRESS;
     pthread_barrier_wait(t->start);
     const double t0 = now_s();
     double t1 = t0;

@@ -49,8 +49,9 @@ def all_blocks():
 
 @pytest.mark.parametrize("codec, variant", [("lz4", 4), ("lz4", 1), ("lz4", 0), ("snappy", 4), ("snappy", 3), ("snappy", 2), ("snappy", 1), ("snappy", 0)])
 def test_compress_is_bit_exact_with_oracle(gb, o, codec, variant):
-    # 0 = serial probes, 1 = 64 probes per step, 4 (LZ4) = many matches per window of 64 positions (lz4_compress_mw.h), 2 = batch probes in two tiers: hash tables in LDS and in global memory, 3 = two tiers
-    # over an LDS input window, one round of loads per batch (snappy_compress_v3.hip: the Snappy default since round 3)
+    # THE DEFAULT OF BOTH CODECS IS 4 = many matches per window of 64 positions (lz4_compress_mw.h / snappy_compress_mw.h, Snappy in two tiers).
+    # Tested non-default variants: 0 = serial probes, 1 = 64 probes per step, 2 (Snappy) = batch probes in two tiers: hash tables in LDS and in
+    # global memory, 3 (Snappy) = two tiers over an LDS input window, one round of loads per batch (snappy_compress_v3.hip)
     gb.set_option("%s.compress.variant" % codec, variant)
     blocks = all_blocks()
     caps = [o.max_compressed_length(codec, len(b)) for b in blocks]

@@ -173,3 +173,20 @@ def test_input_stream_twin_reads_streams_without_a_content_size(o):
     s.close()
     with pytest.raises(IOError):
         s.read()
+
+
+def test_input_stream_twin_caps_the_one_shot_allocation(o):
+    """a few KB of RLE block headers announce gigabytes (the bound adds up to 128 KiB per 4-byte block).  The twin refuses a
+    stream whose bound exceeds max_decoded_bytes BEFORE allocating; legal streams below the cap decode as before, and None lifts the cap."""
+    import struct
+    import aircompressor_amd as A
+    # one frame, no content size, window descriptor 128 KiB; 1000 RLE blocks of 131072 bytes each (4 bytes of input apiece), the last one marked
+    blocks = b"".join(struct.pack("<I", (131072 << 3) | (1 << 1) | (1 if i == 999 else 0))[:3] + b"z" for i in range(1000))
+    amplified = struct.pack("<I", 0xFD2FB528) + bytes([0x00, 0x38]) + blocks
+    assert len(amplified) < 4200
+    with pytest.raises(IOError, match="max_decoded_bytes"):
+        A.ZstdHipInputStream(io.BytesIO(amplified), max_decoded_bytes=1 << 20).read()
+    plain = A.ZstdHipInputStream(io.BytesIO(amplified), max_decoded_bytes=None).read()  # 125 MiB: legal, decodes when the caller allows it
+    assert len(plain) == 1000 * 131072 and plain.count(b"z") == len(plain)
+    small = o.zstd_stream_compress(b"abc" * 1000)
+    assert A.ZstdHipInputStream(io.BytesIO(small), max_decoded_bytes=4096).read() == b"abc" * 1000

@@ -38,6 +38,18 @@ print({k: (v["decompress_GiBps"], v["java_frames_decompress_GiBps"], v["one_kern
 PY
         awk 'NR>1{n=$1; for(i=2;i<=NF-4;i++) n=n" "$i; t[n]+=$(NF-3); c[n]++} END{for(k in t) printf "%-60s n=%d total_us=%.0f\n", k, c[k], t[k]}' gpurun_out/prof_r04zseq$v/keep/dispatches.txt | sort | grep -v "total_us=[0-9]\{1,3\}$" | tee $O/zseq${v}_kernels.txt
       done ;;
+    containers)    # the container extras with their CPU legs (bench.py --section lz4frame / zstdstream)
+      timeout 900 python bench.py --section lz4frame > $O/containers.json 2> $O/containers.err; tail -c 300 $O/containers.err
+      timeout 900 python bench.py --section zstdstream > $O/zstdstream.json 2> $O/zstdstream.err; tail -c 300 $O/zstdstream.err
+      python - <<'PY'
+import json
+for f in ("gpurun_out/r04/containers.json", "gpurun_out/r04/zstdstream.json"):
+    for l in open(f):
+        if l.startswith("{"):
+            for k, v in json.loads(l).items():
+                print(k, {a: b for a, b in v.items() if "GiBps" in a or a in ("cpu_threads", "frames", "ratio")})
+PY
+      ;;
     tests)
       timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
     *) echo "unknown step $step" ;;
