@@ -56,8 +56,8 @@ extern int g_zstd_pipe_exec;
 extern int g_zstd_pipe_seq;
 hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant, const AuxScratch* aux);
 int64_t lz4frame_decompress_scratch_bytes(int32_t nItems, int variant);
-hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch);
-int64_t lz4frame_compress_scratch_bytes();
+hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes);
+int64_t lz4frame_compress_scratch_bytes(int32_t items, bool least);
 hipError_t launch_mix_gather(const int32_t* perm, int32_t n, const BatchArgs& a, int64_t* gSrcOff, int32_t* gSrcLen, int64_t* gDstOff, int32_t* gDstCap, hipStream_t stream);
 hipError_t launch_mix_scatter(const int32_t* perm, int32_t n, const int32_t* gOutLen, const int32_t* gStatus, const int64_t* gErr, const BatchArgs& a, hipStream_t stream);
 hipError_t launch_xxh64_batch(const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int32_t n, uint64_t seed, int64_t* out, hipStream_t stream);
@@ -473,9 +473,13 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             break;
         }
         case ACHIP_OP_LZ4FRAME_COMPRESS: {
-            int32_t r = ensure_scratch(ctx, achip::lz4frame_compress_scratch_bytes());
-            if (r < 0) return r;
-            e = achip::launch_lz4frame_compress(a, ctx->stream, ctx->scratch);
+            // a slab per resident wavefront; when the device cannot give the full set the launch runs with fewer wavefronts
+            if (grow_scratch_keeping_old(ctx, achip::lz4frame_compress_scratch_bytes(a.nBlocks, false)) != 0) {
+                g_lastError.clear();
+                int32_t r = ensure_scratch(ctx, achip::lz4frame_compress_scratch_bytes(a.nBlocks, true));
+                if (r < 0) return r;
+            }
+            e = achip::launch_lz4frame_compress(a, ctx->stream, ctx->scratch, ctx->scratchBytes);
             break;
         }
         case ACHIP_OP_ZSTDSTREAM_COMPRESS: {

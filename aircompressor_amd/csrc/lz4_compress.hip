@@ -256,7 +256,8 @@ __global__ __launch_bounds__(64) void lz4_compress_mw_kernel(BatchArgs a, int32_
 namespace lz4f {
 constexpr int32_t BLOCK_MAX_4MB = 4 * 1024 * 1024;
 constexpr int64_t SLAB_BYTES = ((int64_t)BLOCK_MAX_4MB + BLOCK_MAX_4MB / 255 + 16 + 255) & ~(int64_t)255;
-constexpr int32_t MAX_WAVES = 512;
+constexpr int32_t MAX_WAVES = 2304;  // 9 wavefronts per CU (16 KB of LDS each) x 256 CUs; round 3 ran 512 (2 per CU): 5 GiB/s where the 64 KiB block encoder makes 28
+constexpr int32_t MIN_WAVES = 256;
 }  // namespace lz4f
 
 __global__ __launch_bounds__(64) void lz4frame_compress_kernel(BatchArgs a, uint8_t* slabs, int32_t* nextItem)
@@ -336,9 +337,16 @@ __global__ __launch_bounds__(64) void lz4frame_compress_kernel(BatchArgs a, uint
     }
 }
 
-int64_t lz4frame_compress_scratch_bytes() { return 4096 + (int64_t)lz4f::MAX_WAVES * lz4f::SLAB_BYTES; }
+// one 4 MiB slab per resident wavefront: `items` items never need more wavefronts than that (9.7 GB for a batch that fills the chip, on a
+// 288 GB device; `least`: what the launch can still work with when the device cannot give that)
+int64_t lz4frame_compress_scratch_bytes(int32_t items, bool least)
+{
+    int64_t waves = items < lz4f::MAX_WAVES ? (items > 0 ? items : 1) : lz4f::MAX_WAVES;
+    if (least && waves > lz4f::MIN_WAVES) waves = lz4f::MIN_WAVES;
+    return 4096 + waves * lz4f::SLAB_BYTES;
+}
 
-hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch)
+hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes)
 {
     if (a.nBlocks <= 0) {
         return hipSuccess;
@@ -346,7 +354,10 @@ hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void
     int32_t* counter = (int32_t*)scratch;
     hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
     if (e != hipSuccess) return e;
-    const unsigned grid = (unsigned)(a.nBlocks < lz4f::MAX_WAVES ? a.nBlocks : lz4f::MAX_WAVES);
+    int64_t waves = (scratchBytes - 4096) / lz4f::SLAB_BYTES;  // a slab per wavefront
+    if (waves < 1) return hipErrorInvalidValue;
+    if (waves > lz4f::MAX_WAVES) waves = lz4f::MAX_WAVES;
+    const unsigned grid = (unsigned)(a.nBlocks < waves ? a.nBlocks : waves);
     hipLaunchKernelGGL(lz4frame_compress_kernel, dim3(grid), dim3(64), 0, stream, a, (uint8_t*)scratch + 4096, counter);
     return hipGetLastError();
 }

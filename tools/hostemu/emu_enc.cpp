@@ -37,8 +37,8 @@ extern "C" int emu_encode(int op, const uint8_t* srcBase, const int64_t* srcOff,
         return op == 5 ? achip::launch_zstd_compress(a, nullptr, scratch.data(), (int64_t)scratch.size(), option) : achip::launch_zstd_stream_compress(a, nullptr, scratch.data(), option);
     }
     if (op == 7) {
-        scratch.assign((size_t)achip::lz4frame_compress_scratch_bytes(), 0xCD);
-        return achip::launch_lz4frame_compress(a, nullptr, scratch.data());
+        scratch.assign((size_t)achip::lz4frame_compress_scratch_bytes(n < 8 ? n : 8, false), 0xCD);  // (a slab per wavefront: the emulator runs them one after the other)
+        return achip::launch_lz4frame_compress(a, nullptr, scratch.data(), (int64_t)scratch.size());
     }
     if (op == 9) {
         scratch.assign((size_t)achip::snappyframed_compress_scratch_bytes(n), 0xCD);
