@@ -1009,48 +1009,113 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
     const int32_t logLL = d.log[0], logOF = d.log[1], logML = d.log[2];
     uint64_t* rec = p.seq + d.seqBase;
 
-    QuadBits b;
-    bool bad = !b.init(src, d.seqStart, d.seqEnd);
+    // The bit stream, MSB first: `w` holds the stream from the current bit position down (its top `have` bits came from whole bytes above
+    // `ptr`; what lies below them in `w` is either zero or the stream's next bits, never anything else), `nextWord` the eight bytes below
+    // `ptr`, requested one refill ahead.  A field of n bits at distance `at` from the current position is the top of w << at; consuming is a
+    // shift.  This reads exactly the bits BitInputStream.peekBits reads as long as a step stays inside the Java container -- which it does
+    // for every stream that is not sent to the fallback list below: offset codes above 24 are (7 + 24 + 16 + 16 bits fit a container).
+    // `rem` counts the stream's bits not yet consumed: Loader.load() reports overflow exactly when it is negative at a step's start
+    // (bitsConsumed > 64 is only possible with the container at the stream's first byte), and a step whose EXTRA bits run past the stream's
+    // start -- where the Java code reads whatever its wrapped shifts give -- is handed to the fallback list rather than imitated.
+    bool bad = false;
+    uint64_t w = 0, nextWord = 0;
+    int32_t have = 0, ptr = 0, rem = 0;
+    const int32_t sStart = d.seqStart;
+    {
+        const int32_t end = d.seqEnd, size = end - sStart;
+        if (size < 1 || end < 8 || sStart < 8) {  // (Initializer.initialize :110-130; a stream always has a frame and a block header before it)
+            bad = true;
+        }
+        else {
+            const int32_t last = src[end - 1];
+            bad = last == 0;
+            const int32_t c0 = 8 - zd::highest_bit((uint32_t)(last | 1));
+            uint64_t bits = ld8(src + end - 8);
+            int32_t consumed = c0;
+            if (size >= 8) {
+                ptr = end - 8;
+            }
+            else {
+                bits >>= 8 * (8 - size);
+                consumed += (8 - size) * 8;
+                ptr = sStart;
+            }
+            w = bits << (consumed & 63);
+            have = 64 - consumed;
+            rem = 8 * size - c0;
+            nextWord = ld8(src + ptr - 8);
+        }
+    }
+    auto refill = [&]() {
+        int32_t k = (64 - have) >> 3;
+        const int32_t avail = ptr - sStart;
+        k = k < avail ? k : avail;
+        k = k < 0 ? 0 : (k > 8 ? 8 : k);
+        w |= have >= 64 ? 0ull : (nextWord >> (have & 63));
+        have += 8 * k;
+        ptr -= k;
+        nextWord = ld8(src + ptr - 8);
+    };
+    auto field = [&](int32_t at, int32_t n) -> int32_t {  // n <= 31
+        const uint32_t hi = (uint32_t)((w << (at & 63)) >> 32);
+        return (int32_t)((hi >> 1) >> ((31 - n) & 31));
+    };
     int32_t nDecoded = 0;
     // the repeat-offset history; MB: "what it was before the block", entries 0 .. 2 (see the quad version)
     int32_t p0 = MB ? sx2::REP_SENTINEL : 1, p1 = MB ? (sx2::REP_SENTINEL | (1 << 16)) : 4, p2 = MB ? (sx2::REP_SENTINEL | (2 << 16)) : 8;
     if (!bad) {
         // initial states in stream order LL, OF, ML (:378-386)
-        int32_t sLL = (int32_t)peek_bits(b.consumed, b.bits, logLL) & 511;
-        int32_t sOF = (int32_t)peek_bits(b.consumed + logLL, b.bits, logOF) & 255;
-        int32_t sML = (int32_t)peek_bits(b.consumed + logLL + logOF, b.bits, logML) & 511;
-        b.consumed += logLL + logOF + logML;
+        int32_t sLL = field(0, logLL) & 511;
+        int32_t sOF = field(logLL, logOF) & 255;
+        int32_t sML = field(logLL + logOF, logML) & 511;
+        {
+            const int32_t n0 = logLL + logOF + logML;
+            w <<= n0;
+            have -= n0;
+            rem -= n0;
+        }
         int32_t sequenceCount = d.nbSeq;
         // ZstdFrameDecompressor.java:388-486, straight-line as in the quad version: an irregular stream sets `bad` and keeps decoding
         // harmless garbage (every index is masked) until the count runs out
         while (sequenceCount > 0) {
             sequenceCount--;
-            const bool over = b.load();
+            const bool over = rem < 0;          // Loader.load() :171-175
             bad |= over && sequenceCount != 0;  // "Not all sequences were consumed"
             sequenceCount = over ? 0 : sequenceCount;
+            refill();
             const uint32_t eLL = tLL[sLL], eML = tML[sML], eOF = tOF[sOF];
             const int32_t cLL = (int32_t)(eLL & 63), cML = (int32_t)(eML & 63), cOF = (int32_t)(eOF & 63);
             const uint32_t tl = codeTab[cLL], tm = codeTab[64 + cML];
             const int32_t xLL = (int32_t)(tl >> 24), xML = (int32_t)(tm >> 24), xOF = cOF & 31;
-            bad |= cLL > 35 || cML > 52 || cOF > 28;  // only reachable through a table the Java reader would also have rejected or mis-indexed
+            // codes beyond the tables are only reachable through a table the Java reader would also have rejected or mis-indexed; offset
+            // codes above 24 give offsets no window allows (checked below) and extra-bit counts the shortcut above does not cover
+            bad |= cLL > 35 || cML > 52 || cOF > 24;
             // extra bits are read in the order offset, match length, literal length
-            const int32_t vOF = (cOF < 2 ? cOF : (1 << xOF) - 3) + b.peek(b.consumed, xOF);
-            const int32_t matchLength = (int32_t)(tm & 0xFFFFFF) + b.peek(b.consumed + xOF, xML);
-            const int32_t literalsLength = (int32_t)(tl & 0xFFFFFF) + b.peek(b.consumed + xOF + xML, xLL);
+            const int32_t vOF = (cOF < 2 ? cOF : (1 << xOF) - 3) + field(0, xOF);
+            const int32_t matchLength = (int32_t)(tm & 0xFFFFFF) + field(xOF, xML);
+            const int32_t literalsLength = (int32_t)(tl & 0xFFFFFF) + field(xOF + xML, xLL);
             const int32_t xsum = xLL + xML + xOF;
-            b.consumed += xsum;
+            w <<= (xsum & 63);
+            have -= xsum;
+            rem -= xsum;
+            bad |= rem < 0 && !over;  // the extra bits ran past the stream's start
             if (xsum > 64 - 7 - (9 + 9 + 8)) {
-                b.load();
+                refill();
             }
             // state updates in the order LL, ML, OF
             const int32_t nLL = (int32_t)(eLL >> 6), nML = (int32_t)(eML >> 6), nOF = (int32_t)(eOF >> 6);
             const int32_t nbLL = (logLL - (31 - __builtin_clz((uint32_t)nLL | 1u))) & 15;
             const int32_t nbML = (logML - (31 - __builtin_clz((uint32_t)nML | 1u))) & 15;
             const int32_t nbOF = (logOF - (31 - __builtin_clz((uint32_t)nOF | 1u))) & 15;
-            sLL = ((nLL << nbLL) - (1 << logLL) + b.peek(b.consumed, nbLL)) & 511;
-            sML = ((nML << nbML) - (1 << logML) + b.peek(b.consumed + nbLL, nbML)) & 511;
-            sOF = ((nOF << nbOF) - (1 << logOF) + b.peek(b.consumed + nbLL + nbML, nbOF)) & 255;
-            b.consumed += nbLL + nbML + nbOF;
+            sLL = ((nLL << nbLL) - (1 << logLL) + field(0, nbLL)) & 511;
+            sML = ((nML << nbML) - (1 << logML) + field(nbLL, nbML)) & 511;
+            sOF = ((nOF << nbOF) - (1 << logOF) + field(nbLL + nbML, nbOF)) & 255;
+            {
+                const int32_t nbsum = nbLL + nbML + nbOF;
+                w <<= nbsum;
+                have -= nbsum;
+                rem -= nbsum;
+            }
             // repeat-offset history, :419-452
             const int32_t raw = vOF + ((cOF <= 1 && cLL == 0) ? 1 : 0);
             const bool rep = cOF <= 1;
@@ -1066,7 +1131,8 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
             // an offset beyond 2^24 cannot be a valid back-reference (the window is at most 2^23); keeps the record fields in range and
             // the sentinels apart from real offsets
             bad |= offset <= 0 || (offset > (1 << 24) && !(MB && rep && offset >= sx2::REP_SENTINEL));
-            if (!over) {
+            if (!over) {  // (8 bytes per lane and step, straight to the arena: the L2 merges a line's pieces.  Staging 16 records per lane in
+                          // LDS and storing lines -- what the quad version does -- measured no faster: 427 against 405 ms over the bench's launches)
                 rec[nDecoded] = (uint64_t)(uint32_t)literalsLength | ((uint64_t)(uint32_t)matchLength << 18) | ((uint64_t)(uint32_t)(offset & 0xFFFFFFF) << 36);
             }
             nDecoded += over ? 0 : 1;

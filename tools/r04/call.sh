@@ -50,6 +50,11 @@ for f in ("gpurun_out/r04/containers.json", "gpurun_out/r04/zstdstream.json"):
                 print(k, {a: b for a, b in v.items() if "GiBps" in a or a in ("cpu_threads", "frames", "ratio")})
 PY
       ;;
+    pmc_zseq)      # SQ counters of the Zstd pipeline's kernels (bench.py --section zstd)
+      bash tools/pmc_any.sh r04zs1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" python bench.py --section zstd --no-cpu-baseline
+      bash tools/pmc_any.sh r04zs2 "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM" python bench.py --section zstd --no-cpu-baseline
+      grep "sequences\|execute2\|literals\|pipe_parse" gpurun_out/pmc_r04zs1.txt gpurun_out/pmc_r04zs2.txt | sed 's/gpurun_out.pmc_r04//' | cut -c1-200
+      cp gpurun_out/pmc_r04zs1.txt gpurun_out/pmc_r04zs2.txt $O/ ;;
     tests)
       timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
     *) echo "unknown step $step" ;;
