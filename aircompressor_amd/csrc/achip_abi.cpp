@@ -20,8 +20,6 @@
 
 namespace achip {
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
-hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
-hipError_t launch_lz4_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
 hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
 int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock);
 // record arena per block of the two-pass decoders (8 bytes per record; lz4_decompress_v7.hip: text-like 64 KiB blocks make 6 000 .. 8 500 LZ4
@@ -32,12 +30,9 @@ hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stre
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
 hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
-hipError_t launch_snappy_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
-hipError_t launch_snappy_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* stats);
 hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
 hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant, void* scratch);
-hipError_t launch_snappy_compress_window(const BatchArgs& a, hipStream_t stream, void* scratch);
 int64_t snappy_compress_scratch_bytes();
 hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant, int32_t tileMax, const ZstdMbProvider* mbp);
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
@@ -53,7 +48,6 @@ int64_t hadoop_decompress_scratch_bytes(int32_t nStreams, int32_t bufferSize);
 hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize);
 int64_t hadoop_compress_scratch_bytes(int32_t nStreams);
 extern int g_zstd_pipe_exec;
-extern int g_zstd_pipe_seq;
 hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant, const AuxScratch* aux);
 int64_t lz4frame_decompress_scratch_bytes(int32_t nItems, int variant);
 hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes);
@@ -71,11 +65,11 @@ struct achip_ctx {
     int lz4dGroup = 4;       // lanes per block: measured best on MI355X (profiles/r01_sweep_v2_rings.txt)
     int snappydGroup = 4;
     int lz4dAutoMinBlocks = 4096;  // auto mode probes batches from this size on (smaller ones always take the rings)
-    int lz4dVariant = 5;     // 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 4 = a lane per block, copies straight between the global buffers (lz4_decompress_v5.hip), 6 = a lane per block with an LDS output window (lz4_decompress_v6.hip), 5 = auto
-    int snappydVariant = 5;  // 1 rings (snappy_decompress_v2.hip), 4 / 6 a lane per block (snappy_decompress_v3.hip / _v4.hip), 5 auto as for LZ4
+    int lz4dVariant = 5;     // 5 = chosen on the device per batch (default: DESIGN 4c), 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 7 = two passes: parse to records + a wavefront per block (lz4_decompress_v7.hip).  (4 / 6, a lane per block, lost to 7 on every batch they were built for -- 300 .. 330 GiB/s against 515 on corpus -- and were removed in round 4.)
+    int snappydVariant = 5;  // 5 auto, 1 rings (snappy_decompress_v2.hip), 7 two passes (snappy_decompress_v5.hip), as for LZ4
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
     int lz4cVariant = 4;     // 4 = many matches per window of 64 positions (lz4_compress_mw.h; default since round 3: 25.8 against 18.2 GiB/s on corpus, 100 against 111 on fragments), 0 = serial probes, 1 = 64 probes per step (batch).  (3, the batch over an LDS input window, measured 17.2 against 18.2 GiB/s on corpus in round 3: removed)
-    int snappycVariant = 4;  // THE DEFAULT IS 4 = two tiers, many matches per window (snappy_compress_mw.h; since round 3: 22.0 against 8.3 GiB/s on corpus, 65 against 74 on fragments); tested non-default variants: 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory, 3 = 2 with an LDS input window (snappy_compress_v3.hip: 8.3 against 7.6 GiB/s on corpus for 2)
+    int snappycVariant = 4;  // THE DEFAULT IS 4 = two tiers, many matches per window (snappy_compress_mw.h; since round 3: 22.0 against 8.3 GiB/s on corpus, 65 against 74 on fragments); tested non-default variants: 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory.  (3, variant 2 over an LDS input window, measured 8.3 against 7.6 GiB/s for 2 and a third of variant 4: removed in round 4.)
     int zstddVariant = 1;  // 1 = five-stage pipeline (+ one-kernel decoder for its fallback list), 0 = one-kernel decoder only
     int zstdcVariant = 3;  // match kernel in window form (zstd_dfast_mw.h) + entropy kernel
     int hadoopBufferSize = 262144;        // Hadoop block streams: the streams' buffer size (Lz4HadoopStreams.java:30; io.compression.codec.*.buffersize)
@@ -98,7 +92,7 @@ struct achip_ctx {
     bool lastTwopass = false;   // the last decode was a two-pass one: its arena header leads the scratch
     bool lastLz4dAuto = false;  // the last LZ4 decode ran in auto mode: its probe count leads the scratch
     int maxSrcLenHint = 0;
-    int execVariant = 2;     // two-pass decoders: 2 = the product; 121..123, 201 = timing aids of -DACHIP_DEV builds
+    int execVariant = 2;     // two-pass decoders: 2 = the executor of achip_seqexec2.h (the only one)
     // scratch for the zstd pipeline (grown on demand)
     void* scratch = nullptr;
     int64_t scratchBytes = 0;
@@ -323,7 +317,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
     }
     achip::BatchArgs a = args;
     a.ringPad = ctx->ringPad;
-    if (op == ACHIP_OP_ZSTD_COMPRESS) a.ringPad = ctx->zstdcVariant == 100 ? 999 : (ctx->zstdcVariant == 1 ? 1 : (ctx->zstdcVariant == 3 ? 3 : 0));  // (100: -DACHIP_DEV builds only)  // encoder variant rides in the spare field
+    if (op == ACHIP_OP_ZSTD_COMPRESS) a.ringPad = ctx->zstdcVariant == 1 ? 1 : (ctx->zstdcVariant == 3 ? 3 : 0);  // the encoder variant rides in the spare field
     if (a.nBlocks < 0) {
         return bad_argument("nBlocks < 0");
     }
@@ -371,9 +365,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 e = achip::launch_lz4_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->lz4dGroup, ctx->ringClass, ctx->execVariant, nullptr);
                 break;
             }
-            e = ctx->lz4dVariant == 4 ? achip::launch_lz4_decompress_lanecopy(a, ctx->stream, nullptr)
-                : ctx->lz4dVariant == 6 ? achip::launch_lz4_decompress_lanewindow(a, ctx->stream, nullptr)
-                                        : achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, nullptr);
+            e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, nullptr);
             break;
         case ACHIP_OP_LZ4_COMPRESS:
             e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint);
@@ -410,16 +402,14 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 e = achip::launch_snappy_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->snappydGroup, ctx->ringClass, ctx->execVariant, nullptr);
                 break;
             }
-            e = ctx->snappydVariant == 4 ? achip::launch_snappy_decompress_lanecopy(a, ctx->stream, nullptr)
-                : ctx->snappydVariant == 6 ? achip::launch_snappy_decompress_lanewindow(a, ctx->stream, nullptr)
-                                           : achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, nullptr);
+            e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, nullptr);
             break;
         case ACHIP_OP_SNAPPY_COMPRESS: {
             if (ctx->snappycVariant >= 2) {
                 int32_t r = ensure_scratch(ctx, achip::snappy_compress_scratch_bytes());
                 if (r < 0) return r;
             }
-            e = ctx->snappycVariant == 3 ? achip::launch_snappy_compress_window(a, ctx->stream, ctx->scratch) : achip::launch_snappy_compress(a, ctx->stream, ctx->snappycVariant, ctx->scratch);
+            e = achip::launch_snappy_compress(a, ctx->stream, ctx->snappycVariant, ctx->scratch);
             break;
         }
         case ACHIP_OP_ZSTD_DECOMPRESS: {
@@ -872,7 +862,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->snappydGroup = (int)value;
     }
     else if (k == "lz4.decompress.variant") {
-        if (value != 1 && value != 4 && value != 5 && value != 6 && value != 7) return bad_argument("lz4.decompress.variant: 1 rings, 4 / 6 a lane per block, 7 two passes, 5 auto");
+        if (value != 1 && value != 5 && value != 7) return bad_argument("lz4.decompress.variant: 1 rings, 7 two passes, 5 auto");
         ctx->lz4dVariant = (int)value;
     }
     else if (k == "lz4.decompress.auto_min_blocks") {
@@ -880,7 +870,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->lz4dAutoMinBlocks = (int)value;
     }
     else if (k == "snappy.decompress.variant") {
-        if (value != 1 && value != 4 && value != 5 && value != 6 && value != 7) return bad_argument("snappy.decompress.variant: 1 rings, 4 / 6 a lane per block, 7 two passes, 5 auto");
+        if (value != 1 && value != 5 && value != 7) return bad_argument("snappy.decompress.variant: 1 rings, 7 two passes, 5 auto");
         ctx->snappydVariant = (int)value;
     }
     else if (k == "decompress.ring_class") {
@@ -892,7 +882,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->lz4cVariant = (int)value;
     }
     else if (k == "snappy.compress.variant") {
-        if (value < 0 || value > 4) return bad_argument("snappy.compress.variant: 0 serial probes, 1 batch probes, 2 two tiers, 3 two tiers over LDS input windows, 4 two tiers, many matches per window");
+        if (value < 0 || value > 4 || value == 3) return bad_argument("snappy.compress.variant: 0 serial probes, 1 batch probes, 2 two tiers, 4 two tiers, many matches per window");
         ctx->snappycVariant = (int)value;
     }
     else if (k == "snappyframed.decompress.variant") {
@@ -914,10 +904,6 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     else if (k == "lz4frame.decompress.variant") {
         if (value < 0 || value > 2) return bad_argument("lz4frame.decompress.variant: 0 a wavefront per item, 1 block list through the two-pass decoder, 2 chosen by a probe");
         ctx->lz4FrameDecompressVariant = (int)value;
-    }
-    else if (k == "zstd.decompress.seq") {
-        if (value < 0 || value > 1) return bad_argument("zstd.decompress.seq: 1 a lane per item, 0 a quad per item");
-        achip::g_zstd_pipe_seq = (int)value;
     }
     else if (k == "zstd.decompress.exec") {
         if (value < 0 || value > 2) return bad_argument("zstd.decompress.exec: 0 rings, 1 record executor, 2 chosen per item");
@@ -942,22 +928,14 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->zstdStreamBlocks = (int)value;
     }
     else if (k == "zstd.compress.variant") {
-        // (100, a timing aid whose output is not valid, exists in -DACHIP_DEV builds only: a shipped library has no option that returns wrong data)
-        bool ok = value >= 0 && value <= 3;
-#ifdef ACHIP_DEV
-        ok = ok || value == 100;
-#endif
+        const bool ok = value >= 0 && value <= 3;
         if (!ok) return bad_argument("zstd.compress.variant: 3 match-finder kernel (many matches per window) + entropy kernel, 0 the same with batch probes, 1 with serial probes, 2 one kernel");
         ctx->zstdcVariant = (int)value;
     }
     else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;
     else if (k == "decompress.exec_variant") {
-        // 2 the product -- the only value a shipped library takes.  121 .. 123 and 201 skip work (results NOT valid): -DACHIP_DEV builds only.
-        // (Round 2's experiments 124 / 125 / 302 .. 308 were measured in round 3 and removed: profiles/r03_notes.md.)
-        bool ok = value == 2;
-#ifdef ACHIP_DEV
-        ok = ok || (value >= 121 && value <= 123) || value == 201;
-#endif
+        // 2: the one executor there is.  (Round 2's experiments and timing aids -- 121 .. 125, 201, 302 .. 308 -- were measured, then removed: rounds 3 and 4.)
+        const bool ok = value == 2;
         if (!ok) return bad_argument("decompress.exec_variant: 2");
         ctx->execVariant = (int)value;
     }
@@ -985,7 +963,7 @@ int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name)
         if (hipMemcpy(&v, ctx->scratch, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
         return v;
     }
-    if (k == "decompress.choice") {  // which decoder auto mode ran last: 0 rings, 1 lane per block (copy steps), 2 lane per block (LDS window); -1: no probe ran
+    if (k == "decompress.choice") {  // which decoder auto mode ran last: 0 rings, 3 two passes; -1: no probe ran
         if (!ctx->lastLz4dAuto || ctx->scratch == nullptr) return -1;
         if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
         int32_t v[3] = {0, 0, 0};

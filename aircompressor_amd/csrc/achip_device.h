@@ -49,25 +49,16 @@ __device__ __forceinline__ constexpr int32_t mk_status(int cls, int detail) { re
 // blocks (= the blocks one wavefront of the ring decoder works on) the compressed sizes differ by more than 2x
 __device__ __forceinline__ bool lz4_batch_is_mixed(int32_t mixedGroups, int32_t nBlocks) { return (int64_t)mixedGroups * 4 > (nBlocks + 15) / 16; }
 
-// The LZ4 choice has a third candidate.  stats: [0] mixed groups, [1] sequences parsed from the heads of 1024 sampled blocks, [2] the
-// bytes they produce, in units of 4.  Mixed batch: the lane-per-block decoder with wavefront-wide copy steps (long copies next to short ones);
-// otherwise short sequences (text: 10-40 bytes per sequence at a block's head; the long-copy sets: >= 100): the lane-per-block decoder
-// with the LDS output window; otherwise the rings.
-constexpr int LZ4_PICK_RINGS = 0, LZ4_PICK_LANECOPY = 1, LZ4_PICK_LANEWINDOW = 2, LZ4_PICK_TWOPASS = 3;
+// The decoders' choice.  stats: [0] mixed groups, [1] sequences parsed from the heads of 1024 sampled blocks, [2] the bytes they produce,
+// in units of 4, [3] != 0: the caller has record scratch -- the two-pass decoder (parse to records + a wavefront per block) is
+// a candidate.  Mixed batches (long copies next to short ones) and short-sequence batches (text: 9 .. 40 bytes per sequence at a block's
+// head; the long-copy sets: >= 100) go to it, everything else -- and every batch of a caller without record scratch -- to the rings.
+// (Until round 4 there were two more candidates, lane-per-block decoders; the two-pass decoder beat both from 16384 blocks up.)
+constexpr int LZ4_PICK_RINGS = 0, LZ4_PICK_TWOPASS = 3;
 __device__ __forceinline__ int lz4_pick(const int32_t* stats, int32_t nBlocks, int32_t shortLimit = 12)
 {
-    // stats[3] != 0 (set by the batched block API): mixed or short-sequence batches of any size go to the two-pass decoder
-    // (parse to records + a wavefront per block), which beats both lane-per-block decoders from 16384 blocks up; the framed readers
-    // (whose batch exists on the device only) keep the three-way choice below
     const bool isShort = stats[1] > 0 && (int64_t)stats[2] < (int64_t)shortLimit * (int64_t)stats[1];
-    if (stats[3] != 0) {
-        return (lz4_batch_is_mixed(stats[0], nBlocks) || isShort) ? LZ4_PICK_TWOPASS : LZ4_PICK_RINGS;
-    }
-    if (lz4_batch_is_mixed(stats[0], nBlocks)) {
-        return LZ4_PICK_LANECOPY;
-    }
-    // (the LDS-window decoder runs 8 wavefronts of 64 blocks per CU: below 131072 blocks it cannot fill the chip and the rings win)
-    return (nBlocks >= 131072 && isShort) ? LZ4_PICK_LANEWINDOW : LZ4_PICK_RINGS;
+    return (stats[3] != 0 && (lz4_batch_is_mixed(stats[0], nBlocks) || isShort)) ? LZ4_PICK_TWOPASS : LZ4_PICK_RINGS;
 }
 // Snappy: the sample counts elements (a literal run or a copy -- half an LZ4 sequence)
 __device__ __forceinline__ int snappy_pick(const int32_t* stats, int32_t nBlocks) { return lz4_pick(stats, nBlocks, 6); }

@@ -244,7 +244,6 @@ struct Exec {
         b.dep = dep;
     }
 
-    template <int DBG>
     __device__ __forceinline__ void compose(const Batch& b)
     {
         // (Everything LDS here sits under a branch that only the lanes concerned take -- deliberately: an unaligned LDS access costs by
@@ -252,10 +251,10 @@ struct Exec {
         // parser, measured 22.8 ms against 17.3.)
         const int32_t dstM = b.dstLit + b.lit;
         // ---- literal runs and the matches whose bytes came with the batch ----
-        if (b.lit > 0 && DBG != 2) {
+        if (b.lit > 0) {
             io.write(b.dstLit, b.litShift != 0 ? shr_bytes(b.litData, b.litShift) : b.litData, b.lit);
         }
-        bool pending = b.ml > 0 && DBG != 1;
+        bool pending = b.ml > 0;
         if (pending && b.far != 0) {
             io.write(dstM, b.off < b.ml ? expand_period(b.farData, b.off) : b.farData, b.ml);
             pending = false;
@@ -277,12 +276,10 @@ struct Exec {
         outPos += b.total;
         // ---- the finished 16-byte pieces leave (positions, not addresses, are 16-aligned) ----
         const int32_t wholeEnd = outPos & ~15;
-        if (DBG != 3) {
-            for (int32_t base = flushPos; base < wholeEnd; base += 1024) {  // (uniform; at most two rounds)
-                const int32_t p = base + lane * 16;
-                if (p < wholeEnd) {
-                    st16(out + p, *(const u32x4*)(io.win + (p & MASK)));
-                }
+        for (int32_t base = flushPos; base < wholeEnd; base += 1024) {  // (uniform; at most two rounds)
+            const int32_t p = base + lane * 16;
+            if (p < wholeEnd) {
+                st16(out + p, *(const u32x4*)(io.win + (p & MASK)));
             }
         }
         flushPos = wholeEnd;
@@ -302,7 +299,7 @@ struct Exec {
 // in / inLen: the block's compressed bytes (literal source); out: its output.  win: WIN + 16 bytes of LDS owned by this wavefront.
 // The records were validated by the parser: every literal range lies inside the input, every match source inside the output produced
 // so far, the total inside the block's capacity.
-template <int DBG = 0, int WIN = WIN_DEFAULT>
+template <int WIN = WIN_DEFAULT>
 __device__ __forceinline__ void exec_block(uint8_t* win, const uint8_t* __restrict__ in, int32_t inLen, uint8_t* out, const uint64_t* __restrict__ arena, int32_t chunk,
                                            int32_t count, int lane)
 {
@@ -365,7 +362,7 @@ __device__ __forceinline__ void exec_block(uint8_t* win, const uint8_t* __restri
             rNext = load_records(arena, pChunk, pSlot, lane);
         }
         left -= A.k;
-        X.template compose<DBG>(A);
+        X.compose(A);
         if (left <= 0) {
             break;
         }
@@ -374,7 +371,7 @@ __device__ __forceinline__ void exec_block(uint8_t* win, const uint8_t* __restri
             rNext = load_records(arena, pChunk, pSlot, lane);
         }
         left -= B.k;
-        X.template compose<DBG>(B);
+        X.compose(B);
     }
     X.finish();
 }
@@ -413,7 +410,7 @@ struct RecordSource {  // one block's records for exec_records: `n` records at `
     __device__ __forceinline__ static int32_t off_of(uint64_t r) { return (int32_t)(r >> 36); }
 };
 
-template <int DBG = 0, int WIN = WIN_DEFAULT>
+template <int WIN = WIN_DEFAULT>
 __device__ __forceinline__ int32_t exec_records(uint8_t* win, const RecordSource& S, const uint8_t* __restrict__ lit, int32_t litSize, uint8_t* out, int32_t outLimit, int lane,
                                                 bool& badOut, int32_t startPos = 0)
 {
@@ -583,7 +580,7 @@ __device__ __forceinline__ int32_t exec_records(uint8_t* win, const RecordSource
         if (haveB) {
             prepare(B);
         }
-        X.template compose<DBG>(A);
+        X.compose(A);
         if (!haveB) {
             break;
         }
@@ -596,7 +593,7 @@ __device__ __forceinline__ int32_t exec_records(uint8_t* win, const RecordSource
         if (haveA) {
             prepare(A);
         }
-        X.template compose<DBG>(B);
+        X.compose(B);
     }
     X.finish();
     badOut = bad;

@@ -657,12 +657,8 @@ __global__ __launch_bounds__(64) void hadoop_compact_kernel(BatchArgs a, BlockLi
 }  // namespace hdp
 
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
-hipError_t launch_lz4_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
-hipError_t launch_lz4_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* stats);
 hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
-hipError_t launch_snappy_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
-hipError_t launch_snappy_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* stats);
 hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
 hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
@@ -809,19 +805,12 @@ hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void
     BatchArgs big = c, small = c;
     big.countLo = 32768;
     small.countHi = 32768;
-    e = launch_lz4_mixed_groups(c, stream, stats, 65536);
     if (snappy) {
-        if (e == hipSuccess) e = launch_snappy_element_sample(c, stream, stats, 65536);
-        if (e == hipSuccess) e = launch_snappy_decompress_rings(c, stream, 4, 0, stats);  // (16 lanes per chunk measured slower for Snappy: 390 against 481 GiB/s)
-        if (e == hipSuccess) e = launch_snappy_decompress_lanecopy(c, stream, stats);
-        if (e == hipSuccess) e = launch_snappy_decompress_lanewindow(c, stream, stats);
+        e = launch_snappy_decompress_rings(c, stream, 4, 0, nullptr);  // (16 lanes per chunk measured slower for Snappy: 390 against 481 GiB/s)
     }
     else {
-        if (e == hipSuccess) e = launch_lz4_sequence_sample(c, stream, stats, 65536);
-        if (e == hipSuccess) e = launch_lz4_decompress_rings(big, stream, 4, 0, stats);
-        if (e == hipSuccess) e = launch_lz4_decompress_rings(small, stream, 16, 0, stats);
-        if (e == hipSuccess) e = launch_lz4_decompress_lanecopy(c, stream, stats);
-        if (e == hipSuccess) e = launch_lz4_decompress_lanewindow(c, stream, stats);
+        e = launch_lz4_decompress_rings(big, stream, 4, 0, nullptr);
+        if (e == hipSuccess) e = launch_lz4_decompress_rings(small, stream, 16, 0, nullptr);
     }
     }
     if (e != hipSuccess) return e;

@@ -355,7 +355,7 @@ hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void
     hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
     if (e != hipSuccess) return e;
     int64_t waves = (scratchBytes - 4096) / lz4f::SLAB_BYTES;  // a slab per wavefront
-    if (waves < 1) return hipErrorInvalidValue;
+    if (waves < 1) return hipErrorUnknown;  // (the caller sizes the scratch: never)
     if (waves > lz4f::MAX_WAVES) waves = lz4f::MAX_WAVES;
     const unsigned grid = (unsigned)(a.nBlocks < waves ? a.nBlocks : waves);
     hipLaunchKernelGGL(lz4frame_compress_kernel, dim3(grid), dim3(64), 0, stream, a, (uint8_t*)scratch + 4096, counter);

@@ -12,7 +12,6 @@
 //   seq_execute2_kernel   a wavefront per block: sx2::exec_block.
 #include <type_traits>
 
-#include "achip_lanecopy.h"
 #include "achip_seqexec.h"
 #include "achip_seqexec2.h"
 
@@ -108,7 +107,6 @@ __device__ __forceinline__ bool lz4_parse_general(const uint8_t* __restrict__ in
     return true;
 }
 
-template <int DBG>
 __global__ __launch_bounds__(64) void lz4_parse2_kernel(BatchArgs a, sx::ArenaHeader* hdr, sx::BlockMeta* meta, int32_t* only, uint64_t* arena, int32_t maxChunks, const int32_t* stats)
 {
     if (stats != nullptr && lz4_pick(stats, a.nBlocks) != LZ4_PICK_TWOPASS) {  // auto mode: the ring decoder takes this batch
@@ -301,12 +299,10 @@ __global__ __launch_bounds__(64) void lz4_parse2_kernel(BatchArgs a, sx::ArenaHe
             }
         }
         if (flush && fallback == 0) {
-            if (DBG != 1) {
-                uint8_t* const dst = (uint8_t*)(arena + (int64_t)chunk * sx::CHUNK_SLOTS + fill);
+            uint8_t* const dst = (uint8_t*)(arena + (int64_t)chunk * sx::CHUNK_SLOTS + fill);
 #pragma unroll
-                for (int k = 0; k < 8; k += 2) {
-                    st16(dst + 8 * k, u32x4{(uint32_t)rec[k], (uint32_t)(rec[k] >> 32), (uint32_t)rec[k + 1], (uint32_t)(rec[k + 1] >> 32)});
-                }
+            for (int k = 0; k < 8; k += 2) {
+                st16(dst + 8 * k, u32x4{(uint32_t)rec[k], (uint32_t)(rec[k] >> 32), (uint32_t)rec[k + 1], (uint32_t)(rec[k + 1] >> 32)});
             }
             fill += 8;
             count += 8;
@@ -331,7 +327,7 @@ __global__ __launch_bounds__(64) void lz4_parse2_kernel(BatchArgs a, sx::ArenaHe
 }
 
 // the execute pass (achip_seqexec2.h): pieces of at most 16 + 16 bytes, every global load one batch ahead
-template <int DBG = 0, int WIN = sx2::WIN_DEFAULT, int WAVES = 0>
+template <int WIN = sx2::WIN_DEFAULT, int WAVES = 0>
 __global__ __launch_bounds__(64, WAVES) void seq_execute2_kernel(BatchArgs a, const sx::BlockMeta* meta, const uint64_t* arena, const int32_t* stats, int32_t shortLimit)
 {
     if (stats != nullptr && lz4_pick(stats, a.nBlocks, shortLimit) != LZ4_PICK_TWOPASS) {  // auto mode: the ring decoder takes this batch
@@ -343,7 +339,7 @@ __global__ __launch_bounds__(64, WAVES) void seq_execute2_kernel(BatchArgs a, co
     if (m.count <= 0) {
         return;
     }
-    sx2::exec_block<DBG, WIN>(win, a.srcBase + a.srcOff[block], a.srcLen[block], a.dstBase + a.dstOff[block], arena, m.firstChunk, m.count, (int)threadIdx.x);
+    sx2::exec_block<WIN>(win, a.srcBase + a.srcOff[block], a.srcLen[block], a.dstBase + a.dstOff[block], arena, m.firstChunk, m.count, (int)threadIdx.x);
 }
 
 // scratch: [header 256 B][meta n x 8][only n x 4][arena, 4 KiB aligned]
@@ -357,17 +353,12 @@ int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock)
 }
 int64_t lz4_twopass_scratch_bytes(int32_t nBlocks) { return twopass_scratch_bytes(nBlocks, 98304); }
 
-// the execute pass (shared with snappy_decompress_v5.hip); execVariant 2 = the product; 121..123 timing aids in -DACHIP_DEV builds (results not valid)
+// the execute pass (shared with snappy_decompress_v5.hip).  (execVariant: 2, the only one -- round 2's timing aids, executor and parser variants
+// that left work out, were development tools and went in round 4 together with their build switch)
 hipError_t launch_seq_execute2(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant, const int32_t* stats, int32_t shortLimit)
 {
-    const dim3 grid((unsigned)a.nBlocks), wg(64);
-#ifdef ACHIP_DEV  // timing aids (no matches / no literals / no flush: results NOT valid) -- never in a shipped library
-    if (execVariant == 121) hipLaunchKernelGGL(seq_execute2_kernel<1>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
-    else if (execVariant == 122) hipLaunchKernelGGL(seq_execute2_kernel<2>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
-    else if (execVariant == 123) hipLaunchKernelGGL(seq_execute2_kernel<3>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
-    else
-#endif
-    hipLaunchKernelGGL(seq_execute2_kernel<0>, grid, wg, 0, stream, a, meta, arena, stats, shortLimit);
+    (void)execVariant;
+    hipLaunchKernelGGL(seq_execute2_kernel<>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, meta, arena, stats, shortLimit);
     return hipGetLastError();
 }
 
@@ -394,15 +385,7 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream,
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((a.nBlocks + 63) / 64)), wg(64);
     {
-#ifdef ACHIP_DEV
-    if (execVariant == 201) {  // (timing aid: no record stores -- results NOT valid)
-        hipLaunchKernelGGL(lz4_parse2_kernel<1>, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
-    }
-    else
-#endif
-    {
-        hipLaunchKernelGGL(lz4_parse2_kernel<0>, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
-    }
+    hipLaunchKernelGGL(lz4_parse2_kernel, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
     e = launch_seq_execute2(a, stream, meta, arena, execVariant, stats, 12);
     if (e != hipSuccess) return e;
     }

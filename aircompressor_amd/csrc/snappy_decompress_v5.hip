@@ -8,7 +8,6 @@
 // first record's `skip`.
 #include <type_traits>
 
-#include "achip_lanecopy.h"
 #include "achip_seqexec.h"
 
 namespace achip {
@@ -92,7 +91,6 @@ __device__ __forceinline__ int snappy_parse_general(const uint8_t* __restrict__ 
     return 2;
 }
 
-template <int DBG>
 __global__ __launch_bounds__(64) void snappy_parse2_kernel(BatchArgs a, sx::ArenaHeader* hdr, sx::BlockMeta* meta, int32_t* only, uint64_t* arena, int32_t maxChunks, const int32_t* stats)
 {
     if (stats != nullptr && snappy_pick(stats, a.nBlocks) != LZ4_PICK_TWOPASS) {  // auto mode: the ring decoder takes this batch
@@ -312,12 +310,10 @@ __global__ __launch_bounds__(64) void snappy_parse2_kernel(BatchArgs a, sx::Aren
             }
         }
         if (flush && fallback == 0) {
-            if (DBG != 1) {
-                uint8_t* const dst = (uint8_t*)(arena + (int64_t)chunk * sx::CHUNK_SLOTS + fill);
+            uint8_t* const dst = (uint8_t*)(arena + (int64_t)chunk * sx::CHUNK_SLOTS + fill);
 #pragma unroll
-                for (int k = 0; k < 8; k += 2) {
-                    st16(dst + 8 * k, u32x4{(uint32_t)rec[k], (uint32_t)(rec[k] >> 32), (uint32_t)rec[k + 1], (uint32_t)(rec[k + 1] >> 32)});
-                }
+            for (int k = 0; k < 8; k += 2) {
+                st16(dst + 8 * k, u32x4{(uint32_t)rec[k], (uint32_t)(rec[k] >> 32), (uint32_t)rec[k + 1], (uint32_t)(rec[k + 1] >> 32)});
             }
             fill += 8;
             count += 8;
@@ -373,7 +369,7 @@ hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stre
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((a.nBlocks + 63) / 64)), wg(64);
     {
-        hipLaunchKernelGGL(snappy_parse2_kernel<0>, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+        hipLaunchKernelGGL(snappy_parse2_kernel, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
         e = launch_seq_execute2(a, stream, meta, arena, execVariant, stats, 6);
         if (e != hipSuccess) return e;
     }

@@ -748,8 +748,6 @@ __global__ __launch_bounds__(64) void snappyframed_fold_kernel(BatchArgs a, Chun
 }  // namespace snf
 
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
-hipError_t launch_snappy_decompress_lanecopy(const BatchArgs& a, hipStream_t stream, const int32_t* mixedGroups);
-hipError_t launch_snappy_decompress_lanewindow(const BatchArgs& a, hipStream_t stream, const int32_t* stats);
 hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
 
@@ -869,11 +867,7 @@ hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream
         if (e != hipSuccess) return e;
     }
     else if (!viaTwoPass) {
-        e = launch_lz4_mixed_groups(c, stream, mixedGroups, 65536);  // (the lane-per-block decoder wants 64 blocks per wavefront)
-        if (e == hipSuccess) e = launch_snappy_element_sample(c, stream, mixedGroups, 65536);
-        if (e == hipSuccess) e = launch_snappy_decompress_rings(c, stream, 4, 0, mixedGroups);
-        if (e == hipSuccess) e = launch_snappy_decompress_lanecopy(c, stream, mixedGroups);
-        if (e == hipSuccess) e = launch_snappy_decompress_lanewindow(c, stream, mixedGroups);
+        e = launch_snappy_decompress_rings(c, stream, 4, 0, nullptr);  // (the chunk count is known on the device only: the launch is sized for the most there can be)
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(snf::snappyframed_verify_kernel, dim3(maxWaves), dim3(64), 0, stream, a, L);

@@ -65,7 +65,6 @@ __global__ __launch_bounds__(64) ACHIP_WAVES_PER_EU(4, 8) void zstd_match_kernel
         c.out = nullptr;
         c.outCap = 0;
         c.lane = lane;
-        c.dbgStage = 0;
         c.batchProbe = batchProbe;
         c.failStatus = 0;
         c.pre = nullptr;
@@ -134,7 +133,6 @@ __global__ __launch_bounds__(64) void zstd_compress_kernel(BatchArgs a, uint8_t*
         c.out = a.dstBase + a.dstOff[block];
         c.outCap = a.dstCap[block];
         c.lane = lane;
-        c.dbgStage = a.ringPad == 999 ? 1 : 0;
         c.batchProbe = a.ringPad == 1 ? 0 : (a.ringPad == 3 ? 2 : 1);  // variant 1 = serial probing, 3 = many matches per window
         c.failStatus = 0;
         c.pre = nullptr;

@@ -68,7 +68,6 @@ struct Ctx {
     uint8_t* out;
     int32_t outCap;
     int lane;
-    int dbgStage;
     int batchProbe;
     int32_t failStatus;  // 0 = ok
     const int32_t* pre;  // match-finder results of this item (two-kernel path) or null
@@ -1589,9 +1588,6 @@ __device__ int32_t compress_block(Ctx& c, Shared& sh, int32_t inputAddress, int3
     }
     else {
         const int32_t lastLiteralsSize = match_finder(c, inputAddress, inputSize);
-        if (c.dbgStage == 1) {
-            return 0;  // DEBUG (timing split only): stop after the match finder
-        }
         wave_mem_order();
         group_copy<64>(c.litBuf + c.literalsLength, c.in + inputAddress + inputSize - lastLiteralsSize, lastLiteralsSize, c.lane);
         c.literalsLength += lastLiteralsSize;

@@ -45,8 +45,6 @@ constexpr int FSE_CNT = 1280;                // then three 64-entry regions of p
 constexpr int FSE_SLOT = 1280 + 192;         // u16 entries per item: LL 512, OF 256, ML 512 states (symbol | rank << 6), 3 x 64 counts
 constexpr int LIT_STRIDE = MAX_BLOCK_SIZE + 64;
 constexpr int ITEMS_PER_WAVE = 16;
-constexpr int SEQ_ITEMS_PER_WAVE = 16;  // K3: 16 x (2.9 KiB of FSE tables + 256 B of staged records): three wavefronts per CU
-constexpr int SEQ_STAGE = 32;           // K3: records staged per item between bursts
 
 struct Desc {
     int32_t state;     // 1 = on the fast path, 0 = handed to the fallback list
@@ -736,190 +734,12 @@ __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp:
     }
 }
 
-// ---- K3: sequences (MB: the slots are the blocks of multi-block frames -- each of a block's three tables may be that of an earlier
+// ---- K3: sequences, a lane per item (MB: the slots are the blocks of multi-block frames -- each of a block's three tables may be that of an earlier
 // block (repeat mode), and the repeat-offset history at the block's start is what the block before leaves behind, which is not known
 // here: the history starts as three SENTINELS (achip_seqexec2.h REP_SENTINEL), records may hold sentinels, and the history behind the
 // block goes to MbBlock::repOut for the execute stage, which walks the blocks in order and knows) ----
-template <bool MB, int ITEMS = zp::SEQ_ITEMS_PER_WAVE>
-__global__ __launch_bounds__(64) void zstd_pipe_sequences_kernel(BatchArgs a, zp::Pipe p)
-{
-    using namespace zp;
-    __shared__ __attribute__((aligned(16))) uint16_t tables[ITEMS * FSE_SLOT];       // 46 KiB at 16 items: three wavefronts per CU
-    __shared__ __attribute__((aligned(16))) uint64_t staged[ITEMS * SEQ_STAGE];      // 3.75 KiB: records on their way to HBM
-    __shared__ uint32_t codeTab[128];  // literal-length codes at 0.., match-length codes at 64..: baseline | extra bits << 24
-    const int lane = threadIdx.x;
-    const int q = lane >> 2;
-    const int r = lane & 3;
-    {
-        int32_t base = 0, bits = 0;
-        achip_zstd_ll_code(lane < 36 ? lane : 0, &base, &bits);
-        codeTab[lane] = (uint32_t)base | ((uint32_t)bits << 24);
-        achip_zstd_ml_code(lane < 53 ? lane : 0, &base, &bits);
-        codeTab[64 + lane] = (uint32_t)base | ((uint32_t)bits << 24);
-    }
-    const int32_t slot = blockIdx.x * ITEMS + q;
-    bool valid = q < ITEMS && slot < p.count;
-    int32_t from0 = slot, from1 = slot, from2 = slot;  // the slots the literal-length, offset and match-length tables come from
-    if (MB && valid) {
-        const MbBlock b = p.mb[slot];
-        valid = b.kind == 2 && p.mbItem[b.itemSlot].state == 1;
-        from0 = b.fseSlot[0];
-        from1 = b.fseSlot[1];
-        from2 = b.fseSlot[2];
-    }
-    Desc d;
-    d.state = 0;
-    d.nbSeq = 0;
-    if (valid) {
-        d = p.desc[slot];
-    }
-    const bool live = valid && d.state == 1 && d.nbSeq > 0 && (!MB || (from0 >= 0 && from1 >= 0 && from2 >= 0));
-    if (MB && live) {
-        d.log[0] = p.desc[from0].log[0];
-        d.log[1] = p.desc[from1].log[1];
-        d.log[2] = p.desc[from2].log[2];
-    }
-    for (int k = 0; k < ITEMS; k++) {
-        if (__shfl(live ? 1 : 0, k * 4) != 0) {
-            if (MB) {
-                const int32_t f0 = __shfl(from0, k * 4), f1 = __shfl(from1, k * 4), f2 = __shfl(from2, k * 4);
-                uint16_t* t = tables + k * FSE_SLOT;
-                // the three state tables (512, 256, 512 entries) and the three count tables (64 entries each), each from its slot
-                *(u32x4*)(t + FSE_LL + lane * 8) = *(const u32x4*)(p.fse + (size_t)f0 * FSE_SLOT + FSE_LL + lane * 8);
-                *(u32x4*)(t + FSE_ML + lane * 8) = *(const u32x4*)(p.fse + (size_t)f2 * FSE_SLOT + FSE_ML + lane * 8);
-                if (lane < 32) {
-                    *(u32x4*)(t + FSE_OF + lane * 8) = *(const u32x4*)(p.fse + (size_t)f1 * FSE_SLOT + FSE_OF + lane * 8);
-                }
-                else if (lane < 56) {
-                    const int part = (lane - 32) >> 3, i = (lane - 32) & 7;
-                    const int32_t f = part == 0 ? f0 : (part == 1 ? f1 : f2);
-                    *(u32x4*)(t + FSE_CNT + 64 * part + i * 8) = *(const u32x4*)(p.fse + (size_t)f * FSE_SLOT + FSE_CNT + 64 * part + i * 8);
-                }
-            }
-            else {
-                const uint16_t* g = p.fse + (size_t)(blockIdx.x * ITEMS + k) * FSE_SLOT;
-                for (int32_t i = lane * 8; i < FSE_SLOT; i += 64 * 8) {
-                    *(u32x4*)(tables + k * FSE_SLOT + i) = *(const u32x4*)(g + i);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (!live) {
-        return;  // whole quads leave together
-    }
-    const int32_t block = slot_item<MB>(p, slot);
-    const uint8_t* src = a.srcBase + a.srcOff[block];
-    // per-lane role: FSE table, state mask, code table
-    const uint16_t* tab = tables + q * FSE_SLOT + (r == 0 ? FSE_LL : (r == 1 ? FSE_ML : FSE_OF));
-    const uint16_t* cnt = tables + q * FSE_SLOT + FSE_CNT + (r == 0 ? 0 : (r == 1 ? 128 : 64));
-    const int32_t stateMask = r >= 2 ? 255 : 511;
-    const bool isOF = r >= 2;
-    const uint32_t* codes = codeTab + (r == 1 ? 64 : 0);
-    const int32_t myLog = r == 0 ? d.log[0] : (r == 1 ? d.log[2] : d.log[1]);
-    uint64_t* rec = p.seq + d.seqBase;
-    uint64_t* stage = staged + q * SEQ_STAGE;
-
-    QuadBits b;
-    bool bad = !b.init(src, d.seqStart, d.seqEnd);
-    int32_t nDecoded = 0;
-    // the repeat-offset history (replicated in the quad); MB: "what it was before the block", entries 0 .. 2
-    int32_t p0 = MB ? sx2::REP_SENTINEL : 1, p1 = MB ? (sx2::REP_SENTINEL | (1 << 16)) : 4, p2 = MB ? (sx2::REP_SENTINEL | (2 << 16)) : 8;
-    if (!bad) {
-        // initial states in stream order LL, OF, ML (:378-386)
-        const int32_t initOff = r == 0 ? 0 : (r == 1 ? d.log[0] + d.log[1] : d.log[0]);
-        int32_t state = (int32_t)peek_bits(b.consumed + initOff, b.bits, myLog) & stateMask;
-        b.consumed += d.log[0] + d.log[1] + d.log[2];
-        int32_t sequenceCount = d.nbSeq;
-        // ZstdFrameDecompressor.java:388-486.  The body is straight-line (selects, no early exits): an irregular
-        // stream sets `bad` and keeps decoding harmless garbage (every index is masked) until the count runs out.
-        while (sequenceCount > 0) {
-            sequenceCount--;
-            const bool over = b.load();
-            bad |= over && sequenceCount != 0;  // "Not all sequences were consumed"
-            sequenceCount = over ? 0 : sequenceCount;
-            const uint32_t e = tab[state];
-            const int32_t code = (int32_t)(e & 63);
-            // code -> baseline, extra bits; state transition (see K1 for the table form)
-            const uint32_t t = codes[code];
-            const int32_t next = (int32_t)cnt[code] + (int32_t)(e >> 6);
-            const int32_t nb = (myLog - (31 - __builtin_clz((uint32_t)next | 1u))) & 15;
-            const int32_t newState = (next << nb) - (1 << myLog);
-            const int32_t x = isOF ? (code & 31) : (int32_t)(t >> 24);
-            const int32_t base = isOF ? (code < 2 ? code : (1 << (code & 31)) - 3) : (int32_t)(t & 0xFFFFFF);
-            const int32_t xLL = quad_bcast<0>(x), xML = quad_bcast<1>(x), xOF = quad_bcast<2>(x);
-            const int32_t cLL = quad_bcast<0>(code), cML = quad_bcast<1>(code), cOF = quad_bcast<2>(code);
-            bad |= cLL > 35 || cML > 52 || cOF > 28;  // only reachable through a table the Java reader would also have rejected or mis-indexed
-            // extra bits are read in the order offset, match length, literal length
-            const int32_t extraOff = r == 0 ? xOF + xML : (r == 1 ? xOF : 0);
-            const int32_t value = base + b.peek(b.consumed + extraOff, x);
-            const int32_t xsum = xLL + xML + xOF;
-            b.consumed += xsum;
-            if (xsum > 64 - 7 - (9 + 9 + 8)) {
-                b.load();
-            }
-            // state updates in the order LL, ML, OF
-            const int32_t nbLL = quad_bcast<0>(nb), nbML = quad_bcast<1>(nb), nbOF = quad_bcast<2>(nb);
-            const int32_t stateOff = r == 0 ? 0 : (r == 1 ? nbLL : nbLL + nbML);
-            state = (newState + b.peek(b.consumed + stateOff, nb)) & stateMask;
-            b.consumed += nbLL + nbML + nbOF;
-            // repeat-offset history (replicated), :419-452
-            const int32_t literalsLength = quad_bcast<0>(value), matchLength = quad_bcast<1>(value);
-            const int32_t raw = quad_bcast<2>(value) + ((cOF <= 1 && cLL == 0) ? 1 : 0);
-            const bool rep = cOF <= 1;
-            // (a sentinel's low bits count the "- 1" steps: at most one per sequence, fewer than 2^16)
-            int32_t temp = raw == 3 ? ((MB && p0 >= sx2::REP_SENTINEL) ? p0 + 1 : p0 - 1) : (raw == 1 ? p1 : p2);
-            temp = temp == 0 ? 1 : temp;
-            const bool shift2 = rep ? (raw != 0 && raw != 1) : true;   // p2 = p1
-            const bool shift1 = rep ? raw != 0 : true;                 // p1 = p0, p0 = new
-            const int32_t offset = rep ? (raw != 0 ? temp : p0) : raw;
-            p2 = shift2 ? p1 : p2;
-            p1 = shift1 ? p0 : p1;
-            p0 = shift1 ? offset : p0;
-            // an offset beyond 2^24 cannot be a valid back-reference (the window is at most 2^23); keeps the record fields in range and
-            // the sentinels apart from real offsets
-            bad |= offset <= 0 || (offset > (1 << 24) && !(MB && rep && offset >= sx2::REP_SENTINEL));
-            // records are staged in LDS and leave in 256-byte bursts
-            if (r == 3 && !over) {
-                stage[nDecoded & (SEQ_STAGE - 1)] = (uint64_t)(uint32_t)literalsLength | ((uint64_t)(uint32_t)matchLength << 18) | ((uint64_t)(uint32_t)(offset & 0xFFFFFFF) << 36);
-            }
-            nDecoded += over ? 0 : 1;
-            if ((nDecoded & (SEQ_STAGE - 1)) == 0 && !over) {
-                quad_sync();
-                const u32x4* sv = (const u32x4*)stage + r * (SEQ_STAGE / 8);
-                uint8_t* dst = (uint8_t*)(rec + nDecoded - SEQ_STAGE) + r * (SEQ_STAGE * 2);
-#pragma unroll
-                for (int t2 = 0; t2 < SEQ_STAGE / 8; t2++) {
-                    st16(dst + 16 * t2, sv[t2]);
-                }
-                quad_sync();
-            }
-        }
-        if (!bad) {
-            quad_sync();
-            const int32_t rem = nDecoded & (SEQ_STAGE - 1);
-            for (int32_t t2 = r; t2 < rem; t2 += 4) {
-                rec[nDecoded - rem + t2] = stage[t2];
-            }
-        }
-    }
-    if (r == 0) {
-        if (bad) {
-            slot_to_fallback<MB>(p, slot, 3);
-        }
-        else {
-            p.desc[slot].nDecoded = nDecoded;
-            if (MB) {
-                p.mb[slot].repOut[0] = p0;
-                p.mb[slot].repOut[1] = p1;
-                p.mb[slot].repOut[2] = p2;
-            }
-        }
-    }
-}
-
-// ---- K3, a lane per item (round 4) ----
-// The quad version above spreads one item over four lanes: 16 items and ~216 instructions per step and wavefront.  What bounds the stage
+// Until round 4 the stage gave an item to a QUAD of lanes (one state each, the fields' positions a prefix over the quad): 16 items and ~216
+// instructions per step and wavefront.  What bounds the stage
 // is the LDS: 2.5 KB of state tables per item, ~55 items per CU whatever the launch shape, each a serial chain -- so the rate is (items per
 // CU) / (time of one step), and a step of a wavefront costs its instruction count whether 16 or 60 of its lanes hold an item.  Here a LANE
 // owns an item: its three states, its bit container, its repeat-offset history; the three table lookups of a step are independent loads of
@@ -1061,7 +881,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
         return (int32_t)((hi >> 1) >> ((31 - n) & 31));
     };
     int32_t nDecoded = 0;
-    // the repeat-offset history; MB: "what it was before the block", entries 0 .. 2 (see the quad version)
+    // the repeat-offset history; MB: "what it was before the block", entries 0 .. 2 (see above)
     int32_t p0 = MB ? sx2::REP_SENTINEL : 1, p1 = MB ? (sx2::REP_SENTINEL | (1 << 16)) : 4, p2 = MB ? (sx2::REP_SENTINEL | (2 << 16)) : 8;
     if (!bad) {
         // initial states in stream order LL, OF, ML (:378-386)
@@ -1075,7 +895,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
             rem -= n0;
         }
         int32_t sequenceCount = d.nbSeq;
-        // ZstdFrameDecompressor.java:388-486, straight-line as in the quad version: an irregular stream sets `bad` and keeps decoding
+        // ZstdFrameDecompressor.java:388-486, straight-line: an irregular stream sets `bad` and keeps decoding
         // harmless garbage (every index is masked) until the count runs out
         while (sequenceCount > 0) {
             sequenceCount--;
@@ -1287,7 +1107,6 @@ __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp:
 // 128 KiB frames: fragments data -- 100 bytes per sequence -- 720 against 600 GiB/s; corpus -- 13 bytes per sequence -- 83 against 105), and the
 // item's capacity over its sequence count is what both kernels can see (an upper bound of the bytes per sequence: a caller that hands over far
 // more capacity than the frame needs gets the ring version).
-int g_zstd_pipe_seq = 1;   // context option zstd.decompress.seq: 1 = the sequence stage with a lane per item (default), 0 = a quad per item
 int g_zstd_pipe_exec = 2;  // context option zstd.decompress.exec: 2 = per item (default), 1 = this kernel, 0 = the ring version above
 
 template <int WIN = sx2::WIN_DEFAULT>
@@ -1313,7 +1132,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_execute2_kernel(BatchArgs a, zp:
     const uint8_t* lit = d.litMode == 0 ? src + d.litSrc : p.lit + (size_t)d.litBase * 64;
     sx2::RecordSource S{p.seq + d.seqBase, d.nDecoded};
     bool bad = false;
-    const int32_t output = sx2::exec_records<0, WIN>(win, S, lit, d.litSize, out, a.dstCap[block], lane, bad);
+    const int32_t output = sx2::exec_records<WIN>(win, S, lit, d.litSize, out, a.dstCap[block], lane, bad);
     if (lane == 0) {
         if (bad) {
             to_fallback(p, slot, 4);
@@ -1713,7 +1532,7 @@ __global__ __launch_bounds__(64) void zstd_mb_execute_kernel(BatchArgs a, zp::Pi
         }
         const uint8_t* lit = d.litMode == 0 ? src + d.litSrc : p.lit + (size_t)d.litBase * 64;
         sx2::RecordSource S{p.seq + d.seqBase, d.nDecoded, rep0, rep1, rep2};
-        output = sx2::exec_records<0, WIN>(win, S, lit, d.litSize, out, outLimit, lane, bad, output);
+        output = sx2::exec_records<WIN>(win, S, lit, d.litSize, out, outLimit, lane, bad, output);
         const int32_t n0 = sx2::rep_resolve(b.repOut[0], rep0, rep1, rep2), n1 = sx2::rep_resolve(b.repOut[1], rep0, rep1, rep2), n2 = sx2::rep_resolve(b.repOut[2], rep0, rep1, rep2);
         rep0 = n0;
         rep1 = n1;
@@ -1959,12 +1778,7 @@ hipError_t launch_zstd_mb_stages(const BatchArgs& a, hipStream_t stream, zp::Pip
         hipLaunchKernelGGL(zstd_mb_fill_kernel, dim3((nItems + 63) / 64), dim3(64), 0, stream, a, p);
         hipLaunchKernelGGL(zstd_mb_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
         hipLaunchKernelGGL(zstd_pipe_literals_kernel<true>, dim3(w16), dim3(64), 0, stream, a, p);
-        if (g_zstd_pipe_seq != 0) {
-            hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<true>, dim3((unsigned)((p.count + zp::SEQL_ITEMS - 1) / zp::SEQL_ITEMS)), dim3(64), 0, stream, a, p);
-        }
-        else {
-            hipLaunchKernelGGL(zstd_pipe_sequences_kernel<true>, dim3(w16), dim3(64), 0, stream, a, p);
-        }
+        hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<true>, dim3((unsigned)((p.count + zp::SEQL_ITEMS - 1) / zp::SEQL_ITEMS)), dim3(64), 0, stream, a, p);
         hipLaunchKernelGGL(zstd_mb_execute_kernel<>, dim3(nItems), dim3(64), 0, stream, a, p);
         hipLaunchKernelGGL(zstd_mb_checksum_kernel, dim3((nItems + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE), dim3(64), 0, stream, a, p);
     }
@@ -2017,12 +1831,7 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
         // (items per wavefront in K2 / K3 of 8 instead of 16, and an 8 KiB window for the record executor, were round-2 experiments: measured in
         // round 3 within noise of the defaults on all three data sets -- profiles/r03_notes.md -- and removed)
         hipLaunchKernelGGL(zstd_pipe_literals_kernel<false>, dim3(w16), dim3(64), 0, stream, a, p);
-        if (g_zstd_pipe_seq != 0) {
-            hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<false>, dim3((unsigned)((p.count + zp::SEQL_ITEMS - 1) / zp::SEQL_ITEMS)), dim3(64), 0, stream, a, p);
-        }
-        else {
-            hipLaunchKernelGGL(zstd_pipe_sequences_kernel<false>, dim3((unsigned)((p.count + zp::SEQ_ITEMS_PER_WAVE - 1) / zp::SEQ_ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
-        }
+        hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<false>, dim3((unsigned)((p.count + zp::SEQL_ITEMS - 1) / zp::SEQL_ITEMS)), dim3(64), 0, stream, a, p);
         constexpr int GS = 4, IN_RING = 128, OUT_RING = 256;
         if (g_zstd_pipe_exec != 0) {
             hipLaunchKernelGGL(zstd_pipe_execute2_kernel<>, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, (int32_t)g_zstd_pipe_exec);

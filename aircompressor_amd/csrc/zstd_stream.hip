@@ -212,7 +212,6 @@ __global__ __launch_bounds__(64) void zstd_stream_kernel(BatchArgs a, uint8_t* s
         c.out = a.dstBase + a.dstOff[block];
         c.outCap = a.dstCap[block];
         c.lane = lane;
-        c.dbgStage = 0;
         c.batchProbe = 2;  // the window match finder (zstd_dfast_mw.h)
         c.failStatus = 0;
         c.pre = nullptr;

@@ -44,7 +44,7 @@ def parse_args():
     p.add_argument("--workload", default="lz4_decompress", choices=["lz4_decompress", "snappy_decompress", "lz4_compress", "snappy_compress"])
     p.add_argument("--data", default="fragments", choices=["fragments", "wordmix", "corpus"])
     p.add_argument("--group", type=int, default=0, help="decoder lanes per block (0 = library default)")
-    p.add_argument("--variant", type=int, default=-1, help="decoder variant: 5 = chosen on the device (default), 1 = LDS rings, 7 = two passes, 4 / 6 = a lane per block")
+    p.add_argument("--variant", type=int, default=-1, help="decoder variant: 5 = chosen on the device (default), 1 = LDS rings, 7 = two passes")
     p.add_argument("--ring-class", type=int, default=-1, help="0 = compact LDS rings, 1 = large")
     p.add_argument("--compress-variant", type=int, default=-1, help="LZ4 / Snappy encoder variant: 4 = many matches per window (the default of both); LZ4 also 0 / 1, Snappy 0 .. 3 (see lz4.compress.variant / snappy.compress.variant)")
     p.add_argument("--ring-pad", type=int, default=-1, help="LDS bytes between the ring pairs of consecutive blocks (multiple of 16)")
@@ -57,7 +57,6 @@ def parse_args():
     p.add_argument("--exec-variant", type=int, default=-1, help="DEBUG: decompress.exec_variant (two-pass decoders)")
     p.add_argument("--section", default="all", choices=["all", "zstd", "zstdstream", "xxhash", "lz4frame"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-exec", type=int, default=-1, help="zstd pipeline execute stage: 2 = chosen per item (default), 1 = wavefront per item through the record executor, 0 = LDS rings")
-    p.add_argument("--zstd-seq", type=int, default=-1, help="zstd pipeline sequence stage: 1 = a lane per item (default), 0 = a quad per item")
     p.add_argument("--snappyframed-variant", type=int, default=-1, help="x-snappy-framed reader: 3 = ring or two-pass decoder by a probe (default), 1 = chunks through the ring decoders, 2 = through the two-pass decoder, 0 = a wavefront per stream")
     p.add_argument("--lz4frame-variant", type=int, default=-1, help="LZ4 frame reader: 2 = by a probe (default), 0 = a wavefront per item, 1 = the frames' blocks as one batch through the two-pass block decoder")
     p.add_argument("--hadoop-variant", type=int, default=-1, help="Hadoop block-stream reader: 3 = ring or two-pass decoders by a probe (default), 1 = chunks through the ring decoders, 2 = through the two-pass decoders, 0 = a wavefront per stream")
@@ -537,21 +536,17 @@ def kernel_sources_hash():
     return h.hexdigest()
 
 
-DECODER_NAMES = {0: "rings", 1: "lane-per-block", 2: "lane-per-block with LDS window", 3: "two-pass (parse to records, a wavefront per block executes)"}
+DECODER_NAMES = {0: "rings", 3: "two-pass (parse to records, a wavefront per block executes)"}
 
 
 def kernel_symbol(wl, decoder):
     """the dominant kernel of the timed launch as rocprofv3 names it (profiles/*_kernel_stats.csv)"""
     if wl.endswith("decompress") and decoder.startswith("two-pass"):
-        return "achip::seq_execute2_kernel<0, 4096, 0> (+ achip::%s_parse2_kernel<0>)" % wl.split("_")[0]
+        return "achip::seq_execute2_kernel<4096, 0> (+ achip::%s_parse2_kernel)" % wl.split("_")[0]
     if wl == "lz4_decompress":
-        if decoder.endswith("LDS window"):
-            return "achip::lz4_decompress_lanewindow_kernel<16, 64>"
-        return "achip::lz4_decompress_lanecopy_kernel<16, false>" if decoder.startswith("lane") else "achip::lz4_decompress_rings_kernel<4, 256, 256, 1, false, 4>"
+        return "achip::lz4_decompress_rings_kernel<4, 256, 256, 1, false, 4>"
     if wl == "snappy_decompress":
-        if decoder.endswith("LDS window"):
-            return "achip::snappy_decompress_lanewindow_kernel<16, 64>"
-        return "achip::snappy_decompress_lanecopy_kernel<16>" if decoder.startswith("lane") else "achip::snappy_decompress_rings_kernel<4, 256, 256, 1, false, 1>"
+        return "achip::snappy_decompress_rings_kernel<4, 256, 256, 1, false, 1>"
     return "achip::lz4_compress_mw_kernel<unsigned short>" if wl == "lz4_compress" else "achip::snappy_compress_tiers_kernel<true>"
 
 
@@ -739,8 +734,6 @@ def zstd_extra(torch, A, codec, dev, args):
         codec.native.set_option("zstd.decompress.variant", args.zstd_variant)
     if args.zstd_exec >= 0:
         codec.native.set_option("zstd.decompress.exec", args.zstd_exec)
-    if args.zstd_seq >= 0:
-        codec.native.set_option("zstd.decompress.seq", args.zstd_seq)
     if args.zstd_compress_variant >= 0:
         codec.native.set_option("zstd.compress.variant", args.zstd_compress_variant)
     zc = pa.Codec("zstd", compression_level=3)

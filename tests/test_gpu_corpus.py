@@ -73,7 +73,7 @@ def test_every_block_cut_both_directions(gb, o, codec):
     plain = [corpus[f][off:off + n] for f, off, n, *_ in rows]
     outs, status, _ = gb.run(OPS[codec][0], plain, [o.max_compressed_length(codec, len(b)) for b in plain])
     check_streams(codec, rows, outs, status, java)
-    variants = {"lz4": [5, 1, 4, 6, 7], "snappy": [5, 1, 4, 6, 7], "zstd": [1, 0]}[codec]
+    variants = {"lz4": [5, 1, 7], "snappy": [5, 1, 7], "zstd": [1, 0]}[codec]
     try:
         for v in variants:
             gb.set_option("%s.decompress.variant" % codec, v)

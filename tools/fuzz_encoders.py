@@ -7,7 +7,7 @@ from tests import common, oracle_lib
 from tests.gpu_harness import GpuBatch
 
 OPS = {"lz4": 1, "snappy": 3, "zstd": 5, "lz4frame": 7, "snappyframed": 9}
-VARIANTS = {"lz4": [4, 1, 0], "snappy": [4, 3, 2, 1, 0], "zstd": [3, 0, 2], "lz4frame": [None], "snappyframed": [None]}  # (defaults first; the loop leaves the default set)
+VARIANTS = {"lz4": [4, 1, 0], "snappy": [4, 2, 1, 0], "zstd": [3, 0, 2], "lz4frame": [None], "snappyframed": [None]}  # (defaults first; the loop leaves the default set)
 
 
 def make_inputs(rng, n, max_len):

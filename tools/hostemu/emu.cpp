@@ -8,19 +8,16 @@ thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 extern "C" { long long achip_emu_counters[16]; }  // development counters of kernels under emulation (ACHIP_EMU_COUNT)
 #include "../../aircompressor_amd/csrc/lz4_decompress_v2.hip"
 #include "../../aircompressor_amd/csrc/snappy_decompress_v2.hip"
-#include "../../aircompressor_amd/csrc/lz4_decompress_v6.hip"
-#include "../../aircompressor_amd/csrc/snappy_decompress_v4.hip"
 #include "../../aircompressor_amd/csrc/lz4_decompress_v7.hip"
 #include "../../aircompressor_amd/csrc/snappy_decompress_v5.hip"
 #include "../../aircompressor_amd/csrc/hadoop_streams.hip"
 #include "../../aircompressor_amd/csrc/lz4_frame.hip"
 #include "../../aircompressor_amd/csrc/snappy_frame.hip"
 #include <vector>
-// the decoders the emulator does not build (DPP / cross-lane copy steps) and the probes that would pick them: the probe statistics stay
+// the probes of the decoders' auto mode are not built here: the probe statistics stay
 // zero, which picks the ring decoders
 namespace achip {
-hipError_t launch_lz4_decompress_lanecopy(const BatchArgs&, hipStream_t, const int32_t*) { return hipSuccess; }
-hipError_t launch_snappy_decompress_lanecopy(const BatchArgs&, hipStream_t, const int32_t*) { return hipSuccess; }
+hipError_t launch_snappy_element_sample(const BatchArgs&, hipStream_t, int32_t*, int32_t) { return hipSuccess; }
 hipError_t launch_lz4_sequence_sample(const BatchArgs&, hipStream_t, int32_t*, int32_t) { return hipSuccess; }
 hipError_t launch_lz4_mixed_groups(const BatchArgs&, hipStream_t, int32_t*, int32_t) { return hipSuccess; }
 }  // namespace achip
@@ -37,8 +34,6 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
         return snappy ? achip::launch_snappy_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, 2, nullptr)
                       : achip::launch_lz4_decompress_twopass(a, nullptr, scratch.data(), bytes, 1, 0, 2, nullptr);
     }
-    if (op == 19) return achip::launch_snappy_decompress_lanewindow(a, nullptr, nullptr);
-    if (op == 18) return achip::launch_lz4_decompress_lanewindow(a, nullptr, nullptr);  // lane per block + LDS output window: lane-private
     if (op == 16 || op == 17) {  // default ring decoders at GS = 1 (compact / large rings)
         a.ringPad = 16;
         return achip::launch_lz4_decompress_rings(a, nullptr, 1, op - 16, nullptr);
@@ -77,7 +72,7 @@ void emu_exec_records_kernel(const uint64_t* rec, int32_t n, const uint8_t* lit,
     __shared__ __attribute__((aligned(16))) uint8_t win[achip::sx2::WIN_DEFAULT + 16];
     achip::sx2::RecordSource S{rec, n};
     bool bad = false;
-    const int32_t produced = achip::sx2::exec_records<0>(win, S, lit, litSize, out, outLimit, (int)threadIdx.x, bad);
+    const int32_t produced = achip::sx2::exec_records<>(win, S, lit, litSize, out, outLimit, (int)threadIdx.x, bad);
     if (threadIdx.x == 0) {
         result[0] = produced;
         result[1] = bad ? 1 : 0;

@@ -8,7 +8,6 @@
 #include "emu.cpp"  // (the decoders and the container readers / writers: hadoop_streams.hip, lz4_frame.hip, snappy_frame.hip)
 #include "../../aircompressor_amd/csrc/lz4_compress.hip"
 #include "../../aircompressor_amd/csrc/snappy_compress.hip"
-#include "../../aircompressor_amd/csrc/snappy_compress_v3.hip"
 #ifdef ACHIP_HOST_STATS
 extern "C" { long long g_zc_stats[32]; }  // tools/hostemu/zc_stats.py
 #endif
@@ -29,7 +28,7 @@ extern "C" int emu_encode(int op, const uint8_t* srcBase, const int64_t* srcOff,
     }
     if (op == 3) {
         scratch.assign((size_t)achip::snappy_compress_scratch_bytes(), 0xCD);
-        return option == 3 ? achip::launch_snappy_compress_window(a, nullptr, scratch.data()) : achip::launch_snappy_compress(a, nullptr, option, scratch.data());
+        return achip::launch_snappy_compress(a, nullptr, option, scratch.data());
     }
     if (op == 5 || op == 14) {
         if (op == 5) a.ringPad = option == 1 ? 1 : (option == 3 ? 3 : 0);  // (what achip_abi.cpp does: the one-kernel path reads the variant from the spare field)

@@ -96,9 +96,9 @@ class EmuAllBatch(EmuBatch):
         a = (P(src), P(src_off), P(src_len), P(dst), P(dst_off), P(caps), P(out_len), P(status), P(err), n)
         o = self.options
         if op == 0:
-            return self.lib.emu_batch({1: 44, 7: 24, 6: 18}.get(o.get("lz4.decompress.variant", 1), 44), *a)
+            return self.lib.emu_batch({1: 44, 7: 24}.get(o.get("lz4.decompress.variant", 1), 44), *a)
         if op == 2:
-            return self.lib.emu_batch({1: 54, 7: 34, 6: 19}.get(o.get("snappy.decompress.variant", 1), 54), *a)
+            return self.lib.emu_batch({1: 54, 7: 34}.get(o.get("snappy.decompress.variant", 1), 54), *a)
         if op == 4:
             self.variant = o.get("zstd.decompress.variant", 1)
             return self.lib.emu_zstd_full(*a, int(self.variant), int(o.get("zstd.decompress.stream_blocks", 65536)), P(self.counters))

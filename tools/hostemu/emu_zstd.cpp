@@ -82,7 +82,6 @@ extern "C" int emu_zstd_pipe(const uint8_t* srcBase, const int64_t* srcOff, cons
     const int64_t bytes = achip::zstd_decompress_pipe_scratch_bytes(n, tile);
     scratch.assign((size_t)bytes, 0xCD);
     achip::g_zstd_pipe_exec = execMode & 3;
-    if (getenv("ACHIP_EMU_ZSTD_SEQ")) achip::g_zstd_pipe_seq = atoi(getenv("ACHIP_EMU_ZSTD_SEQ"));  // zstd.decompress.seq
     achip::g_fallback.clear();
     for (int32_t i = 0; i < n; i++) {
         status[i] = -999;  // "not written"

@@ -12,7 +12,7 @@ sample = np.fromfile(os.path.join(root, "tests", "golden", "corpus_sample.bin"),
 meta = json.load(open(os.path.join(root, "tests", "golden", "corpus_sample.json")))
 names = ["%s+%d" % (m["file"], m["offset"]) for m in meta]
 bs, n = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 32768
-variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 4]
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 7]
 i64 = dict(dtype=torch.int64, device=dev); i32 = dict(dtype=torch.int32, device=dev)
 max_c = codec.lib.achip_lz4_max_compressed_length(bs)
 cs = (max_c + 15) // 16 * 16
