@@ -55,6 +55,13 @@ PY
       bash tools/pmc_any.sh r04zs2 "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM" python bench.py --section zstd --no-cpu-baseline
       grep "sequences\|execute2\|literals\|pipe_parse" gpurun_out/pmc_r04zs1.txt gpurun_out/pmc_r04zs2.txt | sed 's/gpurun_out.pmc_r04//' | cut -c1-200
       cp gpurun_out/pmc_r04zs1.txt gpurun_out/pmc_r04zs2.txt $O/ ;;
+    pmc_twopass)   # SQ counters of the two-pass decoders' kernels on the corpus batch
+      for wl in lz4_decompress snappy_decompress; do
+        bash tools/pmc.sh r04tp1_$wl "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" --workload $wl --data corpus --steps 3 --warmup 1
+        bash tools/pmc.sh r04tp2_$wl "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" --workload $wl --data corpus --steps 3 --warmup 1
+        grep "parse2\|execute2" gpurun_out/pmc_r04tp1_$wl.txt gpurun_out/pmc_r04tp2_$wl.txt | sed 's/gpurun_out.pmc_r04//; s/(achip::BatchArgs.*) *SQ/ SQ/' | cut -c1-150
+        cat gpurun_out/pmc_r04tp1_$wl.txt gpurun_out/pmc_r04tp2_$wl.txt > $O/pmc_twopass_$wl.txt
+      done ;;
     tests)
       timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
     *) echo "unknown step $step" ;;
