@@ -41,8 +41,7 @@ using namespace zd;
 constexpr int FAST_HUF_LOG = 11;
 constexpr int HUF_SLOT = 1 << FAST_HUF_LOG;  // u16 entries per item
 constexpr int FSE_LL = 0, FSE_OF = 512, FSE_ML = 768;
-constexpr int FSE_CNT = 1280;                // then three 64-entry regions of per-symbol counts (LL, OF, ML)
-constexpr int FSE_SLOT = 1280 + 192;         // u16 entries per item: LL 512, OF 256, ML 512 states (symbol | rank << 6), 3 x 64 counts
+constexpr int FSE_SLOT = 1280;               // u16 entries per item: LL 512, OF 256, ML 512 states (symbol | nextState << 6)
 constexpr int LIT_STRIDE = MAX_BLOCK_SIZE + 64;
 constexpr int ITEMS_PER_WAVE = 16;
 
@@ -389,16 +388,14 @@ __device__ bool parse_block(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot
         const int32_t maxLog[3] = {9, 8, 9};
         const int32_t dfltLog[3] = {6, 5, 6};
         const int32_t base[3] = {FSE_LL, FSE_OF, FSE_ML};
-        // Published form of a decoding table (half the LDS of the {newState, symbol, bits} form, so K3 keeps 48 items per
-        // CU): per state  symbol | rank << 6  where rank = nextState - count[symbol]  (FseTableReader.java:143-158 walks
-        // the states of a symbol in order, handing out nextState = count, count + 1, ...), and per symbol its count.
-        // K3 recovers  bits = log - highBit(nextState),  newState = (nextState << bits) - (1 << log).
+        // Published form of a decoding table (half the LDS of the {newState, symbol, bits} form, so K3 keeps 64 items per
+        // CU): per state  symbol | nextState << 6  (FseTableReader.java:143-158 walks the states of a symbol in order, handing out nextState
+        // = count, count + 1, ...: below 2 << log = 1024, ten bits).  K3 recovers  bits = log - highBit(nextState),  newState =
+        // (nextState << bits) - (1 << log).  (Until round 4: symbol | rank << 6 plus a count per symbol, added at every step.)
         uint16_t* g = p.fse + (size_t)slot * FSE_SLOT;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int32_t mode = (modes >> (6 - 2 * k)) & 3;
-            uint16_t* cnt = g + FSE_CNT + 64 * k;
-            const int16_t* dnorm = k == 0 ? LL_DEFAULT_NORM : (k == 1 ? OF_DEFAULT_NORM : ML_DEFAULT_NORM);
             int32_t tableLog = 0;
             if (mode == 3) {
                 if (((fseBefore >> k) & 1) == 0) {
@@ -415,8 +412,7 @@ __device__ bool parse_block(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot
                     return false;
                 }
                 if (c.lane == 0) {
-                    g[base[k]] = (uint16_t)value;  // one state: nextState 1 = count 1 + rank 0
-                    cnt[value] = 1;
+                    g[base[k]] = (uint16_t)(value | (1 << 6));  // one state: nextState 1
                 }
             }
             else if (mode == 0) {
@@ -424,13 +420,8 @@ __device__ bool parse_block(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot
                 for (int32_t i = c.lane; i < (1 << log); i += 64) {
                     const uint32_t e = dflt[k].e[i];
                     const int32_t sym = FSE_SYMBOL(e);
-                    const int32_t n = dnorm[sym];
                     const int32_t next = (FSE_NEWSTATE(e) + (1 << log)) >> FSE_NBITS(e);
-                    g[base[k] + i] = (uint16_t)(sym | ((next - (n == -1 ? 1 : n)) << 6));
-                }
-                for (int32_t i = c.lane; i <= maxSym[k]; i += 64) {
-                    const int32_t n = dnorm[i];
-                    cnt[i] = (uint16_t)(n == -1 ? 1 : n);
+                    g[base[k] + i] = (uint16_t)(sym | ((next & 1023) << 6));
                 }
                 tableLog = log;
             }
@@ -444,13 +435,8 @@ __device__ bool parse_block(Ctx& c, TableShared& sh, const Pipe& p, int32_t slot
                 for (int32_t i = c.lane; i < (1 << log); i += 64) {
                     const uint32_t e = sh.fse[k].e[i];
                     const int32_t sym = FSE_SYMBOL(e);
-                    const int32_t cn = sh.norm[sym];
                     const int32_t next = (FSE_NEWSTATE(e) + (1 << log)) >> FSE_NBITS(e);
-                    g[base[k] + i] = (uint16_t)(sym | ((next - (cn == -1 ? 1 : cn)) << 6));
-                }
-                for (int32_t i = c.lane; i <= maxSym[k]; i += 64) {
-                    const int32_t cn = sh.norm[i];
-                    cnt[i] = (uint16_t)(cn == -1 ? 1 : (cn < 0 ? 0 : cn));
+                    g[base[k] + i] = (uint16_t)(sym | ((next & 1023) << 6));
                 }
                 __syncthreads();  // sh.norm is rewritten by the next table
                 tableLog = log;
@@ -744,28 +730,35 @@ __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp:
 // CU) / (time of one step), and a step of a wavefront costs its instruction count whether 16 or 60 of its lanes hold an item.  Here a LANE
 // owns an item: its three states, its bit container, its repeat-offset history; the three table lookups of a step are independent loads of
 // one lane, nothing is broadcast, the record goes straight to the arena (8 bytes per lane and step: the L2 merges a line's pieces).  60 items
-// per wavefront, one wavefront per CU (60 x 2576 B of LDS).  The tables are staged in the form  symbol | nextState << 6  (K1 publishes
-// symbol | rank << 6 and a count per symbol: nextState = count + rank is added here, once per entry, instead of a second dependent lookup
-// per step).
+// per wavefront at first; 64 since K1 publishes  symbol | nextState << 6  itself (the staging is a plain copy, no counts to hold) and the code
+// tables (128 words) moved from LDS to a constant table in memory (hot in the CU's L1): 64 x 2 560 B = the CU's whole LDS, one wavefront per CU.
 namespace zp {
-constexpr int SEQL_ITEMS = 60;
-constexpr int SEQL_STRIDE = 1280 + 8;  // u16 per item in LDS (+ 16 bytes: consecutive items start on different banks)
+constexpr int SEQL_ITEMS = 64;      // every lane holds an item: 64 x 2 560 B of tables = the CU's whole LDS
+constexpr int SEQL_STRIDE = 1280;   // u16 per item in LDS
 }
+// sequence code -> baseline | extra bits << 24: literal-length codes at 0 .. 35, match-length codes at 64 .. 116 (ZstdFrameDecompressor.java:68-83;
+// the arithmetic form in zstd_codes.h is what tests/test_host_logic.py holds against the Java tables, and tests/test_host_logic.py holds THIS
+// table against that form)
+#define ZC(base, bits) ((uint32_t)(base) | ((uint32_t)(bits) << 24))
+__device__ const uint32_t seq_code_table[128] = {
+    ZC(0, 0), ZC(1, 0), ZC(2, 0), ZC(3, 0), ZC(4, 0), ZC(5, 0), ZC(6, 0), ZC(7, 0), ZC(8, 0), ZC(9, 0), ZC(10, 0), ZC(11, 0), ZC(12, 0), ZC(13, 0), ZC(14, 0), ZC(15, 0),
+    ZC(16, 1), ZC(18, 1), ZC(20, 1), ZC(22, 1), ZC(24, 2), ZC(28, 2), ZC(32, 3), ZC(40, 3), ZC(48, 4), ZC(64, 6), ZC(128, 7), ZC(256, 8), ZC(512, 9), ZC(1024, 10),
+    ZC(2048, 11), ZC(4096, 12), ZC(8192, 13), ZC(16384, 14), ZC(32768, 15), ZC(65536, 16),
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+    ZC(3, 0), ZC(4, 0), ZC(5, 0), ZC(6, 0), ZC(7, 0), ZC(8, 0), ZC(9, 0), ZC(10, 0), ZC(11, 0), ZC(12, 0), ZC(13, 0), ZC(14, 0), ZC(15, 0), ZC(16, 0), ZC(17, 0), ZC(18, 0),
+    ZC(19, 0), ZC(20, 0), ZC(21, 0), ZC(22, 0), ZC(23, 0), ZC(24, 0), ZC(25, 0), ZC(26, 0), ZC(27, 0), ZC(28, 0), ZC(29, 0), ZC(30, 0), ZC(31, 0), ZC(32, 0), ZC(33, 0), ZC(34, 0),
+    ZC(35, 1), ZC(37, 1), ZC(39, 1), ZC(41, 1), ZC(43, 2), ZC(47, 2), ZC(51, 3), ZC(59, 3), ZC(67, 4), ZC(83, 4), ZC(99, 5), ZC(131, 7), ZC(259, 8), ZC(515, 9),
+    ZC(1027, 10), ZC(2051, 11), ZC(4099, 12), ZC(8195, 13), ZC(16387, 14), ZC(32771, 15), ZC(65539, 16),
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+};
+#undef ZC
 template <bool MB>
 __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs a, zp::Pipe p)
 {
     using namespace zp;
     __shared__ __attribute__((aligned(16))) uint16_t tables[SEQL_ITEMS * SEQL_STRIDE];
-    __shared__ __attribute__((aligned(16))) uint16_t cntTmp[192];
-    __shared__ uint32_t codeTab[128];  // literal-length codes at 0.., match-length codes at 64..: baseline | extra bits << 24
+    const uint32_t* const codeTab = seq_code_table;  // literal-length codes at 0.., match-length codes at 64..: baseline | extra bits << 24
     const int lane = threadIdx.x;
-    {
-        int32_t base = 0, bits = 0;
-        achip_zstd_ll_code(lane < 36 ? lane : 0, &base, &bits);
-        codeTab[lane] = (uint32_t)base | ((uint32_t)bits << 24);
-        achip_zstd_ml_code(lane < 53 ? lane : 0, &base, &bits);
-        codeTab[64 + lane] = (uint32_t)base | ((uint32_t)bits << 24);
-    }
     const int32_t slot = blockIdx.x * SEQL_ITEMS + lane;
     bool valid = lane < SEQL_ITEMS && slot < p.count;
     int32_t from0 = slot, from1 = slot, from2 = slot;  // the slots the literal-length, offset and match-length tables come from
@@ -797,27 +790,13 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
         const uint16_t* gLL = p.fse + (size_t)f0 * FSE_SLOT;
         const uint16_t* gOF = p.fse + (size_t)f1 * FSE_SLOT;
         const uint16_t* gML = p.fse + (size_t)f2 * FSE_SLOT;
-        if (lane < 24) {  // the three count tables (64 entries each: 8 lanes x 16 bytes)
-            const int part = lane >> 3, i = lane & 7;
-            const uint16_t* g = part == 0 ? gLL : (part == 1 ? gOF : gML);
-            *(u32x4*)(cntTmp + 64 * part + 8 * i) = *(const u32x4*)(g + FSE_CNT + 64 * part + 8 * i);
-        }
-        __syncthreads();
         for (int32_t piece = lane; piece < 160; piece += 64) {  // 1280 states, 8 per piece: LL 0..511, OF 512..767, ML 768..1279
             const int32_t i = piece * 8;
-            const int part = i < FSE_OF ? 0 : (i < FSE_ML ? 1 : 2);
-            const uint16_t* g = part == 0 ? gLL : (part == 1 ? gOF : gML);
-            const u32x4 v = *(const u32x4*)(g + i);
-            const uint16_t* cnt = cntTmp + 64 * part;
-            auto conv = [&](uint32_t w) -> uint32_t {
-                const uint32_t e0 = w & 0xFFFF, e1 = w >> 16;
-                const uint32_t n0 = (uint32_t)cnt[e0 & 63] + (e0 >> 6), n1 = (uint32_t)cnt[e1 & 63] + (e1 >> 6);
-                return ((e0 & 63) | ((n0 & 1023) << 6)) | (((e1 & 63) | ((n1 & 1023) << 6)) << 16);
-            };
-            *(u32x4*)(tables + k * SEQL_STRIDE + i) = u32x4{conv(v.x), conv(v.y), conv(v.z), conv(v.w)};
+            const uint16_t* g = i < FSE_OF ? gLL : (i < FSE_ML ? gOF : gML);
+            *(u32x4*)(tables + k * SEQL_STRIDE + i) = *(const u32x4*)(g + i);
         }
-        __syncthreads();
     }
+    __syncthreads();
     if (!live) {
         return;
     }

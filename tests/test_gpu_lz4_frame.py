@@ -149,3 +149,24 @@ def test_full_size_property(gb, o):
     assert all(s == 0 for s in status)
     want = [hashlib.sha256(b).digest() for b in inputs_] * 8
     assert [hashlib.sha256(p).digest() for p in plain] == want
+
+
+def test_writer_with_more_frames_than_resident_wavefronts(gb, o):
+    """Round 4: the frame writer runs one wavefront (and one 4 MiB slab of scratch) per resident slot, up to 2 304 of them, and its items are drawn
+    from a counter.  3 000 frames -- more than one draw per wavefront, more than round 3's 512 slots -- of sizes around the piece / block borders
+    must be byte-identical to the Java writer's and decode to the plaintext."""
+    import hashlib
+    base = b"".join(d for _, d, _ in common.corpus_sample())
+    sizes = [1, 11, 12, 13, 64, 4096, 65535, 65536, 65537, 100000]
+    blocks = [base[(i * 7919) % 50000:(i * 7919) % 50000 + sizes[i % len(sizes)]] for i in range(3000)]
+    caps = [o.max_compressed_length("lz4frame", len(b)) for b in blocks]
+    outs, status, _ = gb.run(OP_COMPRESS, blocks, caps)
+    assert all(s == 0 for s in status)
+    want = {}
+    for i in range(0, 3000, 37):  # (every distinct size several times; the oracle is the slow side)
+        key = (len(blocks[i]), hashlib.sha256(blocks[i]).digest())
+        if key not in want:
+            want[key] = o.compress("lz4frame", blocks[i])
+        assert outs[i] == want[key], i
+    plain, status, _ = gb.run(OP_DECOMPRESS, outs, [len(b) for b in blocks])
+    assert all(s == 0 for s in status) and plain == blocks

@@ -43,6 +43,37 @@ def test_zstd_code_arithmetic_equals_the_java_tables():
         assert out.strip() == "0"
 
 
+def test_sequence_stage_code_table_equals_the_java_tables():
+    """zstd_decompress_pipe.hip's constant `seq_code_table` (round 4: the sequence stage's code -> baseline | extra bits << 24 table, literal-length codes at
+    0.., match-length codes at 64..) parsed from the source text and compared, entry by entry, with the oracle's restatement of the Java tables
+    (ZstdFrameDecompressor.java:68-83) -- printed by a small C program, as in the test above"""
+    import re
+    src = open(os.path.join(ROOT, "aircompressor_amd", "csrc", "zstd_decompress_pipe.hip")).read()
+    body = src[src.index("__device__ const uint32_t seq_code_table[128] = {"):]
+    body = body[body.index("{") + 1:body.index("};")]
+    entries = []
+    for tok in re.findall(r"ZC\((\d+), (\d+)\)|(?<![\w(])(0)(?=,)", body):
+        entries.append((int(tok[0]), int(tok[1])) if tok[0] else (0, 0))
+    assert len(entries) == 128, len(entries)
+    prog = r"""
+#include <stdio.h>
+#include "oracle/zstd_dec.c"
+int main(void)
+{
+    for (int c = 0; c < 36; c++) printf("%d %d\n", LITERALS_LENGTH_BASE[c], LITERALS_LENGTH_BITS[c]);
+    for (int c = 0; c < 53; c++) printf("%d %d\n", MATCH_LENGTH_BASE[c], MATCH_LENGTH_BITS[c]);
+    return 0;
+}
+"""
+    with tempfile.TemporaryDirectory() as tmp:
+        cfile, exe = os.path.join(tmp, "t.c"), os.path.join(tmp, "t")
+        open(cfile, "w").write(prog)
+        subprocess.run(["gcc", "-O1", "-std=gnu11", "-I", ROOT, "-I", os.path.join(ROOT, "oracle"), "-o", exe, cfile, os.path.join(ROOT, "oracle", "xxhash64.c")], check=True)
+        java = [tuple(int(x) for x in l.split()) for l in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n") if l]
+    assert entries[:36] == java[:36] and entries[64:64 + 53] == java[36:]
+    assert all(e == (0, 0) for e in entries[36:64] + entries[117:])
+
+
 def test_lane_private_decoder_kernels_on_the_cpu():
     """The kernel sources compiled for the host and run under tools/hostemu (every thread a fiber, cross-lane operations as rendezvous, lanes
     in a different order from pass to pass): the ring decoders with one lane per block and -- the product's default, the headline's kernel --

@@ -62,6 +62,27 @@ PY
         grep "parse2\|execute2" gpurun_out/pmc_r04tp1_$wl.txt gpurun_out/pmc_r04tp2_$wl.txt | sed 's/gpurun_out.pmc_r04//; s/(achip::BatchArgs.*) *SQ/ SQ/' | cut -c1-150
         cat gpurun_out/pmc_r04tp1_$wl.txt gpurun_out/pmc_r04tp2_$wl.txt > $O/pmc_twopass_$wl.txt
       done ;;
+    final)         # the pass that ships: suite, smoke, bench.py as the driver runs it, rocprofv3 summaries of BOTH headline kernels, traffic.json, Zstd per-dispatch times, --gpus 2 on one device
+      F=$O/final; rm -rf $F; mkdir -p $F
+      timeout 1500 python -m pytest tests -m gpu -x -q > $F/pytest.log 2>&1; tail -2 $F/pytest.log
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+      timeout 1500 python bench.py > $F/bench_final.json 2> $F/bench_final.err
+      python - <<'PY'
+import json
+r = json.loads([l for l in open("gpurun_out/r04/final/bench_final.json") if l.startswith("{")][-1])
+print("value", r["value"], "frac", r["roofline"]["frac"], "traffic", r["roofline"]["traffic"], "cpu", r["cpu_baseline"]["value"])
+for k in ("value_corpus", "value_snappy", "value_snappy_corpus", "value_zstd", "value_zstd_corpus", "value_zstd_stream_corpus"):
+    print(k, r.get(k))
+PY
+      timeout 700 bash tools/profile.sh r04final_lz4 --steps 5 --warmup 2 > $F/profile_lz4_summary.txt 2>&1
+      cp gpurun_out/prof_r04final_lz4/keep/*kernel_stats.csv $F/lz4_kernel_stats.csv 2>/dev/null
+      timeout 700 bash tools/profile.sh r04final_snappy --steps 5 --warmup 2 --workload snappy_decompress > $F/profile_snappy_summary.txt 2>&1
+      cp gpurun_out/prof_r04final_snappy/keep/*kernel_stats.csv $F/snappy_kernel_stats.csv 2>/dev/null
+      timeout 600 python tools/make_traffic_json.py $F/traffic.json > $F/traffic.log 2>&1; tail -1 $F/traffic.log | cut -c1-400
+      timeout 500 bash tools/profile_zstd.sh r04finalz --no-cpu-baseline > $F/zstd_line.txt 2>&1
+      cp gpurun_out/prof_r04finalz/keep/dispatches.txt $F/zstd_dispatches.txt; cp gpurun_out/prof_r04finalz/keep/*kernel_stats.csv $F/zstd_kernel_stats.csv
+      ACHIP_BENCH_SHARE_DEVICE=1 timeout 600 python bench.py --gpus 2 --blocks 65536 --steps 3 --warmup 1 --no-extra --no-cpu-baseline > $F/n2.json 2> $F/n2.err; grep -c '^{' $F/n2.json
+      ;;
     tests)
       timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
     *) echo "unknown step $step" ;;
