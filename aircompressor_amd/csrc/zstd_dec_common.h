@@ -169,8 +169,9 @@ __device__ __forceinline__ bool bit_load(const Ctx& c, Bits& b)
 }
 
 // ---- FSE decoding table from normalized counts: FseTableReader.java:127-159 + spreadSymbols ----
-// Wave-uniform serial code: every lane computes the same values; lane 0's LDS stores are the ones that count.
-static __device__ int32_t fse_build(Ctx& c, TableShared& sh, FseTable& t, int32_t maxSymbol, int32_t tableLog, int32_t off)
+// Wave-uniform serial code: every lane computes the same values; lane 0's LDS stores are the ones that count.  Since round 4 this is the
+// FALLBACK of fse_build below (count sets whose walk does not visit every position exactly once: corrupt tables, which it reports as the Java code does).
+static __device__ int32_t fse_build_serial(Ctx& c, TableShared& sh, FseTable& t, int32_t maxSymbol, int32_t tableLog, int32_t off)
 {
     const int32_t tableSize = 1 << tableLog;
     int32_t high = tableSize - 1;
@@ -219,6 +220,118 @@ static __device__ int32_t fse_build(Ctx& c, TableShared& sh, FseTable& t, int32_
         }
     }
     __syncthreads();
+    return 0;
+}
+
+
+// The same table built by the wavefront (round 4; the pipeline's parse stage spent most of its time in the serial walk above: 512 states x 3
+// tables per item by one lane).  What the Java code computes, restated as closed forms:
+//   * symbols with count -1 ("less than one") take the table's top positions, in symbol order, one state each (FseTableReader.java:133-141);
+//   * the walk  position = (position + step) & mask  visits position u as its j(u)-th stop, j(u) = u * step^-1 mod size (step is odd), and skips
+//     the stops on the top positions: u is the k-th position FILLED, k = j(u) - #{top positions v with j(v) < j(u)};
+//   * the symbols are handed out in symbol order, count[s] positions each: the k-th filled position gets the symbol whose running total covers k;
+//   * nextState numbers a symbol's states in POSITION order from count[s] on (:143-158): rank = how many lower positions hold the same symbol.
+// A lane takes positions u = lane, lane + 64, ...; ranks come from ballots over 64 positions at a time plus a running count per symbol.
+// Exact for every count set whose walk fills each position once (sum of the positive counts = positions below the top ones: every table
+// readFseTable accepts, the predefined ones, the Huffman weights'); anything else goes to the serial walk.
+static __device__ int32_t fse_build(Ctx& c, TableShared& sh, FseTable& t, int32_t maxSymbol, int32_t tableLog, int32_t off)
+{
+    const int lane = c.lane;
+    const int32_t tableSize = 1 << tableLog, mask = tableSize - 1;
+    int16_t* const cumStart = sh.next;  // [s]: filled positions handed out before symbol s (then reused as the running counts of step C)
+    __syncthreads();                    // (sh.norm is complete)
+    // ---- A: lane = symbol: the top positions of the "less than one" symbols, running totals of the others ----
+    int32_t lowSeen = 0, placed = 0;
+    for (int32_t sBase = 0; sBase <= maxSymbol; sBase += 64) {  // (uniform)
+        const int32_t sym = sBase + lane;
+        const int32_t n = sym <= maxSymbol ? (int32_t)sh.norm[sym] : 0;
+        const bool isLow = n == -1;
+        const int32_t pos = n > 0 ? n : 0;
+        const unsigned long long lowMask = __ballot(isLow);
+        if (isLow) {
+            const int32_t at = tableSize - 1 - (lowSeen + (int32_t)__popcll(lowMask & ((1ull << lane) - 1)));
+            if (at >= 0) {
+                t.e[at] = (uint32_t)sym << 16;
+            }
+        }
+        lowSeen += (int32_t)__popcll(lowMask);
+        int32_t incl = pos;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t up = __shfl_up(incl, d);
+            if (lane >= d) {
+                incl += up;
+            }
+        }
+        if (sym <= maxSymbol) {
+            cumStart[sym] = (int16_t)(placed + incl - pos);
+        }
+        placed += __shfl(incl, 63);
+    }
+    const int32_t high = tableSize - 1 - lowSeen;
+    if (placed != high + 1 || lowSeen > tableSize) {  // (uniform) the walk would not fill every position once: the Java loop decides
+        return fse_build_serial(c, sh, t, maxSymbol, tableLog, off);
+    }
+    __syncthreads();
+    // ---- B: lane = position: the symbol of every position below the top ones ----
+    const uint32_t step = (uint32_t)((tableSize >> 1) + (tableSize >> 3) + 3);
+    uint32_t inv = step;  // step^-1 mod 2^32 (Newton: the correct bits double per round, starting from 3: x * x = 1 mod 8 for odd x)
+    inv *= 2u - step * inv;
+    inv *= 2u - step * inv;
+    inv *= 2u - step * inv;
+    inv *= 2u - step * inv;
+    for (int32_t u = lane; u <= high; u += 64) {
+        const int32_t j = (int32_t)(((uint32_t)u * inv) & (uint32_t)mask);
+        int32_t k = j;
+        for (int32_t v = high + 1; v < tableSize; v++) {  // (uniform bounds) stops on top positions before this one
+            k -= (int32_t)(((uint32_t)v * inv) & (uint32_t)mask) < j ? 1 : 0;
+        }
+        // the last symbol whose running total is <= k (symbols without positions share their successor's total: the last one wins)
+        int32_t lo = 0, hi = maxSymbol;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi + 1) >> 1;
+            if ((int32_t)cumStart[mid] <= k) {
+                lo = mid;
+            }
+            else {
+                hi = mid - 1;
+            }
+        }
+        t.e[u] = (uint32_t)lo << 16;
+    }
+    __syncthreads();
+    // ---- C: nextState in position order: rank among the lower positions with the same symbol ----
+    for (int32_t sBase = 0; sBase <= maxSymbol; sBase += 64) {
+        if (sBase + lane <= maxSymbol) {
+            cumStart[sBase + lane] = 0;  // (now: positions of the symbol seen so far)
+        }
+    }
+    __syncthreads();
+    for (int32_t uBase = 0; uBase < tableSize; uBase += 64) {  // (uniform)
+        const int32_t u = uBase + lane;
+        const bool valid = u < tableSize;
+        const uint32_t symbol = valid ? (t.e[u] >> 16) : (0x100u + (uint32_t)lane);  // (lanes without a position match nobody)
+        unsigned long long same = ~0ull;
+#pragma unroll
+        for (int bit = 0; bit < 9; bit++) {
+            const bool one = ((symbol >> bit) & 1u) != 0;
+            const unsigned long long m = __ballot(one);
+            same &= one ? m : ~m;
+        }
+        const int32_t before = (int32_t)__popcll(same & ((1ull << lane) - 1));
+        if (valid) {
+            const int32_t n = (int32_t)sh.norm[symbol];
+            const int32_t seen = (int32_t)cumStart[symbol];
+            const int32_t nextState = (n == -1 ? 1 : n) + seen + before;
+            const int32_t nb = tableLog - highest_bit((uint32_t)(nextState | 1));
+            const int32_t newState = (int16_t)((nextState << nb) - tableSize);
+            t.e[u] = ((uint32_t)newState & 0xFFFFu) | (symbol << 16) | ((uint32_t)nb << 24);
+        }
+        __syncthreads();  // (every lane has read the running counts)
+        if (valid && before == 0) {
+            cumStart[symbol] = (int16_t)((int32_t)cumStart[symbol] + (int32_t)__popcll(same));
+        }
+        __syncthreads();
+    }
     return 0;
 }
 
