@@ -521,17 +521,20 @@ static __device__ int32_t huf_read_table(Ctx& c, TableShared& sh, int32_t inputA
         if (outputSize < 0) return -1;
     }
 
-    // rank statistics (wave-uniform serial; <= 256 symbols)
+    // rank statistics, a lane per symbol (round 4; was a serial loop over the <= 256 weights): how many symbols have each weight, the total weight
     int32_t totalWeight = 0;
     int32_t ranks[HUF_MAX_TABLE_LOG + 1];
 #pragma unroll
     for (int i = 0; i <= HUF_MAX_TABLE_LOG; i++) ranks[i] = 0;
-    for (int32_t i = 0; i < outputSize; i++) {
-        const int32_t w = sh.hw[i];
-        ZVERIFY(c, w <= HUF_MAX_TABLE_LOG, ACHIP_D_ZSTD_CORRUPTED, input);  // Java: ArrayIndexOutOfBoundsException
+    for (int32_t sBase = 0; sBase < outputSize; sBase += 64) {  // (uniform)
+        const int32_t w = sBase + c.lane < outputSize ? (int32_t)sh.hw[sBase + c.lane] : -1;
+        ZVERIFY(c, __ballot(w > HUF_MAX_TABLE_LOG) == 0, ACHIP_D_ZSTD_CORRUPTED, input);  // Java: ArrayIndexOutOfBoundsException
 #pragma unroll
-        for (int k = 0; k <= HUF_MAX_TABLE_LOG; k++) ranks[k] += (w == k);
-        totalWeight += (1 << w) >> 1;
+        for (int k = 0; k <= HUF_MAX_TABLE_LOG; k++) {
+            const int32_t n = (int32_t)__popcll(__ballot(w == k));
+            ranks[k] += n;
+            totalWeight += n * ((1 << k) >> 1);
+        }
     }
     ZVERIFY(c, totalWeight != 0, ACHIP_D_ZSTD_CORRUPTED, input);
     const int32_t tableLog = highest_bit((uint32_t)totalWeight) + 1;
@@ -549,10 +552,9 @@ static __device__ int32_t huf_read_table(Ctx& c, TableShared& sh, int32_t inputA
     for (int k = 0; k <= HUF_MAX_TABLE_LOG; k++) ranks[k] += (lastWeight == k);
     const int32_t numberOfSymbols = outputSize + 1;
 
+    // where each weight's symbols start (:100-108); ranks[] turns from counts into starts, r1 = where the weight-1 symbols end
     int32_t nextRankStart = 0;
-    if (c.lane == 0) {
-        sh.ranks[0] = ranks[0];
-    }
+    const int32_t count1 = ranks[1];
 #pragma unroll
     for (int i = 1; i <= HUF_MAX_TABLE_LOG; i++) {
         if (i < tableLog + 1) {
@@ -560,26 +562,43 @@ static __device__ int32_t huf_read_table(Ctx& c, TableShared& sh, int32_t inputA
             nextRankStart += ranks[i] << (i - 1);
             ranks[i] = current;
         }
-        if (c.lane == 0) {
-            sh.ranks[i] = ranks[i];
-        }
     }
+    const int32_t r1 = ranks[1] + count1;
     __syncthreads();
-    // populate: symbol n occupies [start(n), start(n)+length) where start = rank start + (symbols of equal weight before n) * length
-    if (c.lane == 0) {
-        for (int32_t n = 0; n < numberOfSymbols; n++) {
-            const int32_t weight = sh.hw[n];
-            const int32_t length = (1 << weight) >> 1;
-            const uint16_t entry = (uint16_t)(n | ((tableLog + 1 - weight) << 8));
-            const int32_t begin = sh.ranks[weight];
-            for (int32_t i = begin; i < begin + length; i++) {
-                sh.huf[i] = entry;
+    // populate (:110-123): symbol n occupies [start(n), start(n) + length), start = its weight's start + (symbols of equal weight before n) * length.
+    // A lane per symbol finds the starts (ballots per weight + the counts of the chunks before); then the wavefront fills symbol after symbol,
+    // 64 entries per step (a weight-11 symbol is 1024 entries; lane 0 alone used to write all 2048 of the table).
+    int16_t* const symStart = sh.next;
+    int32_t seenOfWeight[HUF_MAX_TABLE_LOG + 1];
+#pragma unroll
+    for (int i = 0; i <= HUF_MAX_TABLE_LOG; i++) seenOfWeight[i] = 0;
+    for (int32_t sBase = 0; sBase < numberOfSymbols; sBase += 64) {  // (uniform)
+        const int32_t n = sBase + c.lane;
+        const int32_t w = n < numberOfSymbols ? (int32_t)sh.hw[n] : -1;
+        int32_t start = 0;
+#pragma unroll
+        for (int k = 1; k <= HUF_MAX_TABLE_LOG; k++) {
+            const unsigned long long m = __ballot(w == k);
+            if (w == k) {
+                start = ranks[k] + ((seenOfWeight[k] + (int32_t)__popcll(m & ((1ull << c.lane) - 1))) << (k - 1));
             }
-            sh.ranks[weight] = begin + length;
+            seenOfWeight[k] += (int32_t)__popcll(m);
+        }
+        if (n < numberOfSymbols) {
+            symStart[n] = (int16_t)start;
         }
     }
     __syncthreads();
-    const int32_t r1 = sh.ranks[1];
+    for (int32_t n = 0; n < numberOfSymbols; n++) {  // (uniform)
+        const int32_t weight = sh.hw[n];
+        const int32_t length = (1 << weight) >> 1;
+        const uint16_t entry = (uint16_t)(n | ((tableLog + 1 - weight) << 8));
+        const int32_t begin = symStart[n];
+        for (int32_t i = c.lane; i < length; i += 64) {
+            sh.huf[begin + i] = entry;
+        }
+    }
+    __syncthreads();
     ZVERIFY(c, r1 >= 2 && (r1 & 1) == 0, ACHIP_D_ZSTD_CORRUPTED, input);
     *tableLogOut = tableLog;
     return inputSize + 1;
