@@ -610,7 +610,38 @@ __device__ __forceinline__ bool huf_decode_stream_win(QuadBits& b, const uint16_
 {
     const int32_t fastLimit = outputLimit - 4;
     bool done = false;
-    while (output < fastLimit) {
+    // four trips of the Java loop per 16-byte store (round 4): the stage's lanes each walk their own stream, so every load and store of a
+    // wavefront is 64 separate lines for the memory pipeline -- a quarter of the store instructions is a quarter of that work
+    while (!done && output + 12 < fastLimit) {
+        uint32_t w4[4];
+        int n4 = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (!done) {
+                if (b.load_java()) {
+                    done = true;
+                }
+                else {
+                    uint32_t w = (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed);
+                    w |= (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed) << 8;
+                    w |= (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed) << 16;
+                    w |= (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed) << 24;
+                    w4[t] = w;
+                    n4 = t + 1;
+                }
+            }
+        }
+        if (n4 == 4) {
+            st16(out + output, u32x4{w4[0], w4[1], w4[2], w4[3]});
+        }
+        else {
+            for (int t = 0; t < n4; t++) {
+                st4(out + output + 4 * t, w4[t]);
+            }
+        }
+        output += 4 * n4;
+    }
+    while (!done && output < fastLimit) {
         if (b.load_java()) {
             done = true;
             break;
