@@ -131,8 +131,35 @@ __device__ __forceinline__ void snappy_buffer_decode(uint8_t* ldsIn, uint8_t* ld
                     const int32_t matchOffset = (int32_t)((uint32_t)(entry & 0x700) + (uint32_t)trailer);
                     if (matchOffset <= 0) SN_FAIL(ip);
                     if (matchOffset > op || (int64_t)op + length > outLimit) SN_FAIL(ip);
-                    R.copy_match(op, matchOffset, length);
-                    op += length;
+                    // A match longer than 64 bytes reaches the decoder as several copy elements with one offset (the writers cut at 64 / 60:
+                    // SnappyRawCompressor.java:312-345 -- and a copy element cannot say more).  Elements that continue such a match are taken
+                    // in the same trip: the same bytes in the same order, one pass through the copy machinery instead of one per element.
+                    // Only behind a full-size piece, only a copy with the same offset whose own checks (:84-110, :147-163) all pass here --
+                    // anything else is left to the next trip, which takes it exactly as before.
+                    int32_t total = length;
+                    if (length >= 60) {
+                        while (total < 4096 && ip + 5 < inLimit) {
+                            R.ensure_input(ip, 5);
+                            const int32_t opc2 = (int32_t)R.in_u8(ip);
+                            if ((opc2 & 3) == 0) {
+                                break;
+                            }
+                            const int32_t entry2 = snappy_op_entry2(opc2);
+                            const int32_t tb2 = entry2 >> 11;
+                            const int32_t trailer2 = (int32_t)(R.template ring_ld4<IN_RING>(R.inRing, ip + 1 + R.inBase) & (0xFFFFFFFFu >> (32 - 8 * tb2)));
+                            const int32_t length2 = entry2 & 0xff;
+                            if (trailer2 < 0 || length2 == 0 || (int32_t)((uint32_t)(entry2 & 0x700) + (uint32_t)trailer2) != matchOffset || (int64_t)op + total + length2 > outLimit) {
+                                break;
+                            }
+                            total += length2;
+                            ip += 1 + tb2;
+                            if (length2 < 60) {
+                                break;
+                            }
+                        }
+                    }
+                    R.copy_match(op, matchOffset, total);
+                    op += total;
                 }
             }
         }

@@ -55,7 +55,7 @@ def parse_args():
     p.add_argument("--cpu-leg-seconds", type=float, default=0.6, help="CPU time of each extra entry's CPU leg (per direction)")
     p.add_argument("--no-sweep", action="store_true")
     p.add_argument("--exec-variant", type=int, default=-1, help="DEBUG: decompress.exec_variant (two-pass decoders)")
-    p.add_argument("--section", default="all", choices=["all", "zstd", "zstdstream", "xxhash", "lz4frame"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
+    p.add_argument("--section", default="all", choices=["all", "zstd", "zstdstream", "xxhash", "lz4frame", "sweep"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-exec", type=int, default=-1, help="zstd pipeline execute stage: 2 = chosen per item (default), 1 = wavefront per item through the record executor, 0 = LDS rings")
     p.add_argument("--snappyframed-variant", type=int, default=-1, help="x-snappy-framed reader: 3 = ring or two-pass decoder by a probe (default), 1 = chunks through the ring decoders, 2 = through the two-pass decoder, 0 = a wavefront per stream")
     p.add_argument("--lz4frame-variant", type=int, default=-1, help="LZ4 frame reader: 2 = by a probe (default), 0 = a wavefront per item, 1 = the frames' blocks as one batch through the two-pass block decoder")
@@ -311,6 +311,9 @@ def main():
         codec.native.set_option("lz4frame.decompress.variant", args.lz4frame_variant)
     if args.section == "lz4frame":
         print(json.dumps(lz4frame_extra(torch, A, codec, torch.device("cuda", local_rank), args)), flush=True)
+        return
+    if args.section == "sweep":
+        print(json.dumps(sweep_random301(torch, A, codec, torch.device("cuda", local_rank), args)), flush=True)
         return
     if args.section == "xxhash":
         print(json.dumps(xxhash_extra(torch, A, codec, torch.device("cuda", local_rank), args)), flush=True)

@@ -83,6 +83,14 @@ PY
       cp gpurun_out/prof_r04finalz/keep/dispatches.txt $F/zstd_dispatches.txt; cp gpurun_out/prof_r04finalz/keep/*kernel_stats.csv $F/zstd_kernel_stats.csv
       ACHIP_BENCH_SHARE_DEVICE=1 timeout 600 python bench.py --gpus 2 --blocks 65536 --steps 3 --warmup 1 --no-extra --no-cpu-baseline > $F/n2.json 2> $F/n2.err; grep -c '^{' $F/n2.json
       ;;
+    sweep)         # the Random(301) sweep + the Snappy / LZ4 headline (ring decoders)
+      timeout 600 python bench.py --section sweep 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        for k, v in json.loads(l).items(): print(k, v['decompress_GiBps'], v.get('decompress_hbm_frac'))
+" | tee $O/sweep.txt
+      for wl in lz4_decompress snappy_decompress; do for i in 1 2 3; do timeout 300 python bench.py --no-cpu-baseline --no-extra --steps 6 --warmup 2 --workload $wl 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$wl', r['value'], r['roofline']['frac'])"; done; done | tee -a $O/sweep.txt ;;
     tests)
       timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
     *) echo "unknown step $step" ;;
