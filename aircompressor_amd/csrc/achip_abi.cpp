@@ -28,9 +28,9 @@ constexpr int64_t LZ4_RECORD_BYTES_PER_BLOCK = 98304, LZ4_RECORD_BYTES_PER_BLOCK
 constexpr int64_t SNAPPY_RECORD_BYTES_PER_BLOCK = 131072, SNAPPY_RECORD_BYTES_PER_BLOCK_MIN = 49152;
 hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
-hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
+hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
-hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
+hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
 hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant, void* scratch);
 int64_t snappy_compress_scratch_bytes();
@@ -348,7 +348,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 ctx->lastZstddBlocks = 0;
                 e = achip::launch_lz4_mixed_groups(a, ctx->stream, stats, 0);
                 if (e == hipSuccess) e = hipMemsetAsync(stats + 3, 1, 1, ctx->stream);  // stats[3] = 1: the two-pass scheme (achip_device.h lz4_pick)
-                if (e == hipSuccess) e = achip::launch_lz4_sequence_sample(a, ctx->stream, stats, 0);
+                if (e == hipSuccess) e = achip::launch_lz4_sequence_sample(a, ctx->stream, stats, 0, 12);
                 if (e == hipSuccess) e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, stats);
                 ctx->lastTwopass = true;
                 if (e == hipSuccess) e = achip::launch_lz4_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, ctx->lz4dGroup, ctx->ringClass, ctx->execVariant, stats);
@@ -385,7 +385,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 ctx->lastZstddBlocks = 0;
                 e = achip::launch_lz4_mixed_groups(a, ctx->stream, stats, 0);
                 if (e == hipSuccess) e = hipMemsetAsync(stats + 3, 1, 1, ctx->stream);
-                if (e == hipSuccess) e = achip::launch_snappy_element_sample(a, ctx->stream, stats, 0);
+                if (e == hipSuccess) e = achip::launch_snappy_element_sample(a, ctx->stream, stats, 0, 6);
                 if (e == hipSuccess) e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, stats);
                 ctx->lastTwopass = true;
                 if (e == hipSuccess) e = achip::launch_snappy_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, ctx->snappydGroup, ctx->ringClass, ctx->execVariant, stats);
@@ -966,10 +966,11 @@ int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name)
     if (k == "decompress.choice") {  // which decoder auto mode ran last: 0 rings, 3 two passes; -1: no probe ran
         if (!ctx->lastLz4dAuto || ctx->scratch == nullptr) return -1;
         if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
-        int32_t v[3] = {0, 0, 0};
+        int32_t v[6] = {0, 0, 0, 0, 0, 0};
         if (hipMemcpy(v, ctx->scratch, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        const bool mixed = (int64_t)v[0] * 4 > (ctx->lastAutoBlocks + 15) / 16;
-        const bool isShort = v[1] > 0 && (int64_t)v[2] < (ctx->lastAutoIsLz4 ? 12 : 6) * (int64_t)v[1];
+        const bool mixed = (int64_t)v[0] * 4 > (ctx->lastAutoBlocks + 15) / 16;  // the rule of lz4_pick (achip_device.h)
+        const bool pooledShort = v[1] > 0 && (int64_t)v[2] < (ctx->lastAutoIsLz4 ? 12 : 6) * (int64_t)v[1];
+        const bool isShort = v[5] > 0 ? (int64_t)v[4] * 3 > (int64_t)v[5] : pooledShort;
         return (mixed || isShort) ? 3 : 0;
     }
     if (k == "decompress.scratch_bytes") {  // the context's decode scratch as granted (the two-pass decoders' record arena is what lies behind its fixed part): a smaller grant than a batch asked for shows here and in decompress.twopass_fallback_blocks

@@ -50,14 +50,19 @@ __device__ __forceinline__ constexpr int32_t mk_status(int cls, int detail) { re
 __device__ __forceinline__ bool lz4_batch_is_mixed(int32_t mixedGroups, int32_t nBlocks) { return (int64_t)mixedGroups * 4 > (nBlocks + 15) / 16; }
 
 // The decoders' choice.  stats: [0] mixed groups, [1] sequences parsed from the heads of 1024 sampled blocks, [2] the bytes they produce,
-// in units of 4, [3] != 0: the caller has record scratch -- the two-pass decoder (parse to records + a wavefront per block) is
+// in units of 4, [4] / [5] sampled blocks of short sequences / sampled blocks (0: not counted), [3] != 0: the caller has record scratch -- the two-pass decoder (parse to records + a wavefront per block) is
 // a candidate.  Mixed batches (long copies next to short ones) and short-sequence batches (text: 9 .. 40 bytes per sequence at a block's
 // head; the long-copy sets: >= 100) go to it, everything else -- and every batch of a caller without record scratch -- to the rings.
 // (Until round 4 there were two more candidates, lane-per-block decoders; the two-pass decoder beat both from 16384 blocks up.)
 constexpr int LZ4_PICK_RINGS = 0, LZ4_PICK_TWOPASS = 3;
 __device__ __forceinline__ int lz4_pick(const int32_t* stats, int32_t nBlocks, int32_t shortLimit = 12)
 {
-    const bool isShort = stats[1] > 0 && (int64_t)stats[2] < (int64_t)shortLimit * (int64_t)stats[1];
+    // Short-sequence data, decided block by block where the probe says so (round 4): [4] of the [5] sampled blocks have short sequences.  The pooled
+    // mean of rounds 2-3 -- all sampled bytes / all sampled sequences -- let a handful of long-run blocks (thousands of bytes per sequence) outvote a
+    // batch of text: a batch of text and long copies side by side went to the rings at 227 GiB/s where the two passes make 503.  A third of the
+    // blocks short is where the two passes win (text: 515 against ~200 for the rings; long copies: ~450 against 1 900).
+    const bool pooledShort = stats[1] > 0 && (int64_t)stats[2] < (int64_t)shortLimit * (int64_t)stats[1];
+    const bool isShort = stats[5] > 0 ? (int64_t)stats[4] * 3 > (int64_t)stats[5] : pooledShort;
     return (stats[3] != 0 && (lz4_batch_is_mixed(stats[0], nBlocks) || isShort)) ? LZ4_PICK_TWOPASS : LZ4_PICK_RINGS;
 }
 // Snappy: the sample counts elements (a literal run or a copy -- half an LZ4 sequence)

@@ -62,7 +62,7 @@ __device__ __forceinline__ int32_t sample_stage_head(uint8_t* h, const uint8_t* 
     return limit;
 }
 
-__global__ __launch_bounds__(64) void lz4_sequence_sample_kernel(BatchArgs a, int32_t* stats, int32_t minBlocks)
+__global__ __launch_bounds__(64) void lz4_sequence_sample_kernel(BatchArgs a, int32_t* stats, int32_t minBlocks, int32_t shortLimit)
 {
     const int32_t n = batch_count(a);
     if (n < minBlocks || n <= 0) {
@@ -106,17 +106,25 @@ __global__ __launch_bounds__(64) void lz4_sequence_sample_kernel(BatchArgs a, in
     bytes = bytes < 0 || bytes > (1 << 24) ? (1 << 24) : bytes;
     atomicAdd(stats + 1, seqs);
     atomicAdd(stats + 2, (int32_t)(bytes >> 2));  // (in units of 4 bytes: 1024 samples x 16 MiB stay inside 32 bits)
+    if (shortLimit > 0) {  // the verdict block by block (lz4_pick, achip_device.h): [4] sampled blocks of short sequences, [5] sampled blocks
+        const unsigned long long isShort = __ballot(seqs > 0 && (bytes >> 2) < (int64_t)shortLimit * seqs);
+        if (threadIdx.x == 0) {
+            atomicAdd(stats + 4, (int32_t)__popcll(isShort));
+            atomicAdd(stats + 5, 64);
+        }
+    }
 }
 
-hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks)
+// shortLimit > 0 (the batched block API): also count the sampled BLOCKS whose own sequences are short (bytes / 4 per sequence below the limit)
+hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit)
 {
-    hipLaunchKernelGGL(lz4_sequence_sample_kernel, dim3(16), dim3(64), 0, stream, a, stats, minBlocks);
+    hipLaunchKernelGGL(lz4_sequence_sample_kernel, dim3(16), dim3(64), 0, stream, a, stats, minBlocks, shortLimit);
     return hipGetLastError();
 }
 
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks)
 {
-    const hipError_t e = hipMemsetAsync(mixedGroups, 0, 4 * sizeof(int32_t), stream);
+    const hipError_t e = hipMemsetAsync(mixedGroups, 0, 8 * sizeof(int32_t), stream);
     if (e != hipSuccess) return e;
     const unsigned grid = (unsigned)(((a.nBlocks + 15) / 16 + 255) / 256);
     hipLaunchKernelGGL(lz4_mixed_groups_kernel, dim3(grid), dim3(256), 0, stream, a, mixedGroups, minBlocks);
@@ -138,7 +146,7 @@ __device__ __forceinline__ int32_t snappy_op_entry_probe(int32_t op)  // opLooku
 
 // auto mode: how long are the elements?  1024 sampled blocks, the elements in the first 768 bytes of each (at most 192; a lane per sample;
 // tags only), parsed from an LDS copy of the block's head (the reason: lz4_sequence_sample_kernel above)
-__global__ __launch_bounds__(64) void snappy_element_sample_kernel(BatchArgs a, int32_t* stats, int32_t minBlocks)
+__global__ __launch_bounds__(64) void snappy_element_sample_kernel(BatchArgs a, int32_t* stats, int32_t minBlocks, int32_t shortLimit)
 {
     const int32_t n = batch_count(a);
     if (n < minBlocks || n <= 0) {
@@ -193,11 +201,18 @@ __global__ __launch_bounds__(64) void snappy_element_sample_kernel(BatchArgs a, 
     bytes = bytes < 0 || bytes > (1 << 24) ? (1 << 24) : bytes;
     atomicAdd(stats + 1, elements);
     atomicAdd(stats + 2, (int32_t)(bytes >> 2));
+    if (shortLimit > 0) {
+        const unsigned long long isShort = __ballot(elements > 0 && (bytes >> 2) < (int64_t)shortLimit * elements);
+        if (threadIdx.x == 0) {
+            atomicAdd(stats + 4, (int32_t)__popcll(isShort));
+            atomicAdd(stats + 5, 64);
+        }
+    }
 }
 
-hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks)
+hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit)
 {
-    hipLaunchKernelGGL(snappy_element_sample_kernel, dim3(16), dim3(64), 0, stream, a, stats, minBlocks);
+    hipLaunchKernelGGL(snappy_element_sample_kernel, dim3(16), dim3(64), 0, stream, a, stats, minBlocks, shortLimit);
     return hipGetLastError();
 }
 

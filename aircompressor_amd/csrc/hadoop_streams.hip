@@ -657,9 +657,9 @@ __global__ __launch_bounds__(64) void hadoop_compact_kernel(BatchArgs a, BlockLi
 }  // namespace hdp
 
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
-hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
+hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
-hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
+hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
 hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
 hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
@@ -753,7 +753,7 @@ hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void
         int32_t head[20] = {0};
         if (variant == 3) {
             e = hipMemsetAsync(stats, 0, 4 * sizeof(int32_t), stream);
-            if (e == hipSuccess) e = snappy ? launch_snappy_element_sample(c, stream, stats, 0) : launch_lz4_sequence_sample(c, stream, stats, 0);
+            if (e == hipSuccess) e = snappy ? launch_snappy_element_sample(c, stream, stats, 0, 0) : launch_lz4_sequence_sample(c, stream, stats, 0, 0);
             if (e != hipSuccess) return e;
         }
         e = hipMemcpyAsync(head, counters, sizeof(head), hipMemcpyDeviceToHost, stream);

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64) void lz4frame_decompress_kernel(BatchArgs a, in
     }
 }
 
-hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
+hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit);
 hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
 int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock);
 
@@ -484,7 +484,7 @@ hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, vo
         c.srcLen = L.cSrcLen;
         c.nBlocks = (int32_t)C;
         c.nBlocksDev = L.counters + 1;
-        e = launch_lz4_sequence_sample(c, stream, stats, 0);
+        e = launch_lz4_sequence_sample(c, stream, stats, 0, 0);
         if (e != hipSuccess) return e;
     }
     // the number of listed blocks and their room decide the record arena: the one synchronisation of the call

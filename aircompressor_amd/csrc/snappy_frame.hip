@@ -748,7 +748,7 @@ __global__ __launch_bounds__(64) void snappyframed_fold_kernel(BatchArgs a, Chun
 }  // namespace snf
 
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
-hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks);
+hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
 
 int64_t snappyframed_decompress_scratch_bytes(int32_t nStreams)
@@ -834,7 +834,7 @@ hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream
         int32_t head[20] = {0};
         if (variant == 3) {
             e = hipMemsetAsync(mixedGroups, 0, 4 * sizeof(int32_t), stream);
-            if (e == hipSuccess) e = launch_snappy_element_sample(c, stream, mixedGroups, 0);
+            if (e == hipSuccess) e = launch_snappy_element_sample(c, stream, mixedGroups, 0, 0);
             if (e != hipSuccess) return e;
         }
         e = hipMemcpyAsync(head, counters, sizeof(head), hipMemcpyDeviceToHost, stream);

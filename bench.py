@@ -42,7 +42,7 @@ def parse_args():
     p.add_argument("--pool", type=int, default=4096, help="distinct blocks generated; the batch tiles them at distinct addresses")
     p.add_argument("--ratio", type=float, default=0.5, help="RandomGenerator compressibility (0.5 => LZ4 ratio ~1.9)")
     p.add_argument("--workload", default="lz4_decompress", choices=["lz4_decompress", "snappy_decompress", "lz4_compress", "snappy_compress"])
-    p.add_argument("--data", default="fragments", choices=["fragments", "wordmix", "corpus"])
+    p.add_argument("--data", default="fragments", choices=["fragments", "wordmix", "corpus", "mixed"])
     p.add_argument("--group", type=int, default=0, help="decoder lanes per block (0 = library default)")
     p.add_argument("--variant", type=int, default=-1, help="decoder variant: 5 = chosen on the device (default), 1 = LDS rings, 7 = two passes")
     p.add_argument("--ring-class", type=int, default=-1, help="0 = compact LDS rings, 1 = large")
@@ -139,6 +139,13 @@ def gen_data(torch, dev, kind, n_blocks, block_size, ratio, seed):
         return gen_fragments(torch, dev, n_blocks, block_size, ratio, seed)
     if kind == "wordmix":
         return gen_wordmix(torch, dev, n_blocks, block_size, seed)
+    if kind == "mixed":
+        # a batch of two kinds side by side: even blocks corpus-tiled (short sequences), odd blocks fragments (long copies) -- what the
+        # decoders' batch-level choice has to get right (auto mode)
+        half = (n_blocks + 1) // 2
+        a = gen_corpus(torch, dev, half, block_size).view(half, block_size)
+        b = gen_fragments(torch, dev, half, block_size, ratio, seed).view(half, block_size)
+        return torch.stack([a, b], dim=1).reshape(-1)[:n_blocks * block_size].contiguous()
     return gen_corpus(torch, dev, n_blocks, block_size)
 
 
@@ -431,6 +438,8 @@ def main():
     twopass_fallback = codec.native.get_stat("decompress.twopass_fallback_blocks") if wl.endswith("decompress") else -1
     mixed_groups = codec.native.get_stat("lz4.decompress.mixed_groups") if wl.endswith("decompress") else -1
     choice = codec.native.get_stat("decompress.choice") if wl.endswith("decompress") else -1
+    if choice < 0 and wl.endswith("decompress"):  # a forced decoder (no probe ran): 7 = the two passes, 1 = the rings
+        choice = 3 if args.variant == 7 else 0
     decoder = "n/a" if not wl.endswith("decompress") else DECODER_NAMES.get(choice, "rings")
     ms_per_step = elapsed / args.steps * 1e3
     total_plain = plain_bytes_local * world  # weak scaling: every rank owns n_local blocks
@@ -606,8 +615,8 @@ def extras(torch, A, codec, dev, args):
     CPU rate of the same blocks beside it."""
     out = {}
     bs = args.block_size
-    for data_kind in ("fragments", "wordmix", "corpus"):
-        n = 65536 if data_kind == "fragments" else args.blocks  # text-like and corpus-tiled (the primary data of BASELINE configs[1]) at its size
+    for data_kind in ("fragments", "wordmix", "corpus", "mixed"):
+        n = 65536 if data_kind in ("fragments", "mixed") else args.blocks  # text-like and corpus-tiled (the primary data of BASELINE configs[1]) at its size
         plain = gen_data(torch, dev, data_kind, n, bs, args.ratio, 977)
         for name, cop, dop in (("lz4", A.OP_LZ4_COMPRESS, A.OP_LZ4_DECOMPRESS), ("snappy", A.OP_SNAPPY_COMPRESS, A.OP_SNAPPY_DECOMPRESS)):
             out["%s_%s" % (name, data_kind)] = run_pair(torch, codec, args, name, cop, dop, plain, n, bs, args.cpu_leg_seconds)

@@ -17,8 +17,8 @@ extern "C" { long long achip_emu_counters[16]; }  // development counters of ker
 // the probes of the decoders' auto mode are not built here: the probe statistics stay
 // zero, which picks the ring decoders
 namespace achip {
-hipError_t launch_snappy_element_sample(const BatchArgs&, hipStream_t, int32_t*, int32_t) { return hipSuccess; }
-hipError_t launch_lz4_sequence_sample(const BatchArgs&, hipStream_t, int32_t*, int32_t) { return hipSuccess; }
+hipError_t launch_snappy_element_sample(const BatchArgs&, hipStream_t, int32_t*, int32_t, int32_t) { return hipSuccess; }
+hipError_t launch_lz4_sequence_sample(const BatchArgs&, hipStream_t, int32_t*, int32_t, int32_t) { return hipSuccess; }
 hipError_t launch_lz4_mixed_groups(const BatchArgs&, hipStream_t, int32_t*, int32_t) { return hipSuccess; }
 }  // namespace achip
 extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, const int32_t* srcLen, uint8_t* dstBase, const int64_t* dstOff,

@@ -19,9 +19,9 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs&, hipStream_t, void*, i
 hipError_t launch_snappy_decompress_twopass(const BatchArgs&, hipStream_t, void*, int64_t, int, int, int, const int32_t*) { return hipSuccess; }
 int64_t twopass_scratch_bytes(int32_t, int64_t) { return 0; }
 hipError_t launch_lz4_decompress_rings(const BatchArgs&, hipStream_t, int, int, const int32_t*) { return hipSuccess; }
-hipError_t launch_lz4_sequence_sample(const BatchArgs&, hipStream_t, int32_t*, int32_t) { return hipSuccess; }
+hipError_t launch_lz4_sequence_sample(const BatchArgs&, hipStream_t, int32_t*, int32_t, int32_t) { return hipSuccess; }
 hipError_t launch_snappy_decompress_rings(const BatchArgs&, hipStream_t, int, int, const int32_t*) { return hipSuccess; }
-hipError_t launch_snappy_element_sample(const BatchArgs&, hipStream_t, int32_t*, int32_t) { return hipSuccess; }
+hipError_t launch_snappy_element_sample(const BatchArgs&, hipStream_t, int32_t*, int32_t, int32_t) { return hipSuccess; }
 hipError_t launch_lz4_mixed_groups(const BatchArgs&, hipStream_t, int32_t*, int32_t) { return hipSuccess; }
 int64_t zstd_decompress_pipe_scratch_bytes(int32_t, int32_t) { return 0; }
 hipError_t launch_zstd_decompress_pipe(const BatchArgs&, hipStream_t, void*, void*, int32_t, const ZstdMbProvider*) { return hipSuccess; }

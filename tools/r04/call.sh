@@ -91,6 +91,14 @@ for l in sys.stdin:
         for k, v in json.loads(l).items(): print(k, v['decompress_GiBps'], v.get('decompress_hbm_frac'))
 " | tee $O/sweep.txt
       for wl in lz4_decompress snappy_decompress; do for i in 1 2 3; do timeout 300 python bench.py --no-cpu-baseline --no-extra --steps 6 --warmup 2 --workload $wl 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$wl', r['value'], r['roofline']['frac'])"; done; done | tee -a $O/sweep.txt ;;
+    mixed)         # the mixed batch (corpus + fragments side by side): auto mode beside the forced decoders
+      for wl in lz4_decompress snappy_decompress; do for v in "" "--variant 7" "--variant 1"; do
+        timeout 300 python bench.py --no-cpu-baseline --no-extra --steps 5 --warmup 2 --workload $wl --data mixed $v 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$wl mixed [$v]', r['value'], r['config']['decoder'][:60])"
+      done; done | tee $O/mixed.txt ;;
+    choice)        # what auto mode picks, and what it makes, per kind of batch
+      for wl in lz4_decompress snappy_decompress; do for d in "" "--data corpus" "--data fragments" "--data mixed" "--ratio 0.25" "--ratio 0.1"; do
+        timeout 300 python bench.py --no-cpu-baseline --no-extra --steps 5 --warmup 2 --workload $wl $d 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$wl [$d]', r['value'], r['config']['decoder'][:70])"
+      done; done | tee $O/choice.txt ;;
     tests)
       timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
     *) echo "unknown step $step" ;;
