@@ -142,9 +142,9 @@ def test_snappy_two_pass_decoder(gb, o, variant):
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
 def test_auto_mode_picks_a_decoder_on_the_device(gb, o, codec):
     """variant 5 (the default): batches of at least auto_min_blocks blocks are probed on the device -- groups of 16 consecutive blocks
-    whose compressed sizes differ by more than 2x count as mixed, and the heads of sampled blocks give the bytes per sequence -- and a
-    mostly mixed or short-sequence batch goes to the two-pass decoder (3), a batch of long copies to the rings (0); all give the
-    oracle's plaintext"""
+    whose compressed sizes differ by more than 2x count as mixed, and the heads of sampled blocks say, block by block, whether its
+    sequences are short -- and a mostly mixed batch or one with a third of its blocks short goes to the two-pass decoder (3), a batch of
+    long copies to the rings (0); all give the oracle's plaintext"""
     text = [d for _, d, _ in common.corpus_sample()][:2]
     flat = [bytes(65536), bytes(range(256)) * 256]
     rng = np.random.default_rng(3)
@@ -152,10 +152,13 @@ def test_auto_mode_picks_a_decoder_on_the_device(gb, o, codec):
     uniform = (text * 40)[:64]
     mixed = [text[i % 2] if i % 2 == 0 else flat[(i // 2) % 2] for i in range(64)]
     longcopies = (frag * 16)[:64]
+    # text and runs in separate halves: no mixed groups, and the runs' bytes swamp the pooled bytes per sequence -- but half the blocks are short
+    halves = (text * 16)[:32] + (flat * 16)[:32]
+    sprinkled = (text * 4)[:8] + (frag * 16)[:56]  # an eighth of the blocks short: stays with the rings
     gb.set_option("%s.decompress.variant" % codec, 5)
     gb.set_option("lz4.decompress.auto_min_blocks", 32)  # (one threshold for both codecs)
     try:
-        for blocks, expect_mixed, expect_choice in ((uniform, False, 3), (mixed, True, 3), (longcopies, False, 0), (mixed[:16], None, -1)):
+        for blocks, expect_mixed, expect_choice in ((uniform, False, 3), (mixed, True, 3), (longcopies, False, 0), (halves, False, 3), (sprinkled, False, 0), (mixed[:16], None, -1)):
             comp = [o.compress(codec, b) for b in blocks]
             outs, status, _ = gb.run(CODECS[codec]["d"], comp, [len(b) for b in blocks], unaligned=True)
             assert all(s == 0 for s in status) and outs == blocks
