@@ -952,8 +952,9 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
             // (a sentinel's low bits count the "- 1" steps: at most one per sequence, fewer than 2^16)
             int32_t temp = raw == 3 ? ((MB && p0 >= sx2::REP_SENTINEL) ? p0 + 1 : p0 - 1) : (raw == 1 ? p1 : p2);
             temp = temp == 0 ? 1 : temp;
-            const bool shift2 = rep ? (raw != 0 && raw != 1) : true;   // p2 = p1
-            const bool shift1 = rep ? raw != 0 : true;                 // p1 = p0, p0 = new
+            // (!over: the Java loop leaves at an overflow before it decodes anything -- the history a block leaves behind is that of its last decoded sequence)
+            const bool shift2 = !over && (rep ? (raw != 0 && raw != 1) : true);  // p2 = p1
+            const bool shift1 = !over && (rep ? raw != 0 : true);                // p1 = p0, p0 = new
             const int32_t offset = rep ? (raw != 0 ? temp : p0) : raw;
             p2 = shift2 ? p1 : p2;
             p1 = shift1 ? p0 : p1;
