@@ -153,7 +153,7 @@ def test_auto_mode_picks_a_decoder_on_the_device(gb, o, codec):
     mixed = [text[i % 2] if i % 2 == 0 else flat[(i // 2) % 2] for i in range(64)]
     longcopies = (frag * 16)[:64]
     # text and runs in separate halves: no mixed groups, and the runs' bytes swamp the pooled bytes per sequence -- but half the blocks are short
-    halves = (text * 16)[:32] + (flat * 16)[:32]
+    halves = [text[1]] * 32 + (flat * 16)[:32]  # (text[1]: 18 bytes per sequence at its head; text[0] sits at the threshold)
     sprinkled = (text * 4)[:8] + (frag * 16)[:56]  # an eighth of the blocks short: stays with the rings
     gb.set_option("%s.decompress.variant" % codec, 5)
     gb.set_option("lz4.decompress.auto_min_blocks", 32)  # (one threshold for both codecs)
