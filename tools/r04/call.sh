@@ -99,6 +99,13 @@ for l in sys.stdin:
       for wl in lz4_decompress snappy_decompress; do for d in "" "--data corpus" "--data fragments" "--data mixed" "--ratio 0.25" "--ratio 0.1"; do
         timeout 300 python bench.py --no-cpu-baseline --no-extra --steps 5 --warmup 2 --workload $wl $d 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$wl [$d]', r['value'], r['config']['decoder'][:70])"
       done; done | tee $O/choice.txt ;;
+    fuzz)          # differential fuzz of the decoders (status, offset, plaintext) and the encoders (bytes) against the oracle, on the GPU
+      ( timeout 700 python tools/fuzz_decoders.py 20000 41 lz4,snappy
+        timeout 500 python tools/fuzz_decoders.py 3000 42 lz4,snappy big
+        timeout 900 python tools/fuzz_decoders.py 6000 43 zstd
+        timeout 600 python tools/fuzz_decoders.py 3000 44 zstd big
+        timeout 600 python tools/fuzz_decoders.py 6000 45 lz4frame,snappyframed ) 2>&1 | grep -v "^\[" | tee $O/fuzz_decoders.txt
+      timeout 900 python tools/fuzz_encoders.py 2>&1 | tail -12 | tee $O/fuzz_encoders.txt ;;
     tests)
       timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
     *) echo "unknown step $step" ;;
