@@ -106,6 +106,16 @@ for l in sys.stdin:
         timeout 600 python tools/fuzz_decoders.py 3000 44 zstd big
         timeout 600 python tools/fuzz_decoders.py 6000 45 lz4frame,snappyframed ) 2>&1 | grep -v "^\[" | tee $O/fuzz_decoders.txt
       timeout 900 python tools/fuzz_encoders.py 2>&1 | tail -12 | tee $O/fuzz_encoders.txt ;;
+    kzs)           # per-kernel totals of the Zstd multi-block stream section
+      export TMPDIR=/tmp; rm -rf gpurun_out/ks_zs; mkdir -p gpurun_out/ks_zs
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_zs -o s -- python bench.py --section zstdstream --no-cpu-baseline > gpurun_out/ks_zs/log.txt 2>&1
+      python - $(find gpurun_out/ks_zs -name '*kernel_stats.csv' | head -1) <<'PY' | tee $O/kstats_zstdstream.txt
+import csv, sys
+for row in csv.DictReader(open(sys.argv[1])):
+    if "achip" in row["Name"] and float(row["TotalDurationNs"]) > 2e5:
+        print("%-80s calls=%s avg_ms=%.3f total_ms=%.1f" % (row["Name"][:80], row["Calls"], float(row["AverageNs"]) / 1e6, float(row["TotalDurationNs"]) / 1e6))
+PY
+      grep '^{' gpurun_out/ks_zs/log.txt | cut -c1-900; rm -rf gpurun_out/ks_zs ;;
     tests)
       timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
     *) echo "unknown step $step" ;;
