@@ -4,6 +4,7 @@
 // description and the reference citations.
 #pragma once
 #include "achip_device.h"
+#include "achip_seqexec.h"  // sx::wave_scan_incl, sx::wave_bcast
 
 namespace achip {
 
@@ -1251,24 +1252,94 @@ __device__ int32_t compress_sequences(Ctx& c, Shared& sh, uint8_t* base, int32_t
     }
     base[headerAddress] = (uint8_t)((llType << 6) | (ofType << 4) | (mlType << 2));
 
-    // encodeSequences :228-297 (three interleaved FSE states over one backward bit stream: serial, wave-uniform)
-    BitOut bs;
+    // encodeSequences :228-297.  The stream is a concatenation of bit fields, least significant first: per sequence, from the last to the first,
+    // the state bits of offset, match length and literal length (fse_encode :126-131), then the extra bits of literal length, match length and
+    // offset; behind them the three final states and the end mark.  Only the three STATE CHAINS are serial, and they are independent of each
+    // other: lanes 0 / 1 / 2 walk the offset / match-length / literal-length chain side by side (one instruction stream, a table lookup per
+    // step and chain) and leave every step's {bits, count} in LDS; then all 64 lanes put their sequences' fields together, a scan of the bit
+    // counts places them, and the words go out whole.  Until round 4 one loop did all of it, sequence after sequence, with every lane
+    // computing the same values (~0.27 us per sequence: half the entropy kernel on text).  What the Java flushes do along the way -- which bytes
+    // are stored when -- is not observable: the result is the same bytes, and the one way the stream can fail (it does not fit: close()
+    // returns 0, :82-92) is decided by the same comparison of its final position with the buffer's limit.
     ZC_CHECK(c, outputLimit - output >= 8);
-    bo_init(bs, base, output, outputLimit - output);
-    int32_t n = sequenceCount - 1;
-    int32_t mlState = fse_begin(*mlTable, c.codeML[n]);
-    int32_t ofState = fse_begin(*ofTable, c.codeOF[n]);
-    int32_t llState = fse_begin(*llTable, c.codeLL[n]);
-    bo_add(bs, c.seqLitLen[n], LL_BITS[c.codeLL[n]]);
-    bo_add(bs, c.seqMatchLen[n], ML_BITS[c.codeML[n]]);
-    bo_add(bs, c.seqOffset[n], c.codeOF[n]);
-    bo_flush(bs);
+    const int lane = c.lane;  // (a local: `c` lives in memory, and a store to LDS may be a store to it for all the compiler knows)
+    const int32_t sStart = output;
+    const int32_t n = sequenceCount - 1;
+    const int chain = lane < 2 ? lane : 2;
+    const FseCTable* const myTable = chain == 0 ? ofTable : (chain == 1 ? mlTable : llTable);
+    int32_t st = fse_begin(*myTable, chain == 0 ? c.codeOF[n] : (chain == 1 ? c.codeML[n] : c.codeLL[n]));
+    uint32_t* const win = (uint32_t*)sh.cumulative;  // the stream's words under construction: window[0] is word P >> 5 of the stream (258 words; a group of 64 sequences takes at most 182)
+    int32_t* const piece = sh.nodeCount;             // [64][4]: the chains' {bits | count << 16} of a group's steps
+    static_assert(sizeof(sh.cumulative) >= 4 * 192 && sizeof(sh.nodeCount) >= 4 * 256, "the packing window and the chains' pieces fit the tree builder's arrays");
+    for (int w = lane; w < 192; w += 64) {
+        win[w] = 0;
+    }
+    wave_sync();
+    // `value`'s low `bits` bits (bits <= 31) appended to a lane's 128-bit field (lo, hi, nb)
+    auto append = [](uint64_t& lo, uint64_t& hi, int32_t& nb, int32_t value, int32_t bits) {
+        const uint64_t x = (uint64_t)((uint32_t)value & (uint32_t)((1ull << bits) - 1ull));
+        lo |= nb < 64 ? x << (nb & 63) : 0ull;
+        hi |= nb >= 64 ? x << ((nb - 64) & 63) : (nb + bits > 64 ? x >> ((64 - nb) & 63) : 0ull);
+        nb += bits;
+    };
+    // a field of at most 96 bits ORed into the window at bit `at` (< 32 + 64 x 90)
+    auto put = [&](uint64_t lo, uint64_t hi, int32_t nb, int32_t at) {
+        if (nb <= 0) {
+            return;
+        }
+        const int32_t w0 = at >> 5, sh5 = at & 31;
+        const uint32_t v0 = (uint32_t)lo, v1 = (uint32_t)(lo >> 32), v2 = (uint32_t)hi, v3 = (uint32_t)(hi >> 32);
+        const uint32_t o0 = v0 << sh5;
+        const uint32_t o1 = sh5 == 0 ? v1 : ((v1 << sh5) | (v0 >> (32 - sh5)));
+        const uint32_t o2 = sh5 == 0 ? v2 : ((v2 << sh5) | (v1 >> (32 - sh5)));
+        const uint32_t o3 = sh5 == 0 ? v3 : ((v3 << sh5) | (v2 >> (32 - sh5)));
+        const uint32_t o4 = sh5 == 0 ? 0u : (v3 >> (32 - sh5));
+        if (o0 != 0) atomicOr(win + w0, o0);
+        if (o1 != 0) atomicOr(win + w0 + 1, o1);
+        if (o2 != 0) atomicOr(win + w0 + 2, o2);
+        if (o3 != 0) atomicOr(win + w0 + 3, o3);
+        if (o4 != 0) atomicOr(win + w0 + 4, o4);
+    };
+    int32_t P = 0;      // (uniform) bits of the stream so far
+    int32_t firstBits = 0;
+    bool ovf = false;   // (uniform) the stream has left its buffer: nothing more is stored, close() will say so
+    {
+        // the last sequence's extra bits open the stream (:241-245)
+        uint64_t lo = 0, hi = 0;
+        int32_t nb = 0;
+        append(lo, hi, nb, c.seqLitLen[n], LL_BITS[c.codeLL[n]]);
+        append(lo, hi, nb, c.seqMatchLen[n], ML_BITS[c.codeML[n]]);
+        append(lo, hi, nb, c.seqOffset[n], c.codeOF[n]);
+        if (lane == 0) {
+            put(lo, hi, nb, 0);
+        }
+        firstBits = nb;
+    }
+    wave_sync();
+    // whole words of the window leave for the stream; the word under construction moves to the window's start
+    auto flush_words = [&](int32_t newP) {
+        const int32_t w0 = P >> 5, whole = (newP >> 5) - w0;
+        if ((int64_t)sStart + 4LL * (w0 + whole) > (int64_t)outputLimit) {
+            ovf = true;
+        }
+        if (!ovf) {
+            for (int32_t w = lane; w < whole; w += 64) {
+                st4(base + sStart + 4 * (w0 + w), win[w]);
+            }
+        }
+        const uint32_t carry = win[whole];
+        wave_sync();
+        for (int32_t w = lane; w <= whole; w += 64) {
+            win[w] = w == 0 ? carry : 0u;
+        }
+        wave_sync();
+        P = newP;
+    };
+    flush_words(firstBits);
     // The sequences 64 at a time: lane l fetches sequence top - l -- its codes, its three values, the bit counts of its codes and, from the
-    // three tables, the two per-symbol deltas of each code (none of which depends on the states) -- and the serial loop reads lanes.  With
-    // its loads inside, the loop waited a memory latency per sequence: two thirds of the entropy kernel's time on text.
-    const int32_t seqEnd = outputLimit;  // (the stream's buffer reaches to the end of the block's room: wide flushes stay inside it)
+    // three tables, the two per-symbol deltas of each code (none of which depends on the states).
     for (int32_t top = sequenceCount - 2; top >= 0; top -= 64) {
-        const int32_t mine = top - c.lane;
+        const int32_t mine = top - lane;
         int32_t vLL = 0, vML = 0, vOF = 0, bLL = 0, bML = 0, bOF = 0, nLL = 0, fLL = 0, nML = 0, fML = 0, nOF = 0, fOF = 0;
         if (mine >= 0) {
             const int32_t llCode = c.codeLL[mine];
@@ -1288,38 +1359,56 @@ __device__ int32_t compress_sequences(Ctx& c, Shared& sh, uint8_t* base, int32_t
             fOF = ofTable->deltaFindState[ofCode];
         }
         const int count = top + 1 < 64 ? top + 1 : 64;
-        for (int k = 0; k < count; k++) {
+        // ---- the chains: step k is sequence top - k ----
+        for (int k = 0; k < count; k++) {  // (uniform)
 #define ZC_RL(v) __builtin_amdgcn_readlane((v), k)
-            const int32_t llBits = ZC_RL(bLL);
-            const int32_t ofBits = ZC_RL(bOF);
-            const int32_t mlBits = ZC_RL(bML);
-            {  // fse_encode :126-131 x 3
-                const int32_t ob = (int32_t)((uint32_t)(ofState + ZC_RL(nOF)) >> 16);
-                bo_add(bs, ofState, ob);
-                ofState = ofTable->nextState[(int32_t)((uint32_t)ofState >> (ob & 31)) + ZC_RL(fOF)];
-                const int32_t mb = (int32_t)((uint32_t)(mlState + ZC_RL(nML)) >> 16);
-                bo_add(bs, mlState, mb);
-                mlState = mlTable->nextState[(int32_t)((uint32_t)mlState >> (mb & 31)) + ZC_RL(fML)];
-                const int32_t lb = (int32_t)((uint32_t)(llState + ZC_RL(nLL)) >> 16);
-                bo_add(bs, llState, lb);
-                llState = llTable->nextState[(int32_t)((uint32_t)llState >> (lb & 31)) + ZC_RL(fLL)];
-            }
-            if (ofBits + mlBits + llBits >= 64 - 7 - (9 + 9 + 8)) {
-                bo_flush_wide(bs, seqEnd);
-            }
-            bo_add(bs, ZC_RL(vLL), llBits);
-            if (llBits + mlBits > 24) {
-                bo_flush_wide(bs, seqEnd);
-            }
-            bo_add(bs, ZC_RL(vML), mlBits);
-            if (ofBits + mlBits + llBits > 56) {
-                bo_flush_wide(bs, seqEnd);
-            }
-            bo_add(bs, ZC_RL(vOF), ofBits);
-            bo_flush_wide(bs, seqEnd);
+            const int32_t dnOF = ZC_RL(nOF), dnML = ZC_RL(nML), dnLL = ZC_RL(nLL), dfOF = ZC_RL(fOF), dfML = ZC_RL(fML), dfLL = ZC_RL(fLL);  // (lane reads: every lane takes part)
+            const int32_t dn = chain == 0 ? dnOF : (chain == 1 ? dnML : dnLL);
+            const int32_t df = chain == 0 ? dfOF : (chain == 1 ? dfML : dfLL);
 #undef ZC_RL
+            const int32_t ob = (int32_t)((uint32_t)(st + dn) >> 16);  // fse_encode :126-131
+            if (lane < 3) {
+                piece[4 * k + lane] = (int32_t)(((uint32_t)st & ((1u << (ob & 31)) - 1u)) | ((uint32_t)ob << 16));
+            }
+            st = myTable->nextState[(int32_t)((uint32_t)st >> (ob & 31)) + df];
+        }
+        wave_sync();
+        // ---- the fields of sequence top - lane: state bits of offset, match length, literal length; extra bits of literal length, match length, offset ----
+        uint64_t lo = 0, hi = 0;
+        int32_t nb = 0;
+        if (lane < count) {
+            const int32_t p0 = piece[4 * lane], p1 = piece[4 * lane + 1], p2 = piece[4 * lane + 2];
+            append(lo, hi, nb, p0 & 0xFFFF, p0 >> 16);
+            append(lo, hi, nb, p1 & 0xFFFF, p1 >> 16);
+            append(lo, hi, nb, p2 & 0xFFFF, p2 >> 16);
+            append(lo, hi, nb, vLL, bLL);
+            append(lo, hi, nb, vML, bML);
+            append(lo, hi, nb, vOF, bOF);
+        }
+        const int32_t incl = sx::wave_scan_incl(nb, lane);
+        const int32_t groupBits = sx::wave_bcast(incl, 63);
+        put(lo, hi, nb, (P & 31) + incl - nb);
+        wave_sync();
+        flush_words(P + groupBits);
+    }
+    // the stream goes on through the Java-shaped writer: its position, the bits of its last unfinished byte
+    BitOut bs;
+    bo_init(bs, base, sStart, outputLimit - sStart);
+    {
+        const uint32_t carry = win[0];
+        const int32_t wordStart = 4 * (P >> 5), byteAt = P >> 3;
+        if (!ovf && byteAt > wordStart && lane == 0) {
+            st_le(base + sStart + wordStart, (uint64_t)carry, byteAt - wordStart);
+        }
+        bs.current = sStart + byteAt;
+        bs.bitCount = P & 7;
+        bs.container = (uint64_t)(carry >> (8 * (byteAt - wordStart))) & ((1ull << (P & 7)) - 1ull);
+        if (ovf || bs.current > bs.limit) {
+            bs.current = bs.limit;
         }
     }
+    wave_sync();
+    const int32_t ofState = __builtin_amdgcn_readlane(st, 0), mlState = __builtin_amdgcn_readlane(st, 1), llState = __builtin_amdgcn_readlane(st, 2);
     fse_finish(*mlTable, bs, mlState);
     fse_finish(*ofTable, bs, ofState);
     fse_finish(*llTable, bs, llState);

@@ -440,6 +440,7 @@ inline int __ffsll(unsigned long long v) { return v == 0 ? 0 : __builtin_ctzll(v
 // cross-lane builtins that only NOT emulated kernels of a shared header use (they must compile, they never run here)
 inline int __builtin_amdgcn_update_dpp(int old, int src, int, int, int, bool) { (void)old; return src; }
 template <typename T> inline T atomicAdd(T* p, T v) { T old = *p; *p += v; return old; }
+template <typename T> inline T atomicOr(T* p, T v) { T old = *p; *p |= v; return old; }
 template <typename T> inline T atomicExch(T* p, T v) { T old = *p; *p = v; return old; }
 template <typename T> inline T atomicMax(T* p, T v) { T old = *p; if (v > old) *p = v; return old; }
 
