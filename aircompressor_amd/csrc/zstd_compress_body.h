@@ -373,24 +373,23 @@ __device__ void fse_normalize_counts2(int16_t* norm, int32_t tableLog, const int
     }
 }
 
-__device__ void fse_normalize_counts(int16_t* norm, int32_t tableLog, const int32_t* counts, int32_t total, int32_t maxSymbol)  // :257-316
+// normalizeCounts :257-316 with a lane per symbol (every caller has at most 53 symbols: sequence codes, Huffman weights).  The Java loop's
+// running values are a sum and a first-maximum over the symbols: `stillToDistribute` = table size - (probabilities + one per low symbol),
+// `largest` = the first symbol whose probability exceeds all before it (:291-294; symbol 0 when none is rated).  The second method
+// (:318-405: when the correction would take more than half of the largest probability) is rare and stays the Java loop, run by every lane alike.
+__device__ void fse_normalize_counts(int16_t* norm, int32_t tableLog, const int32_t* counts, int32_t total, int32_t maxSymbol, int lane)
 {
     const int64_t scale = 62 - tableLog;
     const int64_t step = (1LL << 62) / total;
     const int64_t vstep = 1LL << (scale - 20);
-    int32_t stillToDistribute = 1 << tableLog;
-    int32_t largest = 0;
-    int16_t largestProbability = 0;
     const int32_t lowThreshold = (int32_t)((uint32_t)total >> tableLog);
-    for (int32_t symbol = 0; symbol <= maxSymbol; symbol++) {
-        const int32_t cnt = counts[symbol];
-        if (cnt == 0) {
-            norm[symbol] = 0;
-            continue;
-        }
+    const bool mine = lane <= maxSymbol;  // (maxSymbol < 64)
+    const int32_t cnt = mine ? counts[lane] : 0;
+    int32_t value = 0, taken = 0, rated = 0;
+    if (cnt != 0) {
         if (cnt <= lowThreshold) {
-            norm[symbol] = -1;
-            stillToDistribute--;
+            value = -1;
+            taken = 1;
         }
         else {
             int16_t probability = (int16_t)((uint64_t)((int64_t)cnt * step) >> scale);
@@ -401,20 +400,28 @@ __device__ void fse_normalize_counts(int16_t* norm, int32_t tableLog, const int3
                     probability++;
                 }
             }
-            if (probability > largestProbability) {
-                largestProbability = probability;
-                largest = symbol;
-            }
-            norm[symbol] = probability;
-            stillToDistribute -= probability;
+            value = probability;
+            taken = probability;
+            rated = probability;
         }
     }
-    if (-stillToDistribute >= (int32_t)((uint32_t)(int32_t)norm[largest] >> 1)) {
+    const int32_t stillToDistribute = (1 << tableLog) - sx::wave_bcast(sx::wave_scan_incl(taken, lane), 63);
+    int32_t top = rated;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t other = __shfl_xor(top, d);
+        top = other > top ? other : top;
+    }
+    const unsigned long long holders = __ballot(rated == top);
+    const int32_t largest = top > 0 ? (int32_t)__builtin_ctzll(holders) : 0;
+    const int32_t largestValue = __shfl(value, largest);
+    if (-stillToDistribute >= (int32_t)((uint32_t)largestValue >> 1)) {  // (uniform)
         fse_normalize_counts2(norm, tableLog, counts, total, maxSymbol);
     }
-    else {
-        norm[largest] = (int16_t)(norm[largest] + (int16_t)stillToDistribute);
+    else if (mine) {
+        norm[lane] = (int16_t)(lane == largest ? value + stillToDistribute : value);
     }
+    wave_sync();
 }
 
 // writeNormalizedCounts :407-521 ; returns bytes written or -1
@@ -815,7 +822,7 @@ __device__ int32_t huf_compress_weights(Ctx& c, Shared& sh, uint8_t* base, int32
     for (int k = 0; k < 13; k++) countsLds[k] = wcounts[k];
     int16_t* normLds = &sh.norm[128];  // 13 shorts, disjoint from the sequence normalizedCounts use (index < 53)
     const int32_t tableLog = fse_optimal_table_log(6, weightsLength, maxSymbol);
-    fse_normalize_counts(normLds, tableLog, countsLds, weightsLength, maxSymbol);
+    fse_normalize_counts(normLds, tableLog, countsLds, weightsLength, maxSymbol, c.lane);
     int32_t output = outputAddress;
     const int32_t outputLimit = outputAddress + outputSize;
     const int32_t headerSize = fse_write_normalized_counts(c, base, output, outputSize, normLds, maxSymbol, tableLog);
@@ -1153,7 +1160,7 @@ __device__ int32_t build_compression_table(Ctx& c, Shared& sh, FseCTable& table,
         sh.counts[lastCode] = sh.counts[lastCode] - 1;
         sequenceCount--;
     }
-    fse_normalize_counts(sh.norm, tableLog, sh.counts, sequenceCount, maxSymbol);
+    fse_normalize_counts(sh.norm, tableLog, sh.counts, sequenceCount, maxSymbol, c.lane);
     fse_initialize(sh, table, sh.norm, maxSymbol, tableLog);
     return fse_write_normalized_counts(c, base, output, (int32_t)(outputLimit - output), sh.norm, maxSymbol, tableLog);
 }
