@@ -812,19 +812,46 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
         d.log[1] = p.desc[from1].log[1];
         d.log[2] = p.desc[from2].log[2];
     }
-    // stage the tables, item by item (each copy is done by the whole wavefront)
-    for (int k = 0; k < SEQL_ITEMS; k++) {  // (uniform)
-        if (__shfl(live ? 1 : 0, k) == 0) {
+    // stage the tables, item by item (each copy is done by the whole wavefront), eight items' loads in flight at a time: with a load and its store
+    // per trip the staging of 64 items was 192 memory round trips one after the other -- up to 0.4 ms per wavefront, and most of the stage's
+    // time on streams of small blocks (a hundred sequences per block)
+    const unsigned long long liveMask = __ballot(live);
+    constexpr int STAGE_ITEMS = 8;
+    for (int k0 = 0; k0 < SEQL_ITEMS; k0 += STAGE_ITEMS) {  // (uniform)
+        if (((liveMask >> k0) & ((1ull << STAGE_ITEMS) - 1ull)) == 0) {
             continue;
         }
-        const int32_t f0 = __shfl(from0, k), f1 = __shfl(from1, k), f2 = __shfl(from2, k);
-        const uint16_t* gLL = p.fse + (size_t)f0 * FSE_SLOT;
-        const uint16_t* gOF = p.fse + (size_t)f1 * FSE_SLOT;
-        const uint16_t* gML = p.fse + (size_t)f2 * FSE_SLOT;
-        for (int32_t piece = lane; piece < 160; piece += 64) {  // 1280 states, 8 per piece: LL 0..511, OF 512..767, ML 768..1279
-            const int32_t i = piece * 8;
-            const uint16_t* g = i < FSE_OF ? gLL : (i < FSE_ML ? gOF : gML);
-            *(u32x4*)(tables + k * SEQL_STRIDE + i) = *(const u32x4*)(g + i);
+        u32x4 v[STAGE_ITEMS][3];
+#pragma unroll
+        for (int u = 0; u < STAGE_ITEMS; u++) {
+            const int k = k0 + u;
+            if (((liveMask >> k) & 1ull) != 0) {  // (uniform)
+                const int32_t f0 = __shfl(from0, k), f1 = __shfl(from1, k), f2 = __shfl(from2, k);
+                const uint16_t* gLL = p.fse + (size_t)f0 * FSE_SLOT;
+                const uint16_t* gOF = p.fse + (size_t)f1 * FSE_SLOT;
+                const uint16_t* gML = p.fse + (size_t)f2 * FSE_SLOT;
+#pragma unroll
+                for (int t = 0; t < 3; t++) {  // 1280 states, 8 per piece: LL 0..511, OF 512..767, ML 768..1279
+                    const int32_t i = (lane + 64 * t) * 8;
+                    if (i < FSE_SLOT) {
+                        const uint16_t* g = i < FSE_OF ? gLL : (i < FSE_ML ? gOF : gML);
+                        v[u][t] = *(const u32x4*)(g + i);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < STAGE_ITEMS; u++) {
+            const int k = k0 + u;
+            if (((liveMask >> k) & 1ull) != 0) {  // (uniform)
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const int32_t i = (lane + 64 * t) * 8;
+                    if (i < FSE_SLOT) {
+                        *(u32x4*)(tables + k * SEQL_STRIDE + i) = v[u][t];
+                    }
+                }
+            }
         }
     }
     __syncthreads();
