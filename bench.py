@@ -617,8 +617,8 @@ def extras(torch, A, codec, dev, args):
     bs = args.block_size
     for data_kind in ("fragments", "wordmix", "corpus", "mixed"):
         # every kind at the headline's batch size (BASELINE configs[1]: 256K blocks) -- until round 4 the fragments entries ran 65 536 blocks, one
-        # round of the ring decoders' wavefronts, and read 4-8 % below the same kernel on the headline batch; the mixed kind is a secondary case
-        n = 65536 if data_kind == "mixed" else args.blocks
+        # round of the ring decoders' wavefronts, and read 4-8 % below the same kernel on the headline batch
+        n = args.blocks
         plain = gen_data(torch, dev, data_kind, n, bs, args.ratio, 977)
         for name, cop, dop in (("lz4", A.OP_LZ4_COMPRESS, A.OP_LZ4_DECOMPRESS), ("snappy", A.OP_SNAPPY_COMPRESS, A.OP_SNAPPY_DECOMPRESS)):
             out["%s_%s" % (name, data_kind)] = run_pair(torch, codec, args, name, cop, dop, plain, n, bs, args.cpu_leg_seconds)
