@@ -116,6 +116,12 @@ for row in csv.DictReader(open(sys.argv[1])):
         print("%-80s calls=%s avg_ms=%.3f total_ms=%.1f" % (row["Name"][:80], row["Calls"], float(row["AverageNs"]) / 1e6, float(row["TotalDurationNs"]) / 1e6))
 PY
       grep '^{' gpurun_out/ks_zs/log.txt | cut -c1-900; rm -rf gpurun_out/ks_zs ;;
+    traffic_zstd)  # HBM bytes per kernel of the Zstd section (FETCH_SIZE x 2: gfx950 counts 32-byte units as 64 -- profiles/r03_counter_calibration.txt; WRITE_SIZE as counted), in separate passes
+      bash tools/pmc_any.sh r04zf "FETCH_SIZE" python bench.py --section zstd --no-cpu-baseline
+      bash tools/pmc_any.sh r04zw "WRITE_SIZE" python bench.py --section zstd --no-cpu-baseline
+      cat gpurun_out/pmc_r04zf.txt gpurun_out/pmc_r04zw.txt | grep "zstd" | tee $O/zstd_traffic.txt ;;
+    benchtime)     # the wall clock of the default bench.py run
+      S=$(date +%s); python bench.py > $O/bench_timed.json 2> $O/bench_timed.err; echo "bench.py wall: $(( $(date +%s) - S )) s" | tee -a $O/bench_timed.err ;;
     tests)
       timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
     *) echo "unknown step $step" ;;
