@@ -333,8 +333,8 @@ def test_large_inputs_single_block(gb, o, codec):
 
 def test_options_that_would_return_wrong_data_do_not_exist():
     """Round 2 shipped development aids behind public options (executor / parser variants that skip work, an encoder stage that stops
-    early): their results were not valid.  They exist in -DACHIP_DEV builds only; the library the tests load -- the one that ships --
-    refuses them, and refuses values outside every variant option's documented set"""
+    early): their results were not valid.  They were deleted in round 4 together with their build switch; the library refuses their
+    numbers, the numbers of the decoder / encoder variants removed since, and values outside every variant option's documented set"""
     import aircompressor_amd as A
     from aircompressor_amd.errors import IllegalArgumentException
     nat = A.HipNative(0)
