@@ -917,6 +917,14 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
         const uint32_t hi = (uint32_t)((w << (at & 63)) >> 32);
         return (int32_t)((hi >> 1) >> ((31 - n) & 31));
     };
+    // the same for a field that ends inside the accumulator's upper half (at + n <= 32): one bit-field extract
+    auto field32 = [](uint32_t hi, int32_t end, int32_t n) -> int32_t {  // end = at + n
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (int32_t)__builtin_amdgcn_ubfe(hi, (uint32_t)(32 - end), (uint32_t)n);
+#else
+        return n == 0 ? 0 : (int32_t)((hi >> ((32 - end) & 31)) & ((1u << n) - 1u));
+#endif
+    };
     int32_t nDecoded = 0;
     // the repeat-offset history; MB: "what it was before the block", entries 0 .. 2 (see above)
     int32_t p0 = MB ? sx2::REP_SENTINEL : 1, p1 = MB ? (sx2::REP_SENTINEL | (1 << 16)) : 4, p2 = MB ? (sx2::REP_SENTINEL | (2 << 16)) : 8;
@@ -964,11 +972,12 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
             const int32_t nbLL = (logLL - (31 - __builtin_clz((uint32_t)nLL | 1u))) & 15;
             const int32_t nbML = (logML - (31 - __builtin_clz((uint32_t)nML | 1u))) & 15;
             const int32_t nbOF = (logOF - (31 - __builtin_clz((uint32_t)nOF | 1u))) & 15;
-            sLL = ((nLL << nbLL) - (1 << logLL) + field(0, nbLL)) & 511;
-            sML = ((nML << nbML) - (1 << logML) + field(nbLL, nbML)) & 511;
-            sOF = ((nOF << nbOF) - (1 << logOF) + field(nbLL + nbML, nbOF)) & 255;
+            const uint32_t hiS = (uint32_t)(w >> 32);  // (the three counts are at most 9 + 9 + 8 bits: all inside the upper half)
+            const int32_t endML = nbLL + nbML, nbsum = endML + nbOF;
+            sLL = ((nLL << nbLL) - (1 << logLL) + field32(hiS, nbLL, nbLL)) & 511;
+            sML = ((nML << nbML) - (1 << logML) + field32(hiS, endML, nbML)) & 511;
+            sOF = ((nOF << nbOF) - (1 << logOF) + field32(hiS, nbsum, nbOF)) & 255;
             {
-                const int32_t nbsum = nbLL + nbML + nbOF;
                 w <<= nbsum;
                 have -= nbsum;
                 rem -= nbsum;
