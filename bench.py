@@ -54,7 +54,6 @@ def parse_args():
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time of the headline's cpu_baseline leg")
     p.add_argument("--cpu-leg-seconds", type=float, default=0.6, help="CPU time of each extra entry's CPU leg (per direction)")
     p.add_argument("--no-sweep", action="store_true")
-    p.add_argument("--exec-variant", type=int, default=-1, help="DEBUG: decompress.exec_variant (two-pass decoders)")
     p.add_argument("--section", default="all", choices=["all", "zstd", "zstdstream", "xxhash", "lz4frame", "sweep"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-exec", type=int, default=-1, help="zstd pipeline execute stage: 2 = chosen per item (default), 1 = wavefront per item through the record executor, 0 = LDS rings")
     p.add_argument("--snappyframed-variant", type=int, default=-1, help="x-snappy-framed reader: 3 = ring or two-pass decoder by a probe (default), 1 = chunks through the ring decoders, 2 = through the two-pass decoder, 0 = a wavefront per stream")
@@ -308,8 +307,6 @@ def main():
     if args.ring_pad >= 0:
         codec.native.set_option("decompress.ring_pad", args.ring_pad)
     codec.native.set_option("max_src_len_hint", bs)
-    if args.exec_variant >= 0:
-        codec.native.set_option("decompress.exec_variant", args.exec_variant)
     if args.hadoop_variant >= 0:
         codec.native.set_option("hadoop.decompress.variant", args.hadoop_variant)
     if args.snappyframed_variant >= 0:

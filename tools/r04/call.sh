@@ -21,23 +21,6 @@ for step in "$@"; do
       for d in gpurun_out/prof_r04zstd_*; do cp $d/keep/dispatches.txt $O/zstd_dispatches.txt; cp $d/keep/*kernel_stats.csv $O/zstd_kernel_stats.csv; done
       tail -c 1500 $O/zstd_line.txt
       cat $O/zstd_dispatches.txt | awk 'NR>1{t[$1]+=$2; n[$1]++} END{for(k in t) printf "%-48s n=%d total_us=%.0f\n", k, n[k], t[k]}' | sort ;;
-    ab_exec)       # the third executor (decompress.exec_variant 3) beside the second on the corpus batch
-      for ev in 2 3; do
-        ks lz4_corpus_ev$ev --workload lz4_decompress --data corpus --steps 5 --warmup 2 --exec-variant $ev
-        ks snappy_corpus_ev$ev --workload snappy_decompress --data corpus --steps 5 --warmup 2 --exec-variant $ev
-      done ;;
-    ab_zseq)       # Zstd sequence stage: a lane per item (1) beside a quad per item (0); per-kernel totals of bench.py --section zstd
-      for v in 0 1; do
-        timeout 500 bash tools/profile_zstd.sh r04zseq$v --no-cpu-baseline --zstd-seq $v > $O/zseq$v.txt 2>&1
-        python - $O/zseq$v.txt <<'PY'
-import sys, json
-t = open(sys.argv[1]).read()
-i = t.rfind('{"zstd_fragments')
-r = json.loads(t[i:].splitlines()[0])
-print({k: (v["decompress_GiBps"], v["java_frames_decompress_GiBps"], v["one_kernel_fallback_items"]) for k, v in r.items()})
-PY
-        awk 'NR>1{n=$1; for(i=2;i<=NF-4;i++) n=n" "$i; t[n]+=$(NF-3); c[n]++} END{for(k in t) printf "%-60s n=%d total_us=%.0f\n", k, c[k], t[k]}' gpurun_out/prof_r04zseq$v/keep/dispatches.txt | sort | grep -v "total_us=[0-9]\{1,3\}$" | tee $O/zseq${v}_kernels.txt
-      done ;;
     containers)    # the container extras with their CPU legs (bench.py --section lz4frame / zstdstream)
       timeout 900 python bench.py --section lz4frame > $O/containers.json 2> $O/containers.err; tail -c 300 $O/containers.err
       timeout 900 python bench.py --section zstdstream > $O/zstdstream.json 2> $O/zstdstream.err; tail -c 300 $O/zstdstream.err
