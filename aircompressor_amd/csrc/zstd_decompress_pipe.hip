@@ -117,7 +117,12 @@ struct Pipe {
     int32_t itemFirst, itemEnd;  // ... and its items [itemFirst, itemEnd) of the list
     int32_t mbSlots;      // what one pass can hold: block slots, literal arena units, sequence records (an item beyond that goes to the fallback list)
     uint32_t mbLitCap, mbSeqCap;
+    // multi-block stages: the order the sequence stage takes a pass's block slots in -- by sequence count, longest first (`count` entries), and the
+    // sort's 2 x ORDER_BUCKETS counters (bucket sizes, bucket fill); nullptr: slot order
+    int32_t* order;
+    int32_t* orderHist;
 };
+constexpr int ORDER_BUCKETS = 256;  // by sequence count / 256, descending (a block holds at most 128 KiB / 3 = 43 691 sequences: bucket 170)
 
 // K4's choice per item: at least 80 output bytes per sequence (capacity as the stand-in for the output size)
 __device__ __forceinline__ bool long_sequences(int32_t capacity, int32_t nSeq) { return (int64_t)capacity >= 80LL * (nSeq > 0 ? nSeq : 1); }
@@ -751,6 +756,60 @@ __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp:
     }
 }
 
+// ---- multi-block stages: the order K3 takes a pass's block slots in.  A pass is whatever number of blocks its frames hold -- 40 896 for the bench's
+// 1 024 corpus streams: 2.5 rounds of 64 x 256 items, i.e. three --, its slots include the frames' raw and RLE blocks (nothing for K3 to do), and the
+// last round runs as long as its longest item.  Sorted by sequence count, longest first, the slots without work form whole wavefronts at the end
+// and the last round is the shortest items: K3 17.9 -> ~11 ms per launch on those streams.  A counting sort in two launches; one atomic per wavefront
+// and bucket (the lanes of a wavefront that share a bucket go together), so a pass whose blocks all fall into one bucket costs a wavefront one
+// atomic, and a wavefront's slots stay together.  (The single-block pipeline keeps batch order: 65 536 items are exactly four rounds, measured
+// 28.8 against 29.5 ms -- profiles/r04_notes.md.)  The order decides when a slot is decoded, never what it decodes to. ----
+__device__ __forceinline__ int32_t mb_order_bucket(const zp::Pipe& p, int32_t slot)
+{
+    int32_t n = 0;
+    if (p.mb[slot].kind == 2) {
+        const zp::Desc& d = p.desc[slot];
+        n = d.state == 1 ? d.nbSeq : 0;
+    }
+    n = n < 0 ? 0 : n >> 8;
+    return zp::ORDER_BUCKETS - 1 - (n < zp::ORDER_BUCKETS - 1 ? n : zp::ORDER_BUCKETS - 1);
+}
+// PLACE == false: bucket sizes into orderHist[0 .. B); PLACE == true: every slot takes its place (orderHist[B .. 2B) counts what is taken)
+template <bool PLACE>
+__global__ __launch_bounds__(64) void zstd_mb_order_kernel(zp::Pipe p)
+{
+    using namespace zp;
+    __shared__ int32_t start[ORDER_BUCKETS];
+    const int lane = threadIdx.x;
+    if (PLACE) {
+        int32_t base = 0;
+        for (int b0 = 0; b0 < ORDER_BUCKETS; b0 += 64) {  // (uniform) exclusive scan of the bucket sizes
+            const int32_t c = p.orderHist[b0 + lane];
+            const int32_t incl = sx::wave_scan_incl(c, lane);
+            start[b0 + lane] = base + incl - c;
+            base += sx::wave_bcast(incl, 63);
+        }
+        __syncthreads();
+    }
+    const int32_t slot = blockIdx.x * 64 + lane;
+    const bool have = slot < p.count;
+    const int32_t b = have ? mb_order_bucket(p, slot) : -1;
+    unsigned long long left = __ballot(have);
+    while (left != 0) {  // (uniform) bucket by bucket, in the order the buckets turn up among the lanes
+        const int leader = __builtin_ctzll(left);
+        const int32_t k = sx::wave_bcast(b, leader);
+        const unsigned long long same = __ballot(b == k);
+        int32_t at = 0;
+        if (lane == leader) {
+            at = atomicAdd(p.orderHist + (PLACE ? ORDER_BUCKETS : 0) + k, (int32_t)__popcll(same));
+        }
+        at = sx::wave_bcast(at, leader);
+        if (PLACE && b == k) {
+            p.order[start[k] + at + (int32_t)__popcll(same & ((1ull << lane) - 1ull))] = slot;
+        }
+        left &= ~same;
+    }
+}
+
 // ---- K3: sequences, a lane per item (MB: the slots are the blocks of multi-block frames -- each of a block's three tables may be that of an earlier
 // block (repeat mode), and the repeat-offset history at the block's start is what the block before leaves behind, which is not known
 // here: the history starts as three SENTINELS (achip_seqexec2.h REP_SENTINEL), records may hold sentinels, and the history behind the
@@ -790,8 +849,9 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
     __shared__ __attribute__((aligned(16))) uint16_t tables[SEQL_ITEMS * SEQL_STRIDE];
     const uint32_t* const codeTab = seq_code_table;  // literal-length codes at 0.., match-length codes at 64..: baseline | extra bits << 24
     const int lane = threadIdx.x;
-    const int32_t slot = blockIdx.x * SEQL_ITEMS + lane;
-    bool valid = lane < SEQL_ITEMS && slot < p.count;
+    const int32_t place = blockIdx.x * SEQL_ITEMS + lane;
+    bool valid = lane < SEQL_ITEMS && place < p.count;
+    const int32_t slot = MB && valid && p.order != nullptr ? p.order[place] : place;  // (multi-block passes: longest items first, zstd_mb_order_kernel)
     int32_t from0 = slot, from1 = slot, from2 = slot;  // the slots the literal-length, offset and match-length tables come from
     if (MB && valid) {
         const MbBlock b = p.mb[slot];
@@ -1685,7 +1745,7 @@ PipeLayout pipe_layout(int32_t nBlocks, int32_t tileMax)
 // (65 536: ~20 GB, asked for when a batch first holds such frames) is meant to hold a batch of some 8 GiB in one pass.
 constexpr uint32_t MB_LIT_FLOOR = 3 * PIPE_LIT_FLOOR, MB_SEQ_FLOOR = 3 * PIPE_SEQ_FLOOR;  // room for 48 blocks of the maximum size / count
 struct MbLayout {
-    int64_t counters, mb, desc, huf, fse, lit, seq, total;
+    int64_t counters, mb, desc, huf, fse, lit, seq, order, total;
     int32_t slots;
     uint32_t litCap, seqCap;  // literal arena (64-byte units), sequence arena (records)
 };
@@ -1720,6 +1780,8 @@ MbLayout mb_layout(const MbCaps& caps)
     o = up(o + (int64_t)L.litCap * 64 + 4096);  // (+ a chunk to spare: whole-vector stores behind the last literal)
     L.seq = o;
     o = up(o + (int64_t)L.seqCap * 8);
+    L.order = o;  // [bucket sizes, bucket fill][the sequence stage's order]
+    o = up(o + 2 * zp::ORDER_BUCKETS * 4 + (int64_t)L.slots * 4);
     L.total = o;
     return L;
 }
@@ -1825,8 +1887,25 @@ hipError_t launch_zstd_mb_stages(const BatchArgs& a, hipStream_t stream, zp::Pip
         hipLaunchKernelGGL(zstd_mb_fill_kernel, dim3((nItems + 63) / 64), dim3(64), 0, stream, a, p);
         hipLaunchKernelGGL(zstd_mb_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
         hipLaunchKernelGGL(zstd_pipe_literals_kernel<true>, dim3(w16), dim3(64), 0, stream, a, p);
+        p.order = nullptr;
+        if (p.count > zp::SEQL_ITEMS) {  // (more than one wavefront of slots)
+            p.orderHist = (int32_t*)(mbase + M.order);
+            p.order = p.orderHist + 2 * zp::ORDER_BUCKETS;
+            e = hipMemsetAsync(p.orderHist, 0, 2 * zp::ORDER_BUCKETS * 4, stream);
+            if (e != hipSuccess) return e;
+            const unsigned g64 = (unsigned)((p.count + 63) / 64);
+            hipLaunchKernelGGL(zstd_mb_order_kernel<false>, dim3(g64), dim3(64), 0, stream, p);
+            hipLaunchKernelGGL(zstd_mb_order_kernel<true>, dim3(g64), dim3(64), 0, stream, p);
+        }
         hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<true>, dim3((unsigned)((p.count + zp::SEQL_ITEMS - 1) / zp::SEQL_ITEMS)), dim3(64), 0, stream, a, p);
-        hipLaunchKernelGGL(zstd_mb_execute_kernel<>, dim3(nItems), dim3(64), 0, stream, a, p);
+        // A frame is one wavefront's work whatever its size: a pass of few frames leaves the LDS idle, and a window of 32 KiB instead of 4 turns most
+        // of a text frame's far matches (offsets beyond the window: 64-byte sectors re-read through the L2) into LDS reads
+        if (nItems <= 1024) {  // (four wavefronts per CU on 256 CUs: what 32 KiB windows leave room for)
+            hipLaunchKernelGGL(zstd_mb_execute_kernel<32768>, dim3(nItems), dim3(64), 0, stream, a, p);
+        }
+        else {
+            hipLaunchKernelGGL(zstd_mb_execute_kernel<>, dim3(nItems), dim3(64), 0, stream, a, p);
+        }
         hipLaunchKernelGGL(zstd_mb_checksum_kernel, dim3((nItems + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE), dim3(64), 0, stream, a, p);
     }
     return hipGetLastError();
@@ -1864,6 +1943,8 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
     p.itemFirst = p.itemEnd = 0;
     p.mbSlots = 0;
     p.mbLitCap = p.mbSeqCap = 0;
+    p.order = nullptr;
+    p.orderHist = nullptr;
     hipError_t e = hipMemsetAsync(base + L.counters, 0, 256, stream);
     if (e != hipSuccess) return e;
     for (int32_t first = 0; first < a.nBlocks; first += L.tile) {
