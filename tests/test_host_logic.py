@@ -74,6 +74,47 @@ int main(void)
     assert all(e == (0, 0) for e in entries[36:64] + entries[117:])
 
 
+def test_decoder_choice_rule_on_the_cpu():
+    """achip_device.h lz4_pick -- what auto mode's probes amount to -- compiled for the host (tools/hostemu's shim) and asked directly: the pooled
+    bytes-per-sequence rule where no per-block count exists (the stream readers), the per-block rule where it does (round 4: a third of the sampled
+    blocks short => two passes, whatever the pooled mean says), mixed groups, and "no record scratch => rings"."""
+    import shutil
+    import pytest
+    clang = shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("no clang++ for the host build of the kernel source")
+    prog = r"""
+#include "hip/hip_runtime.h"
+#include "achip_device.h"
+#include <cstdio>
+int main()
+{
+    struct C { int32_t s[8]; int32_t n, lim; };
+    const C cases[] = {
+        {{0, 100, 1100, 1, 0, 0}, 1024, 12},           // pooled: 44 bytes per sequence (units of 4: 11 < 12) -> two passes
+        {{0, 100, 1300, 1, 0, 0}, 1024, 12},           // pooled: 52 -> rings
+        {{0, 100, 1000000, 1, 400, 1024}, 1024, 12},   // per block: 400 of 1024 short (> a third) although the pooled mean is long -> two passes
+        {{0, 100, 1000000, 1, 300, 1024}, 1024, 12},   // 300 of 1024 -> rings
+        {{0, 100, 100, 1, 100, 1024}, 1024, 12},       // a tenth of the blocks short although the pooled mean is short -> rings
+        {{0, 100, 100, 0, 1024, 1024}, 1024, 12},      // no record scratch -> rings, always
+        {{17, 0, 0, 1, 0, 1024}, 1024, 12},            // more than a quarter of the 64 groups mixed -> two passes
+        {{16, 0, 0, 1, 0, 1024}, 1024, 12},            // exactly a quarter -> rings
+        {{0, 100, 500, 1, 0, 0}, 1024, 6},             // Snappy's limit (elements): 20 bytes per element -> two passes
+        {{0, 100, 700, 1, 0, 0}, 1024, 6},             // 28 -> rings
+    };
+    for (const C& c : cases) printf("%d\n", achip::lz4_pick(c.s, c.n, c.lim));
+    return 0;
+}
+"""
+    with tempfile.TemporaryDirectory() as tmp:
+        cfile, exe = os.path.join(tmp, "t.cpp"), os.path.join(tmp, "t")
+        open(cfile, "w").write(prog)
+        subprocess.run([clang, "-O1", "-std=c++17", "-I", os.path.join(ROOT, "tools", "hostemu"), "-I", os.path.join(ROOT, "include"),
+                        "-I", os.path.join(ROOT, "aircompressor_amd", "csrc"), "-o", exe, cfile], check=True)
+        got = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    assert got == [3, 0, 3, 0, 0, 0, 3, 0, 3, 0], got
+
+
 def test_lane_private_decoder_kernels_on_the_cpu():
     """The kernel sources compiled for the host and run under tools/hostemu (every thread a fiber, cross-lane operations as rendezvous, lanes
     in a different order from pass to pass): the ring decoders with one lane per block and -- the product's default, the headline's kernel --
