@@ -48,6 +48,7 @@ int64_t hadoop_decompress_scratch_bytes(int32_t nStreams, int32_t bufferSize);
 hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize);
 int64_t hadoop_compress_scratch_bytes(int32_t nStreams);
 extern int g_zstd_pipe_exec;
+extern int g_lz4_parse_mode;
 hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant, const AuxScratch* aux);
 int64_t lz4frame_decompress_scratch_bytes(int32_t nItems, int variant);
 hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes);
@@ -904,6 +905,10 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     else if (k == "lz4frame.decompress.variant") {
         if (value < 0 || value > 2) return bad_argument("lz4frame.decompress.variant: 0 a wavefront per item, 1 block list through the two-pass decoder, 2 chosen by a probe");
         ctx->lz4FrameDecompressVariant = (int)value;
+    }
+    else if (k == "lz4.decompress.parse") {
+        if (value < 0 || value > 2) return bad_argument("lz4.decompress.parse: 0 by the batch (a wavefront per block below 32768 blocks), 1 a lane per block, 2 a wavefront per block");
+        achip::g_lz4_parse_mode = (int)value;
     }
     else if (k == "zstd.decompress.exec") {
         if (value < 0 || value > 2) return bad_argument("zstd.decompress.exec: 0 rings, 1 record executor, 2 chosen per item");

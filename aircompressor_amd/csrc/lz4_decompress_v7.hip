@@ -326,6 +326,244 @@ __global__ __launch_bounds__(64) void lz4_parse2_kernel(BatchArgs a, sx::ArenaHe
     }
 }
 
+// ---- lz4_parse_wave_kernel: the parse pass with a WAVEFRONT per block (round 4), for batches of FEW blocks.
+// The lane-per-block parser above is the efficient one -- 64 blocks per instruction stream -- when there are blocks for every lane of the chip
+// (262 144 and up).  The stream readers hand over a few thousand LARGE blocks (an LZ4 frame's blocks of up to 4 MiB, a Hadoop stream's chunks of
+// 256 KiB): a few wavefronts, each alone on its SIMD, each lane a serial chain of one trip (~1 500 cycles) per sequence -- a 256 KiB chunk took
+// 15 ms, a 4 MiB block 250, whatever the rest of the chip did.  Here the wavefront parses ONE block, 64 token positions per trip:
+//   * the next 352 bytes of the stream are staged in LDS; lane p reads them AS IF a sequence started at position p: token, literal length (one
+//     extension byte at most), where the offset field would be, match length (likewise), and where the sequence after it would begin;
+//   * the real sequences of the window are the chain 0 -> next[0] -> next[next[0]] ...: a scalar loop of lane reads (a handful of scalar
+//     instructions per sequence instead of a trip);
+//   * the lanes on the chain get their output positions from a scan, make the Java loop's checks (exactly the fast path's of the parser above:
+//     its conditions are the complement of the Java loop's failure and last-literals branches) and store one record each.
+// A sequence that is anything else -- a second extension byte, more than 16 literal or match bytes (several records), a failing check, the last
+// 360 bytes of the block -- ends the chain in front of it and is parsed by lz4_parse_general, the Java loop body check by check, its records
+// written by the whole wavefront (a literal run of megabytes is 64 records per step).  Same records, same statuses and error offsets as the
+// parser above: the executor does not know which of the two wrote them.
+namespace wp {
+constexpr int STAGE = 352;  // a sequence that starts within 64 positions and has at most one extension byte per length ends within 337 bytes
+}
+struct WaveRecordSink {  // the block's records: chunks of the arena, claimed one at a time
+    sx::ArenaHeader* hdr;
+    uint64_t* arena;
+    int32_t maxChunks;
+    int32_t firstChunk, chunk, fill, count;  // (uniform)
+    bool fallback;                           // (uniform) the arena is exhausted: the ring decoder takes the block
+    // n (<= 64, uniform) records, lane i's at index idx (< n) of the batch if `valid`
+    __device__ __forceinline__ void put(uint64_t rec, bool valid, int32_t idx, int32_t n, int lane)
+    {
+        if (n <= 0 || fallback) {  // (uniform)
+            return;
+        }
+        const int32_t room = sx::CHUNK_RECS - fill;
+        int32_t fresh = -1;
+        if (n > room) {  // (uniform) the batch reaches into a new chunk
+            int32_t c = 0;
+            if (lane == 0) {
+                c = atomicAdd(&hdr->nextChunk, 1);
+            }
+            c = sx::wave_bcast(c, 0);
+            if (c >= maxChunks) {
+                fallback = true;
+                return;
+            }
+            if (chunk >= 0) {
+                if (lane == 0) {
+                    arena[(int64_t)chunk * sx::CHUNK_SLOTS + sx::CHUNK_RECS] = (uint64_t)(uint32_t)c;  // link
+                }
+            }
+            else {
+                firstChunk = c;
+            }
+            fresh = c;
+        }
+        if (valid) {
+            const int32_t slot = fill + idx;
+            if (slot < sx::CHUNK_RECS) {
+                arena[(int64_t)chunk * sx::CHUNK_SLOTS + slot] = rec;
+            }
+            else {
+                arena[(int64_t)fresh * sx::CHUNK_SLOTS + (slot - sx::CHUNK_RECS)] = rec;
+            }
+        }
+        if (n > room) {
+            chunk = fresh;
+            fill = fill + n - sx::CHUNK_RECS;
+        }
+        else {
+            fill += n;
+        }
+        count += n;
+    }
+};
+
+__global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::ArenaHeader* hdr, sx::BlockMeta* meta, int32_t* only, uint64_t* arena, int32_t maxChunks, const int32_t* stats)
+{
+    if (stats != nullptr && lz4_pick(stats, a.nBlocks) != LZ4_PICK_TWOPASS) {  // auto mode: the ring decoder takes this batch
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) uint8_t stage[wp::STAGE + 16];
+    const int lane = threadIdx.x;
+    const int64_t block = blockIdx.x;
+    const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
+    const int32_t inLimit = uni(a.srcLen[block]);
+    const int32_t outLimit = uni(a.dstCap[block]);
+    Lz4ParseState S;
+    S.ip = 0;
+    S.op = 0;
+    S.st = 0;
+    S.eo = 0;
+    S.litEndPrev = 0;
+    S.done = false;
+    S.fallback = false;
+    if (inLimit == 0) {  // :48-50
+        S.st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_LZ4_INPUT_EMPTY);
+        S.done = true;
+    }
+    else if (outLimit == 0) {  // :52-57 (the Java method returns -1 here)
+        if (!(inLimit == 1 && in[0] == 0)) {
+            S.st = mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_LZ4_EMPTY_OUTPUT);
+        }
+        S.done = true;
+    }
+    WaveRecordSink K;
+    K.hdr = hdr;
+    K.arena = arena;
+    K.maxChunks = maxChunks;
+    K.firstChunk = -1;
+    K.chunk = -1;
+    K.fill = sx::CHUNK_RECS;
+    K.count = 0;
+    K.fallback = false;
+    const int32_t fastOut = outLimit - 8 - 4;  // a match may end here at the latest (:82, :168)
+    bool finished = S.done;                    // (uniform)
+    while (!finished && !K.fallback) {         // (uniform)
+        bool general = true;
+        if ((int64_t)S.ip + wp::STAGE + 8 <= (int64_t)inLimit) {  // (uniform) a window: nothing in it can reach the block's last bytes
+            const int32_t base = S.ip;
+            if (lane < wp::STAGE / 16) {
+                *(u32x4*)(stage + 16 * lane) = ld16(in + base + 16 * lane);
+            }
+            wave_sync();
+            // what a sequence at position `lane` of the window would be
+            uint32_t x;
+            __builtin_memcpy(&x, stage + lane, 4);
+            const uint32_t token = x & 0xFF, e1 = (x >> 8) & 0xFF;
+            const bool litExt = (token >> 4) == 0xF;
+            const int32_t lit = (int32_t)(litExt ? 15u + e1 : (token >> 4));
+            const int32_t litStart = lane + (litExt ? 2 : 1);
+            const int32_t q = litStart + lit;  // the offset field (<= 334)
+            uint32_t y;
+            __builtin_memcpy(&y, stage + q, 4);
+            const int32_t offset = (int32_t)(y & 0xFFFF);
+            const uint32_t e2 = (y >> 16) & 0xFF;
+            const bool mlExt = (token & 0xF) == 0xF;
+            const int32_t ml = (int32_t)(mlExt ? 15u + e2 : (token & 0xF)) + 4;
+            const int32_t next = q + (mlExt ? 3 : 2);
+            // not for the chain: a second extension byte, more than one record's worth of bytes
+            const bool stop = (litExt && e1 == 255) || (mlExt && e2 == 255) || lit > 16 || ml > 16;
+            const unsigned long long stopMask = __ballot(stop);
+            unsigned long long members = 0;
+            int32_t cur = 0;
+            while (cur < 64 && ((stopMask >> cur) & 1ull) == 0) {  // (uniform) the chain
+                members |= 1ull << cur;
+                cur = __builtin_amdgcn_readlane(next, cur);
+            }
+            // the members' places in the output, and the checks that need them (:113-119, :168-171 as the fast path above has them)
+            const bool member = ((members >> lane) & 1ull) != 0;
+            const int32_t tot = member ? lit + ml : 0;
+            const int32_t endRel = sx::wave_scan_incl(tot, lane);
+            const int32_t opEnd = S.op + endRel, opLit = opEnd - ml;
+            const bool wrong = member && (offset == 0 || offset > opLit || opEnd > fastOut);
+            const unsigned long long wrongMask = __ballot(wrong);
+            if (wrongMask != 0) {  // (uniform) the chain ends in front of the first such sequence
+                const int first = __builtin_ctzll(wrongMask);
+                members &= (1ull << first) - 1ull;
+                cur = first;
+            }
+            const bool mine = ((members >> lane) & 1ull) != 0;
+            const int32_t n = (int32_t)__popcll(members);
+            if (n > 0) {  // (uniform)
+                const unsigned long long below = members & ((1ull << lane) - 1ull);
+                const int prevLane = below != 0 ? 63 - __builtin_clzll(below) : 0;
+                const int32_t prevQ = __shfl(q, prevLane);
+                const int32_t skip = base + litStart - (below != 0 ? base + prevQ : S.litEndPrev);
+                const int last = 63 - __builtin_clzll(members);
+                if (__ballot(mine && skip > sx::MAX_SKIP) != 0) {  // (a gap beyond the record field) the ring decoder takes the block
+                    K.fallback = true;
+                }
+                else {
+                    K.put(sx::rec_pack((uint32_t)lit, (uint32_t)ml, (uint32_t)offset, (uint32_t)skip), mine, (int32_t)__popcll(below), n, lane);
+                    S.op += sx::wave_bcast(endRel, last);
+                    S.litEndPrev = base + sx::wave_bcast(q, last);
+                    S.ip = base + cur;
+                    general = false;
+                }
+            }
+            wave_sync();  // (the next window overwrites the staging area)
+        }
+        if (general && !K.fallback) {  // (uniform) one sequence the Java way, its records by the whole wavefront
+            uint32_t rLit = 0, rMl = 0, rOff = 0;
+            int32_t rStart = 0;
+            const bool emit = lz4_parse_general(in, S, inLimit, outLimit, rLit, rMl, rOff, rStart);
+            if (emit) {
+                const int32_t sLit = (int32_t)rLit, sMl = (int32_t)rMl, sOff = (int32_t)rOff;
+                const int32_t litFull = sLit > 16 ? (sLit + 15) / 16 - 1 : 0;
+                const int32_t matchRest = sMl > 16 ? (sMl - 16 + 15) / 16 : 0;
+                const int32_t pieces = litFull + 1 + matchRest;
+                const int32_t skip0 = rStart - S.litEndPrev;
+                if (skip0 > sx::MAX_SKIP) {
+                    K.fallback = true;
+                }
+                for (int32_t k0 = 0; k0 < pieces && !K.fallback; k0 += 64) {  // (uniform)
+                    const int32_t k = k0 + lane;
+                    int32_t pl, pm, o = sOff;
+                    if (k < litFull) {
+                        pl = 16;
+                        pm = 0;
+                    }
+                    else if (k == litFull) {
+                        pl = sLit - 16 * litFull;
+                        pm = sMl < 16 ? sMl : 16;
+                    }
+                    else {
+                        const int32_t m = k - litFull;  // match pieces before this one
+                        pl = 0;
+                        pm = sMl - 16 * m < 16 ? sMl - 16 * m : 16;
+                        const int32_t xm = 16 * m + sOff;
+                        o = sx::largest_multiple(sOff > 0 ? sOff : 1, xm < 65535 ? xm : 65535);
+                    }
+                    const int32_t left = pieces - k0;
+                    K.put(sx::rec_pack((uint32_t)pl, (uint32_t)pm, pm > 0 ? (uint32_t)o : 0u, k == 0 ? (uint32_t)skip0 : 0u), k < pieces, lane, left < 64 ? left : 64, lane);
+                }
+                S.litEndPrev = rStart + sLit;
+            }
+            finished = !emit || S.done;
+        }
+    }
+    if (lane == 0) {
+        if (K.fallback) {
+            only[block] = 1;
+            meta[block].firstChunk = 0;
+            meta[block].count = 0;
+            atomicAdd(&hdr->fallbackBlocks, 1);
+        }
+        else {
+            only[block] = 0;
+            meta[block].firstChunk = K.firstChunk < 0 ? 0 : K.firstChunk;
+            meta[block].count = S.st == 0 ? K.count : 0;
+            a.outLen[block] = S.st == 0 ? S.op : 0;
+            a.status[block] = S.st;
+            a.errOffset[block] = (int64_t)S.eo;
+        }
+    }
+}
+
+// which of the two parsers: 0 = by the batch (a wavefront per block below 32 768 blocks with a count known to the host), 1 = a lane per block, 2 = a
+// wavefront per block (context option lz4.decompress.parse)
+int g_lz4_parse_mode = 0;
+
 // the execute pass (achip_seqexec2.h): pieces of at most 16 + 16 bytes, every global load one batch ahead
 template <int WIN = sx2::WIN_DEFAULT, int WAVES = 0>
 __global__ __launch_bounds__(64, WAVES) void seq_execute2_kernel(BatchArgs a, const sx::BlockMeta* meta, const uint64_t* arena, const int32_t* stats, int32_t shortLimit)
@@ -385,7 +623,13 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream,
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((a.nBlocks + 63) / 64)), wg(64);
     {
-    hipLaunchKernelGGL(lz4_parse2_kernel, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+    const bool wavePerBlock = a.nBlocksDev == nullptr && (g_lz4_parse_mode == 2 || (g_lz4_parse_mode == 0 && a.nBlocks < 32768));
+    if (wavePerBlock) {
+        hipLaunchKernelGGL(lz4_parse_wave_kernel, dim3((unsigned)a.nBlocks), wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+    }
+    else {
+        hipLaunchKernelGGL(lz4_parse2_kernel, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+    }
     e = launch_seq_execute2(a, stream, meta, arena, execVariant, stats, 12);
     if (e != hipSuccess) return e;
     }

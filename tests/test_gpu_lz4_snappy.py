@@ -81,12 +81,17 @@ def test_decompress_matches_plaintext_all_decoder_configs(gb, o, codec, cfg):
     configure(gb, codec, DECODERS[0])
 
 
+@pytest.mark.parametrize("parse", [1, 2], ids=["lane-per-block-parse", "wavefront-per-block-parse"])
 @pytest.mark.parametrize("cfg", [(7, 4, 0)], ids=lambda c: "variant%d-gs%d-rc%d" % c)
-def test_lz4_two_pass_decoder(gb, o, cfg):
-    """variant 7 (lz4_decompress_v7.hip: parse to records, a wavefront per block executes them), forced for any batch size: plaintext, status and
-    error offsets equal the oracle's, corrupt streams included"""
+def test_lz4_two_pass_decoder(gb, o, cfg, parse):
+    """variant 7 (lz4_decompress_v7.hip: parse to records, a wavefront per block executes them), forced for any batch size, with either parser
+    (lz4.decompress.parse: a lane per block -- what large batches take -- or a wavefront per block -- what batches below 32 768 blocks take):
+    plaintext, status and error offsets equal the oracle's, corrupt streams included; blocks of several hundred KiB with literal runs and
+    matches of that order (thousands of records from one sequence, chunk after chunk of the arena)"""
     rng = np.random.default_rng(7)
-    blocks = all_blocks()
+    text = b"".join(d for _, d, _ in common.corpus_sample()[:4])
+    blocks = all_blocks() + [bytes(rng.integers(0, 256, 300000, dtype=np.uint8)), bytes(1 << 20), text[:200000] + bytes(70000) + text[:50000],
+                             (bytes(rng.integers(0, 256, 700, dtype=np.uint8)) * 300)[:200001]]
     cases = [(o.compress("lz4", b), len(b)) for b in blocks] + [(o.compress("lz4", b), len(b) + 37) for b in blocks[:20]]
     cases += [(bytes([15, 0, 0, 255, 255, 0x8A, 49, 255, 255, 0]), 1024), (b"", 10), (b"\x00", 0), (b"\x10a", 0), (bytes([0xF0]) + b"\xff" * 4000, 1 << 16)]
     for b in [d for _, d, _ in common.corpus_sample()[:3]]:
@@ -97,9 +102,11 @@ def test_lz4_two_pass_decoder(gb, o, cfg):
             m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
             cases.append((bytes(m), len(b)))
     configure(gb, "lz4", cfg)
+    gb.set_option("lz4.decompress.parse", parse)
     try:
         outs, status, err = gb.run(CODECS["lz4"]["d"], [c for c, _ in cases], [cap for _, cap in cases], unaligned=True)
     finally:
+        gb.set_option("lz4.decompress.parse", 0)
         configure(gb, "lz4", DECODERS[0])
     for i, (c, cap) in enumerate(cases):
         est, eoff, eout = _oracle_status(o, "lz4", c, cap)

@@ -18,7 +18,8 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
         blocks += [bytes(1 << 20), bytes(range(256)) * 2048, (b"abc" * 100000)[:250001], text, text[:100000] + bytes(50000) + text[:70000],
                    bytes(rng.integers(0, 256, 300000, dtype=np.uint8)), (bytes(rng.integers(0, 256, 1000, dtype=np.uint8)) * 400)]
     OPS = {"lz4": 0, "snappy": 2, "zstd": 4, "lz4frame": 6, "snappyframed": 8}
-    VARIANTS = {"lz4": [1, 7], "snappy": [1, 7], "zstd": [1, 0], "lz4frame": [None], "snappyframed": [None]}
+    VARIANTS = {"lz4": [1, 7, 71], "snappy": [1, 7],  # (71: LZ4 variant 7 with the lane-per-block parser -- batches of this size take the wavefront-per-block one)
+                 "zstd": [1, 0], "lz4frame": [None], "snappyframed": [None]}
 
 
     def expect(codec, data, cap):
@@ -62,7 +63,9 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
         want = [expect(codec, c, cap) for c, cap in cases]
         for variant in VARIANTS[codec]:
             if variant is not None:
-                gb.set_option("%s.decompress.variant" % codec, variant)
+                gb.set_option("%s.decompress.variant" % codec, 7 if variant == 71 else variant)
+                if codec == "lz4":
+                    gb.set_option("lz4.decompress.parse", 1 if variant == 71 else 0)
             outs, status, err = gb.run(OPS[codec], [c for c, _ in cases], [cap for _, cap in cases], unaligned=True)
             wrong = 0
             for i, (est, eoff, eout) in enumerate(want):
@@ -74,6 +77,8 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
             bad += wrong
             n_err = sum(1 for w in want if w[0] != 0)
             print("%s variant %s: %d cases (%d malformed), %d mismatches" % (codec, variant, len(cases), n_err, wrong), flush=True)
+        if codec == "lz4":
+            gb.set_option("lz4.decompress.parse", 0)
     print("TOTAL MISMATCHES", bad)
     return bad
 
