@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64) void lz4_parse2_kernel(BatchArgs a, sx::ArenaHe
 // (262 144 and up).  The stream readers hand over a few thousand LARGE blocks (an LZ4 frame's blocks of up to 4 MiB, a Hadoop stream's chunks of
 // 256 KiB): a few wavefronts, each alone on its SIMD, each lane a serial chain of one trip (~1 500 cycles) per sequence -- a 256 KiB chunk took
 // 15 ms, a 4 MiB block 250, whatever the rest of the chip did.  Here the wavefront parses ONE block, 64 token positions per trip:
-//   * the next 352 bytes of the stream are staged in LDS; lane p reads them AS IF a sequence started at position p: token, literal length (one
+//   * the stream passes through a staging area in LDS (WaveStage); lane p reads the window's bytes AS IF a sequence started at position p: token, literal length (one
 //     extension byte at most), where the offset field would be, match length (likewise), and where the sequence after it would begin;
 //   * the real sequences of the window are the chain 0 -> next[0] -> next[next[0]] ...: a scalar loop of lane reads (a handful of scalar
 //     instructions per sequence instead of a trip);
@@ -343,7 +343,67 @@ __global__ __launch_bounds__(64) void lz4_parse2_kernel(BatchArgs a, sx::ArenaHe
 // parser above: the executor does not know which of the two wrote them.
 namespace wp {
 constexpr int STAGE = 352;  // a sequence that starts within 64 positions and has at most one extension byte per length ends within 337 bytes
+constexpr int SLAB = 2048;  // the staging area holds the stream's bytes [B0, B0 + SLAB + STAGE); it moves on by a slab at a time
+constexpr int CAP = SLAB + STAGE;
 }
+// The stream's bytes for the windows: a linear piece of the stream in LDS that moves on by 2 KiB when the windows have walked through 2 KiB -- the
+// bytes of the NEXT slab are requested when a slab arrives and sit in registers until then (a window consumes ~40 bytes: fifty windows later).
+// Staging every window's 352 bytes on its own cost a memory round trip per window: 2 us for ~7 sequences.
+struct WaveStage {
+    uint8_t* lds;
+    const uint8_t* in;
+    int32_t inLimit;
+    int32_t b0;        // (uniform) stream position of lds[0]; -1: nothing staged
+    u32x4 pend[2];     // this lane's 2 x 16 bytes of [b0 + CAP, b0 + CAP + SLAB)
+    int lane;
+    __device__ __forceinline__ u32x4 fetch(int32_t pos) const
+    {
+        return pos + 16 <= inLimit ? ld16(in + pos) : u32x4{0, 0, 0, 0};  // (what lies beyond the block is never looked at: windows stay 8 bytes clear of the end)
+    }
+    __device__ __forceinline__ void request()
+    {
+        pend[0] = fetch(b0 + wp::CAP + 16 * lane);
+        pend[1] = fetch(b0 + wp::CAP + 16 * (lane + 64));
+    }
+    __device__ __forceinline__ void restart(int32_t base)  // synchronous: the first window, and a window far beyond what is staged (behind a long literal run)
+    {
+        wave_sync();
+        b0 = base;
+        for (int32_t i = lane; i < wp::CAP / 16; i += 64) {
+            *(u32x4*)(lds + 16 * i) = fetch(b0 + 16 * i);
+        }
+        request();
+        wave_sync();
+    }
+    __device__ __forceinline__ void advance()  // by one slab: the tail moves to the front, the requested slab lands behind it, the next one is requested
+    {
+        wave_sync();
+        u32x4 tail = {0, 0, 0, 0};
+        if (lane < wp::STAGE / 16) {
+            tail = *(const u32x4*)(lds + wp::SLAB + 16 * lane);
+        }
+        wave_sync();
+        if (lane < wp::STAGE / 16) {
+            *(u32x4*)(lds + 16 * lane) = tail;
+        }
+        *(u32x4*)(lds + wp::STAGE + 16 * lane) = pend[0];
+        *(u32x4*)(lds + wp::STAGE + 16 * (lane + 64)) = pend[1];
+        b0 += wp::SLAB;
+        request();
+        wave_sync();
+    }
+    // the window at `base` is readable at lds + (base - b0)
+    __device__ __forceinline__ const uint8_t* window(int32_t base)
+    {
+        if (b0 < 0 || base < b0 || base - b0 >= 2 * wp::SLAB) {  // (uniform)
+            restart(base);
+        }
+        else if (base - b0 >= wp::SLAB) {
+            advance();
+        }
+        return lds + (base - b0);
+    }
+};
 struct WaveRecordSink {  // the block's records: chunks of the arena, claimed one at a time
     sx::ArenaHeader* hdr;
     uint64_t* arena;
@@ -403,11 +463,19 @@ __global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::Are
     if (stats != nullptr && lz4_pick(stats, a.nBlocks) != LZ4_PICK_TWOPASS) {  // auto mode: the ring decoder takes this batch
         return;
     }
-    __shared__ __attribute__((aligned(16))) uint8_t stage[wp::STAGE + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t stageLds[wp::CAP + 16];
     const int lane = threadIdx.x;
     const int64_t block = blockIdx.x;
     const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
     const int32_t inLimit = uni(a.srcLen[block]);
+    WaveStage W;
+    W.lds = stageLds;
+    W.in = in;
+    W.inLimit = inLimit;
+    W.b0 = -1;
+    W.pend[0] = u32x4{0, 0, 0, 0};
+    W.pend[1] = u32x4{0, 0, 0, 0};
+    W.lane = lane;
     const int32_t outLimit = uni(a.dstCap[block]);
     Lz4ParseState S;
     S.ip = 0;
@@ -440,12 +508,9 @@ __global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::Are
     bool finished = S.done;                    // (uniform)
     while (!finished && !K.fallback) {         // (uniform)
         bool general = true;
-        if ((int64_t)S.ip + wp::STAGE + 8 <= (int64_t)inLimit) {  // (uniform) a window: nothing in it can reach the block's last bytes
+        if ((int64_t)S.ip + wp::STAGE + 24 <= (int64_t)inLimit) {  // (uniform) a window: nothing in it can reach the block's last bytes (8: the Java loop's margin; 16: every byte it looks at lies in a 16-byte piece that is inside the block whole -- WaveStage::fetch)
             const int32_t base = S.ip;
-            if (lane < wp::STAGE / 16) {
-                *(u32x4*)(stage + 16 * lane) = ld16(in + base + 16 * lane);
-            }
-            wave_sync();
+            const uint8_t* const stage = W.window(base);
             // what a sequence at position `lane` of the window would be
             uint32_t x;
             __builtin_memcpy(&x, stage + lane, 4);
@@ -501,7 +566,6 @@ __global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::Are
                     general = false;
                 }
             }
-            wave_sync();  // (the next window overwrites the staging area)
         }
         if (general && !K.fallback) {  // (uniform) one sequence the Java way, its records by the whole wavefront
             uint32_t rLit = 0, rMl = 0, rOff = 0;
@@ -560,8 +624,9 @@ __global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::Are
     }
 }
 
-// which of the two parsers: 0 = by the batch (a wavefront per block below 32 768 blocks with a count known to the host), 1 = a lane per block, 2 = a
-// wavefront per block (context option lz4.decompress.parse)
+// which of the two parsers: 0 = by the batch (a wavefront per block up to 4 096 blocks with a count known to the host: 1 024 blocks of 4 MiB
+// 13.5 -> 33 GiB/s with it, but 16 384 chunks of 256 KiB 167 -> 118 -- the lane parser's time does not grow with the count until the chip is full,
+// the wavefront parser's does), 1 = a lane per block, 2 = a wavefront per block (context option lz4.decompress.parse)
 int g_lz4_parse_mode = 0;
 
 // the execute pass (achip_seqexec2.h): pieces of at most 16 + 16 bytes, every global load one batch ahead
@@ -623,7 +688,7 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream,
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((a.nBlocks + 63) / 64)), wg(64);
     {
-    const bool wavePerBlock = a.nBlocksDev == nullptr && (g_lz4_parse_mode == 2 || (g_lz4_parse_mode == 0 && a.nBlocks < 32768));
+    const bool wavePerBlock = a.nBlocksDev == nullptr && (g_lz4_parse_mode == 2 || (g_lz4_parse_mode == 0 && a.nBlocks <= 4096));
     if (wavePerBlock) {
         hipLaunchKernelGGL(lz4_parse_wave_kernel, dim3((unsigned)a.nBlocks), wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
     }
