@@ -51,6 +51,53 @@ def partition_blocks(weights, n_parts):
     return starts
 
 
+class HipMultiContextCodec:
+    """ONE process, several contexts (normally one per device), one host thread per context inside the library: the Python twin of
+    java/io/airlift/compress/v3/hip/HipBatchCodec.java's `run` (N contexts, N threads, byte-balanced contiguous slices) over
+    achip_multi_batch_host.  Host numpy arrays in and out; units are independent, the slices exchange nothing."""
+
+    def __init__(self, devices=None, contexts=None):
+        self.lib = native.load_library()
+        if contexts is None:
+            if devices is None:
+                devices = list(range(max(self.lib.achip_device_count(), 0)))
+            contexts = [HipNative(d) for d in devices]
+        if not contexts:
+            raise native.HipUnavailableError("no HIP device visible: the Hip codecs cannot run (no CPU fallback)")
+        self.contexts = list(contexts)
+        self._handles = (ctypes.c_void_p * len(self.contexts))(*[c.ctx for c in self.contexts])
+        self.slice_starts = None
+
+    def run_host(self, op, src, src_off, src_len, dst, dst_off, dst_cap):
+        """`op`: one OP_* for every item, or a sequence of one OP_* per item (a mixed batch, BASELINE configs[4])."""
+        n = len(src_off)
+        ops = None
+        if not np.isscalar(op):
+            ops = np.ascontiguousarray(op, dtype=np.int32)
+            if len(ops) != n:
+                raise native.IllegalArgumentException("ops must have one entry per item")
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        src_off = np.ascontiguousarray(src_off, dtype=np.int64)
+        src_len = np.ascontiguousarray(src_len, dtype=np.int32)
+        dst_off = np.ascontiguousarray(dst_off, dtype=np.int64)
+        dst_cap = np.ascontiguousarray(dst_cap, dtype=np.int32)
+        out_len = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        err_off = np.zeros(n, dtype=np.int64)
+        starts = np.zeros(len(self.contexts) + 1, dtype=np.int32)
+        r = self.lib.achip_multi_batch_host(self._handles, len(self.contexts), 0 if ops is not None else int(op), ops.ctypes.data if ops is not None else None,
+                                            src.ctypes.data, src_off.ctypes.data, src_len.ctypes.data, dst.ctypes.data, dst_off.ctypes.data, dst_cap.ctypes.data,
+                                            out_len.ctypes.data, status.ctypes.data, err_off.ctypes.data, n, starts.ctypes.data)
+        if r < 0:
+            native.raise_for_status(r)
+        self.slice_starts = starts
+        return out_len, status, err_off
+
+    def close(self):
+        for c in self.contexts:
+            c.close()
+
+
 class HipBatchCodec:
     def __init__(self, device=0, native_ctx=None):
         self.native = native_ctx if native_ctx is not None else HipNative(device)

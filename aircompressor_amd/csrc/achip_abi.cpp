@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <thread>
@@ -102,15 +103,25 @@ struct achip_ctx {
     uint8_t* mixDev = nullptr;
     int64_t mixItems = 0;
     hipEvent_t mixUploaded = nullptr;  // the last permutation upload: the pinned buffer may be rewritten once it has completed
-    // host-pointer batches (achip_batch_host / achip_mixed_batch_host): two staging slots, chunks pipelined over three streams
-    struct CopyPool* pool = nullptr;
-    uint8_t* slotHost[2] = {nullptr, nullptr};  // pinned
-    uint8_t* slotDev[2] = {nullptr, nullptr};
+    // host-pointer batches (achip_batch_host / achip_mixed_batch_host): up to four staging slots, chunks pipelined over three streams, gather and
+    // scatter on copy pools of their own
+    static constexpr int kHostSlots = 4;
+    struct CopyPool* pool = nullptr;     // gather: the caller's inputs -> pinned slot
+    struct CopyPool* poolOut = nullptr;  // scatter: pinned slot -> the caller's outputs
+    uint8_t* slotHost[kHostSlots] = {};  // pinned
+    uint8_t* slotDev[kHostSlots] = {};
     int64_t slotBytes = 0;
+    int slotCount = 0;
     hipStream_t copyIn = nullptr, copyOut = nullptr;
-    hipEvent_t evH2D[2] = {nullptr, nullptr}, evK[2] = {nullptr, nullptr}, evD2H[2] = {nullptr, nullptr};
-    int64_t hostChunkBytes = 48 << 20;  // staging bytes (inputs + output capacities) per pipeline chunk
-    int hostCopyThreads = 0;            // 0 = min(8, hardware threads)
+    hipEvent_t evH2D[kHostSlots] = {}, evK[kHostSlots] = {}, evD2H[kHostSlots] = {};
+    int64_t hostChunkBytes = 96 << 20;   // staging bytes (inputs + output capacities) per pipeline chunk: ~1000 blocks of 64 KiB -- a chunk's kernels
+                                         // take a block's serial chain (~1-2 ms) however few blocks it holds, so a chunk must be worth that long on the
+                                         // link; measured (profiles/r05_hostsweep.txt): 96 MiB 36-40 GiB/s, 192 MiB 28-34, 384 MiB 30-33 (the 48 MiB of
+                                         // rounds 1-4 over two slots: 8.7)
+    int hostCopyThreads = 0;             // per copy pool; 0 = hardware threads / 16, 2 .. 8 (4 and 8 measured best; 32 no better: the scatter is
+                                         // bound by the host's memory system, not by the thread count)
+    // achip_ctx_get_stat("host.*"): where the last host-pointer batch of several chunks spent its wall time (microseconds)
+    int64_t hostGatherUs = 0, hostScatterUs = 0, hostWaitSlotUs = 0, hostWaitDownloadUs = 0, hostChunks = 0, hostTotalUs = 0;
     // staging for the one-shot hashers (grown on demand)
     uint8_t* hostStage = nullptr;  // pinned
     uint8_t* devStage = nullptr;
@@ -968,6 +979,12 @@ int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name)
         if (hipMemcpy(&v, ctx->scratch, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
         return v;
     }
+    if (k == "host.gather_us") return ctx->hostGatherUs;          // the gather thread copying the caller's inputs into pinned slots
+    if (k == "host.scatter_us") return ctx->hostScatterUs;        // the finalizer thread copying outputs to the caller's buffers
+    if (k == "host.wait_slot_us") return ctx->hostWaitSlotUs;     // the gather thread waiting for a free slot (the pipeline behind it is the limit)
+    if (k == "host.wait_download_us") return ctx->hostWaitDownloadUs;  // the finalizer waiting for a chunk's download (the device side / the gather is the limit)
+    if (k == "host.chunks") return ctx->hostChunks;
+    if (k == "host.total_us") return ctx->hostTotalUs;
     if (k == "decompress.choice") {  // which decoder auto mode ran last: 0 rings, 3 two passes; -1: no probe ran
         if (!ctx->lastLz4dAuto || ctx->scratch == nullptr) return -1;
         if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
@@ -1350,7 +1367,9 @@ void destroy_host_path(achip_ctx* ctx)
 {
     delete ctx->pool;
     ctx->pool = nullptr;
-    for (int s = 0; s < 2; s++) {
+    delete ctx->poolOut;
+    ctx->poolOut = nullptr;
+    for (int s = 0; s < achip_ctx::kHostSlots; s++) {
         if (ctx->slotHost[s]) (void)hipHostFree(ctx->slotHost[s]);
         if (ctx->slotDev[s]) (void)hipFree(ctx->slotDev[s]);
         if (ctx->evH2D[s]) (void)hipEventDestroy(ctx->evH2D[s]);
@@ -1361,47 +1380,60 @@ void destroy_host_path(achip_ctx* ctx)
     if (ctx->copyOut) (void)hipStreamDestroy(ctx->copyOut);
 }
 
-int32_t ensure_host_path(achip_ctx* ctx, int64_t slotBytes)
+// `slots` staging slots of at least `slotBytes` each (pinned host + device); the copy streams, events and copy threads on first use
+int32_t ensure_host_path(achip_ctx* ctx, int64_t slotBytes, int slots)
 {
     HIP_TRY(hipSetDevice(ctx->device));
     if (!ctx->copyIn) {
         HIP_TRY(hipStreamCreateWithFlags(&ctx->copyIn, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&ctx->copyOut, hipStreamNonBlocking));
-        for (int s = 0; s < 2; s++) {
+        for (int s = 0; s < achip_ctx::kHostSlots; s++) {
             HIP_TRY(hipEventCreateWithFlags(&ctx->evH2D[s], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&ctx->evK[s], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&ctx->evD2H[s], hipEventDisableTiming));
         }
     }
     if (!ctx->pool) {
+        // gather and scatter have a pool each (they run side by side): host.copy_threads threads each, by default a sixteenth of the host's
+        // hardware threads, 2 .. 8 (the calling thread / the finalizer thread is one of each pool's copiers)
         int t = ctx->hostCopyThreads;
-        if (t == 0) t = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
-        ctx->pool = new CopyPool(t - 1);  // the calling thread is one of the copiers
+        if (t == 0) t = (int)std::min<unsigned>(8u, std::max(2u, std::thread::hardware_concurrency() / 16));
+        ctx->pool = new CopyPool(t - 1);
+        ctx->poolOut = new CopyPool(t - 1);
     }
     if (slotBytes > ctx->slotBytes) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->copyIn));
         HIP_TRY(hipStreamSynchronize(ctx->copyOut));
-        for (int s = 0; s < 2; s++) {
+        for (int s = 0; s < achip_ctx::kHostSlots; s++) {
             if (ctx->slotHost[s]) { HIP_TRY(hipHostFree(ctx->slotHost[s])); ctx->slotHost[s] = nullptr; }
             if (ctx->slotDev[s]) { HIP_TRY(hipFree(ctx->slotDev[s])); ctx->slotDev[s] = nullptr; }
         }
         ctx->slotBytes = 0;
+        ctx->slotCount = 0;
         const int64_t want = std::max<int64_t>(slotBytes, 1 << 20);
-        for (int s = 0; s < 2; s++) {
-            HIP_TRY(hipHostMalloc((void**)&ctx->slotHost[s], (size_t)want, hipHostMallocDefault));
-            HIP_TRY(hipMalloc((void**)&ctx->slotDev[s], (size_t)want));
-        }
+        HIP_TRY(hipHostMalloc((void**)&ctx->slotHost[0], (size_t)want, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void**)&ctx->slotDev[0], (size_t)want));
         ctx->slotBytes = want;
+        ctx->slotCount = 1;
+    }
+    while (ctx->slotCount < slots) {
+        const int s = ctx->slotCount;
+        HIP_TRY(hipHostMalloc((void**)&ctx->slotHost[s], (size_t)ctx->slotBytes, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void**)&ctx->slotDev[s], (size_t)ctx->slotBytes));
+        ctx->slotCount = s + 1;
     }
     return 0;
 }
 
+// A chunk's slot: [inputs | srcOff dstOff srcLen dstCap | pad | errOffset outLen status | pad | outputs] -- ONE upload (inputs + what the kernels
+// read) and ONE download (what they wrote + the outputs) per chunk.
 struct HostChunk {
     int64_t first = 0, count = 0;     // range of the processing order
     int32_t op = 0;
-    int64_t srcBytes = 0, dstBytes = 0, metaOff = 0, metaEnd = 0;
-    int64_t oSrcOff = 0, oDstOff = 0, oErr = 0, oSrcLen = 0, oDstCap = 0, oOutLen = 0, oStatus = 0;
+    int64_t srcBytes = 0, dstBytes = 0;
+    int64_t oSrcOff = 0, oDstOff = 0, oSrcLen = 0, oDstCap = 0, inEnd = 0;  // uploaded: [0, inEnd)
+    int64_t oErr = 0, oOutLen = 0, oStatus = 0, oDst = 0, end = 0;          // downloaded: [oErr, end)
     int32_t maxLen = 0;
 };
 
@@ -1414,23 +1446,26 @@ int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t
     auto item = [&](int64_t j) -> int64_t { return order ? order[j] : j; };
     // ---- cut into chunks: homogeneous op, about hostChunkBytes of staging each, at least one item ----
     std::vector<HostChunk> chunks;
-    std::vector<int64_t> sOff(n), dOff(n);  // per processed item: offsets inside its chunk's src / dst regions
+    std::vector<int64_t> sOff(n), dOff(n);  // per processed item: offsets inside its chunk's input / output regions
     int64_t maxSlot = 0;
     {
         HostChunk c;
         bool open = false;
         auto close = [&]() {
-            c.metaOff = (c.srcBytes + c.dstBytes + 63) & ~63LL;
-            int64_t m = c.metaOff;
+            int64_t m = (c.srcBytes + 15) & ~15LL;
             c.oSrcOff = m; m += c.count * 8;
             c.oDstOff = m; m += c.count * 8;
-            c.oErr = m; m += c.count * 8;
             c.oSrcLen = m; m += c.count * 4;
             c.oDstCap = m; m += c.count * 4;
+            c.inEnd = m;
+            m = (m + 63) & ~63LL;
+            c.oErr = m; m += c.count * 8;
             c.oOutLen = m; m += c.count * 4;
             c.oStatus = m; m += c.count * 4;
-            c.metaEnd = m;
-            maxSlot = std::max(maxSlot, m + 64);
+            m = (m + 63) & ~63LL;
+            c.oDst = m;
+            c.end = m + c.dstBytes;
+            maxSlot = std::max(maxSlot, c.end + 64);
             chunks.push_back(c);
             open = false;
         };
@@ -1455,12 +1490,16 @@ int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t
         }
         if (open) close();
     }
-    int32_t r = ensure_host_path(ctx, maxSlot);
+    const int nSlots = (int)std::min<size_t>(chunks.size(), (size_t)achip_ctx::kHostSlots);
+    int32_t r = ensure_host_path(ctx, maxSlot, nSlots);
     if (r < 0) return r;
-    CopyPool& pool = *ctx->pool;
 
     // copy tasks over a chunk's items: consecutive items are grouped up to kCopyGrain bytes, one task per group
-    auto for_items = [&](const HostChunk& c, bool outputs, const std::function<void(int64_t)>& body) {
+    auto for_items = [&](CopyPool& pool, const HostChunk& c, bool outputs, const std::function<void(int64_t)>& body) {
+        if (c.count == 1) {
+            body(c.first);
+            return;
+        }
         std::vector<int64_t> cut;
         cut.push_back(c.first);
         int64_t acc = 0;
@@ -1478,70 +1517,169 @@ int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t
         });
     };
 
-    auto finalize = [&](const HostChunk& c, int slot) -> int32_t {
-        HIP_TRY(hipEventSynchronize(ctx->evD2H[slot]));
-        const uint8_t* h = ctx->slotHost[slot];
-        for (int64_t j = c.first; j < c.first + c.count; j++) {
-            const int64_t i = item(j), k = j - c.first;
-            outLen[i] = ((const int32_t*)(h + c.oOutLen))[k];
-            status[i] = ((const int32_t*)(h + c.oStatus))[k];
-            if (errOffset) errOffset[i] = ((const int64_t*)(h + c.oErr))[k];
-        }
-        for_items(c, true, [&](int64_t j) {
-            const int64_t i = item(j);
-            if (status[i] == 0 && outLen[i] > 0) {
-                memcpy((uint8_t*)dstBase + dstOff[i], h + c.srcBytes + dOff[j], (size_t)outLen[i]);
-            }
-        });
-        return 0;
-    };
-
-    const int savedHint = ctx->maxSrcLenHint;
-    for (size_t ci = 0; ci < chunks.size(); ci++) {
-        const HostChunk& c = chunks[ci];
-        const int slot = (int)(ci & 1);
-        uint8_t* h = ctx->slotHost[slot];
-        uint8_t* d = ctx->slotDev[slot];
-        // (the slot's previous chunk, ci - 2, was finalized at the end of iteration ci - 1: its buffers are free)
-        for_items(c, false, [&](int64_t j) {
+    auto gather = [&](const HostChunk& c, uint8_t* h) {
+        for_items(*ctx->pool, c, false, [&](int64_t j) {
             const int64_t i = item(j);
             if (srcLen[i] > 0) memcpy(h + sOff[j], (const uint8_t*)srcBase + srcOff[i], (size_t)srcLen[i]);
         });
         for (int64_t j = c.first; j < c.first + c.count; j++) {
             const int64_t i = item(j), k = j - c.first;
             ((int64_t*)(h + c.oSrcOff))[k] = sOff[j];
-            ((int64_t*)(h + c.oDstOff))[k] = c.srcBytes + dOff[j];
+            ((int64_t*)(h + c.oDstOff))[k] = c.oDst + dOff[j];
             ((int32_t*)(h + c.oSrcLen))[k] = srcLen[i];
             ((int32_t*)(h + c.oDstCap))[k] = dstCap[i];
         }
-        if (c.srcBytes > 0) HIP_TRY(hipMemcpyAsync(d, h, (size_t)c.srcBytes, hipMemcpyHostToDevice, ctx->copyIn));
-        HIP_TRY(hipMemcpyAsync(d + c.metaOff, h + c.metaOff, (size_t)(c.oOutLen - c.metaOff), hipMemcpyHostToDevice, ctx->copyIn));
-        HIP_TRY(hipEventRecord(ctx->evH2D[slot], ctx->copyIn));
-        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->evH2D[slot], 0));
-        achip::BatchArgs a = make_args(d, (const int64_t*)(d + c.oSrcOff), (const int32_t*)(d + c.oSrcLen), d, (const int64_t*)(d + c.oDstOff),
-                                       (const int32_t*)(d + c.oDstCap), (int32_t*)(d + c.oOutLen), (int32_t*)(d + c.oStatus), (int64_t*)(d + c.oErr), (int32_t)c.count);
+    };
+    auto scatter = [&](const HostChunk& c, const uint8_t* h) {
+        for (int64_t j = c.first; j < c.first + c.count; j++) {
+            const int64_t i = item(j), k = j - c.first;
+            outLen[i] = ((const int32_t*)(h + c.oOutLen))[k];
+            status[i] = ((const int32_t*)(h + c.oStatus))[k];
+            if (errOffset) errOffset[i] = ((const int64_t*)(h + c.oErr))[k];
+        }
+        for_items(*ctx->poolOut, c, true, [&](int64_t j) {
+            const int64_t i = item(j);
+            if (status[i] == 0 && outLen[i] > 0) memcpy((uint8_t*)dstBase + dstOff[i], h + c.oDst + dOff[j], (size_t)outLen[i]);
+        });
+    };
+    auto batch_args = [&](const HostChunk& c, uint8_t* d) {
+        return make_args(d, (const int64_t*)(d + c.oSrcOff), (const int32_t*)(d + c.oSrcLen), d, (const int64_t*)(d + c.oDstOff), (const int32_t*)(d + c.oDstCap),
+                         (int32_t*)(d + c.oOutLen), (int32_t*)(d + c.oStatus), (int64_t*)(d + c.oErr), (int32_t)c.count);
+    };
+    const int savedHint = ctx->maxSrcLenHint;
+
+    if (chunks.size() == 1) {
+        // one chunk (a single block -- what Compressor.compress(MemorySegment, MemorySegment) hands over -- or a small batch): nothing to overlap,
+        // everything in order on the context stream: upload, kernels, download, one wait
+        const HostChunk& c = chunks[0];
+        uint8_t* h = ctx->slotHost[0];
+        uint8_t* d = ctx->slotDev[0];
+        gather(c, h);
+        HIP_TRY(hipMemcpyAsync(d, h, (size_t)c.inEnd, hipMemcpyHostToDevice, ctx->stream));
         ctx->maxSrcLenHint = std::max(c.maxLen, 1);
-        r = launch_op(c.op, ctx, a);
+        r = launch_op(c.op, ctx, batch_args(c, d));
         ctx->maxSrcLenHint = savedHint;
         if (r < 0) {
-            (void)hipStreamSynchronize(ctx->copyIn);
             (void)hipStreamSynchronize(ctx->stream);
-            (void)hipStreamSynchronize(ctx->copyOut);
             return r;
         }
+        HIP_TRY(hipMemcpyAsync(h + c.oErr, d + c.oErr, (size_t)(c.end - c.oErr), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        scatter(c, h);
+        return 0;
+    }
+
+    // ---- several chunks: chunk c uses slot c % nSlots.  This thread gathers chunk after chunk into pinned memory and enqueues upload (copyIn),
+    // kernels (the context stream: they share the context's scratch) and download (copyOut), events ordering the three; a finalizer thread waits
+    // for each download and scatters the outputs to the caller's buffers with a copy pool of its own -- so that gather, upload, kernels, download
+    // and scatter of up to nSlots chunks are in flight side by side. ----
+    using clk = std::chrono::steady_clock;
+    auto us_since = [](clk::time_point t0) { return (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - t0).count(); };
+    const clk::time_point tStart = clk::now();
+    int64_t gatherUs = 0, scatterUs = 0, waitSlotUs = 0, waitDownloadUs = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int64_t enqueued = 0, finalized = 0;  // chunk counts
+    bool aborted = false;
+    int32_t finalizerStatus = 0;
+    std::string finalizerMessage;
+    std::thread finalizer([&] {
+        if (hipSetDevice(ctx->device) != hipSuccess) {
+            std::lock_guard<std::mutex> g(m);
+            finalizerStatus = ACHIP_STATUS(ACHIP_CLASS_DEVICE, ACHIP_D_HIP_ERROR);
+            finalizerMessage = "hipSetDevice failed in the finalizer thread";
+            finalized = (int64_t)chunks.size();
+            cv.notify_all();
+            return;
+        }
+        for (int64_t ci = 0; ci < (int64_t)chunks.size(); ci++) {
+            {
+                std::unique_lock<std::mutex> g(m);
+                cv.wait(g, [&] { return enqueued > ci || aborted; });
+                if (enqueued <= ci) return;
+            }
+            const int slot = (int)(ci % nSlots);
+            clk::time_point t0 = clk::now();
+            const hipError_t e = hipEventSynchronize(ctx->evD2H[slot]);
+            waitDownloadUs += us_since(t0);
+            if (e != hipSuccess) {
+                std::lock_guard<std::mutex> g(m);
+                finalizerStatus = ACHIP_STATUS(ACHIP_CLASS_DEVICE, ACHIP_D_HIP_ERROR);
+                finalizerMessage = std::string("hipEventSynchronize: ") + hipGetErrorString(e);
+            }
+            else {
+                t0 = clk::now();
+                scatter(chunks[(size_t)ci], ctx->slotHost[slot]);
+                scatterUs += us_since(t0);
+            }
+            {
+                std::lock_guard<std::mutex> g(m);
+                finalized = ci + 1;
+            }
+            cv.notify_all();
+        }
+    });
+    auto enqueue = [&](const HostChunk& c, int slot) -> int32_t {
+        uint8_t* h = ctx->slotHost[slot];
+        uint8_t* d = ctx->slotDev[slot];
+        HIP_TRY(hipMemcpyAsync(d, h, (size_t)c.inEnd, hipMemcpyHostToDevice, ctx->copyIn));
+        HIP_TRY(hipEventRecord(ctx->evH2D[slot], ctx->copyIn));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->evH2D[slot], 0));
+        ctx->maxSrcLenHint = std::max(c.maxLen, 1);
+        const int32_t rr = launch_op(c.op, ctx, batch_args(c, d));
+        ctx->maxSrcLenHint = savedHint;
+        if (rr < 0) return rr;
         HIP_TRY(hipEventRecord(ctx->evK[slot], ctx->stream));
         HIP_TRY(hipStreamWaitEvent(ctx->copyOut, ctx->evK[slot], 0));
-        if (c.dstBytes > 0) HIP_TRY(hipMemcpyAsync(h + c.srcBytes, d + c.srcBytes, (size_t)c.dstBytes, hipMemcpyDeviceToHost, ctx->copyOut));
-        HIP_TRY(hipMemcpyAsync(h + c.oErr, d + c.oErr, (size_t)(c.count * 8), hipMemcpyDeviceToHost, ctx->copyOut));
-        HIP_TRY(hipMemcpyAsync(h + c.oOutLen, d + c.oOutLen, (size_t)(c.metaEnd - c.oOutLen), hipMemcpyDeviceToHost, ctx->copyOut));
+        HIP_TRY(hipMemcpyAsync(h + c.oErr, d + c.oErr, (size_t)(c.end - c.oErr), hipMemcpyDeviceToHost, ctx->copyOut));
         HIP_TRY(hipEventRecord(ctx->evD2H[slot], ctx->copyOut));
-        if (ci >= 1) {
-            r = finalize(chunks[ci - 1], (int)((ci - 1) & 1));  // overlaps with this chunk's upload / kernels / download
-            if (r < 0) return r;
+        return 0;
+    };
+    std::string message;
+    for (int64_t ci = 0; ci < (int64_t)chunks.size() && r >= 0; ci++) {
+        const int slot = (int)(ci % nSlots);
+        clk::time_point t0 = clk::now();
+        {
+            std::unique_lock<std::mutex> g(m);
+            cv.wait(g, [&] { return finalized >= ci - nSlots + 1; });  // the slot's previous chunk has left it
+            if (finalizerStatus < 0) break;
         }
+        waitSlotUs += us_since(t0);
+        t0 = clk::now();
+        gather(chunks[(size_t)ci], ctx->slotHost[slot]);
+        gatherUs += us_since(t0);
+        r = enqueue(chunks[(size_t)ci], slot);
+        if (r < 0) message = g_lastError;
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (r < 0) aborted = true;
+            else enqueued = ci + 1;
+        }
+        cv.notify_all();
     }
-    r = finalize(chunks.back(), (int)((chunks.size() - 1) & 1));
-    if (r < 0) return r;
+    {
+        std::lock_guard<std::mutex> g(m);
+        aborted = true;  // (nothing more will be enqueued: the finalizer leaves after the last enqueued chunk)
+    }
+    cv.notify_all();
+    finalizer.join();
+    ctx->hostGatherUs = gatherUs;
+    ctx->hostScatterUs = scatterUs;
+    ctx->hostWaitSlotUs = waitSlotUs;
+    ctx->hostWaitDownloadUs = waitDownloadUs;
+    ctx->hostChunks = (int64_t)chunks.size();
+    ctx->hostTotalUs = us_since(tStart);
+    if (r < 0 || finalizerStatus < 0) {
+        (void)hipStreamSynchronize(ctx->copyIn);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->copyOut);
+        if (r < 0) {
+            g_lastError = message;
+            return r;
+        }
+        g_lastError = finalizerMessage;
+        return finalizerStatus;
+    }
     // the context stream is idle again for the caller (everything it launched was awaited through evK -> evD2H)
     return 0;
 }
@@ -1649,6 +1787,60 @@ int32_t achip_zstd_compress(achip_ctx* ctx, const void* src, void* dst, int32_t 
 int32_t achip_zstd_decompress(achip_ctx* ctx, const void* src, void* dst, int32_t srcLen, int32_t dstCap, int64_t* errOffset)
 {
     return single_block(ACHIP_OP_ZSTD_DECOMPRESS, ctx, src, dst, srcLen, dstCap, errOffset);
+}
+
+// ---- one process, several contexts (normally one per device), one host thread each -------------------------------------------
+// The native twin of java/.../HipBatchCodec.run: the batch is cut into nCtx contiguous slices balanced by srcLen + dstCap (the rule of
+// achip_partition_blocks), slice d goes through achip_batch_host / achip_mixed_batch_host on ctxs[d] in a thread of its own.  Units are
+// independent (M/zstd/ZstdFrameDecompressor.java:151, M/zstd/ZstdFrameCompressor.java:162): no exchange between the slices.
+int32_t achip_multi_batch_host(achip_ctx* const* ctxs, int32_t nCtx, int32_t codecOp, const int32_t* codecOps, const void* srcBase, const int64_t* srcOff,
+                               const int32_t* srcLen, void* dstBase, const int64_t* dstOff, const int32_t* dstCap, int32_t* outLen, int32_t* status,
+                               int64_t* errOffset, int32_t nBlocks, int32_t* sliceStarts)
+{
+    if (!ctxs || nCtx <= 0) return bad_argument("no contexts");
+    if (nCtx > 64) return bad_argument("more than 64 contexts");
+    for (int32_t d = 0; d < nCtx; d++) {
+        if (!ctxs[d]) return bad_argument("ctx is null");
+        for (int32_t e = 0; e < d; e++) {
+            if (ctxs[e] == ctxs[d]) return bad_argument("a context listed twice (a context serves one thread at a time)");
+        }
+    }
+    if (nBlocks < 0) return bad_argument("nBlocks < 0");
+    if (!codecOps && (codecOp < 0 || codecOp >= kNumOps)) return bad_argument("unknown codecOp");
+    std::vector<int32_t> starts((size_t)nCtx + 1, 0);
+    if (nBlocks > 0) {
+        if (!srcOff || !srcLen || !dstOff || !dstCap || !outLen || !status) return bad_argument("null metadata array");
+        std::vector<int64_t> weight((size_t)nBlocks);
+        for (int32_t i = 0; i < nBlocks; i++) weight[(size_t)i] = (int64_t)std::max(srcLen[i], 0) + std::max(dstCap[i], 0);
+        const int32_t r = achip_partition_blocks(weight.data(), nBlocks, nCtx, starts.data());
+        if (r < 0) return r;
+    }
+    if (sliceStarts) {
+        for (int32_t d = 0; d <= nCtx; d++) sliceStarts[d] = starts[(size_t)d];
+    }
+    std::vector<int32_t> rc((size_t)nCtx, 0);
+    std::vector<std::string> messages((size_t)nCtx);
+    auto slice = [&](int32_t d) {
+        const int32_t first = starts[(size_t)d], count = starts[(size_t)d + 1] - first;
+        if (count == 0) return;
+        int64_t* eo = errOffset ? errOffset + first : nullptr;
+        rc[(size_t)d] = codecOps ? achip_mixed_batch_host(ctxs[d], codecOps + first, srcBase, srcOff + first, srcLen + first, dstBase, dstOff + first, dstCap + first,
+                                                          outLen + first, status + first, eo, count)
+                                 : achip_batch_host(codecOp, ctxs[d], srcBase, srcOff + first, srcLen + first, dstBase, dstOff + first, dstCap + first, outLen + first,
+                                                    status + first, eo, count);
+        if (rc[(size_t)d] < 0) messages[(size_t)d] = g_lastError;  // (thread-local: carried to the caller's thread below)
+    };
+    std::vector<std::thread> workers;
+    for (int32_t d = 1; d < nCtx; d++) workers.emplace_back(slice, d);
+    slice(0);
+    for (auto& w : workers) w.join();
+    for (int32_t d = 0; d < nCtx; d++) {
+        if (rc[(size_t)d] < 0) {
+            g_lastError = "context " + std::to_string(d) + ": " + messages[(size_t)d];
+            return rc[(size_t)d];
+        }
+    }
+    return 0;
 }
 
 // ---- multi-GPU partition (host arithmetic) --------------------------------

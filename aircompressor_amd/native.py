@@ -88,6 +88,7 @@ SIGNATURES = {
     "achip_batch_host": (_i32, [_i32] + _BATCH),
     "achip_mixed_batch": (_i32, [_vp, _vp] + _BATCH[1:]),
     "achip_mixed_batch_host": (_i32, [_vp, _vp] + _BATCH[1:]),
+    "achip_multi_batch_host": (_i32, [_vp, _i32, _i32, _vp] + _BATCH[1:] + [_vp]),
     "achip_partition_blocks": (_i32, [_vp, _i32, _i32, _vp]),
 }
 

@@ -54,6 +54,10 @@ def parse_args():
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time of the headline's cpu_baseline leg")
     p.add_argument("--cpu-leg-seconds", type=float, default=0.6, help="CPU time of each extra entry's CPU leg (per direction)")
     p.add_argument("--no-sweep", action="store_true")
+    p.add_argument("--no-host-facing", action="store_true", help="skip the end_to_end (host buffers, PCIe-inclusive) and single_block_us measurements")
+    p.add_argument("--no-legs", action="store_true", help="skip the per-rank legs (Snappy, Zstd configs[3], mixed corpus batch configs[4]) that run at any N")
+    p.add_argument("--zstd-frames", type=int, default=65536, help="Zstd frames of 128 KiB per GPU in the configs[3] leg (a multiple of 1024)")
+    p.add_argument("--mixed-copies", type=int, default=4, help="copies of the 668-line corpus job in the configs[4] leg")
     p.add_argument("--section", default="all", choices=["all", "zstd", "zstdstream", "xxhash", "lz4frame", "sweep"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-exec", type=int, default=-1, help="zstd pipeline execute stage: 2 = chosen per item (default), 1 = wavefront per item through the record executor, 0 = LDS rings")
     p.add_argument("--snappyframed-variant", type=int, default=-1, help="x-snappy-framed reader: 3 = ring or two-pass decoder by a probe (default), 1 = chunks through the ring decoders, 2 = through the two-pass decoder, 0 = a wavefront per stream")
@@ -171,6 +175,274 @@ def gen_wordmix(torch, dev, n_blocks, block_size, seed):
     return torch.cat(out)[:total].contiguous()
 
 
+# ---- the legs every rank runs (any N): the rest of BASELINE's metric -- Snappy, Zstd configs[3], the mixed corpus batch configs[4] ----------
+
+def reduce_leg(dist, world, rank, local_bytes, local_seconds, extra=None):
+    """Whole-job GiB/s of one leg = the bytes of all ranks / the slowest rank's time (no data-path collective: the only traffic is this gather)."""
+    mine = {"rank": rank, "bytes": int(local_bytes), "seconds": round(float(local_seconds), 6), "GiBps": round(local_bytes / max(local_seconds, 1e-12) / 2**30, 2)}
+    if extra:
+        mine.update(extra)
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    total = sum(p["bytes"] for p in per_rank)
+    slowest = max(p["seconds"] for p in per_rank)
+    return {"GiBps": round(total / max(slowest, 1e-12) / 2**30, 2), "per_rank": per_rank}
+
+
+def mixed_job(copies):
+    """BASELINE configs[4] as a list of work items (pure host arithmetic, the same on every rank): every file of the reference's corpus whole and
+    in its 64 KiB (LZ4 / Snappy) / 128 KiB (Zstd) cuts -- the 668 lines of tests/golden/oracle_manifest.tsv, the committed SHA-256 of what the
+    Java-equivalent encoders write -- each as one COMPRESS item and one DECOMPRESS item, `copies` times, shuffled with a fixed seed.
+    Returns (rows, items, weights): items[k] = (row index, direction 0 = compress / 1 = decompress); weights = srcLen + dstCap per item."""
+    import aircompressor_amd as A
+    lib = A.load_library()
+    gold = os.path.join(ROOT, "tests", "golden")
+    rows = []
+    for line in open(os.path.join(gold, "oracle_manifest.tsv")):
+        f = line.rstrip("\n").split("\t")
+        if len(f) == 6:
+            rows.append((f[0], int(f[1]), int(f[2]), f[3], int(f[4]), f[5]))
+    bound = {"lz4": lib.achip_lz4_max_compressed_length, "snappy": lib.achip_snappy_max_compressed_length, "zstd": lib.achip_zstd_max_compressed_length}
+    items, weights = [], []
+    for _ in range(copies):
+        for r, (_, _, n, codec, clen, _) in enumerate(rows):
+            items.append((r, 0))
+            weights.append(n + bound[codec](n))
+            if n > 0:
+                items.append((r, 1))
+                weights.append(clen + n)
+    order = np.random.default_rng(20260925).permutation(len(items))
+    return rows, [items[i] for i in order], np.asarray([weights[i] for i in order], dtype=np.int64)
+
+
+MIXED_OPS = {"lz4": (1, 0), "snappy": (3, 2), "zstd": (5, 4)}  # codec -> (compress op, decompress op)
+
+
+def corpus_files():
+    import lzma
+    gold = os.path.join(ROOT, "tests", "golden")
+    blob = lzma.decompress(open(os.path.join(gold, "corpus_full.bin.xz"), "rb").read())
+    return {e["file"]: blob[e["offset"]:e["offset"] + e["length"]] for e in json.load(open(os.path.join(gold, "corpus_full.json")))}
+
+
+def mixed_leg(torch, A, codec, dev, args, rank, world, dist):
+    """BASELINE configs[4]: the shuffled 3-codec x 2-direction corpus batch cut over the ranks by achip_partition_blocks (weights = bytes in +
+    capacity out), every rank's slice ONE achip_mixed_batch call (bucketed by codec inside the library), device-resident, timed; then every
+    item of every rank checked: a compress item's stream must hash to the manifest's line (= what the Java-equivalent encoder writes), a
+    decompress item must restore the plaintext.  mixed_ok only if every item on every rank is byte-exact."""
+    import hashlib
+    from aircompressor_amd.sharding import shard_for_rank
+    lib = codec.lib
+    rows, items, weights = mixed_job(args.mixed_copies)
+    lo, hi = shard_for_rank(weights, world, rank)
+    mine = items[lo:hi]
+    files = corpus_files()
+    bound = {"lz4": lib.achip_lz4_max_compressed_length, "snappy": lib.achip_snappy_max_compressed_length, "zstd": lib.achip_zstd_max_compressed_length}
+    plain_of = lambda r: files[rows[r][0]][rows[r][1]:rows[r][1] + rows[r][2]]  # noqa: E731
+    i64 = dict(dtype=torch.int64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+
+    def run(ops, blobs, caps, iters):
+        """one achip_mixed_batch call over host blobs (uploaded first); returns (outputs, statuses, seconds per call)"""
+        n = len(blobs)
+        lens = np.asarray([len(b) for b in blobs], dtype=np.int64)
+        pad = (lens + 15) // 16 * 16
+        s_off = np.cumsum(pad) - pad
+        buf = np.zeros(int(pad.sum()) + 16, dtype=np.uint8)
+        for b, o_ in zip(blobs, s_off):
+            buf[o_:o_ + len(b)] = np.frombuffer(b, dtype=np.uint8)
+        caps = np.asarray(caps, dtype=np.int64)
+        cpad = (caps + 15) // 16 * 16
+        d_off = np.cumsum(cpad) - cpad
+        d_src = torch.from_numpy(buf).to(dev)
+        d_dst = torch.zeros(int(cpad.sum()) + 64, dtype=torch.uint8, device=dev)
+        a_so, a_sl = torch.from_numpy(s_off).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev)
+        a_do, a_dc = torch.from_numpy(d_off).to(dev), torch.from_numpy(caps.astype(np.int32)).to(dev)
+        o_len, st, eo = torch.zeros(n, **i32), torch.zeros(n, **i32), torch.zeros(n, **i64)
+        torch.cuda.synchronize()
+        launch = lambda: codec.launch_mixed(ops, d_src, a_so, a_sl, d_dst, a_do, a_dc, o_len, st, eo, n)  # noqa: E731
+        launch()
+        codec.synchronize()
+        seconds = 0.0
+        if iters:
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                launch()
+            codec.synchronize()
+            seconds = (time.perf_counter() - t0) / iters
+        out = d_dst.cpu().numpy()
+        o_len = o_len.cpu().numpy()
+        return [out[o_:o_ + max(int(k), 0)].tobytes() for o_, k in zip(d_off, o_len)], st.cpu().numpy(), seconds
+
+    # untimed setup: the compressed inputs of this rank's decompress items come from the product's own encoders (the oracle is never used to make
+    # inputs), each checked against the manifest's SHA-256 before it is used
+    need = sorted({r for r, d in mine if d == 1})
+    streams = {}
+    if need:
+        outs, st, _ = run([MIXED_OPS[rows[r][3]][0] for r in need], [plain_of(r) for r in need], [bound[rows[r][3]](rows[r][2]) for r in need], 0)
+        for r, c, s_ in zip(need, outs, st):
+            assert s_ == 0 and hashlib.sha256(c).hexdigest() == rows[r][5], "setup: the GPU encoder's stream differs from the manifest (%s)" % (rows[r],)
+            streams[r] = c
+    ops = [MIXED_OPS[rows[r][3]][d] for r, d in mine]
+    blobs = [plain_of(r) if d == 0 else streams[r] for r, d in mine]
+    caps = [bound[rows[r][3]](rows[r][2]) if d == 0 else max(rows[r][2], 1) for r, d in mine]
+    outs, st, seconds = run(ops, blobs, caps, 3) if mine else ([], np.zeros(0, dtype=np.int32), 0.0)
+    bad = 0
+    for (r, d), out, s_ in zip(mine, outs, st):
+        good = s_ == 0 and ((hashlib.sha256(out).hexdigest() == rows[r][5] and len(out) == rows[r][4]) if d == 0 else out == plain_of(r))
+        bad += 0 if good else 1
+    plain_bytes = sum(rows[r][2] for r, _ in mine)  # the decompressed-side bytes of both directions (the metric's numerator convention)
+    leg = reduce_leg(dist, world, rank, plain_bytes, seconds, {"items": len(mine), "slice": [lo, hi], "mismatches": bad, "codec_ops": len(set(ops))})
+    leg.update({"mixed_ok": all(p["mismatches"] == 0 for p in leg["per_rank"]) and sum(p["items"] for p in leg["per_rank"]) == len(items),
+                "items": len(items), "manifest_lines": len(rows), "copies": args.mixed_copies,
+                "what": "BASELINE configs[4]: every corpus file whole + every 64 / 128 KiB cut x LZ4 / Snappy / Zstd x compress / decompress, shuffled, cut over the "
+                        "ranks by achip_partition_blocks, one achip_mixed_batch call per rank; compress items checked against tests/golden/oracle_manifest.tsv's "
+                        "SHA-256 (the Java-equivalent encoders' streams), decompress items against the plaintext"})
+    return leg
+
+
+def zstd_libzstd_batch(torch, dev, args, data_kind, pool_n, reps, seed):
+    """65536 (pool_n x reps) Zstd level-3 frames of 128 KiB made on the host by libzstd (pyarrow): the pool's frames packed at 16-byte aligned
+    starts and tiled, every copy at its own address."""
+    import pyarrow as pa
+    fs = 131072
+    zc = pa.Codec("zstd", compression_level=3)
+    plain = gen_data(torch, dev, data_kind, pool_n, fs, args.ratio, seed)
+    host = plain.cpu().numpy()
+    frames = [zc.compress(host[i * fs:(i + 1) * fs].tobytes(), asbytes=True) for i in range(pool_n)]
+    lens = np.array([len(f) for f in frames], dtype=np.int64)
+    pad = (lens + 15) // 16 * 16
+    offs = np.cumsum(pad) - pad
+    pack = np.zeros(int(pad.sum()), dtype=np.uint8)
+    for f, o_ in zip(frames, offs):
+        pack[o_:o_ + len(f)] = np.frombuffer(f, dtype=np.uint8)
+    n = pool_n * reps
+    i64 = dict(dtype=torch.int64, device=dev)
+    d_pack = torch.from_numpy(pack).to(dev).repeat(reps)
+    rep_idx = torch.arange(reps, **i64).repeat_interleave(pool_n)
+    src_off = torch.from_numpy(offs).to(dev).repeat(reps) + rep_idx * int(pad.sum())
+    src_len = torch.from_numpy(lens.astype(np.int32)).to(dev).repeat(reps)
+    return {"plain": plain, "host": host, "pack": pack, "offs": offs, "lens": lens, "d_pack": d_pack, "src_off": src_off, "src_len": src_len, "n": n, "fs": fs,
+            "cbytes": int(lens.sum()) * reps, "encoder": "libzstd level 3 via pyarrow %s" % pa.__version__}
+
+
+def rank_legs(torch, A, codec, dev, args, rank, world, dist, n_local):
+    """What `--gpus N` reports besides the LZ4 headline, on EVERY rank: Snappy decompress on the headline's batch shape, Zstd level-3 decompress of
+    65536 x 128 KiB frames per GPU (BASELINE configs[3]; libzstd's frames and the GPU encoder's = the Java encoder's, corpus-tiled and fragments) and
+    the mixed corpus batch (configs[4]).  Every leg: warm launch + byte-exact check, barrier, timed launches, the bytes of all ranks over the slowest
+    rank's time.  Each unit is self-contained (M/zstd/ZstdFrameDecompressor.java:151, M/zstd/ZstdFrameCompressor.java:162): ranks own disjoint frames."""
+    out = {}
+    bs = args.block_size
+    i64 = dict(dtype=torch.int64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+
+    def timed(launch, iters):
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            launch()
+        codec.synchronize()
+        return (time.perf_counter() - t0) / iters
+
+    # -- Snappy decompress, fragments, the headline's batch shape (compressed on the GPU by the product's encoder) --
+    n = n_local
+    plain = gen_data(torch, dev, "fragments", min(n, 4096), bs, args.ratio, 1301 + rank)
+    pool_n = plain.numel() // bs
+    max_c = codec.lib.achip_snappy_max_compressed_length(bs)
+    cstride = (max_c + 15) // 16 * 16
+    comp = torch.empty(pool_n * cstride + 64, dtype=torch.uint8, device=dev)
+    clen, st, eo = torch.zeros(pool_n, **i32), torch.zeros(pool_n, **i32), torch.zeros(pool_n, **i64)
+    # (the library launches on the context's stream: every argument stays alive in a named tensor and torch's stream is drained before each first launch)
+    p_off, p_len = torch.arange(pool_n, **i64) * bs, torch.full((pool_n,), bs, **i32)
+    c_off, c_cap = torch.arange(pool_n, **i64) * cstride, torch.full((pool_n,), max_c, **i32)
+    torch.cuda.synchronize()
+    codec.launch(A.OP_SNAPPY_COMPRESS, plain, p_off, p_len, comp, c_off, c_cap, clen, st, eo, pool_n)
+    codec.synchronize()
+    assert int((st != 0).sum()) == 0, "snappy leg: encode failed"
+    reps = n // pool_n
+    n = reps * pool_n
+    src = comp[:pool_n * cstride].repeat(reps)
+    src_off = (torch.arange(pool_n, **i64) * cstride).repeat(reps) + torch.arange(reps, **i64).repeat_interleave(pool_n) * (pool_n * cstride)
+    src_len = clen.repeat(reps)
+    dst = torch.empty(n * bs + 64, dtype=torch.uint8, device=dev)
+    dst_off, dst_cap = torch.arange(n, **i64) * bs, torch.full((n,), bs, **i32)
+    olen, st, eo = torch.zeros(n, **i32), torch.zeros(n, **i32), torch.zeros(n, **i64)
+    launch = lambda: codec.launch(A.OP_SNAPPY_DECOMPRESS, src, src_off, src_len, dst, dst_off, dst_cap, olen, st, eo, n)  # noqa: E731
+    torch.cuda.synchronize()
+    launch()
+    codec.synchronize()
+    assert int((st != 0).sum()) == 0 and bool((dst[:n * bs].view(reps, pool_n * bs) == plain.unsqueeze(0)).all()), "snappy leg: plaintext mismatch"
+    t = timed(launch, 5)
+    out["snappy"] = reduce_leg(dist, world, rank, n * bs, t, {"blocks": n, "ratio": round(pool_n * bs / int(clen.to(torch.int64).sum()), 3)})
+    del src, dst, comp, plain
+    torch.cuda.empty_cache()
+
+    # -- Zstd configs[3] --
+    try:
+        import pyarrow  # noqa: F401
+        have_pa = True
+    except ImportError:
+        have_pa = False
+    for kind in ("fragments", "corpus"):
+        suffix = "" if kind == "fragments" else "_corpus"
+        fs = 131072
+        if have_pa:
+            b = zstd_libzstd_batch(torch, dev, args, kind, 512, args.zstd_frames // 512, 4242 + rank)
+            n = b["n"]
+            dst = torch.empty(n * fs + 64, dtype=torch.uint8, device=dev)
+            dst_off, dst_cap = torch.arange(n, **i64) * fs, torch.full((n,), fs, **i32)
+            olen, st, eo = torch.zeros(n, **i32), torch.zeros(n, **i32), torch.zeros(n, **i64)
+            launch = lambda: codec.launch(A.OP_ZSTD_DECOMPRESS, b["d_pack"], b["src_off"], b["src_len"], dst, dst_off, dst_cap, olen, st, eo, n)  # noqa: E731
+            torch.cuda.synchronize()
+            launch()
+            codec.synchronize()
+            assert int((st != 0).sum()) == 0 and bool((dst[:n * fs].view(-1, 512 * fs) == b["plain"].unsqueeze(0)).all()), "zstd leg: plaintext mismatch"
+            t = timed(launch, 3)
+            out["zstd" + suffix] = reduce_leg(dist, world, rank, n * fs, t, {"frames": n, "ratio": round(n * fs / b["cbytes"], 3)})
+            out["zstd" + suffix]["encoder"] = b["encoder"]
+            plain = b["plain"]
+            del dst, b
+        else:
+            plain = gen_data(torch, dev, kind, 512, fs, args.ratio, 4242 + rank)
+        # frames of the GPU encoder (byte-identical to the Java encoder's, tests/test_gpu_corpus.py): encoded here, decoded, verified, timed
+        nz = 512 * max(1, args.zstd_frames // 1024)
+        zrep = nz // 512
+        max_c = codec.lib.achip_zstd_max_compressed_length(fs)
+        cstride = (max_c + 15) // 16 * 16
+        zplain = plain.repeat(zrep)
+        z_off, z_len = torch.arange(nz, **i64) * fs, torch.full((nz,), fs, **i32)
+        z_dst = torch.empty(nz * cstride + 64, dtype=torch.uint8, device=dev)
+        zc_off, zc_cap = torch.arange(nz, **i64) * cstride, torch.full((nz,), max_c, **i32)
+        zc_len, st, eo = torch.zeros(nz, **i32), torch.zeros(nz, **i32), torch.zeros(nz, **i64)
+        enc = lambda: codec.launch(A.OP_ZSTD_COMPRESS, zplain, z_off, z_len, z_dst, zc_off, zc_cap, zc_len, st, eo, nz)  # noqa: E731
+        torch.cuda.synchronize()
+        enc()
+        codec.synchronize()
+        assert int((st != 0).sum()) == 0, "zstd leg: encode failed"
+        te = timed(enc, 1)
+        back = torch.empty(nz * fs + 64, dtype=torch.uint8, device=dev)
+        b_len = torch.zeros(nz, **i32)
+        dec = lambda: codec.launch(A.OP_ZSTD_DECOMPRESS, z_dst, zc_off, zc_len, back, z_off, z_len, b_len, st, eo, nz)  # noqa: E731
+        torch.cuda.synchronize()
+        dec()
+        codec.synchronize()
+        assert int((st != 0).sum()) == 0 and bool((back[:nz * fs] == zplain).all()), "zstd leg: GPU encode -> GPU decode round trip failed"
+        td = timed(dec, 3)
+        zbytes = int(zc_len.to(torch.int64).sum())
+        out["zstd_java_frames" + suffix] = reduce_leg(dist, world, rank, nz * fs, td, {"frames": nz, "ratio": round(nz * fs / zbytes, 3)})
+        out["zstd_compress" + suffix] = reduce_leg(dist, world, rank, nz * fs, te, {"frames": nz})
+        del z_dst, back, zplain, plain
+        torch.cuda.empty_cache()
+
+    out["mixed"] = mixed_leg(torch, A, codec, dev, args, rank, world, dist)
+    return out
+
+
 def relaunch_with_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this very command under torch.distributed.run (one process per GPU,
     rank r on cuda:r) and hand its exit code on.  The driver's own `python -m torch.distributed.run ... bench.py --gpus N` form sets WORLD_SIZE
@@ -217,8 +489,25 @@ def stub_main(args, rank, world, dist):
         elapsed = float(t.item())
         per_rank = [None] * world
         dist.all_gather_object(per_rank, elapsed_local)
+    # the legs' control plane (reduce_leg's gather, the mixed job's partition over the ranks) with the same memcpy standing in for every kernel
+    legs = {}
+    if not args.no_legs:
+        for name in ("snappy", "zstd", "zstd_corpus", "zstd_java_frames", "zstd_java_frames_corpus"):
+            t0 = time.perf_counter()
+            np.copyto(b, a)
+            legs[name] = reduce_leg(dist, world, rank, a.nbytes, time.perf_counter() - t0)
+        rows, items, weights = mixed_job(args.mixed_copies)
+        mlo, mhi = shard_for_rank(weights, world, rank)
+        t0 = time.perf_counter()
+        np.copyto(b, a)
+        legs["mixed"] = reduce_leg(dist, world, rank, sum(rows[r][2] for r, _ in items[mlo:mhi]), time.perf_counter() - t0, {"items": mhi - mlo, "slice": [mlo, mhi], "mismatches": 0})
+        legs["mixed"].update({"mixed_ok": sum(p["items"] for p in legs["mixed"]["per_rank"]) == len(items), "items": len(items), "manifest_lines": len(rows)})
     if rank == 0:
-        print(json.dumps({"metric": "GiB/s decompressed throughput (Zstd+LZ4) at 1/2/4/8 GPUs; % of HBM3E roofline", "value": 0.0, "unit": "GiB/s", "n_gpus": world,
+        extra_keys = {}
+        if legs:
+            extra_keys = {"legs": legs, "value_mixed": legs["mixed"]["GiBps"], "mixed_ok": legs["mixed"]["mixed_ok"], "value_snappy": legs["snappy"]["GiBps"],
+                          "value_zstd": legs["zstd"]["GiBps"], "value_zstd_corpus": legs["zstd_corpus"]["GiBps"]}
+        print(json.dumps({**extra_keys, "metric": "GiB/s decompressed throughput (Zstd+LZ4) at 1/2/4/8 GPUs; % of HBM3E roofline", "value": 0.0, "unit": "GiB/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "stub (ACHIP_BENCH_STUB_DEVICE=1: no device, control plane only -- not a result)",
                           "stub": True, "config": {"workload": "stub", "blocks_per_gpu": n_local, "shard": [lo, hi], "per_rank_seconds": per_rank}}), flush=True)
@@ -494,10 +783,26 @@ def main():
         except Exception:
             pass
 
+    # release the headline's buffers first: the legs and the extras allocate batches of the same size
+    del src, dst
+    torch.cuda.empty_cache()
+    if not args.no_legs:
+        codec.native.set_option("max_src_len_hint", 0)  # the legs' units are not the headline's 64 KiB blocks (whole files, 128 KiB frames)
+        # the rest of the metric on EVERY rank: at N > 1 all legs (the extras below are N = 1 only); at N = 1 the extras carry Snappy / Zstd and
+        # only the mixed corpus batch (configs[4]) is added here
+        legs = rank_legs(torch, A, codec, dev, args, rank, world, dist, n_local) if world > 1 else {"mixed": mixed_leg(torch, A, codec, dev, args, rank, world, dist)}
+        result["legs"] = legs
+        result["value_mixed"] = legs["mixed"]["GiBps"]
+        result["mixed_ok"] = legs["mixed"]["mixed_ok"]
+        if world > 1:
+            result["value_snappy"] = legs["snappy"]["GiBps"]                        # Snappy decompress, the headline's batch shape
+            if "zstd" in legs:
+                result["value_zstd"] = legs["zstd"]["GiBps"]                        # BASELINE configs[3]: libzstd level-3 frames of 128 KiB, fragments
+                result["value_zstd_corpus"] = legs["zstd_corpus"]["GiBps"]          # ... corpus-tiled
+            result["value_zstd_java_frames"] = legs["zstd_java_frames"]["GiBps"]    # the same plaintext in the GPU encoder's (= the Java encoder's) frames
+            result["value_zstd_java_frames_corpus"] = legs["zstd_java_frames_corpus"]["GiBps"]
+    codec.native.set_option("max_src_len_hint", bs)
     if rank == 0 and world == 1 and not args.no_extra:
-        # release the headline's buffers first: the extras allocate batches of the same size
-        del src, dst
-        torch.cuda.empty_cache()
         ex = extras(torch, A, codec, dev, args)
         ex.update(xxhash_extra(torch, A, codec, dev, args))
         ex.update(lz4frame_extra(torch, A, codec, dev, args))
@@ -523,6 +828,8 @@ def main():
             result["value_zstd_stream_corpus"] = ex["zstdstream_corpus"]["decompress_GiBps"]  # frames of several blocks (4 MiB streams), corpus-tiled
         if not args.no_sweep:
             result["sweep_random301"] = sweep_random301(torch, A, codec, dev, args)
+    if rank == 0 and world == 1 and not args.no_host_facing and wl == "lz4_decompress":
+        result.update(host_facing(torch, A, codec, pool_pack, pool_pack_off, pool_clen, pool_plain, bs))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(torch, pool_pack, pool_pack_off, pool_clen, pool_plain, bs, op, wl, args.cpu_seconds)
     if rank == 0:
@@ -531,6 +838,95 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def host_facing(torch, A, codec, pool_pack, pool_pack_off, pool_clen, pool_plain, bs):
+    """SURVEY 8(d) "timing": the PCIe-inclusive numbers of the headline's workload -- host buffers in, host buffers out -- beside `value` (which is
+    HBM-resident and stays the headline), and the latency of the literal drop-in call, one block per call (Lz4HipDecompressor.decompress(MemorySegment,
+    MemorySegment) -> achip_lz4_decompress: M/lz4/Lz4JavaDecompressor.java:46-70 is what it replaces).  16384 blocks = 1 GiB of plaintext per call:
+      pageable: achip_batch_host on ordinary (numpy) memory -- gather into pinned slots, upload, kernels, download, scatter, pipelined;
+      pinned:   the caller keeps its segments in achip_host_alloc_pinned memory and brackets the device-resident batch call with achip_memcpy_h2d / _d2h."""
+    import statistics
+    lib = codec.lib
+    ctx = codec.native.ctx
+    pool_n = int(pool_clen.numel())
+    n = 16384
+    reps = (n + pool_n - 1) // pool_n
+    pack = pool_pack.cpu().numpy()
+    offs = pool_pack_off.cpu().numpy().astype(np.int64)
+    lens = pool_clen.cpu().numpy().astype(np.int32)
+    src = np.tile(pack, reps)
+    so = (np.tile(offs, reps) + np.repeat(np.arange(reps, dtype=np.int64) * pack.size, pool_n))[:n].copy()
+    sl = np.tile(lens, reps)[:n].copy()
+    dst = np.zeros(n * bs, dtype=np.uint8)
+    do = np.arange(n, dtype=np.int64) * bs
+    dc = np.full(n, bs, dtype=np.int32)
+    plain0 = pool_plain[:bs].cpu().numpy()
+    times = []
+    for it in range(4):  # the first call touches the destination's pages and allocates the staging slots: not timed
+        t0 = time.perf_counter()
+        ol, st, eo = codec.run_host(A.OP_LZ4_DECOMPRESS, src, so, sl, dst, do, dc)
+        if it:
+            times.append(time.perf_counter() - t0)
+        assert (st == 0).all() and (ol == bs).all() and (dst[:bs] == plain0).all() and (dst[(pool_n * (reps - 1)) * bs:(pool_n * (reps - 1)) * bs + bs] == plain0).all()
+    pageable = n * bs / statistics.median(times) / 2**30
+    stages = {k: codec.native.get_stat("host." + k) for k in ("chunks", "total_us", "gather_us", "scatter_us", "wait_slot_us", "wait_download_us")}
+    comp_bytes = int(sl.astype(np.int64).sum())
+    # pinned segments + explicit copies around the device-resident call
+    span = int(so[-1]) + int(sl[-1])
+    meta = np.concatenate([so.view(np.uint8), sl.view(np.uint8), do.view(np.uint8), dc.view(np.uint8)])
+    h_src, h_dst = lib.achip_host_alloc_pinned(span), lib.achip_host_alloc_pinned(n * bs)
+    ctypes.memmove(h_src, src.ctypes.data, span)
+    d_src, d_dst = lib.achip_device_alloc(ctx, span + 64), lib.achip_device_alloc(ctx, n * bs + 64)
+    d_meta = lib.achip_device_alloc(ctx, meta.size + n * 16 + 64)
+    assert h_src and h_dst and d_src and d_dst and d_meta
+    lib.achip_memcpy_h2d(ctx, d_meta, meta.ctypes.data, meta.size)
+    o_so, o_sl, o_do, o_dc, o_ol, o_st, o_eo = 0, n * 8, n * 12, n * 20, n * 24, n * 28, n * 32
+    times = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        lib.achip_memcpy_h2d(ctx, d_src, h_src, span)
+        r = lib.achip_lz4_decompress_batch(ctx, d_src, d_meta + o_so, d_meta + o_sl, d_dst, d_meta + o_do, d_meta + o_dc, d_meta + o_ol, d_meta + o_st, d_meta + o_eo, n)
+        assert r == 0, r
+        lib.achip_memcpy_d2h(ctx, h_dst, d_dst, n * bs)
+        lib.achip_ctx_synchronize(ctx)
+        if it:
+            times.append(time.perf_counter() - t0)
+    assert bytes((ctypes.c_uint8 * bs).from_address(h_dst + (n - 1) * bs)) == dst[(n - 1) * bs:].tobytes()
+    pinned = n * bs / statistics.median(times) / 2**30
+    for ptr in (d_src, d_dst, d_meta):
+        lib.achip_device_free(ctx, ptr)
+    lib.achip_host_free_pinned(h_src)
+    lib.achip_host_free_pinned(h_dst)
+    # one block per call through the single-block entry points (host pointers, synchronous): median of 200 calls each
+    blk = pool_plain[:bs].cpu().numpy()
+    cap = lib.achip_lz4_max_compressed_length(bs)
+    cbuf = np.zeros(cap, dtype=np.uint8)
+    back = np.zeros(bs, dtype=np.uint8)
+    eo1 = ctypes.c_int64()
+    tc, td = [], []
+    clen1 = 0
+    for it in range(220):
+        t0 = time.perf_counter()
+        clen1 = lib.achip_lz4_compress(ctx, blk.ctypes.data, cbuf.ctypes.data, bs, cap, ctypes.byref(eo1))
+        t1 = time.perf_counter()
+        r = lib.achip_lz4_decompress(ctx, cbuf.ctypes.data, back.ctypes.data, clen1, bs, ctypes.byref(eo1))
+        t2 = time.perf_counter()
+        assert clen1 > 0 and r == bs
+        if it >= 20:
+            tc.append(t1 - t0)
+            td.append(t2 - t1)
+    assert (back == blk).all()
+    return {
+        "end_to_end": {"pageable_GiBps": round(pageable, 2), "pinned_GiBps": round(pinned, 2), "blocks": n, "block_bytes": bs, "plain_bytes": n * bs, "compressed_bytes": comp_bytes,
+                       "pageable_stages_last_call": stages,
+                       "what": "LZ4 decompress of the headline's blocks, host memory in and out (H2D + kernels + D2H): pageable = achip_batch_host on ordinary memory "
+                               "(staged through pinned slots, pipelined); pinned = achip_host_alloc_pinned segments, achip_memcpy_h2d + achip_lz4_decompress_batch + "
+                               "achip_memcpy_d2h.  PCIe-bound, never `value`"},
+        "single_block_us": {"lz4_decompress": round(statistics.median(td) * 1e6, 1), "lz4_compress": round(statistics.median(tc) * 1e6, 1), "block_bytes": bs, "calls": 200,
+                            "what": "median latency of ONE 64 KiB block per call through achip_lz4_decompress / achip_lz4_compress (host pointers, synchronous): what "
+                                    "Lz4HipDecompressor.decompress(MemorySegment, MemorySegment) costs per call"},
+    }
 
 
 def kernel_sources_hash():

@@ -355,10 +355,11 @@ int32_t achip_xxhash32(achip_ctx* ctx, const void* src, int64_t srcLen, int32_t 
 #define ACHIP_OP_SNAPPYHADOOP_COMPRESS 13
 #define ACHIP_OP_ZSTDSTREAM_COMPRESS 14
 int32_t achip_batch_host(int32_t codecOp, ACHIP_BATCH_ARGS);
-/* (Staging is chunked and double-buffered: while chunk c runs on the GPU, chunk c+1 is gathered into pinned memory and uploaded
- * and chunk c-1 is downloaded and scattered to dstBase by a few host copy threads -- options "host.chunk_bytes",
- * "host.copy_threads".  Replaces N calls of Compressor.compress(byte[]...) / Decompressor.decompress(byte[]...),
- * M/Compressor.java:20-35, M/Decompressor.java:23-30, over one device.) */
+/* (Staging is chunked and pipelined over up to four pinned slots: this thread gathers chunk c+1 into pinned memory while chunk c
+ * is uploaded / run / downloaded on three streams and a finalizer thread scatters chunk c-1 to dstBase -- each side with a few
+ * copy threads of its own; one upload and one download per chunk.  A single chunk (e.g. a single block) runs in order on the
+ * context stream.  Options "host.chunk_bytes", "host.copy_threads".  Replaces N calls of Compressor.compress(byte[]...) /
+ * Decompressor.decompress(byte[]...), M/Compressor.java:20-35, M/Decompressor.java:23-30, over one device.) */
 
 /* Mixed batches (BASELINE configs[4]): item i is processed by codecOp[i] (ACHIP_OP_*), any interleaving.  The items are
  * bucketed by codec op so that every kernel launch is homogeneous -- what a caller holding e.g. one ORC / Parquet stripe with
@@ -371,6 +372,18 @@ int32_t achip_mixed_batch(achip_ctx* ctx, const int32_t* codecOp, const void* sr
                           const int64_t* dstOff, const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t nBlocks);
 int32_t achip_mixed_batch_host(achip_ctx* ctx, const int32_t* codecOp, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, void* dstBase,
                                const int64_t* dstOff, const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t nBlocks);
+
+/* One process, several devices: the batch is cut into nCtx contiguous slices balanced by srcLen[i] + dstCap[i] (the rule of
+ * achip_partition_blocks) and slice d runs through achip_batch_host (codecOps == NULL: every item is `codecOp`) or
+ * achip_mixed_batch_host (codecOps[i] per item) on ctxs[d], each slice in a host thread of its own, all inside this call -- what
+ * a JVM (one process) does with the GPUs of a node; java/.../HipBatchCodec.run is the same split with Java threads.  ctxs: nCtx
+ * distinct contexts (normally one per device; several on one device are legal).  sliceStarts (may be NULL) receives the nCtx + 1
+ * slice boundaries.  Units are self-contained (each frame decode resets its state, M/zstd/ZstdFrameDecompressor.java:151; each
+ * compress() builds a fresh context, M/zstd/ZstdFrameCompressor.java:162; LZ4 / Snappy blocks likewise): the slices
+ * exchange nothing.  Returns 0, or the first failing slice's negative status (achip_last_error names the slice). */
+int32_t achip_multi_batch_host(achip_ctx* const* ctxs, int32_t nCtx, int32_t codecOp, const int32_t* codecOps, const void* srcBase, const int64_t* srcOff,
+                               const int32_t* srcLen, void* dstBase, const int64_t* dstOff, const int32_t* dstCap, int32_t* outLen, int32_t* status,
+                               int64_t* errOffset, int32_t nBlocks, int32_t* sliceStarts);
 
 /* Balanced contiguous partition of a batch over nParts GPUs: fills
  * starts[0..nParts] with block indices so that each part's sum of weight[i] is

@@ -107,6 +107,35 @@ public final class HipBatchCodec
         return new Result(outputLength, status, errorOffset);
     }
 
+    /**
+     * The same job in ONE downcall: the library makes the split (the rule of {@link #partition}) and runs every slice on its context in a
+     * native host thread ({@code achip_multi_batch_host}); {@code ops} null = every item is {@code op}, otherwise one OP_* per item (a mixed
+     * batch: the items of a slice are bucketed by codec inside the library).
+     */
+    public Result runNative(int op, int[] ops, MemorySegment source, long[] sourceOffset, int[] sourceLength,
+            MemorySegment destination, long[] destinationOffset, int[] destinationCapacity)
+    {
+        int blocks = sourceOffset.length;
+        int[] outputLength = new int[blocks];
+        int[] status = new int[blocks];
+        long[] errorOffset = new long[blocks];
+        try (Arena arena = Arena.ofConfined()) {
+            MemorySegment opsSegment = ops == null ? MemorySegment.NULL : arena.allocateFrom(JAVA_INT, ops);
+            MemorySegment srcOff = arena.allocateFrom(JAVA_LONG, sourceOffset);
+            MemorySegment srcLen = arena.allocateFrom(JAVA_INT, sourceLength);
+            MemorySegment dstOff = arena.allocateFrom(JAVA_LONG, destinationOffset);
+            MemorySegment dstCap = arena.allocateFrom(JAVA_INT, destinationCapacity);
+            MemorySegment outLen = arena.allocate(JAVA_INT, Math.max(blocks, 1));
+            MemorySegment stat = arena.allocate(JAVA_INT, Math.max(blocks, 1));
+            MemorySegment errOff = arena.allocate(JAVA_LONG, Math.max(blocks, 1));
+            HipNative.multiBatchHost(contexts, op, opsSegment, source, srcOff, srcLen, destination, dstOff, dstCap, outLen, stat, errOff, blocks, MemorySegment.NULL);
+            MemorySegment.copy(outLen, JAVA_INT, 0, outputLength, 0, blocks);
+            MemorySegment.copy(stat, JAVA_INT, 0, status, 0, blocks);
+            MemorySegment.copy(errOff, JAVA_LONG, 0, errorOffset, 0, blocks);
+        }
+        return new Result(outputLength, status, errorOffset);
+    }
+
     /** Contiguous split balanced by bytes moved (source + destination), the same rule as achip_partition_blocks. */
     static int[] partition(int[] sourceLength, int[] destinationCapacity, int parts)
     {

@@ -202,7 +202,12 @@ public final class HipNative
             MethodHandle snappyHadoopCompressBatch,
             @NativeSignature(name = "achip_zstd_compress_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
                     MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
-            MethodHandle zstdCompressBatch) {}
+            MethodHandle zstdCompressBatch,
+            // one process, several contexts: (ctxs**, nCtx, op, ops*, srcBase, srcOff*, srcLen*, dstBase, dstOff*, dstCap*, outLen*, status*, errOffset*, nBlocks, sliceStarts*)
+            @NativeSignature(name = "achip_multi_batch_host", returnType = int.class, argumentTypes = {MemorySegment.class, int.class, int.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    int.class, MemorySegment.class})
+            MethodHandle multiBatchHost) {}
 
     private static final Optional<LinkageError> LINKAGE_ERROR;
     private static final MethodHandles HANDLES;
@@ -280,6 +285,36 @@ public final class HipNative
      * Throws what the Java codec would throw for this status: MalformedInputException(offset, reason)
      * for corrupt input, IllegalArgumentException for buffer sizing / arguments.
      */
+    /**
+     * One call, several contexts (normally one per device): the library cuts the batch into contiguous slices balanced by bytes and runs
+     * every slice on its context in a host thread of its own ({@code achip_multi_batch_host}).  {@code ops} is {@link MemorySegment#NULL}
+     * for a homogeneous batch of {@code op}, otherwise one OP_* per item.
+     */
+    public static void multiBatchHost(Context[] contexts, int op, MemorySegment ops, MemorySegment srcBase, MemorySegment srcOff, MemorySegment srcLen,
+            MemorySegment dstBase, MemorySegment dstOff, MemorySegment dstCap, MemorySegment outLen, MemorySegment status, MemorySegment errOffset, int blocks,
+            MemorySegment sliceStarts)
+    {
+        verifyEnabled();
+        int result;
+        try (Arena arena = Arena.ofConfined()) {
+            MemorySegment handles = arena.allocate(java.lang.foreign.ValueLayout.ADDRESS, contexts.length);
+            for (int i = 0; i < contexts.length; i++) {
+                handles.setAtIndex(java.lang.foreign.ValueLayout.ADDRESS, i, contexts[i].handle());
+            }
+            result = (int) HANDLES.multiBatchHost().invokeExact(handles, contexts.length, op, ops, srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset,
+                    blocks, sliceStarts);
+        }
+        catch (RuntimeException e) {
+            throw e;
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+        if (result < 0) {
+            throw toException(result, 0);
+        }
+    }
+
     public static RuntimeException toException(int status, long errorOffset)
     {
         String reason = detailMessage(statusDetail(status));

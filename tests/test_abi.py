@@ -179,6 +179,18 @@ def test_partition_blocks():
     assert list(A.partition_blocks([], 4)) == [0, 0, 0, 0, 0]
 
 
+def test_multi_batch_host_argument_checks(lib):
+    """achip_multi_batch_host without a device: the argument checks that come before any context is touched"""
+    import ctypes
+    z = np.zeros(4, dtype=np.int64)
+    args = [0, None, None, z.ctypes.data, z.ctypes.data, None, z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data, 1, None]
+    assert lib.achip_status_class(lib.achip_multi_batch_host(None, 0, *args)) == 3                       # no contexts
+    one_null = (ctypes.c_void_p * 2)(None, None)
+    assert lib.achip_status_class(lib.achip_multi_batch_host(one_null, 2, *args)) == 3                    # a null context
+    assert b"null" in lib.achip_last_error()
+    assert lib.achip_status_class(lib.achip_multi_batch_host(one_null, 65, *args)) == 3
+
+
 def test_codecs_fail_loudly_without_gpu(lib):
     import aircompressor_amd as A
     if lib.achip_device_count() > 0:

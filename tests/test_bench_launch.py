@@ -34,6 +34,18 @@ def test_gpus_2_starts_two_ranks_by_itself_and_prints_one_line():
     assert line["stub"] is True and "stub" in line["data"]
     assert len(line["config"]["per_rank_seconds"]) == 2            # both ranks reported
     assert line["config"]["blocks_per_gpu"] == 4096                # weak scaling: --blocks per GPU
+    # the line carries the WHOLE metric at N > 1: Snappy, Zstd configs[3] and the mixed corpus batch configs[4] as
+    # aggregates over the ranks, each with its per-rank entries
+    for key in ("value_snappy", "value_zstd", "value_zstd_corpus", "value_mixed"):
+        assert key in line, key
+    for leg in ("snappy", "zstd", "zstd_corpus", "zstd_java_frames", "mixed"):
+        assert {p["rank"] for p in line["legs"][leg]["per_rank"]} == {0, 1}, leg
+    mixed = line["legs"]["mixed"]
+    assert line["mixed_ok"] is True and mixed["manifest_lines"] == 668
+    slices = sorted(p["slice"] for p in mixed["per_rank"])           # achip_partition_blocks: contiguous, complete, balanced by bytes
+    assert slices[0][0] == 0 and slices[0][1] == slices[1][0] and slices[1][1] == mixed["items"]
+    by = [p["bytes"] for p in mixed["per_rank"]]
+    assert abs(by[0] - by[1]) < 0.1 * sum(by)
 
 
 def test_gpus_1_stays_one_process():
@@ -59,7 +71,8 @@ import pytest
 def test_bench_gpus_2_on_one_device():
     """The real thing on a one-GPU box: `python bench.py --gpus 2` with no launcher on the command line, both ranks on cuda:0
     (ACHIP_BENCH_SHARE_DEVICE=1: a path check, labelled as such in the line) -- one line, n_gpus 2, both ranks verified bit-exact."""
-    r = run_bench({"ACHIP_BENCH_SHARE_DEVICE": "1"}, "--gpus", "2", "--blocks", "16384", "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline", timeout=900)
+    r = run_bench({"ACHIP_BENCH_SHARE_DEVICE": "1"}, "--gpus", "2", "--blocks", "16384", "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--zstd-frames", "4096",
+                  "--mixed-copies", "1", timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = json_lines(r.stdout)
     assert len(lines) == 1, r.stdout
@@ -67,6 +80,11 @@ def test_bench_gpus_2_on_one_device():
     assert line["n_gpus"] == 2 and len(line["per_rank"]) == 2 and {p["rank"] for p in line["per_rank"]} == {0, 1}
     assert "ALL RANKS ON ONE DEVICE" in line["config"]["parallelism"]
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+    # ... and the rest of the metric from both ranks: every leg verified byte-exact on every rank before it was timed
+    assert line["mixed_ok"] is True and all(p["mismatches"] == 0 and p["items"] > 0 for p in line["legs"]["mixed"]["per_rank"])
+    for key in ("value_snappy", "value_zstd", "value_zstd_corpus", "value_zstd_java_frames", "value_mixed"):
+        assert line[key] > 0, key
+    assert {p["rank"] for p in line["legs"]["zstd_corpus"]["per_rank"]} == {0, 1}
 
 
 @pytest.mark.gpu

@@ -113,14 +113,68 @@ def test_mixed_batch_device_resident(gb, o):
 
 def test_mixed_batch_host_pointers(gb, o):
     items = mixed_items(o, stride=2)
-    gb.set_option("host.chunk_bytes", 4 << 20)  # many chunks: the staging pipeline wraps around its two slots many times
+    gb.set_option("host.chunk_bytes", 4 << 20)  # many chunks: the staging pipeline wraps around its four slots many times
     try:
         outs, status, _ = gb.run_host([it[0] for it in items], [it[1] for it in items], [it[2] for it in items])
     finally:
-        gb.set_option("host.chunk_bytes", 48 << 20)
+        gb.set_option("host.chunk_bytes", 96 << 20)
     for k, (it, out, s) in enumerate(zip(items, outs, status)):
         assert s == 0, (k, it[0], len(it[1]), s)
         assert out == it[3], "item %d (op %d, %d bytes in)" % (k, it[0], len(it[1]))
+
+
+def test_one_process_several_contexts(gb, o):
+    """achip_multi_batch_host = java/.../HipBatchCodec.run executed: ONE process, N contexts, N host threads inside the library, contiguous
+    byte-balanced slices; the mixed corpus batch (BASELINE configs[4]) and a homogeneous Zstd batch, byte-exact per item and identical to the
+    single-context call.  N contexts on cuda:0 always (3 of them), and one context per device when the box has several."""
+    import torch
+    import aircompressor_amd as A
+    items = mixed_items(o, stride=3)
+    ops = [it[0] for it in items]
+    blocks = [it[1] for it in items]
+    caps = np.asarray([it[2] for it in items], dtype=np.int32)
+    src, src_off, src_len = gb.pack(blocks, align=1)
+    dst_off = np.concatenate([[0], np.cumsum(caps.astype(np.int64) + 5)[:-1]])
+    single = np.full(int(dst_off[-1]) + int(caps[-1]) + 64, 0xA5, dtype=np.uint8)
+    want_len, want_st, want_eo = gb.codec.run_host_mixed(ops, src, src_off, src_len, single, dst_off, caps)
+    layouts = [[0, 0, 0]]
+    if torch.cuda.device_count() > 1:
+        layouts.append(list(range(torch.cuda.device_count())))
+    for devices in layouts:
+        multi = A.HipMultiContextCodec(devices=devices)
+        try:
+            for c in multi.contexts:
+                c.set_option("host.chunk_bytes", 8 << 20)
+            dst = np.full_like(single, 0xA5)
+            out_len, st, eo = multi.run_host(ops, src, src_off, src_len, dst, dst_off, caps)
+            starts = multi.slice_starts
+            assert starts[0] == 0 and starts[-1] == len(items) and all(a < b for a, b in zip(starts, starts[1:])), starts
+            assert (st == 0).all() and (out_len == want_len).all() and (st == want_st).all()
+            assert (dst == single).all(), "several contexts wrote other bytes than one"
+            for k, it in enumerate(items):
+                assert dst[dst_off[k]:dst_off[k] + out_len[k]].tobytes() == it[3], (k, it[0])
+            # homogeneous: every Zstd cut compressed, one damaged item keeps its status and the slices around it their results
+            zrows = [r for r in common.read_manifest_tsv("oracle_manifest.tsv") if r[3] == "zstd"][:90]
+            corpus = common.corpus_full()
+            plain = [corpus[f][off:off + n] for f, off, n, *_ in zrows]
+            comp = [o.compress("zstd", b) for b in plain]
+            comp[40] = comp[40][:len(comp[40]) // 2]
+            zsrc, zoff, zlen = gb.pack(comp, align=1)
+            zcap = np.asarray([max(len(b), 1) for b in plain], dtype=np.int32)
+            zdoff = np.concatenate([[0], np.cumsum(zcap.astype(np.int64))[:-1]])
+            zdst = np.zeros(int(zcap.sum()) + 64, dtype=np.uint8)
+            out_len, st, eo = multi.run_host(A.OP_ZSTD_DECOMPRESS, zsrc, zoff, zlen, zdst, zdoff, zcap)
+            for k, b in enumerate(plain):
+                if k == 40:
+                    with pytest.raises(oracle_lib.OracleError) as e:
+                        o.decompress("zstd", comp[k], len(b))
+                    assert (st[k], eo[k]) == (e.value.status, e.value.offset)
+                else:
+                    assert st[k] == 0 and zdst[zdoff[k]:zdoff[k] + out_len[k]].tobytes() == b, k
+        finally:
+            multi.close()
+    with pytest.raises(A.IllegalArgumentException):
+        A.HipMultiContextCodec(contexts=[gb.codec.native, gb.codec.native]).run_host(A.OP_LZ4_COMPRESS, src, src_off, src_len, single, dst_off, caps)
 
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy", "zstd"])
@@ -137,7 +191,7 @@ def test_batch_host_hundreds_of_ragged_blocks(gb, o, codec):
         plain.append(blob[pos:pos + n])
         pos += n
     cop, dop = OPS[codec]
-    for chunk in (1 << 20, 48 << 20):
+    for chunk in (1 << 20, 96 << 20):
         gb.set_option("host.chunk_bytes", chunk)
         outs, status, _ = gb.run_host(cop, plain, [o.max_compressed_length(codec, len(b)) for b in plain])
         for b, c, s in zip(plain, outs, status):
@@ -156,7 +210,7 @@ def test_batch_host_hundreds_of_ragged_blocks(gb, o, codec):
                 assert (s, err[k] if s else 0) == expect, (k, s, err[k], expect)
             else:
                 assert s == 0 and p == b, (k, s)
-    gb.set_option("host.chunk_bytes", 48 << 20)
+    gb.set_option("host.chunk_bytes", 96 << 20)
 
 
 def test_two_contexts_two_threads(o):

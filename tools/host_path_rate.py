@@ -1,48 +1,42 @@
-"""PCIe-inclusive rate of the host-buffer boundary (achip_batch_host): host numpy in, host numpy out, staged through the
-context's pinned buffer.  Reported in DESIGN.md; never used for bench.py's `value`."""
+"""PCIe-inclusive rate of the host-buffer boundary (achip_batch_host) on ordinary (pageable) memory, swept over the pipeline's two knobs --
+copy threads per pool and staging bytes per chunk -- with the pipeline's own stage times (achip_ctx_get_stat host.*).
+bench.py reports the default configuration as `end_to_end`; never used for `value`.
+    python tools/host_path_rate.py [threads,threads,...] [chunk_MiB,chunk_MiB,...]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
+import torch
 import aircompressor_amd as A
-from tests import oracle_lib
-o = oracle_lib.load()
-codec = A.HipBatchCodec(0)
-rng = np.random.default_rng(1)
-bs, n = 65536, 16384
-frags = rng.integers(0, 256, size=(bs // 100 + 1, 50), dtype=np.uint8)
-block = np.tile(frags, (1, 2)).reshape(-1)[:bs].tobytes()
-comp = o.compress("lz4", block)
-src = np.frombuffer(comp * n, dtype=np.uint8)
-so = np.arange(n, dtype=np.int64) * len(comp); sl = np.full(n, len(comp), dtype=np.int32)
-dst = np.zeros(n * bs, dtype=np.uint8); do = np.arange(n, dtype=np.int64) * bs; dc = np.full(n, bs, dtype=np.int32)
-for it in range(3):
-    t0 = time.perf_counter()
-    ol, st, eo = codec.run_host(A.OP_LZ4_DECOMPRESS, src, so, sl, dst, do, dc)
-    t = time.perf_counter() - t0
-    assert (st == 0).all() and bytes(dst[:bs]) == block and bytes(dst[-bs:]) == block
-    print("host-buffer LZ4 decompress: %d x %d B, %.1f ms, %.2f GiB/s decompressed (H2D %.2f GB + D2H %.2f GB)" % (n, bs, t * 1e3, n * bs / t / 2**30, src.size / 1e9, dst.size / 1e9), flush=True)
 
-# the same batch from PINNED host segments (achip_host_alloc_pinned + explicit H2D / D2H): what a Java caller that keeps
-# its MemorySegments in pinned memory gets
-import ctypes
-lib = codec.lib
-ctx = codec.native.ctx
-meta = np.concatenate([so.view(np.uint8), sl.view(np.uint8), do.view(np.uint8), dc.view(np.uint8)])
-h_src = lib.achip_host_alloc_pinned(src.size); h_dst = lib.achip_host_alloc_pinned(dst.size)
-ctypes.memmove(h_src, src.ctypes.data, src.size)
-d_src = lib.achip_device_alloc(ctx, src.size); d_dst = lib.achip_device_alloc(ctx, dst.size + 64)
-d_meta = lib.achip_device_alloc(ctx, meta.size + n * 16 + 64)
-lib.achip_memcpy_h2d(ctx, d_meta, meta.ctypes.data, meta.size)
-o_so, o_sl, o_do, o_dc = 0, n * 8, n * 12, n * 20
-o_ol, o_st, o_eo = n * 24, n * 28, n * 32
-for it in range(3):
-    t0 = time.perf_counter()
-    lib.achip_memcpy_h2d(ctx, d_src, h_src, src.size)
-    r = lib.achip_lz4_decompress_batch(ctx, d_src, d_meta + o_so, d_meta + o_sl, d_dst, d_meta + o_do, d_meta + o_dc, d_meta + o_ol, d_meta + o_st, d_meta + o_eo, n)
-    assert r == 0, r
-    lib.achip_memcpy_d2h(ctx, h_dst, d_dst, dst.size)
-    lib.achip_ctx_synchronize(ctx)
-    t = time.perf_counter() - t0
-    print("pinned segments: %.1f ms, %.2f GiB/s decompressed, %.1f GB/s over PCIe" % (t * 1e3, n * bs / t / 2**30, (src.size + dst.size) / t / 1e9), flush=True)
-out = (ctypes.c_uint8 * bs).from_address(h_dst + (n - 1) * bs)
-assert bytes(out) == block
+threads = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,4,8,16,32").split(",")]
+chunks = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "192").split(",")]
+bs, n, pool_n = 65536, 16384, 1024
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev); g.manual_seed(5)
+frags = torch.randint(0, 256, (pool_n * bs // 100 + 1, 50), dtype=torch.uint8, device=dev, generator=g)
+plain = frags.repeat(1, 2).reshape(-1)[:pool_n * bs].contiguous().cpu().numpy()
+base = A.HipBatchCodec(0)
+cap = base.lib.achip_lz4_max_compressed_length(bs)
+comp = np.zeros(pool_n * cap, dtype=np.uint8)
+ol, st, _ = base.run_host(A.OP_LZ4_COMPRESS, plain, np.arange(pool_n, dtype=np.int64) * bs, np.full(pool_n, bs, dtype=np.int32), comp, np.arange(pool_n, dtype=np.int64) * cap, np.full(pool_n, cap, dtype=np.int32))
+assert (st == 0).all()
+reps = n // pool_n
+src = np.tile(comp, reps)
+so = np.tile(np.arange(pool_n, dtype=np.int64) * cap, reps) + np.repeat(np.arange(reps, dtype=np.int64) * comp.size, pool_n)
+sl = np.tile(ol, reps)
+dst = np.zeros(n * bs, dtype=np.uint8); do = np.arange(n, dtype=np.int64) * bs; dc = np.full(n, bs, dtype=np.int32)
+for t in threads:
+    for ch in chunks:
+        codec = A.HipBatchCodec(0)
+        codec.native.set_option("host.copy_threads", t)
+        codec.native.set_option("host.chunk_bytes", ch << 20)
+        best = None
+        for it in range(4):
+            t0 = time.perf_counter()
+            o2, s2, _ = codec.run_host(A.OP_LZ4_DECOMPRESS, src, so, sl, dst, do, dc)
+            el = time.perf_counter() - t0
+            assert (s2 == 0).all() and (dst[:pool_n * bs] == plain).all()
+            if it and (best is None or el < best[0]):
+                best = (el, {k: codec.native.get_stat("host." + k) for k in ("chunks", "total_us", "gather_us", "scatter_us", "wait_slot_us", "wait_download_us")})
+        print("threads/pool %2d chunk %4d MiB: %6.2f GiB/s decompressed  %s" % (t, ch, n * bs / best[0] / 2**30, best[1]), flush=True)
+        codec.native.close()

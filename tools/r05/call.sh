@@ -1,0 +1,40 @@
+#!/bin/bash
+# Round 5 GPU calls, one parametrised script: tools/r05/call.sh <step> [<step> ...]
+# Every step runs under its own timeout and writes under gpurun_out/r05/<step>*.
+export TMPDIR=/tmp
+O=gpurun_out/r05
+mkdir -p $O
+ks() {  # ks <tag> <bench args...>: per-kernel average times of one bench.py run -> $O/kstats_<tag>.txt
+  local tag=$1; shift
+  timeout 400 bash tools/kstats.sh r05_$tag "$@"
+  mv gpurun_out/kstats_r05_$tag.txt $O/kstats_$tag.txt 2>/dev/null
+  echo "--- $tag"; cat $O/kstats_$tag.txt
+}
+line() {  # line <label>: one bench line on stdin -> the keys worth reading
+  python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('$1', 'value', r.get('value'), 'frac', r.get('roofline',{}).get('frac'), {k:v for k,v in r.items() if k.startswith('value_') or k in ('mixed_ok','end_to_end','single_block_us')})
+"
+}
+for step in "$@"; do
+  echo "===== $step at $(date +%T)"
+  case $step in
+    newtests)      # this round's new GPU tests: several contexts in one process, the host-pointer pipeline, bench --gpus 2 with all legs
+      timeout 900 python -m pytest tests/test_gpu_corpus.py tests/test_bench_launch.py -m gpu -x -q 2>&1 | tail -5 ;;
+    hostfacing)    # end_to_end + single_block_us (the headline's line without extras)
+      timeout 600 python bench.py --no-extra --no-cpu-baseline --no-legs --steps 5 --warmup 2 2> $O/hostfacing.err | tee $O/hostfacing.json | line hostfacing; tail -3 $O/hostfacing.err ;;
+    n2)            # --gpus 2 on one device with every leg
+      ACHIP_BENCH_SHARE_DEVICE=1 timeout 900 python bench.py --gpus 2 --blocks 65536 --steps 3 --warmup 1 --no-extra --no-cpu-baseline > $O/n2.json 2> $O/n2.err; tail -3 $O/n2.err; cat $O/n2.json | line n2 ;;
+    hostsweep)     # the pageable host path over copy threads x chunk size, with its stage times
+      timeout 600 python tools/host_path_rate.py 0,4,8,16,32 96,192,384 2>&1 | grep -v amdgpu.ids | tee $O/hostsweep.txt ;;
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
+    zstd)          # the Zstd section + per-kernel times
+      timeout 500 bash tools/profile_zstd.sh r05zstd_$RANDOM --no-cpu-baseline > $O/zstd_line.txt 2>&1
+      for d in gpurun_out/prof_r05zstd_*; do cp $d/keep/dispatches.txt $O/zstd_dispatches.txt; cp $d/keep/*kernel_stats.csv $O/zstd_kernel_stats.csv; done
+      tail -c 1500 $O/zstd_line.txt
+      cat $O/zstd_dispatches.txt | awk 'NR>1{t[$1]+=$2; n[$1]++} END{for(k in t) printf "%-48s n=%d total_us=%.0f\n", k, n[k], t[k]}' | sort ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
