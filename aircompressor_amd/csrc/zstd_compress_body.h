@@ -300,83 +300,93 @@ __device__ int32_t fse_optimal_table_log(int32_t maxTableLog, int32_t inputSize,
     return result;
 }
 
-__device__ void fse_normalize_counts2(int16_t* norm, int32_t tableLog, const int32_t* counts, int32_t total, int32_t maxSymbol)  // :318-405
+// normalizeCounts2 :318-405 (the rarely taken second method) with a lane per symbol (maxSymbol < 64).  What the Java loops carry along are
+// sums over the symbols -- `distributed` (symbols given 1 / -1), `total` (what is left for the others) -- and, in the last loop, a running sum
+// of counts x rStep over the unassigned symbols: wave sums and one 64-bit wave scan.  The two corner endings: every symbol is a low one (the
+// first largest count takes the rest), and total == 0 (the rest goes round-robin over the positive symbols: each gets rest / K, the first
+// rest % K of them one more).  Every lane calls it (wave-uniform); the result is in norm[0 .. maxSymbol] after the caller's wave_sync().
+__device__ __forceinline__ int64_t wave_scan_incl_i64(int64_t x, int lane)
 {
-    constexpr int16_t UNASSIGNED = -2;
-    int32_t distributed = 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int32_t)(uint32_t)x, d), hi = (uint32_t)__shfl_up((int32_t)((uint64_t)x >> 32), d);
+        x += lane >= d ? (int64_t)(((uint64_t)hi << 32) | lo) : 0;
+    }
+    return x;
+}
+__device__ __forceinline__ int32_t wave_sum(int32_t x, int lane) { return sx::wave_bcast(sx::wave_scan_incl(x, lane), 63); }
+
+__device__ void fse_normalize_counts2(int16_t* norm, int32_t tableLog, const int32_t* counts, int32_t total, int32_t maxSymbol, int lane)
+{
+    const bool mine = lane <= maxSymbol;
+    const int32_t cnt = mine ? counts[lane] : 0;
     const int32_t lowThreshold = (int32_t)((uint32_t)total >> tableLog);
     int32_t lowOne = (int32_t)((uint32_t)(total * 3) >> (tableLog + 1));
-    for (int32_t i = 0; i <= maxSymbol; i++) {
-        const int32_t cnt = counts[i];
-        if (cnt == 0) {
-            norm[i] = 0;
-        }
-        else if (cnt <= lowThreshold) {
-            norm[i] = -1;
-            distributed++;
-            total -= cnt;
-        }
-        else if (cnt <= lowOne) {
-            norm[i] = 1;
-            distributed++;
-            total -= cnt;
-        }
-        else {
-            norm[i] = UNASSIGNED;
-        }
+    // first pass: 0 stays 0, counts up to lowThreshold get -1, up to lowOne get 1, the rest waits
+    int32_t value = 0;
+    bool open = false;  // not yet assigned
+    if (cnt != 0) {
+        if (cnt <= lowThreshold) value = -1;
+        else if (cnt <= lowOne) value = 1;
+        else open = true;
     }
+    bool low = mine && !open;  // counted in `distributed` (zeros are not: they add nothing to either sum)
+    int32_t distributed = wave_sum(mine && cnt != 0 && !open ? 1 : 0, lane);
+    total -= wave_sum(mine && cnt != 0 && !open ? cnt : 0, lane);
     const int32_t normalizationFactor = 1 << tableLog;
     int32_t toDistribute = normalizationFactor - distributed;
-    if ((total / toDistribute) > lowOne) {
+    if ((total / toDistribute) > lowOne) {  // (uniform) :351-361 -- a second, wider round of ones
         lowOne = (total * 3) / (toDistribute * 2);
-        for (int32_t i = 0; i <= maxSymbol; i++) {
-            if (norm[i] == UNASSIGNED && counts[i] <= lowOne) {
-                norm[i] = 1;
-                distributed++;
-                total -= counts[i];
-            }
+        const bool now = open && cnt <= lowOne;
+        if (now) {
+            value = 1;
+            open = false;
         }
+        distributed += wave_sum(now ? 1 : 0, lane);
+        total -= wave_sum(now ? cnt : 0, lane);
         toDistribute = normalizationFactor - distributed;
     }
-    if (distributed == maxSymbol + 1) {
-        int32_t maxValue = 0, maxCount = 0;
-        for (int32_t i = 0; i <= maxSymbol; i++) {
-            if (counts[i] > maxCount) {
-                maxValue = i;
-                maxCount = counts[i];
-            }
+    (void)low;
+    if (distributed == maxSymbol + 1) {  // (uniform) :363-378 -- nobody is left: the first of the largest counts takes the rest
+        int32_t top = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t other = __shfl_xor(top, d);
+            top = other > top ? other : top;
         }
-        norm[maxValue] = (int16_t)(norm[maxValue] + (int16_t)toDistribute);
-        return;
+        const int32_t first = top > 0 ? (int32_t)__builtin_ctzll(__ballot(mine && cnt == top)) : 0;
+        if (lane == first) {
+            value += toDistribute;
+        }
     }
-    if (total == 0) {
-        for (int32_t i = 0; toDistribute > 0; i = (i + 1) % (maxSymbol + 1)) {
-            if (norm[i] > 0) {
-                toDistribute--;
-                norm[i] = (int16_t)(norm[i] + 1);
-            }
+    else if (total == 0) {  // (uniform) :380-389 -- round-robin over the positive symbols, starting at symbol 0
+        const bool positive = mine && value > 0;
+        const unsigned long long pm = __ballot(positive);
+        const int32_t k = (int32_t)__popcll(pm);
+        if (positive && k > 0) {
+            const int32_t rank = (int32_t)__popcll(pm & ((1ull << lane) - 1ull));
+            value += toDistribute / k + (rank < toDistribute % k ? 1 : 0);
         }
-        return;
     }
-    const int64_t vStepLog = 62 - tableLog;
-    const int64_t mid = (1LL << (vStepLog - 1)) - 1;
-    const int64_t rStep = (((1LL << vStepLog) * toDistribute) + mid) / total;
-    int64_t tmpTotal = mid;
-    for (int32_t i = 0; i <= maxSymbol; i++) {
-        if (norm[i] == UNASSIGNED) {
-            const int64_t end = tmpTotal + ((int64_t)counts[i] * rStep);
-            const int32_t sStart = (int32_t)((uint64_t)tmpTotal >> vStepLog);
-            const int32_t sEnd = (int32_t)((uint64_t)end >> vStepLog);
-            norm[i] = (int16_t)(sEnd - sStart);
-            tmpTotal = end;
+    else {  // :391-404 -- the rest in proportion, by a running total of count x rStep in 62 - tableLog fixed-point bits
+        const int64_t vStepLog = 62 - tableLog;
+        const int64_t mid = (1LL << (vStepLog - 1)) - 1;
+        const int64_t rStep = (((1LL << vStepLog) * toDistribute) + mid) / total;
+        const int64_t weight = open ? (int64_t)cnt * rStep : 0;
+        const int64_t end = mid + wave_scan_incl_i64(weight, lane);
+        if (open) {
+            value = (int32_t)((uint64_t)end >> vStepLog) - (int32_t)((uint64_t)(end - weight) >> vStepLog);
         }
+    }
+    if (mine) {
+        norm[lane] = (int16_t)value;
     }
 }
 
 // normalizeCounts :257-316 with a lane per symbol (every caller has at most 53 symbols: sequence codes, Huffman weights).  The Java loop's
 // running values are a sum and a first-maximum over the symbols: `stillToDistribute` = table size - (probabilities + one per low symbol),
 // `largest` = the first symbol whose probability exceeds all before it (:291-294; symbol 0 when none is rated).  The second method
-// (:318-405: when the correction would take more than half of the largest probability) is rare and stays the Java loop, run by every lane alike.
+// (:318-405: when the correction would take more than half of the largest probability) is rare; it is lane-parallel as well (above).
 __device__ void fse_normalize_counts(int16_t* norm, int32_t tableLog, const int32_t* counts, int32_t total, int32_t maxSymbol, int lane)
 {
     const int64_t scale = 62 - tableLog;
@@ -416,7 +426,7 @@ __device__ void fse_normalize_counts(int16_t* norm, int32_t tableLog, const int3
     const int32_t largest = top > 0 ? (int32_t)__builtin_ctzll(holders) : 0;
     const int32_t largestValue = __shfl(value, largest);
     if (-stillToDistribute >= (int32_t)((uint32_t)largestValue >> 1)) {  // (uniform)
-        fse_normalize_counts2(norm, tableLog, counts, total, maxSymbol);
+        fse_normalize_counts2(norm, tableLog, counts, total, maxSymbol, lane);
     }
     else if (mine) {
         norm[lane] = (int16_t)(lane == largest ? value + stillToDistribute : value);
@@ -424,79 +434,89 @@ __device__ void fse_normalize_counts(int16_t* norm, int32_t tableLog, const int3
     wave_sync();
 }
 
-// writeNormalizedCounts :407-521 ; returns bytes written or -1
-__device__ int32_t fse_write_normalized_counts(Ctx& c, uint8_t* base, int32_t outputAddress, int32_t outputSize, const int16_t* norm, int32_t maxSymbol, int32_t tableLog)
+// writeNormalizedCounts :407-521 with a lane per symbol (maxSymbol < 64); returns bytes written or -1.
+// The Java loop appends bit fields to a 32-bit accumulator and stores two bytes whenever more than 16 bits are pending -- the stream is the
+// plain concatenation of the fields, least significant bit first, and everything a field depends on is a prefix sum over the symbols before it:
+//   remaining(s) = tableSize + 1 - sum of |norm[i]| for i < s        (the loop runs while remaining > 1)
+//   threshold(s) = the largest power of two <= remaining(s), at most tableSize; a field is log2(threshold) + 1 bits, one less for a small value
+//   a symbol is written unless it is a zero BEHIND a zero: a run of zeros is its first zero's field followed by the run's length -- 16 one-bits
+//   per 24 further zeros, two one-bits per 3, two bits for the rest (:437-466)
+// so every lane builds its symbol's bits (<= 62: a field of <= 10 bits, a run code of <= 48, the 4-bit table log in front of symbol 0), a scan
+// of the widths places them, ds_or puts them into a zeroed window of words (sh.cumulative: idle between a table's initialisation and the next),
+// whole bytes leave with one store per lane.  The size checks of the Java loop (two bytes must fit at every store, and once more at the end)
+// amount to 2 * floor((bits - 1) / 16) + 2 <= outputSize.
+__device__ int32_t fse_write_normalized_counts(Ctx& c, Shared& sh, uint8_t* base, int32_t outputAddress, int32_t outputSize, const int16_t* norm, int32_t maxSymbol, int32_t tableLog)
 {
-    int32_t output = outputAddress;
-    const int64_t outputLimit = (int64_t)outputAddress + outputSize;
+    const int lane = c.lane;
+    uint32_t* const window = (uint32_t*)&sh.cumulative[0];  // 64 words
+    wave_sync();
+    window[lane] = 0;
+    const bool mine = lane <= maxSymbol;
+    const int32_t value = mine ? (int32_t)norm[lane] : 0;
+    const int32_t magnitude = value < 0 ? -value : value;
     const int32_t tableSize = 1 << tableLog;
-    int32_t bitCount = 0;
-    int32_t bitStream = tableLog - 5;
-    bitCount += 4;
-    int32_t remaining = tableSize + 1;
-    int32_t threshold = tableSize;
-    int32_t tableBitCount = tableLog + 1;
-    int32_t symbol = 0;
-    bool previousIs0 = false;
-    while (remaining > 1) {
-        if (previousIs0) {
-            int32_t start = symbol;
-            while (norm[symbol] == 0) {
-                symbol++;
-            }
-            while (symbol >= start + 24) {
-                start += 24;
-                bitStream |= (int32_t)(0xFFFFu << (bitCount & 31));
-                ZC_CHECK(c, (int64_t)output + 2 <= outputLimit);
-                st2(base + output, (uint32_t)bitStream);
-                output += 2;
-                bitStream = (int32_t)((uint32_t)bitStream >> 16);
-            }
-            while (symbol >= start + 3) {
-                start += 3;
-                bitStream |= (int32_t)(3u << (bitCount & 31));
-                bitCount += 2;
-            }
-            bitStream |= (int32_t)((uint32_t)(symbol - start) << (bitCount & 31));
-            bitCount += 2;
-            if (bitCount > 16) {
-                ZC_CHECK(c, (int64_t)output + 2 <= outputLimit);
-                st2(base + output, (uint32_t)bitStream);
-                output += 2;
-                bitStream = (int32_t)((uint32_t)bitStream >> 16);
-                bitCount -= 16;
-            }
-        }
-        int32_t count = norm[symbol++];
+    const int32_t before = sx::wave_scan_incl(magnitude, lane) - magnitude;
+    const int32_t remaining = tableSize + 1 - before;
+    const bool inLoop = mine && remaining > 1;
+    const unsigned long long zeros = __ballot(mine && value == 0);
+    const unsigned long long nonZeros = __ballot(mine && value != 0);
+    const bool behindZero = lane > 0 && ((zeros >> (lane - 1)) & 1ull) != 0;
+    const bool written = inLoop && !(value == 0 && behindZero);
+    uint64_t bits = 0;
+    int32_t width = 0;
+    if (written) {
+        int32_t threshold = 1 << highest_bit((uint32_t)remaining);
+        threshold = threshold > tableSize ? tableSize : threshold;
+        const int32_t fieldBits = highest_bit((uint32_t)threshold) + 1;
         const int32_t max = (2 * threshold - 1) - remaining;
-        remaining -= count < 0 ? -count : count;
-        count++;
+        int32_t count = value + 1;
         if (count >= threshold) {
             count += max;
         }
-        bitStream |= (int32_t)((uint32_t)count << (bitCount & 31));
-        bitCount += tableBitCount;
-        bitCount -= (count < max ? 1 : 0);
-        previousIs0 = (count == 1);
-        while (remaining < threshold) {
-            tableBitCount--;
-            threshold >>= 1;
-        }
-        if (bitCount > 16) {
-            ZC_CHECK(c, (int64_t)output + 2 <= outputLimit);
-            st2(base + output, (uint32_t)bitStream);
-            output += 2;
-            bitStream = (int32_t)((uint32_t)bitStream >> 16);
-            bitCount -= 16;
+        bits = (uint64_t)(uint32_t)count;
+        width = fieldBits - (count < max ? 1 : 0);
+        if (value == 0) {
+            // the zeros that follow this one, up to the next symbol that is not zero (there is one: remaining > 1)
+            const unsigned long long above = nonZeros >> lane;  // (bit 0 is this lane: a zero)
+            const int32_t run = above != 0 ? (int32_t)__builtin_ctzll(above) - 1 : 0;
+            const int32_t ones = 16 * (run / 24) + 2 * ((run % 24) / 3);
+            const uint64_t code = ((1ull << ones) - 1ull) | ((uint64_t)((run % 24) % 3) << ones);
+            bits |= code << width;
+            width += ones + 2;
         }
     }
-    ZC_CHECK(c, (int64_t)output + 2 <= outputLimit);
-    // the Java code stores 2 bytes and advances by (bitCount + 7) / 8 of them
-    const int32_t adv = (bitCount + 7) / 8;
-    st_le(base + output, (uint32_t)bitStream & 0xFFFFu, adv < 2 ? adv : 2);
-    output += adv;
-    ZC_CHECK(c, symbol <= maxSymbol + 1);
-    return output - outputAddress;
+    if (lane == 0) {  // the table log leads the stream (:414-416)
+        bits = (bits << 4) | (uint64_t)(uint32_t)(tableLog - 5);
+        width += 4;
+    }
+    const int32_t end = sx::wave_scan_incl(width, lane);
+    const int32_t total = sx::wave_bcast(end, 63);
+    // the loop must have ended inside the table (:518-520: "Error"; normalized counts that do not add up to the table size would run off its end)
+    const int32_t last = 63 - (int32_t)__builtin_clzll(__ballot(inLoop) | 1ull);
+    const int32_t lastMagnitude = sx::wave_bcast(magnitude, last);
+    const int32_t lastRemaining = sx::wave_bcast(remaining, last);
+    ZC_CHECK(c, lastRemaining - lastMagnitude <= 1);
+    ZC_CHECK(c, 2 * ((total - 1) / 16) + 2 <= outputSize);
+    wave_sync();
+    if (width > 0) {
+        const int32_t at = end - width;
+        const int32_t word = at >> 5, shift = at & 31;
+        atomicOr(&window[word], (uint32_t)(bits << shift));
+        const uint64_t rest = shift == 0 ? (bits >> 32) : (bits >> (32 - shift));
+        if ((uint32_t)rest != 0) {
+            atomicOr(&window[word + 1], (uint32_t)rest);
+        }
+        if ((uint32_t)(rest >> 32) != 0) {
+            atomicOr(&window[word + 2], (uint32_t)(rest >> 32));
+        }
+    }
+    wave_sync();
+    const int32_t bytes = (total + 7) / 8;
+    for (int32_t k = lane; k < bytes; k += 64) {
+        base[outputAddress + k] = (uint8_t)(window[k >> 2] >> (8 * (k & 3)));
+    }
+    wave_sync();
+    return bytes;
 }
 
 // FiniteStateEntropy.compress :158-234 over the Huffman weights (<= 255 symbols, LDS)
@@ -592,157 +612,225 @@ __device__ int32_t huf_optimal_number_of_bits(int32_t maxNumberOfBits, int32_t i
     return result;
 }
 
-__device__ int32_t huf_build_tree(Shared& sh, int32_t maxSymbol)  // buildTree :105-190 (counts in sh.counts)
+// buildTree :105-190 (counts in sh.counts; returns lastNonZero).  What the Java method computes, in three parts:
+//   order   the symbols by falling count, equal counts by rising symbol -- except that symbol 0 keeps position 0 whatever its count (the
+//           insertion sort never moves an entry below position 1: `position > 1`).  Here every lane RANKS its symbols: position = 1 + symbols
+//           (other than 0) with a larger count + earlier symbols (other than 0) with the same count; no entry is ever moved.
+//   merge   Huffman's two queues: the leaves from the rarest up (position lastNonZero down to 0) and the inner nodes in the order they were made
+//           (from 256 up), the smaller head first, an inner node on a tie.  A chain by construction: one lane walks it.
+//   depth   a node's code length is its distance from the root: pointer jumping over the parent links (every lane eight nodes: depth += depth of
+//           where the link points, link = the link's link, until every link points at the root) instead of a walk down from the root.
+__device__ int32_t huf_build_tree(Shared& sh, int32_t maxSymbol)
 {
+    const int lane = (int)threadIdx.x & 63;
+    constexpr int32_t INNER = 256;  // the first inner node
     __syncthreads();
-    for (int32_t i = (int32_t)threadIdx.x; i < 512; i += 64) {  // NodeTable.reset(), lanes split the clear
+    for (int32_t i = lane; i < 512; i += 64) {  // NodeTable.reset()
         sh.nodeCount[i] = 0;
         sh.nodeParent[i] = 0;
         sh.nodeSymbol[i] = 0;
         sh.nodeBits[i] = 0;
     }
     __syncthreads();
-    int32_t current = 0;
-    for (int32_t symbol = 0; symbol <= maxSymbol; symbol++) {
-        const int32_t count = sh.counts[symbol];
-        int32_t position = current;
-        while (position > 1 && count > sh.nodeCount[position - 1]) {
-            sh.nodeCount[position] = sh.nodeCount[position - 1];
-            sh.nodeParent[position] = sh.nodeParent[position - 1];
-            sh.nodeSymbol[position] = sh.nodeSymbol[position - 1];
-            sh.nodeBits[position] = sh.nodeBits[position - 1];
-            position--;
-        }
-        sh.nodeCount[position] = count;
-        sh.nodeSymbol[position] = (int16_t)symbol;
-        current++;
+    // ---- order ----
+    int32_t mine[4], place[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int32_t sym = lane + 64 * j;
+        mine[j] = sym <= maxSymbol ? sh.counts[sym] : -1;
+        place[j] = sym == 0 ? 0 : 1;
     }
-    int32_t lastNonZero = maxSymbol;
-    while (sh.nodeCount[lastNonZero] == 0) {
-        lastNonZero--;
-    }
-    const int32_t nonLeafStart = 256;
-    current = nonLeafStart;
-    int32_t currentLeaf = lastNonZero;
-    int32_t currentNonLeaf = current;
-    sh.nodeCount[current] = sh.nodeCount[currentLeaf] + sh.nodeCount[currentLeaf - 1];
-    sh.nodeParent[currentLeaf] = (int16_t)current;
-    sh.nodeParent[currentLeaf - 1] = (int16_t)current;
-    current++;
-    currentLeaf -= 2;
-    const int32_t root = 256 + lastNonZero - 1;
-    for (int32_t n = current; n <= root; n++) {
-        sh.nodeCount[n] = 1 << 30;
-    }
-    while (current <= root) {
-        int32_t child1, child2;
-        if (currentLeaf >= 0 && sh.nodeCount[currentLeaf] < sh.nodeCount[currentNonLeaf]) {
-            child1 = currentLeaf--;
+    for (int32_t t = 1; t <= maxSymbol; t++) {
+        const int32_t other = sh.counts[t];  // (one address for the wavefront: a broadcast)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int32_t sym = lane + 64 * j;
+            place[j] += (other > mine[j] || (other == mine[j] && t < sym)) ? 1 : 0;
         }
-        else {
-            child1 = currentNonLeaf++;
-        }
-        if (currentLeaf >= 0 && sh.nodeCount[currentLeaf] < sh.nodeCount[currentNonLeaf]) {
-            child2 = currentLeaf--;
-        }
-        else {
-            child2 = currentNonLeaf++;
-        }
-        sh.nodeCount[current] = sh.nodeCount[child1] + sh.nodeCount[child2];
-        sh.nodeParent[child1] = (int16_t)current;
-        sh.nodeParent[child2] = (int16_t)current;
-        current++;
     }
-    sh.nodeBits[root] = 0;
-    for (int32_t n = root - 1; n >= nonLeafStart; n--) {
-        sh.nodeBits[n] = (uint8_t)(sh.nodeBits[sh.nodeParent[n]] + 1);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int32_t sym = lane + 64 * j;
+        if (sym <= maxSymbol) {
+            const int32_t at = sym == 0 ? 0 : place[j];
+            sh.nodeCount[at] = mine[j];
+            sh.nodeSymbol[at] = (int16_t)sym;
+        }
     }
-    for (int32_t n = 0; n <= lastNonZero; n++) {
-        sh.nodeBits[n] = (uint8_t)(sh.nodeBits[sh.nodeParent[n]] + 1);
+    __syncthreads();
+    // the last position that holds a count
+    int32_t lastNonZero = 0;
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+        const int32_t pos = lane + 64 * j;
+        const unsigned long long holders = __ballot(pos <= maxSymbol && sh.nodeCount[pos] != 0);
+        if (holders != 0 && lastNonZero == 0) {
+            lastNonZero = 64 * j + 63 - (int32_t)__builtin_clzll(holders);
+        }
+    }
+    const int32_t root = INNER + lastNonZero - 1;
+    // ---- merge ----
+    if (lane == 0) {
+        int32_t leaf = lastNonZero;  // head of the leaf queue (runs down to 0)
+        int32_t inner = INNER;       // head of the inner-node queue
+        for (int32_t made = INNER; made <= root; made++) {
+            int32_t child[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                // (the inner queue is empty while inner == made: its head then counts as larger than any leaf -- the Java table holds 1 << 30 there)
+                const bool takeLeaf = leaf >= 0 && (inner >= made || sh.nodeCount[leaf] < sh.nodeCount[inner]);
+                child[k] = takeLeaf ? leaf-- : inner++;
+            }
+            sh.nodeCount[made] = sh.nodeCount[child[0]] + sh.nodeCount[child[1]];
+            sh.nodeParent[child[0]] = (int16_t)made;
+            sh.nodeParent[child[1]] = (int16_t)made;
+        }
+    }
+    __syncthreads();
+    // ---- depth ---- (nodes in use: the leaves 0 .. lastNonZero, the inner nodes 256 .. root; the root links to itself)
+    int32_t link[8], depth[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int32_t n = lane + 64 * j;
+        const bool used = (n <= lastNonZero) || (n >= INNER && n < root);
+        link[j] = used ? (int32_t)sh.nodeParent[n] : root;
+        depth[j] = used ? 1 : 0;
+    }
+    for (;;) {  // (uniform)
+        bool moved = false;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int32_t n = lane + 64 * j;
+            sh.nodeParent[n] = (int16_t)link[j];
+            sh.nodeBits[n] = (uint8_t)depth[j];
+            moved |= link[j] != root;
+        }
+        __syncthreads();
+        if (__ballot(moved) == 0) {
+            break;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int32_t up = link[j];
+            depth[j] += (int32_t)sh.nodeBits[up];
+            link[j] = (int32_t)sh.nodeParent[up];
+        }
+        __syncthreads();
     }
     return lastNonZero;
 }
 
-__device__ int32_t huf_set_max_height(Shared& sh, int32_t lastNonZero, int32_t maxNumberOfBits)  // :294-390
+// setMaxHeight :294-390.  Code lengths beyond maxNumberOfBits are cut to it (the leaves are in order of falling count, so these are the last
+// ones); every cut overdraws the Kraft budget by baseCost - 2^(largestBits - length), and the debt -- in units of the deepest allowed code -- is paid
+// back by making other leaves one bit longer: always the LAST leaf of some shorter length (rankLast[d] for length maxNumberOfBits - d), chosen
+// per step by comparing what a lengthening costs in weighted length.  Here: the cuts, their cost and the rankLast table by ballots over the
+// leaves (a lane per leaf, four rounds); the repayment holds rankLast[d] in lane d, a step's choice is two ballots (where the downward scan
+// stops, the first rank at or above it that has a leaf) and only the chosen lanes change anything.
+__device__ int32_t huf_set_max_height(Shared& sh, int32_t lastNonZero, int32_t maxNumberOfBits)
 {
+    const int lane = (int)threadIdx.x & 63;
     const int32_t largestBits = sh.nodeBits[lastNonZero];
-    if (largestBits <= maxNumberOfBits) {
+    if (largestBits <= maxNumberOfBits) {  // (uniform)
         return largestBits;
     }
-    int32_t totalCost = 0;
+    constexpr int32_t NONE = (int32_t)0xF0F0F0F0;
+    // ---- the cuts: the run of leaves longer than allowed at the end of the table, and the first leaf below it that is shorter than allowed ----
+    int32_t bitsOf[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int32_t pos = lane + 64 * j;
+        bitsOf[j] = pos <= lastNonZero ? (int32_t)sh.nodeBits[pos] : 0;
+    }
+    auto highest = [&](auto&& pred) -> int32_t {  // the highest leaf position <= lastNonZero for which pred(j) holds on its lane (-1: none)
+        int32_t found = -1;
+#pragma unroll
+        for (int j = 3; j >= 0; j--) {
+            const unsigned long long m = __ballot(lane + 64 * j <= lastNonZero && pred(j));
+            if (m != 0 && found < 0) {
+                found = 64 * j + 63 - (int32_t)__builtin_clzll(m);
+            }
+        }
+        return found;
+    };
+    const int32_t keep = highest([&](int j) { return bitsOf[j] <= maxNumberOfBits; });  // everything above it is cut
     const int32_t baseCost = 1 << (largestBits - maxNumberOfBits);
-    int32_t n = lastNonZero;
-    while (sh.nodeBits[n] > maxNumberOfBits) {
-        totalCost += baseCost - (1 << (largestBits - sh.nodeBits[n]));
-        sh.nodeBits[n] = (uint8_t)maxNumberOfBits;
-        n--;
-    }
-    while (sh.nodeBits[n] == maxNumberOfBits) {
-        n--;
-    }
-    totalCost = (int32_t)((uint32_t)totalCost >> (largestBits - maxNumberOfBits));
-    const int32_t noSymbol = (int32_t)0xF0F0F0F0;
-    for (int i = 0; i < 14; i++) {
-        sh.rankLast[i] = noSymbol;
-    }
-    int32_t currentNbBits = maxNumberOfBits;
-    for (int32_t pos = n; pos >= 0; pos--) {
-        if (sh.nodeBits[pos] >= currentNbBits) {
-            continue;
+    int32_t cost = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int32_t pos = lane + 64 * j;
+        if (pos > keep && pos <= lastNonZero) {
+            cost += baseCost - (1 << (largestBits - bitsOf[j]));
+            bitsOf[j] = maxNumberOfBits;
+            sh.nodeBits[pos] = (uint8_t)maxNumberOfBits;
         }
-        currentNbBits = sh.nodeBits[pos];
-        sh.rankLast[maxNumberOfBits - currentNbBits] = pos;
     }
-    while (totalCost > 0) {
-        int32_t dec = highest_bit((uint32_t)totalCost) + 1;
-        for (; dec > 1; dec--) {
-            const int32_t highPosition = sh.rankLast[dec];
-            const int32_t lowPosition = sh.rankLast[dec - 1];
-            if (highPosition == noSymbol) {
-                continue;
-            }
-            if (lowPosition == noSymbol) {
-                break;
-            }
-            const int32_t highTotal = sh.nodeCount[highPosition];
-            const int32_t lowTotal = 2 * sh.nodeCount[lowPosition];
-            if (highTotal <= lowTotal) {
-                break;
-            }
+    int32_t totalCost = (int32_t)((uint32_t)wave_sum(cost, lane) >> (largestBits - maxNumberOfBits));
+    int32_t n = highest([&](int j) { return lane + 64 * j <= keep && bitsOf[j] != maxNumberOfBits; });  // the last leaf shorter than allowed
+    // ---- rankLast[d]: the last leaf of length maxNumberOfBits - d, where no later leaf (up to n) is as short or shorter ----
+    // (lane d works out its own entry: the highest position of its length, valid if every shorter length's highest position lies below it)
+    int32_t lastOf = -1;  // lane b: the highest position <= n whose length is b
+    for (int32_t b = 1; b < maxNumberOfBits; b++) {  // (uniform; at most 11 rounds of four ballots)
+        const int32_t at = highest([&](int j) { return lane + 64 * j <= n && bitsOf[j] == b; });
+        lastOf = lane == b ? at : lastOf;
+    }
+    int32_t shorterAbove = -1;  // the highest position of any shorter length
+    for (int32_t b = 1; b < maxNumberOfBits; b++) {
+        const int32_t at = __shfl(lastOf, b);
+        shorterAbove = (b < maxNumberOfBits - lane && at > shorterAbove) ? at : shorterAbove;
+    }
+    const int32_t myLength = maxNumberOfBits - lane;  // lane d holds rankLast[d]
+    const int32_t ownLast = __shfl(lastOf, myLength > 0 && myLength < 64 ? myLength : 0);
+    int32_t rank = (lane >= 1 && myLength >= 1 && ownLast >= 0 && ownLast > shorterAbove) ? ownLast : NONE;
+    __syncthreads();
+    // ---- repayment ----
+    while (totalCost > 0) {  // (uniform)
+        const int32_t start = highest_bit((uint32_t)totalCost) + 1;
+        const int32_t below = __shfl(rank, lane > 0 ? lane - 1 : 0);  // rankLast[d - 1]
+        // the downward scan (:334-349) stops at the first d <= start that has a leaf and whose neighbour below has none or costs at least half as much
+        bool stops = false;
+        if (lane > 1 && lane <= start && rank != NONE) {
+            stops = below == NONE || sh.nodeCount[rank] <= 2 * sh.nodeCount[below];
         }
-        while ((dec <= 12) && (sh.rankLast[dec] == noSymbol)) {
-            dec++;
-        }
+        const unsigned long long stopMask = __ballot(stops);
+        int32_t dec = stopMask != 0 ? 63 - (int32_t)__builtin_clzll(stopMask) : 1;
+        // ... and moves up to the first rank that has a leaf (:351-353), 13 when none has
+        const unsigned long long have = __ballot(rank != NONE && lane >= dec && lane <= 12);
+        dec = have != 0 ? (int32_t)__builtin_ctzll(have) : 13;
         totalCost -= 1 << (dec - 1);
-        if (sh.rankLast[dec - 1] == noSymbol) {
-            sh.rankLast[dec - 1] = sh.rankLast[dec];
+        const int32_t at = __shfl(rank, dec);
+        if (at == NONE) {  // (no leaf left to lengthen: the Java loop would index its table with the marker and throw; not reachable from counts that sum up)
+            break;
         }
-        const int32_t at = sh.rankLast[dec];
-        sh.nodeBits[at] = (uint8_t)(sh.nodeBits[at] + 1);
-        if (at == 0) {
-            sh.rankLast[dec] = noSymbol;
+        const int32_t belowDec = __shfl(rank, dec - 1);
+        if (lane == dec - 1 && belowDec == NONE) {
+            rank = at;  // the lengthened leaf becomes the last of its new length
         }
-        else {
-            sh.rankLast[dec] = at - 1;
-            if (sh.nodeBits[at - 1] != maxNumberOfBits - dec) {
-                sh.rankLast[dec] = noSymbol;
-            }
+        if (lane == dec) {
+            sh.nodeBits[at] = (uint8_t)(sh.nodeBits[at] + 1);
+            rank = (at == 0 || (int32_t)sh.nodeBits[at - 1] != maxNumberOfBits - dec) ? NONE : at - 1;
         }
+        __syncthreads();
     }
-    while (totalCost < 0) {
-        if (sh.rankLast[1] == noSymbol) {
-            while (sh.nodeBits[n] == maxNumberOfBits) {
-                n--;
+    // ---- overpaid (:373-388): give a bit back, to the first leaf of the deepest length but one ----
+    if (totalCost < 0) {  // (uniform)
+        int32_t rank1 = __shfl(rank, 1);
+        if (lane == 0) {
+            while (totalCost < 0) {
+                if (rank1 == NONE) {
+                    while ((int32_t)sh.nodeBits[n] == maxNumberOfBits) {
+                        n--;
+                    }
+                    sh.nodeBits[n + 1] = (uint8_t)(sh.nodeBits[n + 1] - 1);
+                    rank1 = n + 1;
+                }
+                else {
+                    rank1++;
+                    sh.nodeBits[rank1] = (uint8_t)(sh.nodeBits[rank1] - 1);
+                }
+                totalCost++;
             }
-            sh.nodeBits[n + 1] = (uint8_t)(sh.nodeBits[n + 1] - 1);
-            sh.rankLast[1] = n + 1;
-            totalCost++;
-            continue;
         }
-        const int32_t at = sh.rankLast[1] + 1;
-        sh.nodeBits[at] = (uint8_t)(sh.nodeBits[at] - 1);
-        sh.rankLast[1] = at;
-        totalCost++;
+        __syncthreads();
     }
     return maxNumberOfBits;
 }
@@ -825,7 +913,7 @@ __device__ int32_t huf_compress_weights(Ctx& c, Shared& sh, uint8_t* base, int32
     fse_normalize_counts(normLds, tableLog, countsLds, weightsLength, maxSymbol, c.lane);
     int32_t output = outputAddress;
     const int32_t outputLimit = outputAddress + outputSize;
-    const int32_t headerSize = fse_write_normalized_counts(c, base, output, outputSize, normLds, maxSymbol, tableLog);
+    const int32_t headerSize = fse_write_normalized_counts(c, sh, base, output, outputSize, normLds, maxSymbol, tableLog);
     ZC_PROPAGATE(headerSize);
     output += headerSize;
     fse_initialize(sh, sh.wt, normLds, maxSymbol, tableLog);
@@ -1162,7 +1250,7 @@ __device__ int32_t build_compression_table(Ctx& c, Shared& sh, FseCTable& table,
     }
     fse_normalize_counts(sh.norm, tableLog, sh.counts, sequenceCount, maxSymbol, c.lane);
     fse_initialize(sh, table, sh.norm, maxSymbol, tableLog);
-    return fse_write_normalized_counts(c, base, output, (int32_t)(outputLimit - output), sh.norm, maxSymbol, tableLog);
+    return fse_write_normalized_counts(c, sh, base, output, (int32_t)(outputLimit - output), sh.norm, maxSymbol, tableLog);
 }
 
 __device__ int32_t compress_sequences(Ctx& c, Shared& sh, uint8_t* base, int32_t outputAddress, int32_t outputSize)

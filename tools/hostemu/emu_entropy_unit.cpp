@@ -1,0 +1,72 @@
+// tools/hostemu/emu_entropy_unit.cpp -- the Zstd encoder's wave-parallel entropy helpers (zstd_compress_body.h: the Huffman table build with its
+// height limiter, normalizeCounts with its second method, writeNormalizedCounts) one function at a time under the fiber emulator, so that
+// tools/hostemu/check_entropy_unit.py can hold each against the oracle's restatement of the Java method on hundreds of thousands of count sets
+// -- including the rare paths (the height limiter's repayment, normalizeCounts2's three endings) that whole-frame inputs seldom reach.
+// Built like emu_enc.cpp (every memory access a soft order point: the untouched serial parts around these helpers run the same code on all lanes):
+//   clang++ -O2 -std=c++17 -fPIC -shared -fno-omit-frame-pointer -fsanitize-coverage=inline-8bit-counters,trace-loads,trace-stores -I tools/hostemu -I include \
+//           -I aircompressor_amd/csrc -o tools/hostemu/libemu_entropy_unit.so tools/hostemu/emu_entropy_unit.cpp
+#define HOSTEMU_ACCESS_LOCKSTEP 1
+#define HOSTEMU_ORDER_IS_RENDEZVOUS 1
+#include "hip/hip_runtime.h"
+thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+extern "C" { long long achip_emu_counters[16]; }
+#include "../../aircompressor_amd/csrc/zstd_compress.hip"
+
+namespace achip {
+namespace {
+__global__ void unit_huf_kernel(const int32_t* counts, int32_t maxSymbol, int32_t maxBits, uint8_t* bitsOut, int16_t* valuesOut, int32_t* maxBitsOut)
+{
+    __shared__ zc::Shared sh;
+    const int lane = (int)threadIdx.x;
+    for (int i = lane; i < 256; i += 64) sh.counts[i] = i <= maxSymbol ? counts[i] : 0;
+    __syncthreads();
+    zc::huf_table_initialize(sh, sh.huf[0], maxSymbol, maxBits);
+    __syncthreads();
+    for (int i = lane; i <= maxSymbol; i += 64) {
+        bitsOut[i] = sh.huf[0].numberOfBits[i];
+        valuesOut[i] = sh.huf[0].values[i];
+    }
+    if (lane == 0) *maxBitsOut = sh.huf[0].maxNumberOfBits;
+}
+__global__ void unit_norm_kernel(const int32_t* counts, int32_t total, int32_t maxSymbol, int32_t tableLog, int32_t forceSecond, int16_t* normOut)
+{
+    __shared__ zc::Shared sh;
+    const int lane = (int)threadIdx.x;
+    if (lane <= maxSymbol) sh.counts[lane] = counts[lane];
+    __syncthreads();
+    if (forceSecond) {
+        zc::fse_normalize_counts2(sh.norm, tableLog, sh.counts, total, maxSymbol, lane);
+    }
+    else {
+        zc::fse_normalize_counts(sh.norm, tableLog, sh.counts, total, maxSymbol, lane);
+    }
+    __syncthreads();
+    if (lane <= maxSymbol) normOut[lane] = sh.norm[lane];
+}
+__global__ void unit_write_kernel(const int16_t* norm, int32_t maxSymbol, int32_t tableLog, uint8_t* out, int32_t cap, int32_t* sizeOut)
+{
+    __shared__ zc::Shared sh;
+    const int lane = (int)threadIdx.x;
+    if (lane <= maxSymbol) sh.norm[lane] = norm[lane];
+    __syncthreads();
+    zc::Ctx c;
+    c.lane = lane;
+    c.failStatus = 0;
+    const int32_t n = zc::fse_write_normalized_counts(c, sh, out, 0, cap, sh.norm, maxSymbol, tableLog);
+    if (lane == 0) *sizeOut = n;
+}
+}  // namespace
+}  // namespace achip
+
+extern "C" void unit_huf(const int32_t* counts, int32_t maxSymbol, int32_t maxBits, uint8_t* bitsOut, int16_t* valuesOut, int32_t* maxBitsOut)
+{
+    hipLaunchKernelGGL(achip::unit_huf_kernel, dim3(1), dim3(64), 0, nullptr, counts, maxSymbol, maxBits, bitsOut, valuesOut, maxBitsOut);
+}
+extern "C" void unit_norm(const int32_t* counts, int32_t total, int32_t maxSymbol, int32_t tableLog, int32_t forceSecond, int16_t* normOut)
+{
+    hipLaunchKernelGGL(achip::unit_norm_kernel, dim3(1), dim3(64), 0, nullptr, counts, total, maxSymbol, tableLog, forceSecond, normOut);
+}
+extern "C" void unit_write(const int16_t* norm, int32_t maxSymbol, int32_t tableLog, uint8_t* out, int32_t cap, int32_t* sizeOut)
+{
+    hipLaunchKernelGGL(achip::unit_write_kernel, dim3(1), dim3(64), 0, nullptr, norm, maxSymbol, tableLog, out, cap, sizeOut);
+}

@@ -28,6 +28,9 @@ for step in "$@"; do
       ACHIP_BENCH_SHARE_DEVICE=1 timeout 900 python bench.py --gpus 2 --blocks 65536 --steps 3 --warmup 1 --no-extra --no-cpu-baseline > $O/n2.json 2> $O/n2.err; tail -3 $O/n2.err; cat $O/n2.json | line n2 ;;
     hostsweep)     # the pageable host path over copy threads x chunk size, with its stage times
       timeout 600 python tools/host_path_rate.py 0,4,8,16,32 96,192,384 2>&1 | grep -v amdgpu.ids | tee $O/hostsweep.txt ;;
+    encfuzz)       # the Zstd encoder after the entropy helpers' rewrite: GPU tests of the encoder + differential fuzz (bytes against the oracle)
+      timeout 900 python -m pytest tests/test_gpu_zstd.py tests/test_gpu_zstd_stream.py tests/test_gpu_corpus.py -m gpu -x -q 2>&1 | tail -3
+      timeout 900 python tools/fuzz_encoders.py 2>&1 | tail -12 | tee $O/fuzz_encoders.txt ;;
     tests)
       timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
     zstd)          # the Zstd section + per-kernel times
