@@ -213,59 +213,101 @@ __device__ void fse_init_rle(FseCTable& t, int32_t symbol)  // :46-55
     t.deltaNumberOfBits[symbol] = 0;
 }
 
-// initialize :57-117 ; norm read through a pointer so the predefined distributions can come from constant memory
+// FseCompressionTable.initialize :57-117 by the wavefront (norm read through a pointer so the predefined distributions can come from constant
+// memory; maxSymbol < 64, table log <= 9).  The Java method spreads the symbols over the table by a walk, then hands every symbol's states its
+// slots in position order.  Closed forms, as in the decoder's table build (zstd_dec_common.h fse_build):
+//   * per SYMBOL (a lane each): slots before it = states before it (one for a "less than one" symbol, which takes a top position in symbol order),
+//     the two deltas from that running total;
+//   * per POSITION (a lane each, 64 at a time): the walk  position = (position + step) & mask  makes position u its j(u)-th stop, j(u) = u * step^-1
+//     mod size; stops on the top positions are skipped, so u is the k-th position filled, k = j(u) - (top positions stopped at earlier); the symbol
+//     is the one whose run of filled positions covers k;
+//   * nextState[slot of the symbol + rank of u among the symbol's positions] = size + u, the rank by ballots over 64 positions and a running count.
 __device__ void fse_initialize(Shared& sh, FseCTable& t, const int16_t* norm, int32_t maxSymbol, int32_t tableLog)
 {
-    const int32_t tableSize = 1 << tableLog;
-    int32_t highThreshold = tableSize - 1;
-    t.log2Size = tableLog;
-    sh.cumulative[0] = 0;
-    for (int32_t i = 1; i <= maxSymbol + 1; i++) {
-        if (norm[i - 1] == -1) {
-            sh.cumulative[i] = sh.cumulative[i - 1] + 1;
-            sh.spread[highThreshold--] = (uint8_t)(i - 1);
+    const int lane = (int)threadIdx.x & 63;
+    const int32_t tableSize = 1 << tableLog, mask = tableSize - 1;
+    int32_t* const filledBefore = &sh.cumulative[0];   // [s]: positions the walk fills before symbol s's
+    int32_t* const slotOf = &sh.cumulative[64];        // [s]: the symbol's first slot, then its next free one
+    int32_t* const seen = &sh.cumulative[128];         // [s]: the symbol's positions below the 64 under way
+    wave_sync();
+    // ---- per symbol ----
+    const bool mine = lane <= maxSymbol;
+    const int32_t n = mine ? (int32_t)norm[lane] : 0;
+    const bool isLow = n == -1;
+    const int32_t states = isLow ? 1 : (n > 0 ? n : 0);
+    const int32_t walked = n > 0 ? n : 0;
+    const int32_t slot = sx::wave_scan_incl(states, lane) - states;
+    const int32_t filled = sx::wave_scan_incl(walked, lane) - walked;
+    const unsigned long long lowMask = __ballot(isLow);
+    const int32_t lows = (int32_t)__popcll(lowMask);
+    const int32_t high = tableSize - 1 - lows;  // the last position the walk may fill
+    if (mine) {
+        filledBefore[lane] = filled;
+        slotOf[lane] = slot;
+        seen[lane] = 0;
+        if (isLow) {
+            sh.spread[tableSize - 1 - (int32_t)__popcll(lowMask & ((1ull << lane) - 1ull))] = (uint8_t)lane;
         }
-        else {
-            sh.cumulative[i] = sh.cumulative[i - 1] + norm[i - 1];
-        }
-    }
-    sh.cumulative[maxSymbol + 1] = tableSize + 1;
-    const int32_t mask = tableSize - 1;
-    const int32_t step = (tableSize >> 1) + (tableSize >> 3) + 3;
-    int32_t position = 0;
-    for (int32_t symbol = 0; symbol <= maxSymbol; symbol++) {
-        const int32_t n = norm[symbol];
-        for (int32_t i = 0; i < n; i++) {
-            sh.spread[position] = (uint8_t)symbol;
-            do {
-                position = (position + step) & mask;
-            } while (position > highThreshold);
-        }
-    }
-    for (int32_t i = 0; i < tableSize; i++) {
-        const int32_t symbol = sh.spread[i];
-        const int32_t slot = sh.cumulative[symbol];
-        sh.cumulative[symbol] = slot + 1;
-        t.nextState[slot] = (int16_t)(tableSize + i);
-    }
-    int32_t total = 0;
-    for (int32_t symbol = 0; symbol <= maxSymbol; symbol++) {
-        const int32_t n = norm[symbol];
         if (n == 0) {
-            t.deltaNumberOfBits[symbol] = ((tableLog + 1) << 16) - tableSize;
+            t.deltaNumberOfBits[lane] = ((tableLog + 1) << 16) - tableSize;
         }
-        else if (n == -1 || n == 1) {
-            t.deltaNumberOfBits[symbol] = (tableLog << 16) - tableSize;
-            t.deltaFindState[symbol] = total - 1;
-            total++;
+        else if (states == 1) {
+            t.deltaNumberOfBits[lane] = (tableLog << 16) - tableSize;
+            t.deltaFindState[lane] = slot - 1;
         }
         else {
             const int32_t maxBitsOut = tableLog - highest_bit((uint32_t)(n - 1));
-            const int32_t minStatePlus = n << maxBitsOut;
-            t.deltaNumberOfBits[symbol] = (maxBitsOut << 16) - minStatePlus;
-            t.deltaFindState[symbol] = total - n;
-            total += n;
+            t.deltaNumberOfBits[lane] = (maxBitsOut << 16) - (n << maxBitsOut);
+            t.deltaFindState[lane] = slot - n;
         }
+    }
+    if (lane == 0) {
+        t.log2Size = tableLog;
+    }
+    wave_sync();
+    // ---- per position: its symbol ----
+    const uint32_t step = (uint32_t)((tableSize >> 1) + (tableSize >> 3) + 3);
+    uint32_t inv = step;  // step^-1 mod 2^32 by Newton's iteration (step is odd: step * step = 1 mod 8)
+    inv *= 2u - step * inv;
+    inv *= 2u - step * inv;
+    inv *= 2u - step * inv;
+    inv *= 2u - step * inv;
+    for (int32_t u = lane; u <= high; u += 64) {
+        const int32_t j = (int32_t)(((uint32_t)u * inv) & (uint32_t)mask);
+        int32_t k = j;
+        for (int32_t v = high + 1; v < tableSize; v++) {  // (uniform bounds)
+            k -= (int32_t)(((uint32_t)v * inv) & (uint32_t)mask) < j ? 1 : 0;
+        }
+        int32_t lo = 0, hi = maxSymbol;  // the last symbol whose filled-before count is <= k (symbols without positions share their successor's: the last wins)
+        while (lo < hi) {
+            const int32_t mid = (lo + hi + 1) >> 1;
+            if (filledBefore[mid] <= k) lo = mid;
+            else hi = mid - 1;
+        }
+        sh.spread[u] = (uint8_t)lo;
+    }
+    wave_sync();
+    // ---- per position: its slot ----
+    for (int32_t base = 0; base < tableSize; base += 64) {  // (uniform)
+        const int32_t u = base + lane;
+        const bool valid = u < tableSize;
+        const uint32_t symbol = valid ? (uint32_t)sh.spread[u] : (0x100u + (uint32_t)lane);  // (lanes without a position match nobody)
+        unsigned long long same = ~0ull;
+#pragma unroll
+        for (int bit = 0; bit < 9; bit++) {
+            const bool one = ((symbol >> bit) & 1u) != 0;
+            const unsigned long long m = __ballot(one);
+            same &= one ? m : ~m;
+        }
+        const int32_t before = (int32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (valid) {
+            t.nextState[slotOf[symbol] + seen[symbol] + before] = (int16_t)(tableSize + u);
+        }
+        wave_sync();  // (every lane has read the running counts)
+        if (valid && before == 0) {
+            seen[symbol] += (int32_t)__popcll(same);
+        }
+        wave_sync();
     }
 }
 __device__ __forceinline__ int32_t fse_begin(const FseCTable& t, int32_t symbol)  // :119-124

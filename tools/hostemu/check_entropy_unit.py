@@ -140,5 +140,30 @@ for run in range(0, 61):
         nm2[run] = (1 << tl) - 1; nm2[run + 1] = -1
         if run > 0:
             write_case(nm2, tl, 512); writes += 1
-print("write: %d tables, %d mismatches in all" % (writes, bad))
+print("write: %d tables, %d mismatches so far" % (writes, bad), flush=True)
+
+
+def init_case(norm, table_log):
+    global bad
+    norm = np.ascontiguousarray(norm, dtype=np.int16)
+    ms = len(norm) - 1
+    res = []
+    for lib, name in ((emu, "unit_fse_init"), (ref, "unit_ref_fse_init")):
+        ns = np.zeros(512, dtype=np.int16); db = np.zeros(56, dtype=np.int32); df = np.zeros(56, dtype=np.int32)
+        getattr(lib, name)(P(norm), ms, table_log, P(ns), P(db), P(df))
+        res.append((ns[:1 << table_log].tolist(), db[:ms + 1].tolist(), df[:ms + 1].tolist()))
+    if res[0] != res[1]:
+        bad += 1
+        print("MISMATCH fse_initialize tableLog %d norm %s\n  gpu %s\n  ref %s" % (table_log, norm.tolist(), res[0], res[1]))
+
+
+inits = 0
+for nm, tl in norms:
+    if int(np.abs(nm).sum()) == (1 << tl) and len(nm) <= 53:
+        init_case(nm, tl); inits += 1
+for nm, tl in (([4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1], 6),
+               ([1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1], 5),
+               ([1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1], 6)):
+    init_case(nm, tl); inits += 1  # the predefined distributions
+print("fse_initialize: %d tables, %d mismatches in all" % (inits, bad))
 sys.exit(1 if bad else 0)

@@ -55,8 +55,25 @@ __global__ void unit_write_kernel(const int16_t* norm, int32_t maxSymbol, int32_
     const int32_t n = zc::fse_write_normalized_counts(c, sh, out, 0, cap, sh.norm, maxSymbol, tableLog);
     if (lane == 0) *sizeOut = n;
 }
+__global__ void unit_fse_init_kernel(const int16_t* norm, int32_t maxSymbol, int32_t tableLog, int16_t* nextStateOut, int32_t* deltaBitsOut, int32_t* deltaFindOut)
+{
+    __shared__ zc::Shared sh;
+    const int lane = (int)threadIdx.x;
+    if (lane <= maxSymbol) sh.norm[lane] = norm[lane];
+    for (int i = lane; i < 512; i += 64) sh.ll.nextState[i] = (int16_t)0x7777;
+    if (lane < 56) { sh.ll.deltaNumberOfBits[lane] = 0x55555555; sh.ll.deltaFindState[lane] = 0x55555555; }
+    __syncthreads();
+    zc::fse_initialize(sh, sh.ll, sh.norm, maxSymbol, tableLog);
+    __syncthreads();
+    for (int i = lane; i < 512; i += 64) nextStateOut[i] = sh.ll.nextState[i];
+    if (lane < 56) { deltaBitsOut[lane] = sh.ll.deltaNumberOfBits[lane]; deltaFindOut[lane] = sh.ll.deltaFindState[lane]; }
+}
 }  // namespace
 }  // namespace achip
+extern "C" void unit_fse_init(const int16_t* norm, int32_t maxSymbol, int32_t tableLog, int16_t* nextStateOut, int32_t* deltaBitsOut, int32_t* deltaFindOut)
+{
+    hipLaunchKernelGGL(achip::unit_fse_init_kernel, dim3(1), dim3(64), 0, nullptr, norm, maxSymbol, tableLog, nextStateOut, deltaBitsOut, deltaFindOut);
+}
 
 extern "C" void unit_huf(const int32_t* counts, int32_t maxSymbol, int32_t maxBits, uint8_t* bitsOut, int16_t* valuesOut, int32_t* maxBitsOut)
 {

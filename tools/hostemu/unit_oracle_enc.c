@@ -32,3 +32,14 @@ int32_t unit_ref_write(const int16_t* norm, int32_t maxSymbol, int32_t tableLog,
     g_fail = NULL;
     return n;
 }
+/* FseCompressionTable.initialize: the state table and the two deltas per symbol (entries the method leaves alone keep the caller's fill) */
+void unit_ref_fse_init(const int16_t* norm, int32_t maxSymbol, int32_t tableLog, int16_t* nextStateOut, int32_t* deltaBitsOut, int32_t* deltaFindOut)
+{
+    static fse_ctable t;
+    for (int i = 0; i < 512; i++) t.nextState[i] = (int16_t)0x7777;
+    for (int i = 0; i < 56; i++) { t.deltaNumberOfBits[i] = 0x55555555; t.deltaFindState[i] = 0x55555555; }
+    fse_initialize(&t, norm, maxSymbol, tableLog);
+    memcpy(nextStateOut, t.nextState, sizeof(t.nextState));
+    memcpy(deltaBitsOut, t.deltaNumberOfBits, 56 * 4);
+    memcpy(deltaFindOut, t.deltaFindState, 56 * 4);
+}
