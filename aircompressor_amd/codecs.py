@@ -312,74 +312,109 @@ class _ZstdStreamEncoder(_HipCompressor):
 
 class ZstdHipInputStream:
     """Drop-in for ZstdInputStream (M/zstd/ZstdInputStream.java:28-151 over ZstdIncrementalFrameDecompressor.java:44-386) over a binary source,
-    in whole-buffer form like the other stream twins: the first read takes everything the source holds, asks the library for the bound of
-    what the frames decode to (achip_zstd_decompress_bound: frame and block headers only -- frames need NOT carry a content size, which
-    ZstdOutputStream's do not from 4 MiB on), decodes all frames in one call of the batched decoder and hands the plaintext out as asked.
-    What differs from the Java stream: a damaged stream fails at the first read, not at the read that reaches the damage; and the whole
-    plaintext is held at once, where ZstdInputStream needs a window.  The bound of a few bytes of input can be huge (every 4-byte RLE block
-    header announces up to 128 KiB; 4 KB of such headers: 2 GiB), so the one-shot allocation is capped: a stream whose bound exceeds
-    `max_decoded_bytes` (DEFAULT_MAX_DECODED_BYTES = 1 GiB unless the caller says otherwise; None = no cap) is refused with an IOError
-    before anything is allocated.  INTEGRATION.md section 6 states the limit for the Java twin as well."""
+    INCREMENTAL like the Java stream: input is read from the source a megabyte at a time and handed to the library's stream state
+    (achip_zstdstream_decompress_begin / _feed / _end), which decodes a frame in steps of whole blocks with tables, repeat offsets, window and
+    running checksum carried on the device -- ~45 MB of host + device memory per open stream at the Java writer's 8 MiB window, whatever the
+    stream's length (a frame of gigabytes, many frames back to back).  A damaged stream delivers every byte in front of the damaged block and
+    fails at the read that reaches it, where ZstdInputStream.read throws; the end of the source anywhere but between frames is "Not enough
+    input bytes" (ZstdInputStream.java:79-85).  `max_decoded_bytes` (None = no limit, the default) makes the stream fail with an IOError once
+    it has delivered more than that -- a guard for callers who collect the whole plaintext (a few KB of RLE block headers decode to
+    gigabytes); the stream itself no longer needs it."""
 
-    DEFAULT_MAX_DECODED_BYTES = 1 << 30
+    DEFAULT_MAX_DECODED_BYTES = None
+    READ_SIZE = 1 << 20
 
     def __init__(self, source, device=0, native_ctx=None, max_decoded_bytes=DEFAULT_MAX_DECODED_BYTES):
         if max_decoded_bytes is not None and max_decoded_bytes < 0:
             raise ValueError("max_decoded_bytes must be >= 0 or None")
         self._source = source
         self._max_decoded = max_decoded_bytes
-        self._codec = ZstdHipDecompressor(device, native_ctx)
-        self._plain = None
-        self._pos = 0
+        self._native = native_ctx if native_ctx is not None else native.HipNative(device)
+        self._lib = self._native.lib
+        self._state = self._lib.achip_zstdstream_decompress_begin(self._native.ctx)
+        if not self._state:
+            raise native.HipUnavailableError("achip_zstdstream_decompress_begin failed: %s" % self._lib.achip_last_error().decode())
+        self._input = np.zeros(0, dtype=np.uint8)  # read from the source, not yet taken by the library
+        self._source_ended = False
+        self._delivered = 0
+        self._seen_input = False
         self._closed = False
 
-    def _fill(self):
-        if self._plain is not None:
-            return
-        data = self._source.read()
-        if len(data) == 0:
-            # the incremental decoder wants a frame magic before it will call the stream ended (ZstdInputStream.java:79-85: not at a stopping point)
-            raise IOError("Not enough input bytes")
-        src = _ro_view(data)
-        eo = ctypes.c_int64(0)
-        bound = self._codec._lib.achip_zstd_decompress_bound(src.ctypes.data, int(src.size), ctypes.byref(eo))
-        if bound < 0:
-            native.raise_for_status(int(bound), eo.value)
-        if self._max_decoded is not None and bound > self._max_decoded:
-            # (memory amplification, not corruption: the frames may well be legal -- ADVICE round 3)
-            raise IOError("Decoded size bound %d exceeds max_decoded_bytes %d" % (int(bound), int(self._max_decoded)))
-        out = bytearray(max(int(bound), 1))
-        n = self._codec.decompress(data, 0, len(data), out, 0, int(bound)) if bound > 0 else 0
-        self._plain = bytes(out[:n])
+    def _more_input(self):
+        if self._source_ended:
+            return False
+        data = self._source.read(self.READ_SIZE)
+        if not data:
+            self._source_ended = True
+            return False
+        self._seen_input = True
+        self._input = np.frombuffer(bytes(data), dtype=np.uint8)
+        return True
+
+    def read_into(self, output_buffer, output_offset, output_length):
+        """ZstdInputStream.read(byte[], int, int) :63-105: the number of bytes delivered (the buffer is filled unless the stream ends), -1 at the
+        end of the stream"""
+        if self._closed:
+            raise IOError("Stream is closed")  # :66-68
+        _verify_range(output_buffer, output_offset, output_length)
+        if output_length == 0:
+            return 0
+        out = _rw_view(output_buffer)[output_offset:output_offset + output_length]
+        used = 0
+        consumed, produced, err = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        while used < output_length:
+            r = self._lib.achip_zstdstream_decompress_feed(self._native.ctx, self._state, self._input.ctypes.data if self._input.size else None, int(self._input.size),
+                                                           out[used:].ctypes.data, int(output_length - used), ctypes.byref(consumed), ctypes.byref(produced), ctypes.byref(err))
+            if r < 0:
+                if used > 0:
+                    break  # (what was decoded goes out; the next read fails)
+                native.raise_for_status(int(r), err.value)
+            self._input = self._input[consumed.value:]
+            used += produced.value
+            if produced.value == 0 and self._input.size == 0 and not self._more_input():
+                # the source has ended: between frames that is the end of the stream, anywhere else the stream is cut short
+                if self._lib.achip_zstdstream_decompress_at_stopping_point(self._state) and self._seen_input:
+                    break
+                if used > 0:
+                    break
+                raise IOError("Not enough input bytes")
+        self._delivered += used
+        if self._max_decoded is not None and self._delivered > self._max_decoded:
+            raise IOError("Decoded size %d exceeds max_decoded_bytes %d" % (self._delivered, int(self._max_decoded)))
+        return used if used > 0 else -1
 
     def read(self, n=-1):
         """io-style: up to n bytes (all that is left for n < 0), b"" at the end"""
         if self._closed:
-            raise IOError("Stream is closed")  # :66-68
-        self._fill()
-        end = len(self._plain) if n is None or n < 0 else min(len(self._plain), self._pos + n)
-        piece = self._plain[self._pos:end]
-        self._pos = end
-        return piece
-
-    def read_into(self, output_buffer, output_offset, output_length):
-        """ZstdInputStream.read(byte[], int, int) :63-105: the number of bytes delivered, -1 at the end of the stream"""
-        if self._closed:
             raise IOError("Stream is closed")
-        _verify_range(output_buffer, output_offset, output_length)
-        if output_length == 0:
-            return 0
-        piece = self.read(output_length)
-        if not piece:
-            return -1
-        _rw_view(output_buffer)[output_offset:output_offset + len(piece)] = _ro_view(piece)
-        return len(piece)
+        pieces = []
+        want = None if n is None or n < 0 else int(n)
+        buf = bytearray(1 << 20 if want is None else max(1, min(want, 1 << 20)))
+        while want is None or want > 0:
+            k = self.read_into(buf, 0, len(buf) if want is None else min(len(buf), want))
+            if k < 0:
+                break
+            pieces.append(bytes(buf[:k]))
+            if want is not None:
+                want -= k
+        return b"".join(pieces)
 
     def close(self):
         if not self._closed:
             self._closed = True
+            if self._state:
+                self._lib.achip_zstdstream_decompress_end(self._native.ctx, self._state)
+                self._state = None
             if hasattr(self._source, "close"):
                 self._source.close()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_state", None):
+                self._lib.achip_zstdstream_decompress_end(self._native.ctx, self._state)
+                self._state = None
+        except Exception:
+            pass
 
     def __enter__(self):
         return self

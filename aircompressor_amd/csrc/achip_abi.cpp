@@ -49,6 +49,11 @@ int64_t hadoop_decompress_scratch_bytes(int32_t nStreams, int32_t bufferSize);
 hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize);
 int64_t hadoop_compress_scratch_bytes(int32_t nStreams);
 extern int g_zstd_pipe_exec;
+int64_t zstd_stream_carry_bytes();
+void zstd_stream_carry_init(void* hostCarry);
+int64_t zstd_stream_step_scratch_bytes(int32_t blocks);
+hipError_t launch_zstd_stream_step(hipStream_t stream, void* scratch, int64_t scratchBytes, void* carryDev, const uint8_t* dSrc, int32_t srcLen, int32_t blocks, uint8_t* dOut,
+                                   int32_t startPos, int32_t outLimit, int32_t closing, int32_t hasChecksum, uint32_t expected, int32_t* result);
 extern int g_lz4_parse_mode;
 hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant, const AuxScratch* aux);
 int64_t lz4frame_decompress_scratch_bytes(int32_t nItems, int variant);
@@ -1841,6 +1846,357 @@ int32_t achip_multi_batch_host(achip_ctx* const* ctxs, int32_t nCtx, int32_t cod
         }
     }
     return 0;
+}
+
+// ---- one long Zstd stream, decoded a step at a time in bounded memory ----------------------------------------------------
+// What ZstdInputStream does over ZstdIncrementalFrameDecompressor (M/zstd/ZstdIncrementalFrameDecompressor.java:44-72: the states; :216-234: the
+// window kept behind the output): input arrives in pieces, output leaves in pieces, a frame may be any length, frames may follow each other.
+// The host walks magic / frame header / block headers (three bytes each) and hands the device STEPS of whole blocks -- up to kStepBlocks, i.e.
+// 4 MiB of output -- which the pipeline's multi-block stages decode with tables, repeat offsets, window and running checksum carried from step
+// to step (zstd_decompress_pipe.hip: launch_zstd_stream_step).  Memory per open stream: the window (at most kMaxWindow) twice + a step of
+// output on the device, a step of input and of output on the host, the stages' scratch for one step: ~45 MB at the 8 MiB window of the Java
+// writer, whatever the stream's length.
+struct achip_zstd_dstream {
+    static constexpr int32_t kStepBlocks = 32;
+    static constexpr int32_t kStepBytes = kStepBlocks * 131072;
+    static constexpr int64_t kMaxWindow = 128LL << 20;  // (window descriptors beyond 2^27: refused -- the Java frame decoder stops at 8 MiB, :303)
+    enum Phase { MAGIC = 0, HEADER = 1, BLOCKS = 2, FAILED = 3 };
+    achip_ctx* ctx = nullptr;
+    int phase = MAGIC;
+    std::vector<uint8_t> pending;  // input accepted, not decoded yet
+    size_t pendingAt = 0;          // ... from here on
+    int64_t streamPos = 0;         // stream offset of pending[pendingAt]
+    // the frame under way
+    int64_t lookBack = 0;          // FrameHeader.computeRequiredOutputBufferLookBackSize
+    bool hasChecksum = false;
+    // output decoded, not delivered yet
+    uint8_t* hostOut = nullptr;    // pinned, kStepBytes
+    int64_t outLen = 0, outAt = 0;
+    int32_t failStatus = 0;
+    int64_t failOffset = 0;
+    // device
+    uint8_t* hist = nullptr;       // [0, window) history (ending at `window`) | [window, window + kStepBytes) a step's output | [.., + window) room to move the history
+    int64_t window = 0;            // bytes of history room
+    int64_t histLen = 0;           // history bytes held (at hist + window - histLen)
+    uint8_t* dSrc = nullptr;       // 6 + kStepBytes + 4 * kStepBlocks + 64
+    uint8_t* hostSrc = nullptr;    // pinned, the same
+    void* carry = nullptr;
+    void* scratch = nullptr;
+    int64_t scratchBytes = 0;
+};
+
+namespace {
+constexpr int64_t kStepSrcBytes = 6 + (int64_t)achip_zstd_dstream::kStepBytes + 4 * achip_zstd_dstream::kStepBlocks + 64;
+
+void dstream_free(achip_zstd_dstream* z)
+{
+    if (!z) return;
+    if (z->ctx) (void)hipSetDevice(z->ctx->device);
+    if (z->hostOut) (void)hipHostFree(z->hostOut);
+    if (z->hostSrc) (void)hipHostFree(z->hostSrc);
+    if (z->hist) (void)hipFree(z->hist);
+    if (z->dSrc) (void)hipFree(z->dSrc);
+    if (z->carry) (void)hipFree(z->carry);
+    if (z->scratch) (void)hipFree(z->scratch);
+    delete z;
+}
+
+int32_t dstream_fail(achip_zstd_dstream* z, int detail, int64_t offset)
+{
+    z->phase = achip_zstd_dstream::FAILED;
+    z->failStatus = ACHIP_STATUS(ACHIP_CLASS_MALFORMED, detail);
+    z->failOffset = offset;
+    return z->failStatus;
+}
+
+// the history room for a frame whose decoder must be able to look `lookBack` bytes back (grown, never shrunk)
+int32_t dstream_window(achip_zstd_dstream* z, int64_t lookBack)
+{
+    const int64_t want = std::max<int64_t>((lookBack + 255) & ~255LL, 1 << 16);
+    if (want > z->window) {
+        if (z->hist) {
+            HIP_TRY(hipStreamSynchronize(z->ctx->stream));
+            HIP_TRY(hipFree(z->hist));
+            z->hist = nullptr;
+        }
+        HIP_TRY(hipMalloc((void**)&z->hist, (size_t)(2 * want + achip_zstd_dstream::kStepBytes + 256)));
+        z->window = want;
+    }
+    z->histLen = 0;
+    return 0;
+}
+
+// Decodes the blocks [first, first + blocks) that lie complete in pending (each: 3-byte header at pos[i], `stored[i]` bytes behind it).
+int32_t dstream_step(achip_zstd_dstream* z, const std::vector<size_t>& pos, const std::vector<int64_t>& stored, bool closing, uint32_t expected)
+{
+    achip_ctx* ctx = z->ctx;
+    const int32_t blocks = (int32_t)pos.size();
+    // the step as a frame of its own: magic, a descriptor that says "single segment, one byte of content size, no checksum", the size byte, the blocks
+    uint8_t* h = z->hostSrc;
+    const uint8_t head[6] = {0x28, 0xB5, 0x2F, 0xFD, 0x20, 0x00};
+    memcpy(h, head, 6);
+    int64_t at = 6;
+    for (int32_t i = 0; i < blocks; i++) {
+        const uint8_t* b = z->pending.data() + pos[(size_t)i];
+        memcpy(h + at, b, (size_t)(3 + stored[(size_t)i]));
+        h[at] = (uint8_t)((h[at] & 0xFE) | (i == blocks - 1 ? 1 : 0));  // the step's last block closes the stand-in frame
+        at += 3 + stored[(size_t)i];
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(z->dSrc, h, (size_t)at, hipMemcpyHostToDevice, ctx->stream));
+    int32_t result[3] = {0, 0, -1};
+    // positions count from the oldest history byte kept: the step writes from histLen on
+    uint8_t* dOut = z->hist + (z->window - z->histLen);
+    HIP_TRY(achip::launch_zstd_stream_step(ctx->stream, z->scratch, z->scratchBytes, z->carry, z->dSrc, (int32_t)at, blocks, dOut, (int32_t)z->histLen,
+                                           (int32_t)(z->histLen + achip_zstd_dstream::kStepBytes), closing ? 1 : 0, z->hasChecksum ? 1 : 0, expected, result));
+    const int32_t good = result[0], produced = result[1];
+    if (produced > 0) {
+        HIP_TRY(hipMemcpyAsync(z->hostOut, z->hist + z->window, (size_t)produced, hipMemcpyDeviceToHost, ctx->stream));
+        // the history for the next step: the last min(window, histLen + produced) bytes, ending where the step's output begins
+        const int64_t keep = std::min<int64_t>(z->lookBack, z->histLen + produced);
+        uint8_t* from = z->hist + z->window + produced - keep;
+        uint8_t* to = z->hist + z->window - keep;
+        if (produced >= keep) {
+            HIP_TRY(hipMemcpyAsync(to, from, (size_t)keep, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        else {  // (the ranges overlap: by way of the room behind the step's output)
+            uint8_t* tmp = z->hist + z->window + achip_zstd_dstream::kStepBytes;
+            HIP_TRY(hipMemcpyAsync(tmp, from, (size_t)keep, hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(to, tmp, (size_t)keep, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        z->histLen = keep;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    z->outLen = produced;
+    z->outAt = 0;
+    if (good < blocks) {
+        // the stream is damaged in block `good`: what lies in front of it is delivered first (the next calls), then the stream fails
+        int64_t off = z->streamPos;
+        for (int32_t i = 0; i < good; i++) off += 3 + stored[(size_t)i];
+        dstream_fail(z, ACHIP_D_ZSTD_CORRUPTED, off);
+        return 0;
+    }
+    if (closing && z->hasChecksum && result[2] != 1) {
+        int64_t off = z->streamPos;
+        for (int32_t i = 0; i < blocks; i++) off += 3 + stored[(size_t)i];
+        dstream_fail(z, ACHIP_D_ZSTD_BAD_CHECKSUM, off + 4);  // (ZstdIncrementalFrameDecompressor.java:318-320: behind the checksum word)
+        return 0;
+    }
+    return 0;
+}
+}  // namespace
+
+void* achip_zstdstream_decompress_begin(achip_ctx* ctx)
+{
+    if (!ctx) {
+        g_lastError = "ctx is null";
+        return nullptr;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        g_lastError = "hipSetDevice failed";
+        return nullptr;
+    }
+    achip_zstd_dstream* z = new achip_zstd_dstream();
+    z->ctx = ctx;
+    z->scratchBytes = achip::zstd_stream_step_scratch_bytes(achip_zstd_dstream::kStepBlocks);
+    bool ok = hipHostMalloc((void**)&z->hostOut, (size_t)achip_zstd_dstream::kStepBytes, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&z->hostSrc, (size_t)kStepSrcBytes, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void**)&z->dSrc, (size_t)kStepSrcBytes) == hipSuccess;
+    ok = ok && hipMalloc(&z->carry, (size_t)achip::zstd_stream_carry_bytes()) == hipSuccess;
+    ok = ok && hipMalloc(&z->scratch, (size_t)z->scratchBytes) == hipSuccess;
+    if (!ok) {
+        g_lastError = "out of memory for a Zstd stream's buffers";
+        dstream_free(z);
+        return nullptr;
+    }
+    return z;
+}
+
+int32_t achip_zstdstream_decompress_end(achip_ctx* ctx, void* state)
+{
+    (void)ctx;
+    dstream_free((achip_zstd_dstream*)state);
+    return 0;
+}
+
+int32_t achip_zstdstream_decompress_at_stopping_point(void* state)
+{
+    const achip_zstd_dstream* z = (const achip_zstd_dstream*)state;
+    if (!z) return 0;
+    return z->phase == achip_zstd_dstream::MAGIC && z->pendingAt == z->pending.size() && z->outAt == z->outLen ? 1 : 0;
+}
+
+int32_t achip_zstdstream_decompress_feed(achip_ctx* ctx, void* state, const void* src, int64_t srcLen, void* dst, int64_t dstCap, int64_t* consumed, int64_t* produced,
+                                         int64_t* errOffset)
+{
+    achip_zstd_dstream* z = (achip_zstd_dstream*)state;
+    if (!ctx || !z || z->ctx != ctx) return bad_argument("stream state");
+    if (srcLen < 0 || dstCap < 0 || (srcLen > 0 && !src) || (dstCap > 0 && !dst) || !consumed || !produced) return bad_argument("buffers");
+    *consumed = 0;
+    *produced = 0;
+    if (errOffset) *errOffset = 0;
+    const uint8_t* in = (const uint8_t*)src;
+    uint8_t* out = (uint8_t*)dst;
+    // what the stream may hold back of the caller's input: a step of blocks with their headers, the frame's checksum, the next frame's header
+    const size_t holdLimit = (size_t)kStepSrcBytes + 64;
+    for (;;) {
+        // ---- decoded bytes first ----
+        if (z->outAt < z->outLen) {
+            const int64_t n = std::min<int64_t>(z->outLen - z->outAt, dstCap - *produced);
+            if (n > 0) {
+                memcpy(out + *produced, z->hostOut + z->outAt, (size_t)n);
+                z->outAt += n;
+                *produced += n;
+            }
+            if (z->outAt < z->outLen) {
+                return 0;  // (the caller's buffer is full)
+            }
+        }
+        if (z->phase == achip_zstd_dstream::FAILED) {
+            if (errOffset) *errOffset = z->failOffset;
+            return *produced > 0 ? 0 : z->failStatus;  // (bytes in front of the damage go out first: the NEXT call fails)
+        }
+        // ---- take input ----
+        if (z->pendingAt > 0 && (z->pendingAt == z->pending.size() || z->pendingAt >= (size_t)(1 << 20))) {
+            z->pending.erase(z->pending.begin(), z->pending.begin() + (ptrdiff_t)z->pendingAt);
+            z->pendingAt = 0;
+        }
+        {
+            const size_t held = z->pending.size() - z->pendingAt;
+            const int64_t take = std::min<int64_t>(srcLen - *consumed, held < holdLimit ? (int64_t)(holdLimit - held) : 0);
+            if (take > 0) {
+                z->pending.insert(z->pending.end(), in + *consumed, in + *consumed + take);
+                *consumed += take;
+            }
+        }
+        const uint8_t* p = z->pending.data() + z->pendingAt;
+        const int64_t have = (int64_t)(z->pending.size() - z->pendingAt);
+        auto advance = [&](int64_t n) {
+            z->pendingAt += (size_t)n;
+            z->streamPos += n;
+        };
+        if (z->phase == achip_zstd_dstream::MAGIC) {
+            if (have < 4) {
+                return 0;  // (more input, or the end of the stream: achip_zstdstream_decompress_at_stopping_point)
+            }
+            const uint32_t magic = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+            if (magic != 0xFD2FB528u) {
+                const int32_t st = dstream_fail(z, magic == 0xFD2FB527u ? ACHIP_D_ZSTD_V07_MAGIC : ACHIP_D_ZSTD_BAD_MAGIC, z->streamPos);
+                if (errOffset) *errOffset = z->failOffset;
+                return *produced > 0 ? 0 : st;
+            }
+            advance(4);
+            z->phase = achip_zstd_dstream::HEADER;
+            continue;
+        }
+        if (z->phase == achip_zstd_dstream::HEADER) {  // ZstdFrameDecompressor.readFrameHeader :860-947 behind determineFrameHeaderSize
+            if (have < 1) return 0;
+            const int32_t fhd = p[0];
+            const bool singleSegment = (fhd & 0x20) != 0;
+            const int32_t dictDesc = fhd & 3, csDesc = fhd >> 6;
+            const int32_t headerSize = 1 + (singleSegment ? 0 : 1) + (dictDesc == 0 ? 0 : (1 << (dictDesc - 1))) + (csDesc == 0 ? (singleSegment ? 1 : 0) : (1 << csDesc));
+            if (have < headerSize) return 0;
+            int32_t at = 1;
+            int64_t windowSize = -1;
+            if (!singleSegment) {
+                const int32_t wd = p[at++];
+                const int64_t base = 1LL << (10 + (wd >> 3));
+                windowSize = base + (base / 8) * (wd & 7);
+            }
+            if (dictDesc != 0) {
+                const int32_t st = dstream_fail(z, ACHIP_D_ZSTD_DICTIONARY, z->streamPos + at + (1 << (dictDesc - 1)));
+                if (errOffset) *errOffset = z->failOffset;
+                return *produced > 0 ? 0 : st;
+            }
+            int64_t contentSize = -1;
+            auto rd = [&](int n) {
+                uint64_t v = 0;
+                for (int i = 0; i < n; i++) v |= (uint64_t)p[at + i] << (8 * i);
+                return v;
+            };
+            if (csDesc == 0) contentSize = singleSegment ? (int64_t)rd(1) : -1;
+            else if (csDesc == 1) contentSize = (int64_t)rd(2) + 256;
+            else if (csDesc == 2) contentSize = (int64_t)rd(4);
+            else contentSize = (int64_t)rd(8);
+            // FrameHeader.computeRequiredOutputBufferLookBackSize
+            int64_t lookBack = contentSize < 0 ? windowSize : (windowSize < 0 ? contentSize : std::min(windowSize, contentSize));
+            if (contentSize < 0 && csDesc == 3) lookBack = windowSize;  // (a content size beyond 2^63 reads negative in Java: "not set")
+            if (lookBack < 0 || lookBack > achip_zstd_dstream::kMaxWindow) {
+                if (windowSize >= 0 && windowSize <= achip_zstd_dstream::kMaxWindow) {
+                    lookBack = windowSize;
+                }
+                else {
+                    const int32_t st = dstream_fail(z, ACHIP_D_ZSTD_WINDOW_TOO_LARGE, z->streamPos);
+                    if (errOffset) *errOffset = z->failOffset;
+                    return *produced > 0 ? 0 : st;
+                }
+            }
+            z->lookBack = lookBack;
+            z->hasChecksum = (fhd & 4) != 0;
+            int32_t r = dstream_window(z, lookBack);
+            if (r < 0) return r;
+            // ZstdFrameDecompressor.reset() :199-203 and a fresh XxHash64: the carry of a new frame
+            {
+                std::vector<uint8_t> zero((size_t)achip::zstd_stream_carry_bytes(), 0);
+                achip::zstd_stream_carry_init(zero.data());
+                HIP_TRY(hipSetDevice(ctx->device));
+                HIP_TRY(hipMemcpy(z->carry, zero.data(), zero.size(), hipMemcpyHostToDevice));
+            }
+            advance(headerSize);
+            z->phase = achip_zstd_dstream::BLOCKS;
+            continue;
+        }
+        // ---- BLOCKS: the whole blocks that lie in pending, up to a step ----
+        std::vector<size_t> pos;
+        std::vector<int64_t> stored;
+        int64_t at = 0;
+        bool closing = false, broken = false;
+        uint32_t expected = 0;
+        while ((int32_t)pos.size() < achip_zstd_dstream::kStepBlocks) {
+            if (have - at < 3) break;
+            const int32_t hd = p[at] | (p[at + 1] << 8) | (p[at + 2] << 16);
+            const int32_t type = (hd >> 1) & 3, size = hd >> 3;
+            if (type == 3 || size > 131072) {
+                // ("Invalid block type" :264; a block beyond Block_Maximum_Size -- no encoder writes one -- would outgrow a step's room)
+                broken = true;
+                break;
+            }
+            const int64_t st = type == 1 ? 1 : size;
+            if (have - at < 3 + st) break;
+            const bool last = (hd & 1) != 0;
+            if (last && z->hasChecksum) {
+                if (have - at < 3 + st + 4) break;  // (the frame's last block goes with its checksum word)
+                const uint8_t* c = p + at + 3 + st;
+                expected = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
+            }
+            pos.push_back(z->pendingAt + (size_t)at);
+            stored.push_back(st);
+            at += 3 + st;
+            if (last) {
+                closing = true;
+                break;
+            }
+        }
+        if (pos.empty()) {
+            if (broken) {
+                const int32_t st = dstream_fail(z, ACHIP_D_ZSTD_INVALID_BLOCK_TYPE, z->streamPos + 3);
+                if (errOffset) *errOffset = z->failOffset;
+                return *produced > 0 ? 0 : st;
+            }
+            if (*consumed == srcLen) {
+                return 0;  // (a block is not whole yet: more input)
+            }
+            continue;  // (there was room for more of the caller's input)
+        }
+        const int32_t r = dstream_step(z, pos, stored, closing, expected);
+        if (r < 0) return r;
+        if (z->phase != achip_zstd_dstream::FAILED) {
+            advance(at + (closing && z->hasChecksum ? 4 : 0));
+            if (closing) {
+                z->phase = achip_zstd_dstream::MAGIC;
+            }
+        }
+    }
 }
 
 // ---- multi-GPU partition (host arithmetic) --------------------------------

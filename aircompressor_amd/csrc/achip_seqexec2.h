@@ -412,7 +412,7 @@ struct RecordSource {  // one block's records for exec_records: `n` records at `
 
 template <int WIN = WIN_DEFAULT>
 __device__ __forceinline__ int32_t exec_records(uint8_t* win, const RecordSource& S, const uint8_t* __restrict__ lit, int32_t litSize, uint8_t* out, int32_t outLimit, int lane,
-                                                bool& badOut, int32_t startPos = 0)
+                                                bool& badOut, int32_t startPos = 0, bool warm = false)
 {
     // startPos > 0: the block continues an output whose first startPos bytes this wavefront produced by earlier calls with the same
     // window (the blocks of one Zstd frame): positions, offsets and the capacity are those of the whole output, the window still holds
@@ -434,6 +434,18 @@ __device__ __forceinline__ int32_t exec_records(uint8_t* win, const RecordSource
     X.init(win, out, litSrc, litLen, lane);
     X.outPos = startPos;
     X.flushPos = startPos & ~15;  // (the bytes between were written by the call before, and are written again with the first flush)
+    if (warm && startPos > 0) {  // (uniform) the output's last bytes were produced by ANOTHER launch (a stream decoded a step at a time): the window is filled from the output buffer
+        const int32_t from = startPos > WIN ? startPos - WIN : 0;
+        for (int32_t p = from + lane; p < startPos; p += 64) {
+            const int32_t q = p & (WIN - 1);
+            const uint8_t byte = out[p];
+            win[q] = byte;
+            if (q < 16) {
+                win[WIN + q] = byte;
+            }
+        }
+        wave_sync();
+    }
 
     // ---- the group under way (per lane: one record of it) ----
     int32_t gLit = 0, gMl = 0, gOff = 0;

@@ -31,6 +31,7 @@
 #include "achip_seqexec2.h"
 #include "zstd_codes.h"
 #include "achip_xxhash.h"
+#include <cstring>
 #include <vector>
 
 namespace achip {
@@ -1976,6 +1977,398 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
         if (e != hipSuccess) return e;
     }
     return launch_zstd_decompress_list(a, stream, generalScratch, p.fallback, p.fallbackCount);
+}
+
+// ================================================================================================================================
+// ONE LONG STREAM, A STEP AT A TIME (what ZstdInputStream does over ZstdIncrementalFrameDecompressor.java:44-72,216-234).
+// The batched calls above want whole frames resident, input and output; a frame of gigabytes (ZstdOutputStream writes ONE frame however long
+// the stream) then needs gigabytes.  Here the host (achip_abi.cpp: achip_zstdstream_decompress_*) cuts a frame into STEPS of whole blocks and
+// the multi-block stages run on a step as if it were a frame -- the host puts a six-byte frame header in front of the step's blocks and
+// marks its last block "last" -- with what a block may inherit from the blocks before it carried from step to step in a device-side record:
+//   tables     a ghost slot 0 in front of the step's block slots receives the carried Huffman table and the three FSE tables; blocks
+//              whose links the walk left open (treeless literals / repeat mode with no definition inside the step) are linked to it
+//   history    the step's output goes behind the frame's last `window` bytes in one buffer (positions count from the oldest byte kept:
+//              a match that reaches further back than the window is malformed, as in the Java decoder), the executor's LDS window is
+//              filled from there (exec_records' warm start), the repeat offsets continue
+//   checksum   a running XXH64 (the four accumulators, the length, the pending stripe), closed and compared at the frame's last block
+// A block that any stage finds irregular ends the step IN FRONT of it: the bytes of the blocks before it are delivered, the stream fails at
+// the read that reaches the block -- where ZstdInputStream throws.
+// ================================================================================================================================
+struct ZstdStreamCarry {
+    int32_t rep[3];        // the repeat-offset history (reset to 1, 4, 8 at a frame's start by the host)
+    int32_t hufLog;        // the carried Huffman table's log; < 0: none
+    int32_t fseLog[3];     // ... the three FSE tables' logs; < 0: none
+    int32_t goodBlocks;    // (out) blocks of the last step that decoded
+    int32_t produced;      // (out) their bytes
+    int32_t checksumOk;    // (out) the frame's checksum matched (only written by a step that closes a frame with one)
+    int32_t tailLen;       // XXH64: bytes of the pending stripe
+    int32_t pad;
+    uint64_t total;        // XXH64: bytes hashed so far
+    uint64_t v[4];         // XXH64: the accumulators
+    uint8_t tail[32];
+    uint16_t huf[zp::HUF_SLOT];
+    uint16_t fse[zp::FSE_SLOT];
+};
+int64_t zstd_stream_carry_bytes() { return (int64_t)sizeof(ZstdStreamCarry); }
+// a frame's first carry (host memory, zstd_stream_carry_bytes() of it): ZstdFrameDecompressor.reset() :199-203, no tables, a fresh XxHash64 (seed 0)
+void zstd_stream_carry_init(void* hostCarry)
+{
+    ZstdStreamCarry* c = (ZstdStreamCarry*)hostCarry;
+    memset((void*)c, 0, sizeof(*c));
+    c->rep[0] = 1;
+    c->rep[1] = 4;
+    c->rep[2] = 8;
+    c->hufLog = -1;
+    c->fseLog[0] = c->fseLog[1] = c->fseLog[2] = -1;
+    constexpr uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL;
+    c->v[0] = P1 + P2;
+    c->v[1] = P2;
+    c->v[2] = 0;
+    c->v[3] = 0 - P1;
+}
+
+// the ghost slot's tables from the carry, and the open links of the step's blocks to the ghost slot
+__global__ __launch_bounds__(64) void zstd_ss_ghost_kernel(zp::Pipe p, const ZstdStreamCarry* carry)
+{
+    using namespace zp;
+    const int lane = threadIdx.x;
+    for (int32_t i = lane * 8; i < HUF_SLOT; i += 64 * 8) {
+        *(u32x4*)(p.huf + i) = *(const u32x4*)(carry->huf + i);
+    }
+    for (int32_t i = lane * 8; i < FSE_SLOT; i += 64 * 8) {
+        *(u32x4*)(p.fse + i) = *(const u32x4*)(carry->fse + i);
+    }
+    if (lane == 0) {
+        Desc d = Desc();
+        d.hufLog = carry->hufLog > 0 ? carry->hufLog : 0;
+        d.log[0] = carry->fseLog[0] > 0 ? carry->fseLog[0] : 0;
+        d.log[1] = carry->fseLog[1] > 0 ? carry->fseLog[1] : 0;
+        d.log[2] = carry->fseLog[2] > 0 ? carry->fseLog[2] : 0;
+        p.desc[0] = d;
+    }
+    // every block its own item record (a copy of the step's): a block that a stage finds irregular leaves the fast path alone -- the blocks in
+    // front of it are still to be delivered
+    const MbItem whole = p.mbItem[0];
+    for (int32_t slot = 1 + lane; slot < p.count; slot += 64) {
+        MbBlock& b = p.mb[slot];
+        p.mbItem[slot] = whole;
+        b.itemSlot = slot;
+        if (b.kind != 2) {
+            continue;
+        }
+        if (b.hufSlot < 0 && carry->hufLog >= 0) {
+            b.hufSlot = 0;
+        }
+        for (int k = 0; k < 3; k++) {
+            if (b.fseSlot[k] < 0 && carry->fseLog[k] >= 0) {
+                b.fseSlot[k] = 0;
+            }
+        }
+    }
+}
+
+// K4 for a step: the step's blocks in order behind the history (positions count from the oldest byte kept)
+template <int WIN>
+__global__ __launch_bounds__(64) void zstd_ss_execute_kernel(BatchArgs a, zp::Pipe p, ZstdStreamCarry* carry, int32_t startPos)
+{
+    using namespace zp;
+    __shared__ __attribute__((aligned(16))) uint8_t win[WIN + 16];
+    const int lane = threadIdx.x;
+    const MbItem it = p.mbItem[0];
+    const uint8_t* src = a.srcBase + a.srcOff[0];
+    uint8_t* out = a.dstBase + a.dstOff[0];
+    const int32_t outLimit = a.dstCap[0];
+    int32_t rep0 = carry->rep[0], rep1 = carry->rep[1], rep2 = carry->rep[2];
+    int32_t output = startPos;
+    int32_t good = 0;
+    bool bad = it.state != 1;
+    for (int32_t i = 0; i < it.nBlocks && !bad; i++) {  // (uniform)
+        const int32_t slot = 1 + i;
+        const Desc d = p.desc[slot];
+        const MbBlock b = p.mb[slot];
+        if (d.state != 1 || p.mbItem[slot].state != 1) {
+            break;
+        }
+        const uint8_t* lit = d.litMode == 0 ? src + d.litSrc : p.lit + (size_t)d.litBase * 64;
+        sx2::RecordSource S{p.seq + d.seqBase, d.nDecoded, rep0, rep1, rep2};
+        const int32_t before = output;
+        output = sx2::exec_records<WIN>(win, S, lit, d.litSize, out, outLimit, lane, bad, output, i == 0);
+        if (bad) {
+            output = before;  // (what the block wrote in front of its damage is not delivered)
+            break;
+        }
+        const int32_t n0 = sx2::rep_resolve(b.repOut[0], rep0, rep1, rep2), n1 = sx2::rep_resolve(b.repOut[1], rep0, rep1, rep2), n2 = sx2::rep_resolve(b.repOut[2], rep0, rep1, rep2);
+        rep0 = n0;
+        rep1 = n1;
+        rep2 = n2;
+        good = i + 1;
+        wave_sync();
+    }
+    if (lane == 0) {
+        carry->rep[0] = rep0;
+        carry->rep[1] = rep1;
+        carry->rep[2] = rep2;
+        carry->goodBlocks = good;
+        carry->produced = output - startPos;
+    }
+}
+
+// the tables the blocks after this step may inherit: for each kind the last good block that defined its own (the walk's links say who)
+__global__ __launch_bounds__(64) void zstd_ss_carry_kernel(zp::Pipe p, ZstdStreamCarry* carry)
+{
+    using namespace zp;
+    const int lane = threadIdx.x;
+    const int32_t good = carry->goodBlocks;
+    int32_t lastHuf = 0, lastFse[3] = {0, 0, 0};  // (0: the ghost slot -- nothing new)
+    for (int32_t slot = 1; slot <= good; slot++) {  // (uniform; the links are a few words per block)
+        const MbBlock b = p.mb[slot];
+        if (b.kind != 2) {
+            continue;
+        }
+        lastHuf = b.hufSlot == slot ? slot : lastHuf;
+        for (int k = 0; k < 3; k++) {
+            lastFse[k] = b.fseSlot[k] == slot ? slot : lastFse[k];
+        }
+    }
+    if (lastHuf > 0) {
+        for (int32_t i = lane * 8; i < HUF_SLOT; i += 64 * 8) {
+            *(u32x4*)(carry->huf + i) = *(const u32x4*)(p.huf + (size_t)lastHuf * HUF_SLOT + i);
+        }
+        if (lane == 0) {
+            carry->hufLog = p.desc[lastHuf].hufLog;
+        }
+    }
+    constexpr int32_t first[4] = {FSE_LL, FSE_OF, FSE_ML, FSE_SLOT};
+    for (int k = 0; k < 3; k++) {
+        if (lastFse[k] > 0) {
+            const int32_t begin = k == 0 ? FSE_LL : (k == 1 ? FSE_OF : FSE_ML), end = k == 0 ? FSE_OF : (k == 1 ? FSE_ML : FSE_SLOT);
+            for (int32_t i = begin + lane * 8; i < end; i += 64 * 8) {
+                *(u32x4*)(carry->fse + i) = *(const u32x4*)(p.fse + (size_t)lastFse[k] * FSE_SLOT + i);
+            }
+            if (lane == 0) {
+                carry->fseLog[k] = p.desc[lastFse[k]].log[k];
+            }
+        }
+    }
+    (void)first;
+}
+
+// the running XXH64 over the step's output (XxHash64.java:182-291 cut at stripe boundaries); closing: the frame's checksum word against the low 32 bits
+__global__ __launch_bounds__(64) void zstd_ss_checksum_kernel(const uint8_t* __restrict__ data, ZstdStreamCarry* carry, int32_t closing, uint32_t expected)
+{
+    constexpr uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+    auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+    auto mix = [&](uint64_t cur, uint64_t v) { return rotl(cur + v * P2, 31) * P1; };
+    const int s = threadIdx.x;  // accumulator of this lane (the first four lanes work)
+    if (s >= 4) {
+        return;
+    }
+    const int32_t n = carry->produced;
+    int32_t tailLen = carry->tailLen;
+    uint64_t v = carry->v[s];
+    int32_t at = 0;
+    if (tailLen > 0) {  // complete the pending stripe first
+        const int32_t take = 32 - tailLen < n ? 32 - tailLen : n;
+        for (int32_t i = s; i < take; i += 4) {
+            carry->tail[tailLen + i] = data[i];
+        }
+        wave_sync();
+        tailLen += take;
+        at = take;
+        if (tailLen == 32) {
+            v = mix(v, ld8(carry->tail + 8 * s));
+            tailLen = 0;
+        }
+    }
+    const int32_t stripes = (n - at) >> 5;
+    const uint8_t* q = data + at + 8 * s;
+    for (int32_t k = 0; k < stripes; k++) {
+        v = mix(v, ld8(q + (int64_t)k * 32));
+    }
+    at += stripes * 32;
+    wave_sync();
+    if (at < n) {  // (the pending stripe was consumed or there was none: the rest starts a new one)
+        for (int32_t i = s; i < n - at; i += 4) {
+            carry->tail[i] = data[at + i];
+        }
+        tailLen = n - at;
+    }
+    wave_sync();
+    const uint64_t total = carry->total + (uint64_t)(uint32_t)n;
+    carry->v[s] = v;
+    if (s == 0) {
+        carry->tailLen = tailLen;
+        carry->total = total;
+    }
+    if (closing) {
+        uint64_t hash;
+        if (total >= 32) {
+            const uint64_t v1 = __shfl(v, 0), v2 = __shfl(v, 1), v3 = __shfl(v, 2), v4 = __shfl(v, 3);
+            hash = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+            hash = (hash ^ mix(0, v1)) * P1 + P4;
+            hash = (hash ^ mix(0, v2)) * P1 + P4;
+            hash = (hash ^ mix(0, v3)) * P1 + P4;
+            hash = (hash ^ mix(0, v4)) * P1 + P4;
+        }
+        else {
+            hash = P5;  // (seed 0)
+        }
+        hash += total;
+        const uint8_t* t = carry->tail;
+        int32_t index = 0;
+        while (index <= tailLen - 8) {
+            hash = rotl(hash ^ mix(0, ld8(t + index)), 27) * P1 + P4;
+            index += 8;
+        }
+        if (index <= tailLen - 4) {
+            hash = rotl(hash ^ ((uint64_t)ld4(t + index) * P1), 23) * P2 + P3;
+            index += 4;
+        }
+        while (index < tailLen) {
+            hash = rotl(hash ^ ((uint64_t)t[index] * P5), 11) * P1;
+            index++;
+        }
+        hash ^= hash >> 33;
+        hash *= P2;
+        hash ^= hash >> 29;
+        hash *= P3;
+        hash ^= hash >> 32;
+        if (s == 0) {
+            carry->checksumOk = (uint32_t)hash == expected ? 1 : 0;
+        }
+    }
+}
+
+namespace {
+struct StepLayout {
+    int64_t counters, fallback, mbList, mbItem, args, mb, desc, huf, fse, lit, seq, order, general, total;
+    int32_t slots;
+    uint32_t litCap, seqCap;
+};
+StepLayout step_layout(int32_t slots, uint32_t litUnits, uint32_t seqs)
+{
+    StepLayout L;
+    L.slots = slots < 64 ? 64 : slots;
+    L.litCap = litUnits + 64;
+    L.seqCap = seqs + 64;
+    auto up = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
+    int64_t o = 0;
+    L.counters = o; o = up(o + 512);           // [0, 256) the pipeline's counters (fallbackCount, mbCount at + 40 words); [256, 512) the pass's cursors
+    L.fallback = o; o = up(o + (int64_t)L.slots * 4 + 64);
+    L.mbList = o; o = up(o + 64);
+    L.mbItem = o; o = up(o + (int64_t)L.slots * sizeof(zp::MbItem));
+    L.args = o; o = up(o + 64);                // the one item's srcOff, dstOff, errOffset (8 bytes each), srcLen, dstCap, outLen, status
+    L.mb = o; o = up(o + (int64_t)L.slots * sizeof(zp::MbBlock));
+    L.desc = o; o = up(o + (int64_t)L.slots * sizeof(zp::Desc));
+    L.huf = o; o = up(o + (int64_t)L.slots * zp::HUF_SLOT * 2);
+    L.fse = o; o = up(o + (int64_t)L.slots * zp::FSE_SLOT * 2);
+    L.lit = o; o = up(o + (int64_t)L.litCap * 64 + 4096);
+    L.seq = o; o = up(o + (int64_t)L.seqCap * 8 + 4096);
+    L.order = o; o = up(o + 2 * zp::ORDER_BUCKETS * 4 + (int64_t)L.slots * 4);
+    L.general = o; o = up(o + 4096 + (int64_t)sizeof(zd::FseTable) * 3);  // (the predefined tables only: launch_zstd_decompress_prepare)
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+// What a step of `blocks` blocks needs at most: slots for the blocks and the ghost, a literal arena and a sequence arena for blocks of the maximum size.
+int64_t zstd_stream_step_scratch_bytes(int32_t blocks)
+{
+    return step_layout(blocks + 1, (uint32_t)blocks * (uint32_t)((zp::LIT_STRIDE + 63) / 64 + 1), (uint32_t)blocks * 43691u + 64u).total;
+}
+
+// One step.  dSrc: the six-byte header + the step's blocks (the last marked last), srcLen bytes; dOut: where position 0 -- the oldest history byte
+// kept -- lies; the step's output starts at startPos and may reach outLimit; closing: the step ends the frame, with a checksum word to verify if
+// hasChecksum.  result[0..2] (host): blocks decoded, bytes produced, checksum verdict (1 ok, 0 mismatch, -1 none checked).  Synchronous.
+hipError_t launch_zstd_stream_step(hipStream_t stream, void* scratch, int64_t scratchBytes, void* carryDev, const uint8_t* dSrc, int32_t srcLen, int32_t blocks, uint8_t* dOut,
+                                   int32_t startPos, int32_t outLimit, int32_t closing, int32_t hasChecksum, uint32_t expected, int32_t* result)
+{
+    ZstdStreamCarry* carry = (ZstdStreamCarry*)carryDev;
+    const StepLayout L = step_layout(blocks + 1, (uint32_t)blocks * (uint32_t)((zp::LIT_STRIDE + 63) / 64 + 1), (uint32_t)blocks * 43691u + 64u);
+    if (L.total > scratchBytes) {
+        return hipErrorUnknown;  // (the caller sized the scratch with zstd_stream_step_scratch_bytes for fewer blocks)
+    }
+    uint8_t* base = (uint8_t*)scratch;
+    const zd::FseTable* dflt = nullptr;
+    hipError_t e = launch_zstd_decompress_prepare(stream, base + L.general, &dflt);
+    if (e != hipSuccess) return e;
+    // the one item
+    struct {
+        int64_t srcOff, dstOff, err;
+        int32_t srcLen, dstCap, outLen, status;
+    } args = {0, 0, 0, srcLen, outLimit, 0, 0};
+    int32_t one[2] = {0, 0};
+    e = hipMemsetAsync(base + L.counters, 0, 512, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(base + L.args, &args, sizeof(args), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(base + L.mbList, one, 4, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    one[0] = 1;
+    e = hipMemcpyAsync(base + L.counters + 160, one, 4, hipMemcpyHostToDevice, stream);  // mbCount[0] = 1 listed item
+    if (e != hipSuccess) return e;
+    BatchArgs a = BatchArgs();
+    a.srcBase = dSrc;
+    a.srcOff = (const int64_t*)(base + L.args);
+    a.dstOff = (const int64_t*)(base + L.args + 8);
+    a.errOffset = (int64_t*)(base + L.args + 16);
+    a.srcLen = (const int32_t*)(base + L.args + 24);
+    a.dstCap = (const int32_t*)(base + L.args + 28);
+    a.outLen = (int32_t*)(base + L.args + 32);
+    a.status = (int32_t*)(base + L.args + 36);
+    a.dstBase = dOut;
+    a.nBlocks = 1;
+    zp::Pipe p = zp::Pipe();
+    p.fallbackCount = (int32_t*)(base + L.counters);
+    p.fallback = (int32_t*)(base + L.fallback);
+    p.mbList = (int32_t*)(base + L.mbList);
+    p.mbCount = (int32_t*)(base + L.counters) + 40;
+    p.mbItem = (zp::MbItem*)(base + L.mbItem);
+    p.mb = (zp::MbBlock*)(base + L.mb);
+    p.desc = (zp::Desc*)(base + L.desc);
+    p.huf = (uint16_t*)(base + L.huf);
+    p.fse = (uint16_t*)(base + L.fse);
+    p.lit = base + L.lit;
+    p.seq = (uint64_t*)(base + L.seq);
+    p.seqCap = L.seqCap;
+    p.litCap = L.litCap;
+    p.seqCursor = (uint32_t*)(base + L.counters + 256);
+    p.litCursor = (uint32_t*)(base + L.counters + 260);
+    p.first = 0;
+    p.count = blocks + 1;
+    p.passFirst = -1;  // (block i of the item sits in slot 1 + i: slot 0 is the ghost)
+    p.itemFirst = 0;
+    p.itemEnd = 1;
+    p.mbSlots = L.slots;
+    p.mbLitCap = L.litCap;
+    p.mbSeqCap = L.seqCap;
+    p.order = nullptr;
+    p.orderHist = nullptr;
+    hipLaunchKernelGGL(zstd_mb_count_kernel, dim3(1), dim3(64), 0, stream, a, p);
+    hipLaunchKernelGGL(zstd_mb_scan_kernel, dim3(1), dim3(64), 0, stream, p);
+    e = hipMemsetAsync(p.mb, 0xFF, (size_t)p.count * sizeof(zp::MbBlock), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(zstd_mb_fill_kernel, dim3(1), dim3(64), 0, stream, a, p);
+    hipLaunchKernelGGL(zstd_ss_ghost_kernel, dim3(1), dim3(64), 0, stream, p, carry);
+    hipLaunchKernelGGL(zstd_mb_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
+    hipLaunchKernelGGL(zstd_pipe_literals_kernel<true>, dim3((unsigned)((p.count + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
+    hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<true>, dim3((unsigned)((p.count + zp::SEQL_ITEMS - 1) / zp::SEQL_ITEMS)), dim3(64), 0, stream, a, p);
+    hipLaunchKernelGGL(zstd_ss_execute_kernel<32768>, dim3(1), dim3(64), 0, stream, a, p, carry, startPos);
+    hipLaunchKernelGGL(zstd_ss_carry_kernel, dim3(1), dim3(64), 0, stream, p, carry);
+    hipLaunchKernelGGL(zstd_ss_checksum_kernel, dim3(1), dim3(64), 0, stream, dOut + startPos, carry, closing != 0 && hasChecksum != 0 ? 1 : 0, expected);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    struct {
+        int32_t goodBlocks, produced, checksumOk;
+    } r = {0, 0, 0};
+    e = hipMemcpyAsync(&r, &carry->goodBlocks, sizeof(r), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    result[0] = r.goodBlocks;
+    result[1] = r.produced;
+    result[2] = (closing != 0 && hasChecksum != 0 && r.goodBlocks == blocks) ? r.checksumOk : -1;
+    return hipSuccess;
 }
 
 }  // namespace achip

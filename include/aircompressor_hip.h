@@ -385,6 +385,26 @@ int32_t achip_multi_batch_host(achip_ctx* const* ctxs, int32_t nCtx, int32_t cod
                                const int32_t* srcLen, void* dstBase, const int64_t* dstOff, const int32_t* dstCap, int32_t* outLen, int32_t* status,
                                int64_t* errOffset, int32_t nBlocks, int32_t* sliceStarts);
 
+/* One long Zstd stream in bounded memory: what ZstdInputStream does over ZstdIncrementalFrameDecompressor
+ * (M/zstd/ZstdInputStream.java:63-105, M/zstd/ZstdIncrementalFrameDecompressor.java:44-72,216-234).  Input arrives in pieces, output
+ * leaves in pieces, a frame may be any length (ZstdOutputStream writes ONE frame per stream), frames may follow each other.
+ *   begin   a stream state on ctx (NULL: achip_last_error); per state ~45 MB of host + device memory at an 8 MiB window, whatever
+ *           the stream's length
+ *   feed    takes up to srcLen bytes of src (*consumed; it holds back at most one step of blocks), writes up to dstCap bytes to dst
+ *           (*produced).  Returns 0, or a negative status once the stream is known to be damaged AND every byte in front of the damage
+ *           has been delivered -- the call that would deliver the first byte of a damaged block fails, where ZstdInputStream.read
+ *           throws (*errOffset: stream offset of the block).  *consumed < srcLen with *produced == dstCap: output room needed;
+ *           *consumed == srcLen and *produced < dstCap: input needed (or the stream's end: at_stopping_point)
+ *   at_stopping_point   1 when nothing is pending and the next byte would start a frame (ZstdIncrementalFrameDecompressor.isAtStoppingPoint):
+ *           where a stream may end; the end of input anywhere else is "Not enough input bytes" (ZstdInputStream.java:83)
+ *   end     releases the state
+ * All host pointers; synchronous; a state serves one thread at a time like its context. */
+void* achip_zstdstream_decompress_begin(achip_ctx* ctx);
+int32_t achip_zstdstream_decompress_feed(achip_ctx* ctx, void* state, const void* src, int64_t srcLen, void* dst, int64_t dstCap, int64_t* consumed, int64_t* produced,
+                                         int64_t* errOffset);
+int32_t achip_zstdstream_decompress_at_stopping_point(void* state);
+int32_t achip_zstdstream_decompress_end(achip_ctx* ctx, void* state);
+
 /* Balanced contiguous partition of a batch over nParts GPUs: fills
  * starts[0..nParts] with block indices so that each part's sum of weight[i] is
  * as equal as a contiguous split allows.  Pure host arithmetic. */

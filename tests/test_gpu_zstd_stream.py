@@ -190,3 +190,150 @@ def test_input_stream_twin_caps_the_one_shot_allocation(o):
     assert len(plain) == 1000 * 131072 and plain.count(b"z") == len(plain)
     small = o.zstd_stream_compress(b"abc" * 1000)
     assert A.ZstdHipInputStream(io.BytesIO(small), max_decoded_bytes=4096).read() == b"abc" * 1000
+
+
+# ---- the reader, a step at a time (achip_zstdstream_decompress_begin / _feed / _end): SURVEY 8f row 3, ZstdIncrementalFrameDecompressor.java:44-72,216-234 ----
+
+def _device_bytes_in_use():
+    import torch
+    free, total = torch.cuda.mem_get_info(0)
+    return total - free
+
+
+def test_a_long_stream_decodes_in_bounded_memory(o):
+    """ONE frame of 320 MiB (libzstd level 3: a 2 MiB window, thousands of blocks, tables and repeat offsets inherited from block to block, a
+    checksum over everything) read through ZstdHipInputStream a megabyte at a time: the plaintext comes back byte for byte, and the device
+    memory the open stream holds stays a small constant (the whole-buffer twin of rounds 2-4 needed input + bound: > 400 MB here)."""
+    import hashlib
+    import pyarrow as pa
+    import torch
+    import aircompressor_amd as A
+    whole = b"".join(d for _, d, _ in common.corpus_sample())
+    rng = np.random.default_rng(3)
+    pieces = []
+    total = 0
+    while total < 320 << 20:   # text with random splices: matches reach back up to the window
+        at = int(rng.integers(0, len(whole) - 70000))
+        n = int(rng.integers(1000, 70000))
+        pieces.append(whole[at:at + n])
+        total += n
+    plain = b"".join(pieces)
+    z = pa.Codec("zstd", compression_level=3).compress(plain, asbytes=True)
+    want = hashlib.sha256(plain).hexdigest()
+    del pieces
+    torch.cuda.synchronize()
+    before = _device_bytes_in_use()
+    h = hashlib.sha256()
+    got = 0
+    peak = 0
+    with A.ZstdHipInputStream(io.BytesIO(z)) as s:
+        buf = bytearray(3 << 20)
+        while True:
+            n = s.read_into(buf, 0, len(buf))
+            if n < 0:
+                break
+            h.update(memoryview(buf)[:n])
+            got += n
+            peak = max(peak, _device_bytes_in_use() - before)
+    assert got == len(plain) and h.hexdigest() == want
+    assert peak < (48 << 20), "the open stream held %d MiB of device memory" % (peak >> 20)
+
+
+def test_streams_of_every_shape_read_in_small_pieces(o):
+    """The writer's streams (one frame, no content size from 4 MiB on), frames back to back, libzstd frames with and without checksum, raw and RLE
+    blocks, a window larger than a step -- read with small and odd buffer sizes from a source that hands out a few bytes at a time."""
+    import pyarrow as pa
+    import aircompressor_amd as A
+
+    class Dribble(io.RawIOBase):  # a source whose read() returns at most 70 001 bytes whatever is asked
+        def __init__(self, data):
+            self.data, self.at = data, 0
+
+        def read(self, n=-1):
+            n = 70001 if n is None or n < 0 else min(n, 70001)
+            piece = self.data[self.at:self.at + n]
+            self.at += len(piece)
+            return piece
+
+    whole = b"".join(d for _, d, _ in common.corpus_sample())
+    tiled = whole * 16
+    rng = np.random.default_rng(9)
+    noise = rng.integers(0, 256, 400000, dtype=np.uint8).tobytes()
+    plains = [tiled[:(4 << 20) + 1], tiled[100:9400100], whole[:70000], b"x", b"", noise + b"\0" * 900000 + noise[:100000], tiled[:20 << 20]]
+    zc = pa.Codec("zstd", compression_level=3)
+    streams = [o.zstd_stream_compress(p) for p in plains[:6]] + [zc.compress(plains[6], asbytes=True)]
+    streams.append(streams[2] + streams[0] + o.compress("zstd", whole[:300]) + zc.compress(noise, asbytes=True))
+    plains.append(plains[2] + plains[0] + whole[:300] + noise)
+    for k, (z, p) in enumerate(zip(streams, plains)):
+        for size in (1 << 20, 77777, 5):
+            if size == 5 and len(p) > 100000:
+                continue
+            with A.ZstdHipInputStream(Dribble(z)) as s:
+                got = bytearray()
+                buf = bytearray(size + 3)
+                while True:
+                    n = s.read_into(buf, 3, size)
+                    if n < 0:
+                        break
+                    assert 0 < n <= size
+                    got += buf[3:3 + n]
+                assert bytes(got) == p, (k, size, len(got), len(p))
+    with pytest.raises(IOError, match="Not enough input"):
+        A.ZstdHipInputStream(io.BytesIO(b"")).read()
+    with pytest.raises(IOError, match="Not enough input"):
+        A.ZstdHipInputStream(io.BytesIO(streams[0][:len(streams[0]) // 2])).read()
+
+
+def test_a_damaged_stream_fails_at_the_read_that_reaches_the_damage(o):
+    """Damage in the middle of a long frame: every byte of the blocks in front of the damaged block is delivered, then the read fails -- where
+    ZstdInputStream throws.  Held against the transliterated reference reader where oracle/_ref/libref.so is present: it fails too, having
+    delivered no more than this reader (it keeps a window's worth of decoded bytes back)."""
+    import ctypes
+    import os
+    import aircompressor_amd as A
+    whole = b"".join(d for _, d, _ in common.corpus_sample())
+    plain = (whole * 8)[:6000000]
+    z = bytearray(o.zstd_stream_compress(plain))
+    # block boundaries of the one frame (header: magic 4 + descriptor 1 + window 1 [+ content size])
+    fhd = z[4]
+    pos = 5 + (0 if fhd & 0x20 else 1) + ((1 if fhd & 0x20 else 0) if fhd >> 6 == 0 else 1 << (fhd >> 6))
+    starts = []
+    while True:
+        hd = int.from_bytes(z[pos:pos + 3], "little")
+        starts.append(pos)
+        pos += 3 + (1 if (hd >> 1) & 3 == 1 else hd >> 3)
+        if hd & 1:
+            break
+    assert len(starts) > 30
+    ref_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref.so")
+    ref = ctypes.CDLL(ref_path) if os.path.exists(ref_path) else None
+    if ref is not None:
+        ref.ref_zstd_stream_decompress_partial.restype = ctypes.c_int64
+        ref.ref_zstd_stream_decompress_partial.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    for victim in (2, 17, len(starts) - 2):
+        g = bytearray(z)
+        g[starts[victim] + 3] ^= 0xFF  # the damaged block's literals section header: the block cannot be parsed
+        g[starts[victim] + 4] ^= 0xFF
+        s = A.ZstdHipInputStream(io.BytesIO(bytes(g)))
+        got = bytearray()
+        buf = bytearray(200000)
+        failed = False
+        try:
+            while True:
+                n = s.read_into(buf, 0, len(buf))
+                if n < 0:
+                    break
+                got += buf[:n]
+        except (A.MalformedInputException, IOError):
+            failed = True
+        assert failed, victim
+        assert bytes(got) == plain[:len(got)] and len(got) > 0
+        # every block in front of the victim was delivered whole: the stream writer's blocks are 128 KiB of input each
+        assert len(got) == victim * 131072, (victim, len(got))
+        if ref is not None:
+            out = ctypes.create_string_buffer(len(plain) + 1)
+            delivered, eo = ctypes.c_int64(0), ctypes.c_int64(0)
+            src = ctypes.create_string_buffer(bytes(g), len(g))
+            r = ref.ref_zstd_stream_decompress_partial(src, len(g), out, len(plain) + 1, 200000, ctypes.byref(delivered), ctypes.byref(eo))
+            assert r < 0, "the reference reader decodes the damaged stream"
+            assert delivered.value <= len(got) and out.raw[:delivered.value] == plain[:delivered.value]

@@ -245,5 +245,132 @@ def main():
         sys.exit(1)
 
 
+def stream_cases():
+    """launch_zstd_stream_step under the emulator: frames cut into steps of a few blocks, tables / repeat offsets / window / checksum carried from
+    step to step; this script plays the host's part (achip_abi.cpp: achip_zstdstream_decompress_feed) -- the walk over the block headers, the
+    stand-in frame header in front of a step, the history kept behind the output.  Damaged frames: the blocks in front of the damage are
+    delivered, the first damaged block is where the oracle's decoder fails too."""
+    import struct
+    emu.emu_zstd_stream_carry_bytes.restype = ctypes.c_int64
+    cb = emu.emu_zstd_stream_carry_bytes()
+
+    def decode(frame, step_blocks, window_cap=None):
+        """returns (plaintext delivered, index of the first bad block or None)"""
+        assert frame[:4] == b"\x28\xb5\x2f\xfd"
+        fhd = frame[4]
+        single = (fhd & 0x20) != 0
+        cs = fhd >> 6
+        pos = 5
+        window = None
+        if not single:
+            wd = frame[pos]; pos += 1
+            base = 1 << (10 + (wd >> 3)); window = base + (base // 8) * (wd & 7)
+        n = (1 if single else 0) if cs == 0 else (1 << cs)
+        content = int.from_bytes(frame[pos:pos + n], "little") + (256 if cs == 1 else 0) if n else None
+        pos += n
+        look = window if content is None else (content if window is None else min(window, content))
+        if window_cap:
+            look = min(look, window_cap)
+        has_checksum = (fhd & 4) != 0
+        carry = np.zeros(cb, dtype=np.uint8)
+        emu.emu_zstd_stream_carry_init(P(carry))
+        W = max(look, 1 << 16)
+        S = step_blocks * 131072
+        hist = np.full(W + S + 64, 0xEE, dtype=np.uint8)
+        hist_len = 0
+        out = bytearray()
+        block_no = 0
+        while True:
+            blocks = []
+            closing = False
+            at = pos
+            while len(blocks) < step_blocks:
+                hd = int.from_bytes(frame[at:at + 3], "little")
+                typ, size = (hd >> 1) & 3, hd >> 3
+                st = 1 if typ == 1 else size
+                blocks.append(frame[at:at + 3 + st])
+                at += 3 + st
+                if hd & 1:
+                    closing = True
+                    break
+            body = bytearray(b"\x28\xb5\x2f\xfd\x20\x00")
+            for i, b in enumerate(blocks):
+                b = bytearray(b)
+                b[0] = (b[0] & 0xFE) | (1 if i == len(blocks) - 1 else 0)
+                body += b
+            src = np.frombuffer(bytes(body), dtype=np.uint8).copy()
+            expected = int.from_bytes(frame[at:at + 4], "little") if closing and has_checksum else 0
+            result = np.zeros(3, dtype=np.int32)
+            base = hist[W - hist_len:]
+            rc = emu.emu_zstd_stream_step(P(carry), P(src), len(src), len(blocks), P(base), hist_len, hist_len + S, 1 if closing else 0, 1 if has_checksum else 0,
+                                          ctypes.c_uint32(expected), P(result))
+            assert rc == 0, rc
+            good, produced, verdict = int(result[0]), int(result[1]), int(result[2])
+            out += hist[W:W + produced].tobytes()
+            keep = min(look, hist_len + produced)
+            hist[W - keep:W] = hist[W + produced - keep:W + produced].copy()
+            hist_len = keep
+            if good < len(blocks):
+                return bytes(out), block_no + good
+            block_no += len(blocks)
+            if closing:
+                if has_checksum and verdict != 1:
+                    return bytes(out), "checksum"
+                return bytes(out), None
+            pos = at
+
+    bad = 0
+    plains = common.multi_block_plains()
+    whole = b"".join(d for _, d, _ in common.corpus_sample())
+    plains = [p for p in plains if len(p) > 131072][:6] + [whole[:700000], (whole * 3)[:1500000]]
+    encs = [("oracle", lambda p: o.compress("zstd", p)), ("oracle-stream", lambda p: o.zstd_stream_compress(p))]
+    if HAVE_LIBZSTD:
+        encs += [("libzstd-3", lambda p: libzstd(p, 3)), ("libzstd-19", lambda p: libzstd(p, 19))]
+    total = 0
+    for name, enc in encs:
+        for k, p in enumerate(plains):
+            f = bytes(enc(p))
+            for step_blocks in ((1, 3, 32) if "--quick" not in sys.argv else (2,)):
+                got, where = decode(f, step_blocks)
+                total += 1
+                if where is not None or got != p:
+                    bad += 1
+                    print("MISMATCH stream %s plain %d (%d bytes) steps of %d: stopped at %s, %d bytes" % (name, k, len(p), step_blocks, where, len(got)))
+    print("zstd stream steps: %d decodes, %d mismatches" % (total, bad), flush=True)
+    # damage: what is delivered is a prefix of the plaintext made of whole blocks, and the oracle's decoder fails as well
+    rng = np.random.default_rng(5)
+    cases = 0
+    for name, enc in encs[:3]:
+        for p in plains[:3]:
+            f = bytearray(enc(p))
+            for _ in range(4 if "--quick" not in sys.argv else 1):
+                g = bytearray(f)
+                g[int(rng.integers(12, len(g) - 4))] ^= 1 << int(rng.integers(0, 8))
+                try:
+                    got, where = decode(bytes(g), 4)
+                except Exception as e:  # (a damaged block header makes this script's own walk run off the frame)
+                    continue
+                cases += 1
+                try:
+                    ref_plain = o.decompress("zstd", bytes(g), len(p) + 1024)
+                    ref_ok = True
+                except oracle_lib.OracleError:
+                    ref_ok = False
+                if where is None:
+                    if not ref_ok or got != ref_plain:
+                        bad += 1
+                        print("MISMATCH damaged %s: the steps decoded %d bytes, the oracle %s" % (name, len(got), "fails" if not ref_ok else "differs"))
+                else:
+                    # (a flipped bit in literal or sequence DATA decodes to other bytes and is caught by the checksum at the frame's end, here as in the
+                    # Java stream; a stop at a block must deliver whole blocks of the plaintext in front of it)
+                    if ref_ok or (where != "checksum" and got != p[:len(got)]):
+                        bad += 1
+                        print("MISMATCH damaged %s: stopped at %s with %d bytes (a prefix: %s), the oracle %s" % (name, where, len(got), got == p[:len(got)], "decodes" if ref_ok else "fails"))
+    print("zstd stream steps, damaged frames: %d cases, %d mismatches in all" % (cases, bad), flush=True)
+    return bad
+
+
 if __name__ == "__main__":
+    if "--stream" in sys.argv:
+        sys.exit(1 if stream_cases() else 0)
     main()

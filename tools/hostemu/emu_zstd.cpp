@@ -71,6 +71,19 @@ void* emu_mb_get(void*, int64_t bytes)
 }
 }  // namespace
 
+// a stream decoded a step at a time (launch_zstd_stream_step): the caller (check_zstd.py --stream) plays the host's part -- the walk over the
+// block headers, the stand-in frame header, the history
+extern "C" int64_t emu_zstd_stream_carry_bytes() { return achip::zstd_stream_carry_bytes(); }
+extern "C" void emu_zstd_stream_carry_init(void* carry) { achip::zstd_stream_carry_init(carry); }
+extern "C" int emu_zstd_stream_step(void* carry, const uint8_t* src, int32_t srcLen, int32_t blocks, uint8_t* out, int32_t startPos, int32_t outLimit, int32_t closing,
+                                    int32_t hasChecksum, uint32_t expected, int32_t* result)
+{
+    static std::vector<uint8_t> scratch;
+    const int64_t bytes = achip::zstd_stream_step_scratch_bytes(blocks);
+    scratch.assign((size_t)bytes, 0xCD);
+    return (int)achip::launch_zstd_stream_step(nullptr, scratch.data(), bytes, carry, src, srcLen, blocks, out, startPos, outLimit, closing, hasChecksum, expected, result);
+}
+
 // passBlocks: blocks per pass of the multi-block stages (0: multi-block frames go to the fallback list); counters: the pipeline's 64 counter words
 extern "C" int emu_zstd_pipe(const uint8_t* srcBase, const int64_t* srcOff, const int32_t* srcLen, uint8_t* dstBase, const int64_t* dstOff, const int32_t* dstCap,
                              int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n, int32_t tile, int32_t execMode, int32_t* fallback, int32_t passBlocks,

@@ -31,6 +31,9 @@ for step in "$@"; do
     encfuzz)       # the Zstd encoder after the entropy helpers' rewrite: GPU tests of the encoder + differential fuzz (bytes against the oracle)
       timeout 900 python -m pytest tests/test_gpu_zstd.py tests/test_gpu_zstd_stream.py tests/test_gpu_corpus.py -m gpu -x -q 2>&1 | tail -3
       timeout 900 python tools/fuzz_encoders.py 2>&1 | tail -12 | tee $O/fuzz_encoders.txt ;;
+    zstream)       # the incremental Zstd reader + the encoder after the FSE table rewrite
+      timeout 1200 python -m pytest tests/test_gpu_zstd_stream.py tests/test_gpu_zstd.py -m gpu -x -q 2>&1 | tail -15
+      timeout 600 python tools/fuzz_encoders.py 1500 77 zstd 2>&1 | tail -5 ;;
     tests)
       timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
     zstd)          # the Zstd section + per-kernel times
