@@ -264,15 +264,19 @@ class ZstdHipCompressor(_HipCompressor):
 
 
 class ZstdHipOutputStream:
-    """Drop-in for ZstdOutputStream (M/zstd/ZstdOutputStream.java:30-221) over a binary sink: write() collects, close() hands everything
-    to the stream encoder (achip_zstdstream_compress: the stream's parameters, not the frame compressor's) and writes the frame to the
-    sink.  The Java stream flushes chunks once 4 MiB have been written and slides its window; the device writer produces those bytes too
-    (include/aircompressor_hip.h: the chunked form), only that they reach the sink at close() in one piece."""
+    """Drop-in for ZstdOutputStream (M/zstd/ZstdOutputStream.java:30-221) over a binary sink, INCREMENTAL like the Java stream: write() hands
+    the bytes to the library's stream state (achip_zstdstream_compress_begin / _feed / _finish), which keeps the Java stream's 4 MiB buffer on the
+    device, flushes whole blocks to the sink whenever that buffer is full (the window slides) and writes the rest and the checksum at close().
+    The bytes are the Java stream's whatever the sizes of the write() calls; memory per open stream is a constant (~12 MB of device memory)."""
 
     def __init__(self, sink, device=0, native_ctx=None):
         self._sink = sink
-        self._codec = _ZstdStreamEncoder(device, native_ctx)
-        self._parts = []
+        self._native = native_ctx if native_ctx is not None else native.HipNative(device)
+        self._lib = self._native.lib
+        self._state = self._lib.achip_zstdstream_compress_begin(self._native.ctx)
+        if not self._state:
+            raise native.HipUnavailableError("achip_zstdstream_compress_begin failed: %s" % self._lib.achip_last_error().decode())
+        self._out = np.zeros(1 << 20, dtype=np.uint8)
         self._closed = False
 
     def write(self, buffer, offset=0, length=None):
@@ -281,23 +285,49 @@ class ZstdHipOutputStream:
         view = _ro_view(buffer)
         length = view.size - offset if length is None else length
         _verify_range(buffer, offset, length)
-        self._parts.append(bytes(view[offset:offset + length]))
+        data = np.ascontiguousarray(view[offset:offset + length])
+        consumed, produced = ctypes.c_int64(0), ctypes.c_int64(0)
+        at = 0
+        while True:
+            r = self._lib.achip_zstdstream_compress_feed(self._native.ctx, self._state, data[at:].ctypes.data if at < length else None, int(length - at), self._out.ctypes.data,
+                                                         int(self._out.size), ctypes.byref(consumed), ctypes.byref(produced))
+            if r < 0:
+                native.raise_for_status(int(r))
+            if produced.value:
+                self._sink.write(self._out[:produced.value].tobytes())
+            at += consumed.value
+            if at >= length and produced.value < self._out.size:
+                return
 
     def close(self):
         if self._closed:
             return
-        # (ZstdOutputStream.close :193-205 sets `closed` only behind writeChunk(true); a failing encode leaves the stream open and the data in
-        # place -- and the sink is closed either way, as its try / finally does)
+        # (ZstdOutputStream.close :193-205 sets `closed` only behind writeChunk(true); a failing encode leaves the stream open -- and the sink is
+        # closed either way, as its try / finally does)
         try:
-            data = b"".join(self._parts)
-            out = bytearray(self._codec.max_compressed_length(len(data)))
-            n = self._codec.compress(data, 0, len(data), out, 0, len(out))
-            self._sink.write(bytes(out[:n]))
-            self._parts = []
+            produced = ctypes.c_int64(0)
+            while True:
+                r = self._lib.achip_zstdstream_compress_finish(self._native.ctx, self._state, self._out.ctypes.data, int(self._out.size), ctypes.byref(produced))
+                if r < 0:
+                    native.raise_for_status(int(r))
+                if produced.value:
+                    self._sink.write(self._out[:produced.value].tobytes())
+                if r == 1:
+                    break
             self._closed = True
+            self._lib.achip_zstdstream_compress_end(self._native.ctx, self._state)
+            self._state = None
         finally:
             if hasattr(self._sink, "close"):
                 self._sink.close()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_state", None):
+                self._lib.achip_zstdstream_compress_end(self._native.ctx, self._state)
+                self._state = None
+        except Exception:
+            pass
 
     def __enter__(self):
         return self

@@ -49,6 +49,9 @@ int64_t hadoop_decompress_scratch_bytes(int32_t nStreams, int32_t bufferSize);
 hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize);
 int64_t hadoop_compress_scratch_bytes(int32_t nStreams);
 extern int g_zstd_pipe_exec;
+int64_t zstd_ostream_state_bytes();
+int64_t zstd_ostream_slab_bytes();
+hipError_t launch_zstd_ostream_step(hipStream_t stream, void* state, void* slab, const uint8_t* buf, int32_t offset, int32_t chunk, int32_t closing, uint8_t* out, int32_t outCap);
 int64_t zstd_stream_carry_bytes();
 void zstd_stream_carry_init(void* hostCarry);
 int64_t zstd_stream_step_scratch_bytes(int32_t blocks);
@@ -2197,6 +2200,166 @@ int32_t achip_zstdstream_decompress_feed(achip_ctx* ctx, void* state, const void
             }
         }
     }
+}
+
+// ---- ... and written a chunk at a time: ZstdOutputStream (M/zstd/ZstdOutputStream.java:93-221) in the 4 MiB it buffers --------------------------
+// write() appends to the stream's buffer -- here on the device --, a full buffer is flushed (compressIfNecessary :122-131: whole blocks, the
+// window and one block stay), close() writes the rest and the checksum.  One kernel step per writeChunk (zstd_stream.hip:
+// zstd_ostream_step_kernel), the CompressionContext between the steps in a device-side record.  The bytes are the Java stream's whatever the
+// sizes of the write() calls: the flush schedule only depends on how many bytes have arrived.
+struct achip_zstd_cstream {
+    static constexpr int32_t kBuffer = 4 << 20, kWindow = 1 << 20, kBlock = 131072;   // maxBufferSize = 4 x window (:52-54), level 3 / unknown size
+    static constexpr int32_t kOutBytes = kBuffer + (kBuffer >> 7) + 4096;              // a step's blocks + their headers + frame header + checksum
+    achip_ctx* ctx = nullptr;
+    uint8_t* buf = nullptr;        // device: the stream's buffer
+    uint8_t* dOut = nullptr;       // device: a step's output
+    uint8_t* hostOut = nullptr;    // pinned: the same, on its way to the caller
+    void* state = nullptr;
+    void* slab = nullptr;
+    int32_t position = 0, offset = 0;  // uncompressedPosition, uncompressedOffset
+    int64_t outLen = 0, outAt = 0;
+    bool finished = false;
+    int32_t failStatus = 0;
+};
+
+namespace {
+void cstream_free(achip_zstd_cstream* z)
+{
+    if (!z) return;
+    if (z->ctx) (void)hipSetDevice(z->ctx->device);
+    if (z->hostOut) (void)hipHostFree(z->hostOut);
+    if (z->buf) (void)hipFree(z->buf);
+    if (z->dOut) (void)hipFree(z->dOut);
+    if (z->state) (void)hipFree(z->state);
+    if (z->slab) (void)hipFree(z->slab);
+    delete z;
+}
+
+// writeChunk(lastChunk) :154-221
+int32_t cstream_step(achip_zstd_cstream* z, bool closing)
+{
+    achip_ctx* ctx = z->ctx;
+    const int32_t chunk = closing ? z->position - z->offset : ((z->position - z->offset - achip_zstd_cstream::kWindow - achip_zstd_cstream::kBlock) / achip_zstd_cstream::kBlock) * achip_zstd_cstream::kBlock;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(achip::launch_zstd_ostream_step(ctx->stream, z->state, z->slab, z->buf, z->offset, chunk, closing ? 1 : 0, z->dOut, achip_zstd_cstream::kOutBytes));
+    int32_t result[2] = {0, 0};  // outSize, status (ZstdOStreamState words 8 and 9)
+    HIP_TRY(hipMemcpyAsync(result, (const int32_t*)z->state + 8, sizeof(result), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (result[1] != 0) {
+        z->failStatus = result[1];
+        return result[1];
+    }
+    if (result[0] > 0) {
+        HIP_TRY(hipMemcpyAsync(z->hostOut, z->dOut, (size_t)result[0], hipMemcpyDeviceToHost, ctx->stream));
+    }
+    z->offset += chunk;
+    if (!closing) {
+        // the window and the bytes not yet compressed move to the buffer's front (:214-219); the slide is larger than what moves: no overlap
+        const int32_t slide = z->offset - achip_zstd_cstream::kWindow;
+        HIP_TRY(hipMemcpyAsync(z->buf, z->buf + slide, (size_t)(achip_zstd_cstream::kWindow + (z->position - z->offset)), hipMemcpyDeviceToDevice, ctx->stream));
+        z->offset -= slide;
+        z->position -= slide;
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    z->outLen = result[0];
+    z->outAt = 0;
+    return 0;
+}
+
+int64_t cstream_deliver(achip_zstd_cstream* z, uint8_t* out, int64_t room)
+{
+    const int64_t n = std::min<int64_t>(z->outLen - z->outAt, room);
+    if (n > 0) {
+        memcpy(out, z->hostOut + z->outAt, (size_t)n);
+        z->outAt += n;
+    }
+    return n > 0 ? n : 0;
+}
+}  // namespace
+
+void* achip_zstdstream_compress_begin(achip_ctx* ctx)
+{
+    if (!ctx) {
+        g_lastError = "ctx is null";
+        return nullptr;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        g_lastError = "hipSetDevice failed";
+        return nullptr;
+    }
+    achip_zstd_cstream* z = new achip_zstd_cstream();
+    z->ctx = ctx;
+    const size_t stateBytes = (size_t)achip::zstd_ostream_state_bytes();
+    bool ok = hipHostMalloc((void**)&z->hostOut, (size_t)achip_zstd_cstream::kOutBytes, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void**)&z->buf, (size_t)achip_zstd_cstream::kBuffer + 256) == hipSuccess;
+    ok = ok && hipMalloc((void**)&z->dOut, (size_t)achip_zstd_cstream::kOutBytes) == hipSuccess;
+    ok = ok && hipMalloc(&z->state, stateBytes) == hipSuccess;
+    ok = ok && hipMalloc(&z->slab, (size_t)achip::zstd_ostream_slab_bytes()) == hipSuccess;
+    ok = ok && hipMemset(z->state, 0, stateBytes) == hipSuccess;
+    if (!ok) {
+        g_lastError = "out of memory for a Zstd stream's buffers";
+        cstream_free(z);
+        return nullptr;
+    }
+    return z;
+}
+
+int32_t achip_zstdstream_compress_end(achip_ctx* ctx, void* state)
+{
+    (void)ctx;
+    cstream_free((achip_zstd_cstream*)state);
+    return 0;
+}
+
+// write(src, 0, srcLen) :93-104, as far as dst has room for what the flushes on the way put out
+int32_t achip_zstdstream_compress_feed(achip_ctx* ctx, void* state, const void* src, int64_t srcLen, void* dst, int64_t dstCap, int64_t* consumed, int64_t* produced)
+{
+    achip_zstd_cstream* z = (achip_zstd_cstream*)state;
+    if (!ctx || !z || z->ctx != ctx) return bad_argument("stream state");
+    if (srcLen < 0 || dstCap < 0 || (srcLen > 0 && !src) || (dstCap > 0 && !dst) || !consumed || !produced) return bad_argument("buffers");
+    if (z->finished) return bad_argument("Stream is closed");
+    *consumed = 0;
+    *produced = 0;
+    if (z->failStatus != 0) return z->failStatus;
+    const uint8_t* in = (const uint8_t*)src;
+    for (;;) {
+        *produced += cstream_deliver(z, (uint8_t*)dst + *produced, dstCap - *produced);
+        if (z->outAt < z->outLen || *consumed == srcLen) {
+            return 0;  // (the caller's buffer is full, or everything is taken)
+        }
+        const int64_t take = std::min<int64_t>(srcLen - *consumed, achip_zstd_cstream::kBuffer - z->position);
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipMemcpyAsync(z->buf + z->position, in + *consumed, (size_t)take, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));  // (the caller's memory is its own again when the call returns)
+        z->position += (int32_t)take;
+        *consumed += take;
+        if (z->position == achip_zstd_cstream::kBuffer) {  // compressIfNecessary :122-131
+            const int32_t r = cstream_step(z, false);
+            if (r < 0) return r;
+        }
+    }
+}
+
+// close() :143-152: the last chunk and the checksum; returns 1 when the stream's last byte has been delivered, 0 when dst was too small for the rest
+// (call again), a negative status otherwise
+int32_t achip_zstdstream_compress_finish(achip_ctx* ctx, void* state, void* dst, int64_t dstCap, int64_t* produced)
+{
+    achip_zstd_cstream* z = (achip_zstd_cstream*)state;
+    if (!ctx || !z || z->ctx != ctx) return bad_argument("stream state");
+    if (dstCap < 0 || (dstCap > 0 && !dst) || !produced) return bad_argument("buffers");
+    *produced = 0;
+    if (z->failStatus != 0) return z->failStatus;
+    *produced += cstream_deliver(z, (uint8_t*)dst, dstCap);
+    if (z->outAt < z->outLen) {
+        return 0;
+    }
+    if (!z->finished) {
+        const int32_t r = cstream_step(z, true);
+        if (r < 0) return r;
+        z->finished = true;
+        *produced += cstream_deliver(z, (uint8_t*)dst + *produced, dstCap - *produced);
+    }
+    return z->outAt < z->outLen ? 0 : 1;
 }
 
 // ---- multi-GPU partition (host arithmetic) --------------------------------

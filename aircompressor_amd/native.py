@@ -92,6 +92,10 @@ SIGNATURES = {
     "achip_zstdstream_decompress_feed": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "achip_zstdstream_decompress_at_stopping_point": (_i32, [_vp]),
     "achip_zstdstream_decompress_end": (_i32, [_vp, _vp]),
+    "achip_zstdstream_compress_begin": (_vp, [_vp]),
+    "achip_zstdstream_compress_feed": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "achip_zstdstream_compress_finish": (_i32, [_vp, _vp, _vp, _i64, ctypes.POINTER(_i64)]),
+    "achip_zstdstream_compress_end": (_i32, [_vp, _vp]),
     "achip_multi_batch_host": (_i32, [_vp, _i32, _i32, _vp] + _BATCH[1:] + [_vp]),
     "achip_partition_blocks": (_i32, [_vp, _i32, _i32, _vp]),
 }

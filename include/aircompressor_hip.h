@@ -405,6 +405,18 @@ int32_t achip_zstdstream_decompress_feed(achip_ctx* ctx, void* state, const void
 int32_t achip_zstdstream_decompress_at_stopping_point(void* state);
 int32_t achip_zstdstream_decompress_end(achip_ctx* ctx, void* state);
 
+/* ... and the writer: ZstdOutputStream (M/zstd/ZstdOutputStream.java:93-221) a chunk at a time, in the 4 MiB the Java stream buffers -- write()
+ * appends to the stream's buffer (on the device), a full buffer is flushed as whole blocks (compressIfNecessary :122-131, writeChunk :154-221: the
+ * window slides), close() writes the rest and the checksum.  The bytes are the Java stream's whatever the sizes of the calls.
+ *   begin    a stream state on ctx (NULL: achip_last_error)
+ *   feed     write(src, 0, srcLen): takes input until dst is full of flushed blocks (*consumed, *produced); 0 or a negative status
+ *   finish   close(): 1 when the stream's last byte has been delivered, 0 when dst was too small for the rest (call again)
+ *   end      releases the state */
+void* achip_zstdstream_compress_begin(achip_ctx* ctx);
+int32_t achip_zstdstream_compress_feed(achip_ctx* ctx, void* state, const void* src, int64_t srcLen, void* dst, int64_t dstCap, int64_t* consumed, int64_t* produced);
+int32_t achip_zstdstream_compress_finish(achip_ctx* ctx, void* state, void* dst, int64_t dstCap, int64_t* produced);
+int32_t achip_zstdstream_compress_end(achip_ctx* ctx, void* state);
+
 /* Balanced contiguous partition of a batch over nParts GPUs: fills
  * starts[0..nParts] with block indices so that each part's sum of weight[i] is
  * as equal as a contiguous split allows.  Pure host arithmetic. */

@@ -337,3 +337,32 @@ def test_a_damaged_stream_fails_at_the_read_that_reaches_the_damage(o):
             r = ref.ref_zstd_stream_decompress_partial(src, len(g), out, len(plain) + 1, 200000, ctypes.byref(delivered), ctypes.byref(eo))
             assert r < 0, "the reference reader decodes the damaged stream"
             assert delivered.value <= len(got) and out.raw[:delivered.value] == plain[:delivered.value]
+
+
+def test_output_stream_twin_writes_in_chunks_whatever_the_write_sizes(o):
+    """ZstdHipOutputStream over achip_zstdstream_compress_begin / _feed / _finish: the bytes of ZstdOutputStream (the oracle's) for streams below and
+    beyond 4 MiB -- no, one, two and six flushes -- written in pieces of many sizes; the sink receives the flushed blocks BEFORE close() (the
+    whole-buffer twin of rounds 2-4 held everything until then); an empty stream; and the incremental reader reads the longest one back."""
+    import aircompressor_amd as A
+    whole = b"".join(d for _, d, _ in common.corpus_sample())
+    rng = np.random.default_rng(47)
+    tiled = whole * 16
+    inputs = [b"", b"z", whole[:300000], tiled[:4 << 20], tiled[:(4 << 20) + 1], tiled[100:6400100],
+              tiled[:3000000] + rng.integers(0, 256, 700000, dtype=np.uint8).tobytes() + tiled[:2500000], tiled[:15 << 20]]
+    for k, data in enumerate(inputs):
+        want = o.zstd_stream_compress(data)
+        for piece in ((1 << 30, 1 << 20, 70001, 999) if len(data) <= (7 << 20) else (3000001,)):
+            if piece == 999 and len(data) > 400000:
+                continue
+            sink = io.BytesIO()
+            sink.close = lambda: None
+            s = A.ZstdHipOutputStream(sink)
+            before_close = 0
+            for at in range(0, len(data), piece):
+                s.write(data, at, min(piece, len(data) - at))
+                before_close = len(sink.getvalue())
+            s.close()
+            assert sink.getvalue() == want, (k, len(data), piece, len(sink.getvalue()), len(want))
+            if len(data) >= (4 << 20):
+                assert before_close > 0, "nothing reached the sink before close()"
+    assert A.ZstdHipInputStream(io.BytesIO(o.zstd_stream_compress(inputs[-1]))).read() == inputs[-1]

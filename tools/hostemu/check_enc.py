@@ -152,7 +152,33 @@ def chunked(n):
     return 0 if same else 1
 
 
+def ostream(sizes):
+    """the writer a chunk per launch (emu_zstd_ostream: the host schedule of achip_zstdstream_compress_feed / _finish over zstd_ostream_step_kernel)
+    against the oracle's ZstdOutputStream: small streams in one closing step, a stream beyond 4 MiB with its flushes and buffer moves"""
+    lib.emu_zstd_ostream.restype = ctypes.c_int64
+    src_all = b"".join(common.multi_block_plains())
+    while len(src_all) < max(sizes):
+        src_all += src_all
+    bad = 0
+    for n in sizes:
+        src = src_all[:n]
+        want = o.zstd_stream_compress(src)
+        for piece in ((1 << 30, 70001) if n < (1 << 20) else (1 << 20,)):
+            t = time.time()
+            out = np.zeros(len(want) + 4096, dtype=np.uint8)
+            a = np.frombuffer(src, dtype=np.uint8) if n else np.zeros(1, dtype=np.uint8)
+            r = lib.emu_zstd_ostream(P(a), ctypes.c_int64(n), P(out), ctypes.c_int64(len(out)), piece)
+            same = r == len(want) and out[:r].tobytes() == want
+            print("ZstdOutputStream of %d bytes, write() pieces of %d, a step per chunk: %d bytes against the oracle's %d: %s  (%.0f s)" % (n, piece, r, len(want), "identical" if same else "MISMATCH", time.time() - t), flush=True)
+            bad += 0 if same else 1
+    return bad
+
+
 def main():
+    if "--ostream" in sys.argv:
+        k = sys.argv.index("--ostream")
+        sizes = [int(x) for x in sys.argv[k + 1].split(",")] if len(sys.argv) > k + 1 else [0, 1, 100, 70000, 131072, 300000]
+        sys.exit(1 if ostream(sizes) else 0)
     if "--chunked" in sys.argv:
         sys.exit(1 if chunked(int(sys.argv[sys.argv.index("--chunked") + 1])) else 0)
     parts = {"block": part_block, "zstd": part_zstd, "stream": part_stream, "containers": part_containers}

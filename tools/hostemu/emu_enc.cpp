@@ -49,3 +49,43 @@ extern "C" int emu_encode(int op, const uint8_t* srcBase, const int64_t* srcOff,
     }
     return -1;
 }
+
+// The stream writer a chunk per launch (zstd_stream.hip: zstd_ostream_step_kernel), driven the way achip_abi.cpp's achip_zstdstream_compress_feed /
+// _finish drive it: ZstdOutputStream's buffer of 4 MiB, a step per writeChunk, the buffer moved down behind a flush.  `piece`: bytes per write() call.
+extern "C" int64_t emu_zstd_ostream(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap, int32_t piece)
+{
+    constexpr int32_t kBuffer = 4 << 20, kWindow = 1 << 20, kBlock = 131072;
+    std::vector<uint8_t> state((size_t)achip::zstd_ostream_state_bytes(), 0), slab((size_t)achip::zstd_ostream_slab_bytes(), 0xCD), buf((size_t)kBuffer + 64, 0xEE),
+        stepOut((size_t)kBuffer + (kBuffer >> 7) + 4096);
+    int32_t position = 0, offset = 0;
+    int64_t produced = 0;
+    auto step = [&](int32_t chunk, int32_t closing) -> int {
+        achip::launch_zstd_ostream_step(nullptr, state.data(), slab.data(), buf.data(), offset, chunk, closing, stepOut.data(), (int32_t)stepOut.size());
+        const int32_t* w = (const int32_t*)state.data();
+        const int32_t outSize = w[8], status = w[9];
+        if (status != 0) return status;
+        if (produced + outSize > cap) return -2;
+        memcpy(out + produced, stepOut.data(), (size_t)outSize);
+        produced += outSize;
+        return 0;
+    };
+    int64_t at = 0;
+    while (at < n) {
+        const int32_t take = (int32_t)std::min<int64_t>(std::min<int64_t>(n - at, piece), kBuffer - position);
+        memcpy(buf.data() + position, in + at, (size_t)take);
+        position += take;
+        at += take;
+        if (position == kBuffer) {  // compressIfNecessary :122-131
+            const int32_t chunk = ((position - offset - kWindow - kBlock) / kBlock) * kBlock;
+            const int r = step(chunk, 0);
+            if (r != 0) return r;
+            offset += chunk;
+            const int32_t slide = offset - kWindow;
+            memmove(buf.data(), buf.data() + slide, (size_t)(kWindow + (position - offset)));
+            offset -= slide;
+            position -= slide;
+        }
+    }
+    const int r = step(position - offset, 1);
+    return r != 0 ? r : produced;
+}
