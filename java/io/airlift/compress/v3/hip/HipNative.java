@@ -207,7 +207,27 @@ public final class HipNative
             @NativeSignature(name = "achip_multi_batch_host", returnType = int.class, argumentTypes = {MemorySegment.class, int.class, int.class, MemorySegment.class, MemorySegment.class,
                     MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
                     int.class, MemorySegment.class})
-            MethodHandle multiBatchHost) {}
+            MethodHandle multiBatchHost,
+            // Zstd streams a step at a time (SURVEY 8f row 3): begin(ctx) -> state; feed(ctx, state, src, srcLen, dst, dstCap, consumed*, produced*[, errOffset*]); ...
+            @NativeSignature(name = "achip_zstdstream_decompress_begin", returnType = MemorySegment.class, argumentTypes = MemorySegment.class)
+            MethodHandle zstdStreamDecompressBegin,
+            @NativeSignature(name = "achip_zstdstream_decompress_feed", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, long.class,
+                    MemorySegment.class, long.class, MemorySegment.class, MemorySegment.class, MemorySegment.class})
+            MethodHandle zstdStreamDecompressFeed,
+            @NativeSignature(name = "achip_zstdstream_decompress_at_stopping_point", returnType = int.class, argumentTypes = MemorySegment.class)
+            MethodHandle zstdStreamDecompressAtStoppingPoint,
+            @NativeSignature(name = "achip_zstdstream_decompress_end", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class})
+            MethodHandle zstdStreamDecompressEnd,
+            @NativeSignature(name = "achip_zstdstream_compress_begin", returnType = MemorySegment.class, argumentTypes = MemorySegment.class)
+            MethodHandle zstdStreamCompressBegin,
+            @NativeSignature(name = "achip_zstdstream_compress_feed", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, long.class,
+                    MemorySegment.class, long.class, MemorySegment.class, MemorySegment.class})
+            MethodHandle zstdStreamCompressFeed,
+            @NativeSignature(name = "achip_zstdstream_compress_finish", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, long.class,
+                    MemorySegment.class})
+            MethodHandle zstdStreamCompressFinish,
+            @NativeSignature(name = "achip_zstdstream_compress_end", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class})
+            MethodHandle zstdStreamCompressEnd) {}
 
     private static final Optional<LinkageError> LINKAGE_ERROR;
     private static final MethodHandles HANDLES;
@@ -707,6 +727,171 @@ public final class HipNative
             if (result < 0) {
                 throw toException(result, 0);
             }
+        }
+
+        /**
+         * A Zstd stream decoded a step at a time in bounded memory ({@code achip_zstdstream_decompress_*}): what {@code ZstdInputStream} does over
+         * {@code ZstdIncrementalFrameDecompressor}.  Not thread-safe; close it before its context.
+         */
+        public final class ZstdDecodeStream
+                implements AutoCloseable
+        {
+            private MemorySegment state;
+            private final Arena arena = Arena.ofConfined();
+            private final MemorySegment counters = arena.allocate(JAVA_LONG, 3);  // consumed, produced, error offset
+
+            ZstdDecodeStream()
+            {
+                try {
+                    state = (MemorySegment) HANDLES.zstdStreamDecompressBegin().invokeExact(handle());
+                }
+                catch (Throwable e) {
+                    throw new AssertionError("should not reach here", e);
+                }
+                if (state.address() == 0) {
+                    throw new IllegalStateException("achip_zstdstream_decompress_begin failed: " + lastError());
+                }
+            }
+
+            /** Takes input, delivers output; {@link #consumed()} / {@link #produced()} say how much.  Throws once the stream is damaged and every byte in front of the damage is out. */
+            public void feed(MemorySegment input, long inputLength, MemorySegment output, long outputLength)
+            {
+                int result;
+                try {
+                    result = (int) HANDLES.zstdStreamDecompressFeed().invokeExact(handle(), state, input, inputLength, output, outputLength,
+                            counters, counters.asSlice(8), counters.asSlice(16));
+                }
+                catch (Throwable e) {
+                    throw new AssertionError("should not reach here", e);
+                }
+                if (result < 0) {
+                    throw toException(result, counters.get(JAVA_LONG, 16));
+                }
+            }
+
+            public long consumed()
+            {
+                return counters.get(JAVA_LONG, 0);
+            }
+
+            public long produced()
+            {
+                return counters.get(JAVA_LONG, 8);
+            }
+
+            /** Nothing is pending and the next byte would start a frame: where a stream may end ({@code ZstdIncrementalFrameDecompressor.isAtStoppingPoint}). */
+            public boolean atStoppingPoint()
+            {
+                try {
+                    return (int) HANDLES.zstdStreamDecompressAtStoppingPoint().invokeExact(state) != 0;
+                }
+                catch (Throwable e) {
+                    throw new AssertionError("should not reach here", e);
+                }
+            }
+
+            @Override
+            public void close()
+            {
+                if (state != null) {
+                    try {
+                        int ignored = (int) HANDLES.zstdStreamDecompressEnd().invokeExact(handle(), state);
+                    }
+                    catch (Throwable e) {
+                        throw new AssertionError("should not reach here", e);
+                    }
+                    state = null;
+                    arena.close();
+                }
+            }
+        }
+
+        public ZstdDecodeStream openZstdDecodeStream()
+        {
+            return new ZstdDecodeStream();
+        }
+
+        /** A Zstd stream written a chunk at a time ({@code achip_zstdstream_compress_*}): {@code ZstdOutputStream}'s bytes in the 4 MiB it buffers. */
+        public final class ZstdEncodeStream
+                implements AutoCloseable
+        {
+            private MemorySegment state;
+            private final Arena arena = Arena.ofConfined();
+            private final MemorySegment counters = arena.allocate(JAVA_LONG, 2);  // consumed, produced
+
+            ZstdEncodeStream()
+            {
+                try {
+                    state = (MemorySegment) HANDLES.zstdStreamCompressBegin().invokeExact(handle());
+                }
+                catch (Throwable e) {
+                    throw new AssertionError("should not reach here", e);
+                }
+                if (state.address() == 0) {
+                    throw new IllegalStateException("achip_zstdstream_compress_begin failed: " + lastError());
+                }
+            }
+
+            /** {@code write(input, 0, inputLength)} as far as {@code output} has room for the blocks flushed on the way. */
+            public void feed(MemorySegment input, long inputLength, MemorySegment output, long outputLength)
+            {
+                int result;
+                try {
+                    result = (int) HANDLES.zstdStreamCompressFeed().invokeExact(handle(), state, input, inputLength, output, outputLength, counters, counters.asSlice(8));
+                }
+                catch (Throwable e) {
+                    throw new AssertionError("should not reach here", e);
+                }
+                if (result < 0) {
+                    throw toException(result, 0);
+                }
+            }
+
+            /** {@code close()}: true once the stream's last byte has been delivered; false: {@code output} was too small for the rest, call again. */
+            public boolean finish(MemorySegment output, long outputLength)
+            {
+                int result;
+                try {
+                    result = (int) HANDLES.zstdStreamCompressFinish().invokeExact(handle(), state, output, outputLength, counters.asSlice(8));
+                }
+                catch (Throwable e) {
+                    throw new AssertionError("should not reach here", e);
+                }
+                if (result < 0) {
+                    throw toException(result, 0);
+                }
+                return result == 1;
+            }
+
+            public long consumed()
+            {
+                return counters.get(JAVA_LONG, 0);
+            }
+
+            public long produced()
+            {
+                return counters.get(JAVA_LONG, 8);
+            }
+
+            @Override
+            public void close()
+            {
+                if (state != null) {
+                    try {
+                        int ignored = (int) HANDLES.zstdStreamCompressEnd().invokeExact(handle(), state);
+                    }
+                    catch (Throwable e) {
+                        throw new AssertionError("should not reach here", e);
+                    }
+                    state = null;
+                    arena.close();
+                }
+            }
+        }
+
+        public ZstdEncodeStream openZstdEncodeStream()
+        {
+            return new ZstdEncodeStream();
         }
 
         public MemorySegment allocateDevice(long bytes)

@@ -23,26 +23,30 @@ import static java.util.Objects.checkFromIndexSize;
 import static java.util.Objects.requireNonNull;
 
 /**
- * {@code ZstdInputStream} with the decoder on an AMD GPU (MI355X, gfx950) through {@code libaircompressor_hip.so}, in whole-buffer form:
- * the first read takes everything the underlying stream holds, asks {@code achip_zstd_decompress_bound} what the frames can decode to
- * (from their frame and block headers: the frames need NOT carry a content size -- {@code ZstdOutputStream}'s do not from 4 MiB on), decodes
- * all frames in one call and hands the plaintext out as asked.  A damaged stream fails at that first read, not at the read that reaches
- * the damage.  The whole plaintext is held at once, and the bound of a few bytes of input can be huge (every 4-byte RLE block header
- * announces up to 128 KiB): a stream whose bound exceeds {@code maxDecodedBytes} (default {@link #DEFAULT_MAX_DECODED_BYTES}, 1 GiB) is refused
- * with an {@link IOException} before anything is allocated -- {@code ZstdInputStream} decodes the same stream in a window's worth of memory.
- * To read many streams at once use {@link io.airlift.compress.v3.hip.HipBatchCodec} with
- * {@link HipNative#OP_ZSTD_DECOMPRESS}: one item per stream, capacities from {@link HipNative#zstdDecompressBound}.
+ * {@code ZstdInputStream} with the decoder on an AMD GPU (MI355X, gfx950) through {@code libaircompressor_hip.so}, INCREMENTAL like the Java
+ * stream ({@code ZstdInputStream.java:63-105} over {@code ZstdIncrementalFrameDecompressor.java:44-72,216-234}): input is read from the
+ * underlying stream a megabyte at a time and handed to the library's stream state ({@code achip_zstdstream_decompress_begin / _feed / _end}),
+ * which decodes a frame in steps of whole blocks with tables, repeat offsets, window and running checksum carried on the device -- about
+ * 45 MB of host and device memory per open stream at {@code ZstdOutputStream}'s window, whatever the stream's length (one frame of
+ * gigabytes, many frames back to back).  A damaged stream delivers every byte in front of the damaged block and fails at the read that
+ * reaches it; the end of the input anywhere but between frames is "Not enough input bytes".
+ * To read many streams at once use {@link io.airlift.compress.v3.hip.HipBatchCodec} with {@link HipNative#OP_ZSTD_DECOMPRESS}: one item per
+ * stream, capacities from {@link HipNative#zstdDecompressBound}.
  */
 public final class ZstdHipInputStream
         extends InputStream
 {
-    public static final long DEFAULT_MAX_DECODED_BYTES = 1L << 30;
+    private static final int READ_SIZE = 1 << 20;
 
     private final InputStream inputStream;
-    private final int device;
-    private final long maxDecodedBytes;
-    private byte[] plain;
-    private int position;
+    private final HipNative.Context context;
+    private final HipNative.Context.ZstdDecodeStream decoder;
+    private final byte[] input = new byte[READ_SIZE];
+    private int inputOffset;
+    private int inputLimit;
+    private boolean inputEnded;
+    private boolean sawInput;
+    private byte[] singleByte;
     private boolean closed;
 
     public ZstdHipInputStream(InputStream inputStream)
@@ -52,58 +56,20 @@ public final class ZstdHipInputStream
 
     public ZstdHipInputStream(InputStream inputStream, int device)
     {
-        this(inputStream, device, DEFAULT_MAX_DECODED_BYTES);
-    }
-
-    public ZstdHipInputStream(InputStream inputStream, int device, long maxDecodedBytes)
-    {
         this.inputStream = requireNonNull(inputStream, "inputStream is null");
-        if (maxDecodedBytes < 0) {
-            throw new IllegalArgumentException("maxDecodedBytes is negative");
-        }
         HipNative.verifyEnabled();
-        this.device = device;
-        this.maxDecodedBytes = maxDecodedBytes;
-    }
-
-    private void fill()
-            throws IOException
-    {
-        if (plain != null) {
-            return;
-        }
-        byte[] input = inputStream.readAllBytes();
-        if (input.length == 0) {
-            // ZstdInputStream wants a frame magic before it calls the stream ended (ZstdInputStream.java:79-85)
-            throw new IOException("Not enough input bytes");
-        }
-        long bound = HipNative.zstdDecompressBound(MemorySegment.ofArray(input));
-        if (bound > maxDecodedBytes) {
-            // (memory amplification, not corruption: the frames may well be legal)
-            throw new IOException("Decoded size bound " + bound + " exceeds maxDecodedBytes " + maxDecodedBytes);
-        }
-        if (bound > Integer.MAX_VALUE - 8) {
-            throw new IOException("Stream decodes to more than a byte[] holds: " + bound);
-        }
-        byte[] output = new byte[(int) Math.max(bound, 1)];
-        int size = 0;
-        if (bound > 0) {
-            try (HipNative.Context context = new HipNative.Context(device)) {
-                size = context.singleBlock(HipNative.OP_ZSTD_DECOMPRESS, MemorySegment.ofArray(input), input.length, MemorySegment.ofArray(output), (int) bound);
-            }
-        }
-        plain = size == output.length ? output : java.util.Arrays.copyOf(output, size);
+        this.context = new HipNative.Context(device);
+        this.decoder = context.openZstdDecodeStream();
     }
 
     @Override
     public int read()
             throws IOException
     {
-        if (closed) {
-            throw new IOException("Stream is closed");
+        if (singleByte == null) {
+            singleByte = new byte[1];
         }
-        fill();
-        return position < plain.length ? plain[position++] & 0xFF : -1;
+        return read(singleByte, 0, 1) == 1 ? singleByte[0] & 0xFF : -1;
     }
 
     @Override
@@ -117,20 +83,50 @@ public final class ZstdHipInputStream
         if (outputLength == 0) {
             return 0;
         }
-        fill();
-        if (position >= plain.length) {
-            return -1;
+        int used = 0;
+        while (used < outputLength) {
+            try {
+                decoder.feed(
+                        MemorySegment.ofArray(input).asSlice(inputOffset), inputLimit - inputOffset,
+                        MemorySegment.ofArray(outputBuffer).asSlice(outputOffset + used), outputLength - used);
+            }
+            catch (RuntimeException e) {
+                if (used > 0) {
+                    break;  // what was decoded goes out; the next read fails
+                }
+                throw e;
+            }
+            inputOffset += (int) decoder.consumed();
+            int produced = (int) decoder.produced();
+            used += produced;
+            if (produced == 0 && inputOffset == inputLimit && !fill()) {
+                // the input has ended: between frames that is the end of the stream, anywhere else the stream is cut short (ZstdInputStream.java:79-85)
+                if ((decoder.atStoppingPoint() && sawInput) || used > 0) {
+                    break;
+                }
+                throw new IOException("Not enough input bytes");
+            }
         }
-        int size = Math.min(outputLength, plain.length - position);
-        System.arraycopy(plain, position, outputBuffer, outputOffset, size);
-        position += size;
-        return size;
+        return used > 0 ? used : -1;
     }
 
-    @Override
-    public int available()
+    private boolean fill()
+            throws IOException
     {
-        return closed || plain == null ? 0 : plain.length - position;
+        if (inputEnded) {
+            return false;
+        }
+        int size = inputStream.read(input, 0, input.length);
+        if (size <= 0) {
+            inputEnded = size < 0;
+            inputOffset = 0;
+            inputLimit = 0;
+            return false;
+        }
+        sawInput = true;
+        inputOffset = 0;
+        inputLimit = size;
+        return true;
     }
 
     @Override
@@ -139,7 +135,13 @@ public final class ZstdHipInputStream
     {
         if (!closed) {
             closed = true;
-            inputStream.close();
+            try {
+                decoder.close();
+                context.close();
+            }
+            finally {
+                inputStream.close();
+            }
         }
     }
 }

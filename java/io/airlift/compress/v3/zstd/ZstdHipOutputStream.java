@@ -15,7 +15,6 @@ package io.airlift.compress.v3.zstd;
 
 import io.airlift.compress.v3.hip.HipNative;
 
-import java.io.ByteArrayOutputStream;
 import java.io.IOException;
 import java.io.OutputStream;
 import java.lang.foreign.MemorySegment;
@@ -23,15 +22,13 @@ import java.lang.foreign.MemorySegment;
 import static java.util.Objects.requireNonNull;
 
 /**
- * {@code ZstdOutputStream} with the encoder on an AMD GPU (MI355X, gfx950) through {@code libaircompressor_hip.so}: what is written is
- * collected and, at {@code close()}, handed to {@code achip_zstdstream_compress}, which produces what {@code ZstdOutputStream} puts on its
- * sink for the same bytes -- the stream's parameters (those for an unknown input size: window 2^20 whatever the size), not
- * {@code ZstdHipCompressor}'s -- and that frame goes to the sink.
- * <p>
- * {@code ZstdOutputStream} starts flushing chunks once 4 MiB have been written (a frame header without the content size, the window
- * slid between chunks); the library writes those bytes too -- they only reach the sink in one piece at {@code close()} -- up to
- * 2^30 bytes per stream.  To write many streams at once use {@link io.airlift.compress.v3.hip.HipBatchCodec} with
- * {@link HipNative#OP_ZSTDSTREAM_COMPRESS}: one item per stream.
+ * {@code ZstdOutputStream} with the encoder on an AMD GPU (MI355X, gfx950) through {@code libaircompressor_hip.so}, INCREMENTAL like the Java
+ * stream ({@code ZstdOutputStream.java:93-221}): {@code write} hands the bytes to the library's stream state
+ * ({@code achip_zstdstream_compress_begin / _feed / _finish}), which keeps the Java stream's 4 MiB buffer on the device, flushes whole blocks to
+ * the sink whenever that buffer is full (the window slides) and writes the rest and the checksum at {@code close()}.  The bytes are
+ * {@code ZstdOutputStream}'s whatever the sizes of the writes -- the stream's parameters (those for an unknown input size: window 2^20), not
+ * {@code ZstdHipCompressor}'s; memory per open stream is a constant.  To write many streams at once use
+ * {@link io.airlift.compress.v3.hip.HipBatchCodec} with {@link HipNative#OP_ZSTDSTREAM_COMPRESS}: one item per stream.
  * <p>
  * Reading: {@link ZstdHipInputStream}.
  */
@@ -40,7 +37,9 @@ public final class ZstdHipOutputStream
 {
     private final OutputStream outputStream;
     private final HipNative.Context context;
-    private final ByteArrayOutputStream pending = new ByteArrayOutputStream();
+    private final HipNative.Context.ZstdEncodeStream encoder;
+    private final byte[] flushed = new byte[1 << 20];
+    private byte[] singleByte;
     private boolean closed;
 
     public ZstdHipOutputStream(OutputStream outputStream)
@@ -53,16 +52,18 @@ public final class ZstdHipOutputStream
         this.outputStream = requireNonNull(outputStream, "outputStream is null");
         HipNative.verifyEnabled();
         this.context = new HipNative.Context(device);
+        this.encoder = context.openZstdEncodeStream();
     }
 
     @Override
     public void write(int b)
             throws IOException
     {
-        if (closed) {
-            throw new IOException("Stream is closed");
+        if (singleByte == null) {
+            singleByte = new byte[1];
         }
-        pending.write(b);
+        singleByte[0] = (byte) b;
+        write(singleByte, 0, 1);
     }
 
     @Override
@@ -72,7 +73,19 @@ public final class ZstdHipOutputStream
         if (closed) {
             throw new IOException("Stream is closed");
         }
-        pending.write(buffer, offset, length);
+        java.util.Objects.checkFromIndexSize(offset, length, buffer.length);
+        int at = 0;
+        while (true) {
+            encoder.feed(MemorySegment.ofArray(buffer).asSlice(offset + at), length - at, MemorySegment.ofArray(flushed), flushed.length);
+            int produced = (int) encoder.produced();
+            if (produced > 0) {
+                outputStream.write(flushed, 0, produced);
+            }
+            at += (int) encoder.consumed();
+            if (at >= length && produced < flushed.length) {
+                return;
+            }
+        }
     }
 
     @Override
@@ -82,14 +95,20 @@ public final class ZstdHipOutputStream
         if (closed) {
             return;
         }
-        // (ZstdOutputStream.close sets `closed` only behind writeChunk(true) and closes its sink in a finally block: M/zstd/ZstdOutputStream.java:193-205)
+        // (ZstdOutputStream.close :193-205 sets `closed` only behind writeChunk(true); the sink is closed either way)
         try {
-            byte[] input = pending.toByteArray();
-            byte[] output = new byte[HipNative.zstdStreamMaxCompressedLength(input.length)];
-            int size = context.singleBlock(HipNative.OP_ZSTDSTREAM_COMPRESS, MemorySegment.ofArray(input), input.length, MemorySegment.ofArray(output), output.length);
-            outputStream.write(output, 0, size);
+            boolean done;
+            do {
+                done = encoder.finish(MemorySegment.ofArray(flushed), flushed.length);
+                int produced = (int) encoder.produced();
+                if (produced > 0) {
+                    outputStream.write(flushed, 0, produced);
+                }
+            }
+            while (!done);
             closed = true;
-            context.close();  // (the native context -- a HIP stream and scratch -- goes with the stream, not with the garbage collector)
+            encoder.close();
+            context.close();
         }
         finally {
             outputStream.close();
