@@ -34,6 +34,21 @@ for step in "$@"; do
     zstream)       # the incremental Zstd reader + the encoder after the FSE table rewrite
       timeout 1200 python -m pytest tests/test_gpu_zstd_stream.py tests/test_gpu_zstd.py -m gpu -x -q 2>&1 | tail -15
       timeout 600 python tools/fuzz_encoders.py 1500 77 zstd 2>&1 | tail -5 ;;
+    bench)         # the default bench.py as the driver runs it, with its wall clock
+      S=$(date +%s); timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench.py wall: $(( $(date +%s) - S )) s rc=$?" | tee -a $O/bench.err; tail -3 $O/bench.err
+      python - <<'PY'
+import json
+r = json.loads([l for l in open("gpurun_out/r05/bench.json") if l.startswith("{")][-1])
+print("value", r["value"], "frac", r["roofline"]["frac"], "traffic", r["roofline"]["traffic"], "cpu", r.get("cpu_baseline", {}).get("value"))
+for k in sorted(r):
+    if k.startswith("value_") or k in ("mixed_ok", "end_to_end", "single_block_us"):
+        print(k, r[k] if not isinstance(r[k], dict) else {a: b for a, b in r[k].items() if a != "what"})
+PY
+      ;;
+    tworounds)     # the two-pass decoders on a batch of two rounds (524288 blocks) beside the one-round batch (verdict 4c)
+      for wl in lz4_decompress snappy_decompress; do for nb in 262144 524288; do
+        timeout 600 python bench.py --no-cpu-baseline --no-extra --no-legs --no-host-facing --steps 5 --warmup 2 --workload $wl --data corpus --blocks $nb 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$wl corpus blocks $nb', r['value'], r['roofline']['frac'], r['roofline']['kernel_ms_avg'])"
+      done; done | tee $O/tworounds.txt ;;
     tests)
       timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
     zstd)          # the Zstd section + per-kernel times
