@@ -77,6 +77,7 @@ struct achip_ctx {
     int lz4dAutoMinBlocks = 4096;  // auto mode probes batches from this size on (smaller ones always take the rings)
     int lz4dVariant = 5;     // 5 = chosen on the device per batch (default: DESIGN 4c), 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 7 = two passes: parse to records + a wavefront per block (lz4_decompress_v7.hip).  (4 / 6, a lane per block, lost to 7 on every batch they were built for -- 300 .. 330 GiB/s against 515 on corpus -- and were removed in round 4.)
     int snappydVariant = 5;  // 5 auto, 1 rings (snappy_decompress_v2.hip), 7 two passes (snappy_decompress_v5.hip), as for LZ4
+    int latencyMaxBlocks = 256;  // batches of at most this many blocks (a single block!) take the ring decoders' latency class: a wavefront and 128 KiB of LDS history per block
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
     int lz4cVariant = 4;     // 4 = many matches per window of 64 positions (lz4_compress_mw.h; default since round 3: 25.8 against 18.2 GiB/s on corpus, 100 against 111 on fragments), 0 = serial probes, 1 = 64 probes per step (batch).  (3, the batch over an LDS input window, measured 17.2 against 18.2 GiB/s on corpus in round 3: removed)
     int snappycVariant = 4;  // THE DEFAULT IS 4 = two tiers, many matches per window (snappy_compress_mw.h; since round 3: 22.0 against 8.3 GiB/s on corpus, 65 against 74 on fragments); tested non-default variants: 0 = serial probes, 1 = 64 probes per step (batch), 2 = batch in two tiers: tables in LDS and in global memory.  (3, variant 2 over an LDS input window, measured 8.3 against 7.6 GiB/s for 2 and a third of variant 4: removed in round 4.)
@@ -385,7 +386,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 e = achip::launch_lz4_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->lz4dGroup, ctx->ringClass, ctx->execVariant, nullptr);
                 break;
             }
-            e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, nullptr);
+            e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass == 0 && a.nBlocks <= ctx->latencyMaxBlocks ? 3 : ctx->ringClass, nullptr);
             break;
         case ACHIP_OP_LZ4_COMPRESS:
             e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint);
@@ -422,7 +423,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 e = achip::launch_snappy_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->snappydGroup, ctx->ringClass, ctx->execVariant, nullptr);
                 break;
             }
-            e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, nullptr);
+            e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass == 0 && a.nBlocks <= ctx->latencyMaxBlocks ? 3 : ctx->ringClass, nullptr);
             break;
         case ACHIP_OP_SNAPPY_COMPRESS: {
             if (ctx->snappycVariant >= 2) {
@@ -933,6 +934,10 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         if (value < 0 || value > 2) return bad_argument("zstd.decompress.exec: 0 rings, 1 record executor, 2 chosen per item");
         achip::g_zstd_pipe_exec = (int)value;
     }  // (process-wide: a development switch between the two execute stages)
+    else if (k == "decompress.latency_max_blocks") {
+        if (value < 0 || value > 65536) return bad_argument("decompress.latency_max_blocks: 0 (never) .. 65536: LZ4 / Snappy batches of at most this many blocks take a wavefront and 128 KiB of LDS history per block");
+        ctx->latencyMaxBlocks = (int)value;
+    }
     else if (k == "decompress.ring_pad") {
         if (value < 0 || value > 256 || (value & 15) != 0) return bad_argument("ring pad must be a multiple of 16 in 0..256");
         ctx->ringPad = (int)value;

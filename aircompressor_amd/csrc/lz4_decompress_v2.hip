@@ -73,9 +73,44 @@ static hipError_t lz4d2_launch(const BatchArgs& a, hipStream_t stream, const int
     return hipGetLastError();
 }
 
-// ringClass: 0 = compact rings (more blocks per CU), 1 = large rings (longer LDS reach)
+// ---- FEW blocks (ring class 3, what the context picks for batches of at most `decompress.latency_max_blocks` blocks -- a single block is the
+// literal Lz4HipDecompressor.decompress(MemorySegment, MemorySegment)): a workgroup of ONE wavefront per block, all 64 lanes on the block, and an
+// output ring of 128 KiB -- every back-reference an LZ4 block can hold (offsets <= 65 535) is an LDS read.  With the compact rings a lone block's
+// far matches (83 % of a text block's) are one memory round trip each on a wavefront that has nothing else to run: 6.3 ms for 64 KiB of text
+// (profiles/r05_single_block_latency.txt); here the chain never leaves the CU.
+template <int IN_RING, int OUT_RING>
+__global__ __launch_bounds__(64) void lz4_decompress_latency_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[IN_RING + OUT_RING + 16];
+    const int lane = threadIdx.x;
+    const int64_t block = blockIdx.x;
+    if (block >= batch_count(a)) {
+        return;
+    }
+    const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
+    uint8_t* out = a.dstBase + a.dstOff[block];
+    const int32_t inLimit = a.srcLen[block];
+    const int32_t outLimit = a.dstCap[block];
+    Rings<64, IN_RING, OUT_RING, 1> R;
+    R.init(smem, smem + IN_RING, in, inLimit, out, lane, nullptr);
+    int32_t st = 0;
+    int32_t eo = 0;
+    int32_t op = 0;
+    lz4_block_decode<64, IN_RING, OUT_RING, 1>(R, in, inLimit, outLimit, st, eo, op);
+    if (lane == 0) {
+        a.outLen[block] = st == 0 ? op : 0;
+        a.status[block] = st;
+        a.errOffset[block] = (int64_t)eo;
+    }
+}
+
+// ringClass: 0 = compact rings (more blocks per CU), 1 = large rings (longer LDS reach), 3 = a wavefront and 128 KiB of history per block (few blocks)
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups)
 {
+    if (ringClass == 3 && a.only == nullptr && mixedGroups == nullptr && a.nBlocksDev == nullptr) {
+        hipLaunchKernelGGL((lz4_decompress_latency_kernel<4096, 131072>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a);
+        return hipGetLastError();
+    }
     switch (groupSize) {
         case 1: return ringClass ? lz4d2_launch<1, 128, 256, 4>(a, stream, mixedGroups) : lz4d2_launch<1, 64, 128, 2>(a, stream, mixedGroups);
         case 2: return ringClass ? lz4d2_launch<2, 128, 256, 2>(a, stream, mixedGroups) : lz4d2_launch<2, 64, 128, 1>(a, stream, mixedGroups);

@@ -66,8 +66,33 @@ static hipError_t snd2_launch(const BatchArgs& a, hipStream_t stream, const int3
     return hipGetLastError();
 }
 
+// FEW blocks (ring class 3: lz4_decompress_v2.hip says why): a workgroup of one wavefront per buffer, 128 KiB of history in LDS
+template <int IN_RING, int OUT_RING>
+__global__ __launch_bounds__(64) void snappy_decompress_latency_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[IN_RING + OUT_RING + 16];
+    const int lane = threadIdx.x;
+    const int64_t block = blockIdx.x;
+    if (block >= batch_count(a)) {
+        return;
+    }
+    int32_t st = 0;
+    int32_t eo = 0;
+    int32_t op = 0;
+    snappy_buffer_decode<64, IN_RING, OUT_RING, 1, 0>(smem, smem + IN_RING, nullptr, a.srcBase + a.srcOff[block], a.srcLen[block], a.dstBase + a.dstOff[block], a.dstCap[block], lane, st, eo, op);
+    if (lane == 0) {
+        a.outLen[block] = st == 0 ? op : 0;
+        a.status[block] = st;
+        a.errOffset[block] = (int64_t)eo;
+    }
+}
+
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups)
 {
+    if (ringClass == 3 && a.only == nullptr && mixedGroups == nullptr && a.nBlocksDev == nullptr) {
+        hipLaunchKernelGGL((snappy_decompress_latency_kernel<4096, 131072>), dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a);
+        return hipGetLastError();
+    }
     switch (groupSize) {
         case 1: return ringClass ? snd2_launch<1, 128, 256, 4>(a, stream, mixedGroups) : snd2_launch<1, 64, 128, 2>(a, stream, mixedGroups);
         case 2: return ringClass ? snd2_launch<2, 128, 256, 2>(a, stream, mixedGroups) : snd2_launch<2, 64, 128, 1>(a, stream, mixedGroups);

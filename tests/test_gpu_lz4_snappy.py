@@ -17,14 +17,17 @@ CODECS = {
     "snappy": dict(c=3, d=2, group_opt="snappy.decompress.group", variant_opt="snappy.decompress.variant"),
 }
 # ring decoder configurations: (variant, lanes per block, ring class); variant 1 = LDS rings
-DECODERS = [(1, 16, 0), (1, 16, 1), (1, 4, 0), (1, 4, 1), (1, 2, 0), (1, 2, 1), (1, 1, 0), (1, 1, 1), (1, 8, 0), (1, 8, 1), (1, 32, 0), (1, 32, 1), (1, 64, 0), (1, 64, 1)]
+DECODERS = [(1, 16, 0), (1, 16, 1), (1, 4, 0), (1, 4, 1), (1, 2, 0), (1, 2, 1), (1, 1, 0), (1, 1, 1), (1, 8, 0), (1, 8, 1), (1, 32, 0), (1, 32, 1), (1, 64, 0), (1, 64, 1), (1, 4, 3)]
 
 
 def configure(gb, codec, cfg):
     variant, group, ring = cfg
     gb.set_option(CODECS[codec]["variant_opt"], variant)
     gb.set_option(CODECS[codec]["group_opt"], group)
-    gb.set_option("decompress.ring_class", ring)
+    # ring class 3 is the LATENCY class: not an option value but what the context picks for batches of at most decompress.latency_max_blocks blocks
+    # (256 by default: a wavefront and 128 KiB of LDS history per block); the other configurations are tested with it switched off
+    gb.set_option("decompress.ring_class", 0 if ring == 3 else ring)
+    gb.set_option("decompress.latency_max_blocks", 65536 if ring == 3 else 0)
 
 
 @pytest.fixture(scope="module")

@@ -50,6 +50,10 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
         const int gs = (op % 10) == 4 ? 4 : ((op % 10) == 6 ? 16 : 64);
         return op < 50 ? achip::launch_lz4_decompress_rings(a, nullptr, gs, 0, nullptr) : achip::launch_snappy_decompress_rings(a, nullptr, gs, 0, nullptr);
     }
+    if (op == 49 || op == 59) {  // the latency class (ring class 3): a wavefront and 128 KiB of LDS history per block
+        a.ringPad = 80;
+        return op == 49 ? achip::launch_lz4_decompress_rings(a, nullptr, 4, 3, nullptr) : achip::launch_snappy_decompress_rings(a, nullptr, 4, 3, nullptr);
+    }
     return -1;
 }
 

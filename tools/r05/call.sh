@@ -49,6 +49,9 @@ PY
       for wl in lz4_decompress snappy_decompress; do for nb in 262144 524288; do
         timeout 600 python bench.py --no-cpu-baseline --no-extra --no-legs --no-host-facing --steps 5 --warmup 2 --workload $wl --data corpus --blocks $nb 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$wl corpus blocks $nb', r['value'], r['roofline']['frac'], r['roofline']['kernel_ms_avg'])"
       done; done | tee $O/tworounds.txt ;;
+    latency)       # the ring decoders' latency class: parity tests + one block per call
+      timeout 900 python -m pytest tests/test_gpu_lz4_snappy.py tests/test_gpu_corpus.py tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -4
+      timeout 300 python tools/single_block_latency.py 2>&1 | grep -v amdgpu.ids | tee $O/single_block_latency.txt ;;
     tests)
       timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
     zstd)          # the Zstd section + per-kernel times
