@@ -77,6 +77,7 @@ struct achip_ctx {
     int lz4dAutoMinBlocks = 4096;  // auto mode probes batches from this size on (smaller ones always take the rings)
     int lz4dVariant = 5;     // 5 = chosen on the device per batch (default: DESIGN 4c), 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 7 = two passes: parse to records + a wavefront per block (lz4_decompress_v7.hip).  (4 / 6, a lane per block, lost to 7 on every batch they were built for -- 300 .. 330 GiB/s against 515 on corpus -- and were removed in round 4.)
     int snappydVariant = 5;  // 5 auto, 1 rings (snappy_decompress_v2.hip), 7 two passes (snappy_decompress_v5.hip), as for LZ4
+    int smallBatchHint = 0;      // set by the host-pointer path for ONE launch: what a look at the first block's tokens says -- 1 short sequences, 2 long ones (0: nobody looked)
     int latencyMaxBlocks = 256;  // batches of at most this many blocks (a single block!) take the ring decoders' latency class: a wavefront and 128 KiB of LDS history per block
     int ringClass = 0;       // 0 = compact rings, 1 = large rings
     int lz4cVariant = 4;     // 4 = many matches per window of 64 positions (lz4_compress_mw.h; default since round 3: 25.8 against 18.2 GiB/s on corpus, 100 against 111 on fragments), 0 = serial probes, 1 = 64 probes per step (batch).  (3, the batch over an LDS input window, measured 17.2 against 18.2 GiB/s on corpus in round 3: removed)
@@ -350,7 +351,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
     ctx->lastLz4dAuto = false;
     ctx->lastTwopass = false;
     switch (op) {
-        case ACHIP_OP_LZ4_DECOMPRESS:
+        case ACHIP_OP_LZ4_DECOMPRESS: {
             if (ctx->lz4dVariant == 5 && a.nBlocks >= ctx->lz4dAutoMinBlocks) {
                 // auto: the choice is made on the device (no host round trip): probes count the mixed 16-block groups and sample the
                 // sequence lengths, every candidate decoder is launched and the ones not chosen return at once.  Mixed or short-sequence
@@ -375,7 +376,13 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 if (e == hipSuccess) e = achip::launch_lz4_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, ctx->lz4dGroup, ctx->ringClass, ctx->execVariant, stats);
                 break;
             }
-            if (ctx->lz4dVariant == 7) {  // two passes: parse to records, a wavefront per block executes them (lz4_decompress_v7.hip)
+            // FEW blocks (at most decompress.latency_max_blocks; a single block is the literal Lz4HipDecompressor.decompress): nothing hides a lone block's chain,
+            // so the choice is by what one 64 KiB block costs (profiles/r05_single_block_latency.txt): long sequences -- the ring decoders' latency class
+            // (0.64 ms; the two passes 1.0); short ones or unknown -- the two passes with the wavefront-per-block parser (text 1.3 ms; the latency class 5.1)
+            const bool fewBlocks = ctx->lz4dVariant == 5 && a.nBlocks <= ctx->latencyMaxBlocks && a.nBlocksDev == nullptr && a.only == nullptr;
+            const int hint = ctx->smallBatchHint;
+            ctx->smallBatchHint = 0;
+            if (ctx->lz4dVariant == 7 || (fewBlocks && hint != 2)) {  // two passes: parse to records, a wavefront per block executes them (lz4_decompress_v7.hip)
                 const int32_t r = ensure_twopass_scratch(ctx, 0, a.nBlocks, achip::LZ4_RECORD_BYTES_PER_BLOCK, achip::LZ4_RECORD_BYTES_PER_BLOCK_MIN);
                 if (r < 0) return r;
                 if (r == 0) {
@@ -388,10 +395,11 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             }
             e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass == 0 && a.nBlocks <= ctx->latencyMaxBlocks ? 3 : ctx->ringClass, nullptr);
             break;
+        }
         case ACHIP_OP_LZ4_COMPRESS:
             e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint);
             break;
-        case ACHIP_OP_SNAPPY_DECOMPRESS:
+        case ACHIP_OP_SNAPPY_DECOMPRESS: {
             if (ctx->snappydVariant == 5 && a.nBlocks >= ctx->lz4dAutoMinBlocks) {  // auto, as for LZ4
                 const int32_t r = ensure_twopass_scratch(ctx, 4096, a.nBlocks, achip::SNAPPY_RECORD_BYTES_PER_BLOCK, achip::SNAPPY_RECORD_BYTES_PER_BLOCK_MIN);
                 if (r < 0) return r;
@@ -412,7 +420,11 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 if (e == hipSuccess) e = achip::launch_snappy_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, ctx->snappydGroup, ctx->ringClass, ctx->execVariant, stats);
                 break;
             }
-            if (ctx->snappydVariant == 7) {  // two passes (snappy_decompress_v5.hip)
+            // (few blocks: the two passes only when the host looked and saw short elements -- Snappy has no wavefront-per-block parser, and the lane parser
+            // costs long-element data more than the latency class does)
+            const bool fewSnappy = ctx->snappydVariant == 5 && a.nBlocks <= ctx->latencyMaxBlocks && a.nBlocksDev == nullptr && a.only == nullptr && ctx->smallBatchHint == 1;
+            ctx->smallBatchHint = 0;
+            if (ctx->snappydVariant == 7 || fewSnappy) {  // two passes (snappy_decompress_v5.hip)
                 const int32_t r = ensure_twopass_scratch(ctx, 0, a.nBlocks, achip::SNAPPY_RECORD_BYTES_PER_BLOCK, achip::SNAPPY_RECORD_BYTES_PER_BLOCK_MIN);
                 if (r < 0) return r;
                 if (r == 0) {
@@ -425,6 +437,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             }
             e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass == 0 && a.nBlocks <= ctx->latencyMaxBlocks ? 3 : ctx->ringClass, nullptr);
             break;
+        }
         case ACHIP_OP_SNAPPY_COMPRESS: {
             if (ctx->snappycVariant >= 2) {
                 int32_t r = ensure_scratch(ctx, achip::snappy_compress_scratch_bytes());
@@ -1452,6 +1465,67 @@ struct HostChunk {
 
 constexpr int64_t kCopyGrain = 256 << 10;  // bytes per copy task: small blocks are grouped, large ones split
 
+// The mean output bytes per sequence over a block's first 64 sequences (LZ4 tokens: M/lz4/Lz4RawDecompressor.java:59-140; Snappy elements:
+// M/snappy/SnappyRawDecompressor.java:84-110), read on the host: 1 = short (below the decoders' auto-mode thresholds: 48 bytes for LZ4, 24 for
+// Snappy), 2 = long, 0 = cannot tell.  Bounds-safe on any bytes.
+int probe_sequences(bool snappy, const uint8_t* p, int64_t n)
+{
+    int64_t at = 0, out = 0;
+    int seqs = 0;
+    if (snappy) {
+        for (int k = 0; k < 5 && at < n; k++) {  // the uncompressed length (a varint)
+            if ((p[at++] & 0x80) == 0) break;
+        }
+        while (seqs < 64 && at < n) {
+            const int tag = p[at++];
+            int64_t len;
+            if ((tag & 3) == 0) {
+                len = (tag >> 2) + 1;
+                if (len > 60) {
+                    const int extra = (int)len - 60;
+                    if (at + extra > n) break;
+                    len = 0;
+                    for (int b = 0; b < extra; b++) len |= (int64_t)p[at + b] << (8 * b);
+                    len += 1;
+                    at += extra;
+                }
+                at += len;
+            }
+            else {
+                len = (tag & 3) == 1 ? ((tag >> 2) & 7) + 4 : (tag >> 2) + 1;
+                at += (tag & 3) == 1 ? 1 : ((tag & 3) == 2 ? 2 : 4);
+            }
+            out += len;
+            seqs++;
+        }
+        return seqs < 8 ? 0 : (out < 24LL * seqs ? 1 : 2);
+    }
+    while (seqs < 64 && at < n) {
+        const int token = p[at++];
+        int64_t lit = token >> 4, ml = token & 15;
+        if (lit == 15) {
+            int v;
+            do {
+                if (at >= n) return seqs < 8 ? 0 : (out < 48LL * seqs ? 1 : 2);
+                v = p[at++];
+                lit += v;
+            } while (v == 255);
+        }
+        at += lit + 2;
+        if (ml == 15) {
+            int v;
+            do {
+                if (at >= n) return seqs < 8 ? 0 : (out < 48LL * seqs ? 1 : 2);
+                v = p[at++];
+                ml += v;
+            } while (v == 255);
+        }
+        out += lit + ml + 4;
+        seqs++;
+    }
+    return seqs < 8 ? 0 : (out < 48LL * seqs ? 1 : 2);
+}
+
 // order[j] = caller's item index of the j-th processed item (nullptr: identity); ops: per item (mixed) or nullptr (all `op`)
 int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t* order, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen,
                    void* dstBase, const int64_t* dstOff, const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int64_t n)
@@ -1568,6 +1642,12 @@ int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t
         uint8_t* h = ctx->slotHost[0];
         uint8_t* d = ctx->slotDev[0];
         gather(c, h);
+        if ((c.op == ACHIP_OP_LZ4_DECOMPRESS || c.op == ACHIP_OP_SNAPPY_DECOMPRESS) && c.count <= ctx->latencyMaxBlocks) {
+            // few blocks in host memory: a look at the first block's first tokens tells the decoders apart (launch_op).  Only the choice of the
+            // decoder depends on it, never a result: whatever these bytes are, both decoders report what the Java decoder would.
+            const int64_t i0 = item(c.first);
+            ctx->smallBatchHint = probe_sequences(c.op == ACHIP_OP_SNAPPY_DECOMPRESS, h + sOff[c.first], srcLen[i0]);
+        }
         HIP_TRY(hipMemcpyAsync(d, h, (size_t)c.inEnd, hipMemcpyHostToDevice, ctx->stream));
         ctx->maxSrcLenHint = std::max(c.maxLen, 1);
         r = launch_op(c.op, ctx, batch_args(c, d));
