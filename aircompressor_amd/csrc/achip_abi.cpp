@@ -379,7 +379,10 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             // FEW blocks (at most decompress.latency_max_blocks; a single block is the literal Lz4HipDecompressor.decompress): nothing hides a lone block's chain,
             // so the choice is by what one 64 KiB block costs (profiles/r05_single_block_latency.txt): long sequences -- the ring decoders' latency class
             // (0.64 ms; the two passes 1.0); short ones or unknown -- the two passes with the wavefront-per-block parser (text 1.3 ms; the latency class 5.1)
-            const bool fewBlocks = ctx->lz4dVariant == 5 && a.nBlocks <= ctx->latencyMaxBlocks && a.nBlocksDev == nullptr && a.only == nullptr;
+            // ... and so does every batch below the size auto mode probes from (4 096): such a batch of LARGE blocks -- files as single blocks, a frame's 4 MiB blocks --
+            // is the compact rings' worst case (four lanes per block, 83 % of a text block's matches a memory round trip each: the 263-item LZ4 bucket of the mixed corpus batch
+            // took 526 ms, its two largest files alone through the two passes 80), and on long sequences the two passes cost about what the rings do at these sizes
+            const bool fewBlocks = ctx->lz4dVariant == 5 && a.nBlocks < ctx->lz4dAutoMinBlocks && a.nBlocksDev == nullptr && a.only == nullptr;
             const int hint = ctx->smallBatchHint;
             ctx->smallBatchHint = 0;
             if (ctx->lz4dVariant == 7 || (fewBlocks && hint != 2)) {  // two passes: parse to records, a wavefront per block executes them (lz4_decompress_v7.hip)
