@@ -18,7 +18,8 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
         blocks += [bytes(1 << 20), bytes(range(256)) * 2048, (b"abc" * 100000)[:250001], text, text[:100000] + bytes(50000) + text[:70000],
                    bytes(rng.integers(0, 256, 300000, dtype=np.uint8)), (bytes(rng.integers(0, 256, 1000, dtype=np.uint8)) * 400)]
     OPS = {"lz4": 0, "snappy": 2, "zstd": 4, "lz4frame": 6, "snappyframed": 8}
-    VARIANTS = {"lz4": [1, 7, 71], "snappy": [1, 7],  # (71: LZ4 variant 7 with the lane-per-block parser -- batches of this size take the wavefront-per-block one)
+    VARIANTS = {"lz4": [1, 13, 7, 71], "snappy": [1, 13, 7],  # (71: LZ4 variant 7 with the lane-per-block parser -- batches of this size take the wavefront-per-block one;
+                                                                # 13: the ring decoders' latency class -- a wavefront and 128 KiB of LDS history per block -- for every batch size)
                  "zstd": [1, 0], "lz4frame": [None], "snappyframed": [None]}
 
 
@@ -63,7 +64,8 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
         want = [expect(codec, c, cap) for c, cap in cases]
         for variant in VARIANTS[codec]:
             if variant is not None:
-                gb.set_option("%s.decompress.variant" % codec, 7 if variant == 71 else variant)
+                gb.set_option("%s.decompress.variant" % codec, 7 if variant == 71 else (1 if variant == 13 else variant))
+                gb.set_option("decompress.latency_max_blocks", 65536 if variant == 13 else 0)
                 if codec == "lz4":
                     gb.set_option("lz4.decompress.parse", 1 if variant == 71 else 0)
             outs, status, err = gb.run(OPS[codec], [c for c, _ in cases], [cap for _, cap in cases], unaligned=True)
@@ -79,6 +81,7 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
             print("%s variant %s: %d cases (%d malformed), %d mismatches" % (codec, variant, len(cases), n_err, wrong), flush=True)
         if codec == "lz4":
             gb.set_option("lz4.decompress.parse", 0)
+        gb.set_option("decompress.latency_max_blocks", 256)
     print("TOTAL MISMATCHES", bad)
     return bad
 

@@ -52,6 +52,12 @@ PY
     latency)       # the ring decoders' latency class: parity tests + one block per call
       timeout 900 python -m pytest tests/test_gpu_lz4_snappy.py tests/test_gpu_corpus.py tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -4
       timeout 300 python tools/single_block_latency.py 2>&1 | grep -v amdgpu.ids | tee $O/single_block_latency.txt ;;
+    fuzz)          # differential fuzz of the decoders (status, offset, plaintext) against the oracle on the GPU, after this round's routing changes
+      ( timeout 700 python tools/fuzz_decoders.py 20000 51 lz4,snappy
+        timeout 500 python tools/fuzz_decoders.py 3000 52 lz4,snappy big
+        timeout 900 python tools/fuzz_decoders.py 6000 53 zstd
+        timeout 600 python tools/fuzz_decoders.py 3000 54 zstd big
+        timeout 600 python tools/fuzz_decoders.py 6000 55 lz4frame,snappyframed ) 2>&1 | grep -v "^\[" | tee $O/fuzz_decoders.txt ;;
     tests)
       timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
     zstd)          # the Zstd section + per-kernel times
