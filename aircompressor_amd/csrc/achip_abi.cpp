@@ -58,6 +58,7 @@ int64_t zstd_stream_step_scratch_bytes(int32_t blocks);
 hipError_t launch_zstd_stream_step(hipStream_t stream, void* scratch, int64_t scratchBytes, void* carryDev, const uint8_t* dSrc, int32_t srcLen, int32_t blocks, uint8_t* dOut,
                                    int32_t startPos, int32_t outLimit, int32_t closing, int32_t hasChecksum, uint32_t expected, int32_t* result);
 extern int g_lz4_parse_mode;
+extern int g_snappy_parse_mode;
 hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int variant, const AuxScratch* aux);
 int64_t lz4frame_decompress_scratch_bytes(int32_t nItems, int variant);
 hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes);
@@ -423,9 +424,9 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 if (e == hipSuccess) e = achip::launch_snappy_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, ctx->snappydGroup, ctx->ringClass, ctx->execVariant, stats);
                 break;
             }
-            // (few blocks: the two passes only when the host looked and saw short elements -- Snappy has no wavefront-per-block parser, and the lane parser
-            // costs long-element data more than the latency class does)
-            const bool fewSnappy = ctx->snappydVariant == 5 && a.nBlocks <= ctx->latencyMaxBlocks && a.nBlocksDev == nullptr && a.only == nullptr && ctx->smallBatchHint == 1;
+            // (few blocks, and every batch below the size auto mode probes from: as for LZ4 -- the two passes with the wavefront-per-block parser unless the host looked and
+            // saw long elements, which take the latency class: one 64 KiB text block 7.2 ms with a lane parsing it, profiles/r05_single_block_latency.txt for what it is now)
+            const bool fewSnappy = ctx->snappydVariant == 5 && a.nBlocks < ctx->lz4dAutoMinBlocks && a.nBlocksDev == nullptr && a.only == nullptr && ctx->smallBatchHint != 2;
             ctx->smallBatchHint = 0;
             if (ctx->snappydVariant == 7 || fewSnappy) {  // two passes (snappy_decompress_v5.hip)
                 const int32_t r = ensure_twopass_scratch(ctx, 0, a.nBlocks, achip::SNAPPY_RECORD_BYTES_PER_BLOCK, achip::SNAPPY_RECORD_BYTES_PER_BLOCK_MIN);
@@ -945,6 +946,10 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     else if (k == "lz4.decompress.parse") {
         if (value < 0 || value > 2) return bad_argument("lz4.decompress.parse: 0 by the batch (a wavefront per block below 32768 blocks), 1 a lane per block, 2 a wavefront per block");
         achip::g_lz4_parse_mode = (int)value;
+    }
+    else if (k == "snappy.decompress.parse") {
+        if (value < 0 || value > 2) return bad_argument("snappy.decompress.parse: 0 by the batch (a wavefront per block up to 4096 blocks), 1 a lane per block, 2 a wavefront per block");
+        achip::g_snappy_parse_mode = (int)value;
     }
     else if (k == "zstd.decompress.exec") {
         if (value < 0 || value > 2) return bad_argument("zstd.decompress.exec: 0 rings, 1 record executor, 2 chosen per item");

@@ -14,6 +14,7 @@
 
 #include "achip_seqexec.h"
 #include "achip_seqexec2.h"
+#include "achip_waveparse.h"
 
 namespace achip {
 
@@ -341,134 +342,18 @@ __global__ __launch_bounds__(64) void lz4_parse2_kernel(BatchArgs a, sx::ArenaHe
 // 360 bytes of the block -- ends the chain in front of it and is parsed by lz4_parse_general, the Java loop body check by check, its records
 // written by the whole wavefront (a literal run of megabytes is 64 records per step).  Same records, same statuses and error offsets as the
 // parser above: the executor does not know which of the two wrote them.
-namespace wp {
-constexpr int STAGE = 352;  // a sequence that starts within 64 positions and has at most one extension byte per length ends within 337 bytes
-constexpr int SLAB = 2048;  // the staging area holds the stream's bytes [B0, B0 + SLAB + STAGE); it moves on by a slab at a time
-constexpr int CAP = SLAB + STAGE;
-}
-// The stream's bytes for the windows: a linear piece of the stream in LDS that moves on by 2 KiB when the windows have walked through 2 KiB -- the
-// bytes of the NEXT slab are requested when a slab arrives and sit in registers until then (a window consumes ~40 bytes: fifty windows later).
-// Staging every window's 352 bytes on its own cost a memory round trip per window: 2 us for ~7 sequences.
-struct WaveStage {
-    uint8_t* lds;
-    const uint8_t* in;
-    int32_t inLimit;
-    int32_t b0;        // (uniform) stream position of lds[0]; -1: nothing staged
-    u32x4 pend[2];     // this lane's 2 x 16 bytes of [b0 + CAP, b0 + CAP + SLAB)
-    int lane;
-    __device__ __forceinline__ u32x4 fetch(int32_t pos) const
-    {
-        return pos + 16 <= inLimit ? ld16(in + pos) : u32x4{0, 0, 0, 0};  // (what lies beyond the block is never looked at: windows stay 8 bytes clear of the end)
-    }
-    __device__ __forceinline__ void request()
-    {
-        pend[0] = fetch(b0 + wp::CAP + 16 * lane);
-        pend[1] = fetch(b0 + wp::CAP + 16 * (lane + 64));
-    }
-    __device__ __forceinline__ void restart(int32_t base)  // synchronous: the first window, and a window far beyond what is staged (behind a long literal run)
-    {
-        wave_sync();
-        b0 = base;
-        for (int32_t i = lane; i < wp::CAP / 16; i += 64) {
-            *(u32x4*)(lds + 16 * i) = fetch(b0 + 16 * i);
-        }
-        request();
-        wave_sync();
-    }
-    __device__ __forceinline__ void advance()  // by one slab: the tail moves to the front, the requested slab lands behind it, the next one is requested
-    {
-        wave_sync();
-        u32x4 tail = {0, 0, 0, 0};
-        if (lane < wp::STAGE / 16) {
-            tail = *(const u32x4*)(lds + wp::SLAB + 16 * lane);
-        }
-        wave_sync();
-        if (lane < wp::STAGE / 16) {
-            *(u32x4*)(lds + 16 * lane) = tail;
-        }
-        *(u32x4*)(lds + wp::STAGE + 16 * lane) = pend[0];
-        *(u32x4*)(lds + wp::STAGE + 16 * (lane + 64)) = pend[1];
-        b0 += wp::SLAB;
-        request();
-        wave_sync();
-    }
-    // the window at `base` is readable at lds + (base - b0)
-    __device__ __forceinline__ const uint8_t* window(int32_t base)
-    {
-        if (b0 < 0 || base < b0 || base - b0 >= 2 * wp::SLAB) {  // (uniform)
-            restart(base);
-        }
-        else if (base - b0 >= wp::SLAB) {
-            advance();
-        }
-        return lds + (base - b0);
-    }
-};
-struct WaveRecordSink {  // the block's records: chunks of the arena, claimed one at a time
-    sx::ArenaHeader* hdr;
-    uint64_t* arena;
-    int32_t maxChunks;
-    int32_t firstChunk, chunk, fill, count;  // (uniform)
-    bool fallback;                           // (uniform) the arena is exhausted: the ring decoder takes the block
-    // n (<= 64, uniform) records, lane i's at index idx (< n) of the batch if `valid`
-    __device__ __forceinline__ void put(uint64_t rec, bool valid, int32_t idx, int32_t n, int lane)
-    {
-        if (n <= 0 || fallback) {  // (uniform)
-            return;
-        }
-        const int32_t room = sx::CHUNK_RECS - fill;
-        int32_t fresh = -1;
-        if (n > room) {  // (uniform) the batch reaches into a new chunk
-            int32_t c = 0;
-            if (lane == 0) {
-                c = atomicAdd(&hdr->nextChunk, 1);
-            }
-            c = sx::wave_bcast(c, 0);
-            if (c >= maxChunks) {
-                fallback = true;
-                return;
-            }
-            if (chunk >= 0) {
-                if (lane == 0) {
-                    arena[(int64_t)chunk * sx::CHUNK_SLOTS + sx::CHUNK_RECS] = (uint64_t)(uint32_t)c;  // link
-                }
-            }
-            else {
-                firstChunk = c;
-            }
-            fresh = c;
-        }
-        if (valid) {
-            const int32_t slot = fill + idx;
-            if (slot < sx::CHUNK_RECS) {
-                arena[(int64_t)chunk * sx::CHUNK_SLOTS + slot] = rec;
-            }
-            else {
-                arena[(int64_t)fresh * sx::CHUNK_SLOTS + (slot - sx::CHUNK_RECS)] = rec;
-            }
-        }
-        if (n > room) {
-            chunk = fresh;
-            fill = fill + n - sx::CHUNK_RECS;
-        }
-        else {
-            fill += n;
-        }
-        count += n;
-    }
-};
 
 __global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::ArenaHeader* hdr, sx::BlockMeta* meta, int32_t* only, uint64_t* arena, int32_t maxChunks, const int32_t* stats)
 {
     if (stats != nullptr && lz4_pick(stats, a.nBlocks) != LZ4_PICK_TWOPASS) {  // auto mode: the ring decoder takes this batch
         return;
     }
-    __shared__ __attribute__((aligned(16))) uint8_t stageLds[wp::CAP + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t stageLds[WaveStage<wp::LZ4_STAGE>::CAP + 16];
     const int lane = threadIdx.x;
     const int64_t block = blockIdx.x;
     const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
     const int32_t inLimit = uni(a.srcLen[block]);
-    WaveStage W;
+    WaveStage<wp::LZ4_STAGE> W;
     W.lds = stageLds;
     W.in = in;
     W.inLimit = inLimit;
@@ -508,7 +393,7 @@ __global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::Are
     bool finished = S.done;                    // (uniform)
     while (!finished && !K.fallback) {         // (uniform)
         bool general = true;
-        if ((int64_t)S.ip + wp::STAGE + 24 <= (int64_t)inLimit) {  // (uniform) a window: nothing in it can reach the block's last bytes (8: the Java loop's margin; 16: every byte it looks at lies in a 16-byte piece that is inside the block whole -- WaveStage::fetch)
+        if ((int64_t)S.ip + wp::LZ4_STAGE + 24 <= (int64_t)inLimit) {  // (uniform) a window: nothing in it can reach the block's last bytes (8: the Java loop's margin; 16: every byte it looks at lies in a 16-byte piece that is inside the block whole -- WaveStage::fetch)
             const int32_t base = S.ip;
             const uint8_t* const stage = W.window(base);
             // what a sequence at position `lane` of the window would be

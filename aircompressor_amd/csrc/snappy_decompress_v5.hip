@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "achip_seqexec.h"
+#include "achip_waveparse.h"
 
 namespace achip {
 
@@ -346,6 +347,243 @@ __global__ __launch_bounds__(64) void snappy_parse2_kernel(BatchArgs a, sx::Aren
     }
 }
 
+// ---- snappy_parse_wave_kernel: the parse pass with a WAVEFRONT per block (round 5), for batches of FEW blocks -- the Snappy counterpart of
+// lz4_parse_wave_kernel (lz4_decompress_v7.hip has the reasons: a lane's serial chain costs a 64 KiB text block 7 ms when nothing else runs).
+// Lane p of a window of 64 stream positions reads the bytes AS IF an element started at p: a run with its length in the tag and the 1- or 2-byte-offset
+// copy behind it (one record, as in the lane parser), a run alone, or a copy alone; `next` is where the element behind that would begin.  The real
+// elements are the chain 0 -> next[0] -> ...: a scalar loop of lane reads.  The lanes on the chain get their output positions from a scan, make the
+// fast path's checks (those of snappy_parse2_kernel above) and store their records -- up to seven pieces each (60 + 64 bytes).  A run with length
+// bytes, a copy with a 4-byte offset, a failing check and the stream's last 168 bytes end the chain and go through snappy_parse_general, the Java loop
+// body check by check, the records of a long run written by the whole wavefront.  Same statuses, error offsets and output as the lane parser.
+__global__ __launch_bounds__(64) void snappy_parse_wave_kernel(BatchArgs a, sx::ArenaHeader* hdr, sx::BlockMeta* meta, int32_t* only, uint64_t* arena, int32_t maxChunks, const int32_t* stats)
+{
+    if (stats != nullptr && snappy_pick(stats, a.nBlocks) != LZ4_PICK_TWOPASS) {  // auto mode: the ring decoder takes this batch
+        return;
+    }
+    using Stage = WaveStage<wp::SNAPPY_STAGE>;
+    static_assert(64 * 7 <= sx::CHUNK_RECS, "a window's records reach into one new chunk at most");
+    __shared__ __attribute__((aligned(16))) uint8_t stageLds[Stage::CAP + 16];
+    const int lane = threadIdx.x;
+    const int64_t block = blockIdx.x;
+    const uint8_t* __restrict__ in0 = a.srcBase + a.srcOff[block];
+    const int32_t inLen0 = uni(a.srcLen[block]);
+    const int32_t outLimit = uni(a.dstCap[block]);
+    SnappyParseState S;
+    S.ip = 0;
+    S.op = 0;
+    S.st = 0;
+    S.eo = 0;
+    // readUncompressedLength :277-321 (uniform: every lane reads the same bytes)
+    uint32_t expected = 0;
+    int32_t nread = 0;
+    for (int i = 0; i < 5; i++) {
+        if (nread >= inLen0) {
+            S.st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_TRUNCATED);
+            S.eo = inLen0 - nread;
+            break;
+        }
+        const uint32_t b = (uint32_t)uni((int32_t)in0[nread]);
+        nread++;
+        expected |= (b & 0x7f) << (7 * i);
+        if ((b & 0x80) == 0) {
+            break;
+        }
+        if (i == 4) {
+            S.st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_LEN_HIGH_BIT);
+            S.eo = nread;
+        }
+    }
+    if (S.st == 0 && (int32_t)expected < 0) {
+        S.st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_INVALID_LENGTH);
+        S.eo = 0;
+    }
+    if (S.st == 0 && (int64_t)expected > (int64_t)outLimit) {  // :49-50
+        S.st = mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_SNAPPY_OUTPUT_TOO_SMALL);
+        S.eo = 0;
+    }
+    bool finished = S.st != 0;  // (uniform)
+    // uncompressAll :70-220 ; positions relative to the first byte after the varint
+    const uint8_t* const in = in0 + (finished ? 0 : nread);
+    const int32_t inLimit = finished ? 0 : inLen0 - nread;
+    Stage W;
+    W.lds = stageLds;
+    W.in = in;
+    W.inLimit = inLimit;
+    W.b0 = -1;
+    W.pend[0] = u32x4{0, 0, 0, 0};
+    W.pend[1] = u32x4{0, 0, 0, 0};
+    W.lane = lane;
+    WaveRecordSink K;
+    K.hdr = hdr;
+    K.arena = arena;
+    K.maxChunks = maxChunks;
+    K.firstChunk = -1;
+    K.chunk = -1;
+    K.fill = sx::CHUNK_RECS;
+    K.count = 0;
+    K.fallback = false;
+    K.fresh = -1;
+    const int32_t fastOutLimit = outLimit - 8;
+    int32_t litEndPrev = 0;  // (uniform) position (counted from in0) the executor's literal cursor stands at behind the records so far
+    while (!finished && !K.fallback) {  // (uniform)
+        bool general = true;
+        if ((int64_t)S.ip + wp::SNAPPY_STAGE + 24 <= (int64_t)inLimit) {  // (uniform) a window: nothing in it can reach the stream's last bytes (the margins of lz4_parse_wave_kernel)
+            const int32_t base = S.ip;
+            const uint8_t* const stage = W.window(base);
+            // what an element at position `lane` of the window would be
+            uint32_t x;
+            __builtin_memcpy(&x, stage + lane, 4);
+            const uint32_t tag = x & 0xFF;
+            const bool isRun = (tag & 3) == 0;
+            const int32_t nLit = isRun ? (int32_t)(tag >> 2) + 1 : 0;  // (a run with its length in the tag)
+            const int32_t q = lane + (isRun ? 1 + nLit : 0);           // the element behind the run (<= 124); the copy itself when there is no run
+            uint32_t y;
+            __builtin_memcpy(&y, stage + q, 4);
+            const uint32_t tag2 = y & 0xFF, kind2 = tag2 & 3;
+            const bool isCopy = kind2 == 1 || kind2 == 2;
+            const int32_t len1 = (int32_t)((tag2 >> 2) & 7) + 4, off1 = (int32_t)(((tag2 >> 5) << 8) | ((y >> 8) & 0xFF));
+            const int32_t len2 = (int32_t)(tag2 >> 2) + 1, off2 = (int32_t)((y >> 8) & 0xFFFF);
+            const int32_t cLen = isCopy ? (kind2 == 1 ? len1 : len2) : 0, cOff = kind2 == 1 ? off1 : off2;
+            const int32_t next = q + (isCopy ? (kind2 == 1 ? 2 : 3) : 0);
+            // not for the chain: a run with length bytes, a copy with a 4-byte offset
+            const bool stop = isRun ? (tag >> 2) >= 60 : (tag & 3) == 3;
+            const unsigned long long stopMask = __ballot(stop);
+            unsigned long long members = 0;
+            int32_t cur = 0;
+            while (cur < 64 && ((stopMask >> cur) & 1ull) == 0) {  // (uniform) the chain
+                members |= 1ull << cur;
+                cur = __builtin_amdgcn_readlane(next, cur);
+            }
+            // the members' places in the output, and the checks that need them (the lane parser's runFast / copyFast; the input-side conditions hold in a window)
+            const bool member = ((members >> lane) & 1ull) != 0;
+            const int32_t tot = member ? nLit + cLen : 0;
+            const int32_t endRel = sx::wave_scan_incl(tot, lane);
+            const int32_t opEnd = S.op + endRel, opCopy = opEnd - cLen;
+            const bool wrong = member && ((isRun && opCopy > fastOutLimit) || (isCopy && (cOff == 0 || cOff > opCopy || opEnd > outLimit)));
+            const unsigned long long wrongMask = __ballot(wrong);
+            if (wrongMask != 0) {  // (uniform) the chain ends in front of the first such element
+                const int first = __builtin_ctzll(wrongMask);
+                members &= (1ull << first) - 1ull;
+                cur = first;
+            }
+            const bool mine = ((members >> lane) & 1ull) != 0;
+            if (members != 0) {  // (uniform)
+                const unsigned long long below = members & ((1ull << lane) - 1ull);
+                const int prevLane = below != 0 ? 63 - __builtin_clzll(below) : 0;
+                const int32_t prevQ = __shfl(q, prevLane);
+                const int32_t litStart = nread + base + lane + (isRun ? 1 : 0);
+                const int32_t skip = litStart - (below != 0 ? nread + base + prevQ : litEndPrev);
+                const int last = 63 - __builtin_clzll(members);
+                const int32_t litFull = nLit > 16 ? (nLit + 15) / 16 - 1 : 0;
+                const int32_t matchRest = cLen > 16 ? (cLen - 16 + 15) / 16 : 0;
+                const int32_t pieces = mine ? litFull + 1 + matchRest : 0;
+                const int32_t pieceEnd = sx::wave_scan_incl(pieces, lane);
+                const int32_t n = sx::wave_bcast(pieceEnd, 63);
+                if (__ballot(mine && skip > sx::MAX_SKIP) != 0) {  // (a gap beyond the record field) the ring decoder takes the block
+                    K.fallback = true;
+                }
+                else if (K.begin(n, lane)) {
+                    for (int32_t k = 0; __ballot(k < pieces) != 0; k++) {  // (uniform) piece k of every element that has one: at most seven rounds, one or two on text
+                        int32_t pl, pm, o = cOff;
+                        if (k < litFull) {
+                            pl = 16;
+                            pm = 0;
+                        }
+                        else if (k == litFull) {
+                            pl = nLit - 16 * litFull;
+                            pm = cLen < 16 ? cLen : 16;
+                        }
+                        else {
+                            const int32_t m = k - litFull;  // copy pieces before this one
+                            pl = 0;
+                            pm = cLen - 16 * m < 16 ? cLen - 16 * m : 16;
+                            const int32_t xm = 16 * m + cOff;
+                            o = sx::largest_multiple(cOff > 0 ? cOff : 1, xm < 65535 ? xm : 65535);
+                        }
+                        K.store(sx::rec_pack((uint32_t)pl, (uint32_t)pm, pm > 0 ? (uint32_t)o : 0u, k == 0 ? (uint32_t)skip : 0u), k < pieces, pieceEnd - pieces + k);
+                    }
+                    K.end(n);
+                    S.op += sx::wave_bcast(endRel, last);
+                    litEndPrev = nread + base + sx::wave_bcast(q, last);
+                    S.ip = base + cur;
+                    general = false;
+                }
+            }
+        }
+        if (general && !K.fallback) {  // (uniform) one element the Java way, its records by the whole wavefront
+            if (S.ip >= inLimit) {  // the loop condition :84
+                finished = true;
+            }
+            else {
+                int32_t rLen = 0, rOff = 0, rStart = 0;
+                const int kindG = snappy_parse_general(in, S, inLimit, outLimit, rLen, rOff, rStart);
+                if (S.st != 0) {
+                    finished = true;
+                }
+                else if (kindG == 2 && rOff > 0xFFFF) {  // an offset beyond the record field: the ring decoder takes the block
+                    K.fallback = true;
+                }
+                else if (kindG != 0) {
+                    const int32_t sLit = kindG == 1 ? rLen : 0, sMl = kindG == 2 ? rLen : 0, sOff = kindG == 2 ? rOff : 0;
+                    const int32_t litFull = sLit > 16 ? (sLit + 15) / 16 - 1 : 0;
+                    const int32_t matchRest = sMl > 16 ? (sMl - 16 + 15) / 16 : 0;
+                    const int32_t pieces = litFull + 1 + matchRest;
+                    const int32_t skip0 = nread + rStart - litEndPrev;
+                    if (skip0 > sx::MAX_SKIP) {
+                        K.fallback = true;
+                    }
+                    for (int32_t k0 = 0; k0 < pieces && !K.fallback; k0 += 64) {  // (uniform)
+                        const int32_t k = k0 + lane;
+                        int32_t pl, pm, o = sOff;
+                        if (k < litFull) {
+                            pl = 16;
+                            pm = 0;
+                        }
+                        else if (k == litFull) {
+                            pl = sLit - 16 * litFull;
+                            pm = sMl < 16 ? sMl : 16;
+                        }
+                        else {
+                            const int32_t m = k - litFull;
+                            pl = 0;
+                            pm = sMl - 16 * m < 16 ? sMl - 16 * m : 16;
+                            const int32_t xm = 16 * m + sOff;
+                            o = sx::largest_multiple(sOff > 0 ? sOff : 1, xm < 65535 ? xm : 65535);
+                        }
+                        const int32_t left = pieces - k0;
+                        K.put(sx::rec_pack((uint32_t)pl, (uint32_t)pm, pm > 0 ? (uint32_t)o : 0u, k == 0 ? (uint32_t)skip0 : 0u), k < pieces, lane, left < 64 ? left : 64, lane);
+                    }
+                    litEndPrev = nread + rStart + sLit;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        if (K.fallback) {
+            only[block] = 1;
+            meta[block].firstChunk = 0;
+            meta[block].count = 0;
+            atomicAdd(&hdr->fallbackBlocks, 1);
+        }
+        else {
+            if (S.st == 0 && (int64_t)expected != (int64_t)S.op) {  // :61-65
+                S.st = mk_status(ACHIP_CLASS_MALFORMED, ACHIP_D_SNAPPY_LENGTH_MISMATCH);
+                S.eo = 0;
+            }
+            only[block] = 0;
+            meta[block].firstChunk = K.firstChunk < 0 ? 0 : K.firstChunk;
+            meta[block].count = S.st == 0 ? K.count : 0;
+            a.outLen[block] = S.st == 0 ? S.op : 0;
+            a.status[block] = S.st;
+            a.errOffset[block] = (int64_t)S.eo;
+        }
+    }
+}
+
+// which of the two parsers: 0 = by the batch (a wavefront per block up to 4 096 blocks with a count known to the host, as for LZ4), 1 = a lane per block,
+// 2 = a wavefront per block (context option snappy.decompress.parse)
+int g_snappy_parse_mode = 0;
+
 hipError_t launch_seq_execute2(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant, const int32_t* stats, int32_t shortLimit);
 int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
@@ -369,7 +607,13 @@ hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stre
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((a.nBlocks + 63) / 64)), wg(64);
     {
-        hipLaunchKernelGGL(snappy_parse2_kernel, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+        const bool wavePerBlock = a.nBlocksDev == nullptr && (g_snappy_parse_mode == 2 || (g_snappy_parse_mode == 0 && a.nBlocks <= 4096));
+        if (wavePerBlock) {
+            hipLaunchKernelGGL(snappy_parse_wave_kernel, dim3((unsigned)a.nBlocks), wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+        }
+        else {
+            hipLaunchKernelGGL(snappy_parse2_kernel, grid, wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
+        }
         e = launch_seq_execute2(a, stream, meta, arena, execVariant, stats, 6);
         if (e != hipSuccess) return e;
     }

@@ -139,3 +139,41 @@ def multi_block_plains():
     return shaped + [whole, whole[:300000], whole[100000:100000 + 131073], whole[:131072] + noise[:140000] + whole[:70000], b"\0" * 400000, b"abc" * 100000 + whole[50000:250000],
             noise[:5], noise, whole[400000:1000000], b"q" * 131072 + b"r" * 131072 + whole[:10], whole[:262144], logs,
             (" ".join(str(x) for x in rng.integers(0, 1000, 200000))).encode(), bytes(rng.choice(list(b"ACGT"), 700000).tolist()), bytes(mixed[:3 << 20])]
+
+
+def snappy_random_stream(rng, target):
+    """A valid raw Snappy stream of about `target` plaintext bytes made of random elements of every kind (what the Java encoder never writes included: copies with
+    4-byte offsets, runs behind runs, runs with one to three length bytes): for the parsers' rarely taken branches."""
+    body, n = bytearray(), 0
+    while n < target:
+        kind = int(rng.integers(0, 10)) if n > 0 else 0
+        if kind <= 2:  # a run, its length in the tag or in 1..3 bytes behind it
+            ln = int(rng.choice([1, 2, 5, 16, 17, 31, 32, 33, 48, 60, 61, 64, 100, 256, 257, 1000, 70000][:15 if target < 100000 else 17]))
+            data = bytes(rng.integers(97, 101, ln, dtype=np.uint8))
+            if ln <= 60 and rng.integers(0, 4) != 0:
+                body.append((ln - 1) << 2)
+            else:
+                nb = 1 if ln <= 256 else (2 if ln <= 65536 else 3)
+                nb = min(3, nb + int(rng.integers(0, 2)))
+                body.append((59 + nb) << 2)
+                body += (ln - 1).to_bytes(nb, "little")
+            body += data
+            n += ln
+        elif kind <= 5:  # a copy with a 1-byte offset: 4..11 bytes, offsets below 2048
+            ln, off = int(rng.integers(4, 12)), int(rng.integers(1, min(n, 2047) + 1))
+            body += bytes([1 | ((ln - 4) << 2) | ((off >> 8) << 5), off & 0xFF])
+            n += ln
+        elif kind <= 8:  # a copy with a 2-byte offset: 1..64 bytes
+            ln, off = int(rng.integers(1, 65)), int(rng.integers(1, min(n, 65535) + 1))
+            body += bytes([2 | ((ln - 1) << 2)]) + off.to_bytes(2, "little")
+            n += ln
+        else:  # a copy with a 4-byte offset
+            ln, off = int(rng.integers(1, 65)), int(rng.integers(1, n + 1))
+            body += bytes([3 | ((ln - 1) << 2)]) + off.to_bytes(4, "little")
+            n += ln
+    pre, v = bytearray(), n
+    while v >= 0x80:
+        pre.append((v & 0x7F) | 0x80)
+        v >>= 7
+    pre.append(v)
+    return bytes(pre + body), n

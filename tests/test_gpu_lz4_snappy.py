@@ -120,13 +120,20 @@ def test_lz4_two_pass_decoder(gb, o, cfg, parse):
             assert outs[i] == eout, "case %d" % i
 
 
+@pytest.mark.parametrize("parse", [1, 2], ids=["lane-per-block-parse", "wavefront-per-block-parse"])
 @pytest.mark.parametrize("variant", [7], ids=["two-pass"])
-def test_snappy_two_pass_decoder(gb, o, variant):
-    """variant 7 (snappy_decompress_v5.hip), forced for any batch size: plaintext, status and error offsets equal the oracle's, corrupt streams
-    included"""
+def test_snappy_two_pass_decoder(gb, o, variant, parse):
+    """variant 7 (snappy_decompress_v5.hip), forced for any batch size, with either parser (snappy.decompress.parse: a lane per block, or a wavefront
+    per block -- what batches of up to 4 096 blocks take): plaintext, status and error offsets equal the oracle's, corrupt streams included; and
+    streams of random elements of every kind (copies with 4-byte offsets, runs with length bytes, runs behind runs: what the Java encoder never
+    writes), some beyond 64 KiB"""
     rng = np.random.default_rng(11)
     blocks = all_blocks()
     cases = [(o.compress("snappy", b), len(b)) for b in blocks] + [(o.compress("snappy", b), len(b) + 37) for b in blocks[:20]]
+    for target in (40, 500, 3000, 20000, 70000, 150000, 400000):
+        for _ in range(4):
+            c, n = common.snappy_random_stream(rng, target)
+            cases += [(c, n), (c, n + 9), (c, n - 1), (c[:len(c) - 1 - int(rng.integers(0, 40))], n)]
     cases += [(b"", 10), (b"\x00", 0), (b"\x05", 16), (bytes([0x80] * 5 + [1]), 16), (bytes([0xFF, 0xFF, 0xFF, 0xFF, 0x0F]), 16)]
     for b in [d for _, d, _ in common.corpus_sample()[:4]]:
         c = bytearray(o.compress("snappy", b))
@@ -136,9 +143,11 @@ def test_snappy_two_pass_decoder(gb, o, variant):
             m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
             cases.append((bytes(m), len(b)))
     configure(gb, "snappy", (variant, 4, 0))
+    gb.set_option("snappy.decompress.parse", parse)
     try:
         outs, status, err = gb.run(CODECS["snappy"]["d"], [c for c, _ in cases], [cap for _, cap in cases], unaligned=True)
     finally:
+        gb.set_option("snappy.decompress.parse", 0)
         configure(gb, "snappy", DECODERS[0])
     for i, (c, cap) in enumerate(cases):
         est, eoff, eout = _oracle_status(o, "snappy", c, cap)

@@ -18,7 +18,7 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
         blocks += [bytes(1 << 20), bytes(range(256)) * 2048, (b"abc" * 100000)[:250001], text, text[:100000] + bytes(50000) + text[:70000],
                    bytes(rng.integers(0, 256, 300000, dtype=np.uint8)), (bytes(rng.integers(0, 256, 1000, dtype=np.uint8)) * 400)]
     OPS = {"lz4": 0, "snappy": 2, "zstd": 4, "lz4frame": 6, "snappyframed": 8}
-    VARIANTS = {"lz4": [1, 13, 7, 71], "snappy": [1, 13, 7],  # (71: LZ4 variant 7 with the lane-per-block parser -- batches of this size take the wavefront-per-block one;
+    VARIANTS = {"lz4": [1, 13, 7, 71], "snappy": [1, 13, 7, 71],  # (71: variant 7 with the lane-per-block parser -- batches of this size take the wavefront-per-block one;
                                                                 # 13: the ring decoders' latency class -- a wavefront and 128 KiB of LDS history per block -- for every batch size)
                  "zstd": [1, 0], "lz4frame": [None], "snappyframed": [None]}
 
@@ -33,19 +33,27 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
     bad = 0
     for codec in codecs:
         comp = [o.compress(codec, b) for b in blocks]
+        caps = [len(b) for b in blocks]
+        if codec == "snappy":  # streams of random elements of every kind (what the Java encoder never writes: 4-byte offsets, runs with length bytes, runs behind runs)
+            for target in (40, 500, 3000, 20000, 70000) + ((150000, 400000) if big else ()):
+                for _ in range(4):
+                    c, n = common.snappy_random_stream(rng, target)
+                    comp.append(c)
+                    caps.append(n)
         if codec == "zstd":  # third-party frames as well (no checksum, other header forms, treeless / repeat modes never from the Java encoder)
             try:
                 import pyarrow as pa
                 z = pa.Codec("zstd", compression_level=3)
                 comp = comp + [z.compress(b, asbytes=True) for b in blocks]
                 blocks = blocks + blocks
+                caps = caps + caps
             except ImportError:
                 pass
         cases = []
         for _ in range(n_cases):
-            k = int(rng.integers(0, len(blocks)))
+            k = int(rng.integers(0, len(comp)))
             c = bytearray(comp[k])
-            cap = len(blocks[k])
+            cap = caps[k]
             kind = int(rng.integers(0, 6))
             if kind <= 2:      # 1..4 byte mutations
                 for _ in range(int(rng.integers(1, 5))):
@@ -66,8 +74,8 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
             if variant is not None:
                 gb.set_option("%s.decompress.variant" % codec, 7 if variant == 71 else (1 if variant == 13 else variant))
                 gb.set_option("decompress.latency_max_blocks", 65536 if variant == 13 else 0)
-                if codec == "lz4":
-                    gb.set_option("lz4.decompress.parse", 1 if variant == 71 else 0)
+                if codec in ("lz4", "snappy"):
+                    gb.set_option("%s.decompress.parse" % codec, 1 if variant == 71 else 0)
             outs, status, err = gb.run(OPS[codec], [c for c, _ in cases], [cap for _, cap in cases], unaligned=True)
             wrong = 0
             for i, (est, eoff, eout) in enumerate(want):
@@ -79,8 +87,8 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
             bad += wrong
             n_err = sum(1 for w in want if w[0] != 0)
             print("%s variant %s: %d cases (%d malformed), %d mismatches" % (codec, variant, len(cases), n_err, wrong), flush=True)
-        if codec == "lz4":
-            gb.set_option("lz4.decompress.parse", 0)
+        if codec in ("lz4", "snappy"):
+            gb.set_option("%s.decompress.parse" % codec, 0)
         gb.set_option("decompress.latency_max_blocks", 256)
     print("TOTAL MISMATCHES", bad)
     return bad

@@ -25,9 +25,10 @@ extern "C" int emu_batch(int op, const uint8_t* srcBase, const int64_t* srcOff, 
                          const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t n)
 {
     achip::BatchArgs a{srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, n, 0};
-    if (op == 24 || op == 25 || op == 26 || op == 27 || op == 34 || op == 35) {  // two-pass decoders (24 / 25 LZ4 with a lane per block parsing, 26 / 27 with a wavefront per block; 34 / 35 Snappy); odd ops: a tiny arena, so that blocks fall back
+    if (op == 24 || op == 25 || op == 26 || op == 27 || op == 34 || op == 35 || op == 36 || op == 37) {  // two-pass decoders (24 / 25 LZ4 with a lane per block parsing, 26 / 27 with a wavefront per block; 34 / 35 and 36 / 37 Snappy likewise); odd ops: a tiny arena, so that blocks fall back
         const bool snappy = op >= 34, tiny = (op & 1) != 0;
         achip::g_lz4_parse_mode = op == 26 || op == 27 ? 2 : 1;
+        achip::g_snappy_parse_mode = op == 36 || op == 37 ? 2 : 1;
         static std::vector<uint8_t> scratch;
         const int64_t bytes = tiny ? 4096 + ((n * 12 + 4095) & ~4095LL) + 4 * 4096 : achip::lz4_twopass_scratch_bytes(n);
         scratch.assign((size_t)bytes, 0xCD);

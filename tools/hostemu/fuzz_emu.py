@@ -12,18 +12,33 @@ exec(compile(src, os.path.join(ROOT, "tools", "hostemu", "check_v3.py"), "exec")
 
 def fuzz(n_cases, seed):
     rng = np.random.default_rng(seed)
+    only = [int(x) for x in ARGS[ARGS.index("--ops") + 1].split(",")] if "--ops" in ARGS else None
     blocks = [d for _, d, _ in common.corpus_sample()[:8]] + common.synthetic_blocks(9, 12) + [d for _, d in common.HAND_CASES if len(d) > 0]
     blocks += [b[:n] for b in blocks[:4] for n in (17, 300, 5000)]
     total_bad = 0
-    for codec, ops in (("lz4", (24, 25)), ("snappy", (34, 35))):
+    for codec, ops in (("lz4", (24, 25, 26)), ("snappy", (34, 35, 36))):
+        if only is not None:
+            ops = tuple(op for op in ops if op in only)
+        if not ops:
+            continue
         comp = [o.compress(codec, b) for b in blocks]
+        caps = [len(b) for b in blocks]
+        if codec == "snappy":
+            for target in (40, 500, 3000, 20000, 70000, 150000):
+                for _ in range(3):
+                    c, n = common.snappy_random_stream(rng, target)
+                    assert len(o.decompress("snappy", c, n)) == n
+                    comp.append(c)
+                    caps.append(n)
         cases = []
         for _ in range(n_cases):
-            i = int(rng.integers(0, len(blocks)))
+            i = int(rng.integers(0, len(comp)))
             c = bytearray(comp[i])
-            cap = len(blocks[i])
-            kind = int(rng.integers(0, 6))
-            if kind <= 2 and len(c) > 0:
+            cap = caps[i]
+            kind = int(rng.integers(0, 8))
+            if kind >= 6:
+                pass  # as it is
+            elif kind <= 2 and len(c) > 0:
                 for _ in range(int(rng.integers(1, 5))):
                     c[int(rng.integers(0, len(c)))] = int(rng.integers(0, 256))
             elif kind == 3 and len(c) > 1:

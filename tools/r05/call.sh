@@ -52,6 +52,12 @@ PY
     latency)       # the ring decoders' latency class: parity tests + one block per call
       timeout 900 python -m pytest tests/test_gpu_lz4_snappy.py tests/test_gpu_corpus.py tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -4
       timeout 300 python tools/single_block_latency.py 2>&1 | grep -v amdgpu.ids | tee $O/single_block_latency.txt ;;
+    snappywave)    # the wavefront-per-block Snappy parser: parity tests of everything that reaches it, fuzz, one block per call, the mixed batch by bucket
+      timeout 1200 python -m pytest tests/test_gpu_lz4_snappy.py tests/test_gpu_snappy_framed.py tests/test_gpu_hadoop.py tests/test_gpu_corpus.py tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -4
+      ( timeout 500 python tools/fuzz_decoders.py 8000 61 snappy
+        timeout 400 python tools/fuzz_decoders.py 2000 62 snappy big ) 2>&1 | grep -v "^\[" | tee $O/fuzz_snappy_wave.txt
+      timeout 300 python tools/single_block_latency.py 2>&1 | grep -v amdgpu.ids | tee $O/single_block_latency.txt
+      timeout 300 python tools/mixed_breakdown.py 2>&1 | grep -v amdgpu.ids | tee $O/mixed_breakdown.txt ;;
     fuzz)          # differential fuzz of the decoders (status, offset, plaintext) against the oracle on the GPU, after this round's routing changes
       ( timeout 700 python tools/fuzz_decoders.py 20000 51 lz4,snappy
         timeout 500 python tools/fuzz_decoders.py 3000 52 lz4,snappy big
