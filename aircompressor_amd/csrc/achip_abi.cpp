@@ -69,10 +69,10 @@ hipError_t launch_xxh64_batch(const void* srcBase, const int64_t* srcOff, const 
 hipError_t launch_xxh32_batch(const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, int32_t n, uint32_t seed, int32_t* out, hipStream_t stream);
 }  // namespace achip
 
-struct achip_ctx {
+// What achip_ctx_set_option sets (and the bookkeeping of the last launch): a context's settings as a value, so that the helper contexts a mixed
+// batch runs its buckets on (mix_lane) can take them over whole.
+struct achip_options {
     int device = 0;
-    hipStream_t stream = nullptr;
-    // options
     int lz4dGroup = 4;       // lanes per block: measured best on MI355X (profiles/r01_sweep_v2_rings.txt)
     int snappydGroup = 4;
     int lz4dAutoMinBlocks = 4096;  // auto mode probes batches from this size on (smaller ones always take the rings)
@@ -94,8 +94,6 @@ struct achip_ctx {
     int zstdStreamChunked = 1;     // 1: the stream writer takes streams from 4 MiB on as well (chunks flushed before close(), window slides: zstd_stream.hip; byte-identical with
                                    // the test suite's CPU restatement under tools/hostemu, not yet run on a GPU); 0: it refuses them (INVALID_ARGUMENT / ACHIP_D_UNSUPPORTED)
     int zstdStreamBlocks = 65536;  // 128 KiB blocks a pass of the pipeline's multi-block stages has room for (0: multi-block frames take the one-kernel decoder); ~20 GB of scratch, allocated when a batch first holds such frames (halved as often as it takes when the device cannot give that)
-    void* zstdMbScratch = nullptr;
-    int64_t zstdMbScratchBytes = 0;
     int ringPad = 80;        // 64 bytes of far-match staging + 16: consecutive blocks start on different LDS banks
     int scratchPoison = -1;
     int32_t lastZstddBlocks = 0;  // achip_ctx_get_stat
@@ -106,9 +104,21 @@ struct achip_ctx {
     bool lastLz4dAuto = false;  // the last LZ4 decode ran in auto mode: its probe count leads the scratch
     int maxSrcLenHint = 0;
     int execVariant = 2;     // two-pass decoders: 2 = the executor of achip_seqexec2.h (the only one)
+    int mixConcurrent = 1;   // mixed batches: 1 = every bucket on a stream (and scratch) of its own, side by side -- a bucket's tail is a few long serial chains on a
+                             // few CUs (a 10 MB file as ONE block: 0.4 s of one wavefront) --, 0 = one after the other on the context's stream
+};
+
+struct achip_ctx : achip_options {
+    hipStream_t stream = nullptr;
     // scratch for the zstd pipeline (grown on demand)
     void* scratch = nullptr;
     int64_t scratchBytes = 0;
+    void* zstdMbScratch = nullptr;
+    int64_t zstdMbScratchBytes = 0;
+    // mixed batches, buckets side by side: a helper context per codec op (made when a batch first holds that op: a stream and scratch of its own, this context's
+    // options), and the events that order it behind the gather and in front of the scatter
+    achip_ctx* mixLane[16] = {};
+    hipEvent_t mixGathered = nullptr, mixLaneDone[16] = {};
     // mixed batches (achip_mixed_batch): item permutation (pinned host + device) and the bucketed descriptor / result arrays
     int32_t* mixHost = nullptr;
     uint8_t* mixDev = nullptr;
@@ -870,6 +880,11 @@ void achip_ctx_destroy(achip_ctx* ctx)
     if (ctx->mixHost) (void)hipHostFree(ctx->mixHost);
     if (ctx->mixDev) (void)hipFree(ctx->mixDev);
     if (ctx->mixUploaded) (void)hipEventDestroy(ctx->mixUploaded);
+    if (ctx->mixGathered) (void)hipEventDestroy(ctx->mixGathered);
+    for (int k = 0; k < 16; k++) {
+        if (ctx->mixLaneDone[k]) (void)hipEventDestroy(ctx->mixLaneDone[k]);
+        if (ctx->mixLane[k]) achip_ctx_destroy(ctx->mixLane[k]);
+    }
     destroy_host_path(ctx);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -946,6 +961,10 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
     else if (k == "lz4.decompress.parse") {
         if (value < 0 || value > 2) return bad_argument("lz4.decompress.parse: 0 by the batch (a wavefront per block below 32768 blocks), 1 a lane per block, 2 a wavefront per block");
         achip::g_lz4_parse_mode = (int)value;
+    }
+    else if (k == "mixed.concurrent") {
+        if (value != 0 && value != 1) return bad_argument("mixed.concurrent: 1 a mixed batch's buckets side by side (a stream and scratch per codec op), 0 one after the other");
+        ctx->mixConcurrent = (int)value;
     }
     else if (k == "snappy.decompress.parse") {
         if (value < 0 || value > 2) return bad_argument("snappy.decompress.parse: 0 by the batch (a wavefront per block up to 4096 blocks), 1 a lane per block, 2 a wavefront per block");
@@ -1195,6 +1214,21 @@ int32_t ensure_mix(achip_ctx* ctx, int64_t n)
     return 0;
 }
 constexpr int kNumOps = 15;
+static_assert(kNumOps <= 16, "achip_ctx::mixLane");
+bool op_is_encoder(int op) { return (op & 1) != 0 || op == ACHIP_OP_ZSTDSTREAM_COMPRESS; }  // (aircompressor_hip.h: ACHIP_OP_*_COMPRESS are the odd ops, and the last one)
+// the helper context bucket `op` of a mixed batch runs on: made at first use, this context's options at every use
+int32_t mix_lane(achip_ctx* ctx, int op, achip_ctx** out)
+{
+    if (!ctx->mixLane[op]) {
+        achip_ctx* lane = achip_ctx_create(ctx->device);
+        if (!lane) return ACHIP_STATUS(ACHIP_CLASS_DEVICE, ACHIP_D_HIP_ERROR);
+        ctx->mixLane[op] = lane;
+        HIP_TRY(hipEventCreateWithFlags(&ctx->mixLaneDone[op], hipEventDisableTiming));
+    }
+    static_cast<achip_options&>(*ctx->mixLane[op]) = static_cast<const achip_options&>(*ctx);
+    *out = ctx->mixLane[op];
+    return 0;
+}
 }  // namespace
 
 int32_t achip_mixed_batch(achip_ctx* ctx, const int32_t* codecOp, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, void* dstBase,
@@ -1236,11 +1270,34 @@ int32_t achip_mixed_batch(achip_ctx* ctx, const int32_t* codecOp, const void* sr
     HIP_TRY(hipEventRecord(ctx->mixUploaded, ctx->stream));
     const achip::BatchArgs all = make_args(srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, nBlocks);
     HIP_TRY(achip::launch_mix_gather(perm, nBlocks, all, gSrcOff, gSrcLen, gDstOff, gDstCap, ctx->stream));
-    for (int k = 0; k < kNumOps; k++) {
-        if (count[k + 1] == 0) continue;
-        const int64_t s = start[k];
-        r = launch_op(k, ctx, make_args(srcBase, gSrcOff + s, gSrcLen + s, dstBase, gDstOff + s, gDstCap + s, gOutLen + s, gStatus + s, gErr + s, (int32_t)count[k + 1]));
-        if (r < 0) return r;
+    int buckets = 0;
+    for (int k = 0; k < kNumOps; k++) buckets += count[k + 1] != 0 ? 1 : 0;
+    const bool sideBySide = ctx->mixConcurrent != 0 && buckets > 1;
+    if (sideBySide) {
+        if (!ctx->mixGathered) HIP_TRY(hipEventCreateWithFlags(&ctx->mixGathered, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ctx->mixGathered, ctx->stream));
+    }
+    // (the encoders first: theirs are the long chains, and they are launched without a host round trip -- a decoder that reads a count back holds the host only
+    // while the encoders already run)
+    for (int pass = 0; pass < 2; pass++) {
+        for (int k = 0; k < kNumOps; k++) {
+            if (count[k + 1] == 0 || (pass == 0) != op_is_encoder(k)) continue;
+            const int64_t s = start[k];
+            const achip::BatchArgs bucket = make_args(srcBase, gSrcOff + s, gSrcLen + s, dstBase, gDstOff + s, gDstCap + s, gOutLen + s, gStatus + s, gErr + s, (int32_t)count[k + 1]);
+            if (!sideBySide) {
+                r = launch_op(k, ctx, bucket);
+                if (r < 0) return r;
+                continue;
+            }
+            achip_ctx* lane = nullptr;
+            r = mix_lane(ctx, k, &lane);
+            if (r < 0) return r;
+            HIP_TRY(hipStreamWaitEvent(lane->stream, ctx->mixGathered, 0));
+            r = launch_op(k, lane, bucket);
+            if (r < 0) return r;
+            HIP_TRY(hipEventRecord(ctx->mixLaneDone[k], lane->stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->mixLaneDone[k], 0));
+        }
     }
     HIP_TRY(achip::launch_mix_scatter(perm, nBlocks, gOutLen, gStatus, gErr, all, ctx->stream));
     return 0;

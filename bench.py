@@ -235,6 +235,8 @@ def mixed_leg(torch, A, codec, dev, args, rank, world, dist):
     import hashlib
     from aircompressor_amd.sharding import shard_for_rank
     lib = codec.lib
+    if os.environ.get("ACHIP_MIXED_CONCURRENT") in ("0", "1"):  # (measurement aid: the buckets one after the other instead of side by side)
+        codec.native.set_option("mixed.concurrent", int(os.environ["ACHIP_MIXED_CONCURRENT"]))
     rows, items, weights = mixed_job(args.mixed_copies)
     lo, hi = shard_for_rank(weights, world, rank)
     mine = items[lo:hi]

@@ -102,13 +102,21 @@ def mixed_items(o, stride=1):
     return [items[i] for i in order]
 
 
-def test_mixed_batch_device_resident(gb, o):
+@pytest.mark.parametrize("concurrent", [1, 0], ids=["buckets-side-by-side", "buckets-in-turn"])
+def test_mixed_batch_device_resident(gb, o, concurrent):
+    """configs[4] as ONE call: the library buckets the items by codec op; by default every bucket runs on a helper context of its own (stream and
+    scratch: mixed.concurrent = 1), twice in a row so that the second call meets the helpers of the first; or one bucket after the other"""
     items = mixed_items(o)
     assert len(items) > 1200 and len({it[0] for it in items}) == 6
-    outs, status, _ = gb.run([it[0] for it in items], [it[1] for it in items], [it[2] for it in items])
-    for k, (it, out, s) in enumerate(zip(items, outs, status)):
-        assert s == 0, (k, it[0], len(it[1]), s)
-        assert out == it[3], "item %d (op %d, %d bytes in)" % (k, it[0], len(it[1]))
+    gb.set_option("mixed.concurrent", concurrent)
+    try:
+        for _ in range(2 if concurrent else 1):
+            outs, status, _ = gb.run([it[0] for it in items], [it[1] for it in items], [it[2] for it in items])
+            for k, (it, out, s) in enumerate(zip(items, outs, status)):
+                assert s == 0, (k, it[0], len(it[1]), s)
+                assert out == it[3], "item %d (op %d, %d bytes in)" % (k, it[0], len(it[1]))
+    finally:
+        gb.set_option("mixed.concurrent", 1)
 
 
 def test_mixed_batch_host_pointers(gb, o):

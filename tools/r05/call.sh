@@ -58,6 +58,9 @@ PY
         timeout 400 python tools/fuzz_decoders.py 2000 62 snappy big ) 2>&1 | grep -v "^\[" | tee $O/fuzz_snappy_wave.txt
       timeout 300 python tools/single_block_latency.py 2>&1 | grep -v amdgpu.ids | tee $O/single_block_latency.txt
       timeout 300 python tools/mixed_breakdown.py 2>&1 | grep -v amdgpu.ids | tee $O/mixed_breakdown.txt ;;
+    mixlanes)      # a mixed batch's buckets on helper contexts: the corpus tests, the bench leg with and without
+      timeout 900 python -m pytest tests/test_gpu_corpus.py tests/test_bench_launch.py -m gpu -x -q 2>&1 | tail -4
+      for c in 1 0; do ACHIP_MIXED_CONCURRENT=$c timeout 600 python bench.py --no-extra --no-cpu-baseline --no-host-facing --blocks 65536 --steps 3 --warmup 1 2> $O/mixlanes_$c.err | tee $O/mixlanes_$c.json | line "mixed.concurrent=$c"; done ;;
     fuzz)          # differential fuzz of the decoders (status, offset, plaintext) against the oracle on the GPU, after this round's routing changes
       ( timeout 700 python tools/fuzz_decoders.py 20000 51 lz4,snappy
         timeout 500 python tools/fuzz_decoders.py 3000 52 lz4,snappy big
