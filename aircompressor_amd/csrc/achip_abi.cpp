@@ -104,8 +104,8 @@ struct achip_options {
     bool lastLz4dAuto = false;  // the last LZ4 decode ran in auto mode: its probe count leads the scratch
     int maxSrcLenHint = 0;
     int execVariant = 2;     // two-pass decoders: 2 = the executor of achip_seqexec2.h (the only one)
-    int mixConcurrent = 1;   // mixed batches: 1 = every bucket on a stream (and scratch) of its own, side by side -- a bucket's tail is a few long serial chains on a
-                             // few CUs (a 10 MB file as ONE block: 0.4 s of one wavefront) --, 0 = one after the other on the context's stream
+    int mixConcurrent = 1;   // mixed batches: 1 = the three codec families side by side, each on a stream (and scratch) of its own -- a bucket's tail is a few long
+                             // serial chains on a few CUs (a 10 MB file as ONE block: 0.4 s of one wavefront) --, 0 = every bucket in turn on the context's stream
 };
 
 struct achip_ctx : achip_options {
@@ -115,10 +115,12 @@ struct achip_ctx : achip_options {
     int64_t scratchBytes = 0;
     void* zstdMbScratch = nullptr;
     int64_t zstdMbScratchBytes = 0;
-    // mixed batches, buckets side by side: a helper context per codec op (made when a batch first holds that op: a stream and scratch of its own, this context's
-    // options), and the events that order it behind the gather and in front of the scatter
-    achip_ctx* mixLane[16] = {};
-    hipEvent_t mixGathered = nullptr, mixLaneDone[16] = {};
+    // mixed batches, codec families side by side: a helper context for Snappy's and for Zstd's buckets (made when a batch first needs it: a stream and scratch of
+    // its own, this context's options; LZ4's run on this context), and the events that order them behind the gather and in front of the scatter.  (Three streams, not
+    // one per bucket: ROCm maps a process's streams onto GPU_MAX_HW_QUEUES = 4 hardware queues, and two long chains on one queue run one after the other --
+    // profiles/r05_notes.md: six helper streams 1.22 s, with 8 queues 0.75.)
+    achip_ctx* mixLane[3] = {};
+    hipEvent_t mixGathered = nullptr, mixLaneDone[3] = {};
     // mixed batches (achip_mixed_batch): item permutation (pinned host + device) and the bucketed descriptor / result arrays
     int32_t* mixHost = nullptr;
     uint8_t* mixDev = nullptr;
@@ -881,7 +883,7 @@ void achip_ctx_destroy(achip_ctx* ctx)
     if (ctx->mixDev) (void)hipFree(ctx->mixDev);
     if (ctx->mixUploaded) (void)hipEventDestroy(ctx->mixUploaded);
     if (ctx->mixGathered) (void)hipEventDestroy(ctx->mixGathered);
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < 3; k++) {
         if (ctx->mixLaneDone[k]) (void)hipEventDestroy(ctx->mixLaneDone[k]);
         if (ctx->mixLane[k]) achip_ctx_destroy(ctx->mixLane[k]);
     }
@@ -963,7 +965,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         achip::g_lz4_parse_mode = (int)value;
     }
     else if (k == "mixed.concurrent") {
-        if (value != 0 && value != 1) return bad_argument("mixed.concurrent: 1 a mixed batch's buckets side by side (a stream and scratch per codec op), 0 one after the other");
+        if (value != 0 && value != 1) return bad_argument("mixed.concurrent: 1 a mixed batch's codec families side by side (a stream and scratch each), 0 every bucket in turn");
         ctx->mixConcurrent = (int)value;
     }
     else if (k == "snappy.decompress.parse") {
@@ -1214,9 +1216,15 @@ int32_t ensure_mix(achip_ctx* ctx, int64_t n)
     return 0;
 }
 constexpr int kNumOps = 15;
-static_assert(kNumOps <= 16, "achip_ctx::mixLane");
+constexpr int kMixFamilies = 3;
+// LZ4 (block, frame, Hadoop), Snappy (block, framed, Hadoop), Zstd (frame, stream): aircompressor_hip.h's ACHIP_OP_* in pairs
+int op_family(int op)
+{
+    static const int family[8] = {0, 1, 2, 0, 1, 0, 1, 2};  // LZ4, Snappy, Zstd, LZ4 frame, x-snappy-framed, LZ4 Hadoop, Snappy Hadoop, Zstd stream
+    return family[(op >> 1) & 7];
+}
 bool op_is_encoder(int op) { return (op & 1) != 0 || op == ACHIP_OP_ZSTDSTREAM_COMPRESS; }  // (aircompressor_hip.h: ACHIP_OP_*_COMPRESS are the odd ops, and the last one)
-// the helper context bucket `op` of a mixed batch runs on: made at first use, this context's options at every use
+// the helper context codec family `op` (1, 2) of a mixed batch runs on: made at first use, this context's options at every use
 int32_t mix_lane(achip_ctx* ctx, int op, achip_ctx** out)
 {
     if (!ctx->mixLane[op]) {
@@ -1270,33 +1278,35 @@ int32_t achip_mixed_batch(achip_ctx* ctx, const int32_t* codecOp, const void* sr
     HIP_TRY(hipEventRecord(ctx->mixUploaded, ctx->stream));
     const achip::BatchArgs all = make_args(srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, nBlocks);
     HIP_TRY(achip::launch_mix_gather(perm, nBlocks, all, gSrcOff, gSrcLen, gDstOff, gDstCap, ctx->stream));
-    int buckets = 0;
-    for (int k = 0; k < kNumOps; k++) buckets += count[k + 1] != 0 ? 1 : 0;
-    const bool sideBySide = ctx->mixConcurrent != 0 && buckets > 1;
+    // The buckets of one codec family in turn (its encoders first: theirs are the long chains -- a file as ONE block is a single wavefront's work for 0.4 s --, and they are
+    // launched without a host round trip), the families side by side: LZ4's on this context's stream, Snappy's and Zstd's on a helper context each.
+    bool familyUsed[kMixFamilies] = {};
+    for (int k = 0; k < kNumOps; k++) familyUsed[op_family(k)] |= count[k + 1] != 0;
+    const bool sideBySide = ctx->mixConcurrent != 0 && (int)familyUsed[0] + (int)familyUsed[1] + (int)familyUsed[2] > 1;
+    achip_ctx* lanes[kMixFamilies] = {ctx, ctx, ctx};
     if (sideBySide) {
         if (!ctx->mixGathered) HIP_TRY(hipEventCreateWithFlags(&ctx->mixGathered, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ctx->mixGathered, ctx->stream));
+        for (int f = 1; f < kMixFamilies; f++) {
+            if (!familyUsed[f]) continue;
+            r = mix_lane(ctx, f, &lanes[f]);
+            if (r < 0) return r;
+            HIP_TRY(hipStreamWaitEvent(lanes[f]->stream, ctx->mixGathered, 0));
+        }
     }
-    // (the encoders first: theirs are the long chains, and they are launched without a host round trip -- a decoder that reads a count back holds the host only
-    // while the encoders already run)
     for (int pass = 0; pass < 2; pass++) {
         for (int k = 0; k < kNumOps; k++) {
             if (count[k + 1] == 0 || (pass == 0) != op_is_encoder(k)) continue;
             const int64_t s = start[k];
-            const achip::BatchArgs bucket = make_args(srcBase, gSrcOff + s, gSrcLen + s, dstBase, gDstOff + s, gDstCap + s, gOutLen + s, gStatus + s, gErr + s, (int32_t)count[k + 1]);
-            if (!sideBySide) {
-                r = launch_op(k, ctx, bucket);
-                if (r < 0) return r;
-                continue;
-            }
-            achip_ctx* lane = nullptr;
-            r = mix_lane(ctx, k, &lane);
+            r = launch_op(k, lanes[op_family(k)], make_args(srcBase, gSrcOff + s, gSrcLen + s, dstBase, gDstOff + s, gDstCap + s, gOutLen + s, gStatus + s, gErr + s, (int32_t)count[k + 1]));
             if (r < 0) return r;
-            HIP_TRY(hipStreamWaitEvent(lane->stream, ctx->mixGathered, 0));
-            r = launch_op(k, lane, bucket);
-            if (r < 0) return r;
-            HIP_TRY(hipEventRecord(ctx->mixLaneDone[k], lane->stream));
-            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->mixLaneDone[k], 0));
+        }
+    }
+    if (sideBySide) {
+        for (int f = 1; f < kMixFamilies; f++) {
+            if (!familyUsed[f]) continue;
+            HIP_TRY(hipEventRecord(ctx->mixLaneDone[f], lanes[f]->stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->mixLaneDone[f], 0));
         }
     }
     HIP_TRY(achip::launch_mix_scatter(perm, nBlocks, gOutLen, gStatus, gErr, all, ctx->stream));

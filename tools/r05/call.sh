@@ -61,6 +61,10 @@ PY
     mixlanes)      # a mixed batch's buckets on helper contexts: the corpus tests, the bench leg with and without
       timeout 900 python -m pytest tests/test_gpu_corpus.py tests/test_bench_launch.py -m gpu -x -q 2>&1 | tail -4
       for c in 1 0; do ACHIP_MIXED_CONCURRENT=$c timeout 600 python bench.py --no-extra --no-cpu-baseline --no-host-facing --blocks 65536 --steps 3 --warmup 1 2> $O/mixlanes_$c.err | tee $O/mixlanes_$c.json | line "mixed.concurrent=$c"; done ;;
+    hwqueues)      # do the helper streams of a mixed batch share hardware queues?  (ROCm maps a process's streams onto GPU_MAX_HW_QUEUES queues, 4 by default)
+      for q in ${HWQ:-4 8}; do GPU_MAX_HW_QUEUES=$q timeout 600 python bench.py --no-extra --no-cpu-baseline --no-host-facing --blocks 65536 --steps 3 --warmup 1 2> $O/hwq_$q.err | tee $O/hwq_$q.json | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('GPU_MAX_HW_QUEUES=$q', r['legs']['mixed']['per_rank'][0]['seconds'], 's', r['value_mixed'], 'GiB/s')"; done ;;
     fuzz)          # differential fuzz of the decoders (status, offset, plaintext) against the oracle on the GPU, after this round's routing changes
       ( timeout 700 python tools/fuzz_decoders.py 20000 51 lz4,snappy
         timeout 500 python tools/fuzz_decoders.py 3000 52 lz4,snappy big
