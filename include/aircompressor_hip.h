@@ -366,7 +366,9 @@ int32_t achip_batch_host(int32_t codecOp, ACHIP_BATCH_ARGS);
  * LZ4, Snappy and Zstd pages would otherwise do by hand with one Decompressor per codec (M/Decompressor.java:23-30) -- and the
  * results land in the caller's item order.
  *   achip_mixed_batch:      codecOp is a HOST array (the caller's own knowledge of its items); every other array and both buffers are
- *                           DEVICE-accessible as for the homogeneous batch calls; asynchronous on the ctx stream.
+ *                           DEVICE-accessible as for the homogeneous batch calls; asynchronous on the ctx stream (the buckets of the
+ *                           Snappy and Zstd families run on streams of the library's own, side by side with LZ4's, ordered by events behind
+ *                           whatever the ctx stream held and in front of whatever is enqueued on it next: option "mixed.concurrent").
  *   achip_mixed_batch_host: everything is HOST memory; staged like achip_batch_host; synchronous. */
 int32_t achip_mixed_batch(achip_ctx* ctx, const int32_t* codecOp, const void* srcBase, const int64_t* srcOff, const int32_t* srcLen, void* dstBase,
                           const int64_t* dstOff, const int32_t* dstCap, int32_t* outLen, int32_t* status, int64_t* errOffset, int32_t nBlocks);
