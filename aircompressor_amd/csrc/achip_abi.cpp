@@ -21,6 +21,7 @@
 
 namespace achip {
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
+int lz4_ring_group_for(int32_t nBlocks);
 hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
 int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock);
 // record arena per block of the two-pass decoders (8 bytes per record; lz4_decompress_v7.hip: text-like 64 KiB blocks make 6 000 .. 8 500 LZ4
@@ -73,7 +74,7 @@ hipError_t launch_xxh32_batch(const void* srcBase, const int64_t* srcOff, const 
 // batch runs its buckets on (mix_lane) can take them over whole.
 struct achip_options {
     int device = 0;
-    int lz4dGroup = 4;       // lanes per block: measured best on MI355X (profiles/r01_sweep_v2_rings.txt)
+    int lz4dGroup = 0;       // ring decoder, lanes per block: 0 = by the batch size (4 from 32 768 blocks on -- the headline's form --, 16 below, 64 up to 4 096: lz4_ring_group_for), else 1 .. 64
     int snappydGroup = 4;
     int lz4dAutoMinBlocks = 4096;  // auto mode probes batches from this size on (smaller ones always take the rings)
     int lz4dVariant = 5;     // 5 = chosen on the device per batch (default: DESIGN 4c), 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 7 = two passes: parse to records + a wavefront per block (lz4_decompress_v7.hip).  (4 / 6, a lane per block, lost to 7 on every batch they were built for -- 300 .. 330 GiB/s against 515 on corpus -- and were removed in round 4.)
@@ -365,6 +366,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
     ctx->lastTwopass = false;
     switch (op) {
         case ACHIP_OP_LZ4_DECOMPRESS: {
+            const int lz4Group = ctx->lz4dGroup > 0 ? ctx->lz4dGroup : (a.nBlocksDev != nullptr ? 4 : achip::lz4_ring_group_for(a.nBlocks));
             if (ctx->lz4dVariant == 5 && a.nBlocks >= ctx->lz4dAutoMinBlocks) {
                 // auto: the choice is made on the device (no host round trip): probes count the mixed 16-block groups and sample the
                 // sequence lengths, every candidate decoder is launched and the ones not chosen return at once.  Mixed or short-sequence
@@ -373,7 +375,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 const int32_t r = ensure_twopass_scratch(ctx, 4096, a.nBlocks, achip::LZ4_RECORD_BYTES_PER_BLOCK, achip::LZ4_RECORD_BYTES_PER_BLOCK_MIN);
                 if (r < 0) return r;
                 if (r == 0) {  // no room for records on this device right now: the rings alone
-                    e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, nullptr);
+                    e = achip::launch_lz4_decompress_rings(a, ctx->stream, lz4Group, ctx->ringClass, nullptr);
                     break;
                 }
                 int32_t* stats = (int32_t*)ctx->scratch;
@@ -384,9 +386,9 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 e = achip::launch_lz4_mixed_groups(a, ctx->stream, stats, 0);
                 if (e == hipSuccess) e = hipMemsetAsync(stats + 3, 1, 1, ctx->stream);  // stats[3] = 1: the two-pass scheme (achip_device.h lz4_pick)
                 if (e == hipSuccess) e = achip::launch_lz4_sequence_sample(a, ctx->stream, stats, 0, 12);
-                if (e == hipSuccess) e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, stats);
+                if (e == hipSuccess) e = achip::launch_lz4_decompress_rings(a, ctx->stream, lz4Group, ctx->ringClass, stats);
                 ctx->lastTwopass = true;
-                if (e == hipSuccess) e = achip::launch_lz4_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, ctx->lz4dGroup, ctx->ringClass, ctx->execVariant, stats);
+                if (e == hipSuccess) e = achip::launch_lz4_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, lz4Group, ctx->ringClass, ctx->execVariant, stats);
                 break;
             }
             // FEW blocks (at most decompress.latency_max_blocks; a single block is the literal Lz4HipDecompressor.decompress): nothing hides a lone block's chain,
@@ -402,14 +404,14 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 const int32_t r = ensure_twopass_scratch(ctx, 0, a.nBlocks, achip::LZ4_RECORD_BYTES_PER_BLOCK, achip::LZ4_RECORD_BYTES_PER_BLOCK_MIN);
                 if (r < 0) return r;
                 if (r == 0) {
-                    e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass, nullptr);
+                    e = achip::launch_lz4_decompress_rings(a, ctx->stream, lz4Group, ctx->ringClass, nullptr);
                     break;
                 }
                 ctx->lastTwopass = true;
-                e = achip::launch_lz4_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->lz4dGroup, ctx->ringClass, ctx->execVariant, nullptr);
+                e = achip::launch_lz4_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, lz4Group, ctx->ringClass, ctx->execVariant, nullptr);
                 break;
             }
-            e = achip::launch_lz4_decompress_rings(a, ctx->stream, ctx->lz4dGroup, ctx->ringClass == 0 && a.nBlocks <= ctx->latencyMaxBlocks ? 3 : ctx->ringClass, nullptr);
+            e = achip::launch_lz4_decompress_rings(a, ctx->stream, lz4Group, ctx->ringClass == 0 && a.nBlocks <= ctx->latencyMaxBlocks ? 3 : ctx->ringClass, nullptr);
             break;
         }
         case ACHIP_OP_LZ4_COMPRESS:
@@ -1709,6 +1711,15 @@ int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t
                          (int32_t*)(d + c.oOutLen), (int32_t*)(d + c.oStatus), (int64_t*)(d + c.oErr), (int32_t)c.count);
     };
     const int savedHint = ctx->maxSrcLenHint;
+    // A chunk of fewer blocks than auto mode probes on the device (launch_op), in host memory: a look at its first block's first tokens tells the decoders
+    // apart -- short sequences: the two passes; long ones: the rings with many lanes per block (LZ4), the latency class (up to decompress.latency_max_blocks).
+    // Only the choice of the decoder depends on it, never a result: whatever these bytes are, every decoder reports what the Java decoder would.
+    auto look_at_tokens = [&](const HostChunk& c, const uint8_t* h) {
+        const bool few = c.op == ACHIP_OP_LZ4_DECOMPRESS ? c.count < ctx->lz4dAutoMinBlocks : (c.op == ACHIP_OP_SNAPPY_DECOMPRESS && c.count <= ctx->latencyMaxBlocks);
+        if (few) {
+            ctx->smallBatchHint = probe_sequences(c.op == ACHIP_OP_SNAPPY_DECOMPRESS, h + sOff[c.first], srcLen[item(c.first)]);
+        }
+    };
 
     if (chunks.size() == 1) {
         // one chunk (a single block -- what Compressor.compress(MemorySegment, MemorySegment) hands over -- or a small batch): nothing to overlap,
@@ -1717,12 +1728,7 @@ int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t
         uint8_t* h = ctx->slotHost[0];
         uint8_t* d = ctx->slotDev[0];
         gather(c, h);
-        if ((c.op == ACHIP_OP_LZ4_DECOMPRESS || c.op == ACHIP_OP_SNAPPY_DECOMPRESS) && c.count <= ctx->latencyMaxBlocks) {
-            // few blocks in host memory: a look at the first block's first tokens tells the decoders apart (launch_op).  Only the choice of the
-            // decoder depends on it, never a result: whatever these bytes are, both decoders report what the Java decoder would.
-            const int64_t i0 = item(c.first);
-            ctx->smallBatchHint = probe_sequences(c.op == ACHIP_OP_SNAPPY_DECOMPRESS, h + sOff[c.first], srcLen[i0]);
-        }
+        look_at_tokens(c, h);
         HIP_TRY(hipMemcpyAsync(d, h, (size_t)c.inEnd, hipMemcpyHostToDevice, ctx->stream));
         ctx->maxSrcLenHint = std::max(c.maxLen, 1);
         r = launch_op(c.op, ctx, batch_args(c, d));
@@ -1794,6 +1800,7 @@ int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t
         HIP_TRY(hipEventRecord(ctx->evH2D[slot], ctx->copyIn));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->evH2D[slot], 0));
         ctx->maxSrcLenHint = std::max(c.maxLen, 1);
+        look_at_tokens(c, h);
         const int32_t rr = launch_op(c.op, ctx, batch_args(c, d));
         ctx->maxSrcLenHint = savedHint;
         if (rr < 0) return rr;

@@ -105,6 +105,12 @@ __global__ __launch_bounds__(64) void lz4_decompress_latency_kernel(BatchArgs a)
 }
 
 // ringClass: 0 = compact rings (more blocks per CU), 1 = large rings (longer LDS reach), 3 = a wavefront and 128 KiB of history per block (few blocks)
+// Lanes per block for a batch of nBlocks blocks whose count the host knows: the rings want ~262 144 lanes in flight (256 CUs x 16 wavefronts), and the phased 4-lane
+// form is the fastest per lane -- so 4 from 32 768 blocks on, 16 below, 64 up to 4 096 (fragments data, GiB/s at 4 / 16 / 64 lanes: 1 024 blocks of 4 MiB 50 / 71 / 85;
+// 4 096 x 256 KiB 198 / 276 / 282; 8 192 x 64 KiB 386 / 519 / 298; 16 384 x 64 KiB 757 / 843 / 324; 32 768 x 64 KiB 1 301 / 912 / 350; 8 and 32 lanes never win:
+// profiles/r05_groupsweep.txt)
+int lz4_ring_group_for(int32_t nBlocks) { return nBlocks <= 4096 ? 64 : (nBlocks < 32768 ? 16 : 4); }
+
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups)
 {
     if (ringClass == 3 && a.only == nullptr && mixedGroups == nullptr && a.nBlocksDev == nullptr) {

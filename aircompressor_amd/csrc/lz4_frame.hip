@@ -427,6 +427,8 @@ __global__ __launch_bounds__(64) void lz4frame_decompress_kernel(BatchArgs a, in
 
 hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit);
 hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
+hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
+int lz4_ring_group_for(int32_t nBlocks);
 int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock);
 
 int64_t lz4frame_decompress_scratch_bytes(int32_t nItems, int variant)
@@ -496,6 +498,18 @@ hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, vo
     const int32_t nListed = counts[1];
     const bool isShort = counts[8 + 1] > 0 && (int64_t)counts[8 + 2] < 12LL * (int64_t)counts[8 + 1];
     int32_t decoded = 0;
+    BatchArgs c = a;
+    c.srcOff = L.cSrcOff;
+    c.srcLen = L.cSrcLen;
+    c.dstOff = L.cDstOff;
+    c.dstCap = L.cDstCap;
+    c.outLen = L.cOutLen;
+    c.status = L.cStatus;
+    c.errOffset = L.cErrOff;
+    c.nBlocks = nListed;
+    c.nBlocksDev = nullptr;
+    c.only = nullptr;
+    c.onlyStats = nullptr;
     if (nListed > 0 && (variant == 1 || isShort)) {
         long long room = 0;
         __builtin_memcpy(&room, counts + 2, 8);
@@ -504,22 +518,18 @@ hipError_t launch_lz4frame_decompress(const BatchArgs& a, hipStream_t stream, vo
         const int64_t bytes = twopass_scratch_bytes(nListed, perBlock < 98304 ? 98304 : perBlock);
         void* arena = aux->get(aux->user, bytes);
         if (arena != nullptr) {
-            BatchArgs c = a;
-            c.srcOff = L.cSrcOff;
-            c.srcLen = L.cSrcLen;
-            c.dstOff = L.cDstOff;
-            c.dstCap = L.cDstCap;
-            c.outLen = L.cOutLen;
-            c.status = L.cStatus;
-            c.errOffset = L.cErrOff;
-            c.nBlocks = nListed;
-            c.nBlocksDev = nullptr;
-            c.only = nullptr;
-            c.onlyStats = nullptr;
             e = launch_lz4_decompress_twopass(c, stream, arena, bytes, 16, 0, 2, nullptr);
             if (e != hipSuccess) return e;
             decoded = 1;
         }
+    }
+    else if (nListed > 0) {
+        // long sequences (round 5): the listed blocks through the ring decoders, the lanes per block by how many blocks there are (profiles/r05_groupsweep.txt: 16 384
+        // blocks of 256 KiB 890 GiB/s at 16 lanes, 1 024 of 4 MiB 85 at 64) -- the wavefront-per-item kernel below, where these frames went until now, is a serial
+        // reader that was never the fast one: 149 GiB/s on 16 384 frames of 256 KiB
+        e = launch_lz4_decompress_rings(c, stream, lz4_ring_group_for(nListed), 0, nullptr);
+        if (e != hipSuccess) return e;
+        decoded = 1;
     }
     hipLaunchKernelGGL(lz4frame_fold_kernel, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, L, decoded);
     hipLaunchKernelGGL(lz4frame_decompress_kernel<true>, dim3(grid), dim3(64), 0, stream, a, counter, (const int32_t*)L.sSerial);

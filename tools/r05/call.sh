@@ -65,6 +65,30 @@ PY
       for q in ${HWQ:-4 8}; do GPU_MAX_HW_QUEUES=$q timeout 600 python bench.py --no-extra --no-cpu-baseline --no-host-facing --blocks 65536 --steps 3 --warmup 1 2> $O/hwq_$q.err | tee $O/hwq_$q.json | python -c "
 import json,sys
 r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('GPU_MAX_HW_QUEUES=$q', r['legs']['mixed']['per_rank'][0]['seconds'], 's', r['value_mixed'], 'GiB/s')"; done ;;
+    groupsweep)    # ring decoders: lanes per block against batch size, blocks of 256 KiB (what the frame and Hadoop readers hand over)
+      for data in fragments corpus; do for n in 4096 16384 65536; do for g in 4 16 64; do
+        timeout 300 python bench.py --workload lz4_decompress --data $data --blocks $n --block-size 262144 --pool 128 --group $g --variant 1 --no-extra --no-legs --no-host-facing --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$data blocks $n x 256 KiB, $g lanes per block:', r['value'], 'GiB/s')"
+      done; done; done 2>&1 | tee $O/groupsweep.txt ;;
+    groupsweep2)   # ... and blocks of 64 KiB, the group sizes between
+      for spec in "8192 65536" "16384 65536" "32768 65536" "65536 65536" "131072 65536" "8192 262144" "32768 262144" "1024 4194304"; do set -- $spec; for g in 4 8 16 32 64; do
+        timeout 300 python bench.py --workload lz4_decompress --data fragments --blocks $1 --block-size $2 --pool 64 --group $g --variant 1 --no-extra --no-legs --no-host-facing --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('fragments blocks $1 x $2, $g lanes per block:', r['value'], 'GiB/s')"
+      done; done 2>&1 | tee $O/groupsweep2.txt ;;
+    ringgroups)    # lanes per block by the batch size + the LZ4 frame reader's listed blocks through the rings: parity, the container section, the block API at mid sizes
+      timeout 1200 python -m pytest tests/test_gpu_lz4_frame.py tests/test_gpu_hadoop.py tests/test_gpu_lz4_snappy.py tests/test_gpu_corpus.py tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -4
+      timeout 600 python bench.py --section lz4frame --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+for k,v in sorted(r.items()): print(k, {a:b for a,b in v.items() if 'GiBps' in a or a in ('decoder',)} if isinstance(v,dict) else v)" | tee $O/lz4frame_section.txt
+      for spec in "1024 4194304" "4096 262144" "16384 65536" "65536 65536"; do set -- $spec
+        timeout 300 python bench.py --workload lz4_decompress --data fragments --blocks $1 --block-size $2 --pool 64 --no-extra --no-legs --no-host-facing --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('default decoder, fragments blocks $1 x $2:', r['value'], 'GiB/s')"
+      done | tee $O/ringgroups_block_api.txt
+      timeout 600 python tools/fuzz_decoders.py 4000 71 lz4frame 2>&1 | grep -v "^\[" | tail -3 ;;
     fuzz)          # differential fuzz of the decoders (status, offset, plaintext) against the oracle on the GPU, after this round's routing changes
       ( timeout 700 python tools/fuzz_decoders.py 20000 51 lz4,snappy
         timeout 500 python tools/fuzz_decoders.py 3000 52 lz4,snappy big
