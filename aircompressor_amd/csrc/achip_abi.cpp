@@ -210,6 +210,15 @@ int32_t grow_scratch_keeping_old(achip_ctx* ctx, int64_t bytes);
 // records do not fit are decoded by the ring decoder: the parse kernels hand them over per block).  Returns 1 with the scratch in
 // place, 0 when not even the minimum could be had -- the caller then runs the ring decoder alone, which needs no scratch: a batch that
 // decoded before the two-pass decoders existed still decodes on a busy device -- and < 0 for an error that is not about memory.
+// Record bytes per block for the few-blocks route (a batch below the size auto mode probes from, its block sizes known on the device only): such blocks may be whole
+// files -- a 4 MiB text block makes 6 MiB of records where the block codec's 64 KiB blocks make 96 KiB --, so the arena is sized as a whole: a GiB over however few
+// blocks there are (as ever at most half of what the device has free; blocks that still do not fit go to the ring decoder, now at 64 lanes each).
+int64_t few_blocks_record_bytes(int32_t nBlocks, int64_t perBlock)
+{
+    if (nBlocks >= 4096 || nBlocks <= 0) return perBlock;
+    return std::max<int64_t>(perBlock, ((1LL << 30) / nBlocks) & ~4095LL);
+}
+
 int32_t ensure_twopass_scratch(achip_ctx* ctx, int64_t lead, int32_t nBlocks, int64_t perBlock, int64_t perBlockMin)
 {
     const int64_t want = lead + achip::twopass_scratch_bytes(nBlocks, perBlock);
@@ -401,7 +410,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             const int hint = ctx->smallBatchHint;
             ctx->smallBatchHint = 0;
             if (ctx->lz4dVariant == 7 || (fewBlocks && hint != 2)) {  // two passes: parse to records, a wavefront per block executes them (lz4_decompress_v7.hip)
-                const int32_t r = ensure_twopass_scratch(ctx, 0, a.nBlocks, achip::LZ4_RECORD_BYTES_PER_BLOCK, achip::LZ4_RECORD_BYTES_PER_BLOCK_MIN);
+                const int32_t r = ensure_twopass_scratch(ctx, 0, a.nBlocks, few_blocks_record_bytes(a.nBlocks, achip::LZ4_RECORD_BYTES_PER_BLOCK), achip::LZ4_RECORD_BYTES_PER_BLOCK_MIN);
                 if (r < 0) return r;
                 if (r == 0) {
                     e = achip::launch_lz4_decompress_rings(a, ctx->stream, lz4Group, ctx->ringClass, nullptr);
@@ -443,7 +452,7 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             const bool fewSnappy = ctx->snappydVariant == 5 && a.nBlocks < ctx->lz4dAutoMinBlocks && a.nBlocksDev == nullptr && a.only == nullptr && ctx->smallBatchHint != 2;
             ctx->smallBatchHint = 0;
             if (ctx->snappydVariant == 7 || fewSnappy) {  // two passes (snappy_decompress_v5.hip)
-                const int32_t r = ensure_twopass_scratch(ctx, 0, a.nBlocks, achip::SNAPPY_RECORD_BYTES_PER_BLOCK, achip::SNAPPY_RECORD_BYTES_PER_BLOCK_MIN);
+                const int32_t r = ensure_twopass_scratch(ctx, 0, a.nBlocks, few_blocks_record_bytes(a.nBlocks, achip::SNAPPY_RECORD_BYTES_PER_BLOCK), achip::SNAPPY_RECORD_BYTES_PER_BLOCK_MIN);
                 if (r < 0) return r;
                 if (r == 0) {
                     e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, nullptr);

@@ -389,6 +389,7 @@ __global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::Are
     K.fill = sx::CHUNK_RECS;
     K.count = 0;
     K.fallback = false;
+    K.fresh = -1;
     const int32_t fastOut = outLimit - 8 - 4;  // a match may end here at the latest (:82, :168)
     bool finished = S.done;                    // (uniform)
     while (!finished && !K.fallback) {         // (uniform)
@@ -411,8 +412,8 @@ __global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::Are
             const bool mlExt = (token & 0xF) == 0xF;
             const int32_t ml = (int32_t)(mlExt ? 15u + e2 : (token & 0xF)) + 4;
             const int32_t next = q + (mlExt ? 3 : 2);
-            // not for the chain: a second extension byte, more than one record's worth of bytes
-            const bool stop = (litExt && e1 == 255) || (mlExt && e2 == 255) || lit > 16 || ml > 16;
+            // not for the chain: a second extension byte
+            const bool stop = (litExt && e1 == 255) || (mlExt && e2 == 255);
             const unsigned long long stopMask = __ballot(stop);
             unsigned long long members = 0;
             int32_t cur = 0;
@@ -432,19 +433,52 @@ __global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::Are
                 members &= (1ull << first) - 1ull;
                 cur = first;
             }
+            // a sequence of more than 16 literal or match bytes is several records (round 5: until then such a sequence ended the chain and went through
+            // lz4_parse_general -- a sixth of a text block's sequences, each a few dependent reads of global memory): pieces as in the general path below,
+            // their places from a scan; a window's records reach into one new chunk at most, so the chain ends where they would exceed a chunk
+            const int32_t litFull = lit > 16 ? (lit + 15) / 16 - 1 : 0;
+            const int32_t matchRest = ml > 16 ? (ml - 16 + 15) / 16 : 0;
+            int32_t pieces = ((members >> lane) & 1ull) != 0 ? litFull + 1 + matchRest : 0;
+            const int32_t pieceEnd = sx::wave_scan_incl(pieces, lane);
+            const unsigned long long overMask = __ballot(pieces > 0 && pieceEnd > sx::CHUNK_RECS);
+            if (overMask != 0) {  // (uniform; a member has at most 35 pieces: the first always fits)
+                const int first = __builtin_ctzll(overMask);
+                members &= (1ull << first) - 1ull;
+                cur = first;
+            }
             const bool mine = ((members >> lane) & 1ull) != 0;
-            const int32_t n = (int32_t)__popcll(members);
-            if (n > 0) {  // (uniform)
+            pieces = mine ? pieces : 0;
+            if (members != 0) {  // (uniform)
                 const unsigned long long below = members & ((1ull << lane) - 1ull);
                 const int prevLane = below != 0 ? 63 - __builtin_clzll(below) : 0;
                 const int32_t prevQ = __shfl(q, prevLane);
                 const int32_t skip = base + litStart - (below != 0 ? base + prevQ : S.litEndPrev);
                 const int last = 63 - __builtin_clzll(members);
+                const int32_t n = sx::wave_bcast(pieceEnd, last);
                 if (__ballot(mine && skip > sx::MAX_SKIP) != 0) {  // (a gap beyond the record field) the ring decoder takes the block
                     K.fallback = true;
                 }
-                else {
-                    K.put(sx::rec_pack((uint32_t)lit, (uint32_t)ml, (uint32_t)offset, (uint32_t)skip), mine, (int32_t)__popcll(below), n, lane);
+                else if (K.begin(n, lane)) {
+                    for (int32_t k = 0; __ballot(k < pieces) != 0; k++) {  // (uniform) piece k of every sequence that has one: one or two rounds on text
+                        int32_t pl, pm, o = offset;
+                        if (k < litFull) {
+                            pl = 16;
+                            pm = 0;
+                        }
+                        else if (k == litFull) {
+                            pl = lit - 16 * litFull;
+                            pm = ml < 16 ? ml : 16;
+                        }
+                        else {
+                            const int32_t m = k - litFull;  // match pieces before this one
+                            pl = 0;
+                            pm = ml - 16 * m < 16 ? ml - 16 * m : 16;
+                            const int32_t xm = 16 * m + offset;
+                            o = sx::largest_multiple(offset > 0 ? offset : 1, xm < 65535 ? xm : 65535);
+                        }
+                        K.store(sx::rec_pack((uint32_t)pl, (uint32_t)pm, pm > 0 ? (uint32_t)o : 0u, k == 0 ? (uint32_t)skip : 0u), k < pieces, pieceEnd - pieces + k);
+                    }
+                    K.end(n);
                     S.op += sx::wave_bcast(endRel, last);
                     S.litEndPrev = base + sx::wave_bcast(q, last);
                     S.ip = base + cur;

@@ -89,6 +89,16 @@ import json,sys
 r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('default decoder, fragments blocks $1 x $2:', r['value'], 'GiB/s')"
       done | tee $O/ringgroups_block_api.txt
       timeout 600 python tools/fuzz_decoders.py 4000 71 lz4frame 2>&1 | grep -v "^\[" | tail -3 ;;
+    fewkernels)    # the wavefront-per-block parsers and the executor on few text blocks, per kernel
+      for spec in "1 65536" "1024 65536" "64 4194304"; do set -- $spec
+        rm -rf $O/fk; rocprofv3 --kernel-trace --stats --output-format csv -d $O/fk -o s -- python tools/few_blocks_kernels.py $1 $2 2>/dev/null | grep "two passes"
+        python - $(find $O/fk -name '*kernel_stats.csv' | head -1) <<'PY'
+import csv, sys
+for row in csv.DictReader(open(sys.argv[1])):
+    if "achip" in row["Name"] and ("parse" in row["Name"] or "execute" in row["Name"]):
+        print("   %-60s calls=%s avg_us=%.1f" % (row["Name"][:60], row["Calls"], float(row["AverageNs"]) / 1e3))
+PY
+      done 2>&1 | tee $O/fewkernels.txt; rm -rf $O/fk ;;
     fuzz)          # differential fuzz of the decoders (status, offset, plaintext) against the oracle on the GPU, after this round's routing changes
       ( timeout 700 python tools/fuzz_decoders.py 20000 51 lz4,snappy
         timeout 500 python tools/fuzz_decoders.py 3000 52 lz4,snappy big
