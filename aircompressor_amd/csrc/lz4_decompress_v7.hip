@@ -543,9 +543,11 @@ __global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::Are
     }
 }
 
-// which of the two parsers: 0 = by the batch (a wavefront per block up to 4 096 blocks with a count known to the host: 1 024 blocks of 4 MiB
-// 13.5 -> 33 GiB/s with it, but 16 384 chunks of 256 KiB 167 -> 118 -- the lane parser's time does not grow with the count until the chip is full,
-// the wavefront parser's does), 1 = a lane per block, 2 = a wavefront per block (context option lz4.decompress.parse)
+// which of the two parsers: 0 = by the batch (a wavefront per block up to 16 384 blocks with a count known to the host, a lane per block above), 1 = a lane per block,
+// 2 = a wavefront per block (context option lz4.decompress.parse).  The lane parser's time does not grow with the count until the chip is full (64 blocks per instruction
+// stream), the wavefront parser's does from 8 192 blocks on (the wavefronts a launch has resident).  Corpus blocks of 64 KiB, GiB/s lane / wavefront (profiles/r05_parsesweep.txt):
+// 4 096 blocks 48 / 132; 8 192: 90 / 153; 16 384: 163 / 186; 32 768: 255 / 205; 131 072: 443 / 220.  (Round 4 had the line at 4 096: the wavefront parser was half as fast then.)
+constexpr int32_t LZ4_WAVE_PARSE_MAX_BLOCKS = 16384;
 int g_lz4_parse_mode = 0;
 
 // the execute pass (achip_seqexec2.h): pieces of at most 16 + 16 bytes, every global load one batch ahead
@@ -607,7 +609,7 @@ hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream,
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((a.nBlocks + 63) / 64)), wg(64);
     {
-    const bool wavePerBlock = a.nBlocksDev == nullptr && (g_lz4_parse_mode == 2 || (g_lz4_parse_mode == 0 && a.nBlocks <= 4096));
+    const bool wavePerBlock = a.nBlocksDev == nullptr && (g_lz4_parse_mode == 2 || (g_lz4_parse_mode == 0 && a.nBlocks <= LZ4_WAVE_PARSE_MAX_BLOCKS));
     if (wavePerBlock) {
         hipLaunchKernelGGL(lz4_parse_wave_kernel, dim3((unsigned)a.nBlocks), wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
     }

@@ -580,8 +580,10 @@ __global__ __launch_bounds__(64) void snappy_parse_wave_kernel(BatchArgs a, sx::
     }
 }
 
-// which of the two parsers: 0 = by the batch (a wavefront per block up to 4 096 blocks with a count known to the host, as for LZ4), 1 = a lane per block,
-// 2 = a wavefront per block (context option snappy.decompress.parse)
+// which of the two parsers: 0 = by the batch (a wavefront per block up to 32 768 blocks with a count known to the host, a lane per block above), 1 = a lane per block,
+// 2 = a wavefront per block (context option snappy.decompress.parse).  Corpus blocks of 64 KiB, GiB/s lane / wavefront (profiles/r05_parsesweep.txt): 4 096 blocks 27 / 106;
+// 8 192: 53 / 129; 16 384: 98 / 156; 32 768: 157 / 173; 65 536: 236 / 182.
+constexpr int32_t SNAPPY_WAVE_PARSE_MAX_BLOCKS = 32768;
 int g_snappy_parse_mode = 0;
 
 hipError_t launch_seq_execute2(const BatchArgs& a, hipStream_t stream, const sx::BlockMeta* meta, const uint64_t* arena, int execVariant, const int32_t* stats, int32_t shortLimit);
@@ -607,7 +609,7 @@ hipError_t launch_snappy_decompress_twopass(const BatchArgs& a, hipStream_t stre
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((a.nBlocks + 63) / 64)), wg(64);
     {
-        const bool wavePerBlock = a.nBlocksDev == nullptr && (g_snappy_parse_mode == 2 || (g_snappy_parse_mode == 0 && a.nBlocks <= 4096));
+        const bool wavePerBlock = a.nBlocksDev == nullptr && (g_snappy_parse_mode == 2 || (g_snappy_parse_mode == 0 && a.nBlocks <= SNAPPY_WAVE_PARSE_MAX_BLOCKS));
         if (wavePerBlock) {
             hipLaunchKernelGGL(snappy_parse_wave_kernel, dim3((unsigned)a.nBlocks), wg, 0, stream, a, hdr, meta, only, arena, maxChunks, stats);
         }

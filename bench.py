@@ -45,6 +45,7 @@ def parse_args():
     p.add_argument("--data", default="fragments", choices=["fragments", "wordmix", "corpus", "mixed"])
     p.add_argument("--group", type=int, default=0, help="decoder lanes per block (0 = library default)")
     p.add_argument("--variant", type=int, default=-1, help="decoder variant: 5 = chosen on the device (default), 1 = LDS rings, 7 = two passes")
+    p.add_argument("--parse", type=int, default=-1, help="two-pass decoders: 0 = the parser by the batch size (default), 1 = a lane per block, 2 = a wavefront per block")
     p.add_argument("--ring-class", type=int, default=-1, help="0 = compact LDS rings, 1 = large")
     p.add_argument("--compress-variant", type=int, default=-1, help="LZ4 / Snappy encoder variant: 4 = many matches per window (the default of both); LZ4 also 0 / 1, Snappy 0 .. 3 (see lz4.compress.variant / snappy.compress.variant)")
     p.add_argument("--ring-pad", type=int, default=-1, help="LDS bytes between the ring pairs of consecutive blocks (multiple of 16)")
@@ -587,6 +588,9 @@ def main():
         codec.native.set_option("snappy.decompress.group", args.group)
     if args.variant >= 0:
         codec.native.set_option("%s.decompress.variant" % ("lz4" if args.workload.startswith("lz4") else "snappy"), args.variant)
+    if args.parse >= 0:
+        codec.native.set_option("lz4.decompress.parse", args.parse)
+        codec.native.set_option("snappy.decompress.parse", args.parse)
     if args.ring_class >= 0:
         codec.native.set_option("decompress.ring_class", args.ring_class)
     if args.compress_variant >= 0:

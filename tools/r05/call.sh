@@ -99,6 +99,12 @@ for row in csv.DictReader(open(sys.argv[1])):
         print("   %-60s calls=%s avg_us=%.1f" % (row["Name"][:60], row["Calls"], float(row["AverageNs"]) / 1e3))
 PY
       done 2>&1 | tee $O/fewkernels.txt; rm -rf $O/fk ;;
+    parsesweep)    # the two parsers of the two-pass decoders against the batch size (corpus blocks of 64 KiB)
+      for w in lz4_decompress snappy_decompress; do for n in 4096 8192 16384 32768 65536 131072; do for ps in 1 2; do
+        timeout 300 python bench.py --workload $w --data corpus --blocks $n --variant 7 --parse $ps --no-extra --no-legs --no-host-facing --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$w corpus blocks $n x 64 KiB, parse $ps:', r['value'], 'GiB/s')"
+      done; done; done 2>&1 | tee $O/parsesweep.txt ;;
     fuzz)          # differential fuzz of the decoders (status, offset, plaintext) against the oracle on the GPU, after this round's routing changes
       ( timeout 700 python tools/fuzz_decoders.py 20000 51 lz4,snappy
         timeout 500 python tools/fuzz_decoders.py 3000 52 lz4,snappy big
