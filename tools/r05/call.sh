@@ -105,6 +105,13 @@ PY
 import json,sys
 r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$w corpus blocks $n x 64 KiB, parse $ps:', r['value'], 'GiB/s')"
       done; done; done 2>&1 | tee $O/parsesweep.txt ;;
+    hybridsweep)   # (measured, removed: needs the parse mode 3 of that experiment) both parsers side by side: the wavefront parser's share against the batch size (corpus blocks of 64 KiB)
+      for w in lz4_decompress snappy_decompress; do for n in 24576 32768 65536 131072 262144; do for share in 8192 16384 24576 32768 49152; do
+        [ $share -ge $n ] && continue
+        timeout 300 python bench.py --workload $w --data corpus --blocks $n --variant 7 --parse 3 --hybrid-wave-blocks $share --no-extra --no-legs --no-host-facing --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$w corpus blocks $n x 64 KiB, wavefront parser takes $share:', r['value'], 'GiB/s')"
+      done; done; done 2>&1 | tee $O/hybridsweep.txt ;;
     fuzz)          # differential fuzz of the decoders (status, offset, plaintext) against the oracle on the GPU, after this round's routing changes
       ( timeout 700 python tools/fuzz_decoders.py 20000 51 lz4,snappy
         timeout 500 python tools/fuzz_decoders.py 3000 52 lz4,snappy big
