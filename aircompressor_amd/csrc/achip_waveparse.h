@@ -141,4 +141,35 @@ struct WaveRecordSink {  // the block's records: chunks of the arena, claimed on
     }
 };
 
+// The chain of a window: lane p holds `next` = where the sequence after the one at p would begin (>= 64: beyond the window), `stop` = p cannot be on the chain.
+// members = the positions 0 -> next[0] -> next[next[0]] ... up to, not including, the first one that stops or lies beyond the window; cur = that position.
+// Four hops per trip of the scalar loop: a hop is a lane read whose lane index was itself just read -- 111 clocks each, half of a window's time, when walked one
+// by one (profiles/r05_notes.md section 12) --, so every lane first gathers where two, three and four hops lead (three lane gathers, all lanes at once), the loop
+// reads the four of the current position side by side and marks them by compares.  (A stopping position ends the chain by pointing beyond the window; it is
+// marked like any other and taken off afterwards.)
+__device__ __forceinline__ void wave_chain(int32_t next, bool stop, unsigned long long stopMask, int lane, unsigned long long& members, int32_t& cur)
+{
+    const int32_t n1 = stop ? 64 : next;
+    int32_t n2 = __shfl(n1, n1 & 63);
+    n2 = n1 < 64 ? n2 : n1;
+    int32_t n3 = __shfl(n1, n2 & 63);
+    n3 = n2 < 64 ? n3 : n2;
+    int32_t n4 = __shfl(n2, n2 & 63);
+    n4 = n2 < 64 ? n4 : n2;
+    members = 0;
+    cur = 0;
+    while (cur < 64) {  // (uniform)
+        const int32_t a1 = __builtin_amdgcn_readlane(n1, cur), a2 = __builtin_amdgcn_readlane(n2, cur), a3 = __builtin_amdgcn_readlane(n3, cur);
+        const int32_t a4 = __builtin_amdgcn_readlane(n4, cur);
+        members |= __ballot(lane == cur || lane == a1 || lane == a2 || lane == a3);  // (a position beyond the window is nobody's lane)
+        cur = a4;
+    }
+    const unsigned long long hit = members & stopMask;
+    if (hit != 0) {  // (uniform) nothing behind a stopping position was marked: it pointed beyond the window
+        const int first = __builtin_ctzll(hit);
+        members &= (1ull << first) - 1ull;
+        cur = first;
+    }
+}
+
 }  // namespace achip

@@ -417,10 +417,7 @@ __global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::Are
             const unsigned long long stopMask = __ballot(stop);
             unsigned long long members = 0;
             int32_t cur = 0;
-            while (cur < 64 && ((stopMask >> cur) & 1ull) == 0) {  // (uniform) the chain
-                members |= 1ull << cur;
-                cur = __builtin_amdgcn_readlane(next, cur);
-            }
+            wave_chain(next, stop, stopMask, lane, members, cur);
             // the members' places in the output, and the checks that need them (:113-119, :168-171 as the fast path above has them)
             const bool member = ((members >> lane) & 1ull) != 0;
             const int32_t tot = member ? lit + ml : 0;

@@ -450,10 +450,7 @@ __global__ __launch_bounds__(64) void snappy_parse_wave_kernel(BatchArgs a, sx::
             const unsigned long long stopMask = __ballot(stop);
             unsigned long long members = 0;
             int32_t cur = 0;
-            while (cur < 64 && ((stopMask >> cur) & 1ull) == 0) {  // (uniform) the chain
-                members |= 1ull << cur;
-                cur = __builtin_amdgcn_readlane(next, cur);
-            }
+            wave_chain(next, stop, stopMask, lane, members, cur);
             // the members' places in the output, and the checks that need them (the lane parser's runFast / copyFast; the input-side conditions hold in a window)
             const bool member = ((members >> lane) & 1ull) != 0;
             const int32_t tot = member ? nLit + cLen : 0;
