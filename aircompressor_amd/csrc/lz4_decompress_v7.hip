@@ -420,26 +420,21 @@ __global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::Are
             wave_chain(next, stop, stopMask, lane, members, cur);
             // the members' places in the output, and the checks that need them (:113-119, :168-171 as the fast path above has them)
             const bool member = ((members >> lane) & 1ull) != 0;
-            const int32_t tot = member ? lit + ml : 0;
-            const int32_t endRel = sx::wave_scan_incl(tot, lane);
-            const int32_t opEnd = S.op + endRel, opLit = opEnd - ml;
-            const bool wrong = member && (offset == 0 || offset > opLit || opEnd > fastOut);
-            const unsigned long long wrongMask = __ballot(wrong);
-            if (wrongMask != 0) {  // (uniform) the chain ends in front of the first such sequence
-                const int first = __builtin_ctzll(wrongMask);
-                members &= (1ull << first) - 1ull;
-                cur = first;
-            }
-            // a sequence of more than 16 literal or match bytes is several records (round 5: until then such a sequence ended the chain and went through
-            // lz4_parse_general -- a sixth of a text block's sequences, each a few dependent reads of global memory): pieces as in the general path below,
-            // their places from a scan; a window's records reach into one new chunk at most, so the chain ends where they would exceed a chunk
+            // (a sequence of more than 16 literal or match bytes is several records -- round 5: until then such a sequence ended the chain and went through
+            // lz4_parse_general, a sixth of a text block's sequences, each a few dependent reads of global memory -- : pieces as in the general path below)
             const int32_t litFull = lit > 16 ? (lit + 15) / 16 - 1 : 0;
             const int32_t matchRest = ml > 16 ? (ml - 16 + 15) / 16 : 0;
-            int32_t pieces = ((members >> lane) & 1ull) != 0 ? litFull + 1 + matchRest : 0;
-            const int32_t pieceEnd = sx::wave_scan_incl(pieces, lane);
-            const unsigned long long overMask = __ballot(pieces > 0 && pieceEnd > sx::CHUNK_RECS);
-            if (overMask != 0) {  // (uniform; a member has at most 35 pieces: the first always fits)
-                const int first = __builtin_ctzll(overMask);
+            int32_t pieces = litFull + 1 + matchRest;
+            // one scan for both: output bytes in the low half (at most 64 x 542), pieces in the high half (at most 64 x 35)
+            const int32_t scanned = sx::wave_scan_incl(member ? ((lit + ml) | (pieces << 16)) : 0, lane);
+            const int32_t endRel = scanned & 0xFFFF, pieceEnd = scanned >> 16;
+            const int32_t opEnd = S.op + endRel, opLit = opEnd - ml;
+            // a failing check ends the chain in front of the sequence; and a window's records reach into one new chunk at most, so the chain also ends where
+            // they would exceed a chunk (a member has at most 35 pieces: the first always fits)
+            const bool wrong = member && (offset == 0 || offset > opLit || opEnd > fastOut || pieceEnd > sx::CHUNK_RECS);
+            const unsigned long long wrongMask = __ballot(wrong);
+            if (wrongMask != 0) {  // (uniform)
+                const int first = __builtin_ctzll(wrongMask);
                 members &= (1ull << first) - 1ull;
                 cur = first;
             }

@@ -453,8 +453,11 @@ __global__ __launch_bounds__(64) void snappy_parse_wave_kernel(BatchArgs a, sx::
             wave_chain(next, stop, stopMask, lane, members, cur);
             // the members' places in the output, and the checks that need them (the lane parser's runFast / copyFast; the input-side conditions hold in a window)
             const bool member = ((members >> lane) & 1ull) != 0;
-            const int32_t tot = member ? nLit + cLen : 0;
-            const int32_t endRel = sx::wave_scan_incl(tot, lane);
+            const int32_t litFull = nLit > 16 ? (nLit + 15) / 16 - 1 : 0;
+            const int32_t matchRest = cLen > 16 ? (cLen - 16 + 15) / 16 : 0;
+            // one scan for both: output bytes in the low half (at most 64 x 124), pieces in the high half (at most 64 x 7)
+            const int32_t scanned = sx::wave_scan_incl(member ? ((nLit + cLen) | ((litFull + 1 + matchRest) << 16)) : 0, lane);
+            const int32_t endRel = scanned & 0xFFFF, pieceEnd = scanned >> 16;
             const int32_t opEnd = S.op + endRel, opCopy = opEnd - cLen;
             const bool wrong = member && ((isRun && opCopy > fastOutLimit) || (isCopy && (cOff == 0 || cOff > opCopy || opEnd > outLimit)));
             const unsigned long long wrongMask = __ballot(wrong);
@@ -471,11 +474,8 @@ __global__ __launch_bounds__(64) void snappy_parse_wave_kernel(BatchArgs a, sx::
                 const int32_t litStart = nread + base + lane + (isRun ? 1 : 0);
                 const int32_t skip = litStart - (below != 0 ? nread + base + prevQ : litEndPrev);
                 const int last = 63 - __builtin_clzll(members);
-                const int32_t litFull = nLit > 16 ? (nLit + 15) / 16 - 1 : 0;
-                const int32_t matchRest = cLen > 16 ? (cLen - 16 + 15) / 16 : 0;
                 const int32_t pieces = mine ? litFull + 1 + matchRest : 0;
-                const int32_t pieceEnd = sx::wave_scan_incl(pieces, lane);
-                const int32_t n = sx::wave_bcast(pieceEnd, 63);
+                const int32_t n = sx::wave_bcast(pieceEnd, last);
                 if (__ballot(mine && skip > sx::MAX_SKIP) != 0) {  // (a gap beyond the record field) the ring decoder takes the block
                     K.fallback = true;
                 }
