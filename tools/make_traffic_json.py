@@ -27,7 +27,7 @@ for wl in ("lz4_decompress", "snappy_decompress"):  # (both headline kernels sin
         shutil.rmtree(d, ignore_errors=True)
         env = dict(os.environ, TMPDIR="/tmp")
         p = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "--pmc", ctr, "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py"),
-                            "--no-cpu-baseline", "--no-extra", "--steps", "3", "--warmup", "1", "--workload", wl], capture_output=True, text=True, cwd=ROOT, env=env)
+                            "--no-cpu-baseline", "--no-extra", "--no-legs", "--no-host-facing", "--steps", "3", "--warmup", "1", "--workload", wl], capture_output=True, text=True, cwd=ROOT, env=env)
         for l in p.stdout.splitlines():
             if l.startswith("{"):
                 line = json.loads(l)

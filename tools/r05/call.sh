@@ -112,6 +112,28 @@ r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$w corpus 
 import json,sys
 r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$w corpus blocks $n x 64 KiB, wavefront parser takes $share:', r['value'], 'GiB/s')"
       done; done; done 2>&1 | tee $O/hybridsweep.txt ;;
+    final)         # the pass that ships: suite, smoke, bench.py as the driver runs it, rocprofv3 summaries of BOTH headline kernels, traffic.json, Zstd per-dispatch times, --gpus 2 on one device
+      F=$O/final; rm -rf $F; mkdir -p $F
+      timeout 1800 python -m pytest tests -m gpu -x -q > $F/pytest.log 2>&1; tail -2 $F/pytest.log
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+      S=$(date +%s); timeout 1500 python bench.py > $F/bench_final.json 2> $F/bench_final.err; echo "bench.py wall: $(( $(date +%s) - S )) s" | tee -a $F/bench_final.err
+      python - <<'PY'
+import json
+r = json.loads([l for l in open("gpurun_out/r05/final/bench_final.json") if l.startswith("{")][-1])
+print("value", r["value"], "frac", r["roofline"]["frac"], "traffic", r["roofline"]["traffic"], "cpu", r["cpu_baseline"]["value"])
+for k in sorted(r):
+    if k.startswith("value_") or k in ("mixed_ok", "end_to_end", "single_block_us"):
+        print(k, r[k] if not isinstance(r[k], dict) else {a: b for a, b in r[k].items() if a != "what"})
+PY
+      timeout 700 bash tools/profile.sh r05final_lz4 --steps 5 --warmup 2 --no-legs --no-host-facing > $F/profile_lz4_summary.txt 2>&1
+      cp gpurun_out/prof_r05final_lz4/keep/*kernel_stats.csv $F/lz4_kernel_stats.csv 2>/dev/null
+      timeout 700 bash tools/profile.sh r05final_snappy --steps 5 --warmup 2 --no-legs --no-host-facing --workload snappy_decompress > $F/profile_snappy_summary.txt 2>&1
+      cp gpurun_out/prof_r05final_snappy/keep/*kernel_stats.csv $F/snappy_kernel_stats.csv 2>/dev/null
+      timeout 600 python tools/make_traffic_json.py $F/traffic.json > $F/traffic.log 2>&1; tail -1 $F/traffic.log | cut -c1-400
+      timeout 500 bash tools/profile_zstd.sh r05finalz --no-cpu-baseline > $F/zstd_line.txt 2>&1
+      cp gpurun_out/prof_r05finalz/keep/dispatches.txt $F/zstd_dispatches.txt; cp gpurun_out/prof_r05finalz/keep/*kernel_stats.csv $F/zstd_kernel_stats.csv
+      ACHIP_BENCH_SHARE_DEVICE=1 timeout 900 python bench.py --gpus 2 --blocks 65536 --steps 3 --warmup 1 --no-extra --no-cpu-baseline > $F/n2.json 2> $F/n2.err; grep -c '^{' $F/n2.json
+      ;;
     fuzz)          # differential fuzz of the decoders (status, offset, plaintext) against the oracle on the GPU, after this round's routing changes
       ( timeout 700 python tools/fuzz_decoders.py 20000 51 lz4,snappy
         timeout 500 python tools/fuzz_decoders.py 3000 52 lz4,snappy big
