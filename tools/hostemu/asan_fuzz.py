@@ -99,9 +99,9 @@ def batch_op(op):
 
 def family(name):
     if name == "lz4":
-        return "lz4", [("rings 4 lanes", batch_op(44)), ("rings 16 lanes", batch_op(46)), ("rings 64 lanes", batch_op(48)), ("two-pass", batch_op(24)), ("lane + LDS window", batch_op(18))]
+        return "lz4", [("rings 4 lanes", batch_op(44)), ("rings 16 lanes", batch_op(46)), ("rings 64 lanes", batch_op(48)), ("two-pass, a lane parsing", batch_op(24)), ("two-pass, a wavefront parsing", batch_op(26)), ("latency class", batch_op(49))]
     if name == "snappy":
-        return "snappy", [("rings 4 lanes", batch_op(54)), ("rings 16 lanes", batch_op(56)), ("rings 64 lanes", batch_op(58)), ("two-pass", batch_op(34)), ("lane + LDS window", batch_op(19))]
+        return "snappy", [("rings 4 lanes", batch_op(54)), ("rings 16 lanes", batch_op(56)), ("rings 64 lanes", batch_op(58)), ("two-pass, a lane parsing", batch_op(34)), ("two-pass, a wavefront parsing", batch_op(36)), ("latency class", batch_op(59))]
     if name == "zstd":
         return "zstd", [("pipeline + one-kernel decoder", lambda *a: lib.emu_zstd_full(*a, 1, 65536, P(counters))), ("one-kernel decoder", lambda *a: lib.emu_zstd_full(*a, 0, 65536, P(counters))),
                         ("pipeline, smallest passes", lambda *a: lib.emu_zstd_full(*a, 1, 16, P(counters)))]
@@ -109,7 +109,7 @@ def family(name):
 
 
 def containers():
-    for v in (0, 1):
+    for v in (0, 1, 2):
         yield "lz4frame", "LZ4 frame reader %d" % v, (lambda *a, v=v: lib.emu_lz4frame(v, *a)), lambda b: o.compress("lz4frame", b)
     for v in (1, 0, 2):
         yield "snappyframed", "x-snappy-framed reader %d" % v, (lambda *a, v=v: lib.emu_snappyframed(v, *a)), lambda b: o.compress("snappyframed", b)
