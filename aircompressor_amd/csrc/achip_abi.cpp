@@ -22,6 +22,7 @@
 namespace achip {
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 int lz4_ring_group_for(int32_t nBlocks);
+int snappy_ring_group_for(int32_t nBlocks);
 hipError_t launch_lz4_decompress_twopass(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int groupSize, int ringClass, int execVariant, const int32_t* stats);
 int64_t twopass_scratch_bytes(int32_t nBlocks, int64_t perBlock);
 // record arena per block of the two-pass decoders (8 bytes per record; lz4_decompress_v7.hip: text-like 64 KiB blocks make 6 000 .. 8 500 LZ4
@@ -75,7 +76,7 @@ hipError_t launch_xxh32_batch(const void* srcBase, const int64_t* srcOff, const 
 struct achip_options {
     int device = 0;
     int lz4dGroup = 0;       // ring decoder, lanes per block: 0 = by the batch size (4 from 32 768 blocks on -- the headline's form --, 16 below, 64 up to 4 096: lz4_ring_group_for), else 1 .. 64
-    int snappydGroup = 4;
+    int snappydGroup = 0;    // likewise (64 up to 2 048 blocks, 16 below 16 384, 4 above: snappy_ring_group_for)
     int lz4dAutoMinBlocks = 4096;  // auto mode probes batches from this size on (smaller ones always take the rings)
     int lz4dVariant = 5;     // 5 = chosen on the device per batch (default: DESIGN 4c), 1 = LDS rings, a lane group per block (lz4_decompress_v2.hip), 7 = two passes: parse to records + a wavefront per block (lz4_decompress_v7.hip).  (4 / 6, a lane per block, lost to 7 on every batch they were built for -- 300 .. 330 GiB/s against 515 on corpus -- and were removed in round 4.)
     int snappydVariant = 5;  // 5 auto, 1 rings (snappy_decompress_v2.hip), 7 two passes (snappy_decompress_v5.hip), as for LZ4
@@ -427,11 +428,12 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint);
             break;
         case ACHIP_OP_SNAPPY_DECOMPRESS: {
+            const int snappyGroup = ctx->snappydGroup > 0 ? ctx->snappydGroup : (a.nBlocksDev != nullptr ? 4 : achip::snappy_ring_group_for(a.nBlocks));
             if (ctx->snappydVariant == 5 && a.nBlocks >= ctx->lz4dAutoMinBlocks) {  // auto, as for LZ4
                 const int32_t r = ensure_twopass_scratch(ctx, 4096, a.nBlocks, achip::SNAPPY_RECORD_BYTES_PER_BLOCK, achip::SNAPPY_RECORD_BYTES_PER_BLOCK_MIN);
                 if (r < 0) return r;
                 if (r == 0) {
-                    e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, nullptr);
+                    e = achip::launch_snappy_decompress_rings(a, ctx->stream, snappyGroup, ctx->ringClass, nullptr);
                     break;
                 }
                 int32_t* stats = (int32_t*)ctx->scratch;
@@ -442,9 +444,9 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 e = achip::launch_lz4_mixed_groups(a, ctx->stream, stats, 0);
                 if (e == hipSuccess) e = hipMemsetAsync(stats + 3, 1, 1, ctx->stream);
                 if (e == hipSuccess) e = achip::launch_snappy_element_sample(a, ctx->stream, stats, 0, 6);
-                if (e == hipSuccess) e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, stats);
+                if (e == hipSuccess) e = achip::launch_snappy_decompress_rings(a, ctx->stream, snappyGroup, ctx->ringClass, stats);
                 ctx->lastTwopass = true;
-                if (e == hipSuccess) e = achip::launch_snappy_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, ctx->snappydGroup, ctx->ringClass, ctx->execVariant, stats);
+                if (e == hipSuccess) e = achip::launch_snappy_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, snappyGroup, ctx->ringClass, ctx->execVariant, stats);
                 break;
             }
             // (few blocks, and every batch below the size auto mode probes from: as for LZ4 -- the two passes with the wavefront-per-block parser unless the host looked and
@@ -455,14 +457,14 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 const int32_t r = ensure_twopass_scratch(ctx, 0, a.nBlocks, few_blocks_record_bytes(a.nBlocks, achip::SNAPPY_RECORD_BYTES_PER_BLOCK), achip::SNAPPY_RECORD_BYTES_PER_BLOCK_MIN);
                 if (r < 0) return r;
                 if (r == 0) {
-                    e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass, nullptr);
+                    e = achip::launch_snappy_decompress_rings(a, ctx->stream, snappyGroup, ctx->ringClass, nullptr);
                     break;
                 }
                 ctx->lastTwopass = true;
-                e = achip::launch_snappy_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, ctx->snappydGroup, ctx->ringClass, ctx->execVariant, nullptr);
+                e = achip::launch_snappy_decompress_twopass(a, ctx->stream, ctx->scratch, ctx->scratchBytes, snappyGroup, ctx->ringClass, ctx->execVariant, nullptr);
                 break;
             }
-            e = achip::launch_snappy_decompress_rings(a, ctx->stream, ctx->snappydGroup, ctx->ringClass == 0 && a.nBlocks <= ctx->latencyMaxBlocks ? 3 : ctx->ringClass, nullptr);
+            e = achip::launch_snappy_decompress_rings(a, ctx->stream, snappyGroup, ctx->ringClass == 0 && a.nBlocks <= ctx->latencyMaxBlocks ? 3 : ctx->ringClass, nullptr);
             break;
         }
         case ACHIP_OP_SNAPPY_COMPRESS: {
@@ -924,7 +926,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->lz4dGroup = (int)value;
     }
     else if (k == "snappy.decompress.group") {
-        if (!pow2(value)) return bad_argument("group size must be a power of two in 1..64");
+        if (value != 0 && !pow2(value)) return bad_argument("snappy.decompress.group: 0 (by the batch size) or a power of two in 1..64");
         ctx->snappydGroup = (int)value;
     }
     else if (k == "lz4.decompress.variant") {

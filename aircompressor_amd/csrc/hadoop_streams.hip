@@ -658,6 +658,7 @@ __global__ __launch_bounds__(64) void hadoop_compact_kernel(BatchArgs a, BlockLi
 
 hipError_t launch_lz4_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 int lz4_ring_group_for(int32_t nBlocks);
+int snappy_ring_group_for(int32_t nBlocks);
 hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit);
@@ -797,7 +798,7 @@ hipError_t launch_hadoop_decompress(const BatchArgs& a, hipStream_t stream, void
         t.nBlocks = nChunksHost;
         t.nBlocksDev = nullptr;
         if (nChunksHost > 0) {
-            e = snappy ? launch_snappy_decompress_rings(t, stream, 4, 0, nullptr) : launch_lz4_decompress_rings(t, stream, lz4_ring_group_for(nChunksHost), 0, nullptr);
+            e = snappy ? launch_snappy_decompress_rings(t, stream, snappy_ring_group_for(nChunksHost), 0, nullptr) : launch_lz4_decompress_rings(t, stream, lz4_ring_group_for(nChunksHost), 0, nullptr);
         }
     }
     else if (!viaTwoPass) {

@@ -87,6 +87,11 @@ __global__ __launch_bounds__(64) void snappy_decompress_latency_kernel(BatchArgs
     }
 }
 
+// Lanes per block for a batch of nBlocks blocks whose count the host knows (lz4_ring_group_for has the reasons; fragments data, GiB/s at 4 / 16 / 64 lanes:
+// 1 024 blocks of 4 MiB 49 / 62 / 72; 4 096 x 256 KiB 193 / 243 / 230; 8 192 x 64 KiB 375 / 464 / 245; 16 384 x 64 KiB 740 / 746 / 268; 32 768: 1 274 / 833 / 288 --
+// profiles/r05_groupsweep.txt)
+int snappy_ring_group_for(int32_t nBlocks) { return nBlocks <= 2048 ? 64 : (nBlocks < 16384 ? 16 : 4); }
+
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups)
 {
     if (ringClass == 3 && a.only == nullptr && mixedGroups == nullptr && a.nBlocksDev == nullptr) {

@@ -748,6 +748,7 @@ __global__ __launch_bounds__(64) void snappyframed_fold_kernel(BatchArgs a, Chun
 }  // namespace snf
 
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
+int snappy_ring_group_for(int32_t nBlocks);
 hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit);
 hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32_t* mixedGroups, int32_t minBlocks);
 
@@ -863,7 +864,7 @@ hipError_t launch_snappyframed_decompress(const BatchArgs& a, hipStream_t stream
         BatchArgs t = c;
         t.nBlocks = nChunksHost;
         t.nBlocksDev = nullptr;
-        e = launch_snappy_decompress_rings(t, stream, 4, 0, nullptr);
+        e = launch_snappy_decompress_rings(t, stream, snappy_ring_group_for(nChunksHost), 0, nullptr);
         if (e != hipSuccess) return e;
     }
     else if (!viaTwoPass) {

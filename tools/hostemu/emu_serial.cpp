@@ -20,6 +20,7 @@ hipError_t launch_snappy_decompress_twopass(const BatchArgs&, hipStream_t, void*
 int64_t twopass_scratch_bytes(int32_t, int64_t) { return 0; }
 hipError_t launch_lz4_decompress_rings(const BatchArgs&, hipStream_t, int, int, const int32_t*) { return hipSuccess; }
 int lz4_ring_group_for(int32_t) { return 4; }
+int snappy_ring_group_for(int32_t) { return 4; }
 hipError_t launch_lz4_sequence_sample(const BatchArgs&, hipStream_t, int32_t*, int32_t, int32_t) { return hipSuccess; }
 hipError_t launch_snappy_decompress_rings(const BatchArgs&, hipStream_t, int, int, const int32_t*) { return hipSuccess; }
 hipError_t launch_snappy_element_sample(const BatchArgs&, hipStream_t, int32_t*, int32_t, int32_t) { return hipSuccess; }

@@ -134,6 +134,14 @@ PY
       cp gpurun_out/prof_r05finalz/keep/dispatches.txt $F/zstd_dispatches.txt; cp gpurun_out/prof_r05finalz/keep/*kernel_stats.csv $F/zstd_kernel_stats.csv
       ACHIP_BENCH_SHARE_DEVICE=1 timeout 900 python bench.py --gpus 2 --blocks 65536 --steps 3 --warmup 1 --no-extra --no-cpu-baseline > $F/n2.json 2> $F/n2.err; grep -c '^{' $F/n2.json
       ;;
+    groupsweep3)   # the same for Snappy
+      for spec in "1024 4194304" "4096 262144" "8192 65536" "16384 65536" "32768 65536"; do set -- $spec; for g in 4 16 64; do
+        timeout 300 python bench.py --workload snappy_decompress --data fragments --blocks $1 --block-size $2 --pool 64 --group $g --variant 1 --no-extra --no-legs --no-host-facing --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('snappy fragments blocks $1 x $2, $g lanes per block:', r['value'], 'GiB/s')"
+      done; done 2>&1 | tee $O/groupsweep3.txt ;;
+    spread)        # run-to-run spread of the headline line on one box
+      for i in 1 2 3 4 5 6 7 8 9; do timeout 300 python bench.py --no-cpu-baseline --no-extra --no-legs --no-host-facing 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('run $i', r['value'], r['roofline']['frac'], r['roofline']['kernel_ms_avg'])"; done | tee $O/headline_spread.txt ;;
     fuzz)          # differential fuzz of the decoders (status, offset, plaintext) against the oracle on the GPU, after this round's routing changes
       ( timeout 700 python tools/fuzz_decoders.py 20000 51 lz4,snappy
         timeout 500 python tools/fuzz_decoders.py 3000 52 lz4,snappy big
