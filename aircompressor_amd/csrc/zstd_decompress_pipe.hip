@@ -107,6 +107,7 @@ struct Pipe {
     uint32_t* litCursor;
     int32_t* fallbackCount;
     int32_t* fallback;
+    int32_t* longCount;   // (single-block tiles) items of this tile whose sequences are long (long_sequences): counted by K3, read by both K4 kernels
     int32_t first;  // first item of this tile
     int32_t count;  // items in this tile (multi-block stages: block slots of this pass)
     // multi-block stages (K1 only appends to mbList; nullptr there: multi-block frames go to the fallback list)
@@ -125,8 +126,14 @@ struct Pipe {
 };
 constexpr int ORDER_BUCKETS = 256;  // by sequence count / 256, descending (a block holds at most 128 KiB / 3 = 43 691 sequences: bucket 170)
 
-// K4's choice per item: at least 80 output bytes per sequence (capacity as the stand-in for the output size)
+// K4's choice per item: at least 80 output bytes per sequence (capacity as the stand-in for the output size) ...
 __device__ __forceinline__ bool long_sequences(int32_t capacity, int32_t nSeq) { return (int64_t)capacity >= 80LL * (nSeq > 0 ? nSeq : 1); }
+// ... and only in a tile with enough such items to fill the chip with ring groups (round 5).  The rings give an item four lanes: a handful of long-sequence items
+// in a tile of text -- the corpus has them: spreadsheets, images, tables of numbers -- made the ring kernel a serial chain of ~6 ms behind the record executor, for
+// a twentieth of the data (65 536 corpus-text frames 70.4 -> 63.2 ms with every item on the record executor; fragments frames, all long: the rings win from
+// ~25 000 items on -- 16 384: 690 GiB/s on the record executor against 614, 32 768: 736 against 815, 65 536: 762 against 985; tools/zstd_batch_sizes.py)
+constexpr int32_t RINGS_MIN_LONG_ITEMS = 24576;
+__device__ __forceinline__ bool item_takes_rings(const Pipe& p, int32_t capacity, int32_t nSeq) { return long_sequences(capacity, nSeq) && *p.longCount >= RINGS_MIN_LONG_ITEMS; }
 
 __device__ __forceinline__ void to_fallback(const Pipe& p, int32_t slot, int stage)
 {
@@ -843,15 +850,25 @@ __device__ const uint32_t seq_code_table[128] = {
     0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
 };
 #undef ZC
+// Items per workgroup of the sequence stage: the stage is ONE wavefront per CU (its tables fill the LDS), every lane a serial chain -- 4 096 items at 64 a workgroup
+// are 64 workgroups on 64 of the 256 CUs, each as long as a full one takes.  So a tile of fewer than 256 x 64 items is spread: count / 256 items a workgroup
+// (the static LDS allocation stays: still one workgroup per CU), down to a single item; a step of a wavefront with fewer lanes on it is also the shorter one.
+constexpr int32_t ZSTD_EXEC_ALL_RECORDS_MAX_ITEMS = 16384;
+inline int32_t seql_items_for(int32_t count)
+{
+    const int32_t per = (count + 255) / 256;
+    return per < 1 ? 1 : (per > zp::SEQL_ITEMS ? zp::SEQL_ITEMS : per);
+}
 template <bool MB>
-__global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs a, zp::Pipe p)
+__global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs a, zp::Pipe p, int32_t itemsPerGroup)
 {
     using namespace zp;
     __shared__ __attribute__((aligned(16))) uint16_t tables[SEQL_ITEMS * SEQL_STRIDE];
     const uint32_t* const codeTab = seq_code_table;  // literal-length codes at 0.., match-length codes at 64..: baseline | extra bits << 24
     const int lane = threadIdx.x;
-    const int32_t place = blockIdx.x * SEQL_ITEMS + lane;
-    bool valid = lane < SEQL_ITEMS && place < p.count;
+    // (itemsPerGroup <= SEQL_ITEMS: a tile of few items is spread over the CUs -- seql_items_for below -- and the lanes beyond sit out)
+    const int32_t place = blockIdx.x * itemsPerGroup + lane;
+    bool valid = lane < itemsPerGroup && place < p.count;
     const int32_t slot = MB && valid && p.order != nullptr ? p.order[place] : place;  // (multi-block passes: longest items first, zstd_mb_order_kernel)
     int32_t from0 = slot, from1 = slot, from2 = slot;  // the slots the literal-length, offset and match-length tables come from
     if (MB && valid) {
@@ -1077,6 +1094,13 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
             p.mb[slot].repOut[2] = p2;
         }
     }
+    if (!MB) {  // the tile's long-sequence items, for K4's choice (one atomic per wavefront)
+        const bool isLong = !bad && long_sequences(a.dstCap[block], nDecoded);
+        const unsigned long long lm = __ballot(isLong);
+        if (isLong && lane == (int)__builtin_ctzll(lm)) {
+            atomicAdd(p.longCount, (int32_t)__popcll(lm));
+        }
+    }
 }
 
 // ---- K4: execute ----
@@ -1098,7 +1122,7 @@ __global__ __launch_bounds__(256) void zstd_pipe_execute_kernel(BatchArgs a, zp:
         return;
     }
     const int32_t block = p.first + slot;
-    if (mode == 2 && !zp::long_sequences(a.dstCap[block], d.nDecoded)) {
+    if (mode == 2 && !zp::item_takes_rings(p, a.dstCap[block], d.nDecoded)) {
         return;  // (auto: the record executor takes this item)
     }
     const uint8_t* src = a.srcBase + a.srcOff[block];
@@ -1232,7 +1256,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_execute2_kernel(BatchArgs a, zp:
     }
     const int lane = threadIdx.x;
     const int32_t block = p.first + slot;
-    if (mode == 2 && zp::long_sequences(a.dstCap[block], d.nDecoded)) {
+    if (mode == 2 && zp::item_takes_rings(p, a.dstCap[block], d.nDecoded)) {
         return;  // (auto: the ring version takes this item)
     }
     const uint8_t* src = a.srcBase + a.srcOff[block];
@@ -1898,7 +1922,7 @@ hipError_t launch_zstd_mb_stages(const BatchArgs& a, hipStream_t stream, zp::Pip
             hipLaunchKernelGGL(zstd_mb_order_kernel<false>, dim3(g64), dim3(64), 0, stream, p);
             hipLaunchKernelGGL(zstd_mb_order_kernel<true>, dim3(g64), dim3(64), 0, stream, p);
         }
-        hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<true>, dim3((unsigned)((p.count + zp::SEQL_ITEMS - 1) / zp::SEQL_ITEMS)), dim3(64), 0, stream, a, p);
+        hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<true>, dim3((unsigned)((p.count + seql_items_for(p.count) - 1) / seql_items_for(p.count))), dim3(64), 0, stream, a, p, seql_items_for(p.count));
         // A frame is one wavefront's work whatever its size: a pass of few frames leaves the LDS idle, and a window of 32 KiB instead of 4 turns most
         // of a text frame's far matches (offsets beyond the window: 64-byte sectors re-read through the L2) into LDS reads
         if (nItems <= 1024) {  // (four wavefronts per CU on 256 CUs: what 32 KiB windows leave room for)
@@ -1933,6 +1957,7 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
     p.fallbackCount = (int32_t*)(base + L.counters);
     p.seqCursor = (uint32_t*)(base + L.counters + 64);
     p.litCursor = (uint32_t*)(base + L.counters + 68);
+    p.longCount = (int32_t*)(base + L.counters + 72);
     p.litCap = (uint32_t)L.tile * PIPE_LIT_PER_ITEM + PIPE_LIT_FLOOR;
     p.fallback = (int32_t*)(base + L.fallback);
     const bool mbOn = mbp != nullptr && mbp->get != nullptr && mbp->passBlocks >= 16;
@@ -1952,7 +1977,7 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
         p.first = first;
         p.count = a.nBlocks - first < L.tile ? a.nBlocks - first : L.tile;
         if (first != 0) {
-            e = hipMemsetAsync(p.seqCursor, 0, 8, stream);  // sequence and literal cursors
+            e = hipMemsetAsync(p.seqCursor, 0, 12, stream);  // sequence and literal cursors, the count of long-sequence items
             if (e != hipSuccess) return e;
         }
         const unsigned w16 = (unsigned)((p.count + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE);
@@ -1960,13 +1985,16 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
         // (items per wavefront in K2 / K3 of 8 instead of 16, and an 8 KiB window for the record executor, were round-2 experiments: measured in
         // round 3 within noise of the defaults on all three data sets -- profiles/r03_notes.md -- and removed)
         hipLaunchKernelGGL(zstd_pipe_literals_kernel<false>, dim3(w16), dim3(64), 0, stream, a, p);
-        hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<false>, dim3((unsigned)((p.count + zp::SEQL_ITEMS - 1) / zp::SEQL_ITEMS)), dim3(64), 0, stream, a, p);
+        hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<false>, dim3((unsigned)((p.count + seql_items_for(p.count) - 1) / seql_items_for(p.count))), dim3(64), 0, stream, a, p, seql_items_for(p.count));
         constexpr int GS = 4, IN_RING = 128, OUT_RING = 256;
-        if (g_zstd_pipe_exec != 0) {
-            hipLaunchKernelGGL(zstd_pipe_execute2_kernel<>, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, (int32_t)g_zstd_pipe_exec);
+        // (a tile of few items: every item to the record executor, a wavefront each -- the rings give an item four lanes, and an item of long sequences is then a
+        // serial chain of 5.4 ms whatever else the chip does: 64 frames 15.2 ms a call, 6.8 of it the sequence stage's own chain, 5.4 this one)
+        const int32_t execMode = g_zstd_pipe_exec == 2 && p.count <= ZSTD_EXEC_ALL_RECORDS_MAX_ITEMS ? 1 : (int32_t)g_zstd_pipe_exec;
+        if (execMode != 0) {
+            hipLaunchKernelGGL(zstd_pipe_execute2_kernel<>, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, execMode);
         }
-        if (g_zstd_pipe_exec != 1) {
-            hipLaunchKernelGGL((zstd_pipe_execute_kernel<GS, IN_RING, OUT_RING>), dim3((unsigned)((p.count + 256 / GS - 1) / (256 / GS))), dim3(256), (size_t)(256 / GS) * (IN_RING + OUT_RING + a.ringPad), stream, a, p, (int32_t)g_zstd_pipe_exec);
+        if (execMode != 1) {
+            hipLaunchKernelGGL((zstd_pipe_execute_kernel<GS, IN_RING, OUT_RING>), dim3((unsigned)((p.count + 256 / GS - 1) / (256 / GS))), dim3(256), (size_t)(256 / GS) * (IN_RING + OUT_RING + a.ringPad), stream, a, p, execMode);
         }
         hipLaunchKernelGGL(zstd_pipe_checksum_kernel, dim3(w16), dim3(64), 0, stream, a, p);
     }
@@ -2352,7 +2380,7 @@ hipError_t launch_zstd_stream_step(hipStream_t stream, void* scratch, int64_t sc
     hipLaunchKernelGGL(zstd_ss_ghost_kernel, dim3(1), dim3(64), 0, stream, p, carry);
     hipLaunchKernelGGL(zstd_mb_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
     hipLaunchKernelGGL(zstd_pipe_literals_kernel<true>, dim3((unsigned)((p.count + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
-    hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<true>, dim3((unsigned)((p.count + zp::SEQL_ITEMS - 1) / zp::SEQL_ITEMS)), dim3(64), 0, stream, a, p);
+    hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<true>, dim3((unsigned)((p.count + seql_items_for(p.count) - 1) / seql_items_for(p.count))), dim3(64), 0, stream, a, p, seql_items_for(p.count));
     hipLaunchKernelGGL(zstd_ss_execute_kernel<32768>, dim3(1), dim3(64), 0, stream, a, p, carry, startPos);
     hipLaunchKernelGGL(zstd_ss_carry_kernel, dim3(1), dim3(64), 0, stream, p, carry);
     hipLaunchKernelGGL(zstd_ss_checksum_kernel, dim3(1), dim3(64), 0, stream, dOut + startPos, carry, closing != 0 && hasChecksum != 0 ? 1 : 0, expected);
