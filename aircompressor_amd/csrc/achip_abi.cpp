@@ -1722,11 +1722,13 @@ int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t
                          (int32_t*)(d + c.oOutLen), (int32_t*)(d + c.oStatus), (int64_t*)(d + c.oErr), (int32_t)c.count);
     };
     const int savedHint = ctx->maxSrcLenHint;
-    // A chunk of fewer blocks than auto mode probes on the device (launch_op), in host memory: a look at its first block's first tokens tells the decoders
-    // apart -- short sequences: the two passes; long ones: the rings with many lanes per block (LZ4), the latency class (up to decompress.latency_max_blocks).
-    // Only the choice of the decoder depends on it, never a result: whatever these bytes are, every decoder reports what the Java decoder would.
+    // A chunk of few blocks (at most decompress.latency_max_blocks: a single block, a small batch) in host memory: a look at its first block's first tokens tells
+    // the decoders apart -- short sequences: the two passes; long ones: the ring decoders' latency class.  Only the choice of the decoder depends on it, never a
+    // result: whatever these bytes are, every decoder reports what the Java decoder would.  (Larger chunks -- a pipeline chunk is ~1 000 blocks -- take the two
+    // passes unseen.  Looking at them too was tried: a chunk's kernels take 0.76 ms with the rings at 64 lanes against 0.92 with the two passes, but the pipeline
+    // is bound by the host's copies and the link, and its rate varies 28-40 GiB/s from run to run on one box with either: nothing to gain, one more rule to explain.)
     auto look_at_tokens = [&](const HostChunk& c, const uint8_t* h) {
-        const bool few = c.op == ACHIP_OP_LZ4_DECOMPRESS ? c.count < ctx->lz4dAutoMinBlocks : (c.op == ACHIP_OP_SNAPPY_DECOMPRESS && c.count <= ctx->latencyMaxBlocks);
+        const bool few = (c.op == ACHIP_OP_LZ4_DECOMPRESS || c.op == ACHIP_OP_SNAPPY_DECOMPRESS) && c.count <= ctx->latencyMaxBlocks;
         if (few) {
             ctx->smallBatchHint = probe_sequences(c.op == ACHIP_OP_SNAPPY_DECOMPRESS, h + sOff[c.first], srcLen[item(c.first)]);
         }

@@ -904,34 +904,45 @@ def host_facing(torch, A, codec, pool_pack, pool_pack_off, pool_clen, pool_plain
         lib.achip_device_free(ctx, ptr)
     lib.achip_host_free_pinned(h_src)
     lib.achip_host_free_pinned(h_dst)
-    # one block per call through the single-block entry points (host pointers, synchronous): median of 200 calls each
-    blk = pool_plain[:bs].cpu().numpy()
-    cap = lib.achip_lz4_max_compressed_length(bs)
-    cbuf = np.zeros(cap, dtype=np.uint8)
-    back = np.zeros(bs, dtype=np.uint8)
-    eo1 = ctypes.c_int64()
-    tc, td = [], []
-    clen1 = 0
-    for it in range(220):
-        t0 = time.perf_counter()
-        clen1 = lib.achip_lz4_compress(ctx, blk.ctypes.data, cbuf.ctypes.data, bs, cap, ctypes.byref(eo1))
-        t1 = time.perf_counter()
-        r = lib.achip_lz4_decompress(ctx, cbuf.ctypes.data, back.ctypes.data, clen1, bs, ctypes.byref(eo1))
-        t2 = time.perf_counter()
-        assert clen1 > 0 and r == bs
-        if it >= 20:
-            tc.append(t1 - t0)
-            td.append(t2 - t1)
-    assert (back == blk).all()
+    # one block per call through the single-block entry points (host pointers, synchronous): median of 100 calls each, every codec, the headline's
+    # kind of data and a block of the reference's corpus (text)
+    single = {"block_bytes": bs, "calls": 100,
+              "what": "median latency in microseconds of ONE 64 KiB block per call through achip_<codec>_decompress / _compress (host pointers, synchronous): what "
+                      "Lz4HipDecompressor.decompress(MemorySegment, MemorySegment) and its siblings cost per call; 'fragments': the headline's data, 'corpus': text"}
+    files = corpus_files()
+    corpus_blk = np.frombuffer((files.get("canterbury/alice29.txt") or files.get("large/bible.txt") or b"")[:bs], dtype=np.uint8).copy()  # (prose)
+    for kind, blk in (("fragments", pool_plain[:bs].cpu().numpy()), ("corpus", corpus_blk if corpus_blk.size == bs else None)):
+        if blk is None:
+            continue
+        for name in ("lz4", "snappy", "zstd"):
+            bound = getattr(lib, "achip_%s_max_compressed_length" % name)
+            comp_fn, dec_fn = getattr(lib, "achip_%s_compress" % name), getattr(lib, "achip_%s_decompress" % name)
+            cap = bound(bs)
+            cbuf = np.zeros(cap, dtype=np.uint8)
+            back = np.zeros(bs, dtype=np.uint8)
+            eo1 = ctypes.c_int64()
+            tc, td = [], []
+            for it in range(110):
+                t0 = time.perf_counter()
+                clen1 = comp_fn(ctx, blk.ctypes.data, cbuf.ctypes.data, bs, cap, ctypes.byref(eo1))
+                t1 = time.perf_counter()
+                r = dec_fn(ctx, cbuf.ctypes.data, back.ctypes.data, clen1, bs, ctypes.byref(eo1))
+                t2 = time.perf_counter()
+                assert clen1 > 0 and r == bs, (name, kind, clen1, r)
+                if it >= 10:
+                    tc.append(t1 - t0)
+                    td.append(t2 - t1)
+            assert (back == blk).all()
+            suffix = "" if kind == "fragments" else "_corpus"
+            single["%s_decompress%s" % (name, suffix)] = round(statistics.median(td) * 1e6, 1)
+            single["%s_compress%s" % (name, suffix)] = round(statistics.median(tc) * 1e6, 1)
     return {
         "end_to_end": {"pageable_GiBps": round(pageable, 2), "pinned_GiBps": round(pinned, 2), "blocks": n, "block_bytes": bs, "plain_bytes": n * bs, "compressed_bytes": comp_bytes,
                        "pageable_stages_last_call": stages,
                        "what": "LZ4 decompress of the headline's blocks, host memory in and out (H2D + kernels + D2H): pageable = achip_batch_host on ordinary memory "
                                "(staged through pinned slots, pipelined); pinned = achip_host_alloc_pinned segments, achip_memcpy_h2d + achip_lz4_decompress_batch + "
                                "achip_memcpy_d2h.  PCIe-bound, never `value`"},
-        "single_block_us": {"lz4_decompress": round(statistics.median(td) * 1e6, 1), "lz4_compress": round(statistics.median(tc) * 1e6, 1), "block_bytes": bs, "calls": 200,
-                            "what": "median latency of ONE 64 KiB block per call through achip_lz4_decompress / achip_lz4_compress (host pointers, synchronous): what "
-                                    "Lz4HipDecompressor.decompress(MemorySegment, MemorySegment) costs per call"},
+        "single_block_us": single,
     }
 
 

@@ -30,6 +30,9 @@ for t in threads:
         codec = A.HipBatchCodec(0)
         codec.native.set_option("host.copy_threads", t)
         codec.native.set_option("host.chunk_bytes", ch << 20)
+        for a_ in sys.argv[3:]:  # e.g. lz4.decompress.variant=7: further context options
+            k_, v_ = a_.split("=")
+            codec.native.set_option(k_, int(v_))
         best = None
         for it in range(4):
             t0 = time.perf_counter()
