@@ -1244,6 +1244,8 @@ int32_t mix_lane(achip_ctx* ctx, int op, achip_ctx** out)
         achip_ctx* lane = achip_ctx_create(ctx->device);
         if (!lane) return ACHIP_STATUS(ACHIP_CLASS_DEVICE, ACHIP_D_HIP_ERROR);
         ctx->mixLane[op] = lane;
+    }
+    if (!ctx->mixLaneDone[op]) {  // (on its own: a context whose event could not be made at the first attempt tries again, it does not record on a null event)
         HIP_TRY(hipEventCreateWithFlags(&ctx->mixLaneDone[op], hipEventDisableTiming));
     }
     static_cast<achip_options&>(*ctx->mixLane[op]) = static_cast<const achip_options&>(*ctx);
