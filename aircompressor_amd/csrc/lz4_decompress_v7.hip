@@ -392,9 +392,67 @@ __global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::Are
     K.fresh = -1;
     const int32_t fastOut = outLimit - 8 - 4;  // a match may end here at the latest (:82, :168)
     bool finished = S.done;                    // (uniform)
+    bool serial = false;                       // (uniform) the sequences are long: one at a time (below)
     while (!finished && !K.fallback) {         // (uniform)
         bool general = true;
-        if ((int64_t)S.ip + wp::LZ4_STAGE + 24 <= (int64_t)inLimit) {  // (uniform) a window: nothing in it can reach the block's last bytes (8: the Java loop's margin; 16: every byte it looks at lies in a 16-byte piece that is inside the block whole -- WaveStage::fetch)
+        const bool windowable = (int64_t)S.ip + wp::LZ4_STAGE + 24 <= (int64_t)inLimit;  // (uniform) nothing a window looks at can reach the block's last bytes (8: the Java loop's margin; 16: every byte it looks at lies in a 16-byte piece that is inside the block whole -- WaveStage::fetch)
+        if (windowable && serial) {
+            // LONG SEQUENCES, one at a time.  A window of 64 stream positions finds as many sequences as start in it: on data whose sequences are longer than the window
+            // (runs of literals, long matches: the headline's kind) that is ONE per trip of ~2 800 clocks.  Here every lane reads the sequence at the window's first
+            // position -- two LDS reads, no chain, no scans --, lane k makes its piece k.  The mode is entered when a window held at most two sequences in 48 bytes and
+            // left when a sequence is shorter than 24 stream bytes.  Same conditions as a member of the chain; anything else goes the general way.
+            const int32_t base = S.ip;
+            const uint8_t* const stage = W.window(base);
+            uint32_t x;
+            __builtin_memcpy(&x, stage, 4);
+            const uint32_t token = x & 0xFF, e1 = (x >> 8) & 0xFF;
+            const bool litExt = (token >> 4) == 0xF;
+            const int32_t lit = uni((int32_t)(litExt ? 15u + e1 : (token >> 4)));
+            const int32_t litStart = litExt ? 2 : 1;
+            const int32_t q = litStart + lit;
+            uint32_t y;
+            __builtin_memcpy(&y, stage + q, 4);
+            const int32_t offset = uni((int32_t)(y & 0xFFFF));
+            const uint32_t e2 = (y >> 16) & 0xFF;
+            const bool mlExt = (token & 0xF) == 0xF;
+            const int32_t ml = uni((int32_t)(mlExt ? 15u + e2 : (token & 0xF)) + 4);
+            const int32_t next = q + (mlExt ? 3 : 2);
+            const int32_t opLit = S.op + lit, opEnd = opLit + ml;
+            const int32_t skip = base + litStart - S.litEndPrev;
+            const bool ok = !((litExt && e1 == 255) || (mlExt && e2 == 255)) && offset != 0 && offset <= opLit && opEnd <= fastOut && skip <= sx::MAX_SKIP;
+            serial = false;
+            if (uni(ok ? 1 : 0) != 0) {  // (uniform)
+                const int32_t litFull = lit > 16 ? (lit + 15) / 16 - 1 : 0;
+                const int32_t matchRest = ml > 16 ? (ml - 16 + 15) / 16 : 0;
+                const int32_t pieces = litFull + 1 + matchRest;  // (<= 35)
+                const int32_t k = lane;
+                int32_t pl, pm, o = offset;
+                if (k < litFull) {
+                    pl = 16;
+                    pm = 0;
+                }
+                else if (k == litFull) {
+                    pl = lit - 16 * litFull;
+                    pm = ml < 16 ? ml : 16;
+                }
+                else {
+                    const int32_t m = k - litFull;
+                    pl = 0;
+                    pm = ml - 16 * m < 16 ? ml - 16 * m : 16;
+                    const int32_t xm = 16 * m + offset;
+                    o = sx::largest_multiple(offset, xm < 65535 ? xm : 65535);
+                }
+                K.put(sx::rec_pack((uint32_t)pl, (uint32_t)pm, pm > 0 ? (uint32_t)o : 0u, k == 0 ? (uint32_t)skip : 0u), k < pieces, lane, pieces, lane);
+                if (!K.fallback) {
+                    S.op = opEnd;
+                    S.litEndPrev = base + q;
+                    S.ip = base + next;
+                    general = false;
+                    serial = next >= 24;
+                }
+            }
+        }
+        else if (windowable) {
             const int32_t base = S.ip;
             const uint8_t* const stage = W.window(base);
             // what a sequence at position `lane` of the window would be
@@ -475,6 +533,7 @@ __global__ __launch_bounds__(64) void lz4_parse_wave_kernel(BatchArgs a, sx::Are
                     S.litEndPrev = base + sx::wave_bcast(q, last);
                     S.ip = base + cur;
                     general = false;
+                    serial = cur >= 48 && __popcll(members) <= 2;
                 }
             }
         }
