@@ -116,6 +116,7 @@ r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$w corpus 
       F=$O/final; rm -rf $F; mkdir -p $F
       timeout 1800 python -m pytest tests -m gpu -x -q > $F/pytest.log 2>&1; tail -2 $F/pytest.log
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+      timeout 600 python tools/make_traffic_json.py $F/traffic.json > $F/traffic.log 2>&1; tail -1 $F/traffic.log | cut -c1-400; cp $F/traffic.json profiles/traffic.json  # (first: the bench line reports it only for the sources it was taken on)
       S=$(date +%s); timeout 1500 python bench.py > $F/bench_final.json 2> $F/bench_final.err; echo "bench.py wall: $(( $(date +%s) - S )) s" | tee -a $F/bench_final.err
       python - <<'PY'
 import json
@@ -129,7 +130,6 @@ PY
       cp gpurun_out/prof_r05final_lz4/keep/*kernel_stats.csv $F/lz4_kernel_stats.csv 2>/dev/null
       timeout 700 bash tools/profile.sh r05final_snappy --steps 5 --warmup 2 --no-legs --no-host-facing --workload snappy_decompress > $F/profile_snappy_summary.txt 2>&1
       cp gpurun_out/prof_r05final_snappy/keep/*kernel_stats.csv $F/snappy_kernel_stats.csv 2>/dev/null
-      timeout 600 python tools/make_traffic_json.py $F/traffic.json > $F/traffic.log 2>&1; tail -1 $F/traffic.log | cut -c1-400
       timeout 500 bash tools/profile_zstd.sh r05finalz --no-cpu-baseline > $F/zstd_line.txt 2>&1
       cp gpurun_out/prof_r05finalz/keep/dispatches.txt $F/zstd_dispatches.txt; cp gpurun_out/prof_r05finalz/keep/*kernel_stats.csv $F/zstd_kernel_stats.csv
       ACHIP_BENCH_SHARE_DEVICE=1 timeout 900 python bench.py --gpus 2 --blocks 65536 --steps 3 --warmup 1 --no-extra --no-cpu-baseline > $F/n2.json 2> $F/n2.err; grep -c '^{' $F/n2.json
