@@ -93,8 +93,11 @@ def test_lz4_two_pass_decoder(gb, o, cfg, parse):
     matches of that order (thousands of records from one sequence, chunk after chunk of the arena)"""
     rng = np.random.default_rng(7)
     text = b"".join(d for _, d, _ in common.corpus_sample()[:4])
+    # (the last three: sequences longer than the wavefront parser's window of 64 stream positions -- 50 / 20 / 130 random bytes, each run twice -- which it reads
+    #  one at a time, next to text, which it reads 64 positions a trip: both modes and the changes between them in one block)
+    fragments = [np.tile(rng.integers(0, 256, size=(2000, w), dtype=np.uint8), (1, 2)).reshape(-1)[:n].tobytes() for w, n in ((50, 65536), (20, 65536), (130, 300000))]
     blocks = all_blocks() + [bytes(rng.integers(0, 256, 300000, dtype=np.uint8)), bytes(1 << 20), text[:200000] + bytes(70000) + text[:50000],
-                             (bytes(rng.integers(0, 256, 700, dtype=np.uint8)) * 300)[:200001]]
+                             (bytes(rng.integers(0, 256, 700, dtype=np.uint8)) * 300)[:200001]] + fragments + [fragments[0][:30000] + text[:40000] + fragments[2][:50000] + text[:3000]]
     cases = [(o.compress("lz4", b), len(b)) for b in blocks] + [(o.compress("lz4", b), len(b) + 37) for b in blocks[:20]]
     cases += [(bytes([15, 0, 0, 255, 255, 0x8A, 49, 255, 255, 0]), 1024), (b"", 10), (b"\x00", 0), (b"\x10a", 0), (bytes([0xF0]) + b"\xff" * 4000, 1 << 16)]
     for b in [d for _, d, _ in common.corpus_sample()[:3]]:
