@@ -425,9 +425,65 @@ __global__ __launch_bounds__(64) void snappy_parse_wave_kernel(BatchArgs a, sx::
     K.fresh = -1;
     const int32_t fastOutLimit = outLimit - 8;
     int32_t litEndPrev = 0;  // (uniform) position (counted from in0) the executor's literal cursor stands at behind the records so far
+    bool serial = false;                // (uniform) the elements are long: one pair at a time (lz4_parse_wave_kernel has the reasons)
     while (!finished && !K.fallback) {  // (uniform)
         bool general = true;
-        if ((int64_t)S.ip + wp::SNAPPY_STAGE + 24 <= (int64_t)inLimit) {  // (uniform) a window: nothing in it can reach the stream's last bytes (the margins of lz4_parse_wave_kernel)
+        const bool windowable = (int64_t)S.ip + wp::SNAPPY_STAGE + 24 <= (int64_t)inLimit;  // (uniform) nothing a window looks at can reach the stream's last bytes (the margins of lz4_parse_wave_kernel)
+        if (windowable && serial) {
+            // the element (pair) at the window's first position, read by every lane at once; lane k makes its piece k (at most seven)
+            const int32_t base = S.ip;
+            const uint8_t* const stage = W.window(base);
+            uint32_t x;
+            __builtin_memcpy(&x, stage, 4);
+            const uint32_t tag = x & 0xFF;
+            const bool isRun = (tag & 3) == 0;
+            const int32_t nLit = uni(isRun ? (int32_t)(tag >> 2) + 1 : 0);
+            const int32_t q = isRun ? 1 + nLit : 0;
+            uint32_t y;
+            __builtin_memcpy(&y, stage + q, 4);
+            const uint32_t tag2 = y & 0xFF, kind2 = tag2 & 3;
+            const bool isCopy = kind2 == 1 || kind2 == 2;
+            const int32_t len1 = (int32_t)((tag2 >> 2) & 7) + 4, off1 = (int32_t)(((tag2 >> 5) << 8) | ((y >> 8) & 0xFF));
+            const int32_t len2 = (int32_t)(tag2 >> 2) + 1, off2 = (int32_t)((y >> 8) & 0xFFFF);
+            const int32_t cLen = uni(isCopy ? (kind2 == 1 ? len1 : len2) : 0), cOff = uni(kind2 == 1 ? off1 : off2);
+            const int32_t next = q + (isCopy ? (kind2 == 1 ? 2 : 3) : 0);
+            const bool stop = isRun ? (tag >> 2) >= 60 : (tag & 3) == 3;
+            const int32_t opCopy = S.op + nLit, opEnd = opCopy + cLen;
+            const int32_t skip = nread + base + (isRun ? 1 : 0) - litEndPrev;
+            const bool ok = !stop && !(isRun && opCopy > fastOutLimit) && !(isCopy && (cOff == 0 || cOff > opCopy || opEnd > outLimit)) && skip <= sx::MAX_SKIP;
+            serial = false;
+            if (uni(ok ? 1 : 0) != 0) {  // (uniform)
+                const int32_t litFull = nLit > 16 ? (nLit + 15) / 16 - 1 : 0;
+                const int32_t matchRest = cLen > 16 ? (cLen - 16 + 15) / 16 : 0;
+                const int32_t pieces = litFull + 1 + matchRest;
+                const int32_t k = lane;
+                int32_t pl, pm, o = cOff;
+                if (k < litFull) {
+                    pl = 16;
+                    pm = 0;
+                }
+                else if (k == litFull) {
+                    pl = nLit - 16 * litFull;
+                    pm = cLen < 16 ? cLen : 16;
+                }
+                else {
+                    const int32_t m = k - litFull;
+                    pl = 0;
+                    pm = cLen - 16 * m < 16 ? cLen - 16 * m : 16;
+                    const int32_t xm = 16 * m + cOff;
+                    o = sx::largest_multiple(cOff > 0 ? cOff : 1, xm < 65535 ? xm : 65535);
+                }
+                K.put(sx::rec_pack((uint32_t)pl, (uint32_t)pm, pm > 0 ? (uint32_t)o : 0u, k == 0 ? (uint32_t)skip : 0u), k < pieces, lane, pieces, lane);
+                if (!K.fallback) {
+                    S.op = opEnd;
+                    litEndPrev = nread + base + q;
+                    S.ip = base + next;
+                    general = false;
+                    serial = next >= 24;
+                }
+            }
+        }
+        else if (windowable) {
             const int32_t base = S.ip;
             const uint8_t* const stage = W.window(base);
             // what an element at position `lane` of the window would be
@@ -504,6 +560,7 @@ __global__ __launch_bounds__(64) void snappy_parse_wave_kernel(BatchArgs a, sx::
                     litEndPrev = nread + base + sx::wave_bcast(q, last);
                     S.ip = base + cur;
                     general = false;
+                    serial = cur >= 48 && __popcll(members) <= 2;
                 }
             }
         }

@@ -131,7 +131,10 @@ def test_snappy_two_pass_decoder(gb, o, variant, parse):
     streams of random elements of every kind (copies with 4-byte offsets, runs with length bytes, runs behind runs: what the Java encoder never
     writes), some beyond 64 KiB"""
     rng = np.random.default_rng(11)
-    blocks = all_blocks()
+    text = b"".join(d for _, d, _ in common.corpus_sample()[:2])
+    # (elements longer than the wavefront parser's window -- 50 / 20 / 58 random bytes, each run twice -- which it reads one pair at a time, alone and next to text)
+    fragments = [np.tile(rng.integers(0, 256, size=(2000, w), dtype=np.uint8), (1, 2)).reshape(-1)[:n].tobytes() for w, n in ((50, 65536), (20, 65536), (58, 200000))]
+    blocks = all_blocks() + fragments + [fragments[0][:30000] + text[:40000] + fragments[2][:50000] + text[:3000]]
     cases = [(o.compress("snappy", b), len(b)) for b in blocks] + [(o.compress("snappy", b), len(b) + 37) for b in blocks[:20]]
     for target in (40, 500, 3000, 20000, 70000, 150000, 400000):
         for _ in range(4):
