@@ -142,6 +142,14 @@ r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('snappy fra
       done; done 2>&1 | tee $O/groupsweep3.txt ;;
     spread)        # run-to-run spread of the headline line on one box
       for i in 1 2 3 4 5 6 7 8 9; do timeout 300 python bench.py --no-cpu-baseline --no-extra --no-legs --no-host-facing 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('run $i', r['value'], r['roofline']['frac'], r['roofline']['kernel_ms_avg'])"; done | tee $O/headline_spread.txt ;;
+    sizesweep)     # the default decoders against the batch size, final library: LZ4 / Snappy blocks of 64 KiB (fragments, corpus), Zstd frames of 128 KiB
+      for w in lz4_decompress snappy_decompress; do for data in fragments corpus; do for n in 1024 4096 16384 65536 262144; do
+        timeout 300 python bench.py --workload $w --data $data --blocks $n --pool 512 --no-extra --no-legs --no-host-facing --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$w $data %7d x 64 KiB: %8.1f GiB/s  %8.3f ms' % ($n, r['value'], r['ms_per_step']))"
+      done; done; done 2>&1 | tee $O/sizesweep.txt
+      timeout 300 python tools/zstd_batch_sizes.py 1024 4096 16384 65536 2>&1 | grep -v amdgpu | tee -a $O/sizesweep.txt
+      timeout 300 python tools/zstd_batch_sizes.py --fragments 1024 4096 16384 65536 2>&1 | grep -v amdgpu | tee -a $O/sizesweep.txt ;;
     fuzz)          # differential fuzz of the decoders (status, offset, plaintext) against the oracle on the GPU, after this round's routing changes
       ( timeout 700 python tools/fuzz_decoders.py 20000 51 lz4,snappy
         timeout 500 python tools/fuzz_decoders.py 3000 52 lz4,snappy big
