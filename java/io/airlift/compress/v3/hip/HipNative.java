@@ -208,6 +208,14 @@ public final class HipNative
                     MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
                     int.class, MemorySegment.class})
             MethodHandle multiBatchHost,
+            // mixed batches (BASELINE configs[4]: item i through codecOps[i]): (ctx, codecOps* [HOST], srcBase, srcOff*, srcLen*, dstBase, dstOff*, dstCap*, outLen*, status*, errOffset*, nBlocks);
+            // achip_mixed_batch: everything but codecOps device-accessible, asynchronous on the context's stream; achip_mixed_batch_host: host memory, synchronous
+            @NativeSignature(name = "achip_mixed_batch", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle mixedBatch,
+            @NativeSignature(name = "achip_mixed_batch_host", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class,
+                    MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, MemorySegment.class, int.class})
+            MethodHandle mixedBatchHost,
             // Zstd streams a step at a time (SURVEY 8f row 3): begin(ctx) -> state; feed(ctx, state, src, srcLen, dst, dstCap, consumed*, produced*[, errOffset*]); ...
             @NativeSignature(name = "achip_zstdstream_decompress_begin", returnType = MemorySegment.class, argumentTypes = MemorySegment.class)
             MethodHandle zstdStreamDecompressBegin,
@@ -704,6 +712,42 @@ public final class HipNative
             }
             catch (RuntimeException e) {
                 throw e;
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+            if (result < 0) {
+                throw toException(result, 0);
+            }
+        }
+
+        /**
+         * A batch whose items name their own codec and direction ({@code codecOps}: one OP_* int per item, HOST memory -- the caller's knowledge of its items;
+         * everything else device-accessible as for {@link #launchBatch}): bucketed by op inside the library, the three codec families side by side, results in the
+         * caller's item order.  Asynchronous on the context's stream.  (BASELINE configs[4]; an ORC / Parquet stripe with pages of three codecs.)
+         */
+        public void launchMixedBatch(MemorySegment codecOps, MemorySegment srcBase, MemorySegment srcOff, MemorySegment srcLen, MemorySegment dstBase, MemorySegment dstOff,
+                MemorySegment dstCap, MemorySegment outLen, MemorySegment status, MemorySegment errOffset, int blocks)
+        {
+            int result;
+            try {
+                result = (int) HANDLES.mixedBatch().invokeExact(handle(), codecOps, srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, blocks);
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+            if (result < 0) {
+                throw toException(result, 0);
+            }
+        }
+
+        /** The same with every array and both buffers in host memory: staged like {@link #batchHost}, synchronous. */
+        public void mixedBatchHost(MemorySegment codecOps, MemorySegment srcBase, MemorySegment srcOff, MemorySegment srcLen, MemorySegment dstBase, MemorySegment dstOff,
+                MemorySegment dstCap, MemorySegment outLen, MemorySegment status, MemorySegment errOffset, int blocks)
+        {
+            int result;
+            try {
+                result = (int) HANDLES.mixedBatchHost().invokeExact(handle(), codecOps, srcBase, srcOff, srcLen, dstBase, dstOff, dstCap, outLen, status, errOffset, blocks);
             }
             catch (Throwable e) {
                 throw new AssertionError("should not reach here", e);
