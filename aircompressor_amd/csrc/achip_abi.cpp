@@ -2045,6 +2045,7 @@ struct achip_zstd_dstream {
     static constexpr int32_t kStepBlocks = 32;
     static constexpr int32_t kStepBytes = kStepBlocks * 131072;
     static constexpr int64_t kMaxWindow = 128LL << 20;  // (window descriptors beyond 2^27: refused -- the Java frame decoder stops at 8 MiB, :303)
+    bool frameDone = false;  // a frame has been read to its end: from then on the stream may end quietly between frames (the Java decoder's INITIAL state is not a stopping point)
     enum Phase { MAGIC = 0, HEADER = 1, BLOCKS = 2, FAILED = 3 };
     achip_ctx* ctx = nullptr;
     int phase = MAGIC;
@@ -2112,20 +2113,31 @@ int32_t dstream_window(achip_zstd_dstream* z, int64_t lookBack)
 }
 
 // Decodes the blocks [first, first + blocks) that lie complete in pending (each: 3-byte header at pos[i], `stored[i]` bytes behind it).
-int32_t dstream_step(achip_zstd_dstream* z, const std::vector<size_t>& pos, const std::vector<int64_t>& stored, bool closing, uint32_t expected)
+// a block of a step: its three header bytes as the step's stand-in frame will carry them (the "last" bit is set there), its payload in `pending`, and what it
+// accounts for of the STREAM's bytes (a RAW / RLE block beyond 128 KiB is handed over as several: see the BLOCKS phase of achip_zstdstream_decompress_feed)
+struct StepBlock {
+    int32_t header;
+    size_t dataPos;
+    int64_t dataLen;
+    int64_t streamBytes;
+};
+int32_t dstream_step(achip_zstd_dstream* z, const std::vector<StepBlock>& list, bool closing, uint32_t expected)
 {
     achip_ctx* ctx = z->ctx;
-    const int32_t blocks = (int32_t)pos.size();
+    const int32_t blocks = (int32_t)list.size();
     // the step as a frame of its own: magic, a descriptor that says "single segment, one byte of content size, no checksum", the size byte, the blocks
     uint8_t* h = z->hostSrc;
     const uint8_t head[6] = {0x28, 0xB5, 0x2F, 0xFD, 0x20, 0x00};
     memcpy(h, head, 6);
     int64_t at = 6;
     for (int32_t i = 0; i < blocks; i++) {
-        const uint8_t* b = z->pending.data() + pos[(size_t)i];
-        memcpy(h + at, b, (size_t)(3 + stored[(size_t)i]));
-        h[at] = (uint8_t)((h[at] & 0xFE) | (i == blocks - 1 ? 1 : 0));  // the step's last block closes the stand-in frame
-        at += 3 + stored[(size_t)i];
+        const StepBlock& b = list[(size_t)i];
+        const int32_t hd = (b.header & ~1) | (i == blocks - 1 ? 1 : 0);  // the step's last block closes the stand-in frame
+        h[at] = (uint8_t)hd;
+        h[at + 1] = (uint8_t)(hd >> 8);
+        h[at + 2] = (uint8_t)(hd >> 16);
+        memcpy(h + at + 3, z->pending.data() + b.dataPos, (size_t)b.dataLen);
+        at += 3 + b.dataLen;
     }
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpyAsync(z->dSrc, h, (size_t)at, hipMemcpyHostToDevice, ctx->stream));
@@ -2157,13 +2169,13 @@ int32_t dstream_step(achip_zstd_dstream* z, const std::vector<size_t>& pos, cons
     if (good < blocks) {
         // the stream is damaged in block `good`: what lies in front of it is delivered first (the next calls), then the stream fails
         int64_t off = z->streamPos;
-        for (int32_t i = 0; i < good; i++) off += 3 + stored[(size_t)i];
+        for (int32_t i = 0; i < good; i++) off += list[(size_t)i].streamBytes;
         dstream_fail(z, ACHIP_D_ZSTD_CORRUPTED, off);
         return 0;
     }
     if (closing && z->hasChecksum && result[2] != 1) {
         int64_t off = z->streamPos;
-        for (int32_t i = 0; i < blocks; i++) off += 3 + stored[(size_t)i];
+        for (int32_t i = 0; i < blocks; i++) off += list[(size_t)i].streamBytes;
         dstream_fail(z, ACHIP_D_ZSTD_BAD_CHECKSUM, off + 4);  // (ZstdIncrementalFrameDecompressor.java:318-320: behind the checksum word)
         return 0;
     }
@@ -2208,7 +2220,9 @@ int32_t achip_zstdstream_decompress_at_stopping_point(void* state)
 {
     const achip_zstd_dstream* z = (const achip_zstd_dstream*)state;
     if (!z) return 0;
-    return z->phase == achip_zstd_dstream::MAGIC && z->pendingAt == z->pending.size() && z->outAt == z->outLen ? 1 : 0;
+    // (state == READ_FRAME_MAGIC, whatever lies buffered: fewer than four bytes behind the last frame end the stream quietly -- ZstdInputStream.java:81-86,
+    //  ZstdIncrementalFrameDecompressor.isAtStoppingPoint)
+    return z->phase == achip_zstd_dstream::MAGIC && z->frameDone && z->outAt == z->outLen ? 1 : 0;
 }
 
 int32_t achip_zstdstream_decompress_feed(achip_ctx* ctx, void* state, const void* src, int64_t srcLen, void* dst, int64_t dstCap, int64_t* consumed, int64_t* produced,
@@ -2332,17 +2346,16 @@ int32_t achip_zstdstream_decompress_feed(achip_ctx* ctx, void* state, const void
             continue;
         }
         // ---- BLOCKS: the whole blocks that lie in pending, up to a step ----
-        std::vector<size_t> pos;
-        std::vector<int64_t> stored;
+        std::vector<StepBlock> list;
         int64_t at = 0;
         bool closing = false, broken = false;
         uint32_t expected = 0;
-        while ((int32_t)pos.size() < achip_zstd_dstream::kStepBlocks) {
+        while ((int32_t)list.size() < achip_zstd_dstream::kStepBlocks) {
             if (have - at < 3) break;
             const int32_t hd = p[at] | (p[at + 1] << 8) | (p[at + 2] << 16);
             const int32_t type = (hd >> 1) & 3, size = hd >> 3;
-            if (type == 3 || size > 131072) {
-                // ("Invalid block type" :264; a block beyond Block_Maximum_Size -- no encoder writes one -- would outgrow a step's room)
+            if (type == 3 || (type == 2 && size > 131072)) {
+                // ("Invalid block type" :264; a compressed block beyond Block_Maximum_Size -- "Expected match length table to be present" or worse in Java -- would outgrow a step's room)
                 broken = true;
                 break;
             }
@@ -2354,15 +2367,29 @@ int32_t achip_zstdstream_decompress_feed(achip_ctx* ctx, void* state, const void
                 const uint8_t* c = p + at + 3 + st;
                 expected = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
             }
-            pos.push_back(z->pendingAt + (size_t)at);
-            stored.push_back(st);
+            // A RAW or RLE block may say any size up to 2^21 - 1: ZstdIncrementalFrameDecompressor.java:204-226 copies / fills that many bytes (no encoder writes such a
+            // block, the format forbids it, the Java reader does not check).  Here it becomes blocks of at most 128 KiB each -- the same bytes, and such blocks touch
+            // neither tables nor repeat offsets -- so that a step's room holds them; a step that has no room left for all of them ends in front of the block.
+            const int32_t parts = type == 2 || size <= 131072 ? 1 : (size + 131071) / 131072;
+            if ((int32_t)list.size() + parts > achip_zstd_dstream::kStepBlocks) {
+                break;  // (at most 16 parts: an empty step always has room)
+            }
+            for (int32_t k = 0; k < parts; k++) {
+                const int32_t partSize = parts == 1 ? size : std::min(131072, size - 131072 * k);
+                StepBlock b;
+                b.header = (hd & 6) | (partSize << 3);
+                b.dataPos = z->pendingAt + (size_t)at + 3 + (type == 0 ? (size_t)131072 * (size_t)k : 0);
+                b.dataLen = type == 1 ? 1 : partSize;
+                b.streamBytes = (k == 0 ? 3 : 0) + (type == 1 ? (k == 0 ? 1 : 0) : partSize);
+                list.push_back(b);
+            }
             at += 3 + st;
             if (last) {
                 closing = true;
                 break;
             }
         }
-        if (pos.empty()) {
+        if (list.empty()) {
             if (broken) {
                 const int32_t st = dstream_fail(z, ACHIP_D_ZSTD_INVALID_BLOCK_TYPE, z->streamPos + 3);
                 if (errOffset) *errOffset = z->failOffset;
@@ -2373,12 +2400,13 @@ int32_t achip_zstdstream_decompress_feed(achip_ctx* ctx, void* state, const void
             }
             continue;  // (there was room for more of the caller's input)
         }
-        const int32_t r = dstream_step(z, pos, stored, closing, expected);
+        const int32_t r = dstream_step(z, list, closing, expected);
         if (r < 0) return r;
         if (z->phase != achip_zstd_dstream::FAILED) {
             advance(at + (closing && z->hasChecksum ? 4 : 0));
             if (closing) {
                 z->phase = achip_zstd_dstream::MAGIC;
+                z->frameDone = true;
             }
         }
     }
@@ -2477,7 +2505,9 @@ void* achip_zstdstream_compress_begin(achip_ctx* ctx)
     ok = ok && hipMalloc((void**)&z->dOut, (size_t)achip_zstd_cstream::kOutBytes) == hipSuccess;
     ok = ok && hipMalloc(&z->state, stateBytes) == hipSuccess;
     ok = ok && hipMalloc(&z->slab, (size_t)achip::zstd_ostream_slab_bytes()) == hipSuccess;
-    ok = ok && hipMemset(z->state, 0, stateBytes) == hipSuccess;
+    // (on the context's stream, where the steps run: a hipMemset on the null stream is not ordered in front of work on a non-blocking stream, and an empty stream's
+    // only step -- begin, close -- then met whatever the allocation held: found by tools/fuzz_zstd_stream.py as a frame without its header)
+    ok = ok && hipMemsetAsync(z->state, 0, stateBytes, ctx->stream) == hipSuccess;
     if (!ok) {
         g_lastError = "out of memory for a Zstd stream's buffers";
         cstream_free(z);

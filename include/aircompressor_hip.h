@@ -397,8 +397,12 @@ int32_t achip_multi_batch_host(achip_ctx* const* ctxs, int32_t nCtx, int32_t cod
  *           has been delivered -- the call that would deliver the first byte of a damaged block fails, where ZstdInputStream.read
  *           throws (*errOffset: stream offset of the block).  *consumed < srcLen with *produced == dstCap: output room needed;
  *           *consumed == srcLen and *produced < dstCap: input needed (or the stream's end: at_stopping_point)
- *   at_stopping_point   1 when nothing is pending and the next byte would start a frame (ZstdIncrementalFrameDecompressor.isAtStoppingPoint):
- *           where a stream may end; the end of input anywhere else is "Not enough input bytes" (ZstdInputStream.java:83)
+ *   at_stopping_point   1 when a frame has been read to its end, its bytes are delivered and the next frame's magic is not complete
+ *           (ZstdIncrementalFrameDecompressor.isAtStoppingPoint: state READ_FRAME_MAGIC -- up to three bytes behind the last frame are
+ *           ignored, as ZstdInputStream.java:81-86 ignores them; before the first frame the Java state is INITIAL and this returns 0):
+ *           where a stream may end; the end of input anywhere else is "Not enough input bytes" (ZstdInputStream.java:86).
+ *           (RAW / RLE blocks that say more than 128 KiB -- the format forbids them, the Java reader copies / fills what they say,
+ *           ZstdIncrementalFrameDecompressor.java:204-226 -- are decoded as several blocks of at most 128 KiB.)
  *   end     releases the state
  * All host pointers; synchronous; a state serves one thread at a time like its context. */
 void* achip_zstdstream_decompress_begin(achip_ctx* ctx);

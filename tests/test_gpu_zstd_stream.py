@@ -366,3 +366,48 @@ def test_output_stream_twin_writes_in_chunks_whatever_the_write_sizes(o):
             if len(data) >= (4 << 20):
                 assert before_close > 0, "nothing reached the sink before close()"
     assert A.ZstdHipInputStream(io.BytesIO(o.zstd_stream_compress(inputs[-1]))).read() == inputs[-1]
+
+
+def test_reader_corners_the_stream_fuzzer_found(o):
+    """tools/fuzz_zstd_stream.py against the transliterated ZstdInputStream (round 5): (1) up to three bytes behind the last frame end the stream quietly -- the Java
+    reader asks for a magic's four bytes, does not get them and is at a stopping point (ZstdInputStream.java:81-86) --, four bytes of garbage are an invalid magic,
+    and fewer than four bytes in front of the FIRST frame are "Not enough input bytes" (the Java state is INITIAL, not a stopping point); (2) RAW and RLE blocks that
+    say more than 128 KiB are decoded for what they say (ZstdIncrementalFrameDecompressor.java:204-226 has no bound on them; here they become several blocks);
+    (3) an empty stream written right after other streams is a whole frame (its state used to be cleared on another stream than the one its step runs on)."""
+    import aircompressor_amd as A
+    whole = b"".join(d for _, d, _ in common.corpus_sample())
+    z = o.zstd_stream_compress(whole[:300000])
+    for tail in (b"\x01", b"\x28\xb5", b"\x28\xb5\x2f"):
+        assert A.ZstdHipInputStream(io.BytesIO(z + tail)).read() == whole[:300000]
+    with pytest.raises((A.MalformedInputException, IOError)):
+        A.ZstdHipInputStream(io.BytesIO(z + b"\x01\x02\x03\x04")).read()
+    with pytest.raises(IOError, match="Not enough input"):
+        A.ZstdHipInputStream(io.BytesIO(b"\x28\xb5")).read()
+    # a frame by hand: window 1 MiB, no checksum, no content size; a compressed-free body of RLE 200 000 x 'q', RAW 150 000 bytes, RLE 131 073 x 0, RAW 5 (last)
+    raw1, raw2 = whole[1000:151000], b"tail!"
+    def block(kind, size, payload, last=0):
+        return int((size << 3) | (kind << 1) | last).to_bytes(3, "little") + payload
+    frame = b"\x28\xb5\x2f\xfd" + b"\x00" + b"\x50" + block(1, 200000, b"q") + block(0, len(raw1), raw1) + block(1, 131073, b"\x00") + block(0, len(raw2), raw2, 1)
+    plain = b"q" * 200000 + raw1 + bytes(131073) + raw2
+    stream = z + frame + o.zstd_stream_compress(whole[:5000])
+    for size in (1 << 20, 4097):
+        s = A.ZstdHipInputStream(io.BytesIO(stream))
+        got = bytearray()
+        buf = bytearray(size)
+        while True:
+            n = s.read_into(buf, 0, size)
+            if n < 0:
+                break
+            got += buf[:n]
+        assert bytes(got) == whole[:300000] + plain + whole[:5000], (size, len(got))
+    # (3)
+    big = io.BytesIO()
+    big.close = lambda: None
+    with A.ZstdHipOutputStream(big) as s:
+        s.write(whole[:2000000])
+    for _ in range(12):
+        sink = io.BytesIO()
+        sink.close = lambda: None
+        A.ZstdHipOutputStream(sink).close()
+        assert sink.getvalue() == o.zstd_stream_compress(b"")
+
