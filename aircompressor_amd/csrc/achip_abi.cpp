@@ -2339,7 +2339,9 @@ int32_t achip_zstdstream_decompress_feed(achip_ctx* ctx, void* state, const void
                 std::vector<uint8_t> zero((size_t)achip::zstd_stream_carry_bytes(), 0);
                 achip::zstd_stream_carry_init(zero.data());
                 HIP_TRY(hipSetDevice(ctx->device));
-                HIP_TRY(hipMemcpy(z->carry, zero.data(), zero.size(), hipMemcpyHostToDevice));
+                // (on the context's stream, where the steps run, and waited for: see achip_zstdstream_compress_begin)
+                HIP_TRY(hipMemcpyAsync(z->carry, zero.data(), zero.size(), hipMemcpyHostToDevice, ctx->stream));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
             }
             advance(headerSize);
             z->phase = achip_zstd_dstream::BLOCKS;
