@@ -353,3 +353,37 @@ def test_input_stream_reads_what_the_one_shot_decoder_reads(ref, oracle):
         out = ctypes.create_string_buffer(max(bound, 1))
         r = ref.lib.ref_zstd_stream_decompress(z, len(z), out, bound, ctypes.byref(eo))
         assert r == len(want) and out.raw[:r] == want, (len(z), r, len(want), ref.lib.ref_zstd_last_error())
+
+
+def test_input_stream_corners_the_gpu_reader_is_held_to(ref, oracle):
+    """What the reference's ZstdInputStream does where tools/fuzz_zstd_stream.py found the GPU reader doing something else (round 5), pinned here against the
+    reference's own code so that tests/test_gpu_zstd_stream.py::test_reader_corners_the_stream_fuzzer_found rests on a fact, not on a reading of the source:
+    up to three bytes behind the last frame end the stream quietly, four are an invalid magic, fewer than four in front of the FIRST frame are an IOException;
+    RAW and RLE blocks that say more than 128 KiB are decoded for what they say."""
+    ref.lib.ref_zstd_stream_decompress_partial.restype = i64
+    ref.lib.ref_zstd_stream_decompress_partial.argtypes = [vp, i64, vp, i64, ctypes.c_int32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+
+    def read(stream, cap):
+        out = ctypes.create_string_buffer(cap + 1)
+        delivered, eo = i64(0), i64(0)
+        src = ctypes.create_string_buffer(bytes(stream), len(stream))
+        r = ref.lib.ref_zstd_stream_decompress_partial(src, len(stream), out, cap + 1, 65536, ctypes.byref(delivered), ctypes.byref(eo))
+        return r, (out.raw[:r] if r >= 0 else out.raw[:delivered.value])
+
+    text = b"".join(d for _, d, _ in common.corpus_sample())
+    z = oracle.zstd_stream_compress(text[:300000])
+    for tail in (b"\x01", b"\x28\xb5", b"\x28\xb5\x2f"):
+        r, got = read(z + tail, 400000)
+        assert r == 300000 and got == text[:300000], (tail, r)
+    r, got = read(z + b"\x01\x02\x03\x04", 400000)
+    assert r == -1 and got == text[:len(got)]  # MalformedInputException ("Invalid magic prefix"); what it delivered before is plaintext
+    assert read(b"\x28\xb5", 100)[0] == -4     # IOException ("Not enough input bytes"): INITIAL is not a stopping point
+    assert read(b"", 100)[0] == -4
+
+    def block(kind, size, payload, last=0):
+        return int((size << 3) | (kind << 1) | last).to_bytes(3, "little") + payload
+    raw1, raw2 = text[1000:151000], b"tail!"
+    frame = b"\x28\xb5\x2f\xfd" + b"\x00" + b"\x50" + block(1, 200000, b"q") + block(0, len(raw1), raw1) + block(1, 131073, b"\x00") + block(0, len(raw2), raw2, 1)
+    plain = b"q" * 200000 + raw1 + bytes(131073) + raw2
+    r, got = read(z + frame + oracle.zstd_stream_compress(text[:5000]), 2000000)
+    assert r == 300000 + len(plain) + 5000 and got == text[:300000] + plain + text[:5000]
