@@ -19,3 +19,17 @@ def test_zstd_and_container_decoders_agree_with_the_oracle_on_mutated_streams():
 def test_encoders_are_byte_identical_with_the_oracle_on_inputs_of_many_shapes():
     from tools import fuzz_encoders
     assert fuzz_encoders.run(400, 13) == 0
+
+
+def test_incremental_zstd_stream_twins_agree_with_the_reference_reader_and_the_oracle_writer():
+    """tools/fuzz_zstd_stream.py, a short run: streams valid, mutated, cut and extended, read through ZstdHipInputStream in random piece sizes against the
+    reference's own ZstdInputStream transliterated (oracle/_ref/libref.so: skipped where that is absent), and random plaintexts written through
+    ZstdHipOutputStream in random piece sizes against the oracle writer's bytes"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "libref.so")):
+        pytest.skip("oracle/_ref/libref.so absent")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_zstd_stream.py"), "80", "25", "31"], capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0 and "TOTAL MISMATCHES 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
