@@ -51,6 +51,7 @@ int64_t hadoop_decompress_scratch_bytes(int32_t nStreams, int32_t bufferSize);
 hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* scratch, bool snappy, int32_t bufferSize);
 int64_t hadoop_compress_scratch_bytes(int32_t nStreams);
 extern int g_zstd_pipe_exec;
+extern int g_zstd_seq_waves;
 int64_t zstd_ostream_state_bytes();
 int64_t zstd_ostream_slab_bytes();
 hipError_t launch_zstd_ostream_step(hipStream_t stream, void* state, void* slab, const uint8_t* buf, int32_t offset, int32_t chunk, int32_t closing, uint8_t* out, int32_t outCap);
@@ -989,6 +990,10 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         if (value < 0 || value > 2) return bad_argument("zstd.decompress.exec: 0 rings, 1 record executor, 2 chosen per item");
         achip::g_zstd_pipe_exec = (int)value;
     }  // (process-wide: a development switch between the two execute stages)
+    else if (k == "zstd.decompress.seq_waves") {
+        if (value != 1 && value != 2 && value != 4) return bad_argument("zstd.decompress.seq_waves: wavefronts per workgroup of the pipeline's sequence stage: 1, 2 or 4 (64 items a workgroup either way)");
+        achip::g_zstd_seq_waves = (int)value;
+    }  // (process-wide, like zstd.decompress.exec)
     else if (k == "decompress.latency_max_blocks") {
         if (value < 0 || value > 65536) return bad_argument("decompress.latency_max_blocks: 0 (never) .. 65536: LZ4 / Snappy batches of at most this many blocks take a wavefront and 128 KiB of LDS history per block");
         ctx->latencyMaxBlocks = (int)value;
@@ -2466,9 +2471,16 @@ int32_t cstream_step(achip_zstd_cstream* z, bool closing)
     }
     z->offset += chunk;
     if (!closing) {
-        // the window and the bytes not yet compressed move to the buffer's front (:214-219); the slide is larger than what moves: no overlap
+        // the window and the bytes not yet compressed move to the buffer's front (:214-219: System.arraycopy, i.e. memmove).  Source and destination
+        // OVERLAP at every flush of a full buffer (slide 1.875 MiB, 2.125 MiB to move), and an overlapping hipMemcpy is undefined: the move is made
+        // in pieces of at most `slide` bytes, front to back on the one stream -- a piece's destination ends where its source begins, and a piece has
+        // been read before the next one overwrites it
         const int32_t slide = z->offset - achip_zstd_cstream::kWindow;
-        HIP_TRY(hipMemcpyAsync(z->buf, z->buf + slide, (size_t)(achip_zstd_cstream::kWindow + (z->position - z->offset)), hipMemcpyDeviceToDevice, ctx->stream));
+        const int32_t toMove = achip_zstd_cstream::kWindow + (z->position - z->offset);
+        for (int32_t at = 0; at < toMove && slide > 0; at += slide) {
+            const int32_t n = std::min(slide, toMove - at);
+            HIP_TRY(hipMemcpyAsync(z->buf + at, z->buf + at + slide, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+        }
         z->offset -= slide;
         z->position -= slide;
     }

@@ -149,6 +149,19 @@ __device__ __forceinline__ uint32_t alignbyte_u32(uint32_t hi, uint32_t lo, uint
 __device__ __forceinline__ void wave_mem_order() { asm volatile("" ::: "memory"); }
 #endif
 
+// "This value is in its register from here on": a load in flight into `v` is waited for at this point, in straight-line code.  For values that
+// are loaded in front of a loop and used inside it -- LLVM's wait-count insertion otherwise carries "maybe still in flight" into the loop and waits
+// for it in EVERY trip, with a count that also drains the stores the trip before issued (profiles/r06_notes.md, the Zstd sequence stage).
+template <class T>
+__device__ __forceinline__ void settle(T& v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#else
+    asm volatile("" : "+r"(v));
+#endif
+}
+
 // The same ordering point for kernels whose lanes COOPERATE on one block: everything the lanes of this wave stored before it (LDS or
 // global) is visible to every lane after it.  On the device a compiler barrier is all it takes (a wavefront's memory operations are
 // performed in program order; wavefront-scope fences are no-ops on gfx950).  Must be called in wave-uniform control flow: tools/hostemu

@@ -850,25 +850,45 @@ __device__ const uint32_t seq_code_table[128] = {
     0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
 };
 #undef ZC
+// where the lanes of the sequence stage that hold no item put the record store every step issues (see the kernel): a slot per lane and workgroup
+// (workgroups SEQ_IDLE_GROUPS apart share theirs: nothing reads it)
+constexpr int SEQ_IDLE_GROUPS = 1024;
+__device__ uint64_t seq_idle_sink[SEQ_IDLE_GROUPS * 256];
 // Items per workgroup of the sequence stage: the stage is ONE wavefront per CU (its tables fill the LDS), every lane a serial chain -- 4 096 items at 64 a workgroup
 // are 64 workgroups on 64 of the 256 CUs, each as long as a full one takes.  So a tile of fewer than 256 x 64 items is spread: count / 256 items a workgroup
 // (the static LDS allocation stays: still one workgroup per CU), down to a single item; a step of a wavefront with fewer lanes on it is also the shorter one.
 constexpr int32_t ZSTD_EXEC_ALL_RECORDS_MAX_ITEMS = 16384;
+int g_zstd_seq_spread = 256;  // (the CUs a small tile is spread over; tools/hostemu sets 1 to get full workgroups from a handful of items)
 inline int32_t seql_items_for(int32_t count)
 {
-    const int32_t per = (count + 255) / 256;
+    const int32_t per = (count + g_zstd_seq_spread - 1) / g_zstd_seq_spread;
     return per < 1 ? 1 : (per > zp::SEQL_ITEMS ? zp::SEQL_ITEMS : per);
 }
+int g_zstd_seq_waves = 1;
+// Wavefronts per workgroup of the sequence stage (context option zstd.decompress.seq_waves: 1, 2 or 4).  The LDS holds 64 items' tables however they are
+// spread; a wavefront's step costs its ~140 vector instructions whether 16 or 64 of its lanes hold an item, but four wavefronts of 16 items issue theirs on
+// four SIMDs side by side where one wavefront of 64 leaves three SIMDs idle.
+inline int32_t seql_waves_for(int32_t count)
+{
+    const int32_t items = seql_items_for(count);
+    return items < g_zstd_seq_waves ? 1 : g_zstd_seq_waves;
+}
+inline int32_t seql_items_per_wave(int32_t count)
+{
+    const int32_t w = seql_waves_for(count);
+    return (seql_items_for(count) + w - 1) / w;
+}
 template <bool MB>
-__global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs a, zp::Pipe p, int32_t itemsPerGroup)
+__global__ __launch_bounds__(256) void zstd_pipe_sequences_lane_kernel(BatchArgs a, zp::Pipe p, int32_t itemsPerGroup, int32_t itemsPerWave)
 {
     using namespace zp;
     __shared__ __attribute__((aligned(16))) uint16_t tables[SEQL_ITEMS * SEQL_STRIDE];
-    const uint32_t* const codeTab = seq_code_table;  // literal-length codes at 0.., match-length codes at 64..: baseline | extra bits << 24
-    const int lane = threadIdx.x;
-    // (itemsPerGroup <= SEQL_ITEMS: a tile of few items is spread over the CUs -- seql_items_for below -- and the lanes beyond sit out)
-    const int32_t place = blockIdx.x * itemsPerGroup + lane;
-    bool valid = lane < itemsPerGroup && place < p.count;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (itemsPerGroup <= SEQL_ITEMS: a tile of few items is spread over the CUs -- seql_items_for below -- and the lanes beyond sit out; the group's items are
+    // dealt to its wavefronts itemsPerWave at a time, an item's place in the group is also its table slot in the LDS)
+    const int32_t inGroup = wave * itemsPerWave + lane;
+    const int32_t place = blockIdx.x * itemsPerGroup + inGroup;
+    bool valid = lane < itemsPerWave && inGroup < itemsPerGroup && place < p.count;
     const int32_t slot = MB && valid && p.order != nullptr ? p.order[place] : place;  // (multi-block passes: longest items first, zstd_mb_order_kernel)
     int32_t from0 = slot, from1 = slot, from2 = slot;  // the slots the literal-length, offset and match-length tables come from
     if (MB && valid) {
@@ -892,8 +912,16 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
     }
     // stage the tables, item by item (each copy is done by the whole wavefront), eight items' loads in flight at a time: with a load and its store
     // per trip the staging of 64 items was 192 memory round trips one after the other -- up to 0.4 ms per wavefront, and most of the stage's
-    // time on streams of small blocks (a hundred sequences per block)
+    // time on streams of small blocks (a hundred sequences per block).  Round 6: the 24 loads of a trip are UNCONDITIONAL (a slot without an item
+    // is filled from the first live item's tables, the lanes beyond a table's last piece copy that piece again) -- under their branches the compiler
+    // put a `vmcnt(0)` in front of every one of them, and "eight items in flight" was one.
     const unsigned long long liveMask = __ballot(live);
+    if (liveMask == 0) {  // (uniform)
+        return;
+    }
+    const int leader = (int)__builtin_ctzll(liveMask);
+    const int32_t lf0 = __shfl(from0, leader), lf1 = __shfl(from1, leader), lf2 = __shfl(from2, leader), leaderSlot = __shfl(slot, leader);
+    const int32_t sf0 = live ? from0 : lf0, sf1 = live ? from1 : lf1, sf2 = live ? from2 : lf2;
     constexpr int STAGE_ITEMS = 8;
     for (int k0 = 0; k0 < SEQL_ITEMS; k0 += STAGE_ITEMS) {  // (uniform)
         if (((liveMask >> k0) & ((1ull << STAGE_ITEMS) - 1ull)) == 0) {
@@ -903,46 +931,50 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
 #pragma unroll
         for (int u = 0; u < STAGE_ITEMS; u++) {
             const int k = k0 + u;
-            if (((liveMask >> k) & 1ull) != 0) {  // (uniform)
-                const int32_t f0 = __shfl(from0, k), f1 = __shfl(from1, k), f2 = __shfl(from2, k);
-                const uint16_t* gLL = p.fse + (size_t)f0 * FSE_SLOT;
-                const uint16_t* gOF = p.fse + (size_t)f1 * FSE_SLOT;
-                const uint16_t* gML = p.fse + (size_t)f2 * FSE_SLOT;
+            const int32_t f0 = __shfl(sf0, k), f1 = __shfl(sf1, k), f2 = __shfl(sf2, k);
+            const uint16_t* gLL = p.fse + (size_t)f0 * FSE_SLOT;
+            const uint16_t* gOF = p.fse + (size_t)f1 * FSE_SLOT;
+            const uint16_t* gML = p.fse + (size_t)f2 * FSE_SLOT;
 #pragma unroll
-                for (int t = 0; t < 3; t++) {  // 1280 states, 8 per piece: LL 0..511, OF 512..767, ML 768..1279
-                    const int32_t i = (lane + 64 * t) * 8;
-                    if (i < FSE_SLOT) {
-                        const uint16_t* g = i < FSE_OF ? gLL : (i < FSE_ML ? gOF : gML);
-                        v[u][t] = *(const u32x4*)(g + i);
-                    }
-                }
+            for (int t = 0; t < 3; t++) {  // 1280 states, 8 per piece: LL 0..511, OF 512..767, ML 768..1279
+                const int32_t i0 = (lane + 64 * t) * 8;
+                const int32_t i = i0 < FSE_SLOT ? i0 : FSE_SLOT - 8;
+                const uint16_t* g = i < FSE_OF ? gLL : (i < FSE_ML ? gOF : gML);
+                v[u][t] = ld16_global((const uint8_t*)(g + i));
             }
         }
 #pragma unroll
         for (int u = 0; u < STAGE_ITEMS; u++) {
             const int k = k0 + u;
-            if (((liveMask >> k) & 1ull) != 0) {  // (uniform)
+            if (k < itemsPerWave) {  // (uniform; the slots beyond belong to the next wavefront)
 #pragma unroll
                 for (int t = 0; t < 3; t++) {
-                    const int32_t i = (lane + 64 * t) * 8;
-                    if (i < FSE_SLOT) {
-                        *(u32x4*)(tables + k * SEQL_STRIDE + i) = v[u][t];
-                    }
+                    const int32_t i0 = (lane + 64 * t) * 8;
+                    const int32_t i = i0 < FSE_SLOT ? i0 : FSE_SLOT - 8;
+                    *(u32x4*)(tables + (wave * itemsPerWave + k) * SEQL_STRIDE + i) = v[u][t];
                 }
             }
         }
     }
-    __syncthreads();
-    if (!live) {
-        return;
-    }
-    const int32_t block = slot_item<MB>(p, slot);
+    wave_sync();  // (a wavefront reads the tables it staged itself)
+    // From here on EVERY lane of the wavefront stays to the end, whether it holds an item or not (round 6).  Two things follow from that, and both are
+    // what the stage's time is made of: the code tables can be held by the lanes and read with a lane gather (`ds_bpermute` returns 0 for a lane that
+    // has left: all have to be there) instead of two loads from memory in the middle of every step's dependency chain, and every step issues the same
+    // vector-memory operations -- one load of stream bytes, one record store -- so that the compiler can count them: the wait for the stream bytes is
+    // `vmcnt(1)`, with the step's record store still on its way, where a store under a branch made it `vmcnt(0)` and every step waited for the
+    // store before it to reach the L2.  A lane without work (no item, an item that is through or has failed) runs the step on harmless values: it reads
+    // its own stream's start (or the first live lane's), looks up its own -- possibly unwritten -- table slot with masked indices, and stores the record
+    // it stored last again (a lane that never had one: into a dummy slot of its own).
+    const int32_t block = slot_item<MB>(p, live ? slot : leaderSlot);
     const uint8_t* src = a.srcBase + a.srcOff[block];
-    const uint16_t* tLL = tables + lane * SEQL_STRIDE + FSE_LL;
-    const uint16_t* tOF = tables + lane * SEQL_STRIDE + FSE_OF;
-    const uint16_t* tML = tables + lane * SEQL_STRIDE + FSE_ML;
-    const int32_t logLL = d.log[0], logOF = d.log[1], logML = d.log[2];
-    uint64_t* rec = p.seq + d.seqBase;
+    const int32_t tableSlot = inGroup < SEQL_ITEMS ? inGroup : SEQL_ITEMS - 1;  // (a lane without an item reads somebody's tables: harmless)
+    const uint16_t* tLL = tables + tableSlot * SEQL_STRIDE + FSE_LL;
+    const uint16_t* tOF = tables + tableSlot * SEQL_STRIDE + FSE_OF;
+    const uint16_t* tML = tables + tableSlot * SEQL_STRIDE + FSE_ML;
+    const int32_t logLL = live ? d.log[0] : 0, logOF = live ? d.log[1] : 0, logML = live ? d.log[2] : 0;
+    uint64_t* rec = live ? p.seq + d.seqBase : seq_idle_sink + ((blockIdx.x & (SEQ_IDLE_GROUPS - 1)) * 256 + threadIdx.x);
+    // literal-length code c -> baseline | extra bits << 24 in lane c, match-length code c likewise (36 and 53 codes: a lane each)
+    const uint32_t codeLL = seq_code_table[lane], codeML = seq_code_table[64 + lane];
 
     // The bit stream, MSB first: `w` holds the stream from the current bit position down (its top `have` bits came from whole bytes above
     // `ptr`; what lies below them in `w` is either zero or the stream's next bits, never anything else), `nextWord` the eight bytes below
@@ -954,14 +986,15 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
     // start -- where the Java code reads whatever its wrapped shifts give -- is handed to the fallback list rather than imitated.
     bool bad = false;
     uint64_t w = 0, nextWord = 0;
-    int32_t have = 0, ptr = 0, rem = 0;
-    const int32_t sStart = d.seqStart;
-    {
-        const int32_t end = d.seqEnd, size = end - sStart;
-        if (size < 1 || end < 8 || sStart < 8) {  // (Initializer.initialize :110-130; a stream always has a frame and a block header before it)
+    int32_t have = 0, ptr = 8, rem = 0;
+    int32_t sStart = 8;  // (a lane without work: "the stream" is empty and ends at byte 8 of a source that has at least a frame and a block header)
+    if (live) {
+        const int32_t end = d.seqEnd, size = end - d.seqStart;
+        if (size < 1 || end < 8 || d.seqStart < 8) {  // (Initializer.initialize :110-130; a stream always has a frame and a block header before it)
             bad = true;
         }
         else {
+            sStart = d.seqStart;
             const int32_t last = src[end - 1];
             bad = last == 0;
             const int32_t c0 = 8 - zd::highest_bit((uint32_t)(last | 1));
@@ -978,9 +1011,9 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
             w = bits << (consumed & 63);
             have = 64 - consumed;
             rem = 8 * size - c0;
-            nextWord = ld8(src + ptr - 8);
         }
     }
+    nextWord = ld8(src + ptr - 8);
     auto refill = [&]() {
         int32_t k = (64 - have) >> 3;
         const int32_t avail = ptr - sStart;
@@ -1006,7 +1039,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
     int32_t nDecoded = 0;
     // the repeat-offset history; MB: "what it was before the block", entries 0 .. 2 (see above)
     int32_t p0 = MB ? sx2::REP_SENTINEL : 1, p1 = MB ? (sx2::REP_SENTINEL | (1 << 16)) : 4, p2 = MB ? (sx2::REP_SENTINEL | (2 << 16)) : 8;
-    if (!bad) {
+    {
         // initial states in stream order LL, OF, ML (:378-386)
         int32_t sLL = field(0, logLL) & 511;
         int32_t sOF = field(logLL, logOF) & 255;
@@ -1017,22 +1050,32 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
             have -= n0;
             rem -= n0;
         }
-        int32_t sequenceCount = d.nbSeq;
+        int32_t sequenceCount = live && !bad ? d.nbSeq : 0;
+        uint64_t lastRecord = 0;
+        uint32_t tabLL = codeLL, tabML = codeML;
+        settle(nextWord);  // (nothing the loop reads is still on its way when it is entered: its waits are then for its own loads alone)
+        settle(tabLL);
+        settle(tabML);
         // ZstdFrameDecompressor.java:388-486, straight-line: an irregular stream sets `bad` and keeps decoding
         // harmless garbage (every index is masked) until the count runs out
-        while (sequenceCount > 0) {
-            sequenceCount--;
-            const bool over = rem < 0;          // Loader.load() :171-175
-            bad |= over && sequenceCount != 0;  // "Not all sequences were consumed"
+#if defined(ACHIP_K3_PROBE)
+        const uint64_t probeT0 = __builtin_readcyclecounter();
+        int32_t probeSteps = 0, probeRefill2 = 0;
+#endif
+        while (__ballot(sequenceCount > 0) != 0) {  // (uniform)
+            const bool act = sequenceCount > 0;  // this lane's item has a sequence to decode in this step
+            sequenceCount -= act ? 1 : 0;
+            const bool over = rem < 0;                 // Loader.load() :171-175
+            bad |= act && over && sequenceCount != 0;  // "Not all sequences were consumed"
             sequenceCount = over ? 0 : sequenceCount;
             refill();
             const uint32_t eLL = tLL[sLL], eML = tML[sML], eOF = tOF[sOF];
             const int32_t cLL = (int32_t)(eLL & 63), cML = (int32_t)(eML & 63), cOF = (int32_t)(eOF & 63);
-            const uint32_t tl = codeTab[cLL], tm = codeTab[64 + cML];
+            const uint32_t tl = (uint32_t)__shfl((int32_t)tabLL, cLL), tm = (uint32_t)__shfl((int32_t)tabML, cML);
             const int32_t xLL = (int32_t)(tl >> 24), xML = (int32_t)(tm >> 24), xOF = cOF & 31;
             // codes beyond the tables are only reachable through a table the Java reader would also have rejected or mis-indexed; offset
             // codes above 24 give offsets no window allows (checked below) and extra-bit counts the shortcut above does not cover
-            bad |= cLL > 35 || cML > 52 || cOF > 24;
+            bad |= act && (cLL > 35 || cML > 52 || cOF > 24);
             // extra bits are read in the order offset, match length, literal length
             const int32_t vOF = (cOF < 2 ? cOF : (1 << xOF) - 3) + field(0, xOF);
             const int32_t matchLength = (int32_t)(tm & 0xFFFFFF) + field(xOF, xML);
@@ -1041,7 +1084,11 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
             w <<= (xsum & 63);
             have -= xsum;
             rem -= xsum;
-            bad |= rem < 0 && !over;  // the extra bits ran past the stream's start
+            bad |= act && rem < 0 && !over;  // the extra bits ran past the stream's start
+#if defined(ACHIP_K3_PROBE)
+            probeSteps++;
+            probeRefill2 += __ballot(xsum > 64 - 7 - (9 + 9 + 8)) != 0 ? 1 : 0;
+#endif
             if (xsum > 64 - 7 - (9 + 9 + 8)) {
                 refill();
             }
@@ -1066,36 +1113,48 @@ __global__ __launch_bounds__(64) void zstd_pipe_sequences_lane_kernel(BatchArgs 
             // (a sentinel's low bits count the "- 1" steps: at most one per sequence, fewer than 2^16)
             int32_t temp = raw == 3 ? ((MB && p0 >= sx2::REP_SENTINEL) ? p0 + 1 : p0 - 1) : (raw == 1 ? p1 : p2);
             temp = temp == 0 ? 1 : temp;
-            // (!over: the Java loop leaves at an overflow before it decodes anything -- the history a block leaves behind is that of its last decoded sequence)
-            const bool shift2 = !over && (rep ? (raw != 0 && raw != 1) : true);  // p2 = p1
-            const bool shift1 = !over && (rep ? raw != 0 : true);                // p1 = p0, p0 = new
+            // (not at an overflow: the Java loop leaves there before it decodes anything -- the history a block leaves behind is that of its last decoded sequence)
+            const bool produce = act && !over;
+            const bool shift2 = produce && (rep ? (raw != 0 && raw != 1) : true);  // p2 = p1
+            const bool shift1 = produce && (rep ? raw != 0 : true);                // p1 = p0, p0 = new
             const int32_t offset = rep ? (raw != 0 ? temp : p0) : raw;
             p2 = shift2 ? p1 : p2;
             p1 = shift1 ? p0 : p1;
             p0 = shift1 ? offset : p0;
             // an offset beyond 2^24 cannot be a valid back-reference (the window is at most 2^23); keeps the record fields in range and
             // the sentinels apart from real offsets
-            bad |= offset <= 0 || (offset > (1 << 24) && !(MB && rep && offset >= sx2::REP_SENTINEL));
-            if (!over) {  // (8 bytes per lane and step, straight to the arena: the L2 merges a line's pieces.  Staging 16 records per lane in
-                          // LDS and storing lines -- what the quad version does -- measured no faster: 427 against 405 ms over the bench's launches)
-                rec[nDecoded] = (uint64_t)(uint32_t)literalsLength | ((uint64_t)(uint32_t)matchLength << 18) | ((uint64_t)(uint32_t)(offset & 0xFFFFFFF) << 36);
-            }
-            nDecoded += over ? 0 : 1;
+            bad |= act && (offset <= 0 || (offset > (1 << 24) && !(MB && rep && offset >= sx2::REP_SENTINEL)));
+            // 8 bytes per lane and step, straight to the arena (the L2 merges a line's pieces; staging 16 records per lane in LDS and storing lines --
+            // what the quad version did -- measured no faster), UNCONDITIONALLY: a lane that has no record in this step stores its last one again
+            const uint64_t record = (uint64_t)(uint32_t)literalsLength | ((uint64_t)(uint32_t)matchLength << 18) | ((uint64_t)(uint32_t)(offset & 0xFFFFFFF) << 36);
+            lastRecord = produce ? record : lastRecord;
+            const int32_t at = produce ? nDecoded : (nDecoded > 0 ? nDecoded - 1 : 0);
+            rec[at] = lastRecord;
+            nDecoded += produce ? 1 : 0;
         }
+#if defined(ACHIP_K3_PROBE)
+        if (lane == 0) {
+            atomicAdd(p.fallbackCount + 32 + 4, probeSteps);
+            atomicAdd(p.fallbackCount + 32 + 5, probeRefill2);
+            atomicAdd(p.fallbackCount + 32 + 6, (int32_t)((__builtin_readcyclecounter() - probeT0) >> 10));
+        }
+#endif
     }
-    if (bad) {
-        slot_to_fallback<MB>(p, slot, 3);
-    }
-    else {
-        p.desc[slot].nDecoded = nDecoded;
-        if (MB) {
-            p.mb[slot].repOut[0] = p0;
-            p.mb[slot].repOut[1] = p1;
-            p.mb[slot].repOut[2] = p2;
+    if (live) {
+        if (bad) {
+            slot_to_fallback<MB>(p, slot, 3);
+        }
+        else {
+            p.desc[slot].nDecoded = nDecoded;
+            if (MB) {
+                p.mb[slot].repOut[0] = p0;
+                p.mb[slot].repOut[1] = p1;
+                p.mb[slot].repOut[2] = p2;
+            }
         }
     }
     if (!MB) {  // the tile's long-sequence items, for K4's choice (one atomic per wavefront)
-        const bool isLong = !bad && long_sequences(a.dstCap[block], nDecoded);
+        const bool isLong = live && !bad && long_sequences(a.dstCap[block], nDecoded);
         const unsigned long long lm = __ballot(isLong);
         if (isLong && lane == (int)__builtin_ctzll(lm)) {
             atomicAdd(p.longCount, (int32_t)__popcll(lm));
@@ -1922,7 +1981,7 @@ hipError_t launch_zstd_mb_stages(const BatchArgs& a, hipStream_t stream, zp::Pip
             hipLaunchKernelGGL(zstd_mb_order_kernel<false>, dim3(g64), dim3(64), 0, stream, p);
             hipLaunchKernelGGL(zstd_mb_order_kernel<true>, dim3(g64), dim3(64), 0, stream, p);
         }
-        hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<true>, dim3((unsigned)((p.count + seql_items_for(p.count) - 1) / seql_items_for(p.count))), dim3(64), 0, stream, a, p, seql_items_for(p.count));
+        hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<true>, dim3((unsigned)((p.count + seql_items_for(p.count) - 1) / seql_items_for(p.count))), dim3(64 * seql_waves_for(p.count)), 0, stream, a, p, seql_items_for(p.count), seql_items_per_wave(p.count));
         // A frame is one wavefront's work whatever its size: a pass of few frames leaves the LDS idle, and a window of 32 KiB instead of 4 turns most
         // of a text frame's far matches (offsets beyond the window: 64-byte sectors re-read through the L2) into LDS reads
         if (nItems <= 1024) {  // (four wavefronts per CU on 256 CUs: what 32 KiB windows leave room for)
@@ -1985,7 +2044,7 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
         // (items per wavefront in K2 / K3 of 8 instead of 16, and an 8 KiB window for the record executor, were round-2 experiments: measured in
         // round 3 within noise of the defaults on all three data sets -- profiles/r03_notes.md -- and removed)
         hipLaunchKernelGGL(zstd_pipe_literals_kernel<false>, dim3(w16), dim3(64), 0, stream, a, p);
-        hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<false>, dim3((unsigned)((p.count + seql_items_for(p.count) - 1) / seql_items_for(p.count))), dim3(64), 0, stream, a, p, seql_items_for(p.count));
+        hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<false>, dim3((unsigned)((p.count + seql_items_for(p.count) - 1) / seql_items_for(p.count))), dim3(64 * seql_waves_for(p.count)), 0, stream, a, p, seql_items_for(p.count), seql_items_per_wave(p.count));
         constexpr int GS = 4, IN_RING = 128, OUT_RING = 256;
         // (a tile of few items: every item to the record executor, a wavefront each -- the rings give an item four lanes, and an item of long sequences is then a
         // serial chain of 5.4 ms whatever else the chip does: 64 frames 15.2 ms a call, 6.8 of it the sequence stage's own chain, 5.4 this one)
@@ -2380,7 +2439,7 @@ hipError_t launch_zstd_stream_step(hipStream_t stream, void* scratch, int64_t sc
     hipLaunchKernelGGL(zstd_ss_ghost_kernel, dim3(1), dim3(64), 0, stream, p, carry);
     hipLaunchKernelGGL(zstd_mb_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
     hipLaunchKernelGGL(zstd_pipe_literals_kernel<true>, dim3((unsigned)((p.count + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
-    hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<true>, dim3((unsigned)((p.count + seql_items_for(p.count) - 1) / seql_items_for(p.count))), dim3(64), 0, stream, a, p, seql_items_for(p.count));
+    hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<true>, dim3((unsigned)((p.count + seql_items_for(p.count) - 1) / seql_items_for(p.count))), dim3(64 * seql_waves_for(p.count)), 0, stream, a, p, seql_items_for(p.count), seql_items_per_wave(p.count));
     hipLaunchKernelGGL(zstd_ss_execute_kernel<32768>, dim3(1), dim3(64), 0, stream, a, p, carry, startPos);
     hipLaunchKernelGGL(zstd_ss_carry_kernel, dim3(1), dim3(64), 0, stream, p, carry);
     hipLaunchKernelGGL(zstd_ss_checksum_kernel, dim3(1), dim3(64), 0, stream, dOut + startPos, carry, closing != 0 && hasChecksum != 0 ? 1 : 0, expected);

@@ -61,6 +61,7 @@ def parse_args():
     p.add_argument("--mixed-copies", type=int, default=4, help="copies of the 668-line corpus job in the configs[4] leg")
     p.add_argument("--section", default="all", choices=["all", "zstd", "zstdstream", "xxhash", "lz4frame", "sweep"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-exec", type=int, default=-1, help="zstd pipeline execute stage: 2 = chosen per item (default), 1 = wavefront per item through the record executor, 0 = LDS rings")
+    p.add_argument("--zstd-seq-waves", type=int, default=0, help="zstd pipeline sequence stage: wavefronts per workgroup (1, 2, 4; 0 = library default)")
     p.add_argument("--snappyframed-variant", type=int, default=-1, help="x-snappy-framed reader: 3 = ring or two-pass decoder by a probe (default), 1 = chunks through the ring decoders, 2 = through the two-pass decoder, 0 = a wavefront per stream")
     p.add_argument("--lz4frame-variant", type=int, default=-1, help="LZ4 frame reader: 2 = by a probe (default), 0 = a wavefront per item, 1 = the frames' blocks as one batch through the two-pass block decoder")
     p.add_argument("--hadoop-variant", type=int, default=-1, help="Hadoop block-stream reader: 3 = ring or two-pass decoders by a probe (default), 1 = chunks through the ring decoders, 2 = through the two-pass decoders, 0 = a wavefront per stream")
@@ -1158,6 +1159,8 @@ def zstd_extra(torch, A, codec, dev, args):
         codec.native.set_option("zstd.decompress.variant", args.zstd_variant)
     if args.zstd_exec >= 0:
         codec.native.set_option("zstd.decompress.exec", args.zstd_exec)
+    if args.zstd_seq_waves > 0:
+        codec.native.set_option("zstd.decompress.seq_waves", args.zstd_seq_waves)
     if args.zstd_compress_variant >= 0:
         codec.native.set_option("zstd.compress.variant", args.zstd_compress_variant)
     zc = pa.Codec("zstd", compression_level=3)

@@ -31,6 +31,9 @@ def o():
     return oracle_lib.load()
 
 
+DEFAULT_SEQ_WAVES = 1  # (the library's default of zstd.decompress.seq_waves, restored by the test that changes it)
+
+
 def zstd_frames(blocks, level):
     import pyarrow as pa
     codec = pa.Codec("zstd", compression_level=level)
@@ -265,6 +268,32 @@ def test_many_frames_full_size_property(gbd, o):
         # single-block frames must stay on the pipeline: none handed to the one-kernel decoder
         stages = [gbd.codec.native.get_stat("zstd.decompress.fallback_stage%d" % k) for k in range(1, 6)]
         assert gbd.codec.native.get_stat("zstd.decompress.fallback_items") == 0, stages
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4])
+def test_sequence_stage_wavefronts_per_workgroup(o, waves):
+    """zstd.decompress.seq_waves: the pipeline's sequence stage with its 64 items a workgroup on 1, 2 or 4 wavefronts (lanes without an item beside lanes
+    with one; single-block frames and the multi-block stages) -- every frame restored, nothing handed to the one-kernel decoder."""
+    import hashlib
+    from tests.gpu_harness import GpuBatch
+    rng = np.random.default_rng(78)
+    sample = b"".join(d for _, d, _ in common.corpus_sample())
+    blocks = []
+    for i in range(250):
+        off = int(rng.integers(0, len(sample) - 131072))
+        blocks.append(sample[off:off + int(rng.integers(2000, 131073))])
+    blocks += [sample[:300000], sample[100000:100000 + 500000]]  # (frames of several blocks: the multi-block stages' instantiation)
+    frames = zstd_frames(blocks, 3)
+    g = GpuBatch(0, options={"zstd.decompress.variant": 1})
+    try:
+        g.set_option("zstd.decompress.seq_waves", waves)
+        outs, status, err = g.run(OP_ZSTD_DECOMPRESS, frames * 16, [len(b) for b in blocks] * 16)
+        assert all(s == 0 for s in status)
+        want = [hashlib.sha256(b).digest() for b in blocks] * 16
+        assert [hashlib.sha256(p).digest() for p in outs] == want
+        assert g.codec.native.get_stat("zstd.decompress.fallback_items") == 0
+    finally:
+        g.set_option("zstd.decompress.seq_waves", DEFAULT_SEQ_WAVES)  # (process-wide)
 
 
 def test_pipeline_takes_java_encoded_frames(gbd, o):

@@ -96,7 +96,8 @@ def multi_block(expect_fast):
                 print("MISMATCH %s pass %d: fallback list %s, expected %s" % (name, pass_blocks, fb, too_long))
     # the multi-block execute stage with the 8 KiB window (option zstd.decompress.exec_window): the oracle's frames again
     frames = [bytes(encs[0][1](p)) for p in plains]
-    outs, status, fb = run(frames, [len(p) for p in plains], exec_mode=1, pass_blocks=2048)
+    # (exec_mode bits 4 .. 6: the sequence stage in full workgroups of 4 wavefronts x 16 block slots -- option zstd.decompress.seq_waves)
+    outs, status, fb = run(frames, [len(p) for p in plains], exec_mode=1 | (4 << 4), pass_blocks=2048)
     wide = sum(1 for i, p in enumerate(plains) if i in fb or status[i] != 0 or outs[i] != p)
     print("oracle, 8 KiB executor window: %d frames, %d mismatches" % (len(frames), wide))
     bad += wide
@@ -227,7 +228,8 @@ def main():
             continue
         frames = [bytes(enc(p)) for p in plains]
         # (second run: the 8-items-per-wavefront instantiations of the literal and sequence stages -- mode bits 2 and 3)
-        for pad, mode in ((0, 1), (37, 1)):
+        # (... and the sequence stage in full workgroups of 1, 2 and 4 wavefronts: mode bits 4 .. 6, lanes without an item beside lanes with one)
+        for pad, mode in ((0, 1), (37, 1), (0, 1 | (1 << 4)), (0, 1 | (2 << 4)), (0, 1 | (4 << 4))):
             outs, status, fb = run(frames, [len(p) + pad for p in plains], exec_mode=mode)
             for i, p in enumerate(plains):
                 total += 1

@@ -1,0 +1,52 @@
+#!/bin/bash
+# Round 6 GPU calls, one parametrised script: tools/r06/call.sh <step> [<step> ...]
+# Every step runs under its own timeout and writes under gpurun_out/r06/<step>*.
+export TMPDIR=/tmp
+O=gpurun_out/r06
+mkdir -p $O
+ks() {  # ks <tag> <bench args...>: per-kernel average times of one bench.py run -> $O/kstats_<tag>.txt
+  local tag=$1; shift
+  timeout 400 bash tools/kstats.sh r06_$tag "$@"
+  mv gpurun_out/kstats_r06_$tag.txt $O/kstats_$tag.txt 2>/dev/null
+  echo "--- $tag"; cat $O/kstats_$tag.txt
+}
+line() {  # line <label>: one bench line on stdin -> the keys worth reading
+  python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('$1', 'value', r.get('value'), 'frac', r.get('roofline',{}).get('frac'), {k:v for k,v in r.items() if k.startswith('value_') or k in ('mixed_ok','end_to_end','single_block_us')})
+"
+}
+for step in "$@"; do
+  echo "===== $step at $(date +%T)"
+  case $step in
+    zstdtests)     # the Zstd decoder's GPU parity tests (pipeline, multi-block stages, streams)
+      timeout 1200 python -m pytest tests/test_gpu_zstd.py tests/test_gpu_zstd_stream.py -m gpu -x -q 2>&1 | tail -5 ;;
+    zstdprof)      # per-dispatch times of the Zstd section (K1 .. K5, the encoder's two kernels) -> $O/zstd_dispatches_<TAG>.txt
+      timeout 900 bash tools/profile_zstd.sh r06_${TAG:-a} --no-cpu-baseline 2>&1 | tail -2 | cut -c1-1500
+      cp gpurun_out/prof_r06_${TAG:-a}/keep/dispatches.txt $O/zstd_dispatches_${TAG:-a}.txt
+      python - $O/zstd_dispatches_${TAG:-a}.txt <<'PY'
+import sys, collections
+t = collections.OrderedDict()
+for l in open(sys.argv[1]).read().splitlines()[1:]:
+    f = l.split()
+    name = " ".join(f[:-4]); us = float(f[-4])
+    t.setdefault(name, []).append(us)
+for n, v in t.items():
+    print("%-52s calls %4d  avg %9.1f us  min %9.1f  max %9.1f" % (n, len(v), sum(v) / len(v), min(v), max(v)))
+PY
+      ;;
+    zstdfuzz)      # differential fuzz of the Zstd decoder (mutated frames: status, offset, plaintext against the oracle)
+      timeout 900 python tools/fuzz_decoders.py ${N:-4000} 66 zstd 2>&1 | grep -v "^\[" | tail -8 | tee $O/fuzz_zstd.txt ;;
+    seqwaves)      # the Zstd sequence stage at 1 / 2 / 4 wavefronts per workgroup: parity test, then the section's per-dispatch times for each
+      timeout 600 python -m pytest tests/test_gpu_zstd.py -m gpu -x -q -k "wavefronts_per_workgroup" 2>&1 | tail -3
+      for w in ${WAVES:-1 2 4}; do
+        timeout 600 bash tools/profile_zstd.sh r06_w$w --no-cpu-baseline --zstd-seq-waves $w 2>&1 | tail -1 | python -c "
+import json,sys
+r=json.loads(sys.stdin.read()); print('waves $w:', {k:(v['decompress_GiBps'], v['java_frames_decompress_GiBps']) for k,v in r.items()})"
+        grep sequences_lane gpurun_out/prof_r06_w$w/keep/dispatches.txt | awk '{print $2}' | tr '\n' ' '; echo
+        cp gpurun_out/prof_r06_w$w/keep/dispatches.txt $O/zstd_dispatches_w$w.txt
+      done 2>&1 | tee $O/seqwaves.txt ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
