@@ -1304,31 +1304,49 @@ int32_t achip_mixed_batch(achip_ctx* ctx, const int32_t* codecOp, const void* sr
     for (int k = 0; k < kNumOps; k++) familyUsed[op_family(k)] |= count[k + 1] != 0;
     const bool sideBySide = ctx->mixConcurrent != 0 && (int)familyUsed[0] + (int)familyUsed[1] + (int)familyUsed[2] > 1;
     achip_ctx* lanes[kMixFamilies] = {ctx, ctx, ctx};
+    bool laneJoined[kMixFamilies] = {};  // helper lanes that were made to wait for the gather (and may have been given work): they must be joined back, also on failure
+    // joins the helper lanes used so far back into the context's stream -- on every way out, so that achip_ctx_synchronize covers them and the next
+    // call cannot reuse the mixed-batch scratch (gOutLen, gStatus, perm) under kernels of this one
+    auto join_lanes = [&]() -> int32_t {
+        int32_t jr = 0;
+        for (int f = 1; f < kMixFamilies; f++) {
+            if (!laneJoined[f]) continue;
+            laneJoined[f] = false;
+            hipError_t e = hipEventRecord(ctx->mixLaneDone[f], lanes[f]->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->mixLaneDone[f], 0);
+            if (e != hipSuccess) {
+                (void)hipStreamSynchronize(lanes[f]->stream);  // (the event path failed: wait here instead)
+                jr = device_failure("joining the mixed batch's helper lanes", e);
+            }
+        }
+        return jr;
+    };
+    r = 0;
     if (sideBySide) {
         if (!ctx->mixGathered) HIP_TRY(hipEventCreateWithFlags(&ctx->mixGathered, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ctx->mixGathered, ctx->stream));
-        for (int f = 1; f < kMixFamilies; f++) {
+        for (int f = 1; f < kMixFamilies && r >= 0; f++) {
             if (!familyUsed[f]) continue;
             r = mix_lane(ctx, f, &lanes[f]);
-            if (r < 0) return r;
-            HIP_TRY(hipStreamWaitEvent(lanes[f]->stream, ctx->mixGathered, 0));
+            if (r < 0) break;
+            const hipError_t e = hipStreamWaitEvent(lanes[f]->stream, ctx->mixGathered, 0);
+            if (e != hipSuccess) {
+                r = device_failure("hipStreamWaitEvent(lane, gathered)", e);
+                break;
+            }
+            laneJoined[f] = true;
         }
     }
-    for (int pass = 0; pass < 2; pass++) {
-        for (int k = 0; k < kNumOps; k++) {
+    for (int pass = 0; pass < 2 && r >= 0; pass++) {
+        for (int k = 0; k < kNumOps && r >= 0; k++) {
             if (count[k + 1] == 0 || (pass == 0) != op_is_encoder(k)) continue;
             const int64_t s = start[k];
             r = launch_op(k, lanes[op_family(k)], make_args(srcBase, gSrcOff + s, gSrcLen + s, dstBase, gDstOff + s, gDstCap + s, gOutLen + s, gStatus + s, gErr + s, (int32_t)count[k + 1]));
-            if (r < 0) return r;
         }
     }
-    if (sideBySide) {
-        for (int f = 1; f < kMixFamilies; f++) {
-            if (!familyUsed[f]) continue;
-            HIP_TRY(hipEventRecord(ctx->mixLaneDone[f], lanes[f]->stream));
-            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->mixLaneDone[f], 0));
-        }
-    }
+    const int32_t joined = join_lanes();
+    if (r < 0) return r;
+    if (joined < 0) return joined;
     HIP_TRY(achip::launch_mix_scatter(perm, nBlocks, gOutLen, gStatus, gErr, all, ctx->stream));
     return 0;
 }
@@ -2060,6 +2078,7 @@ struct achip_zstd_dstream {
     // the frame under way
     int64_t lookBack = 0;          // FrameHeader.computeRequiredOutputBufferLookBackSize
     bool hasChecksum = false;
+    bool windowBeyondJava = false; // the frame's window descriptor says more than 8 MiB: its first compressed block fails as in Java (:303), RAW / RLE blocks pass
     // output decoded, not delivered yet
     uint8_t* hostOut = nullptr;    // pinned, kStepBytes
     int64_t outLen = 0, outAt = 0;
@@ -2325,6 +2344,19 @@ int32_t achip_zstdstream_decompress_feed(achip_ctx* ctx, void* state, const void
             // FrameHeader.computeRequiredOutputBufferLookBackSize
             int64_t lookBack = contentSize < 0 ? windowSize : (windowSize < 0 ? contentSize : std::min(windowSize, contentSize));
             if (contentSize < 0 && csDesc == 3) lookBack = windowSize;  // (a content size beyond 2^63 reads negative in Java: "not set")
+            // What the Java reader does with large windows, and what this one does:
+            //  * a window descriptor above 8 MiB (MAX_WINDOW_SIZE): Java fails the frame's first COMPRESSED block ("Window size too large", ZstdFrameDecompressor
+            //    .java:303) and copies RAW / RLE blocks as they come -- so does this reader (windowBeyondJava, checked where the blocks are listed);
+            //  * a single-segment frame (no descriptor: Java's windowSize is -1 and the check above passes) of any content size: Java decodes it in a buffer
+            //    that never grows beyond 8 MiB + a block (ZstdIncrementalFrameDecompressor.java:318-336) -- this reader keeps min(content size, 128 MiB) behind
+            //    the position, i.e. it decodes every such stream the Java reader decodes, to the same bytes, and in addition accepts offsets between
+            //    Java's buffer and 128 MiB that Java refuses;
+            //  * output is handed out block by block here, where Java holds a window's worth back: an error in a later block is reported after bytes the
+            //    Java reader would not have delivered yet (tests/test_gpu_zstd_stream.py: "everything the reference delivered is a prefix").
+            z->windowBeyondJava = !singleSegment && windowSize > (8LL << 20);
+            if (singleSegment && lookBack > achip_zstd_dstream::kMaxWindow) {
+                lookBack = achip_zstd_dstream::kMaxWindow;
+            }
             if (lookBack < 0 || lookBack > achip_zstd_dstream::kMaxWindow) {
                 if (windowSize >= 0 && windowSize <= achip_zstd_dstream::kMaxWindow) {
                     lookBack = windowSize;
@@ -2355,7 +2387,7 @@ int32_t achip_zstdstream_decompress_feed(achip_ctx* ctx, void* state, const void
         // ---- BLOCKS: the whole blocks that lie in pending, up to a step ----
         std::vector<StepBlock> list;
         int64_t at = 0;
-        bool closing = false, broken = false;
+        bool closing = false, broken = false, brokenWindow = false;
         uint32_t expected = 0;
         while ((int32_t)list.size() < achip_zstd_dstream::kStepBlocks) {
             if (have - at < 3) break;
@@ -2364,6 +2396,11 @@ int32_t achip_zstdstream_decompress_feed(achip_ctx* ctx, void* state, const void
             if (type == 3 || (type == 2 && size > 131072)) {
                 // ("Invalid block type" :264; a compressed block beyond Block_Maximum_Size -- "Expected match length table to be present" or worse in Java -- would outgrow a step's room)
                 broken = true;
+                break;
+            }
+            if (type == 2 && z->windowBeyondJava) {  // ("Window size too large (not yet supported)" :303: the frame's first compressed block)
+                broken = true;
+                brokenWindow = true;
                 break;
             }
             const int64_t st = type == 1 ? 1 : size;
@@ -2398,7 +2435,7 @@ int32_t achip_zstdstream_decompress_feed(achip_ctx* ctx, void* state, const void
         }
         if (list.empty()) {
             if (broken) {
-                const int32_t st = dstream_fail(z, ACHIP_D_ZSTD_INVALID_BLOCK_TYPE, z->streamPos + 3);
+                const int32_t st = dstream_fail(z, brokenWindow ? ACHIP_D_ZSTD_WINDOW_TOO_LARGE : ACHIP_D_ZSTD_INVALID_BLOCK_TYPE, z->streamPos + 3);
                 if (errOffset) *errOffset = z->failOffset;
                 return *produced > 0 ? 0 : st;
             }

@@ -136,25 +136,13 @@ public final class HipBatchCodec
         return new Result(outputLength, status, errorOffset);
     }
 
-    /** Contiguous split balanced by bytes moved (source + destination), the same rule as achip_partition_blocks. */
+    /** Contiguous split balanced by bytes moved (source + destination): achip_partition_blocks itself, so that the split is the library's by construction. */
     static int[] partition(int[] sourceLength, int[] destinationCapacity, int parts)
     {
-        int blocks = sourceLength.length;
-        long total = 0;
-        for (int i = 0; i < blocks; i++) {
-            total += (long) sourceLength[i] + destinationCapacity[i];
+        long[] weight = new long[sourceLength.length];
+        for (int i = 0; i < weight.length; i++) {
+            weight[i] = (long) sourceLength[i] + destinationCapacity[i];
         }
-        int[] starts = new int[parts + 1];
-        long accumulated = 0;
-        int index = 0;
-        for (int p = 1; p < parts; p++) {
-            while (index < blocks && accumulated * parts < total * p) {
-                accumulated += (long) sourceLength[index] + destinationCapacity[index];
-                index++;
-            }
-            starts[p] = index;
-        }
-        starts[parts] = blocks;
-        return starts;
+        return HipNative.partitionBlocks(weight, parts);
     }
 }

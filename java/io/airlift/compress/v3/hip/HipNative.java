@@ -235,7 +235,33 @@ public final class HipNative
                     MemorySegment.class})
             MethodHandle zstdStreamCompressFinish,
             @NativeSignature(name = "achip_zstdstream_compress_end", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class})
-            MethodHandle zstdStreamCompressEnd) {}
+            MethodHandle zstdStreamCompressEnd,
+            // the helpers of the boundary (round 6: every symbol the header declares is bound): status words taken apart by the library, its version string,
+            // a context's device / stream / statistics, a device memset, events for timing on the context's stream, the multi-GPU split
+            @NativeSignature(name = "achip_status_class", returnType = int.class, argumentTypes = int.class)
+            MethodHandle statusClassNative,
+            @NativeSignature(name = "achip_status_detail", returnType = int.class, argumentTypes = int.class)
+            MethodHandle statusDetailNative,
+            @NativeSignature(name = "achip_version", returnType = MemorySegment.class, argumentTypes = {})
+            MethodHandle version,
+            @NativeSignature(name = "achip_ctx_device", returnType = int.class, argumentTypes = MemorySegment.class)
+            MethodHandle ctxDevice,
+            @NativeSignature(name = "achip_ctx_stream", returnType = MemorySegment.class, argumentTypes = MemorySegment.class)
+            MethodHandle ctxStream,
+            @NativeSignature(name = "achip_ctx_get_stat", returnType = long.class, argumentTypes = {MemorySegment.class, MemorySegment.class})
+            MethodHandle ctxGetStat,
+            @NativeSignature(name = "achip_memset_d", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class, int.class, long.class})
+            MethodHandle memsetDevice,
+            @NativeSignature(name = "achip_event_create", returnType = MemorySegment.class, argumentTypes = {})
+            MethodHandle eventCreate,
+            @NativeSignature(name = "achip_event_destroy", returnType = int.class, argumentTypes = MemorySegment.class)
+            MethodHandle eventDestroy,
+            @NativeSignature(name = "achip_event_record", returnType = int.class, argumentTypes = {MemorySegment.class, MemorySegment.class})
+            MethodHandle eventRecord,
+            @NativeSignature(name = "achip_event_elapsed_ms", returnType = float.class, argumentTypes = {MemorySegment.class, MemorySegment.class})
+            MethodHandle eventElapsedMs,
+            @NativeSignature(name = "achip_partition_blocks", returnType = int.class, argumentTypes = {MemorySegment.class, int.class, int.class, MemorySegment.class})
+            MethodHandle partitionBlocks) {}
 
     private static final Optional<LinkageError> LINKAGE_ERROR;
     private static final MethodHandles HANDLES;
@@ -340,6 +366,127 @@ public final class HipNative
         }
         if (result < 0) {
             throw toException(result, 0);
+        }
+    }
+
+    /** achip_version: the library's version string */
+    public static String version()
+    {
+        verifyEnabled();
+        try {
+            MemorySegment text = (MemorySegment) HANDLES.version().invokeExact();
+            return text.reinterpret(256).getString(0);
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
+    /**
+     * achip_partition_blocks: the contiguous split of a batch over {@code parts} GPUs, balanced by {@code weight} (bytes moved per block) -- the rule
+     * {@code achip_multi_batch_host} applies inside the library, so that a caller that launches the slices itself cuts where the library would.
+     * Returns {@code parts + 1} block indices.  Pure host arithmetic: no device is needed.
+     */
+    public static int[] partitionBlocks(long[] weight, int parts)
+    {
+        if (LINKAGE_ERROR.isPresent()) {
+            throw new IllegalStateException("HIP native library is not enabled", LINKAGE_ERROR.get());
+        }
+        int result;
+        int[] starts = new int[parts + 1];
+        try (Arena arena = Arena.ofConfined()) {
+            MemorySegment weights = arena.allocateFrom(java.lang.foreign.ValueLayout.JAVA_LONG, weight);
+            MemorySegment out = arena.allocate(java.lang.foreign.ValueLayout.JAVA_INT, parts + 1);
+            result = (int) HANDLES.partitionBlocks().invokeExact(weights, weight.length, parts, out);
+            MemorySegment.copy(out, java.lang.foreign.ValueLayout.JAVA_INT, 0, starts, 0, parts + 1);
+        }
+        catch (RuntimeException e) {
+            throw e;
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+        if (result < 0) {
+            throw toException(result, 0);
+        }
+        return starts;
+    }
+
+    /** achip_status_class / achip_status_detail: a status word taken apart by the library itself (the Java arithmetic above must agree: asserted by the callers' tests) */
+    public static int nativeStatusClass(int status)
+    {
+        try {
+            return (int) HANDLES.statusClassNative().invokeExact(status);
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
+    public static int nativeStatusDetail(int status)
+    {
+        try {
+            return (int) HANDLES.statusDetailNative().invokeExact(status);
+        }
+        catch (Throwable e) {
+            throw new AssertionError("should not reach here", e);
+        }
+    }
+
+    /** An event on a context's stream (achip_event_*): two of them time what was enqueued between their {@link Context#record} calls. */
+    public static final class Event
+            implements AutoCloseable
+    {
+        private final MemorySegment handle;
+        private final java.util.concurrent.atomic.AtomicBoolean destroyed = new java.util.concurrent.atomic.AtomicBoolean();
+
+        public Event()
+        {
+            verifyEnabled();
+            try {
+                handle = (MemorySegment) HANDLES.eventCreate().invokeExact();
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+            if (handle.equals(MemorySegment.NULL)) {
+                throw new IllegalStateException("achip_event_create failed: " + lastError());
+            }
+        }
+
+        MemorySegment handle()
+        {
+            if (destroyed.get()) {
+                throw new IllegalStateException("HipNative.Event is closed");
+            }
+            return handle;
+        }
+
+        /** milliseconds between this event and {@code stop}, both recorded and reached (achip_event_elapsed_ms: negative on failure) */
+        public float elapsedMillis(Event stop)
+        {
+            try {
+                return (float) HANDLES.eventElapsedMs().invokeExact(handle(), stop.handle());
+            }
+            catch (RuntimeException e) {
+                throw e;
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+        }
+
+        @Override
+        public void close()
+        {
+            if (destroyed.compareAndSet(false, true)) {
+                try {
+                    int ignored = (int) HANDLES.eventDestroy().invokeExact(handle);
+                }
+                catch (Throwable e) {
+                    throw new AssertionError("should not reach here", e);
+                }
+            }
         }
     }
 
@@ -627,6 +774,80 @@ public final class HipNative
             if (status < 0) {
                 throw toException(status, 0);
             }
+        }
+
+        /** achip_ctx_device: the device ordinal this context was created on */
+        public int device()
+        {
+            try {
+                return (int) HANDLES.ctxDevice().invokeExact(handle());
+            }
+            catch (RuntimeException e) {
+                throw e;
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+        }
+
+        /** achip_ctx_stream: the hipStream_t the context's batch calls are enqueued on (for callers that order their own device work against it) */
+        public MemorySegment stream()
+        {
+            try {
+                return (MemorySegment) HANDLES.ctxStream().invokeExact(handle());
+            }
+            catch (RuntimeException e) {
+                throw e;
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+        }
+
+        /** achip_ctx_get_stat: a counter of the context's last call (e.g. "zstd.decompress.fallback_items"); -1 for a name the library does not know */
+        public long getStat(String name)
+        {
+            try (Arena arena = Arena.ofConfined()) {
+                return (long) HANDLES.ctxGetStat().invokeExact(handle(), arena.allocateFrom(name));
+            }
+            catch (RuntimeException e) {
+                throw e;
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+        }
+
+        /** achip_memset_d: fills device memory on the context's stream */
+        public void memsetDevice(MemorySegment destination, int value, long bytes)
+        {
+            int result;
+            try {
+                result = (int) HANDLES.memsetDevice().invokeExact(handle(), destination, value, bytes);
+            }
+            catch (RuntimeException e) {
+                throw e;
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+            throwIfError(result, 0);
+        }
+
+        /** achip_event_record: the event is reached when everything enqueued on this context's stream so far has run */
+        public void record(Event event)
+        {
+            int result;
+            try {
+                result = (int) HANDLES.eventRecord().invokeExact(handle(), event.handle());
+            }
+            catch (RuntimeException e) {
+                throw e;
+            }
+            catch (Throwable e) {
+                throw new AssertionError("should not reach here", e);
+            }
+            throwIfError(result, 0);
         }
 
         /** achip_ctx_set_option: a tuning / format option of this context (e.g. "hadoop.buffer_size") */

@@ -59,7 +59,15 @@ public final class ZstdHipInputStream
         this.inputStream = requireNonNull(inputStream, "inputStream is null");
         HipNative.verifyEnabled();
         this.context = new HipNative.Context(device);
-        this.decoder = context.openZstdDecodeStream();
+        HipNative.Context.ZstdDecodeStream opened;
+        try {
+            opened = context.openZstdDecodeStream();
+        }
+        catch (RuntimeException | Error e) {
+            context.close();  // (the native context must not outlive a constructor that failed)
+            throw e;
+        }
+        this.decoder = opened;
     }
 
     @Override
@@ -83,6 +91,8 @@ public final class ZstdHipInputStream
         if (outputLength == 0) {
             return 0;
         }
+        // (As ZstdInputStream.read :79-103 this fills the caller's buffer unless the stream ends -- the reference loops `while (outputUsed < outputLength)`
+        // and asks its source for more in between; a reader that returned at the first output would deliver the same bytes in other portions.)
         int used = 0;
         while (used < outputLength) {
             try {

@@ -41,6 +41,7 @@ public final class ZstdHipOutputStream
     private final byte[] flushed = new byte[1 << 20];
     private byte[] singleByte;
     private boolean closed;
+    private boolean released;  // the native encoder and context are gone (close() ran, successfully or not)
 
     public ZstdHipOutputStream(OutputStream outputStream)
     {
@@ -70,7 +71,7 @@ public final class ZstdHipOutputStream
     public void write(byte[] buffer, int offset, int length)
             throws IOException
     {
-        if (closed) {
+        if (closed || released) {
             throw new IOException("Stream is closed");
         }
         java.util.Objects.checkFromIndexSize(offset, length, buffer.length);
@@ -95,20 +96,34 @@ public final class ZstdHipOutputStream
         if (closed) {
             return;
         }
-        // (ZstdOutputStream.close :193-205 sets `closed` only behind writeChunk(true); the sink is closed either way)
+        // (ZstdOutputStream.close :193-205 sets `closed` only behind writeChunk(true); the sink is closed either way.)  The NATIVE stream state --
+        // several MB of device and pinned memory -- and the context are released whatever finish() or the sink's write() do: a close() that threw
+        // leaves `closed` false as the reference does, and a second close() finds nothing native left to retry on (ADVICE round 5).
         try {
-            boolean done;
-            do {
-                done = encoder.finish(MemorySegment.ofArray(flushed), flushed.length);
-                int produced = (int) encoder.produced();
-                if (produced > 0) {
-                    outputStream.write(flushed, 0, produced);
+            if (released) {
+                throw new IOException("Stream failed while closing");
+            }
+            try {
+                boolean done;
+                do {
+                    done = encoder.finish(MemorySegment.ofArray(flushed), flushed.length);
+                    int produced = (int) encoder.produced();
+                    if (produced > 0) {
+                        outputStream.write(flushed, 0, produced);
+                    }
+                }
+                while (!done);
+                closed = true;
+            }
+            finally {
+                released = true;
+                try {
+                    encoder.close();
+                }
+                finally {
+                    context.close();
                 }
             }
-            while (!done);
-            closed = true;
-            encoder.close();
-            context.close();
         }
         finally {
             outputStream.close();

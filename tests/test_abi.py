@@ -214,13 +214,29 @@ def test_java_sources_are_consistent_with_the_header_and_with_each_other():
     header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "aircompressor_hip.h")).read(), flags=re.S)
     batch_params = len([p for p in re.search(r"#define ACHIP_BATCH_ARGS\s+((?:.*\\\n)*.*)", header).group(1).replace("\\\n", " ").split(",") if p.strip()])
     native = open(os.path.join(ROOT, "java", "io", "airlift", "compress", "v3", "hip", "HipNative.java")).read()
-    for name, args in re.findall(r'@NativeSignature\(name = "([a-z0-9_]+)", returnType = [A-Za-z.]+, argumentTypes = ([^)]*)\)', native):
-        m = re.search(r"\b%s\(([^;]*)\);" % name, header)
+    batch_decl = re.search(r"#define ACHIP_BATCH_ARGS\s+((?:.*\\\n)*.*)", header).group(1).replace("\\\n", " ")
+
+    def java_type(c_decl):
+        """the java.lang.foreign carrier NativeLoader can bind for a C parameter / return declaration (M/internal/NativeLoader.java:138-153)"""
+        c = " ".join(c_decl.replace("const", " ").split())
+        if "*" in c:
+            return "MemorySegment"
+        base = c.split()[0] if c else "void"
+        return {"int32_t": "int", "int64_t": "long", "int8_t": "byte", "float": "float", "void": "void"}[base]
+
+    bound = set()
+    for name, ret, args in re.findall(r'@NativeSignature\(name = "([a-z0-9_]+)", returnType = ([A-Za-z.]+)\.class, argumentTypes = ([^)]*)\)', native):
+        m = re.search(r"([A-Za-z0-9_ ]+?\**)\s*\b%s\(([^;]*)\);" % name, header)
         assert m, name
-        decl = m.group(1).strip()
-        n_decl = 0 if decl in ("", "void") else sum(batch_params if part.strip() == "ACHIP_BATCH_ARGS" else 1 for part in decl.split(","))
-        n_java = len(re.findall(r"\b[A-Za-z]+\.class", args))
-        assert n_java == n_decl, (name, n_java, n_decl)
+        bound.add(name)
+        decl = m.group(2).strip().replace("ACHIP_BATCH_ARGS", batch_decl)
+        want = [] if decl in ("", "void") else [java_type(part) for part in decl.split(",") if part.strip()]
+        got = re.findall(r"\b([A-Za-z]+)\.class", args)
+        assert got == want, (name, got, want)          # argument TYPES, in order: int / long / MemorySegment <-> int32 / int64 / pointer
+        assert ret == java_type(m.group(1)), (name, ret, m.group(1))
+    assert batch_params == len([p for p in batch_decl.split(",") if p.strip()])
+    # every symbol the header declares is bound (round 6: the twelve helper symbols -- events, statistics, achip_partition_blocks ... -- included)
+    assert bound == set(re.findall(r"\b(achip_[a-z0-9_]+)\s*\(", header)), sorted(set(re.findall(r"\b(achip_[a-z0-9_]+)\s*\(", header)) ^ bound)
     declared = set(re.findall(r"\b(?:public|static|final|private|protected)\s+(?:static\s+|final\s+)*[A-Za-z<>\[\].]+\s+([A-Za-z_][A-Za-z0-9_]*)\s*(?:\(|=|;)", native))
     declared |= set(re.findall(r"\b(?:class|record|enum|interface)\s+([A-Za-z_][A-Za-z0-9_]*)", native))
     for path in glob.glob(os.path.join(ROOT, "java", "**", "*.java"), recursive=True):

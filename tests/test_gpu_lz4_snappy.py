@@ -415,9 +415,9 @@ def test_single_block_host_api_mirrors_reference_interface(o):
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
 def test_full_size_properties(gb, o, codec):
-    """BASELINE-size property check (size-independent): 4096 x 64 KiB random-fragment blocks, GPU compress ->
-    GPU decompress must be the identity, every block's stream must be the oracle's for a sampled subset,
-    and compressed sizes must match a checksum of the oracle's sizes for the sample."""
+    """Size-independent properties on 1024 x 64 KiB random-fragment blocks: GPU compress -> GPU decompress must be the identity and a
+    sampled subset of the streams must be the oracle's bytes.  (The BASELINE-size batches -- 262 144 blocks, 65 536 frames, oracle-written
+    streams, every output byte compared -- are tests/test_gpu_baseline_size.py.)"""
     rng = np.random.default_rng(2024)
     n, size = 1024, 65536
     blocks = []

@@ -411,3 +411,28 @@ def test_reader_corners_the_stream_fuzzer_found(o):
         A.ZstdHipOutputStream(sink).close()
         assert sink.getvalue() == o.zstd_stream_compress(b"")
 
+
+
+def test_reader_window_rules_are_the_java_readers(o):
+    """(1) a window descriptor above 8 MiB -- the Java reader copies the frame's RAW / RLE blocks and fails its first COMPRESSED block with
+    "Window size too large (not yet supported)" (ZstdFrameDecompressor.java:303): so does this one; (2) the same blocks behind a 1 MiB descriptor decode."""
+    import aircompressor_amd as A
+    whole = b"".join(d for _, d, _ in common.corpus_sample())
+    def block(kind, size, payload, last=0):
+        return int((size << 3) | (kind << 1) | last).to_bytes(3, "little") + payload
+    raw = whole[2000:9000]
+    magic = b"\x28\xb5\x2f\xfd"
+    big_window = b"\x00" + bytes([14 << 3])  # no single segment, no checksum, no content size; 2^(10 + 14) = 16 MiB
+    assert A.ZstdHipInputStream(io.BytesIO(magic + big_window + block(1, 70000, b"w") + block(0, len(raw), raw, 1))).read() == b"w" * 70000 + raw
+    # a compressed block of the Java encoder's (a single-segment frame with a checksum: header 4 + 1 + content-size bytes, then the blocks, then 4 bytes)
+    plain = whole[:100000]
+    f = o.compress("zstd", plain)
+    fhd = f[4]
+    assert fhd & 0x20 and fhd & 4
+    cs = fhd >> 6
+    body = f[5 + (1 if cs == 0 else 1 << cs):-4]
+    assert A.ZstdHipInputStream(io.BytesIO(magic + b"\x00" + bytes([10 << 3]) + body)).read() == plain  # 1 MiB: fine
+    s = A.ZstdHipInputStream(io.BytesIO(magic + big_window + block(0, len(raw), raw) + body))
+    with pytest.raises((A.MalformedInputException, IOError), match="Window size too large"):
+        got = s.read()
+        raise AssertionError("decoded %d bytes of a frame the Java reader refuses" % len(got))
