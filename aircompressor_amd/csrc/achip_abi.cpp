@@ -35,8 +35,8 @@ hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, in
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
-hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant, void* scratch);
-int64_t snappy_compress_scratch_bytes();
+hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant, void* scratch, bool fan);
+int64_t snappy_compress_scratch_bytes(int32_t nBlocks);
 hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant, int32_t tileMax, const ZstdMbProvider* mbp);
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
 hipError_t launch_zstd_stream_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int chunked);
@@ -106,6 +106,7 @@ struct achip_options {
     bool lastTwopass = false;   // the last decode was a two-pass one: its arena header leads the scratch
     bool lastLz4dAuto = false;  // the last LZ4 decode ran in auto mode: its probe count leads the scratch
     int maxSrcLenHint = 0;
+    int snappyFan = 1;     // snappy.compress.fan: 1 = the sub-blocks of buffers beyond 64 KiB are work units of their own (default), 0 = a buffer is one wavefront's work
     int execVariant = 2;     // two-pass decoders: 2 = the executor of achip_seqexec2.h (the only one)
     int mixConcurrent = 1;   // mixed batches: 1 = the three codec families side by side, each on a stream (and scratch) of its own -- a bucket's tail is a few long
                              // serial chains on a few CUs (a 10 MB file as ONE block: 0.4 s of one wavefront) --, 0 = every bucket in turn on the context's stream
@@ -470,10 +471,11 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
         }
         case ACHIP_OP_SNAPPY_COMPRESS: {
             if (ctx->snappycVariant >= 2) {
-                int32_t r = ensure_scratch(ctx, achip::snappy_compress_scratch_bytes());
+                int32_t r = ensure_scratch(ctx, achip::snappy_compress_scratch_bytes(a.nBlocks));
                 if (r < 0) return r;
             }
-            e = achip::launch_snappy_compress(a, ctx->stream, ctx->snappycVariant, ctx->scratch);
+            // (buffers beyond 64 KiB: their independent sub-blocks side by side -- unless the caller, or the host-pointer path that has seen the lengths, says there are none)
+            e = achip::launch_snappy_compress(a, ctx->stream, ctx->snappycVariant, ctx->scratch, ctx->snappyFan != 0 && !(ctx->maxSrcLenHint > 0 && ctx->maxSrcLenHint <= 65536));
             break;
         }
         case ACHIP_OP_ZSTD_DECOMPRESS: {
@@ -1022,6 +1024,10 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->zstdcVariant = (int)value;
     }
     else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;
+    else if (k == "snappy.compress.fan") {
+        if (value != 0 && value != 1) return bad_argument("snappy.compress.fan: 1 the independent 64 KiB sub-blocks of a buffer side by side (default), 0 in turn on one wavefront");
+        ctx->snappyFan = (int)value;
+    }
     else if (k == "decompress.exec_variant") {
         // 2: the one executor there is.  (Round 2's experiments and timing aids -- 121 .. 125, 201, 302 .. 308 -- were measured, then removed: rounds 3 and 4.)
         const bool ok = value == 2;

@@ -33,8 +33,11 @@ __device__ __forceinline__ uint64_t probe_lanes(int c)
 }
 }  // namespace snmw
 
+// subFirst / subLimit / outputAt (round 6): the buffer's independent 64 KiB sub-blocks (SnappyRawCompressor.java:93-99: the table is cleared for each, positions are
+// relative to it, no copy reaches across) from sub-block subFirst up to, not including, subLimit; outputAt < 0: the stream's start (the length preamble is written,
+// the sub-blocks follow it), otherwise the sub-blocks' bytes start at out + outputAt and no preamble is written.  The defaults are the whole buffer.
 __device__ __forceinline__ void snappy_compress_buffer_mw(uint16_t* table, const uint8_t* __restrict__ in0, int32_t inLen, uint8_t* __restrict__ out, int32_t outCap, int lane,
-                                                          int32_t& stOut, int32_t& outputOut)
+                                                          int32_t& stOut, int32_t& outputOut, int32_t subFirst = 0, int32_t subLimit = 0x7FFF, int32_t outputAt = -1)
 {
     using namespace snc;
     using namespace snmw;
@@ -47,7 +50,7 @@ __device__ __forceinline__ void snappy_compress_buffer_mw(uint16_t* table, const
         st = mk_status(ACHIP_CLASS_OUTPUT_TOO_SMALL, ACHIP_D_SNAPPY_MAX_OUTPUT);
     }
     else {
-        {
+        if (outputAt < 0) {
             uint32_t n = (uint32_t)inLen;
             int32_t nb = n < (1u << 7) ? 1 : (n < (1u << 14) ? 2 : (n < (1u << 21) ? 3 : (n < (1u << 28) ? 4 : 5)));
             if (lane == 0) {
@@ -57,7 +60,11 @@ __device__ __forceinline__ void snappy_compress_buffer_mw(uint16_t* table, const
             }
             output = nb;
         }
-        for (int64_t blockAddress = 0; blockAddress < inLen; blockAddress += BLOCK_SIZE) {
+        else {
+            output = outputAt;
+        }
+        const int64_t endAddress = (int64_t)subLimit * BLOCK_SIZE < inLen ? (int64_t)subLimit * BLOCK_SIZE : inLen;
+        for (int64_t blockAddress = (int64_t)subFirst * BLOCK_SIZE; blockAddress < endAddress; blockAddress += BLOCK_SIZE) {
             const uint8_t* __restrict__ in = in0 + blockAddress;
             const int32_t blockLimit = (int32_t)((inLen - blockAddress) < BLOCK_SIZE ? (inLen - blockAddress) : BLOCK_SIZE);
             int32_t tableSize = blockLimit <= 1 ? 0 : (int32_t)((0x80000000u >> __builtin_clz((uint32_t)(blockLimit - 1))) << 1);

@@ -241,7 +241,7 @@ def test_encoders_and_writers_on_the_cpu():
                     "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "aircompressor_amd", "csrc"),
                     "-o", os.path.join(emu_dir, "libemu_enc.so"), os.path.join(emu_dir, "emu_enc.cpp")], check=True)
     jobs = [subprocess.Popen([sys.executable, os.path.join(emu_dir, "check_enc.py"), "--quick", "--part", part], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT)
-            for part in ("block", "zstd", "stream", "containers")]  # (side by side)
+            for part in ("block", "zstd", "stream", "containers", "snappyfan")]  # (side by side)
     outs = [j.communicate()[0] for j in jobs]
     assert all(j.returncode == 0 for j in jobs), "\n".join(outs)
     assert all(o.strip().endswith("encoders under the emulator: 0 mismatches") for o in outs) and "MISMATCH" not in "".join(outs), "\n".join(outs)

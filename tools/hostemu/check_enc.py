@@ -136,6 +136,25 @@ def part_containers():
     return bad
 
 
+def part_snappyfan():
+    """Snappy buffers of several 64 KiB sub-blocks: the sub-blocks as work units of their own (snappy_compress.hip: list, encode into provisional places, fold),
+    beside buffers of one sub-block, a capacity below the bound among them; option 4 | 16 is the same encoder with the sub-blocks in turn"""
+    whole = b"".join(d for _, d, _ in common.corpus_sample())
+    rng = np.random.default_rng(19)
+    noise = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+    if quick:
+        inputs = [whole[:65537], bytes(140000), whole[:3000], (b"abcdefgh" * 9000 + noise[:3000]) * 2, noise[:65536] + whole[:2], b"", whole[:131072 - 65000] + bytes(65000) + b"z"]
+    else:
+        inputs = [whole[:65537], whole[:131072], whole[5000:5000 + 200001], bytes(300000), whole[:3000], noise + whole[:70000] + noise[:1], b"", whole[:65536]]
+    caps = [o.max_compressed_length("snappy", len(b)) for b in inputs]
+    bad = 0
+    for opt, what in ((4, "sub-blocks side by side"), (4 | 16, "sub-blocks in turn")):
+        bad += compare("snappy compress, buffers beyond 64 KiB, %s" % what, 3, opt, inputs, caps, lambda b, c: o.compress("snappy", b, c))
+    tight = [caps[0] - 1, caps[1], caps[2], caps[3] - 40]
+    bad += compare("snappy compress, buffers beyond 64 KiB, capacities below the bound", 3, 4, inputs[:4], tight, lambda b, c: o.compress("snappy", b, c))
+    return bad
+
+
 def chunked(n):
     src = b"".join(common.multi_block_plains())
     while len(src) < n:
@@ -181,7 +200,7 @@ def main():
         sys.exit(1 if ostream(sizes) else 0)
     if "--chunked" in sys.argv:
         sys.exit(1 if chunked(int(sys.argv[sys.argv.index("--chunked") + 1])) else 0)
-    parts = {"block": part_block, "zstd": part_zstd, "stream": part_stream, "containers": part_containers}
+    parts = {"block": part_block, "zstd": part_zstd, "stream": part_stream, "containers": part_containers, "snappyfan": part_snappyfan}
     only = sys.argv[sys.argv.index("--part") + 1] if "--part" in sys.argv else None
     bad = 0
     for name, fn in parts.items():

@@ -27,8 +27,9 @@ extern "C" int emu_encode(int op, const uint8_t* srcBase, const int64_t* srcOff,
         return achip::launch_lz4_compress(a, nullptr, option, maxLen);
     }
     if (op == 3) {
-        scratch.assign((size_t)achip::snappy_compress_scratch_bytes(), 0xCD);
-        return achip::launch_snappy_compress(a, nullptr, option, scratch.data());
+        scratch.assign((size_t)achip::snappy_compress_scratch_bytes(n), 0xCD);
+        achip::g_snappy_tier_workgroups = 2;  // (the persistent grid: the emulator runs its wavefronts one after the other)
+        return achip::launch_snappy_compress(a, nullptr, option & 15, scratch.data(), (option & 16) == 0);  // (option bit 4: the sub-blocks in turn, as until round 5)
     }
     if (op == 5 || op == 14) {
         if (op == 5) a.ringPad = option == 1 ? 1 : (option == 3 ? 3 : 0);  // (what achip_abi.cpp does: the one-kernel path reads the variant from the spare field)

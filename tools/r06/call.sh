@@ -47,6 +47,9 @@ r=json.loads(sys.stdin.read()); print('waves $w:', {k:(v['decompress_GiBps'], v[
         grep sequences_lane gpurun_out/prof_r06_w$w/keep/dispatches.txt | awk '{print $2}' | tr '\n' ' '; echo
         cp gpurun_out/prof_r06_w$w/keep/dispatches.txt $O/zstd_dispatches_w$w.txt
       done 2>&1 | tee $O/seqwaves.txt ;;
+    snappyfan)     # Snappy buffers beyond 64 KiB: the sub-blocks side by side -- parity (corpus manifest, encoder tests, mixed batch), then a 4 MB file per call
+      timeout 1200 python -m pytest tests/test_gpu_lz4_snappy.py tests/test_gpu_corpus.py tests/test_gpu_hadoop.py tests/test_gpu_snappy_framed.py -m gpu -x -q 2>&1 | tail -4
+      timeout 300 python tools/r06/big_snappy.py 2>&1 | grep -v amdgpu.ids | tee $O/big_snappy.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done
