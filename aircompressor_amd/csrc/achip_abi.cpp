@@ -36,6 +36,7 @@ hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream
 hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit);
 hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
 hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant, void* scratch, bool fan);
+hipError_t launch_blit(void* dst, const void* src, int64_t bytes, int workgroups, hipStream_t stream);
 int64_t snappy_compress_scratch_bytes(int32_t nBlocks);
 hipError_t launch_zstd_decompress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant, int32_t tileMax, const ZstdMbProvider* mbp);
 hipError_t launch_zstd_compress(const BatchArgs& a, hipStream_t stream, void* scratch, int64_t scratchBytes, int variant);
@@ -132,7 +133,11 @@ struct achip_ctx : achip_options {
     hipEvent_t mixUploaded = nullptr;  // the last permutation upload: the pinned buffer may be rewritten once it has completed
     // host-pointer batches (achip_batch_host / achip_mixed_batch_host): up to four staging slots, chunks pipelined over three streams, gather and
     // scatter on copy pools of their own
-    static constexpr int kHostSlots = 4;
+    static constexpr int kHostSlots = 8;
+    int hostLookMaxBlocks = 0;  // host.look_max_blocks: chunks of up to this many blocks have their first tokens looked at on the host (long sequences: the rings at 64 lanes)
+    int hostCopyLowPriority = 1;  // host.copy_priority: 1 = the pipeline's copy streams at the lowest stream priority (to be set before the first host-pointer batch)
+    int hostRamp = 1;  // host.ramp: 1 = smaller chunks at a batch's start and end (default), 0 = chunks of host.chunk_bytes throughout
+    int hostSlots = 8;  // host.slots: staging slots the host-pointer pipeline uses (2 .. kHostSlots; round 6: 8 -- with 4 the gather thread waited for a slot 20 of a call's 34 ms)
     struct CopyPool* pool = nullptr;     // gather: the caller's inputs -> pinned slot
     struct CopyPool* poolOut = nullptr;  // scatter: pinned slot -> the caller's outputs
     uint8_t* slotHost[kHostSlots] = {};  // pinned
@@ -141,10 +146,13 @@ struct achip_ctx : achip_options {
     int slotCount = 0;
     hipStream_t copyIn = nullptr, copyOut = nullptr;
     hipEvent_t evH2D[kHostSlots] = {}, evK[kHostSlots] = {}, evD2H[kHostSlots] = {};
-    int64_t hostChunkBytes = 96 << 20;   // staging bytes (inputs + output capacities) per pipeline chunk: ~1000 blocks of 64 KiB -- a chunk's kernels
+    int hostBlit = 0;          // host.blit: bit 0 = the pipeline's uploads by a copy kernel instead of hipMemcpyAsync, bit 1 = its downloads
+    int hostBlitGroups = 128;  // host.blit_groups: workgroups of that kernel
+    int64_t hostChunkBytes = 192 << 20;   // staging bytes (inputs + output capacities) per pipeline chunk: ~2000 blocks of 64 KiB -- a chunk's kernels
                                          // take a block's serial chain (~1-2 ms) however few blocks it holds, so a chunk must be worth that long on the
-                                         // link; measured (profiles/r05_hostsweep.txt): 96 MiB 36-40 GiB/s, 192 MiB 28-34, 384 MiB 30-33 (the 48 MiB of
-                                         // rounds 1-4 over two slots: 8.7)
+                                         // link.  Round 6 (profiles/r06_hostsweep.txt, r06_host_timeline.txt): with eight slots, the copy streams at the lowest
+                                         // priority and smaller chunks at both ends 192 MiB gives 40-42 GiB/s where round 5's 96 MiB over four slots gave 26-30
+                                         // on the same box (the 48 MiB of rounds 1-4 over two slots: 8.7)
     int hostCopyThreads = 0;             // per copy pool; 0 = hardware threads / 16, 2 .. 8 (4 and 8 measured best; 32 no better: the scatter is
                                          // bound by the host's memory system, not by the thread count)
     // achip_ctx_get_stat("host.*"): where the last host-pointer batch of several chunks spent its wall time (microseconds)
@@ -1023,6 +1031,30 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         if (!ok) return bad_argument("zstd.compress.variant: 3 match-finder kernel (many matches per window) + entropy kernel, 0 the same with batch probes, 1 with serial probes, 2 one kernel");
         ctx->zstdcVariant = (int)value;
     }
+    else if (k == "host.look_max_blocks") {
+        if (value < 0 || value > 65536) return bad_argument("host.look_max_blocks: 0 .. 65536");
+        ctx->hostLookMaxBlocks = (int)value;
+    }
+    else if (k == "host.copy_priority") {
+        if (value != 0 && value != 1) return bad_argument("host.copy_priority: 1 the host-pointer pipeline's copy streams at the lowest priority (default), 0 at the default priority");
+        ctx->hostCopyLowPriority = (int)value;
+    }
+    else if (k == "host.ramp") {
+        if (value != 0 && value != 1) return bad_argument("host.ramp: 1 smaller chunks at the start and the end of a host-pointer batch (default), 0 equal chunks");
+        ctx->hostRamp = (int)value;
+    }
+    else if (k == "host.slots") {
+        if (value < 2 || value > achip_ctx::kHostSlots) return bad_argument("host.slots: 2 .. 8 staging slots of the host-pointer pipeline");
+        ctx->hostSlots = (int)value;
+    }
+    else if (k == "host.blit") {
+        if (value < 0 || value > 3) return bad_argument("host.blit: bit 0 = the host-pointer pipeline's uploads by a copy kernel, bit 1 = its downloads (0 = both by hipMemcpyAsync)");
+        ctx->hostBlit = (int)value;
+    }
+    else if (k == "host.blit_groups") {
+        if (value < 1 || value > 4096) return bad_argument("host.blit_groups: 1 .. 4096 workgroups of the copy kernel");
+        ctx->hostBlitGroups = (int)value;
+    }
     else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;
     else if (k == "snappy.compress.fan") {
         if (value != 0 && value != 1) return bad_argument("snappy.compress.fan: 1 the independent 64 KiB sub-blocks of a buffer side by side (default), 0 in turn on one wavefront");
@@ -1530,8 +1562,19 @@ int32_t ensure_host_path(achip_ctx* ctx, int64_t slotBytes, int slots)
 {
     HIP_TRY(hipSetDevice(ctx->device));
     if (!ctx->copyIn) {
-        HIP_TRY(hipStreamCreateWithFlags(&ctx->copyIn, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&ctx->copyOut, hipStreamNonBlocking));
+        // The download of a chunk is a copy KERNEL of the runtime's (`__amd_rocclr_copyBuffer`: the timeline in profiles/r06_host_timeline.txt), launched wide;
+        // at the decode stream's priority the next chunk's decode kernels only got the CUs when it had drained -- a chunk's kernels took 1.7 ms beside it
+        // against 0.5 alone, and the pipeline ran at the sum of its stages.  The copy streams therefore have the LOWEST priority (host.copy_priority = 0: the default one).
+        int least = 0, greatest = 0;
+        if (ctx->hostCopyLowPriority != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+            HIP_TRY(hipStreamCreateWithPriority(&ctx->copyIn, hipStreamNonBlocking, least));
+            HIP_TRY(hipStreamCreateWithPriority(&ctx->copyOut, hipStreamNonBlocking, least));
+        }
+        else {
+            (void)hipGetLastError();
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->copyIn, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->copyOut, hipStreamNonBlocking));
+        }
         for (int s = 0; s < achip_ctx::kHostSlots; s++) {
             HIP_TRY(hipEventCreateWithFlags(&ctx->evH2D[s], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&ctx->evK[s], hipEventDisableTiming));
@@ -1675,18 +1718,35 @@ int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t
             chunks.push_back(c);
             open = false;
         };
+        // The pipeline's first stage has nothing to overlap with and neither has its last (a chunk's upload before the first kernel, the last chunk's download and
+        // scatter behind everything): the first chunks are smaller -- a quarter, half of host.chunk_bytes -- and so are the last ones (half of what is left,
+        // down to a quarter).  (round 6: 16 384 blocks of 64 KiB 25 -> ~21 ms per call)
+        int64_t totalBytes = 0;
         for (int64_t j = 0; j < n; j++) {
             const int64_t i = item(j);
             if (srcLen[i] < 0 || dstCap[i] < 0) return bad_argument("negative length");
+            totalBytes += (((int64_t)srcLen[i] + 15) & ~15LL) + (((int64_t)dstCap[i] + 15) & ~15LL);
+        }
+        const int64_t base = ctx->hostChunkBytes;
+        const bool ramp = ctx->hostRamp != 0 && totalBytes > base;
+        int64_t doneBytes = 0, limit = base;
+        for (int64_t j = 0; j < n; j++) {
+            const int64_t i = item(j);
             const int32_t o = ops ? ops[i] : op;
             const int64_t sb = ((int64_t)srcLen[i] + 15) & ~15LL, db = ((int64_t)dstCap[i] + 15) & ~15LL;
-            if (open && (o != c.op || c.srcBytes + c.dstBytes + sb + db > ctx->hostChunkBytes)) close();
+            if (open && (o != c.op || c.srcBytes + c.dstBytes + sb + db > limit)) close();
             if (!open) {
                 c = HostChunk();
                 c.first = j;
                 c.op = o;
                 open = true;
+                if (ramp) {
+                    const int64_t head = chunks.size() == 0 ? base / 4 : (chunks.size() == 1 ? base / 2 : base);
+                    const int64_t tail = std::max(base / 4, (totalBytes - doneBytes) / 2);
+                    limit = std::min(head, tail);
+                }
             }
+            doneBytes += sb + db;
             sOff[j] = c.srcBytes;
             dOff[j] = c.dstBytes;
             c.srcBytes += sb;
@@ -1696,7 +1756,7 @@ int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t
         }
         if (open) close();
     }
-    const int nSlots = (int)std::min<size_t>(chunks.size(), (size_t)achip_ctx::kHostSlots);
+    const int nSlots = (int)std::min<size_t>(chunks.size(), (size_t)ctx->hostSlots);
     int32_t r = ensure_host_path(ctx, maxSlot, nSlots);
     if (r < 0) return r;
 
@@ -1759,7 +1819,7 @@ int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t
     // passes unseen.  Looking at them too was tried: a chunk's kernels take 0.76 ms with the rings at 64 lanes against 0.92 with the two passes, but the pipeline
     // is bound by the host's copies and the link, and its rate varies 28-40 GiB/s from run to run on one box with either: nothing to gain, one more rule to explain.)
     auto look_at_tokens = [&](const HostChunk& c, const uint8_t* h) {
-        const bool few = (c.op == ACHIP_OP_LZ4_DECOMPRESS || c.op == ACHIP_OP_SNAPPY_DECOMPRESS) && c.count <= ctx->latencyMaxBlocks;
+        const bool few = (c.op == ACHIP_OP_LZ4_DECOMPRESS || c.op == ACHIP_OP_SNAPPY_DECOMPRESS) && c.count <= std::max(ctx->latencyMaxBlocks, ctx->hostLookMaxBlocks);
         if (few) {
             ctx->smallBatchHint = probe_sequences(c.op == ACHIP_OP_SNAPPY_DECOMPRESS, h + sOff[c.first], srcLen[item(c.first)]);
         }
@@ -1840,7 +1900,8 @@ int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t
     auto enqueue = [&](const HostChunk& c, int slot) -> int32_t {
         uint8_t* h = ctx->slotHost[slot];
         uint8_t* d = ctx->slotDev[slot];
-        HIP_TRY(hipMemcpyAsync(d, h, (size_t)c.inEnd, hipMemcpyHostToDevice, ctx->copyIn));
+        if ((ctx->hostBlit & 1) != 0) HIP_TRY(achip::launch_blit(d, h, c.inEnd, ctx->hostBlitGroups, ctx->copyIn));
+        else HIP_TRY(hipMemcpyAsync(d, h, (size_t)c.inEnd, hipMemcpyHostToDevice, ctx->copyIn));
         HIP_TRY(hipEventRecord(ctx->evH2D[slot], ctx->copyIn));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->evH2D[slot], 0));
         ctx->maxSrcLenHint = std::max(c.maxLen, 1);
@@ -1850,7 +1911,8 @@ int32_t host_batch(achip_ctx* ctx, int32_t op, const int32_t* ops, const int32_t
         if (rr < 0) return rr;
         HIP_TRY(hipEventRecord(ctx->evK[slot], ctx->stream));
         HIP_TRY(hipStreamWaitEvent(ctx->copyOut, ctx->evK[slot], 0));
-        HIP_TRY(hipMemcpyAsync(h + c.oErr, d + c.oErr, (size_t)(c.end - c.oErr), hipMemcpyDeviceToHost, ctx->copyOut));
+        if ((ctx->hostBlit & 2) != 0) HIP_TRY(achip::launch_blit(h + c.oErr, d + c.oErr, c.end - c.oErr, ctx->hostBlitGroups, ctx->copyOut));
+        else HIP_TRY(hipMemcpyAsync(h + c.oErr, d + c.oErr, (size_t)(c.end - c.oErr), hipMemcpyDeviceToHost, ctx->copyOut));
         HIP_TRY(hipEventRecord(ctx->evD2H[slot], ctx->copyOut));
         return 0;
     };

@@ -48,4 +48,31 @@ hipError_t launch_mix_scatter(const int32_t* perm, int32_t n, const int32_t* gOu
     return hipGetLastError();
 }
 
+// A copy by a kernel (the host-pointer pipeline, achip_abi.cpp: option host.blit): dst / src may be pinned HOST memory -- hipHostMalloc'ed slots are
+// mapped into the device's address space --, 16 bytes per lane, a KiB per wavefront and instruction.  Why not hipMemcpyAsync: the pipeline's uploads and
+// downloads, on two streams, did not overlap on the link (the times of the two directions ADDED: profiles/r06_notes.md); a copy engine one way and a kernel
+// the other do.  bytes need not be a multiple of 16; dst and src are 16-byte aligned (slot offsets are multiples of 256).
+__global__ __launch_bounds__(256) void blit_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, int64_t bytes)
+{
+    const int64_t whole = bytes >> 4;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < whole; i += stride) {
+        st16(dst + 16 * i, ld16(src + 16 * i));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(bytes & 15)) {
+        dst[16 * whole + threadIdx.x] = src[16 * whole + threadIdx.x];
+    }
+}
+
+hipError_t launch_blit(void* dst, const void* src, int64_t bytes, int workgroups, hipStream_t stream)
+{
+    if (bytes <= 0) {
+        return hipSuccess;
+    }
+    const int64_t need = ((bytes >> 4) + 255) / 256;
+    const unsigned grid = (unsigned)(need < 1 ? 1 : (need < workgroups ? need : workgroups));
+    hipLaunchKernelGGL(blit_kernel, dim3(grid), dim3(256), 0, stream, (uint8_t*)dst, (const uint8_t*)src, bytes);
+    return hipGetLastError();
+}
+
 }  // namespace achip

@@ -50,6 +50,20 @@ r=json.loads(sys.stdin.read()); print('waves $w:', {k:(v['decompress_GiBps'], v[
     snappyfan)     # Snappy buffers beyond 64 KiB: the sub-blocks side by side -- parity (corpus manifest, encoder tests, mixed batch), then a 4 MB file per call
       timeout 1200 python -m pytest tests/test_gpu_lz4_snappy.py tests/test_gpu_corpus.py tests/test_gpu_hadoop.py tests/test_gpu_snappy_framed.py -m gpu -x -q 2>&1 | tail -4
       timeout 300 python tools/r06/big_snappy.py 2>&1 | grep -v amdgpu.ids | tee $O/big_snappy.txt ;;
+    profweak)      # kernel-trace + HBM + issue counters of everything that is NOT the headline, on corpus data
+      B="python bench.py --no-cpu-baseline --no-extra --no-legs --no-host-facing --no-sweep --steps 3 --warmup 1"
+      for spec in ${SPECS:-lz4d snappyd lz4c snappyc zstdd zstdc}; do case $spec in
+        lz4d)    timeout 900 bash tools/r06/counters.sh lz4_decompress_corpus $B --workload lz4_decompress --data corpus ;;
+        snappyd) timeout 900 bash tools/r06/counters.sh snappy_decompress_corpus $B --workload snappy_decompress --data corpus ;;
+        lz4c)    timeout 900 bash tools/r06/counters.sh lz4_compress_corpus $B --workload lz4_compress --data corpus --blocks 65536 ;;
+        snappyc) timeout 900 bash tools/r06/counters.sh snappy_compress_corpus $B --workload snappy_compress --data corpus --blocks 65536 ;;
+        zstdd)   timeout 900 bash tools/r06/counters.sh zstd_decompress_corpus python tools/zstd_batch_sizes.py 65536 ;;
+        zstdc)   timeout 900 bash tools/r06/counters.sh zstd_compress_corpus python tools/r06/zstd_compress_run.py 32768 ;;
+      esac; done 2>&1 | grep -v amdgpu.ids ;;
+    hostblit)      # the host-pointer pipeline with its uploads / downloads by a copy kernel instead of hipMemcpyAsync (host.blit bits 0 / 1), three runs each
+      for spec in ${SPECS:-"host.blit=0" "host.blit=2 host.blit_groups=128" "host.blit=2 host.blit_groups=32" "host.blit=1 host.blit_groups=128" "host.blit=3 host.blit_groups=128"}; do
+        for rep in 1 2 3; do echo -n "$spec: "; timeout 300 python tools/host_path_rate.py 0 96 $spec 2>&1 | grep -v amdgpu.ids | tail -1; done
+      done | tee $O/hostblit.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done
