@@ -39,6 +39,19 @@ __device__ __forceinline__ uint64_t bits(int lo, int hi)
     const uint64_t below = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
     return upTo & ~below;
 }
+// The same for WAVE-UNIFORM lo <= hi with hi - lo <= 63 (every call site below: the masks of the replay), in one scalar instruction: `bits` compiles to a
+// dozen (two 64-bit shifts with their >= 64 cases, subtractions, selects), twice per sequence, in a kernel whose time IS its scalar instructions -- 6.0e10
+// of them against 2.1e10 vector instructions per launch on the corpus batch, one scalar unit per CU (profiles/r06_counters_lz4_compress_corpus.txt).
+__device__ __forceinline__ uint64_t sbits(int lo, int hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t m;
+    asm("s_bfm_b64 %0, %1, %2" : "=s"(m) : "s"(hi - lo), "s"(lo));
+    return m;
+#else
+    return bits(lo, hi);
+#endif
+}
 // 8 bytes starting at byte `off` (0 .. 8) of the 16 bytes (lo, hi)
 __device__ __forceinline__ uint64_t ext64(uint64_t lo, uint64_t hi, int off)
 {
@@ -222,69 +235,120 @@ __device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t
                     c4 = ld4(in + tc);
                 }
 
+                // What a match of this lane against ITS TABLE ENTRY would be, measured by every lane at once (round 6; zstd_dfast_mw.h does the same): the
+                // equal bytes behind the 4-byte hit as far as the registers go (0 .. 8: this window's bytes from lane + 4 against the 8 fetched behind the
+                // candidate) and before it (0 .. 4: lane - 4's bytes against the 4 fetched before the candidate) -- the replay below reads one packed word
+                // with one v_readlane where it used to take the 16 candidate bytes apart in scalar code, per sequence.
+                // bits 0..3 forward count, 4..6 backward count, 8 the forward count is usable (lane + 4 inside the window, 8 bytes there inside the input),
+                // 9 the backward count is usable (lane >= 4)
+                uint32_t facts = 0;
+                {
+                    const uint32_t upHi = (uint32_t)__shfl((int32_t)(uint32_t)(x >> 32), lane < 60 ? lane + 4 : lane);  // bytes [pos + 4, pos + 8) are x's upper half, [pos + 8, pos + 12) lane + 4's
+                    const uint64_t my8 = (x >> 32) | ((uint64_t)upHi << 32);                                // [pos + 4, pos + 12)
+                    const uint64_t cand8 = ext64(rLo, rHi, shift + 4);                                        // [tc + 4, tc + 12)
+                    const uint64_t dF = my8 ^ cand8;
+                    const uint32_t fwd = dF == 0 ? 8u : (uint32_t)(__builtin_ctzll(dF) >> 3);
+                    const bool fwdOk = fast && lane < 60 && pos + 12 <= inLen;
+                    const uint32_t before = (uint32_t)__shfl((int32_t)x4, lane >= 4 ? lane - 4 : lane);      // [pos - 4, pos), last byte in the top bits
+                    const uint32_t candBefore = shift == 4 ? (uint32_t)rLo : (uint32_t)((uint32_t)rLo << (8 * (4 - shift)));
+                    const uint32_t dB = before ^ candBefore;
+                    const uint32_t bwd = dB == 0 ? 4u : (uint32_t)(__builtin_clz(dB) >> 3);
+                    const bool bwdOk = fast && lane >= 4;
+                    facts = fwd | (bwd << 4) | (fwdOk ? 256u : 0u) | (bwdOk ? 512u : 0u);
+                }
+                const unsigned long long belowMe = (1ull << lane) - 1ull;
+                const unsigned long long sameBelow = same & belowMe;
+
                 unsigned long long M = 1ull;     // inserted lanes
                 int c = mode == 0 ? 1 : 3;      // first lane of the search that follows
                 int r = mode == 0 ? -1 : 2;     // lane of a pending re-probe (the position right behind a match), -1: none
                 bool blockDone = false;          // the search ran off the end, or a match ended beyond matchFindLimit
                 bool searchGoesOn = false;       // the window is used up in the middle of a search
                 for (;;) {
-                    int wl = -1;                 // lane where the match starts
-                    int32_t cand = 0;            // its candidate's position
-                    int jl = -1;                 // ... as a lane of this window (-1: the table's entry)
-                    bool zeroLit = false;
+                    // ONE step finds the next match (round 6): the immediate re-probe :171-176 at lane r -- the position right behind a match, the table as the
+                    // replay has left it -- is the first probing lane of the search :113-138 over the lanes behind it; its test is the search lanes' test (the
+                    // same 4 bytes, the same distance rule), a hit there is the match without literals.  Until round 6 the re-probe was a block of scalar
+                    // code of its own, ~65 scalar instructions per sequence in a kernel bound by its scalar instructions.
+                    // (Its position is at most matchFindLimit -- the check behind the match before it -- so it always probes; a search lane needs its
+                    // successor inside the limit: canProbe.)
+                    const int p0 = r >= 0 ? r : c;  // the first probing lane
                     if (r >= 0) {
-                        // the immediate re-probe :171-176 at lane r: the table as the replay has left it
-                        const unsigned long long elig = rl64(same, r) & M & bits(0, r);
-                        jl = elig != 0 ? 63 - __builtin_clzll(elig) : -1;
-                        const uint32_t xr = rl32(x4, r);
-                        const uint32_t cr = jl >= 0 ? rl32(x4, jl) : rl32(c4, r);
-                        cand = jl >= 0 ? base + jl : (int32_t)rl32((uint32_t)tc, r);
-                        const bool hit = cr == xr && (jl >= 0 || cand + MAX_DISTANCE >= base + r);
-                        M |= 1ull << r;
-                        if (hit) {
-                            wl = r;
-                            zeroLit = true;
-                        }
-                        else {
-                            c = r + 1;
-                        }
-                        r = -1;
+                        c = r + 1;                  // where the search proper starts (its probe 0: the skip schedule counts from here if it runs through the window)
                     }
-                    if (wl < 0) {
-                        // the search :113-138 over lanes c .. 63 at once: a lane sees the inserts of the replay so far and of the search lanes before it
-                        const unsigned long long elig = same & (M | bits(c, lane)) & bits(0, lane);
-                        const int j = elig != 0 ? 63 - __builtin_clzll(elig) : -1;
-                        const uint32_t cv = __shfl(x4, j >= 0 ? j : lane);
-                        const uint32_t cmp = j >= 0 ? cv : c4;
-                        const int32_t cp = j >= 0 ? base + j : tc;
-                        const bool probing = lane >= c;
-                        const bool hit = probing && canProbe && cmp == x4 && (j >= 0 || cp + MAX_DISTANCE >= pos);
-                        const unsigned long long hm = __ballot(hit);
-                        const unsigned long long im = __ballot(probing && !canProbe);
-                        const unsigned long long first = hm | im;
-                        if (first == 0) {
-                            M |= bits(c, 64);
-                            searchGoesOn = true;
-                            break;
-                        }
-                        const int w = __builtin_ctzll(first);
-                        if (((im >> w) & 1ull) != 0) {  // the probe at lane w would step beyond matchFindLimit: the block ends in literals
-                            M |= bits(c, w);
-                            blockDone = true;
-                            break;
-                        }
-                        M |= bits(c, w + 1);
-                        wl = w;
-                        cand = (int32_t)rl32((uint32_t)cp, w);
-                        jl = (int)rl32((uint32_t)j, w);
+                    // a lane sees the inserts of the replay so far and of the probing lanes before it
+                    const unsigned long long elig = sameBelow & (M | ~sbits(0, p0));  // (= same & (M | bits(p0, lane)) & bits(0, lane))
+                    const int j = elig != 0 ? 63 - __builtin_clzll(elig) : -1;
+                    const uint32_t cv = __shfl(x4, j >= 0 ? j : lane);
+                    const uint32_t cmp = j >= 0 ? cv : c4;
+                    const int32_t cp = j >= 0 ? base + j : tc;
+                    const bool probing = lane >= p0;
+                    const bool mayProbe = canProbe || lane == r;
+                    const bool hit = probing && mayProbe && cmp == x4 && (j >= 0 || cp + MAX_DISTANCE >= pos);
+                    const unsigned long long hm = __ballot(hit);
+                    const unsigned long long im = __ballot(probing && !mayProbe);
+                    const unsigned long long first = hm | im;
+                    if (first == 0) {
+                        M |= sbits(p0, 64);
+                        searchGoesOn = true;
+                        break;
                     }
+                    const int w = __builtin_ctzll(first);
+                    if (((im >> w) & 1ull) != 0) {  // the probe at lane w would step beyond matchFindLimit: the block ends in literals
+                        M |= sbits(p0, w);
+                        blockDone = true;
+                        break;
+                    }
+                    M |= sbits(p0, w + 1);
+                    const int wl = w;                                    // lane where the match starts
+                    int32_t cand = (int32_t)rl32((uint32_t)cp, w);      // its candidate's position
+                    const int jl = (int)rl32((uint32_t)j, w);           // ... as a lane of this window (-1: the table's entry)
+                    const bool zeroLit = w == r;
+                    r = -1;
                     // ---- a match starts at lane wl against `cand` (lane jl of the window, or the table's entry of lane wl) ----
                     input = base + wl;
-                    const bool winFast = jl >= 0 || rl32((uint32_t)fast, wl) != 0;
-                    const int shiftW = (int)rl32((uint32_t)shift, wl);
-                    const uint64_t rLoW = rl64(rLo, wl), rHiW = rl64(rHi, wl);
+                    // the table's entry as the candidate (the common case): what this lane measured before the replay began, one lane read
+                    const uint32_t factsW = jl < 0 ? rl32(facts, wl) : 0u;
+                    const bool quick = jl < 0 && (factsW & 768u) == 768u;  // both counts usable (which includes `fast`)
                     int32_t back = 0;
-                    if (!zeroLit) {  // catch up :141-144
+                    int32_t matchLength = -1;
+                    if (quick) {
+                        bool slow = false;
+                        if (!zeroLit) {  // catch up :141-144
+                            const int32_t room = input - anchor < cand ? input - anchor : cand;
+                            if (room > 0) {
+                                const int32_t t = (int32_t)((factsW >> 4) & 7u);
+                                back = t < room ? t : room;
+                                slow = back == 4 && room > 4;  // more than 4 bytes match backwards: the general way below goes to memory for the rest
+                            }
+                        }
+                        if (!slow) {
+                            // count :240-267: `back` bytes of the 4-byte hit itself lie behind the new start + 4, then what was measured behind the hit
+                            const int32_t a0 = input - back + MIN_MATCH, b0 = cand - back + MIN_MATCH;
+                            const int32_t limitLen = matchLimit - a0;
+                            const int32_t fwd = (int32_t)(factsW & 15u);
+                            const int32_t known = back + fwd;
+                            if (fwd < 8 || known >= limitLen) {
+                                matchLength = known < limitLen ? known : limitLen;
+                            }
+                            else {
+                                matchLength = known + wave_count(in, a0 + known, b0 + known, matchLimit, lane);
+                            }
+                            input -= back;
+                            cand -= back;
+                        }
+                        else {
+                            back = 0;
+                        }
+                    }
+                    const bool general = matchLength < 0;
+                    const bool winFast = general && (jl >= 0 || rl32((uint32_t)fast, wl) != 0);
+                    const int shiftW = general ? (int)rl32((uint32_t)shift, wl) : 0;
+                    uint64_t rLoW = 0, rHiW = 0;
+                    if (general) {
+                        rLoW = rl64(rLo, wl);
+                        rHiW = rl64(rHi, wl);
+                    }
+                    if (general && !zeroLit) {  // catch up :141-144
                         int32_t room = input - anchor < cand ? input - anchor : cand;
                         bool slow = !winFast;
                         if (room > 0 && !slow) {
@@ -348,8 +412,7 @@ __device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t
                         output = litPos + literalLength;
                     }
                     // count :240-267 from input + 4 against cand + 4: the first 8 bytes from registers
-                    int32_t matchLength;
-                    {
+                    if (general) {
                         const int32_t a0 = input + MIN_MATCH, b0 = cand + MIN_MATCH;
                         const int32_t limitLen = matchLimit - a0;  // (>= 4: input <= matchFindLimit - 1)
                         const int la = a0 - base;

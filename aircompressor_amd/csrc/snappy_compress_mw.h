@@ -20,6 +20,17 @@ __device__ __forceinline__ uint64_t bits(int lo, int hi)
     const uint64_t below = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
     return upTo & ~below;
 }
+// bits [lo, hi) for WAVE-UNIFORM lo <= hi with hi - lo <= 63, in one scalar instruction (lz4_compress_mw.h: these encoders' time is their scalar instructions)
+__device__ __forceinline__ uint64_t sbits(int lo, int hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t m;
+    asm("s_bfm_b64 %0, %1, %2" : "=s"(m) : "s"(hi - lo), "s"(lo));
+    return m;
+#else
+    return bits(lo, hi);
+#endif
+}
 // the lanes of a window that a search starting at lane c probes: c .. c + 32 (its first 33 probes advance by one), then every second lane
 __device__ __forceinline__ uint64_t probe_lanes(int c)
 {
@@ -191,7 +202,7 @@ __device__ __forceinline__ void snappy_compress_buffer_mw(uint16_t* table, const
                         bool viaReprobe = false;
                         if (r >= 0) {
                             // :207-219 the table lookup at `input` and its insert; the copy loop goes on while the 4 bytes match
-                            const unsigned long long elig = rl64(same, r) & M & bits(0, r);
+                            const unsigned long long elig = rl64(same, r) & M & sbits(0, r);
                             jl = elig != 0 ? 63 - __builtin_clzll(elig) : -1;
                             const uint32_t xr = rl32(x4, r);
                             const uint32_t cr = jl >= 0 ? rl32(x4, jl) : rl32(c4, r);
@@ -231,11 +242,11 @@ __device__ __forceinline__ void snappy_compress_buffer_mw(uint16_t* table, const
                             }
                             const int w = __builtin_ctzll(first);
                             if (((im >> w) & 1ull) != 0) {  // the loop condition of :141 fails at lane w: the block ends in a literal
-                                M |= probes & bits(c, w);
+                                M |= probes & sbits(c, w);
                                 blockDone = true;
                                 break;
                             }
-                            M |= probes & bits(c, w + 1);
+                            M |= probes & sbits(c, w + 1);
                             wl = w;
                             cand = (int32_t)rl32((uint32_t)cp, w);
                             jl = (int)rl32((uint32_t)j, w);

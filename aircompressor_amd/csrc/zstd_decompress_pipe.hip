@@ -1058,10 +1058,6 @@ __global__ __launch_bounds__(256) void zstd_pipe_sequences_lane_kernel(BatchArgs
         settle(tabML);
         // ZstdFrameDecompressor.java:388-486, straight-line: an irregular stream sets `bad` and keeps decoding
         // harmless garbage (every index is masked) until the count runs out
-#if defined(ACHIP_K3_PROBE)
-        const uint64_t probeT0 = __builtin_readcyclecounter();
-        int32_t probeSteps = 0, probeRefill2 = 0;
-#endif
         while (__ballot(sequenceCount > 0) != 0) {  // (uniform)
             const bool act = sequenceCount > 0;  // this lane's item has a sequence to decode in this step
             sequenceCount -= act ? 1 : 0;
@@ -1085,10 +1081,6 @@ __global__ __launch_bounds__(256) void zstd_pipe_sequences_lane_kernel(BatchArgs
             have -= xsum;
             rem -= xsum;
             bad |= act && rem < 0 && !over;  // the extra bits ran past the stream's start
-#if defined(ACHIP_K3_PROBE)
-            probeSteps++;
-            probeRefill2 += __ballot(xsum > 64 - 7 - (9 + 9 + 8)) != 0 ? 1 : 0;
-#endif
             if (xsum > 64 - 7 - (9 + 9 + 8)) {
                 refill();
             }
@@ -1132,13 +1124,6 @@ __global__ __launch_bounds__(256) void zstd_pipe_sequences_lane_kernel(BatchArgs
             rec[at] = lastRecord;
             nDecoded += produce ? 1 : 0;
         }
-#if defined(ACHIP_K3_PROBE)
-        if (lane == 0) {
-            atomicAdd(p.fallbackCount + 32 + 4, probeSteps);
-            atomicAdd(p.fallbackCount + 32 + 5, probeRefill2);
-            atomicAdd(p.fallbackCount + 32 + 6, (int32_t)((__builtin_readcyclecounter() - probeT0) >> 10));
-        }
-#endif
     }
     if (live) {
         if (bad) {

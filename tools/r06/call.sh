@@ -64,6 +64,13 @@ r=json.loads(sys.stdin.read()); print('waves $w:', {k:(v['decompress_GiBps'], v[
       for spec in ${SPECS:-"host.blit=0" "host.blit=2 host.blit_groups=128" "host.blit=2 host.blit_groups=32" "host.blit=1 host.blit_groups=128" "host.blit=3 host.blit_groups=128"}; do
         for rep in 1 2 3; do echo -n "$spec: "; timeout 300 python tools/host_path_rate.py 0 96 $spec 2>&1 | grep -v amdgpu.ids | tail -1; done
       done | tee $O/hostblit.txt ;;
+    enctests)      # the LZ4 / Snappy encoders: parity tests (oracle bytes, manifest hashes, containers) + GPU fuzz
+      timeout 1200 python -m pytest tests/test_gpu_lz4_snappy.py tests/test_gpu_corpus.py tests/test_gpu_hadoop.py tests/test_gpu_snappy_framed.py tests/test_gpu_lz4_frame.py -m gpu -x -q 2>&1 | tail -4
+      timeout 900 python tools/fuzz_encoders.py ${N:-3000} 91 ${CODECS:-lz4 snappy} 2>&1 | tail -8 | tee $O/fuzz_encoders.txt ;;
+    encrate)       # LZ4 / Snappy compress on the corpus batch: GiB/s as bench.py reports it
+      for wl in ${WLS:-lz4_compress snappy_compress}; do for data in corpus fragments; do
+        timeout 600 python bench.py --no-cpu-baseline --no-extra --no-legs --no-host-facing --no-sweep --steps 3 --warmup 1 --workload $wl --data $data --blocks 65536 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$wl $data', r['value'], 'GiB/s', r['roofline'].get('kernel_ms_avg'))"
+      done; done | tee $O/encrate_${TAG:-a}.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done
