@@ -61,6 +61,7 @@ def parse_args():
     p.add_argument("--mixed-copies", type=int, default=4, help="copies of the 668-line corpus job in the configs[4] leg")
     p.add_argument("--section", default="all", choices=["all", "zstd", "zstdstream", "xxhash", "lz4frame", "sweep"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-exec", type=int, default=-1, help="zstd pipeline execute stage: 2 = chosen per item (default), 1 = wavefront per item through the record executor, 0 = LDS rings")
+    p.add_argument("--zstd-kinds", default="fragments,wordmix,corpus", help="data kinds of the zstd section (development aid: tools/make_traffic_json.py measures one kind per run)")
     p.add_argument("--zstd-seq-waves", type=int, default=0, help="zstd pipeline sequence stage: wavefronts per workgroup (1, 2, 4; 0 = library default)")
     p.add_argument("--snappyframed-variant", type=int, default=-1, help="x-snappy-framed reader: 3 = ring or two-pass decoder by a probe (default), 1 = chunks through the ring decoders, 2 = through the two-pass decoder, 0 = a wavefront per stream")
     p.add_argument("--lz4frame-variant", type=int, default=-1, help="LZ4 frame reader: 2 = by a probe (default), 0 = a wavefront per item, 1 = the frames' blocks as one batch through the two-pass block decoder")
@@ -823,6 +824,27 @@ def main():
         except ImportError:
             pass
         result["extra"] = ex
+        # the same `roofline` object for the real-data entries: algorithmic bytes over the launch's time, and the HBM bytes the
+        # launch's kernels moved by the counters -- profiles/traffic.json, only where it was measured on these kernel sources and this batch size
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        except Exception:
+            tj = {}
+        for key, units, unit_bytes in (("lz4_corpus", "blocks", args.block_size), ("snappy_corpus", "blocks", args.block_size), ("zstd_corpus", "frames", 131072)):
+            e = ex.get(key)
+            if not e:
+                continue
+            n_units = e[units]
+            alg = int(n_units * unit_bytes * (1.0 + 1.0 / e["ratio"])) + 20 * n_units
+            seconds = n_units * unit_bytes / (e["decompress_GiBps"] * 2**30)
+            roof = {"bound": "hbm", "achieved": round(alg / seconds / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / seconds / 1e9 / HBM_PEAK_GBS, 4),
+                    "traffic": None, "algorithmic_bytes_per_launch": alg}
+            t = tj.get(key)
+            if t and t.get("units") == n_units and t.get("kernel_sources_sha256") == kernel_sources_hash():
+                roof["traffic"] = t["hbm_bytes_per_launch"]
+                roof["traffic_per_kernel"] = t.get("per_kernel")
+                roof["traffic_source"] = t.get("source")
+            e["roofline"] = roof
         # the real-data and Zstd numbers next to `value` (same unit; the headline stays BASELINE configs[1] on synthetic blocks)
         result["value_corpus"] = ex["lz4_corpus"]["decompress_GiBps"]            # LZ4 decompress, corpus-tiled 64 KiB blocks (SURVEY 8d C2 primary)
         result["value_corpus_hbm_frac"] = ex["lz4_corpus"]["decompress_hbm_frac"]
@@ -1164,7 +1186,7 @@ def zstd_extra(torch, A, codec, dev, args):
     if args.zstd_compress_variant >= 0:
         codec.native.set_option("zstd.compress.variant", args.zstd_compress_variant)
     zc = pa.Codec("zstd", compression_level=3)
-    for data_kind in ("fragments", "wordmix", "corpus"):
+    for data_kind in [k for k in ("fragments", "wordmix", "corpus") if k in args.zstd_kinds.split(",")]:
         plain = gen_data(torch, dev, data_kind, pool_n, fs, args.ratio, 4242)
         host = plain.cpu().numpy()
         frames = [zc.compress(host[i * fs:(i + 1) * fs].tobytes(), asbytes=True) for i in range(pool_n)]

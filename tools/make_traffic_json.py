@@ -49,5 +49,42 @@ for wl in ("lz4_decompress", "snappy_decompress"):  # (both headline kernels sin
         "source": "tools/make_traffic_json.py: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --no-extra --steps 3`; FETCH_SIZE doubled (gfx950, "
                   "calibrated: profiles/r03_notes.md), WRITE_SIZE as counted (calibrated exact)",
     }
+
+
+def launch_traffic(key, bench_args, keep, units_key):
+    """the real-data launches (round 6): every kernel of ONE decode launch -- the two passes' parse and execute, the Zstd pipeline's stages -- summed:
+    average FETCH_SIZE x 2 + WRITE_SIZE per dispatch of each kernel whose name `keep` accepts (each runs once per launch)"""
+    per = collections.defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+    line = None
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(ROOT, "gpurun_out", "traffic_" + ctr)
+        shutil.rmtree(d, ignore_errors=True)
+        env = dict(os.environ, TMPDIR="/tmp")
+        p = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "--pmc", ctr, "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                            "--no-cpu-baseline", "--no-legs", "--no-host-facing", "--no-sweep", "--steps", "3", "--warmup", "1"] + bench_args, capture_output=True, text=True, cwd=ROOT, env=env)
+        for l in p.stdout.splitlines():
+            if l.startswith("{"):
+                line = json.loads(l)
+        acc = collections.defaultdict(list)
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                name = r["Kernel_Name"].split("(")[0].replace("achip::", "").replace("void ", "")
+                if r.get("Counter_Name") == ctr and keep(name):
+                    acc[name].append((int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0), float(r["Counter_Value"])))
+        for name, v in acc.items():
+            top = max(g for g, _ in v)  # (a run may hold smaller launches of the same kernels -- the Zstd section decodes 32 768 of the GPU encoder's frames too: the largest grid is the batch)
+            vals = [c for g, c in v if g == top]
+            per[name][ctr] = sum(vals) / len(vals) * 1024
+        shutil.rmtree(d, ignore_errors=True)
+    per_kernel = {k: int(v["FETCH_SIZE"] * 2 + v["WRITE_SIZE"]) for k, v in per.items() if v["FETCH_SIZE"] * 2 + v["WRITE_SIZE"] >= 1e6}
+    units = line[units_key[0]][units_key[1]] if isinstance(units_key, tuple) else line["config"]["blocks_per_gpu"]
+    result[key] = {"units": units, "hbm_bytes_per_launch": sum(per_kernel.values()), "per_kernel": per_kernel, "kernel_sources_sha256": bench.kernel_sources_hash(),
+                   "source": "tools/make_traffic_json.py: the launch's kernels summed (FETCH_SIZE x 2 + WRITE_SIZE per dispatch, separate rocprofv3 --pmc passes over `bench.py " + " ".join(bench_args) + "`)"}
+
+
+decode = lambda n: "decompress" not in n and ("parse" in n or "execute" in n or "rings" in n or "sample" in n or "mixed_groups" in n or "handover" in n)  # noqa: E731
+launch_traffic("lz4_corpus", ["--no-extra", "--workload", "lz4_decompress", "--data", "corpus"], lambda n: decode(n) or "lz4_decompress" in n, None)
+launch_traffic("snappy_corpus", ["--no-extra", "--workload", "snappy_decompress", "--data", "corpus"], lambda n: decode(n) or "snappy_decompress" in n, None)
+launch_traffic("zstd_corpus", ["--section", "zstd", "--zstd-kinds", "corpus"], lambda n: n.startswith("zstd_pipe") or n.startswith("zstd_mb") or n.startswith("zstd_decompress") or n.startswith("zstd_default"), ("zstd_corpus", "frames"))
 json.dump(result, open(out, "w"), indent=1)
 print(json.dumps(result))
