@@ -58,6 +58,7 @@ def parse_args():
     p.add_argument("--no-host-facing", action="store_true", help="skip the end_to_end (host buffers, PCIe-inclusive) and single_block_us measurements")
     p.add_argument("--no-legs", action="store_true", help="skip the per-rank legs (Snappy, Zstd configs[3], mixed corpus batch configs[4]) that run at any N")
     p.add_argument("--zstd-frames", type=int, default=65536, help="Zstd frames of 128 KiB per GPU in the configs[3] leg (a multiple of 1024)")
+    p.add_argument("--no-mixed-large", action="store_true", help="skip the second mixed-batch measurement at 8 x --mixed-copies (N = 1 only)")
     p.add_argument("--mixed-copies", type=int, default=4, help="copies of the 668-line corpus job in the configs[4] leg")
     p.add_argument("--section", default="all", choices=["all", "zstd", "zstdstream", "xxhash", "lz4frame", "sweep"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
     p.add_argument("--zstd-exec", type=int, default=-1, help="zstd pipeline execute stage: 2 = chosen per item (default), 1 = wavefront per item through the record executor, 0 = LDS rings")
@@ -802,6 +803,20 @@ def main():
         result["legs"] = legs
         result["value_mixed"] = legs["mixed"]["GiBps"]
         result["mixed_ok"] = legs["mixed"]["mixed_ok"]
+        if world == 1 and not args.no_mixed_large:
+            # the same job eight times over in one call (round 6): a mixed batch is as long as its longest serial chain -- a 4 MB file as ONE Zstd frame or
+            # ONE LZ4 block is 0.4-0.7 s of a single wavefront --, so its rate is a matter of how much work lies beside that chain; both are in the line
+            copies = args.mixed_copies
+            try:
+                args.mixed_copies = 8 * copies
+                big = mixed_leg(torch, A, codec, dev, args, rank, world, dist)
+                result["value_mixed_8x_batch"] = big["GiBps"]
+                result["mixed_8x_batch"] = {"copies": big["copies"], "items": big["items"], "mixed_ok": big["mixed_ok"], "seconds": big["per_rank"][0]["seconds"],
+                                            "what": "the configs[4] job with 8 x --mixed-copies: same longest chain, eight times the items beside it"}
+            except Exception as e:  # (a secondary entry must not take the run's line with it)
+                result["mixed_8x_batch"] = {"error": repr(e)}
+            finally:
+                args.mixed_copies = copies
         if world > 1:
             result["value_snappy"] = legs["snappy"]["GiBps"]                        # Snappy decompress, the headline's batch shape
             if "zstd" in legs:
