@@ -199,7 +199,7 @@ def test_batch_host_hundreds_of_ragged_blocks(gb, o, codec):
         plain.append(blob[pos:pos + n])
         pos += n
     cop, dop = OPS[codec]
-    for chunk in (1 << 20, 96 << 20):
+    for chunk in (1 << 20, 192 << 20):
         gb.set_option("host.chunk_bytes", chunk)
         outs, status, _ = gb.run_host(cop, plain, [o.max_compressed_length(codec, len(b)) for b in plain])
         for b, c, s in zip(plain, outs, status):
@@ -218,7 +218,38 @@ def test_batch_host_hundreds_of_ragged_blocks(gb, o, codec):
                 assert (s, err[k] if s else 0) == expect, (k, s, err[k], expect)
             else:
                 assert s == 0 and p == b, (k, s)
-    gb.set_option("host.chunk_bytes", 96 << 20)
+    gb.set_option("host.chunk_bytes", 192 << 20)
+
+
+def test_host_pipeline_options_change_no_byte(o):
+    """The knobs of the host-pointer pipeline (round 6: host.slots, host.ramp -- smaller chunks at a batch's ends --, host.blit -- uploads / downloads by a copy kernel of
+    the library's own --, host.copy_priority, host.look_max_blocks) over a batch of many chunks: outputs, statuses and error offsets are those of the default settings."""
+    from tests.gpu_harness import GpuBatch
+    import aircompressor_amd as A
+    corpus = common.corpus_full()
+    blob = b"".join(corpus[f] for f in sorted(corpus))
+    rng = np.random.default_rng(21)
+    plain = []
+    pos = 0
+    while pos < len(blob) and len(plain) < 500:
+        n = int(rng.choice([7, 300, 4096, 20000, 65536, 70000]))
+        plain.append(blob[pos:pos + n])
+        pos += n
+    comp = [o.compress("lz4", b) for b in plain]
+    comp[11] = comp[11][:len(comp[11]) // 2]  # (a damaged item among them)
+    caps = [len(b) for b in plain]
+    want = None
+    for options in ({}, {"host.slots": 2}, {"host.ramp": 0}, {"host.blit": 1, "host.blit_groups": 8}, {"host.blit": 2}, {"host.blit": 3, "host.slots": 3}, {"host.copy_priority": 0},
+                    {"host.look_max_blocks": 4095}):
+        g = GpuBatch(0, options=dict({"host.chunk_bytes": 1 << 20}, **options))
+        got = g.run_host(A.OP_LZ4_DECOMPRESS, comp, caps)
+        assert g.codec.native.get_stat("host.chunks") > 8
+        if want is None:
+            want = got
+            assert all(s == 0 and p == b for k, (b, p, s) in enumerate(zip(plain, got[0], got[1])) if k != 11) and got[1][11] != 0
+        else:
+            assert got == want, options
+        g.codec.native.close()
 
 
 def test_two_contexts_two_threads(o):
