@@ -58,6 +58,7 @@ def parse_args():
     p.add_argument("--no-host-facing", action="store_true", help="skip the end_to_end (host buffers, PCIe-inclusive) and single_block_us measurements")
     p.add_argument("--no-legs", action="store_true", help="skip the per-rank legs (Snappy, Zstd configs[3], mixed corpus batch configs[4]) that run at any N")
     p.add_argument("--zstd-frames", type=int, default=65536, help="Zstd frames of 128 KiB per GPU in the configs[3] leg (a multiple of 1024)")
+    p.add_argument("--option", action="append", default=[], help="development aid: a context option as name=value (repeatable), set on the bench's context before anything runs")
     p.add_argument("--no-mixed-large", action="store_true", help="skip the second mixed-batch measurement at 8 x --mixed-copies (N = 1 only)")
     p.add_argument("--mixed-copies", type=int, default=4, help="copies of the 668-line corpus job in the configs[4] leg")
     p.add_argument("--section", default="all", choices=["all", "zstd", "zstdstream", "xxhash", "lz4frame", "sweep"], help="zstd: run only the Zstd extra section and print its JSON (development aid)")
@@ -585,6 +586,9 @@ def main():
     n_local = hi - lo
 
     codec = A.HipBatchCodec(local_rank)
+    for kv in args.option:
+        k_, v_ = kv.split("=")
+        codec.native.set_option(k_, int(v_))
     lib = codec.lib
     if args.group:
         codec.native.set_option("lz4.decompress.group", args.group)

@@ -182,6 +182,7 @@ def test_auto_mode_picks_a_decoder_on_the_device(gb, o, codec):
     sprinkled = (text * 4)[:8] + (frag * 16)[:56]  # an eighth of the blocks short: stays with the rings
     gb.set_option("%s.decompress.variant" % codec, 5)
     gb.set_option("lz4.decompress.auto_min_blocks", 32)  # (one threshold for both codecs)
+    gb.set_option("decompress.auto_reprobe", 1)  # (every call probes: the batches below have one shape and different data)
     try:
         for blocks, expect_mixed, expect_choice in ((uniform, False, 3), (mixed, True, 3), (longcopies, False, 0), (halves, False, 3), (sprinkled, False, 0), (mixed[:16], None, -1)):
             comp = [o.compress(codec, b) for b in blocks]
@@ -197,7 +198,55 @@ def test_auto_mode_picks_a_decoder_on_the_device(gb, o, codec):
                 assert gb.codec.native.get_stat("decompress.twopass_fallback_blocks") == 0
     finally:
         gb.set_option("lz4.decompress.auto_min_blocks", 4096)
+        gb.set_option("decompress.auto_reprobe", 16)
         configure(gb, codec, DECODERS[0])
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy"])
+def test_auto_mode_remembers_its_choice_and_probes_again(o, codec):
+    """decompress.auto_reprobe (round 6): a probed call's statistics come home behind its kernels; while the batches keep their shape (codec, count, buffers) the chosen decoder
+    runs alone, and every n-th call probes again -- so a context whose data changes character follows within n calls.  Whatever runs, the bytes are the reference's."""
+    import torch
+    from tests.gpu_harness import GpuBatch
+    import aircompressor_amd as A
+    g = GpuBatch(0, options={"lz4.decompress.auto_min_blocks": 32, "decompress.auto_reprobe": 4})
+    text = [d for _, d, _ in common.corpus_sample()][:2]
+    rng = np.random.default_rng(5)
+    frag = [np.tile(rng.integers(0, 256, size=(656, 50), dtype=np.uint8), (1, 2)).reshape(-1)[:65536].tobytes() for _ in range(4)]
+    n, bs = 64, 65536
+    kinds = {"text": (text * 32)[:n], "long": (frag * 16)[:n]}
+    comp = {k: [o.compress(codec, b) for b in v] for k, v in kinds.items()}
+    cap = max(len(c) for v in comp.values() for c in v) + 15 & ~15
+    dev = g.dev
+    d_src = torch.zeros(n * cap, dtype=torch.uint8, device=dev)   # ONE pair of buffers for every call: the shape the memory keys on
+    d_dst = torch.zeros(n * bs + 64, dtype=torch.uint8, device=dev)
+    a_so = torch.arange(n, dtype=torch.int64, device=dev) * cap
+    a_do = torch.arange(n, dtype=torch.int64, device=dev) * bs
+    a_dc = torch.full((n,), bs, dtype=torch.int32, device=dev)
+    o_len, st, eo = torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int64, device=dev)
+    op = A.OP_LZ4_DECOMPRESS if codec == "lz4" else A.OP_SNAPPY_DECOMPRESS
+
+    def call(kind):
+        host = np.zeros(n * cap, dtype=np.uint8)
+        for i, c in enumerate(comp[kind]):
+            host[i * cap:i * cap + len(c)] = np.frombuffer(c, dtype=np.uint8)
+        d_src.copy_(torch.from_numpy(host))
+        a_sl = torch.tensor([len(c) for c in comp[kind]], dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        g.codec.launch(op, d_src, a_so, a_sl, d_dst, a_do, a_dc, o_len, st, eo, n)
+        g.codec.synchronize()
+        assert int(st.abs().sum().item()) == 0
+        assert d_dst[:n * bs].cpu().numpy().tobytes() == b"".join(kinds[kind])
+        return g.codec.native.get_stat("decompress.choice"), g.codec.native.get_stat("lz4.decompress.mixed_groups")
+
+    assert call("text") == (3, 0)                       # probed: the two passes
+    seen = [call("text") for _ in range(3)]
+    assert seen == [(3, -1)] * 3, seen                  # remembered: the two passes alone (no probe ran: mixed_groups -1)
+    assert call("text")[1] == 0                         # the fourth call since the probe probes again
+    # the data changes character under the same shape: at most `auto_reprobe` calls later the rings run
+    choices = [call("long")[0] for _ in range(6)]
+    assert choices[0] == 3 and choices[-1] == 0 and 0 in choices[:5], choices
+    g.codec.native.close()
 
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
