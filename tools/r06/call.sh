@@ -71,6 +71,38 @@ r=json.loads(sys.stdin.read()); print('waves $w:', {k:(v['decompress_GiBps'], v[
       for wl in ${WLS:-lz4_compress snappy_compress}; do for data in corpus fragments; do
         timeout 600 python bench.py --no-cpu-baseline --no-extra --no-legs --no-host-facing --no-sweep --steps 3 --warmup 1 --workload $wl --data $data --blocks 65536 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$wl $data', r['value'], 'GiB/s', r['roofline'].get('kernel_ms_avg'))"
       done; done | tee $O/encrate_${TAG:-a}.txt ;;
+    final)         # the pass that ships: suite, smoke, traffic.json, bench.py as the driver runs it, rocprofv3 summaries of both headline kernels, Zstd per-dispatch times, --gpus 2 on one device
+      F=$O/final; rm -rf $F; mkdir -p $F
+      timeout 1800 python -m pytest tests -m gpu -x -q > $F/pytest.log 2>&1; tail -2 $F/pytest.log
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+      timeout 1500 python tools/make_traffic_json.py $F/traffic.json > $F/traffic.log 2>&1; tail -1 $F/traffic.log | cut -c1-600; cp $F/traffic.json profiles/traffic.json  # (first: the bench line reports it only for the sources it was taken on)
+      S=$(date +%s); timeout 1500 python bench.py > $F/bench_final.json 2> $F/bench_final.err; echo "bench.py wall: $(( $(date +%s) - S )) s" | tee -a $F/bench_final.err
+      python - <<'PY'
+import json
+r = json.loads([l for l in open("gpurun_out/r06/final/bench_final.json") if l.startswith("{")][-1])
+print("value", r["value"], "frac", r["roofline"]["frac"], "traffic", r["roofline"]["traffic"], "cpu", r["cpu_baseline"]["value"])
+for k in sorted(r):
+    if k.startswith("value_") or k in ("mixed_ok", "end_to_end", "single_block_us", "mixed_8x_batch"):
+        print(k, r[k] if not isinstance(r[k], dict) else {a: b for a, b in r[k].items() if a != "what"})
+for k in ("lz4_corpus", "snappy_corpus", "zstd_corpus"):
+    print(k, {a: b for a, b in r["extra"][k].get("roofline", {}).items() if a not in ("traffic_source", "traffic_per_kernel")})
+PY
+      timeout 700 bash tools/profile.sh r06final_lz4 --steps 5 --warmup 2 --no-legs --no-host-facing > $F/profile_lz4_summary.txt 2>&1
+      cp gpurun_out/prof_r06final_lz4/keep/*kernel_stats.csv $F/lz4_kernel_stats.csv 2>/dev/null
+      timeout 700 bash tools/profile.sh r06final_snappy --steps 5 --warmup 2 --no-legs --no-host-facing --workload snappy_decompress > $F/profile_snappy_summary.txt 2>&1
+      cp gpurun_out/prof_r06final_snappy/keep/*kernel_stats.csv $F/snappy_kernel_stats.csv 2>/dev/null
+      timeout 500 bash tools/profile_zstd.sh r06finalz --no-cpu-baseline > $F/zstd_line.txt 2>&1
+      cp gpurun_out/prof_r06finalz/keep/dispatches.txt $F/zstd_dispatches.txt; cp gpurun_out/prof_r06finalz/keep/*kernel_stats.csv $F/zstd_kernel_stats.csv
+      ACHIP_BENCH_SHARE_DEVICE=1 timeout 900 python bench.py --gpus 2 --blocks 65536 --steps 3 --warmup 1 --no-extra --no-cpu-baseline > $F/n2.json 2> $F/n2.err; grep -c '^{' $F/n2.json
+      ;;
+    spread)        # run-to-run spread of the headline line on one box
+      for i in 1 2 3 4 5 6 7 8 9; do timeout 300 python bench.py --no-cpu-baseline --no-extra --no-legs --no-host-facing 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('run $i', r['value'], r['roofline']['frac'], r['roofline']['kernel_ms_avg'])"; done | tee $O/headline_spread.txt ;;
+    sizesweep)     # the default decoders against the batch size, final library
+      for w in lz4_decompress snappy_decompress; do for data in fragments corpus; do for n in 1024 4096 16384 65536 262144; do
+        timeout 300 python bench.py --workload $w --data $data --blocks $n --pool 512 --no-extra --no-legs --no-host-facing --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$w $data %7d x 64 KiB: %8.1f GiB/s  %8.3f ms' % ($n, r['value'], r['ms_per_step']))"
+      done; done; done 2>&1 | tee $O/sizesweep.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done
