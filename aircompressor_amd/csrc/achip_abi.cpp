@@ -106,11 +106,14 @@ struct achip_options {
     bool lastAutoIsLz4 = false;
     bool lastTwopass = false;   // the last decode was a two-pass one: its arena header leads the scratch
     bool lastLz4dAuto = false;  // the last LZ4 decode ran in auto mode: its probe count leads the scratch
-    // Auto mode remembers (round 6): a probed call's statistics come back to pinned memory behind its kernels, without a wait; while the batches that follow have
-    // its shape (codec, block count, the same source and destination buffers) the decoder it chose runs alone -- no probes, no second decoder launched to return
-    // at once: ~107 us of a 8.2 ms headline call, more where calls are short -- and every `autoReprobe`-th call probes again.  Either decoder decodes ANY
-    // batch to the reference's bytes: what a stale choice can cost is speed, never a result.  (decompress.auto_reprobe = 1: every call probes, as until round 5.)
-    int autoReprobe = 16;
+    // Auto mode remembers (round 6): a call's probe statistics come back to pinned memory behind its kernels, without a wait; while the batches that follow have its
+    // shape (codec, block count, the same source and destination buffers) the decoder the LAST ARRIVED statistics chose is the only one launched -- the other
+    // decoder's kernels, launched to return at once, were ~65 us of a 8.2 ms headline call.  The probes still run in every call and go home, so a context whose
+    // data changes character under one shape runs the wrong (slower, never incorrect: either decoder decodes any batch to the reference's bytes) decoder for as
+    // many calls as it takes the first new statistics to arrive: one, for a caller that waits for its results.  (A first version probed one call in sixteen
+    // and ran the rest blind: bench.py's own extras -- fragments, then text, same shape, same buffers -- decoded text on the rings for a whole measurement, 148
+    // against 377 GiB/s.)  decompress.auto_remember = 0: both decoders are launched in every call, as until round 5.
+    int autoRemember = 1;
     int32_t* autoPinned = nullptr;     // 8 words: the probe statistics of the call in flight
     hipEvent_t autoEv = nullptr;
     bool autoInFlight = false;
@@ -122,7 +125,6 @@ struct achip_options {
     int32_t autoBlocks[2] = {0, 0};
     const void* autoSrc[2] = {nullptr, nullptr};
     const void* autoDst[2] = {nullptr, nullptr};
-    int autoUses[2] = {0, 0};
     int lastRemembered = -1;           // the last decode ran on a remembered choice: that choice (decompress.choice reports it)
     int maxSrcLenHint = 0;
     int snappyFan = 1;     // snappy.compress.fan: 1 = the sub-blocks of buffers beyond 64 KiB are work units of their own (default), 0 = a buffer is one wavefront's work
@@ -248,8 +250,8 @@ int64_t few_blocks_record_bytes(int32_t nBlocks, int64_t perBlock)
     return std::max<int64_t>(perBlock, ((1LL << 30) / nBlocks) & ~4095LL);
 }
 
-// Auto mode's memory (achip_ctx::autoReprobe).  auto_remembered: the decoder to run alone for this batch (0 rings, 3 two passes), or -1: probe.  First takes in what
-// the last probed call sent home, if it has arrived (an event query, never a wait).
+// Auto mode's memory (achip_ctx::autoRemember).  auto_remembered: the decoder to launch alone for this batch (0 rings, 3 two passes), or -1: launch both.  First takes
+// in what an earlier call sent home, if it has arrived (an event query, never a wait).
 int auto_remembered(achip_ctx* ctx, int fam, const achip::BatchArgs& a)
 {
     if (ctx->autoInFlight && hipEventQuery(ctx->autoEv) == hipSuccess) {
@@ -262,29 +264,26 @@ int auto_remembered(achip_ctx* ctx, int fam, const achip::BatchArgs& a)
         ctx->autoBlocks[pf] = ctx->autoPendingBlocks;
         ctx->autoSrc[pf] = ctx->autoPendingSrc;
         ctx->autoDst[pf] = ctx->autoPendingDst;
-        ctx->autoUses[pf] = 0;
         ctx->autoInFlight = false;
     }
     else if (ctx->autoInFlight) {
         (void)hipGetLastError();  // (hipErrorNotReady is not an error)
     }
-    if (ctx->autoReprobe <= 1 || ctx->autoChoice[fam] < 0 || a.nBlocksDev != nullptr || a.only != nullptr) return -1;
+    if (ctx->autoRemember == 0 || ctx->autoChoice[fam] < 0 || a.nBlocksDev != nullptr || a.only != nullptr) return -1;
     if (ctx->autoBlocks[fam] != a.nBlocks || ctx->autoSrc[fam] != (const void*)a.srcBase || ctx->autoDst[fam] != (const void*)a.dstBase) return -1;
-    if (ctx->autoUses[fam] >= ctx->autoReprobe - 1) return -1;
-    ctx->autoUses[fam]++;
     ctx->lastRemembered = ctx->autoChoice[fam];
     return ctx->autoChoice[fam];
 }
-// behind a probed call's kernels: its statistics on their way to pinned memory (nothing waits for them)
+// behind a call's kernels: its probe statistics on their way to pinned memory (nothing waits for them; one set in flight at a time)
 void auto_send_home(achip_ctx* ctx, int fam, const achip::BatchArgs& a, const int32_t* stats)
 {
-    if (ctx->autoReprobe <= 1 || ctx->autoInFlight || a.nBlocksDev != nullptr || a.only != nullptr) return;
+    if (ctx->autoRemember == 0 || ctx->autoInFlight || a.nBlocksDev != nullptr || a.only != nullptr) return;
     if (!ctx->autoPinned) {
         if (hipHostMalloc((void**)&ctx->autoPinned, 64, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&ctx->autoEv, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             if (ctx->autoPinned) (void)hipHostFree(ctx->autoPinned);
             ctx->autoPinned = nullptr;
-            ctx->autoReprobe = 1;  // (no memory for it: every call probes)
+            ctx->autoRemember = 0;  // (no memory for it: both decoders in every call)
             return;
         }
     }
@@ -297,8 +296,6 @@ void auto_send_home(achip_ctx* ctx, int fam, const achip::BatchArgs& a, const in
     ctx->autoPendingBlocks = a.nBlocks;
     ctx->autoPendingSrc = a.srcBase;
     ctx->autoPendingDst = a.dstBase;
-    // (until these arrive the family's last choice stays in force for batches of ITS shape -- the host may be many calls ahead of the device -- and counts anew)
-    ctx->autoUses[fam] = 0;
 }
 
 int32_t ensure_twopass_scratch(achip_ctx* ctx, int64_t lead, int32_t nBlocks, int64_t perBlock, int64_t perBlockMin)
@@ -473,27 +470,18 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 int32_t* stats = (int32_t*)ctx->scratch;
                 ctx->lastZstddBlocks = 0;
                 const int remembered = auto_remembered(ctx, 0, a);
-                if (remembered == 0) {
-                    e = achip::launch_lz4_decompress_rings(a, ctx->stream, lz4Group, ctx->ringClass, nullptr);
-                    break;
-                }
-                if (remembered == 3) {
-                    ctx->lastTwopass = true;
-                    ctx->lastLz4dAuto = true;  // (the scratch layout of auto mode: decompress.twopass_fallback_blocks reads behind the probe words)
-                    ctx->lastAutoBlocks = a.nBlocks;
-                    ctx->lastAutoIsLz4 = true;
-                    e = achip::launch_lz4_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, lz4Group, ctx->ringClass, ctx->execVariant, nullptr);
-                    break;
-                }
                 ctx->lastLz4dAuto = true;
                 ctx->lastAutoBlocks = a.nBlocks;
                 ctx->lastAutoIsLz4 = true;
                 e = achip::launch_lz4_mixed_groups(a, ctx->stream, stats, 0);
                 if (e == hipSuccess) e = hipMemsetAsync(stats + 3, 1, 1, ctx->stream);  // stats[3] = 1: the two-pass scheme (achip_device.h lz4_pick)
                 if (e == hipSuccess) e = achip::launch_lz4_sequence_sample(a, ctx->stream, stats, 0, 12);
-                if (e == hipSuccess) e = achip::launch_lz4_decompress_rings(a, ctx->stream, lz4Group, ctx->ringClass, stats);
-                ctx->lastTwopass = true;
-                if (e == hipSuccess) e = achip::launch_lz4_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, lz4Group, ctx->ringClass, ctx->execVariant, stats);
+                // (remembered: that decoder alone and whatever this call's probes say -- they are for the calls to come)
+                if (e == hipSuccess && remembered != 3) e = achip::launch_lz4_decompress_rings(a, ctx->stream, lz4Group, ctx->ringClass, remembered == 0 ? nullptr : stats);
+                if (remembered != 0) {
+                    ctx->lastTwopass = true;
+                    if (e == hipSuccess) e = achip::launch_lz4_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, lz4Group, ctx->ringClass, ctx->execVariant, remembered == 3 ? nullptr : stats);
+                }
                 if (e == hipSuccess) auto_send_home(ctx, 0, a, stats);
                 break;
             }
@@ -535,27 +523,17 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
                 int32_t* stats = (int32_t*)ctx->scratch;
                 ctx->lastZstddBlocks = 0;
                 const int remembered = auto_remembered(ctx, 1, a);
-                if (remembered == 0) {
-                    e = achip::launch_snappy_decompress_rings(a, ctx->stream, snappyGroup, ctx->ringClass, nullptr);
-                    break;
-                }
-                if (remembered == 3) {
-                    ctx->lastTwopass = true;
-                    ctx->lastLz4dAuto = true;
-                    ctx->lastAutoBlocks = a.nBlocks;
-                    ctx->lastAutoIsLz4 = false;
-                    e = achip::launch_snappy_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, snappyGroup, ctx->ringClass, ctx->execVariant, nullptr);
-                    break;
-                }
                 ctx->lastLz4dAuto = true;
                 ctx->lastAutoBlocks = a.nBlocks;
                 ctx->lastAutoIsLz4 = false;
                 e = achip::launch_lz4_mixed_groups(a, ctx->stream, stats, 0);
                 if (e == hipSuccess) e = hipMemsetAsync(stats + 3, 1, 1, ctx->stream);
                 if (e == hipSuccess) e = achip::launch_snappy_element_sample(a, ctx->stream, stats, 0, 6);
-                if (e == hipSuccess) e = achip::launch_snappy_decompress_rings(a, ctx->stream, snappyGroup, ctx->ringClass, stats);
-                ctx->lastTwopass = true;
-                if (e == hipSuccess) e = achip::launch_snappy_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, snappyGroup, ctx->ringClass, ctx->execVariant, stats);
+                if (e == hipSuccess && remembered != 3) e = achip::launch_snappy_decompress_rings(a, ctx->stream, snappyGroup, ctx->ringClass, remembered == 0 ? nullptr : stats);
+                if (remembered != 0) {
+                    ctx->lastTwopass = true;
+                    if (e == hipSuccess) e = achip::launch_snappy_decompress_twopass(a, ctx->stream, (uint8_t*)ctx->scratch + 4096, ctx->scratchBytes - 4096, snappyGroup, ctx->ringClass, ctx->execVariant, remembered == 3 ? nullptr : stats);
+                }
                 if (e == hipSuccess) auto_send_home(ctx, 1, a, stats);
                 break;
             }
@@ -1141,9 +1119,9 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         if (value != 0 && value != 1) return bad_argument("host.copy_priority: 1 the host-pointer pipeline's copy streams at the lowest priority (default), 0 at the default priority");
         ctx->hostCopyLowPriority = (int)value;
     }
-    else if (k == "decompress.auto_reprobe") {
-        if (value < 1 || value > 65536) return bad_argument("decompress.auto_reprobe: 1 (every auto-mode call probes) .. 65536 (one call in that many probes while the batches keep their shape)");
-        ctx->autoReprobe = (int)value;
+    else if (k == "decompress.auto_remember") {
+        if (value != 0 && value != 1) return bad_argument("decompress.auto_remember: 1 auto mode launches only the decoder the last arrived probe statistics chose for batches of that shape (default), 0 both decoders in every call");
+        ctx->autoRemember = (int)value;
         ctx->autoChoice[0] = ctx->autoChoice[1] = -1;
     }
     else if (k == "host.ramp") {
@@ -1191,7 +1169,7 @@ int64_t achip_ctx_get_stat(achip_ctx* ctx, const char* name)
     if (!ctx || !name) return -1;
     std::string k(name);
     if (k == "lz4.decompress.mixed_groups") {  // auto mode's probe result of the last LZ4 decode (-1: it did not run)
-        if (!ctx->lastLz4dAuto || ctx->scratch == nullptr || ctx->lastRemembered >= 0) return -1;
+        if (!ctx->lastLz4dAuto || ctx->scratch == nullptr) return -1;
         if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
         int32_t v = 0;
         if (hipMemcpy(&v, ctx->scratch, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;

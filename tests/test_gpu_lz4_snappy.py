@@ -182,7 +182,7 @@ def test_auto_mode_picks_a_decoder_on_the_device(gb, o, codec):
     sprinkled = (text * 4)[:8] + (frag * 16)[:56]  # an eighth of the blocks short: stays with the rings
     gb.set_option("%s.decompress.variant" % codec, 5)
     gb.set_option("lz4.decompress.auto_min_blocks", 32)  # (one threshold for both codecs)
-    gb.set_option("decompress.auto_reprobe", 1)  # (every call probes: the batches below have one shape and different data)
+    gb.set_option("decompress.auto_remember", 0)  # (both decoders in every call, the probes of THIS call pick: the batches below have one shape and different data)
     try:
         for blocks, expect_mixed, expect_choice in ((uniform, False, 3), (mixed, True, 3), (longcopies, False, 0), (halves, False, 3), (sprinkled, False, 0), (mixed[:16], None, -1)):
             comp = [o.compress(codec, b) for b in blocks]
@@ -198,25 +198,26 @@ def test_auto_mode_picks_a_decoder_on_the_device(gb, o, codec):
                 assert gb.codec.native.get_stat("decompress.twopass_fallback_blocks") == 0
     finally:
         gb.set_option("lz4.decompress.auto_min_blocks", 4096)
-        gb.set_option("decompress.auto_reprobe", 16)
+        gb.set_option("decompress.auto_remember", 1)
         configure(gb, codec, DECODERS[0])
 
 
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
-def test_auto_mode_remembers_its_choice_and_probes_again(o, codec):
-    """decompress.auto_reprobe (round 6): a probed call's statistics come home behind its kernels; while the batches keep their shape (codec, count, buffers) the chosen decoder
-    runs alone, and every n-th call probes again -- so a context whose data changes character follows within n calls.  Whatever runs, the bytes are the reference's."""
+def test_auto_mode_remembers_its_choice(o, codec):
+    """decompress.auto_remember (round 6): a call's probe statistics come home behind its kernels; while the batches keep their shape (codec, count, buffers) only the decoder
+    the last arrived statistics chose is launched -- the probes still run in every call, so a context whose data changes character follows one call later (for a caller
+    that waits for its results).  Whatever runs, the bytes are the reference's."""
     import torch
     from tests.gpu_harness import GpuBatch
     import aircompressor_amd as A
-    g = GpuBatch(0, options={"lz4.decompress.auto_min_blocks": 32, "decompress.auto_reprobe": 4})
+    g = GpuBatch(0, options={"lz4.decompress.auto_min_blocks": 32})
     text = [d for _, d, _ in common.corpus_sample()][:2]
     rng = np.random.default_rng(5)
     frag = [np.tile(rng.integers(0, 256, size=(656, 50), dtype=np.uint8), (1, 2)).reshape(-1)[:65536].tobytes() for _ in range(4)]
     n, bs = 64, 65536
     kinds = {"text": (text * 32)[:n], "long": (frag * 16)[:n]}
     comp = {k: [o.compress(codec, b) for b in v] for k, v in kinds.items()}
-    cap = max(len(c) for v in comp.values() for c in v) + 15 & ~15
+    cap = (max(len(c) for v in comp.values() for c in v) + 15) & ~15
     dev = g.dev
     d_src = torch.zeros(n * cap, dtype=torch.uint8, device=dev)   # ONE pair of buffers for every call: the shape the memory keys on
     d_dst = torch.zeros(n * bs + 64, dtype=torch.uint8, device=dev)
@@ -232,20 +233,20 @@ def test_auto_mode_remembers_its_choice_and_probes_again(o, codec):
             host[i * cap:i * cap + len(c)] = np.frombuffer(c, dtype=np.uint8)
         d_src.copy_(torch.from_numpy(host))
         a_sl = torch.tensor([len(c) for c in comp[kind]], dtype=torch.int32, device=dev)
+        d_dst.zero_()
         torch.cuda.synchronize()
         g.codec.launch(op, d_src, a_so, a_sl, d_dst, a_do, a_dc, o_len, st, eo, n)
         g.codec.synchronize()
         assert int(st.abs().sum().item()) == 0
         assert d_dst[:n * bs].cpu().numpy().tobytes() == b"".join(kinds[kind])
-        return g.codec.native.get_stat("decompress.choice"), g.codec.native.get_stat("lz4.decompress.mixed_groups")
+        return g.codec.native.get_stat("decompress.choice")
 
-    assert call("text") == (3, 0)                       # probed: the two passes
-    seen = [call("text") for _ in range(3)]
-    assert seen == [(3, -1)] * 3, seen                  # remembered: the two passes alone (no probe ran: mixed_groups -1)
-    assert call("text")[1] == 0                         # the fourth call since the probe probes again
-    # the data changes character under the same shape: at most `auto_reprobe` calls later the rings run
-    choices = [call("long")[0] for _ in range(6)]
-    assert choices[0] == 3 and choices[-1] == 0 and 0 in choices[:5], choices
+    assert [call("text") for _ in range(3)] == [3, 3, 3]      # probed, then remembered: the two passes
+    # the data changes character under the same shape: ONE call on the remembered decoder (its probes go home), then the rings
+    assert [call("long") for _ in range(4)] == [3, 0, 0, 0]
+    assert [call("text") for _ in range(3)] == [0, 3, 3]
+    g.set_option("decompress.auto_remember", 0)                # both decoders launched, this call's probes pick
+    assert [call("long"), call("text"), call("long")] == [0, 3, 0]
     g.codec.native.close()
 
 
