@@ -982,10 +982,11 @@ __global__ __launch_bounds__(256) void zstd_pipe_sequences_lane_kernel(BatchArgs
     // shift.  This reads exactly the bits BitInputStream.peekBits reads as long as a step stays inside the Java container -- which it does
     // for every stream that is not sent to the fallback list below: offset codes above 24 are (7 + 24 + 16 + 16 bits fit a container).
     // `rem` counts the stream's bits not yet consumed: Loader.load() reports overflow exactly when it is negative at a step's start
-    // (bitsConsumed > 64 is only possible with the container at the stream's first byte), and a step whose EXTRA bits run past the stream's
-    // start -- where the Java code reads whatever its wrapped shifts give -- is handed to the fallback list rather than imitated.
+    // (bitsConsumed > 64 is only possible with the container at the stream's first byte).  A step whose EXTRA bits run past the stream's start
+    // reads what the Java code reads there (round 6, below): zeros behind the stream's last real bits, and from bit 64 on the container's own
+    // top bits again -- its shifts wrap.
     bool bad = false;
-    uint64_t w = 0, nextWord = 0;
+    uint64_t w = 0, nextWord = 0, startWord = 0;
     int32_t have = 0, ptr = 8, rem = 0;
     int32_t sStart = 8;  // (a lane without work: "the stream" is empty and ends at byte 8 of a source that has at least a frame and a block header)
     if (live) {
@@ -1011,6 +1012,9 @@ __global__ __launch_bounds__(256) void zstd_pipe_sequences_lane_kernel(BatchArgs
             w = bits << (consumed & 63);
             have = 64 - consumed;
             rem = 8 * size - c0;
+            // the Java reader's container once it sits at the stream's start (BitInputStream.Loader.load :176-204: `bits = getLong(startAddress)`; a stream
+            // shorter than 8 bytes: what readTail :39-59 built) -- only read where a sequence's extra bits run past the stream's start (below)
+            startWord = size >= 8 ? ld8(src + sStart) : bits;
         }
     }
     nextWord = ld8(src + ptr - 8);
@@ -1071,16 +1075,40 @@ __global__ __launch_bounds__(256) void zstd_pipe_sequences_lane_kernel(BatchArgs
             const int32_t xLL = (int32_t)(tl >> 24), xML = (int32_t)(tm >> 24), xOF = cOF & 31;
             // codes beyond the tables are only reachable through a table the Java reader would also have rejected or mis-indexed; offset
             // codes above 24 give offsets no window allows (checked below) and extra-bit counts the shortcut above does not cover
-            bad |= act && (cLL > 35 || cML > 52 || cOF > 24);
+            // (only where the Java loop decodes the sequence at all: at an overflow it leaves before it reads a code -- an item with nothing left to decode is not
+            // irregular for the garbage this loop computes in that step.  Until round 6 these checks ran in every step: such items went to the fallback list, and
+            // the incremental reader, which has none, refused streams the reference reads: tools/fuzz_zstd_tail.py)
+            bad |= act && !over && (cLL > 35 || cML > 52 || cOF > 24);
             // extra bits are read in the order offset, match length, literal length
-            const int32_t vOF = (cOF < 2 ? cOF : (1 << xOF) - 3) + field(0, xOF);
-            const int32_t matchLength = (int32_t)(tm & 0xFFFFFF) + field(xOF, xML);
-            const int32_t literalsLength = (int32_t)(tl & 0xFFFFFF) + field(xOF + xML, xLL);
+            int32_t vOF = (cOF < 2 ? cOF : (1 << xOF) - 3) + field(0, xOF);
+            int32_t matchLength = (int32_t)(tm & 0xFFFFFF) + field(xOF, xML);
+            int32_t literalsLength = (int32_t)(tl & 0xFFFFFF) + field(xOF + xML, xLL);
             const int32_t xsum = xLL + xML + xOF;
             w <<= (xsum & 63);
             have -= xsum;
             rem -= xsum;
-            bad |= act && rem < 0 && !over;  // the extra bits ran past the stream's start
+            // The extra bits ran past the stream's start: a corrupt stream's last sequence or two.  The Java reader does not notice here -- its next load() reports
+            // the overflow, and with no sequence left to decode that is not an error (:395-399) -- so the sequence it executes is made of what peekBits returns:
+            // at that point its container sits at the stream's start (every other position of Loader.load leaves more than 56 bits in it, more than three extra
+            // fields take), so a field at container bit q reads `((C << (q & 63)) >>> 1) >>> (63 - n)`: real bits, then zeros, and from q = 64 on C's top bits again.
+            // (Until round 6 such an item went to the fallback list; the incremental reader has none and refused a stream the reference reads:
+            // tools/fuzz_zstd_stream.py, profiles/r06_notes.md.)
+            // (The block-slot instantiation -- frames of several blocks and the incremental reader's steps, which have no other decoder behind them -- reads them; the
+            // single-block instantiation, whose step this check and its merge made 3.6 % longer on the corpus batch, keeps handing such items to the one-kernel
+            // decoder, which reads the same bits its own way.)
+            const bool overrun = act && !over && rem < 0;
+            if (!MB) {
+                bad |= overrun;
+            }
+            else if (__ballot(overrun) != 0) {  // (uniform, rare)
+                if (overrun) {
+                    const int32_t q0 = 64 - (rem + xsum);  // Java's bitsConsumed at the step's start: 64 - the stream's remaining bits (in 8 .. 64 here)
+                    auto peek = [&](int32_t q, int32_t n) -> int32_t { return n == 0 ? 0 : (int32_t)(((startWord << (q & 63)) >> 1) >> ((63 - n) & 63)); };
+                    vOF = (cOF < 2 ? cOF : (1 << xOF) - 3) + peek(q0, xOF);
+                    matchLength = (int32_t)(tm & 0xFFFFFF) + peek(q0 + xOF, xML);
+                    literalsLength = (int32_t)(tl & 0xFFFFFF) + peek(q0 + xOF + xML, xLL);
+                }
+            }
             if (xsum > 64 - 7 - (9 + 9 + 8)) {
                 refill();
             }
@@ -1099,7 +1127,9 @@ __global__ __launch_bounds__(256) void zstd_pipe_sequences_lane_kernel(BatchArgs
                 have -= nbsum;
                 rem -= nbsum;
             }
-            // repeat-offset history, :419-452
+            // repeat-offset history, :419-452.  (Round 6 moved it into a kernel of its own -- a lane per item on every SIMD, the records rewritten in place -- to shorten
+            // this loop: the loop lost 14 % of its instructions and 4 % of its time (28.3 -> 27.0 ms), the new kernel took 12.6 ms: a lane's serial walk over records
+            // in memory is a memory round trip a step.  Back here: profiles/r06_notes.md.)
             const int32_t raw = vOF + ((cOF <= 1 && cLL == 0) ? 1 : 0);
             const bool rep = cOF <= 1;
             // (a sentinel's low bits count the "- 1" steps: at most one per sequence, fewer than 2^16)
@@ -1115,7 +1145,7 @@ __global__ __launch_bounds__(256) void zstd_pipe_sequences_lane_kernel(BatchArgs
             p0 = shift1 ? offset : p0;
             // an offset beyond 2^24 cannot be a valid back-reference (the window is at most 2^23); keeps the record fields in range and
             // the sentinels apart from real offsets
-            bad |= act && (offset <= 0 || (offset > (1 << 24) && !(MB && rep && offset >= sx2::REP_SENTINEL)));
+            bad |= produce && (offset <= 0 || (offset > (1 << 24) && !(MB && rep && offset >= sx2::REP_SENTINEL)));
             // 8 bytes per lane and step, straight to the arena (the L2 merges a line's pieces; staging 16 records per lane in LDS and storing lines --
             // what the quad version did -- measured no faster), UNCONDITIONALLY: a lane that has no record in this step stores its last one again
             const uint64_t record = (uint64_t)(uint32_t)literalsLength | ((uint64_t)(uint32_t)matchLength << 18) | ((uint64_t)(uint32_t)(offset & 0xFFFFFFF) << 36);

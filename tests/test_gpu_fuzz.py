@@ -16,6 +16,14 @@ def test_zstd_and_container_decoders_agree_with_the_oracle_on_mutated_streams():
     assert fuzz_decoders.run(1500, 12, ("zstd", "lz4frame", "snappyframed")) == 0
 
 
+def test_zstd_sequence_streams_damaged_at_their_end_decode_as_the_reference_decodes_them():
+    """tools/fuzz_zstd_tail.py, a short run (round 6): frames damaged where their sequence bit streams are read LAST.  A sequence whose extra bits run past the stream's
+    start is executed by the Java reader from what its wrapped shifts return -- the pipeline's sequence stage now reads the same bits (it used to hand such items to the
+    one-kernel decoder, and the incremental reader, which has none behind it, refused a stream the reference reads: found by tools/fuzz_zstd_stream.py)."""
+    from tools import fuzz_zstd_tail
+    assert fuzz_zstd_tail.run(768, 14) == 0
+
+
 def test_encoders_are_byte_identical_with_the_oracle_on_inputs_of_many_shapes():
     from tools import fuzz_encoders
     assert fuzz_encoders.run(400, 13) == 0

@@ -68,6 +68,7 @@ def reference(stream, cap):
 zc = [pa.Codec("zstd", compression_level=l) for l in (1, 3, 9)]
 bad = 0
 fails = 0
+deviations = 0
 for case in range(n_read):
     frames, plain = [], b""
     for _ in range(int(rng.integers(1, 4))):
@@ -86,7 +87,9 @@ for case in range(n_read):
         z = z[:int(rng.integers(0, len(z)))]
     elif m == 4:
         z += bytes(rng.integers(0, 256, int(rng.integers(1, 12)), dtype=np.uint8))
-    r, want = reference(z, len(plain) + (1 << 20))
+    cap = len(plain) + (2 << 20)
+    r, want = reference(z, cap)
+    truncated = r == cap + 1  # (a mutated size field: the stream decodes to more than this harness lets the reference write -- what it delivered is a prefix)
     got = bytearray()
     failed = False
     size = int(rng.choice([7, 1000, 65536, 77777, 1 << 20, 3 << 20]))
@@ -106,11 +109,28 @@ for case in range(n_read):
         failed = True
     fails += 1 if r < 0 else 0
     ok = (r >= 0 and not failed and bytes(got) == want) or (r < 0 and failed and bytes(got[:len(want)]) == want)
+    if not ok and truncated and bytes(got[:len(want)]) == want:
+        ok = True  # (both decode beyond the harness' cap: this reader's "runaway" guard stopped it behind the reference's last byte)
+    if not ok and r < 0 and not failed and bytes(got[:len(want)]) == want:
+        # The documented deviation: a RAW / RLE block that says more than 128 KiB.  ZstdIncrementalFrameDecompressor.java:204-226 copies / fills what
+        # the block says IF its window buffer happens to have the room (its resize :291-340 only guarantees 128 KiB: "window buffer is too small" otherwise -- which
+        # depends on how the caller has been reading); the one-shot ZstdFrameDecompressor decodes such a frame, and so does this reader.  Counted, not a mismatch,
+        # where the ONE-SHOT Java decoder (the oracle's restatement) reads the stream to exactly this reader's bytes.
+        try:
+            if o.decompress("zstd", bytes(z), len(got) + 16) == bytes(got):
+                deviations += 1
+                ok = True
+        except oracle_lib.OracleError:
+            pass
     if not ok:
         bad += 1
         if bad <= 8:
             print("MISMATCH reader case %d: mutation %d, %d stream bytes, reference r=%d delivered %d | this reader failed=%s delivered %d" % (case, m, len(z), r, len(want), failed, len(got)), flush=True)
-print("reader: %d streams (%d the reference refuses), %d mismatches" % (n_read, fails, bad), flush=True)
+            if os.environ.get("ACHIP_FUZZ_DUMP"):  # (keep the stream for a closer look)
+                os.makedirs(os.environ["ACHIP_FUZZ_DUMP"], exist_ok=True)
+                open(os.path.join(os.environ["ACHIP_FUZZ_DUMP"], "stream_case_%d.zst" % case), "wb").write(bytes(z))
+print("reader: %d streams (%d the reference refuses, %d of them for an oversized RAW / RLE block that the one-shot reference decoder and this reader decode alike), %d mismatches" % (
+    n_read, fails, deviations, bad), flush=True)
 
 wbad = 0
 for case in range(n_write):
