@@ -1669,9 +1669,11 @@ int32_t ensure_host_path(achip_ctx* ctx, int64_t slotBytes, int slots)
     }
     if (!ctx->pool) {
         // gather and scatter have a pool each (they run side by side): host.copy_threads threads each, by default a sixteenth of the host's
-        // hardware threads, 2 .. 8 (the calling thread / the finalizer thread is one of each pool's copiers)
+        // hardware threads, 2 .. 16 (the calling thread / the finalizer thread is one of each pool's copiers).  (Round 6: 16 where it was 8 -- on boxes whose
+        // host copies are slow, two NUMA nodes and the process on the far one, the scatter IS the call: 8 threads 31-34 GiB/s, 16 threads 33-40; on the
+        // others 8 and 16 are alike: profiles/r06_notes.md)
         int t = ctx->hostCopyThreads;
-        if (t == 0) t = (int)std::min<unsigned>(8u, std::max(2u, std::thread::hardware_concurrency() / 16));
+        if (t == 0) t = (int)std::min<unsigned>(16u, std::max(2u, std::thread::hardware_concurrency() / 16));
         ctx->pool = new CopyPool(t - 1);
         ctx->poolOut = new CopyPool(t - 1);
     }
