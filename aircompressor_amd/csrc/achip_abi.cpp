@@ -53,6 +53,7 @@ hipError_t launch_hadoop_compress(const BatchArgs& a, hipStream_t stream, void* 
 int64_t hadoop_compress_scratch_bytes(int32_t nStreams);
 extern int g_zstd_pipe_exec;
 extern int g_zstd_seq_waves;
+extern int g_zstd_lit_items;
 int64_t zstd_ostream_state_bytes();
 int64_t zstd_ostream_slab_bytes();
 hipError_t launch_zstd_ostream_step(hipStream_t stream, void* state, void* slab, const uint8_t* buf, int32_t offset, int32_t chunk, int32_t closing, uint8_t* out, int32_t outCap);
@@ -1084,6 +1085,10 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         if (value != 1 && value != 2 && value != 4) return bad_argument("zstd.decompress.seq_waves: wavefronts per workgroup of the pipeline's sequence stage: 1, 2 or 4 (64 items a workgroup either way)");
         achip::g_zstd_seq_waves = (int)value;
     }  // (process-wide, like zstd.decompress.exec)
+    else if (k == "zstd.decompress.lit_items") {
+        if (value != 8 && value != 10 && value != 16) return bad_argument("zstd.decompress.lit_items: items per wavefront of the pipeline's literal stage: 8, 10 or 16 (4 KiB of LDS an item)");
+        achip::g_zstd_lit_items = (int)value;
+    }  // (process-wide)
     else if (k == "decompress.latency_max_blocks") {
         if (value < 0 || value > 65536) return bad_argument("decompress.latency_max_blocks: 0 (never) .. 65536: LZ4 / Snappy batches of at most this many blocks take a wavefront and 128 KiB of LDS history per block");
         ctx->latencyMaxBlocks = (int)value;

@@ -305,6 +305,19 @@ __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_read
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t uni(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
 
+// The opposite direction (round 6): "keep this wave-uniform value in a VECTOR register, and do what is computed from it with vector instructions".  A CU has
+// one scalar unit for its four SIMDs; the window encoders' replay loops (lz4_compress_mw.h, snappy_compress_mw.h) had become 70 % scalar instructions and
+// were bound by that unit while the vector units idled (profiles/r06_notes.md section 4).  Straight-line arithmetic on a sequence's positions and lengths costs
+// the same instruction count on either side -- and none of the scalar side's s_cselect / s_and pairs and branches per condition.
+__device__ __forceinline__ int32_t vec(int32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(v));
+#endif
+    return v;
+}
+__device__ __forceinline__ uint32_t vec(uint32_t v) { return (uint32_t)vec((int32_t)v); }
+
 // ---- wave-wide match-length count (one wavefront per block) ----
 // Number of equal bytes of in[a..] vs in[b..] with a < limit, b < a: the `count` routines of the Java
 // encoders (M/lz4/Lz4RawCompressor.java:240-267, M/snappy/SnappyRawCompressor.java:235-266) both return

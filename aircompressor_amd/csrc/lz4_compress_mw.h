@@ -27,6 +27,12 @@
 #pragma once
 #include "lz4_compress_body.h"
 
+#if defined(ACHIP_HOST_STATS)  // (tools/hostemu, a counting build: which way the replay's sequences go -- tools/hostemu/lz4_paths.py)
+extern "C" long long g_zc_stats[32];
+#define MWC(k) do { if (lane == 0) g_zc_stats[k]++; } while (0)
+#else
+#define MWC(k)
+#endif
 namespace achip {
 
 namespace lz4mw {
@@ -116,6 +122,30 @@ __device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t
             }
         };
 
+        // the same with every argument in a vector register (see vec(), achip_device.h): returns the output position behind the match
+        auto emit_match_v = [&](int32_t tokenPos, int32_t literalLength, int32_t offset, int32_t matchLength, int32_t at) -> int32_t {
+            if (lane == 0) {
+                lz4_write_run_length(out, tokenPos, literalLength, matchLength >= ML_MASK ? ML_MASK : (uint32_t)matchLength);
+                out[at] = (uint8_t)offset;
+                out[at + 1] = (uint8_t)((uint32_t)offset >> 8);
+                if (matchLength >= ML_MASK) {
+                    int32_t o = at + 2;
+                    int32_t remaining = matchLength - ML_MASK;
+                    while (remaining >= 510) {
+                        out[o++] = 255;
+                        out[o++] = 255;
+                        remaining -= 510;
+                    }
+                    if (remaining >= 255) {
+                        out[o++] = 255;
+                        remaining -= 255;
+                    }
+                    out[o++] = (uint8_t)remaining;
+                }
+            }
+            return at + 2 + (matchLength >= ML_MASK ? 1 + (int32_t)((uint32_t)(matchLength - ML_MASK) / 255u) : 0);
+        };
+
         if (inLen >= MIN_LENGTH) {
             // mode 0: block start (position 0 is inserted, the search starts at 1); mode 1: after a match that ended at `input`;
             // mode 2: a search that has run through a window goes on (probe k0 of the search that began at scanStart comes next)
@@ -172,6 +202,7 @@ __device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t
                         k0 += 64;
                         continue;
                     }
+                    MWC(25);
                     input = (int32_t)rl32((uint32_t)pos, winner);
                     int32_t matchIndex = (int32_t)rl32((uint32_t)cand, winner);
                     int32_t room = input - anchor < matchIndex ? input - anchor : matchIndex;  // catch up :141-144
@@ -203,6 +234,7 @@ __device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t
                 }
 
                 // ---- a window: 64 consecutive positions from `base`; lane 0 (position 0, or input - 2) is inserted, never probed ----
+                MWC(26);
                 const int32_t base = mode == 0 ? 0 : input - 2;
                 const int32_t pos = base + lane;
                 const bool canLoad = pos + 8 <= inLen;
@@ -248,17 +280,26 @@ __device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t
                     const uint64_t cand8 = ext64(rLo, rHi, shift + 4);                                        // [tc + 4, tc + 12)
                     const uint64_t dF = my8 ^ cand8;
                     const uint32_t fwd = dF == 0 ? 8u : (uint32_t)(__builtin_ctzll(dF) >> 3);
-                    const bool fwdOk = fast && lane < 60 && pos + 12 <= inLen;
-                    const uint32_t before = (uint32_t)__shfl((int32_t)x4, lane >= 4 ? lane - 4 : lane);      // [pos - 4, pos), last byte in the top bits
+                    // (the window's last four lanes hold only the first 4 of those 8 bytes: a difference among them is still the count)
+                    const bool fwdOk = fast && pos + 12 <= inLen && (lane < 60 || fwd < 4);
+                    // [pos - 4, pos), last byte in the top bits.  The window's first lanes have only the bytes from `base` on -- which is all a catch-up from there
+                    // may use: it stops at `anchor`, and anchor >= base whenever a window is replayed (the unknown low bytes cannot raise a count above that room)
+                    const uint32_t x0 = (uint32_t)__shfl((int32_t)x4, 0);
+                    const uint32_t farBefore = (uint32_t)__shfl((int32_t)x4, lane >= 4 ? lane - 4 : lane);
+                    const uint32_t before = lane >= 4 ? farBefore : (lane == 0 ? 0u : x0 << (8 * (4 - lane)));
                     const uint32_t candBefore = shift == 4 ? (uint32_t)rLo : (uint32_t)((uint32_t)rLo << (8 * (4 - shift)));
                     const uint32_t dB = before ^ candBefore;
                     const uint32_t bwd = dB == 0 ? 4u : (uint32_t)(__builtin_clz(dB) >> 3);
-                    const bool bwdOk = fast && lane >= 4;
+                    const bool bwdOk = fast;
                     facts = fwd | (bwd << 4) | (fwdOk ? 256u : 0u) | (bwdOk ? 512u : 0u);
                 }
                 const unsigned long long belowMe = (1ull << lane) - 1ull;
                 const unsigned long long sameBelow = same & belowMe;
 
+                // the sequence's positions on the vector side (round 6): `anchor` and `output` travel through the replay in vector registers, the common
+                // sequence -- its candidate the table's entry, both of its counts in `facts`, nothing for memory to settle -- is measured and emitted with
+                // straight-line vector instructions; the scalar variables are brought up to date where scalar code needs them
+                int32_t vAnchor = vec(anchor), vOutput = vec(output);
                 unsigned long long M = 1ull;     // inserted lanes
                 int c = mode == 0 ? 1 : 3;      // first lane of the search that follows
                 int r = mode == 0 ? -1 : 2;     // lane of a pending re-probe (the position right behind a match), -1: none
@@ -307,8 +348,68 @@ __device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t
                     // ---- a match starts at lane wl against `cand` (lane jl of the window, or the table's entry of lane wl) ----
                     input = base + wl;
                     // the table's entry as the candidate (the common case): what this lane measured before the replay began, one lane read
-                    const uint32_t factsW = jl < 0 ? rl32(facts, wl) : 0u;
-                    const bool quick = jl < 0 && (factsW & 768u) == 768u;  // both counts usable (which includes `fast`)
+                    uint32_t factsW = 0;
+                    if (jl < 0) {
+                        factsW = rl32(facts, wl);
+                    }
+                    else if (jl >= 4 && wl < 60 && input + 12 <= inLen) {
+                        // a candidate inside the window (another lane's position): the same two counts from the lanes' registers -- the 8 bytes behind either 4-byte
+                        // hit are the words of lanes wl + 4 and jl + 4, the 4 before them the low words of lanes wl - 4 and jl - 4 (wl > jl >= 4)
+                        const uint64_t dF = rl64(x, wl + 4) ^ rl64(x, jl + 4);
+                        const uint32_t dB = rl32(x4, wl - 4) ^ rl32(x4, jl - 4);
+                        factsW = (dF == 0 ? 8u : (uint32_t)(__builtin_ctzll(dF) >> 3)) | ((dB == 0 ? 4u : (uint32_t)(__builtin_clz(dB) >> 3)) << 4) | 768u;
+                    }
+                    const bool quick = (factsW & 768u) == 768u;  // both counts usable (which includes `fast` for a table entry)
+                    MWC(20);
+                    if (jl >= 0) MWC(23);
+                    if (!quick) MWC(24);
+                    if (quick) {
+                        const int32_t vIn0 = vec(input), vCand0 = vec(cand);
+                        const uint32_t vF = vec(factsW);
+                        // catch up :141-144 (not behind a re-probe's hit :171-176), then count :240-267 -- `back` bytes of the 4-byte hit itself lie behind the new
+                        // start + 4, then what was measured behind the hit
+                        const int32_t vRoom = (vIn0 - vAnchor) < vCand0 ? (vIn0 - vAnchor) : vCand0;
+                        const int32_t vT = (int32_t)((vF >> 4) & 7u);
+                        int32_t vBack = vT < vRoom ? vT : vRoom;
+                        vBack = vBack > 0 && !zeroLit ? vBack : 0;
+                        const int32_t vInput = vIn0 - vBack, vCand = vCand0 - vBack;
+                        const int32_t vLimitLen = matchLimit - (vInput + MIN_MATCH);
+                        const int32_t vFwd = (int32_t)(vF & 15u);
+                        const int32_t vKnown = vBack + vFwd;
+                        // not this way: more than 4 bytes match backwards -- the general way below goes to memory for the rest
+                        const bool beyond = vBack == 4 && vRoom > 4;
+                        if (__ballot(beyond) != 0) MWC(22);
+                        if (__ballot(beyond) == 0) {  // (uniform)
+                            MWC(21);
+                            int32_t vMl = vKnown < vLimitLen ? vKnown : vLimitLen;
+                            if (__ballot(vFwd >= 8 && vKnown < vLimitLen) != 0) {  // (uniform) the registers' 8 bytes behind the hit all match: memory has the rest
+                                vMl = vKnown + vec(wave_count(in, vInput + MIN_MATCH + vKnown, vCand + MIN_MATCH + vKnown, matchLimit, lane));
+                            }
+                            const int32_t vLit = vInput - vAnchor;  // (0 behind a re-probe's hit: the zero-literal token :181-183 is the token of an empty run)
+                            const int32_t vTok = vOutput;
+                            const int32_t vLitPos = vTok + (vLit >= RUN_MASK ? 2 + (int32_t)((uint32_t)(vLit - RUN_MASK) / 255u) : 1);
+                            if (pos >= vAnchor && pos < vInput) {
+                                out[vLitPos + (pos - vAnchor)] = (uint8_t)x4;
+                            }
+                            vOutput = emit_match_v(vTok, vLit, vInput - vCand, vMl, vLitPos + vLit);
+                            vAnchor = vInput + vMl + MIN_MATCH;
+                            input = uni(vAnchor);
+                            if (input > matchFindLimit) {  // :152-155
+                                blockDone = true;
+                                break;
+                            }
+                            const int rr = input - base;
+                            if (rr < 64) {
+                                M |= 1ull << (rr - 2);  // :157-159 the `input - 2` insert
+                                r = rr;
+                                continue;
+                            }
+                            break;  // the match ends beyond the window: the next one starts at input - 2
+                        }
+                    }
+                    // ---- every other sequence: scalar code, as before round 6 ----
+                    anchor = uni(vAnchor);
+                    output = uni(vOutput);
                     int32_t back = 0;
                     int32_t matchLength = -1;
                     if (quick) {
@@ -438,6 +539,8 @@ __device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t
                     emit_match(tokenPos, literalLength, input - cand, matchLength);
                     input += matchLength + MIN_MATCH;
                     anchor = input;
+                    vAnchor = vec(anchor);
+                    vOutput = vec(output);
                     if (input > matchFindLimit) {  // :152-155
                         blockDone = true;
                         break;
@@ -450,6 +553,8 @@ __device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t
                     }
                     break;  // the match ends beyond the window: the next one starts at input - 2
                 }
+                anchor = uni(vAnchor);
+                output = uni(vOutput);
                 // the table takes the latest inserted lane of every hash
                 {
                     const unsigned long long later = same & M & ~((2ull << lane) - 1ull);

@@ -764,6 +764,26 @@ __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp:
     }
 }
 
+// K2's launch.  The stage's wavefronts wait more than they issue (53 % of their cycles on the corpus batch, round 6 counters), so what counts is streams in
+// flight per CU, and that is LDS: 4 KiB of table an item.  16 items a wavefront are 64 KiB -- two wavefronts a CU, 128 streams, 32 KiB of the LDS unused;
+// `zstd.decompress.lit_items` 10 (40 KiB: four wavefronts, 160 streams) or 8 (32 KiB: five, 160) use all of it, with lanes idle in every wavefront.
+// Measured (profiles/r06_notes.md section 10; 32 768 corpus frames): 16 items 6.96 ms, 10 items **4.83**, 8 items 6.96 (the fifth wavefront does not get
+// its LDS: four of 32 lanes are the 128 streams of two full ones).  10 is the default.
+int g_zstd_lit_items = 10;
+template <bool MB>
+inline void launch_literals(const BatchArgs& a, const zp::Pipe& p, hipStream_t stream)
+{
+    if (g_zstd_lit_items == 8) {
+        hipLaunchKernelGGL((zstd_pipe_literals_kernel<MB, 8>), dim3((unsigned)((p.count + 7) / 8)), dim3(64), 0, stream, a, p);
+    }
+    else if (g_zstd_lit_items == 10) {
+        hipLaunchKernelGGL((zstd_pipe_literals_kernel<MB, 10>), dim3((unsigned)((p.count + 9) / 10)), dim3(64), 0, stream, a, p);
+    }
+    else {
+        hipLaunchKernelGGL((zstd_pipe_literals_kernel<MB, 16>), dim3((unsigned)((p.count + 15) / 16)), dim3(64), 0, stream, a, p);
+    }
+}
+
 // ---- multi-block stages: the order K3 takes a pass's block slots in.  A pass is whatever number of blocks its frames hold -- 40 896 for the bench's
 // 1 024 corpus streams: 2.5 rounds of 64 x 256 items, i.e. three --, its slots include the frames' raw and RLE blocks (nothing for K3 to do), and the
 // last round runs as long as its longest item.  Sorted by sequence count, longest first, the slots without work form whole wavefronts at the end
@@ -1982,10 +2002,9 @@ hipError_t launch_zstd_mb_stages(const BatchArgs& a, hipStream_t stream, zp::Pip
         e = hipMemsetAsync(p.mb, 0xFF, (size_t)p.count * sizeof(zp::MbBlock), stream);
         if (e != hipSuccess) return e;
         const unsigned nItems = (unsigned)(p.itemEnd - p.itemFirst);
-        const unsigned w16 = (unsigned)((p.count + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE);
         hipLaunchKernelGGL(zstd_mb_fill_kernel, dim3((nItems + 63) / 64), dim3(64), 0, stream, a, p);
         hipLaunchKernelGGL(zstd_mb_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
-        hipLaunchKernelGGL(zstd_pipe_literals_kernel<true>, dim3(w16), dim3(64), 0, stream, a, p);
+        launch_literals<true>(a, p, stream);
         p.order = nullptr;
         if (p.count > zp::SEQL_ITEMS) {  // (more than one wavefront of slots)
             p.orderHist = (int32_t*)(mbase + M.order);
@@ -2058,7 +2077,7 @@ hipError_t launch_zstd_decompress_pipe(const BatchArgs& a, hipStream_t stream, v
         hipLaunchKernelGGL(zstd_pipe_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
         // (items per wavefront in K2 / K3 of 8 instead of 16, and an 8 KiB window for the record executor, were round-2 experiments: measured in
         // round 3 within noise of the defaults on all three data sets -- profiles/r03_notes.md -- and removed)
-        hipLaunchKernelGGL(zstd_pipe_literals_kernel<false>, dim3(w16), dim3(64), 0, stream, a, p);
+        launch_literals<false>(a, p, stream);
         hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<false>, dim3((unsigned)((p.count + seql_items_for(p.count) - 1) / seql_items_for(p.count))), dim3(64 * seql_waves_for(p.count)), 0, stream, a, p, seql_items_for(p.count), seql_items_per_wave(p.count));
         constexpr int GS = 4, IN_RING = 128, OUT_RING = 256;
         // (a tile of few items: every item to the record executor, a wavefront each -- the rings give an item four lanes, and an item of long sequences is then a
@@ -2453,7 +2472,7 @@ hipError_t launch_zstd_stream_step(hipStream_t stream, void* scratch, int64_t sc
     hipLaunchKernelGGL(zstd_mb_fill_kernel, dim3(1), dim3(64), 0, stream, a, p);
     hipLaunchKernelGGL(zstd_ss_ghost_kernel, dim3(1), dim3(64), 0, stream, p, carry);
     hipLaunchKernelGGL(zstd_mb_parse_kernel, dim3((unsigned)p.count), dim3(64), 0, stream, a, p, dflt);
-    hipLaunchKernelGGL(zstd_pipe_literals_kernel<true>, dim3((unsigned)((p.count + zp::ITEMS_PER_WAVE - 1) / zp::ITEMS_PER_WAVE)), dim3(64), 0, stream, a, p);
+    launch_literals<true>(a, p, stream);
     hipLaunchKernelGGL(zstd_pipe_sequences_lane_kernel<true>, dim3((unsigned)((p.count + seql_items_for(p.count) - 1) / seql_items_for(p.count))), dim3(64 * seql_waves_for(p.count)), 0, stream, a, p, seql_items_for(p.count), seql_items_per_wave(p.count));
     hipLaunchKernelGGL(zstd_ss_execute_kernel<32768>, dim3(1), dim3(64), 0, stream, a, p, carry, startPos);
     hipLaunchKernelGGL(zstd_ss_carry_kernel, dim3(1), dim3(64), 0, stream, p, carry);

@@ -419,7 +419,7 @@ def test_options_that_would_return_wrong_data_do_not_exist():
         bad += [("lz4.compress.variant", v) for v in (2, 3, 100)] + [("snappy.compress.variant", v) for v in (3, 5, -1, 100)]
         bad += [("lz4.decompress.variant", v) for v in (0, 2, 3, 4, 6, 8)] + [("snappy.decompress.variant", v) for v in (0, 2, 3, 4, 6, 8)]
         bad += [("hadoop.decompress.variant", 4), ("lz4frame.decompress.variant", 3), ("snappyframed.decompress.variant", 4), ("snappyframed.compress.variant", 2),
-                ("zstd.decompress.variant", 2), ("zstd.decompress.exec", 3), ("decompress.ring_class", 3), ("zstd.decompress.lit_items", 8),
+                ("zstd.decompress.variant", 2), ("zstd.decompress.exec", 3), ("decompress.ring_class", 3), ("zstd.decompress.lit_items", 12),
                 ("zstd.decompress.seq_items", 8), ("zstd.decompress.exec_window", 8192), ("no.such.option", 1)]
         for name, value in bad:
             with pytest.raises(IllegalArgumentException):

@@ -32,6 +32,7 @@ def o():
 
 
 DEFAULT_SEQ_WAVES = 1  # (the library's default of zstd.decompress.seq_waves, restored by the test that changes it)
+DEFAULT_LIT_ITEMS = 10  # (... of zstd.decompress.lit_items)
 
 
 def zstd_frames(blocks, level):
@@ -294,6 +295,33 @@ def test_sequence_stage_wavefronts_per_workgroup(o, waves):
         assert g.codec.native.get_stat("zstd.decompress.fallback_items") == 0
     finally:
         g.set_option("zstd.decompress.seq_waves", DEFAULT_SEQ_WAVES)  # (process-wide)
+
+
+@pytest.mark.parametrize("items", [8, 10, 16])
+def test_literal_stage_items_per_wavefront(o, items):
+    """zstd.decompress.lit_items: the pipeline's literal stage with 8, 10 or 16 items a wavefront (4 KiB of LDS an item: 5 / 4 / 2 wavefronts a CU) -- every
+    frame restored (libzstd's frames and the Java encoder's, single-block and multi-block), nothing handed to the one-kernel decoder."""
+    import hashlib
+    from tests.gpu_harness import GpuBatch
+    rng = np.random.default_rng(79)
+    sample = b"".join(d for _, d, _ in common.corpus_sample())
+    blocks = []
+    for i in range(203):  # (not a multiple of any of the three item counts)
+        off = int(rng.integers(0, len(sample) - 131072))
+        blocks.append(sample[off:off + int(rng.integers(2000, 131073))])
+    blocks += [sample[:300000], sample[100000:100000 + 500000]]
+    frames = zstd_frames(blocks, 3)
+    frames[:60] = [o.compress("zstd", b) for b in blocks[:60]]
+    g = GpuBatch(0, options={"zstd.decompress.variant": 1})
+    try:
+        g.set_option("zstd.decompress.lit_items", items)
+        outs, status, err = g.run(OP_ZSTD_DECOMPRESS, frames * 8, [len(b) for b in blocks] * 8)
+        assert all(s == 0 for s in status)
+        want = [hashlib.sha256(b).digest() for b in blocks] * 8
+        assert [hashlib.sha256(p).digest() for p in outs] == want
+        assert g.codec.native.get_stat("zstd.decompress.fallback_items") == 0
+    finally:
+        g.set_option("zstd.decompress.lit_items", DEFAULT_LIT_ITEMS)  # (process-wide)
 
 
 def test_pipeline_takes_java_encoded_frames(gbd, o):

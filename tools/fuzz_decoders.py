@@ -17,14 +17,17 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
         text = b"".join(d for _, d, _ in common.corpus_sample()[:5])
         blocks += [bytes(1 << 20), bytes(range(256)) * 2048, (b"abc" * 100000)[:250001], text, text[:100000] + bytes(50000) + text[:70000],
                    bytes(rng.integers(0, 256, 300000, dtype=np.uint8)), (bytes(rng.integers(0, 256, 1000, dtype=np.uint8)) * 400)]
-    OPS = {"lz4": 0, "snappy": 2, "zstd": 4, "lz4frame": 6, "snappyframed": 8}
+    OPS = {"lz4": 0, "snappy": 2, "zstd": 4, "lz4frame": 6, "snappyframed": 8, "lz4hadoop": 10, "snappyhadoop": 12}  # (round 6: the Hadoop block-stream readers)
+    HADOOP = {"lz4hadoop": "lz4", "snappyhadoop": "snappy"}
     VARIANTS = {"lz4": [1, 13, 7, 71], "snappy": [1, 13, 7, 71],  # (71: variant 7 with the lane-per-block parser -- batches of this size take the wavefront-per-block one;
                                                                 # 13: the ring decoders' latency class -- a wavefront and 128 KiB of LDS history per block -- for every batch size)
-                 "zstd": [1, 0], "lz4frame": [None], "snappyframed": [None]}
+                 "zstd": [1, 0], "lz4frame": [None], "snappyframed": [None], "lz4hadoop": [3, 1, 2, 0], "snappyhadoop": [3, 1, 2, 0]}  # (hadoop.decompress.variant)
 
 
     def expect(codec, data, cap):
         try:
+            if codec in HADOOP:
+                return 0, 0, o.hadoop_decompress(HADOOP[codec], data, cap)
             return 0, 0, o.decompress(codec, data, cap)
         except OracleError as e:
             return e.status, e.offset, None
@@ -32,7 +35,7 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
 
     bad = 0
     for codec in codecs:
-        comp = [o.compress(codec, b) for b in blocks]
+        comp = [o.hadoop_compress(HADOOP[codec], b, buffer_size=(262144, 8192, 1024)[i % 3]) if codec in HADOOP else o.compress(codec, b) for i, b in enumerate(blocks)]  # (several chunks per stream)
         caps = [len(b) for b in blocks]
         if codec == "snappy":  # streams of random elements of every kind (what the Java encoder never writes: 4-byte offsets, runs with length bytes, runs behind runs)
             for target in (40, 500, 3000, 20000, 70000) + ((150000, 400000) if big else ()):
@@ -54,7 +57,7 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
             k = int(rng.integers(0, len(comp)))
             c = bytearray(comp[k])
             cap = caps[k]
-            kind = int(rng.integers(0, 6))
+            kind = int(rng.integers(0, 6)) if len(c) else 3  # (an empty stream -- what the Hadoop writers make of no input -- can only be extended)
             if kind <= 2:      # 1..4 byte mutations
                 for _ in range(int(rng.integers(1, 5))):
                     c[int(rng.integers(0, len(c)))] = int(rng.integers(0, 256))
@@ -71,7 +74,9 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
             cases.append((bytes(c), cap))
         want = [expect(codec, c, cap) for c, cap in cases]
         for variant in VARIANTS[codec]:
-            if variant is not None:
+            if variant is not None and codec in HADOOP:
+                gb.set_option("hadoop.decompress.variant", variant)
+            elif variant is not None:
                 gb.set_option("%s.decompress.variant" % codec, 7 if variant == 71 else (1 if variant == 13 else variant))
                 gb.set_option("decompress.latency_max_blocks", 65536 if variant == 13 else 0)
                 if codec in ("lz4", "snappy"):
@@ -89,6 +94,8 @@ def run(n_cases, seed, codecs=("lz4", "snappy"), big=False):
             print("%s variant %s: %d cases (%d malformed), %d mismatches" % (codec, variant, len(cases), n_err, wrong), flush=True)
         if codec in ("lz4", "snappy"):
             gb.set_option("%s.decompress.parse" % codec, 0)
+        if codec in HADOOP:
+            gb.set_option("hadoop.decompress.variant", 3)
         gb.set_option("decompress.latency_max_blocks", 256)
     print("TOTAL MISMATCHES", bad)
     return bad

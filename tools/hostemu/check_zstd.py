@@ -229,7 +229,8 @@ def main():
         frames = [bytes(enc(p)) for p in plains]
         # (second run: the 8-items-per-wavefront instantiations of the literal and sequence stages -- mode bits 2 and 3)
         # (... and the sequence stage in full workgroups of 1, 2 and 4 wavefronts: mode bits 4 .. 6, lanes without an item beside lanes with one)
-        for pad, mode in ((0, 1), (37, 1), (0, 1 | (1 << 4)), (0, 1 | (2 << 4)), (0, 1 | (4 << 4))):
+        # (... and the literal stage at 8 and 10 items per wavefront: mode bits 2, 3 -- option zstd.decompress.lit_items)
+        for pad, mode in ((0, 1), (37, 1), (0, 1 | (1 << 4)), (0, 1 | (2 << 4)), (0, 1 | (4 << 4)), (0, 1 | (1 << 2)), (0, 1 | (2 << 2))):
             outs, status, fb = run(frames, [len(p) + pad for p in plains], exec_mode=mode)
             for i, p in enumerate(plains):
                 total += 1

@@ -71,6 +71,15 @@ r=json.loads(sys.stdin.read()); print('waves $w:', {k:(v['decompress_GiBps'], v[
       for wl in ${WLS:-lz4_compress snappy_compress}; do for data in corpus fragments; do
         timeout 600 python bench.py --no-cpu-baseline --no-extra --no-legs --no-host-facing --no-sweep --steps 3 --warmup 1 --workload $wl --data $data --blocks 65536 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$wl $data', r['value'], 'GiB/s', r['roofline'].get('kernel_ms_avg'))"
       done; done | tee $O/encrate_${TAG:-a}.txt ;;
+    lititems)      # the Zstd literal stage at 16 / 10 / 8 items per wavefront (zstd.decompress.lit_items): parity on the GPU, then the section's per-dispatch times
+      for v in ${ITEMS:-16 10 8}; do
+        timeout 600 bash tools/profile_zstd.sh r06_li$v --no-cpu-baseline --option zstd.decompress.lit_items=$v 2>&1 | tail -1 | python -c "
+import json,sys
+r=json.loads(sys.stdin.read()); print('lit_items $v:', {k:(v['decompress_GiBps'], v['java_frames_decompress_GiBps']) for k,v in r.items()})"
+        grep literals_kernel gpurun_out/prof_r06_li$v/keep/dispatches.txt | awk '{print $(NF-3)}' | tr '\n' ' '; echo
+      done 2>&1 | tee $O/lititems.txt ;;
+    hadoopfuzz)    # differential fuzz of the Hadoop block-stream readers and the Snappy framed reader (mutated streams: status, offset, plaintext against the oracle)
+      timeout 1200 python tools/fuzz_decoders.py ${N:-8000} 631 lz4hadoop,snappyhadoop,snappyframed 2>&1 | grep -v amdgpu.ids | tail -14 | tee $O/fuzz_hadoop.txt ;;
     final)         # the pass that ships: suite, smoke, traffic.json, bench.py as the driver runs it, rocprofv3 summaries of both headline kernels, Zstd per-dispatch times, --gpus 2 on one device
       F=$O/final; rm -rf $F; mkdir -p $F
       timeout 1800 python -m pytest tests -m gpu -x -q > $F/pytest.log 2>&1; tail -2 $F/pytest.log
