@@ -190,6 +190,20 @@ __device__ __forceinline__ void snappy_compress_buffer_mw(uint16_t* table, const
                         c4 = ld4(in + tc);
                     }
 
+                    // What a copy of this lane against ITS TABLE ENTRY would measure behind the 4-byte hit, by every lane at once (round 6, as lz4_compress_mw.h): this
+                    // window's bytes from lane + 4 against the 8 fetched behind the candidate -- bits 0..3 the count (0 .. 8), bit 8 "usable" (the last four lanes
+                    // hold only the first 4 of those bytes: a difference among them is still the count).  The replay reads one word with one lane read.
+                    uint32_t facts = 0;
+                    {
+                        const uint32_t upHi = (uint32_t)__shfl((int32_t)(uint32_t)(x >> 32), lane < 60 ? lane + 4 : lane);
+                        const uint64_t dF = ((x >> 32) | ((uint64_t)upHi << 32)) ^ after8;
+                        const uint32_t fwd = dF == 0 ? 8u : (uint32_t)(__builtin_ctzll(dF) >> 3);
+                        facts = fwd | (fast && pos + 12 <= blockLimit && (lane < 60 || fwd < 4) ? 256u : 0u);
+                    }
+                    // the copy's positions on the vector side (round 6; vec(), achip_device.h): `nextEmit` and `output` travel through the replay in vector registers, a
+                    // copy whose count the registers know is measured and emitted with straight-line vector instructions -- the replay was bound by the CU's one
+                    // scalar unit; the scalar variables are brought up to date where scalar code needs them
+                    int32_t vNextEmit = vec(nextEmit), vOutput = vec(output);
                     unsigned long long M = mode == 0 ? 0ull : 1ull;  // inserted lanes
                     int c = mode == 0 ? 1 : 2;                      // first lane of the search that follows
                     int r = mode == 0 ? -1 : 1;                     // lane of a pending re-probe, -1: none
@@ -213,7 +227,8 @@ __device__ __forceinline__ void snappy_compress_buffer_mw(uint16_t* table, const
                                 viaReprobe = true;
                             }
                             else {
-                                nextEmit = base + r;  // :220
+                                nextEmit = base + r;  // :220 (where it already is: the copy before ended here)
+                                vNextEmit = vec(nextEmit);
                                 c = r + 1;
                             }
                             r = -1;
@@ -253,6 +268,49 @@ __device__ __forceinline__ void snappy_compress_buffer_mw(uint16_t* table, const
                         }
                         // ---- a copy starts at lane wl against `cand` ----
                         input = base + wl;
+                        uint32_t factsW = 0;
+                        if (jl < 0) {
+                            factsW = rl32(facts, wl);
+                        }
+                        else if (wl < 60 && input + 12 <= blockLimit) {  // a candidate inside the window: the 8 bytes behind either hit are the words of lanes wl + 4 and jl + 4
+                            const uint64_t dF = rl64(x, wl + 4) ^ rl64(x, jl + 4);
+                            factsW = (dF == 0 ? 8u : (uint32_t)(__builtin_ctzll(dF) >> 3)) | 256u;
+                        }
+                        if ((factsW & 256u) != 0) {
+                            const int32_t vIn = vec(input), vCand = vec(cand);
+                            const uint32_t vF = vec(factsW);
+                            if (!viaReprobe) {  // the literal before it :169-175: bytes of this window, stored from the lanes' registers
+                                const int32_t vLit = vIn - vNextEmit;
+                                vOutput += snappy_literal_header(out, vOutput, vLit, lane);
+                                if (pos >= vNextEmit && pos < vIn) {
+                                    out[vOutput + (pos - vNextEmit)] = (uint8_t)x4;
+                                }
+                                vOutput += vLit;
+                            }
+                            const int32_t vLimitLen = blockLimit - (vIn + 4);
+                            const int32_t vFwd = (int32_t)(vF & 15u);
+                            int32_t vMatched = 4 + (vFwd < vLimitLen ? vFwd : vLimitLen);
+                            if (__ballot(vFwd == 8 && vLimitLen > 8) != 0) {  // (uniform) the registers' 8 bytes all match: memory has the rest
+                                vMatched = 12 + vec(wave_count(in, vIn + 12, vCand + 12, blockLimit, lane));
+                            }
+                            vOutput = snappy_emit_copy(out, vOutput, vIn - vCand, vMatched, lane);
+                            vNextEmit = vIn + vMatched;
+                            input = uni(vNextEmit);
+                            if (input >= fastInputLimit) {  // :194-196
+                                blockDone = true;
+                                break;
+                            }
+                            const int rr = input - base;
+                            if (rr < 64) {
+                                M |= 1ull << (rr - 1);  // :203-205 the `input - 1` insert
+                                r = rr;
+                                continue;
+                            }
+                            break;  // the copy ends beyond the window: the next one starts at input - 1
+                        }
+                        // ---- every other copy: scalar code, as before round 6 ----
+                        nextEmit = uni(vNextEmit);
+                        output = uni(vOutput);
                         if (!viaReprobe) {  // the literal before it :169-175: bytes of this window, stored from the lanes' registers
                             const int32_t literalLength = input - nextEmit;
                             output += snappy_literal_header(out, output, literalLength, lane);
@@ -286,6 +344,8 @@ __device__ __forceinline__ void snappy_compress_buffer_mw(uint16_t* table, const
                         output = snappy_emit_copy(out, output, input - cand, matched, lane);
                         input += matched;
                         nextEmit = input;
+                        vNextEmit = vec(nextEmit);
+                        vOutput = vec(output);
                         if (input >= fastInputLimit) {  // :194-196
                             blockDone = true;
                             break;
@@ -298,6 +358,8 @@ __device__ __forceinline__ void snappy_compress_buffer_mw(uint16_t* table, const
                         }
                         break;  // the copy ends beyond the window: the next one starts at input - 1
                     }
+                    nextEmit = uni(vNextEmit);
+                    output = uni(vOutput);
                     // the table takes the latest inserted lane of every hash
                     {
                         const unsigned long long later = same & M & ~((2ull << lane) - 1ull);
