@@ -32,13 +32,14 @@ __device__ __forceinline__ uint64_t sbits(int lo, int hi)
 #endif
 }
 // the lanes of a window that a search starting at lane c probes: c .. c + 32 (its first 33 probes advance by one), then every second lane
-__device__ __forceinline__ uint64_t probe_lanes(int c)
+__device__ __forceinline__ uint64_t probe_lanes(int c)  // (wave-uniform c in 1 .. 64)
 {
-    uint64_t m = bits(c, c + 33);
+    c = uni(c);  // (the compiler's analysis does not always see it)
+    uint64_t m = sbits(c, c + 33 < 64 ? c + 33 : 64);
     if (c + 34 < 64) {
         // lanes c + 34, c + 36, ...: same parity as c
         const uint64_t parity = (c & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
-        m |= parity & bits(c + 34, 64);
+        m |= parity & sbits(c + 34, 64);
     }
     return m;
 }
@@ -204,6 +205,7 @@ __device__ __forceinline__ void snappy_compress_buffer_mw(uint16_t* table, const
                     // copy whose count the registers know is measured and emitted with straight-line vector instructions -- the replay was bound by the CU's one
                     // scalar unit; the scalar variables are brought up to date where scalar code needs them
                     int32_t vNextEmit = vec(nextEmit), vOutput = vec(output);
+                    const unsigned long long sameBelow = same & ((1ull << lane) - 1ull);
                     unsigned long long M = mode == 0 ? 0ull : 1ull;  // inserted lanes
                     int c = mode == 0 ? 1 : 2;                      // first lane of the search that follows
                     int r = mode == 0 ? -1 : 1;                     // lane of a pending re-probe, -1: none
@@ -240,7 +242,8 @@ __device__ __forceinline__ void snappy_compress_buffer_mw(uint16_t* table, const
                             const int32_t kk = d <= 32 ? d : 32 + ((d - 32) >> 1);
                             const bool probing = lane >= c && ((probes >> lane) & 1ull) != 0;
                             const bool canProbe = pos + ((32 + kk) >> 5) <= fastInputLimit;
-                            const unsigned long long elig = same & (M | (probes & bits(c, lane))) & bits(0, lane);
+                            // a lane sees the inserts of the replay so far and of the probing lanes before it (`probes` holds no lane below c, sameBelow none from this lane on)
+                            const unsigned long long elig = sameBelow & (M | probes);
                             const int j = elig != 0 ? 63 - __builtin_clzll(elig) : -1;
                             const uint32_t cv = __shfl(x4, j >= 0 ? j : lane);
                             const uint32_t cmp = j >= 0 ? cv : c4;
