@@ -54,6 +54,7 @@ int64_t hadoop_compress_scratch_bytes(int32_t nStreams);
 extern int g_zstd_pipe_exec;
 extern int g_zstd_seq_waves;
 extern int g_zstd_lit_items;
+extern int g_snappy_mem_waves;
 int64_t zstd_ostream_state_bytes();
 int64_t zstd_ostream_slab_bytes();
 hipError_t launch_zstd_ostream_step(hipStream_t stream, void* state, void* slab, const uint8_t* buf, int32_t offset, int32_t chunk, int32_t closing, uint8_t* out, int32_t outCap);
@@ -1146,6 +1147,10 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->hostBlitGroups = (int)value;
     }
     else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;
+    else if (k == "snappy.compress.mem_waves") {
+        if (value < 0 || value > 3) return bad_argument("snappy.compress.mem_waves: wavefronts per workgroup of the two-tier encoder whose table lies in memory, 0 .. 3");
+        achip::g_snappy_mem_waves = (int)value;
+    }  // (process-wide)
     else if (k == "snappy.compress.fan") {
         if (value != 0 && value != 1) return bad_argument("snappy.compress.fan: 1 the independent 64 KiB sub-blocks of a buffer side by side (default), 0 in turn on one wavefront");
         ctx->snappyFan = (int)value;

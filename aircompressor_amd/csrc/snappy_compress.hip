@@ -338,6 +338,9 @@ namespace {
 constexpr int SNC_TIER_WORKGROUPS = 256 * 5;  // five 32 KB LDS tables per CU
 }
 int g_snappy_tier_workgroups = SNC_TIER_WORKGROUPS;  // (the persistent grid where the unit count is known on the device only; tools/hostemu makes it small)
+// wavefronts of a workgroup whose table lies in memory (0 .. 3; `snappy.compress.mem_waves`).  Their tables are what the kernel's HBM traffic is made of -- 431 GB
+// a launch on the corpus batch, 100 x the input: 1 280 workgroups x 3 slabs x 32 KiB = 120 MB of tables, 15 MB per XCD against 4 MB of L2.
+int g_snappy_mem_waves = 3;
 namespace {
 constexpr int64_t SNC_SLABS_BYTES = (int64_t)SNC_TIER_WORKGROUPS * 3 * snc::MAX_HASH_TABLE_SIZE * 2;
 }
@@ -356,7 +359,8 @@ hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int va
         const hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
         if (e != hipSuccess) return e;
         uint16_t* slabs = (uint16_t*)((uint8_t*)scratch + 4096);
-        const unsigned need = (unsigned)((a.nBlocks + 3) / 4);
+        const unsigned perGroup = (unsigned)(1 + g_snappy_mem_waves);
+        const unsigned need = (unsigned)((a.nBlocks + perGroup - 1) / perGroup);
         if (variant == 4 && fan) {
             snfan::State* state = (snfan::State*)scratch;
             int32_t* bigItem = (int32_t*)((uint8_t*)scratch + 4096 + SNC_SLABS_BYTES);
@@ -364,13 +368,13 @@ hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int va
             const unsigned listGrid = (unsigned)((a.nBlocks + 255) / 256);
             hipLaunchKernelGGL(snappy_fan_list_kernel, dim3(listGrid < 1024u ? listGrid : 1024u), dim3(256), 0, stream, a, state, bigItem, bigFirst);
             // (the extra units are known on the device only: the persistent grid is launched whole)
-            hipLaunchKernelGGL(snappy_compress_tiers_kernel<true>, dim3((unsigned)g_snappy_tier_workgroups), dim3(256), 0, stream, a, slabs, counter, state, bigItem, bigFirst);
+            hipLaunchKernelGGL(snappy_compress_tiers_kernel<true>, dim3((unsigned)g_snappy_tier_workgroups), dim3(64 * (1 + g_snappy_mem_waves)), 0, stream, a, slabs, counter, state, bigItem, bigFirst);
             hipLaunchKernelGGL(snappy_fan_fold_kernel, dim3((unsigned)(a.nBlocks < 4096 ? a.nBlocks : 4096)), dim3(64), 0, stream, a, state, bigItem);
             return hipGetLastError();
         }
         const unsigned grid = need < (unsigned)SNC_TIER_WORKGROUPS ? need : (unsigned)SNC_TIER_WORKGROUPS;
-        if (variant == 4) hipLaunchKernelGGL(snappy_compress_tiers_kernel<true>, dim3(grid), dim3(256), 0, stream, a, slabs, counter, nullptr, nullptr, nullptr);
-        else hipLaunchKernelGGL(snappy_compress_tiers_kernel<false>, dim3(grid), dim3(256), 0, stream, a, slabs, counter, nullptr, nullptr, nullptr);
+        if (variant == 4) hipLaunchKernelGGL(snappy_compress_tiers_kernel<true>, dim3(grid), dim3(64 * perGroup), 0, stream, a, slabs, counter, nullptr, nullptr, nullptr);
+        else hipLaunchKernelGGL(snappy_compress_tiers_kernel<false>, dim3(grid), dim3(64 * perGroup), 0, stream, a, slabs, counter, nullptr, nullptr, nullptr);
         return hipGetLastError();
     }
     if (variant == 0) {

@@ -80,6 +80,10 @@ r=json.loads(sys.stdin.read()); print('lit_items $v:', {k:(v['decompress_GiBps']
       done 2>&1 | tee $O/lititems.txt ;;
     hadoopfuzz)    # differential fuzz of the Hadoop block-stream readers and the Snappy framed reader (mutated streams: status, offset, plaintext against the oracle)
       timeout 1200 python tools/fuzz_decoders.py ${N:-8000} 631 lz4hadoop,snappyhadoop,snappyframed 2>&1 | grep -v amdgpu.ids | tail -14 | tee $O/fuzz_hadoop.txt ;;
+    memwaves)      # the Snappy encoder's memory tier at 3 / 2 / 1 / 0 wavefronts per workgroup (snappy.compress.mem_waves), corpus and fragments
+      for data in corpus fragments; do for w in ${WAVES:-3 2 1 0}; do
+        timeout 600 python bench.py --no-cpu-baseline --no-extra --no-legs --no-host-facing --no-sweep --steps 3 --warmup 1 --workload snappy_compress --data $data --blocks 65536 --option snappy.compress.mem_waves=$w 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('snappy_compress $data mem_waves $w:', r['value'], 'GiB/s  kernel ms', r['roofline'].get('kernel_ms_avg'))"
+      done; done | tee $O/memwaves.txt ;;
     final)         # the pass that ships: suite, smoke, traffic.json, bench.py as the driver runs it, rocprofv3 summaries of both headline kernels, Zstd per-dispatch times, --gpus 2 on one device
       F=$O/final; rm -rf $F; mkdir -p $F
       timeout 1800 python -m pytest tests -m gpu -x -q > $F/pytest.log 2>&1; tail -2 $F/pytest.log
