@@ -34,7 +34,10 @@ hipError_t launch_lz4_mixed_groups(const BatchArgs& a, hipStream_t stream, int32
 hipError_t launch_lz4_sequence_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit);
 hipError_t launch_snappy_decompress_rings(const BatchArgs& a, hipStream_t stream, int groupSize, int ringClass, const int32_t* mixedGroups);
 hipError_t launch_snappy_element_sample(const BatchArgs& a, hipStream_t stream, int32_t* stats, int32_t minBlocks, int32_t shortLimit);
-hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint);
+hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint, void* scratch);
+int64_t lz4_compress_scratch_bytes();
+extern int g_lz4_mem_waves;
+extern int g_lz4_tier_min_blocks;
 hipError_t launch_snappy_compress(const BatchArgs& a, hipStream_t stream, int variant, void* scratch, bool fan);
 hipError_t launch_blit(void* dst, const void* src, int64_t bytes, int workgroups, hipStream_t stream);
 int64_t snappy_compress_scratch_bytes(int32_t nBlocks);
@@ -510,9 +513,14 @@ int32_t launch_op(int32_t op, achip_ctx* ctx, const achip::BatchArgs& args)
             e = achip::launch_lz4_decompress_rings(a, ctx->stream, lz4Group, ctx->ringClass == 0 && a.nBlocks <= ctx->latencyMaxBlocks ? 3 : ctx->ringClass, nullptr);
             break;
         }
-        case ACHIP_OP_LZ4_COMPRESS:
-            e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint);
+        case ACHIP_OP_LZ4_COMPRESS: {
+            if (ctx->lz4cVariant == 4 && achip::g_lz4_mem_waves > 0) {  // (the two-tier kernel's table slabs)
+                const int32_t r = ensure_scratch(ctx, achip::lz4_compress_scratch_bytes());
+                if (r < 0) return r;
+            }
+            e = achip::launch_lz4_compress(a, ctx->stream, ctx->lz4cVariant, ctx->maxSrcLenHint, ctx->scratch);
             break;
+        }
         case ACHIP_OP_SNAPPY_DECOMPRESS: {
             const int snappyGroup = ctx->snappydGroup > 0 ? ctx->snappydGroup : (a.nBlocksDev != nullptr ? 4 : achip::snappy_ring_group_for(a.nBlocks));
             if (ctx->snappydVariant == 5 && a.nBlocks >= ctx->lz4dAutoMinBlocks) {  // auto, as for LZ4
@@ -1147,6 +1155,14 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         ctx->hostBlitGroups = (int)value;
     }
     else if (k == "max_src_len_hint") ctx->maxSrcLenHint = (int)value;
+    else if (k == "lz4.compress.mem_waves") {
+        if (value < 0 || value > 2) return bad_argument("lz4.compress.mem_waves: wavefronts per workgroup of the window encoder whose table lies in memory: 0 (one wavefront per block, table in LDS), 1 or 2");
+        achip::g_lz4_mem_waves = (int)value;
+    }  // (process-wide)
+    else if (k == "lz4.compress.tier_min_blocks") {
+        if (value < 1 || value > (1 << 30)) return bad_argument("lz4.compress.tier_min_blocks: batches of at least this many blocks take the two-tier kernel (default 5120)");
+        achip::g_lz4_tier_min_blocks = (int)value;
+    }  // (process-wide)
     else if (k == "snappy.compress.mem_waves") {
         if (value < 0 || value > 3) return bad_argument("snappy.compress.mem_waves: wavefronts per workgroup of the two-tier encoder whose table lies in memory, 0 .. 3");
         achip::g_snappy_mem_waves = (int)value;

@@ -248,6 +248,63 @@ __global__ __launch_bounds__(64) void lz4_compress_mw_kernel(BatchArgs a, int32_
     }
 }
 
+// Two tiers (round 6), the arrangement of snappy_compress_tiers_kernel for the 64 KiB blocks of this encoder.  The 8 KiB table allows twenty wavefronts a CU when
+// it sits in LDS, the encoder is a serial chain per block whose wavefronts wait 42 % of their cycles (profiles/r06_counters_lz4_compress_corpus_after2.txt), and 72
+// vector registers hold 28.  A workgroup here is FIVE wavefronts with their tables in LDS and up to two with theirs in a slab of global memory (8 KiB each: L2-resident)
+// -- four workgroups a CU: the twenty LDS chains as before, and eight slower ones beside them.  Persistent; every wavefront draws its next block from a counter, so
+// the slower chains simply take fewer.  (First shape tried: a workgroup of one LDS and one memory wavefront -- 14 + 14 chains a CU: corpus 38.9 -> 44.5 GiB/s,
+// fragments 103.6 -> 71.6: on data whose searches run through windows the memory tier's table round trips are what a chain is made of.  profiles/r06_notes.md.)
+// (Blocks beyond 64 KiB keep lz4_compress_mw_kernel<int32_t>.)
+namespace lz4t {
+constexpr int LDS_WAVES = 5;
+constexpr int MEM_WAVES_MAX = 2;
+constexpr int WORKGROUPS = 256 * 4;
+}  // namespace lz4t
+__global__ __launch_bounds__(64 * (lz4t::LDS_WAVES + lz4t::MEM_WAVES_MAX), 7) void lz4_compress_tiers_kernel(BatchArgs a, int32_t bothWidths, uint16_t* slabs, int32_t* nextItem)
+{
+    using namespace lz4c;
+    __shared__ uint16_t ldsTable[lz4t::LDS_WAVES][MAX_TABLE_SIZE];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint16_t* const slab = slabs + ((size_t)blockIdx.x * lz4t::MEM_WAVES_MAX + (wave >= lz4t::LDS_WAVES ? wave - lz4t::LDS_WAVES : 0)) * MAX_TABLE_SIZE;
+    for (;;) {
+        int32_t unit = 0;
+        if (lane == 0) {
+            unit = atomicAdd(nextItem, 1);
+        }
+        unit = __builtin_amdgcn_readfirstlane(unit);
+        if (unit >= a.nBlocks) {
+            return;
+        }
+        const int64_t block = unit;
+        const int32_t inLen = uni(a.srcLen[block]);
+        if (inLen > 65536) {
+            if (!bothWidths && lane == 0) {
+                a.outLen[block] = 0;
+                a.status[block] = mk_status(ACHIP_CLASS_INVALID_ARGUMENT, ACHIP_D_BAD_ARGUMENT);
+                a.errOffset[block] = 0;
+            }
+            continue;
+        }
+        const uint8_t* __restrict__ in = a.srcBase + a.srcOff[block];
+        uint8_t* __restrict__ out = a.dstBase + a.dstOff[block];
+        int32_t st = 0;
+        int32_t output;
+        if (wave < lz4t::LDS_WAVES) {
+            output = lz4_compress_block_mw<uint16_t>(in, inLen, out, a.dstCap[block], ldsTable[wave], lane, st);
+        }
+        else {
+            output = lz4_compress_block_mw<uint16_t>(in, inLen, out, a.dstCap[block], slab, lane, st);
+        }
+        if (lane == 0) {
+            a.outLen[block] = st == 0 ? output : 0;
+            a.status[block] = st;
+            a.errOffset[block] = 0;
+        }
+        wave_mem_order();
+    }
+}
+
 // ---- LZ4 frame container, encoder -------------------------------------------------------------
 // Replaces Lz4FrameCompression.compress (M/lz4/Lz4FrameCompression.java:96-140): header (magic, FLG = version 01 +
 // independent blocks, BD = 4 MiB, xxHash32 header checksum byte), 4 MiB blocks each through the block encoder above into a
@@ -362,7 +419,14 @@ hipError_t launch_lz4frame_compress(const BatchArgs& a, hipStream_t stream, void
     return hipGetLastError();
 }
 
-hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint)
+// the two-tier kernel: from batches that fill the LDS tier on (fewer blocks: a wavefront per block, all tables in LDS)
+int g_lz4_mem_waves = 1;            // `lz4.compress.mem_waves`: 0 = one wavefront per block, table in LDS (until round 6); 1 / 2 = memory-tier wavefronts beside five LDS ones.
+                                    // Measured, 65 536 blocks (profiles/r06_ab_lz4_compress_tiers.txt): corpus 38.8 / **44.1** / 41.3 GiB/s at 0 / 1 / 2, fragments 103.6 / 104.8 / 93.0
+int g_lz4_tier_workgroups = 0;      // (0: lz4t::WORKGROUPS; tools/hostemu makes it small)
+int g_lz4_tier_min_blocks = 256 * 20;  // `lz4.compress.tier_min_blocks` (what the LDS tier holds at once)
+int64_t lz4_compress_scratch_bytes() { return 4096 + (int64_t)lz4t::WORKGROUPS * lz4t::MEM_WAVES_MAX * lz4c::MAX_TABLE_SIZE * 2; }
+
+hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int variant, int maxSrcLenHint, void* scratch)
 {
     if (a.nBlocks <= 0) {
         return hipSuccess;
@@ -370,6 +434,20 @@ hipError_t launch_lz4_compress(const BatchArgs& a, hipStream_t stream, int varia
     // maxSrcLenHint: 0 = unknown, else the caller's promise about the largest srcLen in the batch: when it is <= 64 KiB the launch of
     // the wide-table kernel is skipped (a block that breaks the promise gets an INVALID_ARGUMENT status, not silence)
     const int32_t both = maxSrcLenHint == 0 || maxSrcLenHint > 65536;
+    if (variant == 4 && g_lz4_mem_waves > 0 && scratch != nullptr && a.nBlocks >= g_lz4_tier_min_blocks) {
+        int32_t* counter = (int32_t*)scratch;
+        const hipError_t e = hipMemsetAsync(counter, 0, 64, stream);
+        if (e != hipSuccess) return e;
+        const unsigned perGroup = (unsigned)(lz4t::LDS_WAVES + g_lz4_mem_waves);
+        unsigned groups = g_lz4_tier_workgroups > 0 ? (unsigned)g_lz4_tier_workgroups : (unsigned)lz4t::WORKGROUPS;
+        groups = groups > (unsigned)lz4t::WORKGROUPS ? (unsigned)lz4t::WORKGROUPS : groups;
+        const unsigned need = ((unsigned)a.nBlocks + perGroup - 1) / perGroup;
+        hipLaunchKernelGGL(lz4_compress_tiers_kernel, dim3(need < groups ? need : groups), dim3(64 * perGroup), 0, stream, a, both, (uint16_t*)((uint8_t*)scratch + 4096), counter);
+        if (both) {
+            hipLaunchKernelGGL(lz4_compress_mw_kernel<int32_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, both);
+        }
+        return hipGetLastError();
+    }
     if (variant == 4) {
         hipLaunchKernelGGL(lz4_compress_mw_kernel<uint16_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, stream, a, both);
         if (both) {

@@ -87,7 +87,7 @@ __device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t
         for (int i = lane; i < tableSize; i += 64) {
             table[i] = 0;
         }
-        __syncthreads();
+        wave_sync();  // (the accesses of this wavefront to its table, in order; it may share its workgroup with others: lz4_compress_tiers_kernel)
         const int32_t mask = tableSize - 1;
         const int hashBits = 32 - __builtin_clz((uint32_t)mask | 1u);
         const int32_t inputLimit = inLen;
@@ -194,7 +194,7 @@ __device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t
                             table[h] = (TableT)pos;
                         }
                     }
-                    __syncthreads();
+                    wave_sync();  // (the accesses of this wavefront to its table, in order; it may share its workgroup with others: lz4_compress_tiers_kernel)
                     if (winner < 0) {
                         if (firstInvalid < 64) {
                             break;  // the search ran off the end: last literals from anchor
@@ -562,7 +562,7 @@ __device__ int32_t lz4_compress_block_mw(const uint8_t* __restrict__ in, int32_t
                         table[h] = (TableT)pos;
                     }
                 }
-                __syncthreads();
+                wave_sync();  // (the accesses of this wavefront to its table, in order; it may share its workgroup with others: lz4_compress_tiers_kernel)
                 if (blockDone) {
                     break;
                 }

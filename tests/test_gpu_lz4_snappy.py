@@ -69,6 +69,32 @@ def test_compress_is_bit_exact_with_oracle(gb, o, codec, variant):
     gb.set_option("%s.compress.variant" % codec, 4)
 
 
+@pytest.mark.parametrize("mem_waves", [1, 2])
+def test_lz4_two_tier_encoder_is_bit_exact_with_oracle(o, mem_waves):
+    """lz4.compress.mem_waves: the window encoder in workgroups of five wavefronts with their tables in LDS and one or two with theirs in global memory (batches
+    of 5 120 blocks and more; here the threshold is lowered so that a small batch takes it, and a batch beyond the default threshold follows) -- the oracle's
+    bytes for every block, whichever wavefront drew it."""
+    from tests.gpu_harness import GpuBatch
+    g = GpuBatch(0)
+    blocks = [b for b in all_blocks() if len(b) <= 65536]
+    caps = [o.max_compressed_length("lz4", len(b)) for b in blocks]
+    want = [o.compress("lz4", b) for b in blocks]
+    try:
+        g.set_option("lz4.compress.mem_waves", mem_waves)
+        g.set_option("lz4.compress.tier_min_blocks", 1)
+        outs, status, _ = g.run(CODECS["lz4"]["c"], blocks, caps)
+        assert all(s == 0 for s in status), status
+        assert outs == want
+        g.set_option("lz4.compress.tier_min_blocks", 5120)
+        reps = 5120 // len(blocks) + 1
+        outs, status, _ = g.run(CODECS["lz4"]["c"], blocks * reps, caps * reps)
+        assert all(s == 0 for s in status)
+        assert [hashlib.sha256(c).digest() for c in outs] == [hashlib.sha256(c).digest() for c in want] * reps
+    finally:
+        g.set_option("lz4.compress.mem_waves", 1)
+        g.set_option("lz4.compress.tier_min_blocks", 5120)
+
+
 @pytest.mark.parametrize("codec", ["lz4", "snappy"])
 @pytest.mark.parametrize("cfg", DECODERS)
 def test_decompress_matches_plaintext_all_decoder_configs(gb, o, codec, cfg):

@@ -70,7 +70,8 @@ def part_block():
         blocks.append(b"".join(d for _, d, _ in common.corpus_sample()[:2])[:100000])  # beyond 64 KiB: the i32 table (LZ4), a second sub-block (Snappy)
     # (the serial-probe variants 0 run `if (lane == 0) { emit }` in the middle of replicated serial code and have the other lanes wait at the
     # join: what the shim's earliest-in-the-program-first release of paused lanes is for)
-    for codec, op, variants in (("lz4", 1, (4, 1, 0)), ("snappy", 3, (4, 2, 1, 0))):  # (4: the window encoders, the defaults; Snappy 2 / 1 / 0: two tiers, one tier, serial probes)
+    # (LZ4 4 | 16 / 4 | 48: the window encoder as one wavefront per block / with two memory-tier wavefronts per workgroup; plain 4 is the default: one)
+    for codec, op, variants in (("lz4", 1, (4, 4 | 16, 4 | 48, 1, 0)), ("snappy", 3, (4, 2, 1, 0))):  # (4: the window encoders, the defaults; Snappy 2 / 1 / 0: two tiers, one tier, serial probes)
         caps = [o.max_compressed_length(codec, len(b)) for b in blocks]
         for v in variants:
             bad += compare("%s compress, variant %d" % (codec, v), op, v, blocks, caps, lambda b, c, codec=codec: o.compress(codec, b, c))

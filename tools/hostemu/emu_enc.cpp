@@ -24,7 +24,11 @@ extern "C" int emu_encode(int op, const uint8_t* srcBase, const int64_t* srcOff,
     if (op == 1) {
         int maxLen = 0;
         for (int i = 0; i < n; i++) maxLen = srcLen[i] > maxLen ? srcLen[i] : maxLen;
-        return achip::launch_lz4_compress(a, nullptr, option, maxLen);
+        scratch.assign((size_t)achip::lz4_compress_scratch_bytes(), 0xCD);
+        achip::g_lz4_tier_workgroups = 2;  // (the persistent grid: the emulator runs its wavefronts one after the other)
+        achip::g_lz4_tier_min_blocks = 1;   // (... and its batches are small)
+        achip::g_lz4_mem_waves = (option >> 4) & 3 ? ((option >> 4) & 3) - 1 : 1;  // (option bits 4, 5: 1 = one wavefront per block, 2 / 3 = one / two memory-tier wavefronts; 0 = the default)
+        return achip::launch_lz4_compress(a, nullptr, option & 15, maxLen, scratch.data());
     }
     if (op == 3) {
         scratch.assign((size_t)achip::snappy_compress_scratch_bytes(n), 0xCD);
