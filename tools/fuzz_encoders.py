@@ -7,7 +7,11 @@ from tests import common, oracle_lib
 from tests.gpu_harness import GpuBatch
 
 OPS = {"lz4": 1, "snappy": 3, "zstd": 5, "lz4frame": 7, "snappyframed": 9}
-VARIANTS = {"lz4": [4, 1, 0], "snappy": [4, 2, 1, 0], "zstd": [3, 0, 2], "lz4frame": [None], "snappyframed": [None]}  # (defaults first; the loop leaves the default set)
+# (defaults first; the loop leaves the default set.  A pair: the variant and further options -- LZ4's window encoder in two tiers whatever the batch size, with one
+# and two memory-tier wavefronts per workgroup: batches below 5 120 blocks otherwise take the wavefront-per-block kernel)
+VARIANTS = {"lz4": [4, (4, {"lz4.compress.tier_min_blocks": 1, "lz4.compress.mem_waves": 1}), (4, {"lz4.compress.tier_min_blocks": 1, "lz4.compress.mem_waves": 2}), 1, 0],
+            "snappy": [4, 2, 1, 0], "zstd": [3, 0, 2], "lz4frame": [None], "snappyframed": [None]}
+DEFAULTS = {"lz4.compress.tier_min_blocks": 5120, "lz4.compress.mem_waves": 1}
 
 
 def make_inputs(rng, n, max_len):
@@ -56,15 +60,22 @@ def run(n_cases, seed, codecs=("lz4", "snappy", "zstd", "lz4frame", "snappyframe
         want = [o.compress(codec, b) for b in inputs]
         caps = [o.max_compressed_length(codec, len(b)) for b in inputs]
         for variant in VARIANTS[codec]:
+            extra = {}
+            if isinstance(variant, tuple):
+                variant, extra = variant
             if variant is not None:
                 gb.set_option("%s.compress.variant" % codec, variant)
+            for k, v in extra.items():
+                gb.set_option(k, v)
             outs, status, _ = gb.run(OPS[codec], inputs, caps, unaligned=True)
             wrong = sum(1 for i in range(len(inputs)) if status[i] != 0 or outs[i] != want[i])
             for i in range(len(inputs)):
                 if (status[i] != 0 or outs[i] != want[i]) and wrong <= 5:
                     print("MISMATCH", codec, "variant", variant, "case", i, "len", len(inputs[i]), "status", status[i], flush=True)
             bad += wrong
-            print("%s variant %s: %d inputs, %d mismatches" % (codec, variant, len(inputs), wrong), flush=True)
+            print("%s variant %s%s: %d inputs, %d mismatches" % (codec, variant, " %s" % extra if extra else "", len(inputs), wrong), flush=True)
+            for k in extra:
+                gb.set_option(k, DEFAULTS[k])
         if VARIANTS[codec][0] is not None:
             gb.set_option("%s.compress.variant" % codec, VARIANTS[codec][0])
     print("TOTAL MISMATCHES", bad)
