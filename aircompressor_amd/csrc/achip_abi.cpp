@@ -1095,7 +1095,7 @@ int32_t achip_ctx_set_option(achip_ctx* ctx, const char* name, int64_t value)
         achip::g_zstd_seq_waves = (int)value;
     }  // (process-wide, like zstd.decompress.exec)
     else if (k == "zstd.decompress.lit_items") {
-        if (value != 8 && value != 10 && value != 16) return bad_argument("zstd.decompress.lit_items: items per wavefront of the pipeline's literal stage: 8, 10 or 16 (4 KiB of LDS an item)");
+        if (value != 8 && value != 10 && value != 13 && value != 16 && value != 20) return bad_argument("zstd.decompress.lit_items: items per wavefront of the pipeline's literal stage: 8, 10 or 16 (4 KiB of LDS an item), 13 (3 KiB: symbols and length nibbles apart), 20 (16 items of 2 304 bytes: symbols, and lengths by symbol)");
         achip::g_zstd_lit_items = (int)value;
     }  // (process-wide)
     else if (k == "decompress.latency_max_blocks") {

@@ -619,7 +619,28 @@ struct QuadBits {
 
 // One Huffman stream (Huffman.decodeSingleStream :130-164 body + decodeTail :291-317) decoded by the calling lane through
 // the windowed reader: same loads, symbols and end-of-stream test as zd::huf_decode_stream.
-__device__ __forceinline__ bool huf_decode_stream_win(QuadBits& b, const uint16_t* huf, int32_t tableLog, uint8_t* out, int32_t output, int32_t outputLimit)
+// SPLIT (round 6): the table as the literal stage keeps it in LDS since then -- HUF_SLOT symbol bytes, then HUF_SLOT / 2 bytes of code lengths, a nibble each (3 KiB an
+// item instead of 4: more items, i.e. more streams, per CU) -- two independent LDS reads and a nibble select per symbol; !SPLIT: K1's u16 entries, `symbol | length << 8`.
+// SPLIT == 2: HUF_SLOT symbol bytes, then the code length of each of the 256 symbols (2 304 bytes an item): the length is a second, DEPENDENT LDS read.
+template <int SPLIT>
+__device__ __forceinline__ int32_t huf_symbol_at(const void* huf, int32_t tableLog, uint64_t bits, int32_t& consumed)
+{
+    if (SPLIT == 0) {
+        return zd::huf_symbol((const uint16_t*)huf, tableLog, bits, consumed);
+    }
+    const uint8_t* t = (const uint8_t*)huf;
+    const int32_t idx = (int32_t)zd::peek_bits_fast(consumed, bits, tableLog);
+    const uint32_t sym = t[idx];
+    if (SPLIT == 2) {
+        consumed += (int32_t)t[zp::HUF_SLOT + sym];
+        return (int32_t)sym;
+    }
+    const uint32_t pair = t[zp::HUF_SLOT + (idx >> 1)];
+    consumed += (int32_t)((pair >> ((idx & 1) * 4)) & 15u);
+    return (int32_t)sym;
+}
+template <int SPLIT = 0>
+__device__ __forceinline__ bool huf_decode_stream_win(QuadBits& b, const void* huf, int32_t tableLog, uint8_t* out, int32_t output, int32_t outputLimit)
 {
     const int32_t fastLimit = outputLimit - 4;
     bool done = false;
@@ -635,10 +656,10 @@ __device__ __forceinline__ bool huf_decode_stream_win(QuadBits& b, const uint16_
                     done = true;
                 }
                 else {
-                    uint32_t w = (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed);
-                    w |= (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed) << 8;
-                    w |= (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed) << 16;
-                    w |= (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed) << 24;
+                    uint32_t w = (uint32_t)huf_symbol_at<SPLIT>(huf, tableLog, b.bits, b.consumed);
+                    w |= (uint32_t)huf_symbol_at<SPLIT>(huf, tableLog, b.bits, b.consumed) << 8;
+                    w |= (uint32_t)huf_symbol_at<SPLIT>(huf, tableLog, b.bits, b.consumed) << 16;
+                    w |= (uint32_t)huf_symbol_at<SPLIT>(huf, tableLog, b.bits, b.consumed) << 24;
                     w4[t] = w;
                     n4 = t + 1;
                 }
@@ -659,10 +680,10 @@ __device__ __forceinline__ bool huf_decode_stream_win(QuadBits& b, const uint16_
             done = true;
             break;
         }
-        uint32_t w = (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed);
-        w |= (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed) << 8;
-        w |= (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed) << 16;
-        w |= (uint32_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed) << 24;
+        uint32_t w = (uint32_t)huf_symbol_at<SPLIT>(huf, tableLog, b.bits, b.consumed);
+        w |= (uint32_t)huf_symbol_at<SPLIT>(huf, tableLog, b.bits, b.consumed) << 8;
+        w |= (uint32_t)huf_symbol_at<SPLIT>(huf, tableLog, b.bits, b.consumed) << 16;
+        w |= (uint32_t)huf_symbol_at<SPLIT>(huf, tableLog, b.bits, b.consumed) << 24;
         st4(out + output, w);
         output += 4;
     }
@@ -671,11 +692,11 @@ __device__ __forceinline__ bool huf_decode_stream_win(QuadBits& b, const uint16_
             if (b.load_java()) {
                 break;
             }
-            out[output++] = (uint8_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed);
+            out[output++] = (uint8_t)huf_symbol_at<SPLIT>(huf, tableLog, b.bits, b.consumed);
         }
     }
     while (output < outputLimit) {
-        out[output++] = (uint8_t)zd::huf_symbol(huf, tableLog, b.bits, b.consumed);
+        out[output++] = (uint8_t)huf_symbol_at<SPLIT>(huf, tableLog, b.bits, b.consumed);
     }
     return b.start == b.current && b.consumed == 64;
 }
@@ -684,11 +705,12 @@ __device__ __forceinline__ bool huf_decode_stream_win(QuadBits& b, const uint16_
 // link names) ----
 // ITEMS: items per wavefront (16: every quad has one; 8 -- an experiment for the next round -- leaves half the lanes idle and halves the LDS,
 // so that more wavefronts share a CU: the stage waits for memory more than it computes)
-template <bool MB, int ITEMS = zp::ITEMS_PER_WAVE>
+template <bool MB, int ITEMS = zp::ITEMS_PER_WAVE, int SPLIT = 0>
 __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp::Pipe p)
 {
     using namespace zp;
-    __shared__ __attribute__((aligned(16))) uint16_t tables[ITEMS * HUF_SLOT];  // 64 KiB at 16 items
+    constexpr int SLOT_U16 = SPLIT == 1 ? HUF_SLOT * 3 / 4 : (SPLIT == 2 ? HUF_SLOT / 2 + 128 : HUF_SLOT);  // an item's table in LDS, in u16 units (1: 2 048 symbol bytes + 1 024 bytes of length nibbles; 2: + 256 lengths by symbol)
+    __shared__ __attribute__((aligned(16))) uint16_t tables[ITEMS * SLOT_U16];  // 64 KiB at 16 items
     const int lane = threadIdx.x;
     const int q = lane >> 2;  // item of this lane
     const int s = lane & 3;   // stream of this lane
@@ -716,7 +738,35 @@ __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp:
         if (useHuf > 0) {
             const uint16_t* g = p.huf + (size_t)from * HUF_SLOT;
             for (int32_t i = lane * 8; i < (1 << useHuf); i += 64 * 8) {
-                *(u32x4*)(tables + k * HUF_SLOT + i) = *(const u32x4*)(g + i);
+                const u32x4 v = *(const u32x4*)(g + i);
+                if (SPLIT == 0) {
+                    *(u32x4*)(tables + k * SLOT_U16 + i) = v;
+                }
+                else {  // eight entries `symbol | length << 8`: eight symbol bytes, eight length nibbles
+                    uint8_t* t = (uint8_t*)(tables + k * SLOT_U16);
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                    uint32_t symLo = 0, symHi = 0, lens = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t two = (w[j] & 0xFFu) | ((w[j] >> 8) & 0xFF00u);  // the two symbols of the pair
+                        const uint32_t nib = ((w[j] >> 8) & 0xFu) | ((w[j] >> 20) & 0xF0u);  // their two lengths
+                        if (j < 2) symLo |= two << (16 * j);
+                        else symHi |= two << (16 * (j - 2));
+                        lens |= nib << (8 * j);
+                    }
+                    *(uint32_t*)(t + i) = symLo;
+                    *(uint32_t*)(t + i + 4) = symHi;
+                    if (SPLIT == 1) {
+                        *(uint32_t*)(t + HUF_SLOT + i / 2) = lens;
+                    }
+                    else {  // (every entry of a symbol carries the symbol's length: whichever store lands last, lands the same byte)
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const uint32_t sy = ((j < 4 ? symLo : symHi) >> (8 * (j & 3))) & 0xFFu;
+                            t[HUF_SLOT + sy] = (uint8_t)((lens >> (4 * j)) & 15u);
+                        }
+                    }
+                }
             }
         }
     }
@@ -752,7 +802,7 @@ __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp:
             if (!b.init(c.in, myStart, myEnd) || oStart > oEnd) {
                 bad = 1;
             }
-            else if (!huf_decode_stream_win(b, tables + q * HUF_SLOT, d.hufLog, lit, oStart, oEnd)) {
+            else if (!huf_decode_stream_win<SPLIT>(b, tables + q * SLOT_U16, d.hufLog, lit, oStart, oEnd)) {
                 bad = 1;
             }
         }
@@ -768,12 +818,20 @@ __global__ __launch_bounds__(64) void zstd_pipe_literals_kernel(BatchArgs a, zp:
 // flight per CU, and that is LDS: 4 KiB of table an item.  16 items a wavefront are 64 KiB -- two wavefronts a CU, 128 streams, 32 KiB of the LDS unused;
 // `zstd.decompress.lit_items` 10 (40 KiB: four wavefronts, 160 streams) or 8 (32 KiB: five, 160) use all of it, with lanes idle in every wavefront.
 // Measured (profiles/r06_notes.md section 10; 32 768 corpus frames): 16 items 6.96 ms, 10 items **4.83**, 8 items 6.96 (the fifth wavefront does not get
-// its LDS: four of 32 lanes are the 128 streams of two full ones).  10 is the default.
-int g_zstd_lit_items = 10;
+// its LDS: four of 32 lanes are the 128 streams of two full ones).  Then the table itself (SPLIT, above): symbol bytes and length nibbles apart are 3 KiB an item --
+// 13 items a wavefront, 208 streams a CU: **4.11**; symbols and lengths-by-symbol (2 304 bytes, 16 items, 256 streams, but a dependent second lookup): 4.60.
+// 13 is the default.
+int g_zstd_lit_items = 13;
 template <bool MB>
 inline void launch_literals(const BatchArgs& a, const zp::Pipe& p, hipStream_t stream)
 {
-    if (g_zstd_lit_items == 8) {
+    if (g_zstd_lit_items == 13) {  // (3 KiB an item: 13 items = 39 KiB, four wavefronts a CU, 208 streams)
+        hipLaunchKernelGGL((zstd_pipe_literals_kernel<MB, 13, 1>), dim3((unsigned)((p.count + 12) / 13)), dim3(64), 0, stream, a, p);
+    }
+    else if (g_zstd_lit_items == 20) {  // (2 304 bytes an item, 16 items = 36 KiB, four wavefronts a CU, 256 streams -- and a dependent second lookup per symbol)
+        hipLaunchKernelGGL((zstd_pipe_literals_kernel<MB, 16, 2>), dim3((unsigned)((p.count + 15) / 16)), dim3(64), 0, stream, a, p);
+    }
+    else if (g_zstd_lit_items == 8) {
         hipLaunchKernelGGL((zstd_pipe_literals_kernel<MB, 8>), dim3((unsigned)((p.count + 7) / 8)), dim3(64), 0, stream, a, p);
     }
     else if (g_zstd_lit_items == 10) {

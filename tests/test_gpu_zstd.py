@@ -32,7 +32,7 @@ def o():
 
 
 DEFAULT_SEQ_WAVES = 1  # (the library's default of zstd.decompress.seq_waves, restored by the test that changes it)
-DEFAULT_LIT_ITEMS = 10  # (... of zstd.decompress.lit_items)
+DEFAULT_LIT_ITEMS = 13  # (... of zstd.decompress.lit_items)
 
 
 def zstd_frames(blocks, level):
@@ -297,9 +297,10 @@ def test_sequence_stage_wavefronts_per_workgroup(o, waves):
         g.set_option("zstd.decompress.seq_waves", DEFAULT_SEQ_WAVES)  # (process-wide)
 
 
-@pytest.mark.parametrize("items", [8, 10, 16])
+@pytest.mark.parametrize("items", [8, 10, 13, 16, 20])
 def test_literal_stage_items_per_wavefront(o, items):
-    """zstd.decompress.lit_items: the pipeline's literal stage with 8, 10 or 16 items a wavefront (4 KiB of LDS an item: 5 / 4 / 2 wavefronts a CU) -- every
+    """zstd.decompress.lit_items: the pipeline's literal stage with 8, 10 or 16 items a wavefront (4 KiB of LDS an item: 5 / 4 / 2 wavefronts a CU), with 13
+    (the default: symbol bytes and length nibbles apart, 3 KiB an item) and with 20 (16 items of symbol bytes + lengths by symbol) -- every
     frame restored (libzstd's frames and the Java encoder's, single-block and multi-block), nothing handed to the one-kernel decoder."""
     import hashlib
     from tests.gpu_harness import GpuBatch

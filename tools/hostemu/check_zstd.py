@@ -97,7 +97,7 @@ def multi_block(expect_fast):
     # the multi-block execute stage with the 8 KiB window (option zstd.decompress.exec_window): the oracle's frames again
     frames = [bytes(encs[0][1](p)) for p in plains]
     # (exec_mode bits 4 .. 6: the sequence stage in full workgroups of 4 wavefronts x 16 block slots -- option zstd.decompress.seq_waves)
-    outs, status, fb = run(frames, [len(p) for p in plains], exec_mode=1 | (4 << 4), pass_blocks=2048)
+    outs, status, fb = run(frames, [len(p) for p in plains], exec_mode=1 | (4 << 4) | (3 << 2), pass_blocks=2048)  # (... and the literal stage's split tables)
     wide = sum(1 for i, p in enumerate(plains) if i in fb or status[i] != 0 or outs[i] != p)
     print("oracle, 8 KiB executor window: %d frames, %d mismatches" % (len(frames), wide))
     bad += wide
@@ -230,7 +230,7 @@ def main():
         # (second run: the 8-items-per-wavefront instantiations of the literal and sequence stages -- mode bits 2 and 3)
         # (... and the sequence stage in full workgroups of 1, 2 and 4 wavefronts: mode bits 4 .. 6, lanes without an item beside lanes with one)
         # (... and the literal stage at 8 and 10 items per wavefront: mode bits 2, 3 -- option zstd.decompress.lit_items)
-        for pad, mode in ((0, 1), (37, 1), (0, 1 | (1 << 4)), (0, 1 | (2 << 4)), (0, 1 | (4 << 4)), (0, 1 | (1 << 2)), (0, 1 | (2 << 2))):
+        for pad, mode in ((0, 1), (37, 1), (0, 1 | (1 << 4)), (0, 1 | (2 << 4)), (0, 1 | (4 << 4)), (0, 1 | (1 << 2)), (0, 1 | (2 << 2)), (0, 1 | (3 << 2)), (0, 1 | (1 << 7))):  # (3 << 2: 13 items, symbols and length nibbles apart; 1 << 7: 16 items, lengths by symbol)
             outs, status, fb = run(frames, [len(p) + pad for p in plains], exec_mode=mode)
             for i, p in enumerate(plains):
                 total += 1

@@ -97,7 +97,8 @@ extern "C" int emu_zstd_pipe(const uint8_t* srcBase, const int64_t* srcOff, cons
     achip::g_zstd_pipe_exec = execMode & 3;
     achip::g_zstd_seq_waves = (execMode >> 4) & 7 ? (execMode >> 4) & 7 : 1;  // (bits 4 .. 6: wavefronts per workgroup of the sequence stage, with full workgroups)
     achip::g_zstd_seq_spread = (execMode >> 4) & 7 ? 1 : 256;
-    achip::g_zstd_lit_items = ((execMode >> 2) & 3) == 1 ? 8 : (((execMode >> 2) & 3) == 2 ? 10 : 16);  // (bits 2, 3: items per wavefront of the literal stage)
+    achip::g_zstd_lit_items = ((execMode >> 2) & 3) == 1 ? 8 : (((execMode >> 2) & 3) == 2 ? 10 : (((execMode >> 2) & 3) == 3 ? 13 : 16));  // (bits 2, 3: items per wavefront of the literal stage; 13: the split table layout)
+    if ((execMode >> 7) & 1) achip::g_zstd_lit_items = 20;  // (bit 7: 16 items, symbols and lengths by symbol)
     achip::g_fallback.clear();
     for (int32_t i = 0; i < n; i++) {
         status[i] = -999;  // "not written"
