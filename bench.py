@@ -58,6 +58,8 @@ def parse_args():
     p.add_argument("--no-host-facing", action="store_true", help="skip the end_to_end (host buffers, PCIe-inclusive) and single_block_us measurements")
     p.add_argument("--no-legs", action="store_true", help="skip the per-rank legs (Snappy, Zstd configs[3], mixed corpus batch configs[4]) that run at any N")
     p.add_argument("--zstd-frames", type=int, default=65536, help="Zstd frames of 128 KiB per GPU in the configs[3] leg (a multiple of 1024)")
+    p.add_argument("--dst-pad", type=int, default=0, help="development aid (decompress workloads): bytes between the outputs of consecutive blocks -- 0, the default and the headline's layout, is one contiguous output buffer; "
+                   "a run with a pad is a layout experiment, not a result (the line says so in config.dst_pad)")
     p.add_argument("--option", action="append", default=[], help="development aid: a context option as name=value (repeatable), set on the bench's context before anything runs")
     p.add_argument("--no-mixed-large", action="store_true", help="skip the second mixed-batch measurement at 8 x --mixed-copies (N = 1 only)")
     p.add_argument("--mixed-copies", type=int, default=4, help="copies of the 668-line corpus job in the configs[4] leg")
@@ -677,8 +679,9 @@ def main():
         src = pool_pack.repeat(reps)
         src_off = pool_pack_off.repeat(reps) + rep_idx * pool_pack_bytes
         src_len = pool_clen.repeat(reps)
-        dst = torch.empty(n_local * bs + 64, dtype=torch.uint8, device=dev)
-        dst_off = torch.arange(n_local, **i64) * bs
+        dst_stride = bs + max(0, args.dst_pad)
+        dst = torch.empty(n_local * dst_stride + 64, dtype=torch.uint8, device=dev)
+        dst_off = torch.arange(n_local, **i64) * dst_stride
         dst_cap = torch.full((n_local,), bs, **i32)
         op = decompress_op
     else:
@@ -729,7 +732,10 @@ def main():
         print("DEBUG RUN: output not verified", file=sys.stderr)
     elif wl.endswith("decompress"):
         assert int((out_len != bs).sum()) == 0
-        ok = bool((dst[:n_local * bs].view(reps, pool_n * bs) == pool_plain.unsqueeze(0)).all())
+        if args.dst_pad > 0:
+            ok = bool((dst[:n_local * dst_stride].view(reps, pool_n, dst_stride)[:, :, :bs] == pool_plain.view(1, pool_n, bs)).all())
+        else:
+            ok = bool((dst[:n_local * bs].view(reps, pool_n * bs) == pool_plain.unsqueeze(0)).all())
         assert ok, "decompressed output differs from the plaintext"
     else:
         assert bool((out_len == pool_clen.repeat(reps)).all())
@@ -766,6 +772,7 @@ def main():
             "parallelism": "block-sharded x%d, no collective" % world + (" -- ALL RANKS ON ONE DEVICE (ACHIP_BENCH_SHARE_DEVICE=1): a path check, not a scaling number" if world > 1 and os.environ.get("ACHIP_BENCH_SHARE_DEVICE") == "1" else ""),
             "decoder": decoder + (" (chosen on the device: %d of %d 16-block groups mixed)" % (mixed_groups, (n_local + 15) // 16) if mixed_groups >= 0 else ""),
             "twopass_fallback_blocks": twopass_fallback,
+            **({"dst_pad": args.dst_pad, "LAYOUT_EXPERIMENT": "outputs %d bytes apart, not one contiguous buffer: not the headline" % (bs + args.dst_pad)} if args.dst_pad > 0 and wl.endswith("decompress") else {}),
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
